@@ -1,0 +1,155 @@
+"""Generate the ViT golden fixtures by EXECUTING THE REFERENCE (build container only).
+
+    python tests/golden/gen_golden_vit.py
+
+Writes (all small enough to commit):
+    vit_tiny_full.npz            every cache tensor + output, fp32, arch 'tiny', bs=3
+    vit_tiny_ragged_full.npz     same for 'tiny-ragged' (T=10, no ln_pre, no normalise), bs=2
+    vit_b32_fp32_bs16.json       fingerprints (oracle/vit_oracle.fingerprint) of all 214 cache
+                                 tensors + output of CLIP ViT-B/32, bs=16 (BASELINE config 1),
+                                 plus the variants stop_at_layer=7 / names_filter / remove_batch_dim
+    vit_l14_fp32_bs1.json        fingerprints of scores/pattern for layers {0,23} + output, L/14@336
+    vit_b32_bf16_budget.json     per-key rel-Frobenius error of the reference's OWN bf16 path
+                                 (cfg.dtype=bf16, .to(bf16)) against its fp32 path, bs=4: the error
+                                 budget the bf16 HIP mode is held to (hard part 1)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from _refimport import reference_classes  # noqa: E402
+from oracle.vit_oracle import fingerprint  # noqa: E402
+from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state  # noqa: E402
+
+
+def build_reference_model(arch_name: str, dtype=torch.float32, seed: int = 0, outliers: bool = False):
+    R = reference_classes()
+    arch = ARCHS[arch_name]
+    cfg = R["HookedViTConfig"](**arch, dtype=dtype, device="cpu")
+    model = R["HookedViT"](cfg)
+    sd = {k: torch.from_numpy(v) for k, v in synth_vit_state(arch, seed=seed, outliers=outliers).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    model = model.to(dtype)
+    model.eval()
+    return model, arch
+
+
+def run_ref(model, images, **kw):
+    with torch.no_grad():
+        out, cache = model.run_with_cache(torch.from_numpy(images).to(next(model.parameters()).dtype), **kw)
+    return out, cache
+
+
+def dump_full(arch_name: str, bs: int, fname: str, outliers: bool = False):
+    model, arch = build_reference_model(arch_name, outliers=outliers)
+    imgs = synth_images(arch, bs, seed=1)
+    out, cache = run_ref(model, imgs)
+    blob = {"__out__": out.numpy(), "__keys__": np.array(list(cache.cache_dict.keys()))}
+    for k, v in cache.cache_dict.items():
+        blob[k] = np.ascontiguousarray(v.numpy())
+    np.savez_compressed(os.path.join(HERE, fname), **blob)
+    print(fname, len(cache.cache_dict), "keys", os.path.getsize(os.path.join(HERE, fname)) // 1024, "kB")
+
+
+def fp_cache(out, cache_dict):
+    return {
+        "keys": list(cache_dict.keys()),
+        "dtypes": {k: str(v.dtype) for k, v in cache_dict.items()},
+        "out": fingerprint(out.float().numpy()),
+        "cache": {k: fingerprint(v.float().numpy()) for k, v in cache_dict.items()},
+    }
+
+
+def dump_b32():
+    model, arch = build_reference_model("clip-vit-b32")
+    imgs = synth_images(arch, 16, seed=1)
+    t0 = time.time()
+    out, cache = run_ref(model, imgs)
+    print("b32 bs16 reference forward", time.time() - t0, "s")
+    res = {"arch": "clip-vit-b32", "batch": 16, "all": fp_cache(out, cache.cache_dict)}
+    # harvest form used by VisionActivationsStore.get_activations (activations_store.py:268-270)
+    out7, c7 = run_ref(model, imgs, names_filter=["blocks.6.hook_resid_post"], stop_at_layer=7)
+    res["stop7_filter"] = fp_cache(out7, c7.cache_dict)
+    # stop_at_layer with every hook; negative index (python slicing, base_vit.py:187)
+    outm, cm = run_ref(model, imgs[:2], stop_at_layer=-9)
+    res["stop_neg9_bs2"] = fp_cache(outm, cm.cache_dict)
+    # callable filter
+    outc, cc = run_ref(model, imgs[:2], names_filter=lambda n: n.endswith("hook_pattern") or n == "hook_embed")
+    res["callable_bs2"] = fp_cache(outc, cc.cache_dict)
+    # str filter + remove_batch_dim with bs=1
+    outr, cr = run_ref(model, imgs[:1], names_filter="blocks.3.attn.hook_z", remove_batch_dim=True)
+    res["str_rmbatch_bs1"] = fp_cache(outr, cr.cache_dict)
+    with open(os.path.join(HERE, "vit_b32_fp32_bs16.json"), "w") as f:
+        json.dump(res, f)
+    print("vit_b32_fp32_bs16.json", os.path.getsize(os.path.join(HERE, "vit_b32_fp32_bs16.json")) // 1024, "kB")
+
+
+def dump_l14():
+    model, arch = build_reference_model("clip-vit-l14-336")
+    imgs = synth_images(arch, 1, seed=1)
+    want = [f"blocks.{l}.attn.{h}" for l in (0, 23) for h in ("hook_attn_scores", "hook_pattern")]
+    t0 = time.time()
+    out, cache = run_ref(model, imgs, names_filter=want)
+    print("l14 bs1 reference forward", time.time() - t0, "s")
+    # key/shape inventory with all hooks (no values)
+    _, call = run_ref(model, imgs)
+    res = {"arch": "clip-vit-l14-336", "batch": 1, "sel": fp_cache(out, cache.cache_dict),
+           "all_keys": list(call.cache_dict.keys()),
+           "all_shapes": {k: list(v.shape) for k, v in call.cache_dict.items()}}
+    with open(os.path.join(HERE, "vit_l14_fp32_bs1.json"), "w") as f:
+        json.dump(res, f)
+
+
+def dump_bf16_budget():
+    """Reference bf16 path vs reference fp32 path, per cache key (rel Frobenius + max-abs)."""
+    arch = ARCHS["clip-vit-b32"]
+    imgs = synth_images(arch, 4, seed=1)
+    m32, _ = build_reference_model("clip-vit-b32", dtype=torch.float32)
+    _, c32 = run_ref(m32, imgs)
+    o32, _ = run_ref(m32, imgs)
+    m16, _ = build_reference_model("clip-vit-b32", dtype=torch.bfloat16)
+    o16, c16 = run_ref(m16, imgs)
+    budget = {}
+    for k in c32.cache_dict:
+        a = c32.cache_dict[k].double()
+        b = c16.cache_dict[k].double()
+        budget[k] = {
+            "rel_fro": float((a - b).norm() / a.norm().clamp_min(1e-30)),
+            "max_abs": float((a - b).abs().max()),
+            "ref_absmax": float(a.abs().max()),
+            "dtype_bf16_run": str(c16.cache_dict[k].dtype),
+        }
+    budget["__out__"] = {
+        "rel_fro": float((o32.double() - o16.double()).norm() / o32.double().norm()),
+        "max_abs": float((o32.double() - o16.double()).abs().max()),
+        "ref_absmax": float(o32.abs().max()), "dtype_bf16_run": str(o16.dtype)}
+    with open(os.path.join(HERE, "vit_b32_bf16_budget.json"), "w") as f:
+        json.dump({"arch": "clip-vit-b32", "batch": 4, "budget": budget}, f)
+    rel = sorted(v["rel_fro"] for v in budget.values())
+    print("bf16 budget rel_fro min/median/max", rel[0], rel[len(rel) // 2], rel[-1])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    what = sys.argv[1:] or ["tiny", "b32", "l14", "bf16"]
+    if "tiny" in what:
+        dump_full("tiny", 3, "vit_tiny_full.npz")
+        dump_full("tiny-ragged", 2, "vit_tiny_ragged_full.npz")
+    if "b32" in what:
+        dump_b32()
+    if "l14" in what:
+        dump_l14()
+    if "bf16" in what:
+        dump_bf16_budget()
