@@ -1,0 +1,242 @@
+/*
+ * pv_native.h -- C ABI of libpvnative.so, the MI355X (gfx950) implementation of ViT-Prisma's
+ * run_with_cache forward path and SAE training step.
+ *
+ * The reference (Prisma-Multimodal/ViT-Prisma) is 100 % Python and has NO plugin / FFI interface
+ * for this path; its boundary is the Python class surface.  This header is
+ * therefore the narrow C ABI *underneath* that surface.  Each entry point names the reference
+ * Python code it replaces (paths relative to /root/reference/src/vit_prisma/).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  Every pointer is a DEVICE pointer on the
+ *     current HIP device unless stated otherwise.
+ *   - every call returns an int status (PV_OK == 0); no exception crosses the ABI;
+ *     pv_last_error() gives the message of the last failure on the calling thread.
+ *   - every compute call is asynchronous on the supplied hipStream_t (passed as void*; 0 = the
+ *     legacy default stream).  The caller passes torch.cuda.current_stream().cuda_stream.
+ *   - the library never allocates device memory: weights are borrowed from the caller's module
+ *     parameters, MFMA-layout weight shadows, workspaces and every tap destination are caller-owned
+ *     (sizes from the *_bytes queries).  Plans are not thread-safe; one plan per device.
+ */
+#ifndef PV_NATIVE_H
+#define PV_NATIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_OK 0
+#define PV_ERR_INVALID 1      /* bad argument / unsupported configuration          */
+#define PV_ERR_HIP 2          /* a HIP runtime call or kernel launch failed        */
+#define PV_ERR_WORKSPACE 3    /* caller-provided buffer too small                  */
+
+#define PV_DTYPE_F32 0
+#define PV_DTYPE_BF16 1
+
+#define PV_ACT_GELU 0         /* exact erf GELU, models/layers/mlp.py:43-44        */
+#define PV_ACT_QUICK_GELU 1   /* models/activation_fns.py:19                       */
+#define PV_ACT_RELU 2
+
+/* ABI version; bumped on any struct/signature change. */
+#define PV_ABI_VERSION 3
+int pv_abi_version(void);
+/* Copies the calling thread's last error message (NUL terminated) into buf. */
+void pv_last_error(char* buf, size_t len);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ViT forward with taps (HookedViT.forward, models/base_vit.py:152-217, with the caching hooks */
+/* of prisma_tools/hooked_root_module.py:289-332 fused in as tap stores)                        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct pv_vit_desc {
+    int32_t n_layers, d_model, n_heads, d_head, d_mlp;
+    int32_t n_channels, patch_size, image_size;
+    int32_t n_tokens;          /* patches (+1 with cls token)                                 */
+    int32_t n_classes;         /* head width; ignored when has_head == 0                      */
+    int32_t use_cls_token;     /* models/base_vit.py:171-175                                  */
+    int32_t layer_norm_pre;    /* models/base_vit.py:183-185                                  */
+    int32_t has_head;          /* return_type != "pre_logits", models/base_vit.py:210         */
+    int32_t normalize_output;  /* F.normalize(dim=-1), models/base_vit.py:214-215             */
+    int32_t activation;        /* PV_ACT_*                                                    */
+    int32_t dtype;             /* PV_DTYPE_*: storage dtype of params, residual stream, taps  */
+    float eps;                 /* LayerNorm eps, models/layers/layer_norm.py:88               */
+    float attn_scale;          /* sqrt(d_head) or 1, models/layers/attention.py:96-99         */
+} pv_vit_desc;
+
+/* Parameters in the reference's own layouts (the state-dict layout produced by
+ * models/weight_conversion.py:276-313, 345-429); element type = desc.dtype. */
+typedef struct pv_vit_layer_weights {
+    const void *ln1_w, *ln1_b;             /* [d]                                            */
+    const void *W_Q, *W_K, *W_V;           /* [H, d, dh]   models/layers/attention.py:37-61  */
+    const void *b_Q, *b_K, *b_V;           /* [H, dh]                                        */
+    const void *W_O;                       /* [H, dh, d]   attention.py:62-69                */
+    const void *b_O;                       /* [d]                                            */
+    const void *ln2_w, *ln2_b;             /* [d]                                            */
+    const void *W_in, *b_in;               /* [d, d_mlp], [d_mlp]  models/layers/mlp.py:24-29 */
+    const void *W_out, *b_out;             /* [d_mlp, d], [d]      mlp.py:30-35              */
+} pv_vit_layer_weights;
+
+typedef struct pv_vit_weights {
+    const void *cls_token;                 /* [1,1,d]  (NULL if !use_cls_token)              */
+    const void *conv_w, *conv_b;           /* [d, C, p, p], [d]  patch_embedding.py:14-20    */
+    const void *W_pos;                     /* [T, d]   position_embedding.py:28-30           */
+    const void *ln_pre_w, *ln_pre_b;       /* [d]      (NULL if !layer_norm_pre)             */
+    const void *ln_final_w, *ln_final_b;   /* [d]                                            */
+    const void *W_H, *b_H;                 /* [d, n_classes], [n_classes]  head.py:20-25     */
+    const pv_vit_layer_weights* layers;    /* HOST array of n_layers entries                 */
+} pv_vit_weights;
+
+/* Unique activation buffers of one forward.  Several HookPoint names may alias one buffer
+ * (e.g. blocks.l.hook_resid_post == blocks.l+1.hook_resid_pre); that mapping lives in the Python
+ * tap planner.  "T" = desc.dtype.  *_NORM_F32 exist only for dtype == BF16, where the reference
+ * fires hook_normalized on the fp32 value before the down-cast (layer_norm.py:89-93). */
+enum pv_slot {
+    /* global slots (layer field ignored) */
+    PV_SLOT_EMBED = 0,        /* hook_embed                         [B, P, d]    T            */
+    PV_SLOT_FULL_EMBED = 1,   /* hook_full_embed                    [B, T, d]    T            */
+    PV_SLOT_LNPRE_SCALE = 2,  /* ln_pre.hook_scale                  [B, T, 1]    f32          */
+    PV_SLOT_LNPRE_NORM_F32 = 3, /* ln_pre.hook_normalized (bf16 mode) [B, T, d]  f32          */
+    PV_SLOT_LNPRE_OUT = 4,    /* hook_ln_pre == blocks.0.hook_resid_pre [B,T,d]  T            */
+    PV_SLOT_LNF_SCALE = 5,    /* ln_final.hook_scale                [B, T, 1]    f32          */
+    PV_SLOT_LNF_NORM_F32 = 6, /* ln_final.hook_normalized (bf16 mode) [B, T, d]  f32          */
+    PV_SLOT_LNF_OUT = 7,      /* hook_ln_final                      [B, T, d]    T            */
+    PV_SLOT_HEAD_OUT = 8,     /* hook_post_head_pre_normalize       [B, n_cls] or [B, d]  T   */
+    /* per-layer slots */
+    PV_SLOT_LN1_SCALE = 16,   /* blocks.l.ln1.hook_scale            [B, T, 1]    f32          */
+    PV_SLOT_LN1_NORM_F32 = 17,
+    PV_SLOT_LN1_OUT = 18,     /* ln1 output in T (fp32 mode: == ln1.hook_normalized)          */
+    PV_SLOT_Q = 19,           /* attn.hook_q                        [B, T, H, dh] T           */
+    PV_SLOT_K = 20,
+    PV_SLOT_V = 21,
+    PV_SLOT_SCORES = 22,      /* attn.hook_attn_scores              [B, H, T, T]  T           */
+    PV_SLOT_PATTERN = 23,     /* attn.hook_pattern                  [B, H, T, T]  T           */
+    PV_SLOT_Z = 24,           /* attn.hook_z                        [B, T, H, dh] T           */
+    PV_SLOT_ATTN_OUT = 25,    /* hook_attn_out                      [B, T, d]     T           */
+    PV_SLOT_RESID_MID = 26,   /* hook_resid_mid                     [B, T, d]     T           */
+    PV_SLOT_LN2_SCALE = 27,
+    PV_SLOT_LN2_NORM_F32 = 28,
+    PV_SLOT_LN2_OUT = 29,
+    PV_SLOT_MLP_PRE = 30,     /* mlp.hook_pre                       [B, T, d_mlp] T           */
+    PV_SLOT_MLP_POST = 31,    /* mlp.hook_post                      [B, T, d_mlp] T           */
+    PV_SLOT_MLP_OUT = 32,     /* hook_mlp_out                       [B, T, d]     T           */
+    PV_SLOT_RESID_POST = 33,  /* hook_resid_post == next hook_resid_pre [B,T,d]   T           */
+    PV_SLOT__COUNT = 34
+};
+
+/* "store this buffer at dst": the fused replacement for one caching hook
+ * (hooked_root_module.py:312-316 `cache[hook.name] = tensor.detach().to(device)`). */
+typedef struct pv_tap {
+    int32_t slot;   /* enum pv_slot */
+    int32_t layer;  /* block index for per-layer slots, 0 otherwise */
+    void* dst;      /* caller-owned device memory of the slot's shape/dtype, 256-byte aligned */
+} pv_tap;
+
+typedef struct pv_vit_plan pv_vit_plan;
+
+/* Replaces HookedViT.__init__'s shape bookkeeping (models/base_vit.py:68-150). */
+int pv_vit_plan_create(const pv_vit_desc* desc, pv_vit_plan** out_plan);
+void pv_vit_plan_destroy(pv_vit_plan* plan);
+
+/* Bytes of the MFMA-layout weight shadow ([N][K] K-contiguous copies of W_QKV, W_O, W_in, W_out,
+ * W_H) the caller must provide to pv_vit_plan_set_weights. */
+size_t pv_vit_shadow_bytes(const pv_vit_plan* plan);
+/* Borrows the parameter pointers (never owns/copies them) and (re)packs the shadow on `stream`.
+ * Call again whenever parameters change (weight edits, .to(dtype), load_state_dict). */
+int pv_vit_plan_set_weights(pv_vit_plan* plan, const pv_vit_weights* w, void* shadow,
+                            size_t shadow_bytes, void* stream);
+
+/* Workspace for the non-tapped intermediates of one forward at batch size B. */
+size_t pv_vit_workspace_bytes(const pv_vit_plan* plan, int32_t batch);
+
+/* HookedViT.forward (models/base_vit.py:152-217) + run_with_cache's caching hooks.
+ *   images         [B, C, S, S] NCHW, element type desc.dtype
+ *   n_blocks       number of transformer blocks to run: n_layers for a full forward, k for
+ *                  stop_at_layer=k (the caller resolves negative indices, base_vit.py:187)
+ *   run_head       0: stop after the blocks (stop_at_layer semantics, base_vit.py:189-190; the
+ *                  caller taps the last residual), 1: ln_final + cls + head (+normalise) -> out
+ *   taps           HOST array; buffers not listed are kept in the workspace or never materialised
+ *   out            [B, n_classes] (or [B, d] without head) T; may be NULL when run_head == 0
+ */
+int pv_vit_forward(pv_vit_plan* plan, const void* images, int32_t batch, int32_t n_blocks,
+                   int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                   size_t workspace_bytes, void* out, void* stream);
+
+/* Kernel-level entry points (used by the unit tests and by bench.py's roofline leg). */
+/* C[M,N] = A[M,K] @ Bt[N,K]^T + bias[N]; dtype T for A, Bt, bias, C. */
+int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const void* Bt, int64_t ldb,
+                 const void* bias, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                 void* stream);
+/* out[b][c][r] = in[b][r][c], element size 2 or 4 bytes. */
+int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t batch, int32_t R,
+                         int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* SAE training step (sae/sae.py:557-645 forward; sae/train_sae.py:278-411 step)                */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct pv_sae_desc {
+    int32_t d_in, d_sae, k;          /* sae/config.py: d_in, d_sae = d_in*expansion_factor, topk k  */
+    int32_t normalize_layer_norm;    /* normalize_activations == "layer_norm", sae.py:78-93         */
+    int32_t max_tokens;              /* largest N a step will be called with                        */
+    float ln_eps;                    /* 1e-5, sae.py:80                                             */
+} pv_sae_desc;
+
+/* fp32 master parameters in the reference's layouts (sae.py:537-555), their gradients, Adam
+ * moments and training statistics -- all caller-owned (torch tensors), fp32 unless stated. */
+typedef struct pv_sae_state {
+    float *W_enc, *W_dec, *b_enc, *b_dec;          /* [d_in,d_sae] [d_sae,d_in] [d_sae] [d_in]   */
+    float *gW_enc, *gW_dec, *gb_enc, *gb_dec;      /* same shapes; ONE contiguous flat buffer is */
+                                                   /* recommended so a single all-reduce covers it */
+    float *mW_enc, *mW_dec, *mb_enc, *mb_dec;      /* Adam exp_avg                               */
+    float *vW_enc, *vW_dec, *vb_enc, *vb_dec;      /* Adam exp_avg_sq                            */
+    float *act_freq_scores;                        /* [d_sae]  train_sae.py:360                  */
+    float *n_fwd_since_fired;                      /* [d_sae]  train_sae.py:357-358              */
+} pv_sae_state;
+
+/* Per-step outputs, caller-owned. */
+typedef struct pv_sae_out {
+    float* sae_out;        /* [N, d_in] reconstruction (after LN-out), may be NULL                */
+    int32_t* topk_idx;     /* [N, k]   selected feature indices                                  */
+    float* topk_val;       /* [N, k]   relu(hidden_pre) at those indices (feature_acts, sparse)   */
+    float* scalars;        /* [8]: 0 loss, 1 mse_loss, 2 l0, 3 grad_sqnorm(local, pre-clip), ...  */
+} pv_sae_out;
+
+typedef struct pv_sae_plan pv_sae_plan;
+int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan);
+void pv_sae_plan_destroy(pv_sae_plan* plan);
+size_t pv_sae_workspace_bytes(const pv_sae_plan* plan);
+
+/* set_decoder_norm_to_unit_norm (sae.py:275-277): W_dec /= ||W_dec||_row, in place. */
+int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
+
+/* Forward + backward + statistics of one train step on N tokens x [N, d_in] fp32
+ * (train_sae.py:328-392 between zero_grad and clip).  Gradients are WRITTEN (not accumulated)
+ * into st->g*.  `batch_mean` [d_in] is mean_n(x) over the GLOBAL batch (sae.py:145) -- pass NULL to
+ * have it computed from x (single process); `n_global` scales the loss mean (N for 1 process).
+ * update_stats: apply did_fire / act_freq updates (train_sae.py:356-361). */
+int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
+                const float* batch_mean, int32_t n_global, int32_t update_stats, pv_sae_out* out,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* sum of squares of all four gradients -> scalars[3] (device), for clip_grad_norm_
+ * (train_sae.py:394-397); called after the (optional) gradient all-reduce. */
+int pv_sae_grad_sqnorm(pv_sae_plan* plan, pv_sae_state* st, float* scalars, void* stream);
+
+/* clip (coef from scalars[3] on device, max_norm <= 0 disables) -> remove gradient parallel to
+ * decoder rows (sae.py:279-297) -> Adam(betas .9/.999, eps 1e-8, wd 0; train_sae.py:229) with
+ * learning rate lr at 1-based step `step` -- one fused pass over parameters + moments. */
+int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* scalars, float max_grad_norm,
+                 float lr, int32_t step, void* stream);
+
+/* Inference-side pieces for the module API (StandardSparseAutoencoder.encode/decode). */
+int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t n_tokens,
+                       int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PV_NATIVE_H */

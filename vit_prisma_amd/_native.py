@@ -1,0 +1,138 @@
+"""ctypes binding of libpvnative.so (C ABI declared in include/pv_native.h).
+
+The product path has no CPU or PyTorch-eager substitute for these kernels: if the library is
+missing or its ABI version is wrong, ``lib()`` raises -- loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpvnative.so")
+ABI_VERSION = 3
+
+PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
+PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
+
+# enum pv_slot
+SLOT = dict(
+    EMBED=0, FULL_EMBED=1, LNPRE_SCALE=2, LNPRE_NORM_F32=3, LNPRE_OUT=4,
+    LNF_SCALE=5, LNF_NORM_F32=6, LNF_OUT=7, HEAD_OUT=8,
+    LN1_SCALE=16, LN1_NORM_F32=17, LN1_OUT=18, Q=19, K=20, V=21, SCORES=22, PATTERN=23, Z=24,
+    ATTN_OUT=25, RESID_MID=26, LN2_SCALE=27, LN2_NORM_F32=28, LN2_OUT=29, MLP_PRE=30, MLP_POST=31,
+    MLP_OUT=32, RESID_POST=33,
+)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class VitDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_layers", "d_model", "n_heads", "d_head", "d_mlp", "n_channels", "patch_size", "image_size",
+        "n_tokens", "n_classes", "use_cls_token", "layer_norm_pre", "has_head", "normalize_output",
+        "activation", "dtype")] + [("eps", C.c_float), ("attn_scale", C.c_float)]
+
+
+class VitLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_w", "ln1_b", "W_Q", "W_K", "W_V", "b_Q", "b_K", "b_V", "W_O", "b_O", "ln2_w", "ln2_b",
+        "W_in", "b_in", "W_out", "b_out")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "cls_token", "conv_w", "conv_b", "W_pos", "ln_pre_w", "ln_pre_b", "ln_final_w", "ln_final_b",
+        "W_H", "b_H")] + [("layers", C.POINTER(VitLayerWeights))]
+
+
+class Tap(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("layer", C.c_int32), ("dst", C.c_void_p)]
+
+
+class SaeDesc(C.Structure):
+    _fields_ = [("d_in", C.c_int32), ("d_sae", C.c_int32), ("k", C.c_int32),
+                ("normalize_layer_norm", C.c_int32), ("max_tokens", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class SaeState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "W_enc", "W_dec", "b_enc", "b_dec", "gW_enc", "gW_dec", "gb_enc", "gb_dec",
+        "mW_enc", "mW_dec", "mb_enc", "mb_dec", "vW_enc", "vW_dec", "vb_enc", "vb_dec",
+        "act_freq_scores", "n_fwd_since_fired")]
+
+
+class SaeOut(C.Structure):
+    _fields_ = [("sae_out", C.c_void_p), ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p),
+                ("scalars", C.c_void_p)]
+
+
+_lib: Optional[C.CDLL] = None
+
+# every symbol include/pv_native.h declares
+EXPORTS = [
+    "pv_abi_version", "pv_last_error",
+    "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
+    "pv_vit_workspace_bytes", "pv_vit_forward", "pv_gemm_bias", "pv_transpose_batched",
+    "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
+    "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_apply", "pv_sae_encode_topk",
+]
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+            "(run `python -m vit_prisma_amd.build`). There is no fallback for the native path.")
+    L = C.CDLL(LIB_PATH)
+    L.pv_abi_version.restype = C.c_int
+    if L.pv_abi_version() != ABI_VERSION:
+        raise NativeError(f"libpvnative ABI {L.pv_abi_version()} != binding {ABI_VERSION}; rebuild")
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    L.pv_last_error.argtypes = [C.c_char_p, sz]
+    L.pv_last_error.restype = None
+    L.pv_vit_plan_create.argtypes = [C.POINTER(VitDesc), C.POINTER(vp)]
+    L.pv_vit_plan_destroy.argtypes = [vp]
+    L.pv_vit_plan_destroy.restype = None
+    L.pv_vit_shadow_bytes.argtypes = [vp]
+    L.pv_vit_shadow_bytes.restype = sz
+    L.pv_vit_plan_set_weights.argtypes = [vp, C.POINTER(VitWeights), vp, sz, vp]
+    L.pv_vit_workspace_bytes.argtypes = [vp, i32]
+    L.pv_vit_workspace_bytes.restype = sz
+    L.pv_vit_forward.argtypes = [vp, vp, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
+    L.pv_gemm_bias.argtypes = [i32, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp]
+    L.pv_transpose_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp]
+    if hasattr(L, "pv_sae_plan_create"):
+        L.pv_sae_plan_create.argtypes = [C.POINTER(SaeDesc), C.POINTER(vp)]
+        L.pv_sae_plan_destroy.argtypes = [vp]
+        L.pv_sae_plan_destroy.restype = None
+        L.pv_sae_workspace_bytes.argtypes = [vp]
+        L.pv_sae_workspace_bytes.restype = sz
+        L.pv_sae_renorm_decoder.argtypes = [vp, C.POINTER(SaeState), vp]
+        L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_grad_sqnorm.argtypes = [vp, C.POINTER(SaeState), vp, vp]
+        L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, vp]
+        L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib().pv_last_error(buf, 1024)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeError(f"{what} failed (status {rc}): {last_error()}")

@@ -1,0 +1,258 @@
+// Attention core for one (image, head, query block) per workgroup on gfx950:
+//     scores  = q k^T / attn_scale          -> hook_attn_scores tap   (attention.py:246-265)
+//     pattern = softmax(scores), NaN -> 0   -> hook_pattern tap       (attention.py:148-150)
+//     z       = pattern v                   -> hook_z                 (attention.py:267-281)
+// Because attn_scores and pattern are OUTPUTS of run_with_cache, the full T x T matrices are
+// materialised (no flash-style fusion is allowed); each is written exactly
+// once, row-contiguous, straight from the LDS copy that also feeds the PV MFMAs.
+//
+//   phase 1  QK^T on MFMA 32x32 tiles, operands loaded as 16-byte fragments straight from global
+//            (q/k rows of one head are 64..256-byte segments, no cross-wave reuse -> no LDS staging),
+//            scaled scores (rounded to the storage dtype, like the reference's bf16 tensor) -> LDS
+//            fp32 [QB][Tpad] (row stride Tpad*4+16 bytes: conflict-free b128 fragment reads later)
+//   phase 2  one wave per row: max / exp / sum / normalise in registers; stores both taps with
+//            coalesced row writes; writes P back to LDS in the storage dtype (bf16 in place)
+//   phase 3  z = P V on MFMA; bf16: V^T blocks staged through LDS so the B fragment is k-contiguous,
+//            fp32: V rows read directly (the f32 MFMA takes one float per lane)
+#include "attention.hpp"
+
+namespace {
+
+constexpr int VT_ROW = 272;     // bytes: 128 keys * 2 + 16 pad
+constexpr int KBLK = 128;       // keys per V^T block (bf16)
+
+template <typename T, int QB, int DH, int MAXC>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EB = DT<T>::kBytes;
+    constexpr int NJ = DH * EB / 32;       // 16-byte fragment pairs along d_head
+    constexpr int NTQ = QB / 32;
+    constexpr int NTN = DH / 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int T_ = p.T, H = p.H;
+    const int q0 = qb * QB;
+    const int Tpad = p.Tpad;
+    const int srow = Tpad * 4 + 16;                 // bytes
+    unsigned char* S = smem;                        // [QB][srow]
+    unsigned char* Vt = smem + QB * srow;           // bf16 only: [DH][VT_ROW]
+
+    const int64_t tok_stride = (int64_t)H * DH;     // elements between tokens of one head
+    const T* qbase = reinterpret_cast<const T*>(p.q) + ((int64_t)b * T_ * H + h) * DH;
+    const T* kbase = reinterpret_cast<const T*>(p.k) + ((int64_t)b * T_ * H + h) * DH;
+    const T* vbase = reinterpret_cast<const T*>(p.v) + ((int64_t)b * T_ * H + h) * DH;
+
+    // ------------------------------------------------------------------ phase 1: scores
+    const int ntk = Tpad / 32;
+    for (int id = wave; id < NTQ * ntk; id += 4) {
+        const int tq = id % NTQ, tk = id / NTQ;
+        const int qi = q0 + tq * 32 + l31;
+        const int ki = tk * 32 + l31;
+        uint4 qa[NJ], kb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            qa[j] = (qi < T_) ? *reinterpret_cast<const uint4*>(
+                                    reinterpret_cast<const unsigned char*>(qbase + qi * tok_stride) + (2 * j + half) * 16)
+                              : make_uint4(0, 0, 0, 0);
+            kb[j] = (ki < T_) ? *reinterpret_cast<const uint4*>(
+                                    reinterpret_cast<const unsigned char*>(kbase + ki * tok_stride) + (2 * j + half) * 16)
+                              : make_uint4(0, 0, 0, 0);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (EB == 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[j]),
+                                                              __builtin_bit_cast(bf16x8, kb[j]), acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(qa[j].x), __uint_as_float(kb[j].x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(qa[j].y), __uint_as_float(kb[j].y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(qa[j].z), __uint_as_float(kb[j].z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(qa[j].w), __uint_as_float(kb[j].w), acc, 0, 0, 0);
+            }
+        }
+        // C layout: col = lane & 31 (key), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (query)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const float s = DT<T>::round(acc[e] / p.attn_scale);
+            *reinterpret_cast<float*>(S + row * srow + (tk * 32 + l31) * 4) = s;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ phase 2: softmax rows
+    for (int r = wave; r < QB; r += 4) {
+        const int qi = q0 + r;
+        if (qi >= T_) continue;                      // pad rows: never stored, never normalised
+        float* srowp = reinterpret_cast<float*>(S + r * srow);
+        float v[MAXC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = lane + 64 * c;
+            v[c] = (col < Tpad) ? srowp[col] : 0.f;
+            if (col < T_) m = fmaxf(m, v[c]);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        float e_[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = lane + 64 * c;
+            e_[c] = (col < T_) ? expf(v[c] - m) : 0.f;
+            sum += e_[c];
+        }
+        sum = wave_sum(sum);
+        const int64_t grow = (((int64_t)b * H + h) * T_ + qi) * T_;
+        T* sc_out = p.scores ? reinterpret_cast<T*>(p.scores) + grow : nullptr;
+        T* pt_out = p.pattern ? reinterpret_cast<T*>(p.pattern) + grow : nullptr;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = lane + 64 * c;
+            if (col < Tpad) {
+                float pr = e_[c] / sum;
+                if (pr != pr) pr = 0.f;              // attention.py:149
+                pr = DT<T>::round(pr);               // attention.py:152 pattern.to(cfg.dtype)
+                if (col < T_) {
+                    if (sc_out) DT<T>::store(sc_out + col, v[c]);
+                    if (pt_out) DT<T>::store(pt_out + col, pr);
+                }
+                // P for the PV product, in the storage dtype, in place (all of this row's fp32
+                // scores were read into registers above; the row belongs to this wave only)
+                if constexpr (EB == 2) reinterpret_cast<bf16_t*>(srowp)[col] = f32_to_bf16(pr);
+                else srowp[col] = pr;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ phase 3: z = P V
+    f32x16 zacc[(NTQ * NTN + 3) / 4];
+#pragma unroll
+    for (int t = 0; t < (NTQ * NTN + 3) / 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zacc[t][e] = 0.f;
+
+    if constexpr (EB == 2) {
+        for (int kb0 = 0; kb0 < Tpad; kb0 += KBLK) {
+            __syncthreads();   // P rows visible (first block) / previous V^T block fully consumed
+            // stage V^T: item -> (key pair kp, 8-wide d_head chunk ch); lanes 0-15 take 16 key
+            // pairs of one chunk (conflict-free ds_write_b32 rows), next 16 lanes the next chunk
+            constexpr int NCH = DH / 8;
+            for (int item = tid; item < (KBLK / 2) * NCH; item += 256) {
+                const int kp = (item & 15) | ((item / (16 * NCH)) << 4);
+                const int ch = (item >> 4) % NCH;
+                const int k0 = kb0 + 2 * kp, k1 = k0 + 1;
+                uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+                if (k0 < T_) v0 = *reinterpret_cast<const uint4*>(vbase + k0 * tok_stride + ch * 8);
+                if (k1 < T_) v1 = *reinterpret_cast<const uint4*>(vbase + k1 * tok_stride + ch * 8);
+                const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w};
+                const uint32_t a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);            // element 2e
+                    const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);        // element 2e+1
+                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e) * VT_ROW + kp * 4) = lo;
+                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e + 1) * VT_ROW + kp * 4) = hi;
+                }
+            }
+            __syncthreads();
+            const int ksteps = min(KBLK, Tpad - kb0) / 16;
+            int t = 0;
+            for (int id = wave; id < NTQ * NTN; id += 4, ++t) {
+                const int tq = id % NTQ, tn = id / NTQ;
+                const unsigned char* prow = S + (tq * 32 + l31) * srow + (kb0 + half * 8) * 2;
+                const unsigned char* vrow = Vt + (tn * 32 + l31) * VT_ROW + half * 16;
+                for (int ks = 0; ks < ksteps; ++ks) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(prow + ks * 32);
+                    const uint4 bb = *reinterpret_cast<const uint4*>(vrow + ks * 32);
+                    zacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                      __builtin_bit_cast(bf16x8, bb), zacc[t], 0, 0, 0);
+                }
+            }
+        }
+    } else {
+        __syncthreads();       // P rows visible to every wave
+        int t = 0;
+        for (int id = wave; id < NTQ * NTN; id += 4, ++t) {
+            const int tq = id % NTQ, tn = id / NTQ;
+            const float* prow = reinterpret_cast<const float*>(S + (tq * 32 + l31) * srow);
+            const T* vcol = vbase + tn * 32 + l31;
+            for (int kb0 = 0; kb0 < Tpad; kb0 += 8) {
+                const int kk = kb0 + half * 4;
+                const float4 a = *reinterpret_cast<const float4*>(prow + kk);
+                float bv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (kk + e < T_) ? DT<T>::load(vcol + (kk + e) * tok_stride) : 0.f;
+                zacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[0], zacc[t], 0, 0, 0);
+                zacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[1], zacc[t], 0, 0, 0);
+                zacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[2], zacc[t], 0, 0, 0);
+                zacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[3], zacc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ store z [B, T, H, dh]
+    {
+        T* zbase = reinterpret_cast<T*>(p.z) + ((int64_t)b * T_ * H + h) * DH;
+        int t = 0;
+        for (int id = wave; id < NTQ * NTN; id += 4, ++t) {
+            const int tq = id % NTQ, tn = id / NTQ;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = q0 + tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (qi < T_) DT<T>::store(zbase + qi * tok_stride + tn * 32 + l31, zacc[t][e]);
+            }
+        }
+    }
+}
+
+template <typename T, int QB, int DH, int MAXC>
+int launch_attn(const AttnParams& p, hipStream_t stream) {
+    constexpr int EB = DT<T>::kBytes;
+    const int srow = p.Tpad * 4 + 16;
+    const int lds = QB * srow + (EB == 2 ? DH * VT_ROW : 0);
+    PV_REQUIRE(lds <= 160 * 1024, "attention LDS footprint exceeds 160 KiB");
+    static int max_set = 0;
+    if (lds > max_set) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<T, QB, DH, MAXC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        max_set = lds;
+    }
+    const dim3 grid((p.T + QB - 1) / QB, p.H, p.B), block(256);
+    hipLaunchKernelGGL((attn_kernel<T, QB, DH, MAXC>), grid, block, lds, stream, p);
+    PV_LAUNCH_CHECK("attn_kernel");
+    return PV_OK;
+}
+
+template <typename T>
+int dispatch_attn(AttnParams& p, hipStream_t stream) {
+    p.Tpad = (p.T + 31) / 32 * 32;
+    if (p.T <= 64) {
+        if (p.dh == 64) return launch_attn<T, 64, 64, 1>(p, stream);
+        if (p.dh == 32) return launch_attn<T, 64, 32, 1>(p, stream);
+    } else if (p.T <= 640) {
+        if (p.dh == 64) return launch_attn<T, 32, 64, 10>(p, stream);
+        if (p.dh == 32) return launch_attn<T, 32, 32, 10>(p, stream);
+    }
+    pv_set_error("attention: unsupported (T, d_head); supported: T <= 640, d_head in {32, 64}");
+    return PV_ERR_INVALID;
+}
+
+}  // namespace
+
+int pv_attention_supported(int T, int dh) { return (T <= 640 && (dh == 64 || dh == 32)) ? 1 : 0; }
+
+int pv_launch_attention(int dtype, AttnParams p, hipStream_t stream) {
+    PV_REQUIRE(p.q && p.k && p.v && p.z, "attention operands must be non-null");
+    PV_REQUIRE(pv_aligned16(p.q) && pv_aligned16(p.k) && pv_aligned16(p.v), "attention operands must be 16-byte aligned");
+    PV_REQUIRE(p.B <= 65535 && p.H <= 65535, "attention grid limits");
+    if (dtype == PV_DTYPE_BF16) return dispatch_attn<bf16_t>(p, stream);
+    if (dtype == PV_DTYPE_F32) return dispatch_attn<float>(p, stream);
+    pv_set_error("attention: unsupported dtype");
+    return PV_ERR_INVALID;
+}

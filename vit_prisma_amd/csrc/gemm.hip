@@ -1,0 +1,360 @@
+// LDS-tiled MFMA GEMM for gfx950 with fused tap epilogues.
+//
+//   tile 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA
+//   tiles of 32 x 32), K consumed in slabs of 128 BYTES per row (64 bf16 or 32 fp32), so the
+//   staging / LDS geometry is identical for both dtypes:
+//     - global -> registers: 16-byte chunks, 8 consecutive lanes cover one 128-byte row segment
+//     - registers -> LDS rows of 144 bytes (128 + one 16-byte access width of padding): the
+//       ds_read_b128 fragment reads (32 distinct rows per half-wave at one chunk column) are
+//       bank-conflict free (9*r mod 16 is a permutation over each 16-lane service group)
+//     - fragments: lane l reads row (l & 31), chunk 2*j + (l >> 5); for bf16 that IS the
+//       v_mfma_f32_32x32x16_bf16 operand (8 consecutive k per lane); for fp32 the 4 floats feed 4
+//       consecutive v_mfma_f32_32x32x2_f32 (A and B use the same k <-> lane-half assignment, so
+//       any consistent assignment gives the exact dot product)
+//     - double-buffered LDS, next slab's global loads issued before the MFMAs of the current one
+//   epilogue: accumulators -> per-wave LDS staging (reusing the operand buffers) -> each lane owns
+//   8 consecutive columns of a row -> bias / GELU / residual in fp32 -> 16-byte coalesced stores of
+//   every requested tap straight from the epilogue (the "fused hook-tap": caching an activation
+//   costs one HBM store, nothing is re-read).
+//   blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (which share the A rows)
+//   are placed on the same XCD so the A slab is served from that XCD's L2.
+#include "gemm.hpp"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int SLAB = 128;            // bytes of K per row per stage
+constexpr int ROWB = 144;            // padded LDS row (bytes)
+constexpr int TILE_BYTES = BM * ROWB;   // 18432
+constexpr int CS_LD = 68;            // fp32 staging row (floats): 64 + 4 pad
+constexpr int GEMM_LDS = 4 * TILE_BYTES;   // As[2] + Bs[2] = 73728 >= 4 waves * 64*68*4 = 69632
+
+template <typename T, int AMODE, bool VEC>
+struct Loader {
+    // one 16-byte chunk of operand A for global row gm at K byte offset kb
+    __device__ static __forceinline__ uint4 load_a(const GemmParams& p, int gm, int kb) {
+        constexpr int EB = DT<T>::kBytes;
+        constexpr int PC = DT<T>::kPerChunk;
+        const int Kb = p.K * EB;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (gm >= p.M || kb >= Kb) return z;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.A);
+        if constexpr (AMODE == PV_A_PLAIN) {
+            const unsigned char* ptr = base + (int64_t)gm * p.lda * EB + kb;
+            if constexpr (VEC) {
+                return *reinterpret_cast<const uint4*>(ptr);
+            } else {
+                alignas(16) T tmp[PC];
+                const T* e = reinterpret_cast<const T*>(ptr);
+                const int ke = kb / EB;
+#pragma unroll
+                for (int i = 0; i < PC; ++i) tmp[i] = (ke + i < p.K) ? e[i] : T(0);
+                return *reinterpret_cast<uint4*>(tmp);
+            }
+        } else {
+            // im2col-free patch gather: row gm = (image b, patch py, px); k = (c, i, j)
+            const int np = p.pG * p.pG;
+            const int b = gm / np, pidx = gm - b * np;
+            const int py = pidx / p.pG, px = pidx - py * p.pG;
+            const int pp = p.pP * p.pP;
+            const int ke = kb / EB;
+            if constexpr (VEC) {
+                const int c = ke / pp, rem = ke - c * pp;
+                const int i = rem / p.pP, j = rem - i * p.pP;
+                const int64_t off = (((int64_t)b * p.pC + c) * p.pS + (py * p.pP + i)) * p.pS + px * p.pP + j;
+                return *reinterpret_cast<const uint4*>(base + off * EB);
+            } else {
+                alignas(16) T tmp[PC];
+#pragma unroll
+                for (int t = 0; t < PC; ++t) {
+                    const int k = ke + t;
+                    if (k < p.K) {
+                        const int c = k / pp, rem = k - c * pp;
+                        const int i = rem / p.pP, j = rem - i * p.pP;
+                        const int64_t off = (((int64_t)b * p.pC + c) * p.pS + (py * p.pP + i)) * p.pS + px * p.pP + j;
+                        tmp[t] = reinterpret_cast<const T*>(base)[off];
+                    } else {
+                        tmp[t] = T(0);
+                    }
+                }
+                return *reinterpret_cast<uint4*>(tmp);
+            }
+        }
+    }
+    __device__ static __forceinline__ uint4 load_b(const GemmParams& p, int gn, int kb) {
+        constexpr int EB = DT<T>::kBytes;
+        constexpr int PC = DT<T>::kPerChunk;
+        const int Kb = p.K * EB;
+        if (gn >= p.N || kb >= Kb) return make_uint4(0, 0, 0, 0);
+        const unsigned char* ptr = reinterpret_cast<const unsigned char*>(p.Bt) + (int64_t)gn * p.ldb * EB + kb;
+        if constexpr (VEC) {
+            return *reinterpret_cast<const uint4*>(ptr);
+        } else {
+            alignas(16) T tmp[PC];
+            const T* e = reinterpret_cast<const T*>(ptr);
+            const int ke = kb / EB;
+#pragma unroll
+            for (int i = 0; i < PC; ++i) tmp[i] = (ke + i < p.K) ? e[i] : T(0);
+            return *reinterpret_cast<uint4*>(tmp);
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], int gm, int gn) {
+    T* out0 = reinterpret_cast<T*>(p.out0);
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    const T* bias = reinterpret_cast<const T*>(p.bias0);
+    int col = gn;
+    if (p.epi == PV_EPI_QKV) {
+        const int which = gn / p.nsplit;
+        col = gn - which * p.nsplit;
+        if (which == 1) { out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
+        if (which == 2) { out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
+    }
+    const int nvalid = min(8, p.N - gn);
+    if (p.vec_out && nvalid == 8) {
+        if (bias) {
+            float b[8];
+            load8(bias + col, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += b[i];
+        }
+        if (p.epi == PV_EPI_BIAS || p.epi == PV_EPI_QKV) {
+            store8(out0 + (int64_t)gm * p.ldo + col, v);
+        } else if (p.epi == PV_EPI_RESID) {
+            // attn_out / mlp_out is rounded to the storage dtype first (it is what the reference
+            // adds to the residual: transformer_block.py:122-124, :134)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
+            if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
+            float r[8];
+            load8(reinterpret_cast<const T*>(p.resid) + (int64_t)gm * p.ldr + gn, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += r[i];
+            store8(out1 + (int64_t)gm * p.ldo + gn, v);
+        } else {  // PV_EPI_ACT: mlp.py:67-72, activation applied to the stored pre-activation
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
+            if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = pv_act(v[i], p.act);
+            store8(out1 + (int64_t)gm * p.ldo + gn, v);
+        }
+    } else {
+        for (int i = 0; i < nvalid; ++i) {
+            float x = v[i];
+            int c = col + i, g = gn + i;
+            T* o0 = out0;
+            const T* bs = bias;
+            if (p.epi == PV_EPI_QKV) {   // a chunk may straddle outputs when nsplit % 8 != 0
+                const int which = g / p.nsplit;
+                c = g - which * p.nsplit;
+                o0 = reinterpret_cast<T*>(which == 0 ? p.out0 : (which == 1 ? p.out1 : p.out2));
+                bs = reinterpret_cast<const T*>(which == 0 ? p.bias0 : (which == 1 ? p.bias1 : p.bias2));
+            }
+            if (bs) x += DT<T>::load(bs + c);
+            if (p.epi == PV_EPI_BIAS || p.epi == PV_EPI_QKV) {
+                DT<T>::store(o0 + (int64_t)gm * p.ldo + c, x);
+            } else if (p.epi == PV_EPI_RESID) {
+                x = DT<T>::round(x);
+                if (o0) DT<T>::store(o0 + (int64_t)gm * p.ldo + g, x);
+                x += DT<T>::load(reinterpret_cast<const T*>(p.resid) + (int64_t)gm * p.ldr + g);
+                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, x);
+            } else {
+                x = DT<T>::round(x);
+                if (o0) DT<T>::store(o0 + (int64_t)gm * p.ldo + g, x);
+                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, pv_act(x, p.act));
+            }
+        }
+    }
+}
+
+template <typename T, int AMODE, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                      // [2][TILE_BYTES]
+    unsigned char* Bs = smem + 2 * TILE_BYTES;     // [2][TILE_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware, bijective remap of the linear workgroup id (block b runs on XCD b % 8): each XCD
+    // gets a contiguous run of tiles; tiles are ordered N-fastest so a run shares A rows.
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    constexpr int EB = DT<T>::kBytes;
+    const int Kb = p.K * EB;
+    const int nk = (Kb + SLAB - 1) / SLAB;
+
+    // staging assignment: chunk c = tid + 256*i -> row c >> 3, 16-byte column c & 7
+    uint4 ra[4], rb[4];
+    auto load_slab = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 3, kc = c & 7;
+            const int kb = kt * SLAB + kc * 16;
+            ra[i] = Loader<T, AMODE, VEC>::load_a(p, m0 + row, kb);
+            rb[i] = Loader<T, AMODE, VEC>::load_b(p, n0 + row, kb);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 3, kc = c & 7;
+            *reinterpret_cast<uint4*>(As + buf * TILE_BYTES + row * ROWB + kc * 16) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + row * ROWB + kc * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int a_off = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    const int b_off = (wn * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_slab(kt + 1);
+        const unsigned char* Ab = As + buf * TILE_BYTES;
+        const unsigned char* Bb = Bs + buf * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 a[2], b[2];
+            a[0] = *reinterpret_cast<const uint4*>(Ab + a_off + j * 32);
+            a[1] = *reinterpret_cast<const uint4*>(Ab + a_off + 32 * ROWB + j * 32);
+            b[0] = *reinterpret_cast<const uint4*>(Bb + b_off + j * 32);
+            b[1] = *reinterpret_cast<const uint4*>(Bb + b_off + 32 * ROWB + j * 32);
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]),
+                            acc[mi][ni], 0, 0, 0);
+            } else {
+                const float af[2][4] = {{__uint_as_float(a[0].x), __uint_as_float(a[0].y),
+                                         __uint_as_float(a[0].z), __uint_as_float(a[0].w)},
+                                        {__uint_as_float(a[1].x), __uint_as_float(a[1].y),
+                                         __uint_as_float(a[1].z), __uint_as_float(a[1].w)}};
+                const float bf[2][4] = {{__uint_as_float(b[0].x), __uint_as_float(b[0].y),
+                                         __uint_as_float(b[0].z), __uint_as_float(b[0].w)},
+                                        {__uint_as_float(b[1].x), __uint_as_float(b[1].y),
+                                         __uint_as_float(b[1].z), __uint_as_float(b[1].w)}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (per wave) -> row-major 8-column chunks per lane
+    float* Cs = reinterpret_cast<float*>(smem) + wave * (64 * CS_LD);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int col = ni * 32 + (lane & 31);
+                Cs[row * CS_LD + col] = acc[mi][ni][e];
+            }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int cc = (lane & 7) * 8;
+        const int gm = m0 + wm * 64 + row;
+        const int gn = n0 + wn * 64 + cc;
+        if (gm < p.M && gn < p.N) {
+            float v[8];
+            const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc);
+            const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            epilogue8<T>(p, v, gm, gn);
+        }
+    }
+}
+
+template <typename T, int AMODE, bool VEC>
+int launch(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AMODE, VEC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, AMODE, VEC>), dim3(ntm * ntn), dim3(256), GEMM_LDS, stream, p);
+    PV_LAUNCH_CHECK("gemm_kernel");
+    return PV_OK;
+}
+
+template <typename T>
+int dispatch(GemmParams& p, hipStream_t stream) {
+    constexpr int EB = DT<T>::kBytes;
+    const bool kvec = ((int64_t)p.K * EB) % 16 == 0;
+    const bool b_vec = kvec && (p.ldb * EB) % 16 == 0 && pv_aligned16(p.Bt);
+    bool a_vec;
+    if (p.a_mode == PV_A_PLAIN) {
+        a_vec = kvec && (p.lda * EB) % 16 == 0 && pv_aligned16(p.A);
+    } else {
+        a_vec = (p.pP * EB) % 16 == 0 && (p.pS * EB) % 16 == 0 && pv_aligned16(p.A);
+    }
+    const bool vec = a_vec && b_vec;
+    // vector epilogue legality
+    bool vo = (p.ldo * EB) % 16 == 0 && pv_aligned16(p.out0) && pv_aligned16(p.out1) && pv_aligned16(p.out2) &&
+              pv_aligned16(p.bias0) && pv_aligned16(p.bias1) && pv_aligned16(p.bias2);
+    if (p.epi == PV_EPI_RESID) vo = vo && (p.ldr * EB) % 16 == 0 && pv_aligned16(p.resid);
+    if (p.epi == PV_EPI_QKV) vo = vo && (p.nsplit % 8) == 0;
+    p.vec_out = vo ? 1 : 0;
+    if (p.a_mode == PV_A_PLAIN) {
+        return vec ? launch<T, PV_A_PLAIN, true>(p, stream) : launch<T, PV_A_PLAIN, false>(p, stream);
+    }
+    return vec ? launch<T, PV_A_PATCH, true>(p, stream) : launch<T, PV_A_PATCH, false>(p, stream);
+}
+
+}  // namespace
+
+int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
+    PV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm dims must be positive");
+    PV_REQUIRE(p.A && p.Bt, "gemm operands must be non-null");
+    if (p.epi == PV_EPI_BIAS) PV_REQUIRE(p.out0, "EPI_BIAS needs out0");
+    if (p.epi == PV_EPI_QKV) PV_REQUIRE(p.out0 && p.out1 && p.out2 && p.nsplit > 0 && p.N == 3 * p.nsplit, "EPI_QKV outputs");
+    if (p.epi == PV_EPI_RESID) PV_REQUIRE(p.out1 && p.resid, "EPI_RESID needs out1 and resid");
+    if (p.epi == PV_EPI_ACT) PV_REQUIRE(p.out1, "EPI_ACT needs out1");
+    if (dtype == PV_DTYPE_BF16) return dispatch<bf16_t>(p, stream);
+    if (dtype == PV_DTYPE_F32) return dispatch<float>(p, stream);
+    pv_set_error("gemm: unsupported dtype");
+    return PV_ERR_INVALID;
+}

@@ -1,0 +1,37 @@
+// MFMA GEMM with fused bias / activation / residual / tap-store epilogues (gfx950).
+#pragma once
+#include "pv_common.hpp"
+
+enum { PV_EPI_BIAS = 0, PV_EPI_QKV = 1, PV_EPI_RESID = 2, PV_EPI_ACT = 3 };
+enum { PV_A_PLAIN = 0, PV_A_PATCH = 1 };
+
+// C[M,N] = A[M,K] * Bt[N,K]^T  (+ epilogue).  All tensors have element type T (fp32 | bf16),
+// accumulation is fp32 on the matrix cores.
+struct GemmParams {
+    // A operand
+    const void* A;
+    int64_t lda;             // elements (PLAIN)
+    int32_t a_mode;          // PV_A_PLAIN | PV_A_PATCH (im2col-free patch gather from NCHW)
+    int32_t pC, pP, pS, pG;  // PATCH: channels, patch size, image size, patches per row
+    // B operand, [N][K] K-contiguous ("Bt")
+    const void* Bt;
+    int64_t ldb;             // elements
+    int32_t M, N, K;
+    // epilogue
+    int32_t epi;             // PV_EPI_*
+    int32_t act;             // PV_ACT_* (EPI_ACT)
+    int32_t nsplit;          // EPI_QKV: columns per output
+    const void* bias0;       // [N] (or [nsplit] x3 for QKV); may be NULL
+    const void* bias1;
+    const void* bias2;
+    void* out0;              // BIAS: C ; QKV: q ; RESID: (acc+bias) tap or NULL ; ACT: pre tap or NULL
+    void* out1;              // QKV: k ; RESID: resid + (acc+bias) ; ACT: act(pre)
+    void* out2;              // QKV: v
+    int64_t ldo;             // elements, all outputs
+    const void* resid;       // RESID: [M][ldr]
+    int64_t ldr;
+    int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
+};
+
+// dtype: PV_DTYPE_*.  Returns PV_OK / error code (pv_last_error has the message).
+int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream);

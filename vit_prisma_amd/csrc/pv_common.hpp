@@ -1,0 +1,124 @@
+// Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave = 64 lanes, MFMA
+// 32x32x16 bf16 / 32x32x2 f32, 160 KiB LDS per CU.  No CUDA/HIP dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/pv_native.h"
+
+typedef uint16_t bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define PV_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void pv_set_error(const std::string& msg);
+#define PV_HIP_CHECK(expr)                                                                \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            pv_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            return PV_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+#define PV_LAUNCH_CHECK(name)                                                             \
+    do {                                                                                  \
+        hipError_t _e = hipGetLastError();                                                \
+        if (_e != hipSuccess) {                                                           \
+            pv_set_error(std::string("launch ") + name + ": " + hipGetErrorString(_e));   \
+            return PV_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+#define PV_REQUIRE(cond, msg)                                                             \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            pv_set_error(std::string("invalid: ") + msg + " [" #cond "]");                \
+            return PV_ERR_INVALID;                                                        \
+        }                                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int kBytes = 4;
+    static constexpr int kPerChunk = 4;   // elements per 16-byte chunk
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int kBytes = 2;
+    static constexpr int kPerChunk = 8;
+    __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// load / store 8 consecutive elements (as floats); pointer must be 16-byte aligned for the vector
+// forms (callers guarantee it, scalar fallbacks otherwise)
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = pack_bf16x2(v[0], v[1]); a.y = pack_bf16x2(v[2], v[3]);
+    a.z = pack_bf16x2(v[4], v[5]); a.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activation functions of models/layers/mlp.py:41-63 that the fast path supports
+__device__ __forceinline__ float pv_act(float x, int act) {
+    if (act == PV_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (act == PV_ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    return fmaxf(x, 0.0f);
+}
+
+static inline int64_t pv_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline bool pv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

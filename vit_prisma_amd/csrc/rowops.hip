@@ -1,0 +1,156 @@
+// Row-wise HBM-bound kernels: LayerNorm (+ embed assembly) with fused tap stores, L2 normalise,
+// batched transpose (weight shadow packing).  One 64-lane wave owns one row; 16-byte vector
+// loads/stores; every tensor is read once and every requested tap written once.
+#include "rowops.hpp"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;   // 8-element chunks per lane -> d <= 64 * 8 * 4 = 2048
+
+// LayerNorm exactly as models/layers/layer_norm.py:75-93:
+//   x <- x - mean(x);  scale = sqrt(mean(x^2) + eps);  y = x / scale * w + b
+// In bf16 mode the input is up-cast to fp32 first (:84-85), hook_scale / hook_normalized fire on
+// fp32 values (:88-93) and only the returned tensor is cast back to bf16.
+// EMBED mode builds the row on the fly (models/base_vit.py:171-181):
+//   row(b, t) = (t == 0 ? cls_token : patch_embed[b, t-1]) + W_pos[t]   -> hook_full_embed
+template <typename T, bool EMBED>
+__global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int d = p.d;
+    const int nchunks = d >> 3;
+
+    float x[LN_MAX_CHUNKS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+            if constexpr (EMBED) {
+                const int b = row / p.T, t = row - b * p.T;
+                float e[8], pos[8];
+                if (p.use_cls && t == 0) {
+                    load8(reinterpret_cast<const T*>(p.cls) + ch * 8, e);
+                } else {
+                    const int64_t prow = (int64_t)b * (p.T - p.use_cls) + (t - p.use_cls);
+                    load8(reinterpret_cast<const T*>(p.x) + prow * d + ch * 8, e);
+                }
+                load8(reinterpret_cast<const T*>(p.pos) + (int64_t)t * d + ch * 8, pos);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[c][i] = DT<T>::round(e[i] + pos[i]);
+                if (p.full_out) store8(reinterpret_cast<T*>(p.full_out) + (int64_t)row * d + ch * 8, x[c]);
+            } else {
+                load8(reinterpret_cast<const T*>(p.x) + (int64_t)row * p.ldx + ch * 8, x[c]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += x[c][i];
+        }
+    }
+    if (!p.do_ln) return;
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        if (lane + 64 * c < nchunks) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                x[c][i] -= mean;
+                sq += x[c][i] * x[c][i];
+            }
+        }
+    }
+    const float scale = sqrtf(wave_sum(sq) / (float)d + p.eps);
+    if (p.scale_out && lane == 0) p.scale_out[row] = scale;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunks) {
+            float w[8], b[8], y[8];
+            load8(reinterpret_cast<const T*>(p.w) + ch * 8, w);
+            load8(reinterpret_cast<const T*>(p.b) + ch * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) y[i] = (x[c][i] / scale) * w[i] + b[i];
+            if (p.norm_f32_out) store8(p.norm_f32_out + (int64_t)row * d + ch * 8, y);
+            if (p.out) store8(reinterpret_cast<T*>(p.out) + (int64_t)row * d + ch * 8, y);
+        }
+    }
+}
+
+// F.normalize(x, dim=-1) (models/base_vit.py:214-215): x / max(||x||_2, 1e-12); one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ x, T* __restrict__ out, int rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float sq = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float v = DT<T>::load(x + (int64_t)row * n + i);
+        sq += v * v;
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+    for (int i = lane; i < n; i += 64) {
+        const float v = DT<T>::load(x + (int64_t)row * n + i);
+        DT<T>::store(out + (int64_t)row * n + i, v / nrm);
+    }
+}
+
+// out[b][c][r] = in[b][r][c]; 32 x 32 tiles through LDS (+1 pad), coalesced on both sides
+template <typename E>
+__global__ __launch_bounds__(256) void transpose_kernel(const E* __restrict__ in, E* __restrict__ out, int R, int C) {
+    __shared__ E tile[32][33];
+    const int64_t boff = (int64_t)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 8 * i][tx] = in[boff + (int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < C) out[boff + (int64_t)c * R + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+}  // namespace
+
+int pv_launch_ln(int dtype, const LnParams& p, hipStream_t stream) {
+    PV_REQUIRE(p.d % 8 == 0 && p.d <= 64 * 8 * LN_MAX_CHUNKS, "layernorm width must be a multiple of 8 and <= 2048");
+    PV_REQUIRE(p.rows > 0, "layernorm rows");
+    if (!p.embed) PV_REQUIRE(p.ldx % 8 == 0, "layernorm row stride must be a multiple of 8");
+    const dim3 grid((p.rows + 3) / 4), block(256);
+    if (dtype == PV_DTYPE_BF16) {
+        if (p.embed) hipLaunchKernelGGL((ln_kernel<bf16_t, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((ln_kernel<bf16_t, false>), grid, block, 0, stream, p);
+    } else {
+        if (p.embed) hipLaunchKernelGGL((ln_kernel<float, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((ln_kernel<float, false>), grid, block, 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("ln_kernel");
+    return PV_OK;
+}
+
+int pv_launch_l2norm(int dtype, const void* x, void* out, int rows, int n, hipStream_t stream) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (dtype == PV_DTYPE_BF16)
+        hipLaunchKernelGGL((l2norm_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, n);
+    else
+        hipLaunchKernelGGL((l2norm_kernel<float>), grid, block, 0, stream, (const float*)x, (float*)out, rows, n);
+    PV_LAUNCH_CHECK("l2norm_kernel");
+    return PV_OK;
+}
+
+int pv_launch_transpose(int elem_bytes, const void* in, void* out, int batch, int R, int C, hipStream_t stream) {
+    PV_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "transpose element size must be 2 or 4");
+    PV_REQUIRE(batch > 0 && R > 0 && C > 0 && batch < 65536, "transpose dims");
+    const dim3 grid((C + 31) / 32, (R + 31) / 32, batch), block(256);
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL((transpose_kernel<uint16_t>), grid, block, 0, stream, (const uint16_t*)in, (uint16_t*)out, R, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, block, 0, stream, (const uint32_t*)in, (uint32_t*)out, R, C);
+    PV_LAUNCH_CHECK("transpose_kernel");
+    return PV_OK;
+}

@@ -1,0 +1,373 @@
+// Host-side plan + launch sequence of the tapped ViT forward (C ABI in include/pv_native.h).
+// Mirrors HookedViT.forward (/root/reference/src/vit_prisma/models/base_vit.py:152-217) and
+// TransformerBlock.forward (models/layers/transformer_block.py:80-138); ln1 is evaluated ONCE per
+// block (the reference evaluates it three times with identical results, :106-109).
+#include <string.h>
+
+#include <vector>
+
+#include "attention.hpp"
+#include "gemm.hpp"
+#include "rowops.hpp"
+
+static thread_local std::string g_last_error;
+void pv_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" int pv_abi_version(void) { return PV_ABI_VERSION; }
+extern "C" void pv_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return;
+    strncpy(buf, g_last_error.c_str(), len - 1);
+    buf[len - 1] = 0;
+}
+
+struct LayerShadow {
+    unsigned char* Wqkv;   // [3*H*dh][d]
+    unsigned char* WoT;    // [d][H*dh]
+    unsigned char* WinT;   // [d_mlp][d]
+    unsigned char* WoutT;  // [d][d_mlp]
+};
+
+struct pv_vit_plan {
+    pv_vit_desc d;
+    int P, G, T, HD, EB;
+    pv_vit_weights w;
+    std::vector<pv_vit_layer_weights> lw;
+    std::vector<LayerShadow> sh;
+    unsigned char* WhT;
+    bool weights_set;
+};
+
+static size_t seg(size_t elems, int eb) { return (size_t)pv_align_up((int64_t)elems * eb, 256); }
+
+extern "C" int pv_vit_plan_create(const pv_vit_desc* desc, pv_vit_plan** out_plan) {
+    PV_REQUIRE(desc && out_plan, "null argument");
+    const pv_vit_desc& d = *desc;
+    PV_REQUIRE(d.dtype == PV_DTYPE_F32 || d.dtype == PV_DTYPE_BF16, "dtype must be fp32 or bf16");
+    PV_REQUIRE(d.n_layers >= 0 && d.d_model > 0 && d.n_heads > 0 && d.d_head > 0 && d.d_mlp > 0, "dims");
+    PV_REQUIRE(d.d_model % 8 == 0 && d.d_model <= 2048, "d_model must be a multiple of 8 and <= 2048");
+    PV_REQUIRE(d.d_mlp % 8 == 0, "d_mlp must be a multiple of 8");
+    PV_REQUIRE(d.patch_size > 0 && d.image_size >= d.patch_size, "patch/image size");
+    const int G = d.image_size / d.patch_size;
+    const int P = G * G;
+    PV_REQUIRE(d.n_tokens == P + (d.use_cls_token ? 1 : 0), "n_tokens != patches (+cls)");
+    PV_REQUIRE(pv_attention_supported(d.n_tokens, d.d_head), "attention shape unsupported (T <= 640, d_head in {32,64})");
+    PV_REQUIRE(d.activation >= PV_ACT_GELU && d.activation <= PV_ACT_RELU, "activation");
+    if (d.has_head) PV_REQUIRE(d.n_classes > 0, "n_classes");
+    pv_vit_plan* p = new pv_vit_plan();
+    p->d = d;
+    p->G = G;
+    p->P = P;
+    p->T = d.n_tokens;
+    p->HD = d.n_heads * d.d_head;
+    p->EB = d.dtype == PV_DTYPE_BF16 ? 2 : 4;
+    p->WhT = nullptr;
+    p->weights_set = false;
+    *out_plan = p;
+    return PV_OK;
+}
+
+extern "C" void pv_vit_plan_destroy(pv_vit_plan* plan) { delete plan; }
+
+extern "C" size_t pv_vit_shadow_bytes(const pv_vit_plan* p) {
+    if (!p) return 0;
+    const pv_vit_desc& d = p->d;
+    size_t per_layer = seg((size_t)3 * p->HD * d.d_model, p->EB) + seg((size_t)d.d_model * p->HD, p->EB) +
+                       2 * seg((size_t)d.d_model * d.d_mlp, p->EB);
+    size_t total = per_layer * d.n_layers;
+    if (d.has_head) total += seg((size_t)d.n_classes * d.d_model, p->EB);
+    return total + 256;
+}
+
+extern "C" int pv_vit_plan_set_weights(pv_vit_plan* p, const pv_vit_weights* w, void* shadow,
+                                       size_t shadow_bytes, void* stream_) {
+    PV_REQUIRE(p && w && shadow, "null argument");
+    PV_REQUIRE(shadow_bytes >= pv_vit_shadow_bytes(p), "shadow buffer too small");
+    PV_REQUIRE(((uintptr_t)shadow & 255) == 0, "shadow buffer must be 256-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const pv_vit_desc& d = p->d;
+    PV_REQUIRE(w->conv_w && w->conv_b && w->W_pos && w->ln_final_w && w->ln_final_b, "missing global weights");
+    if (d.use_cls_token) PV_REQUIRE(w->cls_token, "missing cls_token");
+    if (d.layer_norm_pre) PV_REQUIRE(w->ln_pre_w && w->ln_pre_b, "missing ln_pre weights");
+    if (d.has_head) PV_REQUIRE(w->W_H && w->b_H, "missing head weights");
+    PV_REQUIRE(d.n_layers == 0 || w->layers, "missing layer weights");
+    p->w = *w;
+    p->lw.assign(w->layers, w->layers + d.n_layers);
+    p->w.layers = p->lw.data();
+    p->sh.resize(d.n_layers);
+    unsigned char* cur = (unsigned char*)shadow;
+    const int EB = p->EB, HD = p->HD, dm = d.d_model, dmlp = d.d_mlp, H = d.n_heads, dh = d.d_head;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const pv_vit_layer_weights& L = p->lw[l];
+        PV_REQUIRE(L.ln1_w && L.ln1_b && L.W_Q && L.W_K && L.W_V && L.b_Q && L.b_K && L.b_V && L.W_O && L.b_O &&
+                       L.ln2_w && L.ln2_b && L.W_in && L.b_in && L.W_out && L.b_out,
+                   "missing block weights");
+        LayerShadow& S = p->sh[l];
+        S.Wqkv = cur; cur += seg((size_t)3 * HD * dm, EB);
+        S.WoT = cur;  cur += seg((size_t)dm * HD, EB);
+        S.WinT = cur; cur += seg((size_t)dm * dmlp, EB);
+        S.WoutT = cur; cur += seg((size_t)dm * dmlp, EB);
+        // W_Q[h][k][e] -> Wqkv[(h*dh+e)][k]   (attention.py:216-220: x @ W[h] + b[h])
+        int rc;
+        if ((rc = pv_launch_transpose(EB, L.W_Q, S.Wqkv, H, dm, dh, stream))) return rc;
+        if ((rc = pv_launch_transpose(EB, L.W_K, S.Wqkv + (size_t)HD * dm * EB, H, dm, dh, stream))) return rc;
+        if ((rc = pv_launch_transpose(EB, L.W_V, S.Wqkv + (size_t)2 * HD * dm * EB, H, dm, dh, stream))) return rc;
+        // W_O[h][e][n] == [K = h*dh+e][N = d] -> [N][K]   (attention.py:155-167)
+        if ((rc = pv_launch_transpose(EB, L.W_O, S.WoT, 1, HD, dm, stream))) return rc;
+        if ((rc = pv_launch_transpose(EB, L.W_in, S.WinT, 1, dm, dmlp, stream))) return rc;
+        if ((rc = pv_launch_transpose(EB, L.W_out, S.WoutT, 1, dmlp, dm, stream))) return rc;
+    }
+    if (d.has_head) {
+        p->WhT = cur;
+        int rc;
+        if ((rc = pv_launch_transpose(EB, w->W_H, p->WhT, 1, dm, d.n_classes, stream))) return rc;
+    }
+    p->weights_set = true;
+    return PV_OK;
+}
+
+namespace {
+struct Workspace {
+    size_t total;
+    size_t embed, resid_a, resid_b, ln_out, q, k, v, z, resid_mid, mlp_post, lnf, head;
+};
+Workspace carve(const pv_vit_plan* p, int B) {
+    const pv_vit_desc& d = p->d;
+    const size_t M = (size_t)B * p->T;
+    const int EB = p->EB;
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t elems) { size_t o = off; off += seg(elems, EB); return o; };
+    w.embed = take((size_t)B * p->P * d.d_model);
+    w.resid_a = take(M * d.d_model);
+    w.resid_b = take(M * d.d_model);
+    w.ln_out = take(M * d.d_model);
+    w.q = take(M * p->HD);
+    w.k = take(M * p->HD);
+    w.v = take(M * p->HD);
+    w.z = take(M * p->HD);
+    w.resid_mid = take(M * d.d_model);
+    w.mlp_post = take(M * d.d_mlp);
+    w.lnf = take(M * d.d_model);
+    w.head = take((size_t)B * (d.has_head ? d.n_classes : d.d_model));
+    w.total = off + 256;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
+    if (!p || batch <= 0) return 0;
+    return carve(p, batch).total;
+}
+
+extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int32_t n_blocks,
+                              int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                              size_t workspace_bytes, void* out, void* stream_) {
+    PV_REQUIRE(p && images && workspace, "null argument");
+    PV_REQUIRE(p->weights_set, "pv_vit_plan_set_weights has not been called");
+    PV_REQUIRE(B > 0, "batch must be positive");
+    const pv_vit_desc& d = p->d;
+    PV_REQUIRE(n_blocks >= 0 && n_blocks <= d.n_layers, "n_blocks out of range");
+    PV_REQUIRE(!run_head || n_blocks == d.n_layers, "run_head requires all blocks");
+    PV_REQUIRE(!run_head || out, "run_head requires an output buffer");
+    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    PV_REQUIRE(pv_aligned16(images), "images must be 16-byte aligned");
+    const Workspace ws = carve(p, B);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    const int dt = d.dtype, T = p->T, dm = d.d_model, HD = p->HD, dmlp = d.d_mlp;
+    const int M = B * T;
+    const bool bf16 = dt == PV_DTYPE_BF16;
+
+    // tap table
+    std::vector<void*> tap((size_t)PV_SLOT__COUNT * (size_t)(d.n_layers + 1), nullptr);
+    auto tap_at = [&](int slot, int layer) -> void*& { return tap[(size_t)layer * PV_SLOT__COUNT + slot]; };
+    for (int i = 0; i < n_taps; ++i) {
+        const pv_tap& t = taps[i];
+        PV_REQUIRE(t.slot >= 0 && t.slot < PV_SLOT__COUNT && t.dst, "bad tap slot");
+        const int layer = t.slot >= PV_SLOT_LN1_SCALE ? t.layer : 0;
+        PV_REQUIRE(layer >= 0 && layer < d.n_layers + 1, "bad tap layer");
+        PV_REQUIRE(pv_aligned16(t.dst), "tap destinations must be 16-byte aligned");
+        if (!bf16) {
+            PV_REQUIRE(t.slot != PV_SLOT_LNPRE_NORM_F32 && t.slot != PV_SLOT_LNF_NORM_F32 &&
+                           t.slot != PV_SLOT_LN1_NORM_F32 && t.slot != PV_SLOT_LN2_NORM_F32,
+                       "*_NORM_F32 slots exist only in bf16 mode");
+        }
+        tap_at(t.slot, layer) = t.dst;
+    }
+    auto pick = [&](int slot, int layer, size_t ws_off) -> void* {
+        void* t = tap_at(slot, layer);
+        return t ? t : (void*)(wsb + ws_off);
+    };
+    int rc;
+
+    // ---- patch embedding: stride-p conv as an im2col-free GEMM (patch_embedding.py:26-32)
+    void* embed = pick(PV_SLOT_EMBED, 0, ws.embed);
+    {
+        GemmParams g = {};
+        g.A = images; g.a_mode = PV_A_PATCH; g.pC = d.n_channels; g.pP = d.patch_size; g.pS = d.image_size; g.pG = p->G;
+        g.Bt = p->w.conv_w; g.ldb = (int64_t)d.n_channels * d.patch_size * d.patch_size;
+        g.M = B * p->P; g.N = dm; g.K = d.n_channels * d.patch_size * d.patch_size;
+        g.epi = PV_EPI_BIAS; g.bias0 = p->w.conv_b; g.out0 = embed; g.ldo = dm;
+        if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+    }
+    // ---- cls + pos (+ ln_pre) (base_vit.py:171-185)
+    void* resid;
+    {
+        LnParams L = {};
+        L.x = embed; L.rows = M; L.d = dm; L.eps = d.eps; L.embed = 1; L.T = T; L.use_cls = d.use_cls_token ? 1 : 0;
+        L.cls = p->w.cls_token; L.pos = p->w.W_pos;
+        if (d.layer_norm_pre) {
+            L.do_ln = 1; L.w = p->w.ln_pre_w; L.b = p->w.ln_pre_b;
+            L.full_out = tap_at(PV_SLOT_FULL_EMBED, 0);
+            L.scale_out = (float*)tap_at(PV_SLOT_LNPRE_SCALE, 0);
+            L.norm_f32_out = (float*)tap_at(PV_SLOT_LNPRE_NORM_F32, 0);
+            resid = pick(PV_SLOT_LNPRE_OUT, 0, ws.resid_a);
+            L.out = resid;
+        } else {
+            L.do_ln = 0;
+            resid = pick(PV_SLOT_FULL_EMBED, 0, ws.resid_a);
+            L.full_out = resid;
+        }
+        if ((rc = pv_launch_ln(dt, L, stream))) return rc;
+    }
+    bool resid_in_a = true;   // which workspace residual buffer may hold `resid`
+
+    for (int l = 0; l < n_blocks; ++l) {
+        const pv_vit_layer_weights& W = p->lw[l];
+        const LayerShadow& S = p->sh[l];
+        void* resid_pre = resid;
+        // ln1 (transformer_block.py:106-109 ; layer_norm.py:75-93)
+        void* ln1 = pick(PV_SLOT_LN1_OUT, l, ws.ln_out);
+        {
+            LnParams L = {};
+            L.x = resid_pre; L.ldx = dm; L.rows = M; L.d = dm; L.eps = d.eps; L.do_ln = 1;
+            L.w = W.ln1_w; L.b = W.ln1_b;
+            L.scale_out = (float*)tap_at(PV_SLOT_LN1_SCALE, l);
+            L.norm_f32_out = (float*)tap_at(PV_SLOT_LN1_NORM_F32, l);
+            L.out = ln1;
+            if ((rc = pv_launch_ln(dt, L, stream))) return rc;
+        }
+        // q, k, v (attention.py:186-244) as one GEMM against the packed [3*H*dh][d] shadow
+        void* q = pick(PV_SLOT_Q, l, ws.q);
+        void* k = pick(PV_SLOT_K, l, ws.k);
+        void* v = pick(PV_SLOT_V, l, ws.v);
+        {
+            GemmParams g = {};
+            g.A = ln1; g.lda = dm; g.a_mode = PV_A_PLAIN; g.Bt = S.Wqkv; g.ldb = dm;
+            g.M = M; g.N = 3 * HD; g.K = dm; g.epi = PV_EPI_QKV; g.nsplit = HD;
+            g.bias0 = W.b_Q; g.bias1 = W.b_K; g.bias2 = W.b_V; g.out0 = q; g.out1 = k; g.out2 = v; g.ldo = HD;
+            if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+        }
+        // scores / pattern / z (attention.py:135-152, 246-281)
+        void* z = pick(PV_SLOT_Z, l, ws.z);
+        {
+            AttnParams a = {};
+            a.q = q; a.k = k; a.v = v; a.z = z;
+            a.scores = tap_at(PV_SLOT_SCORES, l); a.pattern = tap_at(PV_SLOT_PATTERN, l);
+            a.B = B; a.T = T; a.H = d.n_heads; a.dh = d.d_head; a.attn_scale = d.attn_scale;
+            if ((rc = pv_launch_attention(dt, a, stream))) return rc;
+        }
+        // attn_out = z W_O + b_O ; resid_mid = resid_pre + attn_out (attention.py:155-167 ; block :117-124)
+        void* resid_mid = pick(PV_SLOT_RESID_MID, l, ws.resid_mid);
+        {
+            GemmParams g = {};
+            g.A = z; g.lda = HD; g.a_mode = PV_A_PLAIN; g.Bt = S.WoT; g.ldb = HD;
+            g.M = M; g.N = dm; g.K = HD; g.epi = PV_EPI_RESID; g.bias0 = W.b_O;
+            g.out0 = tap_at(PV_SLOT_ATTN_OUT, l); g.out1 = resid_mid; g.ldo = dm; g.resid = resid_pre; g.ldr = dm;
+            if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+        }
+        // ln2 (block :130)
+        void* ln2 = pick(PV_SLOT_LN2_OUT, l, ws.ln_out);
+        {
+            LnParams L = {};
+            L.x = resid_mid; L.ldx = dm; L.rows = M; L.d = dm; L.eps = d.eps; L.do_ln = 1;
+            L.w = W.ln2_w; L.b = W.ln2_b;
+            L.scale_out = (float*)tap_at(PV_SLOT_LN2_SCALE, l);
+            L.norm_f32_out = (float*)tap_at(PV_SLOT_LN2_NORM_F32, l);
+            L.out = ln2;
+            if ((rc = pv_launch_ln(dt, L, stream))) return rc;
+        }
+        // mlp (mlp.py:65-80): pre -> act -> post
+        void* post = pick(PV_SLOT_MLP_POST, l, ws.mlp_post);
+        {
+            GemmParams g = {};
+            g.A = ln2; g.lda = dm; g.a_mode = PV_A_PLAIN; g.Bt = S.WinT; g.ldb = dm;
+            g.M = M; g.N = dmlp; g.K = dm; g.epi = PV_EPI_ACT; g.act = d.activation; g.bias0 = W.b_in;
+            g.out0 = tap_at(PV_SLOT_MLP_PRE, l); g.out1 = post; g.ldo = dmlp;
+            if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+        }
+        // mlp_out ; resid_post = resid_mid + mlp_out (block :131-134)
+        void* resid_post = tap_at(PV_SLOT_RESID_POST, l);
+        if (!resid_post) {
+            // the workspace buffer NOT holding resid_pre (resid_pre is dead after the O-proj, but keep
+            // it simple and safe: ping-pong)
+            resid_post = wsb + (resid_in_a ? ws.resid_b : ws.resid_a);
+            resid_in_a = !resid_in_a;
+        }
+        {
+            GemmParams g = {};
+            g.A = post; g.lda = dmlp; g.a_mode = PV_A_PLAIN; g.Bt = S.WoutT; g.ldb = dmlp;
+            g.M = M; g.N = dm; g.K = dmlp; g.epi = PV_EPI_RESID; g.bias0 = W.b_out;
+            g.out0 = tap_at(PV_SLOT_MLP_OUT, l); g.out1 = resid_post; g.ldo = dm; g.resid = resid_mid; g.ldr = dm;
+            if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+        }
+        resid = resid_post;
+    }
+    if (!run_head) return PV_OK;
+
+    // ---- ln_final on all tokens only if one of its taps is requested, else on the CLS rows only
+    const bool lnf_all = tap_at(PV_SLOT_LNF_SCALE, 0) || tap_at(PV_SLOT_LNF_NORM_F32, 0) || tap_at(PV_SLOT_LNF_OUT, 0);
+    void* lnf = pick(PV_SLOT_LNF_OUT, 0, ws.lnf);
+    int64_t lnf_ld;   // row stride (elements) between CLS rows of consecutive images
+    {
+        LnParams L = {};
+        L.x = resid; L.d = dm; L.eps = d.eps; L.do_ln = 1; L.w = p->w.ln_final_w; L.b = p->w.ln_final_b;
+        if (lnf_all) {
+            L.ldx = dm; L.rows = M;
+            L.scale_out = (float*)tap_at(PV_SLOT_LNF_SCALE, 0);
+            L.norm_f32_out = (float*)tap_at(PV_SLOT_LNF_NORM_F32, 0);
+            lnf_ld = (int64_t)T * dm;
+        } else {
+            L.ldx = (int64_t)T * dm; L.rows = B;
+            lnf_ld = dm;
+        }
+        L.out = lnf;
+        if ((rc = pv_launch_ln(dt, L, stream))) return rc;
+    }
+    // ---- cls row -> head (head.py:27-37) -> hook_post_head_pre_normalize -> F.normalize
+    const int nout = d.has_head ? d.n_classes : dm;
+    void* head_tap = tap_at(PV_SLOT_HEAD_OUT, 0);
+    void* hb = head_tap ? head_tap : (d.normalize_output ? (void*)(wsb + ws.head) : out);
+    if (d.has_head) {
+        GemmParams g = {};
+        g.A = lnf; g.lda = lnf_ld; g.a_mode = PV_A_PLAIN; g.Bt = p->WhT; g.ldb = dm;
+        g.M = B; g.N = nout; g.K = dm; g.epi = PV_EPI_BIAS; g.bias0 = p->w.b_H; g.out0 = hb; g.ldo = nout;
+        if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+    } else {
+        PV_HIP_CHECK(hipMemcpy2DAsync(hb, (size_t)dm * p->EB, lnf, (size_t)lnf_ld * p->EB, (size_t)dm * p->EB, B,
+                                      hipMemcpyDeviceToDevice, stream));
+    }
+    if (d.normalize_output) {
+        if ((rc = pv_launch_l2norm(dt, hb, out, B, nout, stream))) return rc;
+    } else if (hb != out) {
+        PV_HIP_CHECK(hipMemcpyAsync(out, hb, (size_t)B * nout * p->EB, hipMemcpyDeviceToDevice, stream));
+    }
+    return PV_OK;
+}
+
+// ---- kernel-level entry points -------------------------------------------------------------
+extern "C" int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const void* Bt, int64_t ldb,
+                            const void* bias, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                            void* stream) {
+    GemmParams g = {};
+    g.A = A; g.lda = lda; g.a_mode = PV_A_PLAIN; g.Bt = Bt; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.epi = PV_EPI_BIAS; g.bias0 = bias; g.out0 = C; g.ldo = ldc;
+    return pv_launch_gemm(dtype, g, (hipStream_t)stream);
+}
+
+extern "C" int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t batch,
+                                    int32_t R, int32_t C, void* stream) {
+    PV_REQUIRE(in && out, "null argument");
+    return pv_launch_transpose(elem_bytes, in, out, batch, R, C, (hipStream_t)stream);
+}

@@ -1,0 +1,301 @@
+"""Host driver of the native (HIP) tapped ViT forward: plan, weight shadow, workspace, and the
+HBM tap arena that backs ActivationCache tensors.
+
+PyTorch is plumbing here: it owns device memory and streams; all arithmetic happens in
+libpvnative.so behind the C ABI of include/pv_native.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+from .tap_plan import TapSpec, final_residual_name, hook_order, tap_spec
+
+_ALIGN = 256
+_ESIZE = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2}
+
+
+def _use_count(t: torch.Tensor) -> int:
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class TapArena:
+    """Ring of HBM slabs that tap stores go to.  One ``run_with_cache`` call takes ONE slab and
+    carves every cached activation out of it as a tensor view, so the reference's lifetime
+    semantics hold (a cache entry stays valid for as long as the user holds it, cf.
+    hooked_root_module.py:312-316 where entries alias live activations): a slab is handed out
+    again only when the storage use-count shows no outstanding view; if every slab is still
+    referenced a new one is allocated (spill), never overwritten.
+    """
+
+    def __init__(self, device: torch.device, max_slabs: int = 4):
+        self.device = device
+        self.max_slabs = max_slabs
+        self._slabs: List[Tuple[torch.Tensor, int]] = []   # (uint8 tensor, baseline use-count)
+        self.n_alloc = 0
+        self.n_reuse = 0
+
+    def acquire(self, nbytes: int) -> torch.Tensor:
+        nbytes = max(int(nbytes), _ALIGN)
+        for slab, base in self._slabs:
+            if slab.numel() >= nbytes and _use_count(slab) <= base:
+                self.n_reuse += 1
+                return slab
+        slab = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        base = _use_count(slab)
+        self.n_alloc += 1
+        # keep the ring bounded: evict free slabs that are too small, oldest first
+        free_small = [i for i, (s, b) in enumerate(self._slabs) if _use_count(s) <= b and s.numel() < nbytes]
+        for i in reversed(free_small):
+            del self._slabs[i]
+        if len(self._slabs) < self.max_slabs:
+            self._slabs.append((slab, base))
+        return slab
+
+    def bytes_held(self) -> int:
+        return sum(s.numel() for s, _ in self._slabs)
+
+
+class PinnedMirror:
+    """Pinned host slab for ``device='cpu'`` requests: ONE async D2H copy of the whole tap slab on
+    a side stream and one event sync, instead of one synchronous copy per hook point."""
+
+    def __init__(self):
+        self._buf: Optional[torch.Tensor] = None
+        self._stream: Optional[torch.cuda.Stream] = None
+
+    def copy_from(self, slab: torch.Tensor, nbytes: int) -> torch.Tensor:
+        # a fresh pinned buffer per call keeps cache lifetime semantics (the user owns the views)
+        host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=slab.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(slab.device))
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(ev)
+            host.copy_(slab[:nbytes], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        done.synchronize()
+        return host
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class NativeViT:
+    """Owns one pv_vit_plan for one (config, dtype, device)."""
+
+    def __init__(self, cfg, n_tokens: int, device: torch.device):
+        if cfg.dtype not in (torch.float32, torch.bfloat16):
+            raise N.NativeError(f"native path supports fp32 / bf16 storage, not {cfg.dtype}")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.n_tokens = n_tokens
+        self.lib = N.lib()
+        desc = N.VitDesc(
+            n_layers=cfg.n_layers, d_model=cfg.d_model, n_heads=cfg.n_heads, d_head=cfg.d_head,
+            d_mlp=cfg.d_mlp, n_channels=cfg.n_channels, patch_size=cfg.patch_size,
+            image_size=cfg.image_size, n_tokens=n_tokens, n_classes=cfg.n_classes,
+            use_cls_token=int(bool(cfg.use_cls_token)), layer_norm_pre=int(bool(cfg.layer_norm_pre)),
+            has_head=int(cfg.return_type != "pre_logits"), normalize_output=int(bool(cfg.normalize_output)),
+            activation=N.PV_ACT[cfg.activation_name],
+            dtype=N.PV_DTYPE_BF16 if cfg.dtype == torch.bfloat16 else N.PV_DTYPE_F32,
+            eps=float(cfg.eps),
+            attn_scale=float(cfg.d_head ** 0.5) if cfg.use_attn_scale else 1.0)
+        self._plan = C.c_void_p()
+        N.check(self.lib.pv_vit_plan_create(C.byref(desc), C.byref(self._plan)), "pv_vit_plan_create")
+        self._shadow: Optional[torch.Tensor] = None
+        self._weights_key = None
+        self._frozen = False
+        self._keepalive = None
+        self._workspace: Optional[torch.Tensor] = None
+        self.arena = TapArena(self.device)
+        self.mirror = PinnedMirror()
+        self.n_forward = 0
+        self.n_repack = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) is not None and self._plan.value:
+                self.lib.pv_vit_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------
+    @staticmethod
+    def supported(cfg, n_tokens: int) -> Optional[str]:
+        """None if the native plan supports this config, else the reason it does not."""
+        if cfg.dtype not in (torch.float32, torch.bfloat16):
+            return f"dtype {cfg.dtype}"
+        if cfg.normalization_type != "LN":
+            return f"normalization_type {cfg.normalization_type}"
+        if cfg.activation_name not in N.PV_ACT:
+            return f"activation {cfg.activation_name}"
+        if cfg.classification_type != "cls" or "dino-vitb" in str(cfg.model_name):
+            return "classification_type"
+        if getattr(cfg, "is_video_transformer", False) or getattr(cfg, "use_bert_block", False) or cfg.attn_only:
+            return "architecture variant"
+        if cfg.use_attn_result or cfg.use_split_qkv_input or cfg.use_attn_in or cfg.use_hook_mlp_in:
+            return "per-head input/result hooks enabled"
+        if cfg.d_model % 8 or cfg.d_mlp % 8 or cfg.d_model > 2048:
+            return "d_model/d_mlp alignment"
+        if n_tokens > 640 or cfg.d_head not in (32, 64):
+            return "attention shape"
+        if cfg.attn_dropout_rate or cfg.mlp_dropout_rate:
+            return None  # dropout is the identity in eval mode; training mode is checked by the caller
+        return None
+
+    def _collect(self, model) -> Tuple[N.VitWeights, list, tuple]:
+        cfg = self.cfg
+        keep: List[torch.Tensor] = []
+
+        def P(t: Optional[torch.Tensor]) -> Optional[int]:
+            if t is None:
+                return None
+            t = t.detach()
+            if t.device != self.device or t.dtype != cfg.dtype:
+                raise N.NativeError(f"parameter on {t.device}/{t.dtype}, plan is {self.device}/{cfg.dtype}")
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        L = (N.VitLayerWeights * max(cfg.n_layers, 1))()
+        for i, blk in enumerate(model.blocks):
+            a, m = blk.attn, blk.mlp
+            L[i] = N.VitLayerWeights(
+                ln1_w=P(blk.ln1.w), ln1_b=P(blk.ln1.b), W_Q=P(a.W_Q), W_K=P(a.W_K), W_V=P(a.W_V),
+                b_Q=P(a.b_Q), b_K=P(a.b_K), b_V=P(a.b_V), W_O=P(a.W_O), b_O=P(a.b_O),
+                ln2_w=P(blk.ln2.w), ln2_b=P(blk.ln2.b), W_in=P(m.W_in), b_in=P(m.b_in),
+                W_out=P(m.W_out), b_out=P(m.b_out))
+        has_head = cfg.return_type != "pre_logits"
+        W = N.VitWeights(
+            cls_token=P(model.cls_token) if cfg.use_cls_token else None,
+            conv_w=P(model.embed.proj.weight), conv_b=P(model.embed.proj.bias),
+            W_pos=P(model.pos_embed.W_pos),
+            ln_pre_w=P(model.ln_pre.w) if cfg.layer_norm_pre else None,
+            ln_pre_b=P(model.ln_pre.b) if cfg.layer_norm_pre else None,
+            ln_final_w=P(model.ln_final.w), ln_final_b=P(model.ln_final.b),
+            W_H=P(model.head.W_H) if has_head else None, b_H=P(model.head.b_H) if has_head else None,
+            layers=C.cast(L, C.POINTER(N.VitLayerWeights)))
+        key = tuple((p.data_ptr(), p._version) for p in model.parameters())
+        return W, [keep, L], key
+
+    def sync_weights(self, model, force: bool = False) -> None:
+        """(Re)pack the MFMA-layout weight shadow when parameters changed (data_ptr / _version of
+        any parameter) -- or unconditionally with force=True (edits through ``.data`` are invisible
+        to the version counter; ``HookedViT.invalidate_native_weights()`` forces a repack)."""
+        if self._frozen and not force and self._weights_key is not None:
+            return
+        key = tuple((p.data_ptr(), p._version) for p in model.parameters())
+        if not force and key == self._weights_key:
+            return
+        W, keep, key = self._collect(model)
+        nbytes = self.lib.pv_vit_shadow_bytes(self._plan)
+        if self._shadow is None or self._shadow.numel() < nbytes:
+            self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.pv_vit_plan_set_weights(self._plan, C.byref(W), self._shadow.data_ptr(), nbytes, stream),
+                "pv_vit_plan_set_weights")
+        self._keepalive = keep
+        self._weights_key = key
+        self.n_repack += 1
+
+    def freeze_weights(self, frozen: bool = True) -> None:
+        self._frozen = frozen
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _get_workspace(self, batch: int) -> torch.Tensor:
+        need = self.lib.pv_vit_workspace_bytes(self._plan, batch)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def forward(self, model, images: torch.Tensor, names: Sequence[str], n_blocks: int, run_head: bool,
+                cache_device=None, remove_batch_dim: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
+        Returns (model_out, {name: tensor})."""
+        cfg = self.cfg
+        if images.device != self.device:
+            raise N.NativeError(f"input on {images.device}, model on {self.device}")
+        if images.dtype != cfg.dtype:
+            images = images.to(cfg.dtype)
+        images = images.contiguous()
+        B = images.shape[0]
+        if tuple(images.shape[1:]) != (cfg.n_channels, cfg.image_size, cfg.image_size):
+            raise ValueError(f"expected images [B,{cfg.n_channels},{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
+        T = self.n_tokens
+        self.sync_weights(model)
+
+        specs: Dict[str, TapSpec] = {n: tap_spec(n, cfg, B, T) for n in names}
+        out_name = None
+        if not run_head:
+            out_name = final_residual_name(cfg, n_blocks)
+            if out_name not in specs:
+                specs[out_name] = tap_spec(out_name, cfg, B, T)
+        # unique buffers -> slab offsets
+        offsets: Dict[Tuple[int, int], Tuple[int, TapSpec]] = {}
+        total = 0
+        for n, s in specs.items():
+            if s.slot < 0:
+                continue
+            key = (s.slot, s.layer)
+            if key not in offsets:
+                nbytes = _ESIZE[s.dtype]
+                for dim in s.shape:
+                    nbytes *= dim
+                offsets[key] = (total, s)
+                total += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        n_out = cfg.n_classes if cfg.return_type != "pre_logits" else cfg.d_model
+        out_off = total
+        if run_head:
+            total += (B * n_out * images.element_size() + _ALIGN - 1) // _ALIGN * _ALIGN
+        slab = self.arena.acquire(total)
+        base = slab.data_ptr()
+
+        taps = (N.Tap * max(len(offsets), 1))()
+        for i, ((slot, layer), (off, _)) in enumerate(offsets.items()):
+            taps[i] = N.Tap(slot=slot, layer=layer, dst=base + off)
+        ws = self._get_workspace(B)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
+                                        ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
+                "pv_vit_forward")
+        self.n_forward += 1
+
+        def view(src: torch.Tensor, off: int, s_dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
+            n = 1
+            for dim in shape:
+                n *= dim
+            nb = n * _ESIZE[s_dtype]
+            return src[off:off + nb].view(s_dtype).view(shape)
+
+        to_cpu = cache_device is not None and torch.device(cache_device).type == "cpu"
+        src = self.mirror.copy_from(slab, total) if (to_cpu and names) else slab
+        cache: Dict[str, torch.Tensor] = {}
+        for n in names:
+            s = specs[n]
+            if s.slot < 0:
+                # hook_pos_embed: stride-0 broadcast view of W_pos, as in position_embedding.py:36-38
+                t = model.pos_embed.W_pos.detach().unsqueeze(0).expand(B, -1, -1)
+                if cache_device is not None:
+                    t = t.to(cache_device)
+            else:
+                off, _ = offsets[(s.slot, s.layer)]
+                t = view(src, off, s.dtype, s.shape)
+                if cache_device is not None and not to_cpu:
+                    t = t.to(cache_device)
+            cache[n] = t[0] if remove_batch_dim else t
+        if run_head:
+            out = view(slab, out_off, cfg.dtype, (B, n_out))
+        else:
+            off, s = offsets[(specs[out_name].slot, specs[out_name].layer)]
+            out = view(slab, off, s.dtype, s.shape)
+        return out, cache

@@ -1,0 +1,536 @@
+"""HookedViT and its layers -- the Python class surface of the hot path.
+
+Drop-in for the reference's classes (module / parameter / HookPoint names, signatures and hook
+semantics identical; state dicts interchange):
+    PatchEmbedding    /root/reference/src/vit_prisma/models/layers/patch_embedding.py:8-32
+    PosEmbedding      models/layers/position_embedding.py:12-38
+    LayerNorm         models/layers/layer_norm.py:48-93
+    Attention         models/layers/attention.py:23-281
+    MLP               models/layers/mlp.py:15-80
+    TransformerBlock  models/layers/transformer_block.py:30-138
+    Head              models/layers/head.py:13-37
+    HookedViT         models/base_vit.py:60-269, 670-824
+
+``HookedViT.run_with_cache`` dispatches pure-caching calls on a GPU to the native HIP plan
+(``native_vit.NativeViT`` -> libpvnative.so); every module's ``forward`` below is the faithful
+PyTorch implementation used when user hooks must run as Python callbacks (mutating hooks,
+backward hooks, per-head input hooks, training mode) and on machines without a GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native
+from .activation_cache import ActivationCache
+from .configs import HookedViTConfig
+from .hook_points import HookPoint
+from .hooked_root_module import HookedRootModule, names_filter_to_fn
+from .tap_plan import hook_order, resolve_n_blocks
+
+
+def _as_cfg(cfg: Union[Dict, HookedViTConfig]) -> HookedViTConfig:
+    return HookedViTConfig.from_dict(cfg) if isinstance(cfg, dict) else cfg
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    return x * torch.sigmoid(1.702 * x)
+
+
+def gelu_new(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+def gelu_fast(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * x * (1.0 + torch.tanh(x * 0.7978845608 * (1.0 + 0.044715 * x * x)))
+
+
+_ACTIVATIONS = {"relu": F.relu, "gelu": F.gelu, "silu": F.silu, "gelu_new": gelu_new,
+                "gelu_fast": gelu_fast, "quick_gelu": quick_gelu}
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, config, logger=None):
+        super().__init__()
+        self.config = config
+        self.logger = logger
+        self.proj = nn.Conv2d(config.n_channels, config.d_model, kernel_size=config.patch_size,
+                              stride=config.patch_size, bias=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.proj(x).flatten(2).transpose(1, 2)       # [B, d, gy, gx] -> [B, P, d]
+
+
+class PosEmbedding(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        n = (cfg.image_size // cfg.patch_size) ** 2
+        if cfg.is_video_transformer:
+            n *= cfg.video_num_frames // cfg.video_tubelet_depth
+        self.W_pos = nn.Parameter(torch.empty(n + 1 if cfg.use_cls_token else n, cfg.d_model, dtype=cfg.dtype))
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        return self.W_pos.unsqueeze(0).expand(tokens.size(0), -1, -1)   # stride-0 broadcast view
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, cfg, length: Optional[int] = None):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        self.eps = cfg.eps
+        self.length = cfg.d_model if length is None else length
+        self.w = nn.Parameter(torch.ones(self.length, dtype=cfg.dtype))
+        self.b = nn.Parameter(torch.zeros(self.length, dtype=cfg.dtype))
+        self.hook_scale = HookPoint()        # [batch, pos, 1]
+        self.hook_normalized = HookPoint()   # [batch, pos, length]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.cfg.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float32)
+        x = x - x.mean(-1, keepdim=True)
+        scale = self.hook_scale((x.pow(2).mean(-1, keepdim=True) + self.eps).sqrt())
+        return self.hook_normalized(x / scale * self.w + self.b).to(self.cfg.dtype)
+
+
+class LayerNormPre(nn.Module):
+    """Centre + normalise without affine parameters (layer_norm.py:11-45)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        self.eps = cfg.eps
+        self.hook_scale = HookPoint()
+        self.hook_normalized = HookPoint()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.cfg.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float32)
+        x = x - x.mean(-1, keepdim=True)
+        scale = self.hook_scale((x.pow(2).mean(-1, keepdim=True) + self.eps).sqrt())
+        return self.hook_normalized(x / scale).to(self.cfg.dtype)
+
+
+def _make_norm(cfg, length: Optional[int] = None) -> nn.Module:
+    if cfg.normalization_type == "LN":
+        return LayerNorm(cfg, length)
+    if cfg.normalization_type == "LNPre":
+        return LayerNormPre(cfg)
+    if cfg.normalization_type is None:
+        return nn.Identity()
+    raise ValueError(f"Invalid normalization type: {cfg.normalization_type}")
+
+
+class Attention(nn.Module):
+    def __init__(self, cfg, layer_id: Optional[int] = None):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        H, d, dh, dt = cfg.n_heads, cfg.d_model, cfg.d_head, cfg.dtype
+        self.W_Q = nn.Parameter(torch.empty(H, d, dh, dtype=dt))
+        self.W_K = nn.Parameter(torch.empty(H, d, dh, dtype=dt))
+        self.W_V = nn.Parameter(torch.empty(H, d, dh, dtype=dt))
+        self.W_O = nn.Parameter(torch.empty(H, dh, d, dtype=dt))
+        self.b_Q = nn.Parameter(torch.zeros(H, dh, dtype=dt))
+        self.b_K = nn.Parameter(torch.zeros(H, dh, dtype=dt))
+        self.b_V = nn.Parameter(torch.zeros(H, dh, dtype=dt))
+        self.b_O = nn.Parameter(torch.zeros(d, dtype=dt))
+        self.hook_k = HookPoint()            # [batch, pos, head, d_head]
+        self.hook_q = HookPoint()
+        self.hook_v = HookPoint()
+        self.hook_z = HookPoint()
+        self.hook_attn_scores = HookPoint()  # [batch, head, query, key]
+        self.hook_pattern = HookPoint()
+        self.hook_result = HookPoint()       # [batch, pos, head, d_model] (use_attn_result only)
+        self.layer_id = layer_id
+        self.attn_scale = math.sqrt(cfg.d_head) if cfg.use_attn_scale else 1.0
+
+    def _project(self, x: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        if x.ndim == 4:      # per-head inputs [B, T, H, d] (use_split_qkv_input / use_attn_in)
+            return torch.einsum("bthd,hde->bthe", x, W) + b
+        return torch.einsum("btd,hde->bthe", x, W) + b
+
+    def calculate_qkv_matrices(self, query_input, key_input, value_input):
+        q = self.hook_q(self._project(query_input, self.W_Q, self.b_Q))
+        k = self.hook_k(self._project(key_input, self.W_K, self.b_K))
+        v = self.hook_v(self._project(value_input, self.W_V, self.b_V))
+        return q, k, v
+
+    def calculate_attn_scores(self, q, k, attention_mask=None):
+        scores = torch.einsum("bqhe,bkhe->bhqk", q, k) / self.attn_scale
+        if attention_mask is not None:
+            scores = scores + attention_mask
+        return scores
+
+    def calculate_z_scores(self, v, pattern):
+        return self.hook_z(torch.einsum("bkhe,bhqk->bqhe", v, pattern))
+
+    def forward(self, query_input, key_input, value_input, attention_mask=None) -> torch.Tensor:
+        q, k, v = self.calculate_qkv_matrices(query_input, key_input, value_input)
+        scores = self.hook_attn_scores(self.calculate_attn_scores(q, k, attention_mask))
+        pattern = F.softmax(scores, dim=-1)
+        pattern = torch.where(torch.isnan(pattern), torch.zeros_like(pattern), pattern)
+        pattern = self.hook_pattern(pattern).to(self.cfg.dtype)
+        z = self.calculate_z_scores(v, pattern)
+        if not self.cfg.use_attn_result:
+            return torch.einsum("bqhe,hed->bqd", z, self.W_O) + self.b_O
+        result = self.hook_result(torch.einsum("bqhe,hed->bqhd", z, self.W_O))
+        return result.sum(dim=2) + self.b_O
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        d, dm, dt = cfg.d_model, cfg.d_mlp, cfg.dtype
+        self.W_in = nn.Parameter(torch.empty(d, dm, dtype=dt))
+        self.b_in = nn.Parameter(torch.empty(dm, dtype=dt))
+        self.W_out = nn.Parameter(torch.empty(dm, d, dtype=dt))
+        self.b_out = nn.Parameter(torch.empty(d, dtype=dt))
+        self.hook_pre = HookPoint()
+        self.hook_post = HookPoint()
+        if cfg.activation_name in _ACTIVATIONS:
+            self.act_fn = _ACTIVATIONS[cfg.activation_name]
+        elif cfg.activation_name == "solu_ln":
+            self.act_fn = lambda x: x * F.softmax(x, dim=-1)
+            self.hook_mid = HookPoint()
+            self.ln = LayerNorm(cfg, cfg.d_mlp) if cfg.normalization_type == "LN" else LayerNormPre(cfg)
+        else:
+            raise ValueError(f"Invalid activation function name: {cfg.activation_name}")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        pre = self.hook_pre(x @ self.W_in + self.b_in)
+        if self.cfg.activation_name.endswith("_ln"):
+            post = self.hook_post(self.ln(self.hook_mid(self.act_fn(pre))))
+        else:
+            post = self.hook_post(self.act_fn(pre))
+        return post @ self.W_out + self.b_out
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, cfg, block_index=None):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        self.ln1 = _make_norm(cfg)
+        if not cfg.attn_only:
+            self.ln2 = _make_norm(cfg)
+        self.attn = Attention(cfg)
+        if not cfg.attn_only:
+            self.mlp = MLP(cfg)
+        self.hook_attn_in = HookPoint()
+        self.hook_q_input = HookPoint()
+        self.hook_k_input = HookPoint()
+        self.hook_v_input = HookPoint()
+        self.hook_mlp_in = HookPoint()
+        self.hook_attn_out = HookPoint()
+        self.hook_mlp_out = HookPoint()
+        self.hook_resid_pre = HookPoint()
+        if not cfg.attn_only:
+            self.hook_resid_mid = HookPoint()
+        self.hook_resid_post = HookPoint()
+        self.attn_dropout = nn.Dropout(cfg.attn_dropout_rate)
+        self.mlp_dropout = nn.Dropout(cfg.mlp_dropout_rate)
+
+    def forward(self, resid_pre: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        cfg = self.cfg
+        resid_pre = self.hook_resid_pre(resid_pre)
+        attn_in = resid_pre
+        if cfg.use_attn_in or cfg.use_split_qkv_input:
+            attn_in = resid_pre.unsqueeze(2).expand(-1, -1, cfg.n_heads, -1)   # per-head copy of the stream
+        if cfg.use_attn_in:
+            attn_in = self.hook_attn_in(attn_in.clone())
+        if cfg.use_split_qkv_input:
+            q_in = self.hook_q_input(attn_in.clone())
+            k_in = self.hook_k_input(attn_in.clone())
+            v_in = self.hook_v_input(attn_in.clone())
+        else:
+            q_in = k_in = v_in = attn_in
+        # the reference normalises the three inputs separately (three ln1 calls, block :106-109)
+        attn_out = self.attn(query_input=self.ln1(q_in), key_input=self.ln1(k_in),
+                             value_input=self.ln1(v_in), attention_mask=attn_mask)
+        attn_out = self.hook_attn_out(self.attn_dropout(attn_out))
+        if cfg.attn_only:
+            return self.hook_resid_post(resid_pre + attn_out)
+        resid_mid = self.hook_resid_mid(resid_pre + attn_out)
+        mlp_in = self.hook_mlp_in(resid_mid.clone()) if cfg.use_hook_mlp_in else resid_mid
+        mlp_out = self.hook_mlp_out(self.mlp_dropout(self.mlp(self.ln2(mlp_in))))
+        return self.hook_resid_post(resid_mid + mlp_out)
+
+
+class Head(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg = _as_cfg(cfg)
+        self.W_H = nn.Parameter(torch.empty(cfg.d_model, cfg.n_classes, dtype=cfg.dtype))
+        self.b_H = nn.Parameter(torch.zeros(cfg.n_classes, dtype=cfg.dtype))
+
+    def forward(self, residual: torch.Tensor) -> torch.Tensor:
+        return residual @ self.W_H + self.b_H
+
+
+class HookedViT(HookedRootModule):
+    """Vision transformer with a HookPoint on every intermediate activation."""
+
+    def __init__(self, cfg: Union[HookedViTConfig, Dict]):
+        super().__init__()
+        if isinstance(cfg, dict):
+            cfg = HookedViTConfig(**cfg)
+        elif isinstance(cfg, str):
+            raise ValueError("Please pass in a config dictionary or HookedViTConfig object.")
+        self.cfg = cfg
+        if cfg.is_video_transformer or cfg.use_bert_block:
+            raise NotImplementedError("video (tubelet) and BERT-block variants are outside the MI355X hot path")
+
+        self.cls_token = nn.Parameter(torch.randn(1, 1, cfg.d_model))
+        self.embed = PatchEmbedding(cfg)
+        self.hook_embed = HookPoint()
+        self.pos_embed = PosEmbedding(cfg)
+        self.hook_pos_embed = HookPoint()
+        self.hook_full_embed = HookPoint()
+        if cfg.layer_norm_pre:
+            self.ln_pre = _make_norm(cfg)
+            self.hook_ln_pre = HookPoint()
+        self.blocks = nn.ModuleList([TransformerBlock(cfg, i) for i in range(cfg.n_layers)])
+        self.ln_final = _make_norm(cfg)
+        self.hook_ln_final = HookPoint()
+        self.head = Head(cfg)
+        self.hook_post_head_pre_normalize = HookPoint()
+        self.init_weights()
+        self.setup()
+        # native (HIP) execution state
+        self.native_mode = "auto"            # "auto" | "off" | "force"
+        self._native = None
+        self.last_run_native = False
+        self.native_fallback_reason: Optional[str] = None
+
+    # ------------------------------------------------------------------------------ PyTorch path
+    def forward(self, input: torch.Tensor, stop_at_layer: Optional[int] = None) -> torch.Tensor:
+        cfg = self.cfg
+        embed = self.hook_embed(self.embed(input))
+        if cfg.use_cls_token:
+            embed = torch.cat((self.cls_token.expand(input.shape[0], -1, -1), embed), dim=1)
+        residual = embed + self.hook_pos_embed(self.pos_embed(input))
+        self.hook_full_embed(residual)                       # observe-only (return value unused)
+        if cfg.layer_norm_pre:
+            residual = self.hook_ln_pre(self.ln_pre(residual))
+        for block in self.blocks[:stop_at_layer]:
+            residual = block(residual)
+        if stop_at_layer is not None:
+            return residual
+        x = self.ln_final(residual)
+        self.hook_ln_final(x)                                # observe-only
+        if cfg.classification_type == "gaap":
+            x = x.mean(dim=1)
+        elif cfg.classification_type == "cls":
+            cls_tok = x[:, 0]
+            if "dino-vitb" in cfg.model_name:
+                x = torch.cat((cls_tok.unsqueeze(-1), x[:, 1:].mean(dim=1).unsqueeze(-1)), dim=-1)
+            else:
+                x = cls_tok
+        if cfg.return_type != "pre_logits":
+            x = self.head(x)
+        self.hook_post_head_pre_normalize(x)                 # observe-only
+        if cfg.normalize_output:
+            x = F.normalize(x, dim=-1)
+        return x
+
+    def init_weights(self) -> None:
+        cfg = self.cfg
+        if cfg.use_cls_token:
+            nn.init.normal_(self.cls_token, std=cfg.cls_std)
+        if cfg.weight_type != "he":
+            return
+        for m in self.modules():
+            if isinstance(m, PosEmbedding):
+                nn.init.normal_(m.W_pos, std=cfg.pos_std)
+            elif isinstance(m, Attention):
+                for w in (m.W_Q, m.W_K, m.W_V, m.W_O):
+                    nn.init.xavier_uniform_(w)
+            elif isinstance(m, MLP):
+                nn.init.kaiming_normal_(m.W_in, nonlinearity="relu")
+                nn.init.kaiming_normal_(m.W_out, nonlinearity="relu")
+                nn.init.zeros_(m.b_in)
+                nn.init.zeros_(m.b_out)
+            elif isinstance(m, Head):
+                nn.init.kaiming_normal_(m.W_H, nonlinearity="relu")
+                nn.init.zeros_(m.b_H)
+            elif isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------------------ native path
+    @property
+    def n_tokens(self) -> int:
+        return self.pos_embed.W_pos.shape[0]
+
+    def use_native(self, mode: Union[bool, str, None]) -> "HookedViT":
+        """True/"force": raise unless the HIP path can run; False/"off": always PyTorch hooks;
+        None/"auto": HIP path whenever the call is a pure caching call on a GPU."""
+        self.native_mode = {True: "force", False: "off", None: "auto"}.get(mode, mode)
+        assert self.native_mode in ("auto", "off", "force")
+        return self
+
+    def invalidate_native_weights(self) -> None:
+        """Force a repack of the MFMA-layout weight shadow on the next native call (needed only
+        after edits through ``param.data`` which do not bump the version counter)."""
+        if self._native is not None:
+            self._native._weights_key = None
+
+    def freeze_native_weights(self, frozen: bool = True) -> None:
+        """Promise that parameters do not change (skips the per-call change detection)."""
+        self._native_frozen = frozen
+        if self._native is not None:
+            self._native.freeze_weights(frozen)
+
+    def _native_reason(self, model_args, kwargs) -> Optional[str]:
+        """None when the call can run on the native plan, else why not."""
+        if len(model_args) != 1 or not isinstance(model_args[0], torch.Tensor):
+            return "positional arguments"
+        x = model_args[0]
+        extra = set(kwargs) - {"names_filter", "device", "stop_at_layer", "incl_bwd", "reset_hooks_end",
+                               "clear_contexts", "fwd_hooks", "bwd_hooks"}
+        if extra:
+            return f"unsupported kwargs {sorted(extra)}"
+        if kwargs.get("incl_bwd", False) or kwargs.get("bwd_hooks"):
+            return "backward hooks requested"
+        if kwargs.get("fwd_hooks"):
+            return "user forward hooks must run as Python callbacks"
+        if not x.is_cuda:
+            return "input is not on a GPU"
+        p0 = self.cls_token
+        if p0.device != x.device:
+            return "model and input on different devices"
+        if x.ndim != 4:
+            return "input rank"
+        why = _native_supported(self.cfg, self.n_tokens)
+        if why:
+            return why
+        if self.training and (self.cfg.attn_dropout_rate or self.cfg.mlp_dropout_rate):
+            return "dropout active in training mode"
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
+        for hp in self.hook_dict.values():
+            if hp._forward_hooks or hp._backward_hooks:
+                return f"hook registered on {hp.name}"
+        for mod in self.modules():
+            if not isinstance(mod, HookPoint) and (mod._forward_hooks or mod._forward_pre_hooks):
+                return "nn.Module hooks registered"
+        return None
+
+    def _get_native(self, device: torch.device):
+        from .native_vit import NativeViT
+        nv = self._native
+        if nv is None or nv.device != device or nv.cfg.dtype != self.cfg.dtype:
+            nv = NativeViT(self.cfg, self.n_tokens, device)
+            nv.freeze_weights(getattr(self, "_native_frozen", False))
+            self._native = nv
+        return nv
+
+    def run_with_cache(self, *model_args, return_cache_object: bool = True, remove_batch_dim: bool = False,
+                       **kwargs) -> Tuple[torch.Tensor, Union[ActivationCache, Dict[str, torch.Tensor]]]:
+        """Same contract as base_vit.py:245-269 + hooked_root_module.py:255-287.  Pure caching
+        calls on a GPU run on the native HIP plan: every requested activation is written once by
+        the kernel that produces it into one HBM slab (no Python hook callbacks, no extra copies)."""
+        reason = "native_mode == 'off'" if self.native_mode == "off" else self._native_reason(model_args, kwargs)
+        if reason is None:
+            out, cache_dict = self._run_with_cache_native(model_args[0], remove_batch_dim, **kwargs)
+            self.last_run_native = True
+            self.native_fallback_reason = None
+        else:
+            if self.native_mode == "force":
+                raise _native.NativeError(f"native run_with_cache impossible: {reason}")
+            self.last_run_native = False
+            self.native_fallback_reason = reason
+            out, cache_dict = super().run_with_cache(*model_args, remove_batch_dim=remove_batch_dim, **kwargs)
+        if return_cache_object:
+            return out, ActivationCache(cache_dict, self, has_batch_dim=not remove_batch_dim)
+        return out, cache_dict
+
+    def _run_with_cache_native(self, x: torch.Tensor, remove_batch_dim: bool, names_filter=None, device=None,
+                               stop_at_layer: Optional[int] = None, **_ignored):
+        cfg = self.cfg
+        keep = names_filter_to_fn(names_filter)
+        run_head = stop_at_layer is None
+        n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
+        names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        nv = self._get_native(x.device)
+        return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
+                          remove_batch_dim=remove_batch_dim)
+
+    # ------------------------------------------------------------------------------ flag setters
+    def set_use_attn_result(self, use_attn_result: bool):
+        self.cfg.use_attn_result = use_attn_result
+
+    def set_use_split_qkv_input(self, use_split_qkv_input: bool):
+        self.cfg.use_split_qkv_input = use_split_qkv_input
+
+    def set_use_hook_mlp_in(self, use_hook_mlp_in: bool):
+        assert not self.cfg.attn_only, "Can't use hook_mlp_in with attn_only model"
+        self.cfg.use_hook_mlp_in = use_hook_mlp_in
+
+    def set_use_attn_in(self, use_attn_in: bool):
+        self.cfg.use_attn_in = use_attn_in
+
+    def check_hooks_to_add(self, hook_point, hook_point_name, hook, dir="fwd", is_permanent=False,
+                           prepend=False) -> None:
+        cfg = self.cfg
+        if hook_point_name.endswith("attn.hook_result"):
+            assert cfg.use_attn_result, f"Cannot add hook {hook_point_name} if use_attn_result_hook is False"
+        if hook_point_name.endswith(("hook_q_input", "hook_k_input", "hook_v_input")):
+            assert cfg.use_split_qkv_input, f"Cannot add hook {hook_point_name} if use_split_qkv_input is False"
+        if hook_point_name.endswith("mlp_in"):
+            assert cfg.use_hook_mlp_in, f"Cannot add hook {hook_point_name} if use_hook_mlp_in is False"
+        if hook_point_name.endswith("attn_in"):
+            assert cfg.use_attn_in, f"Cannot add hook {hook_point_name} if use_attn_in is False"
+
+    # ------------------------------------------------------------------------------ helpers
+    def cuda(self):
+        return self.to("cuda")
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def tokens_to_residual_directions(self, labels: torch.Tensor) -> torch.Tensor:
+        w = self.head.W_H[:, labels]
+        return w.movedim(0, -1)
+
+    def accumulated_bias(self, layer: int, mlp_input: bool = False, include_mlp_biases: bool = True) -> torch.Tensor:
+        bias = torch.zeros(self.cfg.d_model, device=self.cls_token.device)
+        for i in range(layer):
+            bias = bias + self.blocks[i].attn.b_O
+            if include_mlp_biases:
+                bias = bias + self.blocks[i].mlp.b_out
+        if mlp_input:
+            assert layer < self.cfg.n_layers, "Cannot include attn_bias from beyond the final layer"
+            bias = bias + self.blocks[layer].attn.b_O
+        return bias
+
+    def _stack(self, getter) -> torch.Tensor:
+        return torch.stack([getter(b) for b in self.blocks], dim=0)
+
+    W_E = property(lambda self: self.embed.proj.weight)
+    b_E = property(lambda self: self.embed.proj.bias)
+    W_pos = property(lambda self: self.pos_embed.W_pos)
+    W_K = property(lambda self: self._stack(lambda b: b.attn.W_K))
+    b_K = property(lambda self: self._stack(lambda b: b.attn.b_K))
+    W_Q = property(lambda self: self._stack(lambda b: b.attn.W_Q))
+    b_Q = property(lambda self: self._stack(lambda b: b.attn.b_Q))
+    W_V = property(lambda self: self._stack(lambda b: b.attn.W_V))
+    b_V = property(lambda self: self._stack(lambda b: b.attn.b_V))
+    W_O = property(lambda self: self._stack(lambda b: b.attn.W_O))
+    b_O = property(lambda self: self._stack(lambda b: b.attn.b_O))
+    W_in = property(lambda self: self._stack(lambda b: b.mlp.W_in))
+    b_in = property(lambda self: self._stack(lambda b: b.mlp.b_in))
+    W_out = property(lambda self: self._stack(lambda b: b.mlp.W_out))
+    b_out = property(lambda self: self._stack(lambda b: b.mlp.b_out))
+    W_H = property(lambda self: self.head.W_H)
+    b_H = property(lambda self: self.head.b_H)
+
+
+def _native_supported(cfg, n_tokens: int) -> Optional[str]:
+    from .native_vit import NativeViT
+    return NativeViT.supported(cfg, n_tokens)
