@@ -1,0 +1,203 @@
+"""bench.py -- headline measurement of the MI355X-native hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``HookedViT.run_with_cache`` pass (ALL hooks, 214 cache entries) of CLIP ViT-B/32
+@224 over one batch of 512 synthetic images per GPU, bf16 storage (BASELINE.json configs[1]),
+inputs already resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run)
+the image batches are sharded across ranks with no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line; ``value`` is the whole-job images/s.
+
+Extra objects on the same line:
+  roofline      dominant kernel (the MFMA GEMM family): algorithmic FLOPs per launch / average launch
+                duration measured with HIP events on the launch stream inside the timed region
+  kernels       the same live measurement for the other kernel families (attention, layernorm)
+  cpu_baseline  the oracle (numpy port of the reference algorithm, oracle/vit_oracle.py) timed on the
+                host cores for a bounded sample (rank 0, N == 1 only)
+  sae           SAE train-step tokens/s (BASELINE.json configs[2]; second half of the metric)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic work per image, CLIP ViT-B/32 all hooks (SURVEY.md 8d / DESIGN.md section 4)
+FLOP_PER_IMAGE_B32 = 8.818e9
+TAP_BYTES_PER_IMAGE_B32_BF16 = 20.34e6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sae", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float) -> dict:
+    """Oracle (port of the reference algorithm) on the host cores, same workload at bs=16
+    (images/s is flat in batch size on CPU)."""
+    from oracle.vit_oracle import vit_forward
+    from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state
+    arch = ARCHS["clip-vit-b32"]
+    sd = synth_vit_state(arch, 0)
+    imgs = synth_images(arch, 16, 1)
+    vit_forward(sd, arch, imgs)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        _, cache = vit_forward(sd, arch, imgs)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 64:
+            break
+    assert len(cache) == 214
+    return {"value": 16 * n / dt, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} x run_with_cache(all 214 hooks) of CLIP ViT-B/32 at bs=16, fp32 numpy oracle, "
+                      f"{dt:.1f} s on {os.cpu_count()} host threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from vit_prisma_amd import HookedViT, HookedViTConfig, _native as N
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    arch = ARCHS["clip-vit-b32"]
+    model = HookedViT(HookedViTConfig(**arch, dtype=dtype, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.to(dtype).to(dev).eval().use_native(True)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g).to(dtype)
+
+    def step():
+        out, cache = model.run_with_cache(images)
+        return out, cache
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out, cache = step()
+            n_keys = len(cache)
+            del out, cache
+        N.prof_reset()
+        N.prof_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out, cache = step()
+            del out, cache
+        barrier()
+        elapsed = time.perf_counter() - t0
+        N.prof_enable(False)
+    assert n_keys == 214 and model.last_run_native
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images_total = a.batch * a.steps * world
+    value = images_total / elapsed
+    ms_per_step = elapsed / a.steps * 1e3
+
+    gemm = N.prof_read("gemm")
+    attn = N.prof_read("attention")
+    ln = N.prof_read("layernorm")
+    peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+    gemm_tf = gemm["flops"] / max(gemm["ms"], 1e-9) / 1e9
+    roofline = {
+        "kernel": "gemm_kernel (MFMA GEMM + fused bias/GELU/residual/tap epilogue)",
+        "bound": "mfma", "achieved": round(gemm_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
+        "frac": round(gemm_tf / peak_tf, 4),
+        "launches": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),
+        "flops_per_launch": gemm["flops"] / max(gemm["launches"], 1),
+        "hbm_GBps_algorithmic": round(gemm["bytes"] / max(gemm["ms"], 1e-9) / 1e6, 1),
+        "share_of_step": round(gemm["ms"] / (ms_per_step * a.steps), 4),
+        "traffic": None,
+    }
+    kernels = {}
+    for nm, k in (("attention", attn), ("layernorm", ln)):
+        kernels[nm] = {
+            "bound": "hbm", "achieved": round(k["bytes"] / max(k["ms"], 1e-9) / 1e6, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(k["bytes"] / max(k["ms"], 1e-9) / 1e6 / PEAK_HBM_GBS, 4),
+            "launches": k["launches"], "avg_launch_us": round(k["ms"] * 1e3 / max(k["launches"], 1), 2),
+            "share_of_step": round(k["ms"] / (ms_per_step * a.steps), 4)}
+    per_gpu = value / world
+    whole = {
+        "flop_frac_of_mfma_peak": round(per_gpu * FLOP_PER_IMAGE_B32 / (peak_tf * 1e12), 4),
+        "tap_store_GBps": round(per_gpu * TAP_BYTES_PER_IMAGE_B32_BF16 * (1.0 if a.dtype == "bf16" else 36.68 / 20.34) / 1e9, 1),
+    }
+
+    line = {
+        "metric": "images/sec run_with_cache (all hooks) CLIP ViT-B/32 @224",
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic (randn images, seeded random weights in the converted CLIP layout)",
+        "config": {"workload": f"CLIP ViT-B/32 run_with_cache, all 214 hooks tapped to the HBM arena, "
+                               f"bs={a.batch}/GPU, {a.dtype}", "images_per_gpu_per_step": a.batch,
+                   "cache_keys": n_keys, "parallelism": f"image-batch sharding x{world}, no data-path collective"},
+        "roofline": roofline, "kernels": kernels, "whole_forward": whole,
+    }
+
+    if rank == 0 and world == 1 and not a.no_sae:
+        try:
+            from vit_prisma_amd.sae.bench_leg import sae_bench_leg
+            line["sae"] = sae_bench_leg(dev)
+        except ImportError:
+            line["sae"] = None
+    elif world > 1 and not a.no_sae:
+        try:
+            from vit_prisma_amd.sae.bench_leg import sae_bench_leg
+            sae = sae_bench_leg(dev, dist=dist)
+            if rank == 0:
+                line["sae"] = sae
+        except ImportError:
+            pass
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 3
+#define PV_ABI_VERSION 4
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -173,6 +173,14 @@ int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const void* Bt, int6
 int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t batch, int32_t R,
                          int32_t C, void* stream);
 
+/* Opt-in per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * kind: 0 GEMM, 1 attention, 2 layernorm/embed, 3 SAE encoder+topk, 4 SAE backward, 5 SAE apply, 6 misc.
+ * pv_prof_read synchronises the events and returns launch count, summed kernel milliseconds and the
+ * summed ALGORITHMIC flops / bytes of those launches. */
+int pv_prof_enable(int32_t on);
+int pv_prof_reset(void);
+int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------ */
 /* SAE training step (sae/sae.py:557-645 forward; sae/train_sae.py:278-411 step)                */
 /* ------------------------------------------------------------------------------------------ */
@@ -188,8 +196,11 @@ typedef struct pv_sae_desc {
  * moments and training statistics -- all caller-owned (torch tensors), fp32 unless stated. */
 typedef struct pv_sae_state {
     float *W_enc, *W_dec, *b_enc, *b_dec;          /* [d_in,d_sae] [d_sae,d_in] [d_sae] [d_in]   */
-    float *gW_enc, *gW_dec, *gb_enc, *gb_dec;      /* same shapes; ONE contiguous flat buffer is */
-                                                   /* recommended so a single all-reduce covers it */
+    float *gW_enc, *gW_dec, *gb_enc, *gb_dec;      /* gradients; gW_enc is stored TRANSPOSED,      */
+                                                   /* [d_sae, d_in] (coalesced sparse backward; the */
+                                                   /* Adam kernel transposes it back tile-wise).    */
+                                                   /* ONE contiguous flat buffer is recommended so  */
+                                                   /* a single all-reduce + one norm pass cover it  */
     float *mW_enc, *mW_dec, *mb_enc, *mb_dec;      /* Adam exp_avg                               */
     float *vW_enc, *vW_dec, *vb_enc, *vb_dec;      /* Adam exp_avg_sq                            */
     float *act_freq_scores;                        /* [d_sae]  train_sae.py:360                  */
@@ -201,7 +212,8 @@ typedef struct pv_sae_out {
     float* sae_out;        /* [N, d_in] reconstruction (after LN-out), may be NULL                */
     int32_t* topk_idx;     /* [N, k]   selected feature indices                                  */
     float* topk_val;       /* [N, k]   relu(hidden_pre) at those indices (feature_acts, sparse)   */
-    float* scalars;        /* [8]: 0 loss, 1 mse_loss, 2 l0, 3 grad_sqnorm(local, pre-clip), ...  */
+    float* scalars;        /* [8]: 0 loss, 1 mse_loss, 2 l0, 3 grad sum-of-squares (pre-clip)     */
+    float* fire_count;     /* [d_sae] tokens of this call on which each feature fired, or NULL     */
 } pv_sae_out;
 
 typedef struct pv_sae_plan pv_sae_plan;
@@ -221,9 +233,10 @@ int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_t
                 const float* batch_mean, int32_t n_global, int32_t update_stats, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);
 
-/* sum of squares of all four gradients -> scalars[3] (device), for clip_grad_norm_
- * (train_sae.py:394-397); called after the (optional) gradient all-reduce. */
-int pv_sae_grad_sqnorm(pv_sae_plan* plan, pv_sae_state* st, float* scalars, void* stream);
+/* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
+ * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.
+ * partial_1024: 1024 floats of scratch.  Deterministic two-stage reduction. */
+int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* partial_1024, float* scalars, void* stream);
 
 /* clip (coef from scalars[3] on device, max_norm <= 0 disables) -> remove gradient parallel to
  * decoder rows (sae.py:279-297) -> Adam(betas .9/.999, eps 1e-8, wd 0; train_sae.py:229) with

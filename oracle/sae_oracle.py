@@ -1,0 +1,152 @@
+"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of ViT-Prisma's top-k SAE
+forward, loss, backward and optimiser step.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
+
+Parity pin: the reference's own tests hold NO numeric golden vector for the SAE path (SURVEY.md
+section 4: "parity unpinned" by the reference), so this restatement is pinned against outputs of the
+reference itself executed in the build container -- ``tests/golden/gen_golden_sae.py`` drives the
+reference's real ``StandardSparseAutoencoder`` and ``VisionSAETrainer.train_step`` for three
+consecutive steps and dumps losses, gradients and post-step parameters
+(``tests/test_oracle_sae_vs_golden.py``).
+
+Citations are relative to /root/reference/src/vit_prisma/.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+Array = np.ndarray
+F32 = np.float32
+
+
+def ln_in(x: Array, eps: float = 1e-5) -> Tuple[Array, Array, Array]:
+    """sae/sae.py:78-87 -- mu = mean; x <- x - mu; std = x.std() (UNBIASED); x / (std + eps)."""
+    mu = x.mean(axis=-1, keepdims=True)
+    xc = x - mu
+    std = xc.std(axis=-1, keepdims=True, ddof=1)
+    return xc / (std + x.dtype.type(eps)), mu, std
+
+
+def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
+    """sae/sae.py:795-810 -- torch.topk(k) -> relu -> scatter into zeros.  Returns (idx [N,k] sorted by
+    value descending, vals [N,k] after relu)."""
+    part = np.argpartition(-hidden_pre, k - 1, axis=-1)[:, :k]
+    pv = np.take_along_axis(hidden_pre, part, axis=-1)
+    order = np.argsort(-pv, axis=-1, kind="stable")
+    idx = np.take_along_axis(part, order, axis=-1)
+    vals = np.maximum(np.take_along_axis(hidden_pre, idx, axis=-1), hidden_pre.dtype.type(0))
+    return idx, vals
+
+
+def sae_forward(P: Dict[str, Array], x: Array, k: int, layer_norm: bool = True, batch_mean: Optional[Array] = None,
+                n_global: Optional[int] = None) -> Dict[str, Array]:
+    """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
+    :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).
+
+    batch_mean / n_global: the data-parallel form -- mean_n(x) over the GLOBAL
+    batch and the global token count; default = this batch (single process, the reference)."""
+    dt = x.dtype.type
+    N, d = x.shape
+    if layer_norm:
+        xh, mu, std = ln_in(x)
+    else:
+        xh, mu, std = x, np.zeros((N, 1), x.dtype), np.ones((N, 1), x.dtype)
+    sae_in = xh - P["b_dec"]                                           # :563-565
+    hidden_pre = sae_in @ P["W_enc"] + P["b_enc"]                      # :567-574
+    idx, vals = topk_mask(hidden_pre, k)                               # :576
+    feats = np.zeros_like(hidden_pre)
+    np.put_along_axis(feats, idx, vals, axis=-1)
+    pre_out = feats @ P["W_dec"] + P["b_dec"]                          # :584-591
+    sae_out = pre_out * std + mu if layer_norm else pre_out            # :89-90 (no eps on the way out)
+    bm = x.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
+    nf = np.sqrt(((x - bm) ** 2).sum(axis=-1, keepdims=True))          # :145-147
+    ng = N if n_global is None else n_global
+    mse = ((sae_out - x) ** 2 / nf).sum() / dt(ng * d)                 # :146-148 (mean over N*d)
+    l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()            # train_sae.py:364
+    return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
+                mu=mu, std=std, norm_factor=nf, loss=dt(mse), mse_loss=dt(mse), l0=l0)
+
+
+def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True,
+                 n_global: Optional[int] = None) -> Dict[str, Array]:
+    """What ``loss.backward()`` (train_sae.py:392) deposits in the four ``.grad`` fields."""
+    dt = x.dtype.type
+    N, d = x.shape
+    ng = N if n_global is None else n_global
+    d_out = dt(2.0) * (fw["sae_out"] - x) / fw["norm_factor"] / dt(ng * d)
+    d_pre = d_out * fw["std"] if layer_norm else d_out
+    feats = fw["feature_acts"]
+    g = {}
+    g["W_dec"] = feats.T @ d_pre
+    d_feats = d_pre @ P["W_dec"].T
+    d_hidden = np.where(feats > 0, d_feats, dt(0))                    # topk scatter + ReLU gates
+    g["W_enc"] = fw["sae_in"].T @ d_hidden
+    g["b_enc"] = d_hidden.sum(axis=0)
+    d_sae_in = d_hidden @ P["W_enc"].T
+    g["b_dec"] = d_pre.sum(axis=0) - d_sae_in.sum(axis=0)             # decode bias + "sae_in = x_hat - b_dec"
+    return g
+
+
+def renorm_decoder(P: Dict[str, Array]) -> None:
+    """set_decoder_norm_to_unit_norm, sae/sae.py:275-277 (in place)."""
+    P["W_dec"] /= np.linalg.norm(P["W_dec"], axis=1, keepdims=True)
+
+
+def grad_total_norm(g: Dict[str, Array]) -> float:
+    return float(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g.values())))
+
+
+def clip_and_project(P: Dict[str, Array], g: Dict[str, Array], max_grad_norm: Optional[float]) -> float:
+    """clip_grad_norm_ over all four tensors (train_sae.py:394-397; coef = clamp(max/(norm+1e-6), max=1))
+    then remove_gradient_parallel_to_decoder_directions (sae/sae.py:279-297).  In place; returns the
+    pre-clip total norm."""
+    total = grad_total_norm(g)
+    if max_grad_norm:
+        coef = min(max_grad_norm / (total + 1e-6), 1.0)
+        for v in g.values():
+            v *= v.dtype.type(coef)
+    par = (g["W_dec"] * P["W_dec"]).sum(axis=1, keepdims=True)
+    g["W_dec"] -= par * P["W_dec"]
+    return total
+
+
+def adam_step(P: Dict[str, Array], g: Dict[str, Array], m: Dict[str, Array], v: Dict[str, Array], lr: float, step: int,
+              b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8) -> None:
+    """torch.optim.Adam(params, lr) defaults (train_sae.py:229): no weight decay, no amsgrad."""
+    bc1 = 1.0 - b1 ** step
+    bc2s = np.sqrt(1.0 - b2 ** step)
+    for key in P:
+        dt = P[key].dtype.type
+        m[key] += (g[key] - m[key]) * dt(1.0 - b1)
+        v[key] *= dt(b2)
+        v[key] += dt(1.0 - b2) * g[key] * g[key]
+        denom = np.sqrt(v[key]) / dt(bc2s) + dt(eps)
+        P[key] -= dt(lr / bc1) * (m[key] / denom)
+
+
+def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, lr_end: float) -> float:
+    """sae/training/get_scheduler.py:50-60 (``cosineannealingwarmup``; NB ``lr_end`` enters as a
+    *multiplier*, train_sae.py:236 passes cfg.lr / 10)."""
+    if step < warm_up_steps:
+        return (step + 1) / warm_up_steps
+    progress = (step - warm_up_steps) / (training_steps - warm_up_steps)
+    return lr_end + 0.5 * (1 - lr_end) * (1 + np.cos(np.pi * progress))
+
+
+def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: int, lr: float,
+               step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True) -> Dict[str, float]:
+    """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
+    firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count)."""
+    renorm_decoder(P)                                                   # :306-307
+    fw = sae_forward(P, x, k, layer_norm)
+    fired = (fw["feature_acts"] > 0).sum(axis=0)                        # :356-361
+    stats["n_fwd_since_fired"] += 1
+    stats["n_fwd_since_fired"][fired > 0] = 0
+    stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
+    g = sae_backward(P, x, fw, layer_norm)
+    total = clip_and_project(P, g, max_grad_norm)
+    adam_step(P, g, opt["m"], opt["v"], lr, step)
+    return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total)

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpvnative.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -67,7 +67,7 @@ class SaeState(C.Structure):
 
 class SaeOut(C.Structure):
     _fields_ = [("sae_out", C.c_void_p), ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p),
-                ("scalars", C.c_void_p)]
+                ("scalars", C.c_void_p), ("fire_count", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +77,7 @@ EXPORTS = [
     "pv_abi_version", "pv_last_error",
     "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
     "pv_vit_workspace_bytes", "pv_vit_forward", "pv_gemm_bias", "pv_transpose_batched",
+    "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_apply", "pv_sae_encode_topk",
 ]
@@ -112,6 +113,9 @@ def lib() -> C.CDLL:
     L.pv_vit_forward.argtypes = [vp, vp, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_gemm_bias.argtypes = [i32, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp]
     L.pv_transpose_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp]
+    L.pv_prof_enable.argtypes = [i32]
+    L.pv_prof_read.argtypes = [i32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]
     if hasattr(L, "pv_sae_plan_create"):
         L.pv_sae_plan_create.argtypes = [C.POINTER(SaeDesc), C.POINTER(vp)]
         L.pv_sae_plan_destroy.argtypes = [vp]
@@ -120,7 +124,7 @@ def lib() -> C.CDLL:
         L.pv_sae_workspace_bytes.restype = sz
         L.pv_sae_renorm_decoder.argtypes = [vp, C.POINTER(SaeState), vp]
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
-        L.pv_sae_grad_sqnorm.argtypes = [vp, C.POINTER(SaeState), vp, vp]
+        L.pv_sae_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
         L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, vp]
         L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]
     _lib = L
@@ -136,3 +140,22 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise NativeError(f"{what} failed (status {rc}): {last_error()}")
+
+
+PROF_KINDS = {"gemm": 0, "attention": 1, "layernorm": 2, "sae_encode_topk": 3, "sae_backward": 4,
+              "sae_apply": 5, "misc": 6}
+
+
+def prof_enable(on: bool = True) -> None:
+    lib().pv_prof_enable(int(on))
+
+
+def prof_reset() -> None:
+    lib().pv_prof_reset()
+
+
+def prof_read(kind: str) -> dict:
+    """{'launches', 'ms', 'flops', 'bytes'} of one kernel family since the last reset."""
+    n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    check(lib().pv_prof_read(PROF_KINDS[kind], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "pv_prof_read")
+    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}

@@ -15,6 +15,7 @@
 //   phase 3  z = P V on MFMA; bf16: V^T blocks staged through LDS so the B fragment is k-contiguous,
 //            fp32: V rows read directly (the f32 MFMA takes one float per lane)
 #include "attention.hpp"
+#include "prof.hpp"
 
 namespace {
 
@@ -224,7 +225,12 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         max_set = lds;
     }
     const dim3 grid((p.T + QB - 1) / QB, p.H, p.B), block(256);
-    hipLaunchKernelGGL((attn_kernel<T, QB, DH, MAXC>), grid, block, lds, stream, p);
+    {
+        const double bh = (double)p.B * p.H, tt = (double)p.T * p.T;
+        const double bytes = (4.0 * bh * p.T * DH + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * EB;
+        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * DH, bytes);
+        hipLaunchKernelGGL((attn_kernel<T, QB, DH, MAXC>), grid, block, lds, stream, p);
+    }
     PV_LAUNCH_CHECK("attn_kernel");
     return PV_OK;
 }

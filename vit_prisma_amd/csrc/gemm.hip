@@ -19,6 +19,7 @@
 //   blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (which share the A rows)
 //   are placed on the same XCD so the A slab is served from that XCD's L2.
 #include "gemm.hpp"
+#include "prof.hpp"
 
 namespace {
 
@@ -171,8 +172,11 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
     }
 }
 
-template <typename T, int AMODE, bool VEC>
+constexpr int BKN_ROW = 528;         // [K][N]-layout B tile: 128 floats + 16 pad bytes per k row
+
+template <typename T, int AMODE, bool VEC, bool BKN = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    static_assert(!BKN || sizeof(T) == 4, "[K][N] B operand is fp32 only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                      // [2][TILE_BYTES]
     unsigned char* Bs = smem + 2 * TILE_BYTES;     // [2][TILE_BYTES]
@@ -205,7 +209,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             const int row = c >> 3, kc = c & 7;
             const int kb = kt * SLAB + kc * 16;
             ra[i] = Loader<T, AMODE, VEC>::load_a(p, m0 + row, kb);
-            rb[i] = Loader<T, AMODE, VEC>::load_b(p, n0 + row, kb);
+            if constexpr (BKN) {
+                // B[k][n]: chunk c -> k row c >> 5 (32 per slab), 4-float column group c & 31
+                const int krow = kt * 32 + (c >> 5), nn = n0 + (c & 31) * 4;
+                rb[i] = (krow < p.K && nn < p.N)
+                            ? *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.Bt) + (int64_t)krow * p.ldb + nn)
+                            : make_uint4(0, 0, 0, 0);
+            } else {
+                rb[i] = Loader<T, AMODE, VEC>::load_b(p, n0 + row, kb);
+            }
         }
     };
     auto store_slab = [&](int buf) {
@@ -214,7 +226,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             const int c = tid + 256 * i;
             const int row = c >> 3, kc = c & 7;
             *reinterpret_cast<uint4*>(As + buf * TILE_BYTES + row * ROWB + kc * 16) = ra[i];
-            *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + row * ROWB + kc * 16) = rb[i];
+            if constexpr (BKN)
+                *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + (c >> 5) * BKN_ROW + (c & 31) * 16) = rb[i];
+            else
+                *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + row * ROWB + kc * 16) = rb[i];
         }
     };
 
@@ -243,8 +258,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             uint4 a[2], b[2];
             a[0] = *reinterpret_cast<const uint4*>(Ab + a_off + j * 32);
             a[1] = *reinterpret_cast<const uint4*>(Ab + a_off + 32 * ROWB + j * 32);
-            b[0] = *reinterpret_cast<const uint4*>(Bb + b_off + j * 32);
-            b[1] = *reinterpret_cast<const uint4*>(Bb + b_off + 32 * ROWB + j * 32);
+            if constexpr (BKN) {
+                // MFMA step (j, e) consumes k = 8 j + 4 (lane >> 5) + e on the A side; fetch the same k
+                const float* bk = reinterpret_cast<const float*>(Bb + (8 * j + 4 * (lane >> 5)) * BKN_ROW) + wn * 64 + (lane & 31);
+                b[0] = make_uint4(__float_as_uint(bk[0]), __float_as_uint(bk[BKN_ROW / 4]),
+                                  __float_as_uint(bk[2 * (BKN_ROW / 4)]), __float_as_uint(bk[3 * (BKN_ROW / 4)]));
+                b[1] = make_uint4(__float_as_uint(bk[32]), __float_as_uint(bk[BKN_ROW / 4 + 32]),
+                                  __float_as_uint(bk[2 * (BKN_ROW / 4) + 32]), __float_as_uint(bk[3 * (BKN_ROW / 4) + 32]));
+            } else {
+                b[0] = *reinterpret_cast<const uint4*>(Bb + b_off + j * 32);
+                b[1] = *reinterpret_cast<const uint4*>(Bb + b_off + 32 * ROWB + j * 32);
+            }
             if constexpr (EB == 2) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
@@ -306,16 +330,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int AMODE, bool VEC>
+template <typename T, int AMODE, bool VEC, bool BKN = false>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     static bool attr_done = false;
     if (!attr_done) {
-        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AMODE, VEC>),
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, AMODE, VEC, BKN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, AMODE, VEC>), dim3(ntm * ntn), dim3(256), GEMM_LDS, stream, p);
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;                                   // BIAS / QKV: one M x N store
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);   // resid read + out1 (+ tap)
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel<T, AMODE, VEC, BKN>), dim3(ntm * ntn), dim3(256), GEMM_LDS, stream, p);
+    }
     PV_LAUNCH_CHECK("gemm_kernel");
     return PV_OK;
 }
@@ -353,6 +385,13 @@ int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     if (p.epi == PV_EPI_QKV) PV_REQUIRE(p.out0 && p.out1 && p.out2 && p.nsplit > 0 && p.N == 3 * p.nsplit, "EPI_QKV outputs");
     if (p.epi == PV_EPI_RESID) PV_REQUIRE(p.out1 && p.resid, "EPI_RESID needs out1 and resid");
     if (p.epi == PV_EPI_ACT) PV_REQUIRE(p.out1, "EPI_ACT needs out1");
+    if (p.b_kn) {
+        PV_REQUIRE(dtype == PV_DTYPE_F32 && p.a_mode == PV_A_PLAIN, "[K][N] B operand: fp32, plain A only");
+        PV_REQUIRE(p.N % 4 == 0 && p.ldb % 4 == 0 && pv_aligned16(p.Bt), "[K][N] B operand alignment");
+        PV_REQUIRE(((int64_t)p.K * 4) % 16 == 0 && (p.lda * 4) % 16 == 0 && pv_aligned16(p.A), "[K][N] path needs 16-byte aligned A rows");
+        p.vec_out = ((p.ldo * 4) % 16 == 0 && pv_aligned16(p.out0) && pv_aligned16(p.out1) && pv_aligned16(p.bias0)) ? 1 : 0;
+        return launch<float, PV_A_PLAIN, true, true>(p, stream);
+    }
     if (dtype == PV_DTYPE_BF16) return dispatch<bf16_t>(p, stream);
     if (dtype == PV_DTYPE_F32) return dispatch<float>(p, stream);
     pv_set_error("gemm: unsupported dtype");

@@ -16,6 +16,7 @@ struct GemmParams {
     // B operand, [N][K] K-contiguous ("Bt")
     const void* Bt;
     int64_t ldb;             // elements
+    int32_t b_kn;            // 1: B is given as [K][N] row-major (N-contiguous), fp32 only (SAE W_enc)
     int32_t M, N, K;
     // epilogue
     int32_t epi;             // PV_EPI_*

@@ -1,0 +1,67 @@
+#include "prof.hpp"
+
+#include <vector>
+
+namespace {
+struct Pool {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+    double flops = 0, bytes = 0;
+};
+Pool g_pool[PV_PROF__COUNT];
+bool g_on = false;
+constexpr size_t kMaxEvents = 16384;
+}  // namespace
+
+bool pv_prof_on() { return g_on; }
+
+int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes) {
+    Pool& p = g_pool[kind];
+    if (p.used >= kMaxEvents) return -1;
+    if (p.used >= p.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        p.start.push_back(a);
+        p.stop.push_back(b);
+    }
+    const int tok = (int)p.used++;
+    p.flops += flops;
+    p.bytes += bytes;
+    (void)hipEventRecord(p.start[tok], stream);
+    return tok;
+}
+
+void pv_prof_end(int kind, int token, hipStream_t stream) { (void)hipEventRecord(g_pool[kind].stop[token], stream); }
+
+extern "C" int pv_prof_enable(int32_t on) {
+    g_on = on != 0;
+    return PV_OK;
+}
+
+extern "C" int pv_prof_reset(void) {
+    for (auto& p : g_pool) {
+        p.used = 0;
+        p.flops = 0;
+        p.bytes = 0;
+    }
+    return PV_OK;
+}
+
+// Synchronises the recorded events of `kind` and returns launches, summed kernel time (ms) and the
+// summed algorithmic flops / bytes the launchers declared.
+extern "C" int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+    PV_REQUIRE(kind >= 0 && kind < PV_PROF__COUNT, "profile kind");
+    Pool& p = g_pool[kind];
+    double ms = 0;
+    for (size_t i = 0; i < p.used; ++i) {
+        PV_HIP_CHECK(hipEventSynchronize(p.stop[i]));
+        float t = 0;
+        PV_HIP_CHECK(hipEventElapsedTime(&t, p.start[i], p.stop[i]));
+        ms += t;
+    }
+    if (launches) *launches = (int64_t)p.used;
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = p.flops;
+    if (bytes) *bytes = p.bytes;
+    return PV_OK;
+}

@@ -2,6 +2,7 @@
 // batched transpose (weight shadow packing).  One 64-lane wave owns one row; 16-byte vector
 // loads/stores; every tensor is read once and every requested tap written once.
 #include "rowops.hpp"
+#include "prof.hpp"
 
 namespace {
 
@@ -122,6 +123,11 @@ int pv_launch_ln(int dtype, const LnParams& p, hipStream_t stream) {
     PV_REQUIRE(p.rows > 0, "layernorm rows");
     if (!p.embed) PV_REQUIRE(p.ldx % 8 == 0, "layernorm row stride must be a multiple of 8");
     const dim3 grid((p.rows + 3) / 4), block(256);
+    const double eb = dtype == PV_DTYPE_BF16 ? 2.0 : 4.0;
+    const double rd = (double)p.rows * p.d;
+    ProfScope prof(PV_PROF_LN, stream, 8.0 * rd,
+                   rd * eb * (1.0 + (p.out ? 1.0 : 0.0) + (p.full_out ? 1.0 : 0.0)) + (p.norm_f32_out ? 4.0 * rd : 0.0) +
+                       (p.scale_out ? 4.0 * p.rows : 0.0));
     if (dtype == PV_DTYPE_BF16) {
         if (p.embed) hipLaunchKernelGGL((ln_kernel<bf16_t, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((ln_kernel<bf16_t, false>), grid, block, 0, stream, p);

@@ -1,0 +1,749 @@
+// SAE training step for gfx950 (C ABI: pv_sae_* in include/pv_native.h).
+//
+// Reference semantics: StandardSparseAutoencoder.forward (/root/reference/src/vit_prisma/sae/sae.py:
+// 557-645), TopK (:795-810), _compute_mse_loss (:144-149), run-time LayerNorm of the input (:78-93),
+// and VisionSAETrainer.train_step (sae/train_sae.py:278-411).  fp32 throughout (the reference's SAE
+// config has no bf16, sae/config.py:14-45).
+//
+// Data flow of one step on N tokens (k-sparse everywhere after the encoder):
+//   prep        x -> mu, std (unbiased), x_hat = (x - mu)/(std + eps), sae_in = x_hat - b_dec,
+//               norm_n = ||x_n - mean_batch(x)||_2                                    (one wave / token)
+//   encode      hidden_pre = sae_in @ W_enc + b_enc      fp32 MFMA GEMM, W_enc read in its own [K][N] layout
+//   topk        exact per-row radix select of the k largest -> (idx, relu(val))       (one workgroup / token)
+//   decode      sae_out = (sum_s val_s W_dec[idx_s] + b_dec) * std + mu ; err ; loss partials ;
+//               dY = 2 err std / (norm N_glob d_in) ; dh_s = dY . W_dec[idx_s]        (one wave / token)
+//   csr         active (token, slot) pairs grouped by feature: count -> scan -> fill
+//   backward    per feature j: gW_dec[j,:] = sum a dY[n,:] ; gW_encT[j,:] = sum g sae_in[n,:] ; gb_enc[j] = sum g
+//               (rows of both gradients are written coalesced; W_enc's gradient is kept TRANSPOSED,
+//               [d_sae][d_in], and transposed back tile-wise inside the Adam kernel)
+//   bias grads  gb_dec = colsum(dY) - W_enc @ gb_enc   (the encoder-input path of b_dec, folded into a GEMV)
+//   apply       clip coefficient -> remove component parallel to decoder rows -> Adam, fused per tensor
+#include <math.h>
+
+#include "gemm.hpp"
+#include "prof.hpp"
+
+namespace {
+
+constexpr int MAXK = 64;
+
+// ------------------------------------------------------------------------------------------------
+// generic helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// column sums of a [rows][d] fp32 matrix, stage 1: partial[blk][c] over 64-row blocks
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                             int rows, int d) {
+    const int r0 = blockIdx.x * 64;
+    const int r1 = min(r0 + 64, rows);
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += x[(int64_t)r * d + c];
+        partial[(int64_t)blockIdx.x * d + c] = s;
+    }
+}
+// stage 2: out[c] = scale * sum_blk partial[blk][c]  (+ add[c] if given)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nblk, int d, float scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * d + c];
+    out[c] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: LN-in (sae.py:78-87), sae_in (sae.py:563-565), loss normaliser (sae.py:145-147)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
+                                                       const float* __restrict__ batch_mean, float* __restrict__ sae_in,
+                                                       float* __restrict__ mu_out, float* __restrict__ std_out,
+                                                       float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    const float* xr = x + (int64_t)n * d;
+    float s = 0.f, cn = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float v = xr[i];
+        s += v;
+        const float c = v - batch_mean[i];
+        cn += c * c;
+    }
+    const float mu = use_ln ? wave_sum(s) / (float)d : 0.f;
+    cn = wave_sum(cn);
+    float sq = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float c = xr[i] - mu;
+        sq += c * c;
+    }
+    // torch.std: unbiased (divide by d - 1)
+    const float sd = use_ln ? sqrtf(wave_sum(sq) / (float)(d - 1)) : 1.f;
+    for (int i = lane; i < d; i += 64) {
+        const float xh = use_ln ? (xr[i] - mu) / (sd + eps) : xr[i];
+        sae_in[(int64_t)n * d + i] = xh - b_dec[i];
+    }
+    if (lane == 0) {
+        mu_out[n] = mu;
+        std_out[n] = sd;
+        norm_out[n] = sqrtf(cn);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact top-k per row by radix select on the order-preserving uint image of the floats
+// (TopK.forward, sae.py:795-810: torch.topk -> relu -> scatter; only the selected SET matters)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int PER>   // values per thread: d_sae <= 256 * PER
+__global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__ hidden, int32_t* __restrict__ idx_out,
+                                                       float* __restrict__ val_out, int d_sae, int k) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_k, sh_wcnt[4], sh_eqcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const float* h = hidden + row * d_sae;
+    uint32_t key[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        key[i] = (c < d_sae) ? f2ord(h[c]) : 0u;        // 0 sorts below every real float
+    }
+    uint32_t prefix = 0, kk = (uint32_t)k;
+    // MSB-first radix select: after the 4 passes `prefix` is the k-th largest key
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if ((key[i] & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key[i] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            int dsel = 0;
+            for (int dgt = 255; dgt >= 0; --dgt) {
+                if (acc + hist[dgt] >= kk) { dsel = dgt; break; }
+                acc += hist[dgt];
+            }
+            sh_prefix = prefix | ((uint32_t)dsel << shift);
+            sh_k = kk - acc;
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        kk = sh_k;
+        __syncthreads();
+    }
+    // kk = how many elements EQUAL to the threshold are taken (ties: lowest (thread, slot) order first)
+    uint32_t ngt = 0, neq = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        ngt += key[i] > prefix;
+        neq += key[i] == prefix;
+    }
+    // exclusive scans over threads of (ngt) and (neq) -> deterministic output slots
+    uint32_t inc_gt = ngt, inc_eq = neq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc_gt, o, 64), b = __shfl_up(inc_eq, o, 64);
+        if (lane >= o) { inc_gt += a; inc_eq += b; }
+    }
+    if (lane == 63) { sh_wcnt[wave] = inc_gt; sh_eqcnt[wave] = inc_eq; }
+    __syncthreads();
+    uint32_t base_gt = 0, base_eq = 0, tot_gt = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) { base_gt += sh_wcnt[w]; base_eq += sh_eqcnt[w]; }
+        tot_gt += sh_wcnt[w];
+    }
+    uint32_t pos_gt = base_gt + inc_gt - ngt;     // exclusive
+    uint32_t pos_eq = base_eq + inc_eq - neq;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        int slot = -1;
+        if (key[i] > prefix) slot = (int)pos_gt++;
+        else if (key[i] == prefix) { if (pos_eq < kk) slot = (int)(tot_gt + pos_eq); pos_eq++; }
+        if (slot >= 0 && slot < k) {
+            idx_out[row * k + slot] = c;
+            val_out[row * k + slot] = fmaxf(h[c], 0.f);      // postact_fn = ReLU (sae.py:806)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode + LN-out + loss partial + dY + dh    (one wave per token)
+// ------------------------------------------------------------------------------------------------
+template <int DPL>   // dims per lane: d_in <= 64 * DPL
+__global__ __launch_bounds__(256) void sae_decode_kernel(
+    const float* __restrict__ x, const float* __restrict__ W_dec, const float* __restrict__ b_dec,
+    const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ mu,
+    const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out,
+    float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
+    float grad_scale /* 2 / (N_global * d_in) */, int want_grad) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    float acc[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        acc[i] = 0.f;
+        (void)c;
+    }
+    const int32_t* ir = idx + (int64_t)n * k;
+    const float* vr = val + (int64_t)n * k;
+    for (int s = 0; s < k; ++s) {
+        const float a = vr[s];
+        const float* w = W_dec + (int64_t)ir[s] * d;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) acc[i] += a * w[c];
+        }
+    }
+    const float m = mu[n], sdv = sd[n], nf = norm[n];
+    float lsum = 0.f;
+    float g[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        g[i] = 0.f;
+        if (c < d) {
+            const float o = (acc[i] + b_dec[c]) * sdv + m;        // decode (sae.py:583-595) + LN-out (:89-90)
+            const float e = o - x[(int64_t)n * d + c];
+            if (sae_out) sae_out[(int64_t)n * d + c] = o;
+            lsum += (e * e) / nf;                                 // sae.py:146-148
+            g[i] = grad_scale * e / nf * sdv;                     // dL/d(pre-LN-out reconstruction)
+            if (want_grad) dY[(int64_t)n * d + c] = g[i];
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) loss_partial[n] = lsum;
+    if (!want_grad) return;
+    for (int s = 0; s < k; ++s) {
+        const float* w = W_dec + (int64_t)ir[s] * d;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) dot += g[i] * w[c];
+        }
+        dot = wave_sum(dot);
+        // TopK backward: gradient reaches only selected entries; ReLU gate on the kept value
+        if (lane == 0) dh[(int64_t)n * k + s] = vr[s] > 0.f ? dot : 0.f;
+    }
+}
+
+// deterministic scalar reduction: out[slot] = scale * sum(v[0..n))
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ v, float* __restrict__ out, int n,
+                                                         float scale, int slot) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[slot] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR by feature of the active (token, slot) pairs
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                        uint32_t* __restrict__ cnt, int n_pairs) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n_pairs && val[p] > 0.f) atomicAdd(&cnt[idx[p]], 1u);
+}
+// single-workgroup exclusive scan over d_sae counts (d_sae ~ 25k: 96 per thread)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
+                                                        uint32_t* __restrict__ cursor, int d_sae) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (d_sae + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, d_sae);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t a = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += a;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+        offs[i] = run;
+        cursor[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) offs[d_sae] = part[1023];
+}
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                       uint32_t* __restrict__ cursor, int32_t* __restrict__ pairs, int n_pairs) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n_pairs && val[p] > 0.f) pairs[atomicAdd(&cursor[idx[p]], 1u)] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse backward, one wave per feature (writes EVERY row: doubles as zero_grad)
+// ------------------------------------------------------------------------------------------------
+template <int DPL>
+__global__ __launch_bounds__(256) void sae_backward_kernel(
+    const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs, const float* __restrict__ val,
+    const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in,
+    float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+    float* __restrict__ act_freq, float* __restrict__ n_since_fired, float* __restrict__ fire_count, int d_sae, int d, int k,
+    int update_stats) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= d_sae) return;
+    const uint32_t lo = offs[j], hi = offs[j + 1];
+    const int cnt = (int)(hi - lo);
+    float gd[DPL], ge[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) { gd[i] = 0.f; ge[i] = 0.f; }
+    float gb = 0.f;
+    for (uint32_t q = lo; q < hi; ++q) {
+        const int32_t p = pairs[q];
+        const int n = p / k;
+        const float a = val[p], g = dh[p];
+        const float* dy = dY + (int64_t)n * d;
+        const float* si = sae_in + (int64_t)n * d;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) {
+                gd[i] += a * dy[c];       // d loss / d W_dec[j, c]
+                ge[i] += g * si[c];       // d loss / d W_enc[c, j]
+            }
+        }
+        gb += g;
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) {
+            gW_dec[(int64_t)j * d + c] = gd[i];
+            gW_encT[(int64_t)j * d + c] = ge[i];
+        }
+    }
+    if (lane == 0) {
+        gb_enc[j] = gb;
+        if (fire_count) fire_count[j] = (float)cnt;
+        if (update_stats) {
+            // train_sae.py:356-361
+            act_freq[j] += (float)cnt;
+            n_since_fired[j] = cnt > 0 ? 0.f : n_since_fired[j] + 1.f;
+        }
+    }
+}
+
+// gb_dec[i] = colsum(dY)[i] - sum_j W_enc[i][j] gb_enc[j]     (one workgroup per input dim i)
+__global__ __launch_bounds__(256) void sae_gbdec_kernel(const float* __restrict__ W_enc, const float* __restrict__ gb_enc,
+                                                        const float* __restrict__ dy_colsum, float* __restrict__ gb_dec,
+                                                        int d_sae) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    const float* w = W_enc + (int64_t)i * d_sae;
+    float s = 0.f;
+    for (int j = threadIdx.x * 4; j < d_sae; j += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(w + j);
+        const float4 b = *reinterpret_cast<const float4*>(gb_enc + j);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) gb_dec[i] = dy_colsum[i] - s;
+}
+
+// l0 = mean_n count(val > 0)   (train_sae.py:364)
+__global__ __launch_bounds__(256) void sae_l0_kernel(const float* __restrict__ val, float* __restrict__ scalars, int n_pairs,
+                                                     float inv_tokens) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n_pairs; i += 256) s += val[i] > 0.f ? 1.f : 0.f;
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) scalars[2] = s * inv_tokens;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient square-norm (two stage, deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(g + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        } else {
+            for (int64_t t = i; t < n; ++t) s += g[t] * g[t];
+        }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply: clip -> project -> Adam  (train_sae.py:394-401; sae.py:279-297; torch.optim.Adam defaults)
+// ------------------------------------------------------------------------------------------------
+struct AdamC {
+    float lr, b1, b2, eps, bc1, bc2_sqrt, max_norm;
+};
+__device__ __forceinline__ float clip_coef(const float* scalars, float max_norm) {
+    if (max_norm <= 0.f) return 1.f;
+    const float total = sqrtf(scalars[3]);
+    return fminf(max_norm / (total + 1e-6f), 1.f);          // clip_grad_norm_: clamp(max_norm/(norm+1e-6), max=1)
+}
+__device__ __forceinline__ float adam_update(float w, float g, float& m, float& v, const AdamC& c) {
+    m = m + (g - m) * (1.f - c.b1);                         // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * c.b2 + (1.f - c.b2) * g * g;                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    return w - (c.lr / c.bc1) * (m / denom);
+}
+
+template <int DPL>   // W_dec rows: one wave per row, with the parallel-gradient projection
+__global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, const float* __restrict__ G,
+                                                        float* __restrict__ M, float* __restrict__ V,
+                                                        const float* __restrict__ scalars, AdamC c, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    const float coef = clip_coef(scalars, c.max_norm);
+    float w[DPL], g[DPL];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int col = lane + 64 * i;
+        w[i] = g[i] = 0.f;
+        if (col < d) {
+            w[i] = W[(int64_t)j * d + col];
+            g[i] = G[(int64_t)j * d + col] * coef;
+            dot += g[i] * w[i];
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int col = lane + 64 * i;
+        if (col < d) {
+            const int64_t o = (int64_t)j * d + col;
+            const float gp = g[i] - dot * w[i];             // remove_gradient_parallel_to_decoder_directions
+            float m = M[o], v = V[o];
+            W[o] = adam_update(w[i], gp, m, v, c);
+            M[o] = m;
+            V[o] = v;
+        }
+    }
+}
+
+// W_enc [d_in][d_sae] with its gradient stored transposed [d_sae][d_in]: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void adam_wenc_kernel(float* __restrict__ W, const float* __restrict__ GT,
+                                                        float* __restrict__ M, float* __restrict__ V,
+                                                        const float* __restrict__ scalars, AdamC c, int d_in, int d_sae) {
+    __shared__ float tile[32][33];
+    const float coef = clip_coef(scalars, c.max_norm);
+    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + 8 * r, i = i0 + tx;
+        tile[ty + 8 * r][tx] = (j < d_sae && i < d_in) ? GT[(int64_t)j * d_in + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < d_in && j < d_sae) {
+            const int64_t o = (int64_t)i * d_sae + j;
+            float m = M[o], v = V[o];
+            W[o] = adam_update(W[o], tile[tx][ty + 8 * r] * coef, m, v, c);
+            M[o] = m;
+            V[o] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, const float* __restrict__ G,
+                                                       float* __restrict__ M, float* __restrict__ V,
+                                                       const float* __restrict__ scalars, AdamC c, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float coef = clip_coef(scalars, c.max_norm);
+    float m = M[i], v = V[i];
+    W[i] = adam_update(W[i], G[i] * coef, m, v, c);
+    M[i] = m;
+    V[i] = v;
+}
+
+// set_decoder_norm_to_unit_norm (sae.py:275-277)
+template <int DPL>
+__global__ __launch_bounds__(256) void renorm_rows_kernel(float* __restrict__ W, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    float w[DPL];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        w[i] = c < d ? W[(int64_t)j * d + c] : 0.f;
+        sq += w[i] * w[i];
+    }
+    const float nrm = sqrtf(wave_sum(sq));
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) W[(int64_t)j * d + c] = w[i] / nrm;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// plan + C ABI
+// ------------------------------------------------------------------------------------------------
+struct pv_sae_plan {
+    pv_sae_desc d;
+};
+
+namespace {
+struct SaeWs {
+    size_t total;
+    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, pairs, colpart, colsum, batch_mean, sqpart;
+    int nblk64, sq_blocks;
+};
+SaeWs sae_carve(const pv_sae_desc& d) {
+    SaeWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    const size_t N = d.max_tokens;
+    w.nblk64 = (int)((N + 63) / 64);
+    w.sq_blocks = 1024;
+    w.hidden = take(N * (size_t)d.d_sae * 4);
+    w.sae_in = take(N * (size_t)d.d_in * 4);
+    w.dY = take(N * (size_t)d.d_in * 4);
+    w.mu = take(N * 4);
+    w.sd = take(N * 4);
+    w.norm = take(N * 4);
+    w.dh = take(N * (size_t)d.k * 4);
+    w.loss_part = take(N * 4);
+    w.cnt = take((size_t)d.d_sae * 4);
+    w.offs = take(((size_t)d.d_sae + 1) * 4);
+    w.cursor = take((size_t)d.d_sae * 4);
+    w.pairs = take(N * (size_t)d.k * 4);
+    w.colpart = take((size_t)w.nblk64 * d.d_in * 4);
+    w.colsum = take((size_t)d.d_in * 4);
+    w.batch_mean = take((size_t)d.d_in * 4);
+    w.sqpart = take((size_t)w.sq_blocks * 4);
+    w.total = off + 256;
+    return w;
+}
+}  // namespace
+
+extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan) {
+    PV_REQUIRE(desc && out_plan, "null argument");
+    PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 16 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1024");
+    PV_REQUIRE(desc->d_sae >= desc->k && desc->d_sae % 4 == 0 && desc->d_sae <= 256 * 128, "d_sae must be a multiple of 4, <= 32768");
+    PV_REQUIRE(desc->k >= 1 && desc->k <= MAXK, "k must be in [1, 64]");
+    PV_REQUIRE(desc->max_tokens >= 1, "max_tokens");
+    pv_sae_plan* p = new pv_sae_plan();
+    p->d = *desc;
+    *out_plan = p;
+    return PV_OK;
+}
+extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) { delete plan; }
+extern "C" size_t pv_sae_workspace_bytes(const pv_sae_plan* plan) { return plan ? sae_carve(plan->d).total : 0; }
+
+#define DPL_DISPATCH(d_in, CALL)            \
+    do {                                    \
+        if ((d_in) <= 64 * 4) { CALL(4); }  \
+        else if ((d_in) <= 64 * 12) { CALL(12); } \
+        else { CALL(16); }                  \
+    } while (0)
+
+extern "C" int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream_) {
+    PV_REQUIRE(plan && st && st->W_dec, "null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const pv_sae_desc& d = plan->d;
+    const dim3 grid((d.d_sae + 3) / 4), block(256);
+#define CALL(D) hipLaunchKernelGGL((renorm_rows_kernel<D>), grid, block, 0, stream, st->W_dec, d.d_sae, d.d_in)
+    DPL_DISPATCH(d.d_in, CALL);
+#undef CALL
+    PV_LAUNCH_CHECK("renorm_rows_kernel");
+    return PV_OK;
+}
+
+static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
+                           int32_t* topk_idx, float* topk_val, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+    const pv_sae_desc& d = plan->d;
+    float* bmean = (float*)(wsb + ws.batch_mean);
+    if (batch_mean) {
+        PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
+    } else {
+        const int nblk = (N + 63) / 64;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, (float*)(wsb + ws.colpart), N, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 255) / 256), dim3(256), 0, stream,
+                           (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
+    }
+    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, st->b_dec, bmean,
+                       (float*)(wsb + ws.sae_in), (float*)(wsb + ws.mu), (float*)(wsb + ws.sd), (float*)(wsb + ws.norm), N,
+                       d.d_in, d.normalize_layer_norm, d.ln_eps);
+    PV_LAUNCH_CHECK("sae_prep_kernel");
+    {
+        // hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574); W_enc consumed in its own [d_in][d_sae] layout
+        ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
+                       ((double)N * d.d_in + (double)d.d_in * d.d_sae + (double)N * d.d_sae) * 4.0);
+        GemmParams g = {};
+        g.A = wsb + ws.sae_in; g.lda = d.d_in; g.a_mode = PV_A_PLAIN; g.Bt = st->W_enc; g.ldb = d.d_sae; g.b_kn = 1;
+        g.M = N; g.N = d.d_sae; g.K = d.d_in; g.epi = PV_EPI_BIAS; g.bias0 = st->b_enc; g.out0 = wsb + ws.hidden; g.ldo = d.d_sae;
+        int rc = pv_launch_gemm(PV_DTYPE_F32, g, stream);
+        if (rc) return rc;
+        const float* hid = (const float*)(wsb + ws.hidden);
+        const int per = (d.d_sae + 255) / 256;
+        if (per <= 8) hipLaunchKernelGGL((sae_topk_kernel<8>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+        else if (per <= 32) hipLaunchKernelGGL((sae_topk_kernel<32>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+        else if (per <= 96) hipLaunchKernelGGL((sae_topk_kernel<96>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+        else hipLaunchKernelGGL((sae_topk_kernel<128>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+    }
+    PV_LAUNCH_CHECK("sae_topk_kernel");
+    return PV_OK;
+}
+
+extern "C" int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t N,
+                                  int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(plan && st && x && topk_idx && topk_val && workspace, "null argument");
+    PV_REQUIRE(N >= 1 && N <= plan->d.max_tokens, "n_tokens exceeds plan max_tokens");
+    const SaeWs ws = sae_carve(plan->d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    int rc = sae_encode_topk(plan, st, x, N, nullptr, topk_idx, topk_val, wsb, ws, stream);
+    if (rc) return rc;
+    if (ln_mu) PV_HIP_CHECK(hipMemcpyAsync(ln_mu, wsb + ws.mu, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
+    if (ln_std) PV_HIP_CHECK(hipMemcpyAsync(ln_std, wsb + ws.sd, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
+    return PV_OK;
+}
+
+extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                           int32_t n_global, int32_t update_stats, pv_sae_out* out, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(plan && st && x && out && workspace, "null argument");
+    PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
+    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    const int k = d.k, n_pairs = N * k;
+
+    int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, wsb, ws, stream);
+    if (rc) return rc;
+
+    float* dY = (float*)(wsb + ws.dY);
+    float* dh = (float*)(wsb + ws.dh);
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
+        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        const dim3 grid((N + 3) / 4), block(256);
+#define CALL(D)                                                                                                      \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
+                       (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)(wsb + ws.mu),      \
+                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, dh,             \
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1)
+        DPL_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel");
+        // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
+                           1.0f / ((float)n_global * (float)d.d_in), 1);
+        hipLaunchKernelGGL(sae_l0_kernel, dim3(1), dim3(256), 0, stream, (const float*)out->topk_val, out->scalars, n_pairs,
+                           1.0f / (float)N);
+        // CSR by feature
+        uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
+        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
+        uint32_t* cursor = (uint32_t*)(wsb + ws.cursor);
+        int32_t* pairs = (int32_t*)(wsb + ws.pairs);
+        PV_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)d.d_sae * 4, stream));
+        hipLaunchKernelGGL(csr_count_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
+                           (const float*)out->topk_val, cnt, n_pairs);
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, cursor, d.d_sae);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
+                           (const float*)out->topk_val, cursor, pairs, n_pairs);
+        PV_LAUNCH_CHECK("csr kernels");
+        const dim3 gridf((d.d_sae + 3) / 4);
+#define CALL(D)                                                                                                        \
+    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, pairs,                \
+                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, st->gW_dec, \
+                       st->gW_enc, st->gb_enc, st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, d.d_in, k, update_stats)
+        DPL_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_backward_kernel");
+        // gb_dec = colsum(dY) - W_enc @ gb_enc
+        const int nblk = (N + 63) / 64;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 255) / 256), dim3(256), 0, stream,
+                           (const float*)(wsb + ws.colpart), (float*)(wsb + ws.colsum), nblk, d.d_in, 1.0f);
+        hipLaunchKernelGGL(sae_gbdec_kernel, dim3(d.d_in), dim3(256), 0, stream, (const float*)st->W_enc, (const float*)st->gb_enc,
+                           (const float*)(wsb + ws.colsum), st->gb_dec, d.d_sae);
+        PV_LAUNCH_CHECK("sae bias-grad kernels");
+    }
+    // scalars[0] = loss (== mse for topk)
+    PV_HIP_CHECK(hipMemcpyAsync(out->scalars, out->scalars + 1, 4, hipMemcpyDeviceToDevice, stream));
+    return PV_OK;
+}
+
+// sum of squares of a flat gradient buffer -> scalars[3]; `partial` = 1024 floats of scratch
+extern "C" int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* partial, float* scalars, void* stream_) {
+    PV_REQUIRE(flat_grads && partial && scalars && n > 0, "null argument");
+    PV_REQUIRE(pv_aligned16(flat_grads), "gradient buffer must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, stream, flat_grads, n, partial);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3);
+    PV_LAUNCH_CHECK("sqnorm kernels");
+    return PV_OK;
+}
+
+extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* scalars, float max_grad_norm, float lr,
+                            int32_t step, void* stream_) {
+    PV_REQUIRE(plan && st && scalars && step >= 1, "null argument / step must be >= 1");
+    PV_REQUIRE(st->mW_enc && st->mW_dec && st->mb_enc && st->mb_dec && st->vW_enc && st->vW_dec && st->vb_enc && st->vb_dec, "Adam state");
+    hipStream_t stream = (hipStream_t)stream_;
+    const pv_sae_desc& d = plan->d;
+    AdamC c;
+    c.lr = lr; c.b1 = 0.9f; c.b2 = 0.999f; c.eps = 1e-8f; c.max_norm = max_grad_norm;
+    c.bc1 = (float)(1.0 - pow(0.9, (double)step));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, (double)step));
+    ProfScope prof(PV_PROF_SAE_APPLY, stream, 0.0, 7.0 * 4.0 * (2.0 * d.d_in * (double)d.d_sae + d.d_sae + d.d_in));
+    const dim3 block(256);
+#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, d.d_sae, d.d_in)
+    DPL_DISPATCH(d.d_in, CALL);
+#undef CALL
+    hipLaunchKernelGGL(adam_wenc_kernel, dim3((d.d_sae + 31) / 32, (d.d_in + 31) / 32), block, 0, stream, st->W_enc,
+                       (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae);
+    hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
+                       st->mb_enc, st->vb_enc, scalars, c, d.d_sae);
+    hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, st->b_dec, (const float*)st->gb_dec,
+                       st->mb_dec, st->vb_dec, scalars, c, d.d_in);
+    PV_LAUNCH_CHECK("adam kernels");
+    return PV_OK;
+}
