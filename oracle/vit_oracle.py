@@ -162,16 +162,24 @@ def vit_forward(
         y, sc = layer_norm(resid_pre, P[p + "ln1.w"], P[p + "ln1.b"], eps)   # :106-109 (x3, identical)
         tap(p + "ln1.hook_scale", sc)
         y = tap(p + "ln1.hook_normalized", y)
-        # attention.py:186-244: x[b,t,:] @ W[h] + b[h]  -> [B,T,H,dh]
-        q = tap(p + "attn.hook_q", np.einsum("btd,hde->bthe", y, P[p + "attn.W_Q"], optimize=True) + P[p + "attn.b_Q"])
-        k = tap(p + "attn.hook_k", np.einsum("btd,hde->bthe", y, P[p + "attn.W_K"], optimize=True) + P[p + "attn.b_K"])
-        v = tap(p + "attn.hook_v", np.einsum("btd,hde->bthe", y, P[p + "attn.W_V"], optimize=True) + P[p + "attn.b_V"])
-        # attention.py:246-265 (vision path: no mask)
-        scores = np.einsum("bqhe,bkhe->bhqk", q, k, optimize=True) / attn_scale
+        # attention.py:186-244: x[b,t,:] @ W[h] + b[h]  -> [B,T,H,dh]; W[h] stacked head-major into one
+        # [d, H*dh] matrix so the projection is a single BLAS GEMM (same arithmetic, same result layout)
+        def proj(W, b):
+            Wm = np.ascontiguousarray(W.transpose(1, 0, 2).reshape(d, H * dh))
+            return (y.reshape(B * T, d) @ Wm).reshape(B, T, H, dh) + b
+        q = tap(p + "attn.hook_q", proj(P[p + "attn.W_Q"], P[p + "attn.b_Q"]))
+        k = tap(p + "attn.hook_k", proj(P[p + "attn.W_K"], P[p + "attn.b_K"]))
+        v = tap(p + "attn.hook_v", proj(P[p + "attn.W_V"], P[p + "attn.b_V"]))
+        # attention.py:246-265 (vision path: no mask): scores[b,h,q,k] = q . k / attn_scale
+        qh = np.ascontiguousarray(q.transpose(0, 2, 1, 3))          # [B,H,T,dh]
+        kh = np.ascontiguousarray(k.transpose(0, 2, 3, 1))          # [B,H,dh,T]
+        scores = np.matmul(qh, kh) / attn_scale
         scores = tap(p + "attn.hook_attn_scores", scores.astype(dtype))
         pattern = tap(p + "attn.hook_pattern", softmax_lastdim(scores).astype(dtype))   # :148-150
-        z = tap(p + "attn.hook_z", np.einsum("bkhe,bhqk->bqhe", v, pattern, optimize=True))   # :267-281
-        attn_out = np.einsum("bqhe,hed->bqd", z, P[p + "attn.W_O"], optimize=True) + P[p + "attn.b_O"]  # :155-167
+        vh = np.ascontiguousarray(v.transpose(0, 2, 1, 3))          # [B,H,T,dh]
+        z = tap(p + "attn.hook_z", np.ascontiguousarray(np.matmul(pattern, vh).transpose(0, 2, 1, 3)))   # :267-281
+        # attention.py:155-167: sum_h z[:,:,h,:] @ W_O[h] + b_O  ==  [B*T, H*dh] @ [H*dh, d]
+        attn_out = (z.reshape(B * T, H * dh) @ P[p + "attn.W_O"].reshape(H * dh, d)).reshape(B, T, d) + P[p + "attn.b_O"]
         attn_out = tap(p + "hook_attn_out", attn_out.astype(dtype))                    # transformer_block.py:117-119
         resid_mid = tap(p + "hook_resid_mid", resid_pre + attn_out)                    # :122-124
         y2, sc2 = layer_norm(resid_mid, P[p + "ln2.w"], P[p + "ln2.b"], eps)           # :130

@@ -1,0 +1,170 @@
+"""GPU parity tests of the native SAE step (through the C ABI) against the numpy oracle and the
+reference-generated golden fixtures.  Tolerance: 1e-4 relative on losses (north_star) and on every
+gradient / parameter tensor (measured ~1e-6); top-k index SETS and firing statistics exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sae_oracle as O
+from oracle.vit_oracle import fingerprint
+from vit_prisma_amd import HookedViT, HookedViTConfig
+from vit_prisma_amd.sae import (StandardSparseAutoencoder, VisionActivationsStore, VisionModelSAERunnerConfig,
+                                VisionSAETrainer)
+from vit_prisma_amd.sae.native_sae import NativeSAE
+from vit_prisma_amd.synth import ARCHS, synth_images, synth_sae_batch, synth_sae_state, synth_vit_state
+
+from conftest import GOLDEN, rel_fro
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def fresh(d_in, d_sae):
+    sd = synth_sae_state(d_in, d_sae, 0)
+    P = {k: v.copy() for k, v in sd.items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    T = {k: torch.from_numpy(v.copy()).cuda() for k, v in sd.items()}
+    return P, opt, stats, T
+
+
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(64, 512, 8, 256), (96, 1024, 16, 300), (768, 24576, 32, 4096)])
+def test_native_step_vs_oracle(d_in, d_sae, k, n):
+    P, opt, stats, T = fresh(d_in, d_sae)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+    for t in range(2):
+        x = synth_sae_batch(n, d_in, seed=t)
+        Pc = {kk: v.copy() for kk, v in P.items()}
+        O.renorm_decoder(Pc)
+        fw = O.sae_forward(Pc, x, k)
+        gr = O.sae_backward(Pc, x, fw)
+        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1)
+        eng.renorm_decoder()
+        eng.step(torch.from_numpy(x).cuda(), want_out=True)
+        eng.grad_sqnorm()
+        torch.cuda.synchronize()
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - ref["loss"]) <= TOL * ref["loss"] and abs(sc[1] - ref["mse_loss"]) <= TOL * ref["mse_loss"]
+        assert sc[2] == ref["l0"] == float(k)
+        assert abs(np.sqrt(sc[3]) - ref["grad_norm"]) <= TOL * ref["grad_norm"]
+        idx = np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1)
+        assert np.array_equal(idx, np.sort(fw["idx"], axis=1))                       # exact index sets
+        assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
+        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
+        for name in ("W_dec", "b_enc", "b_dec"):
+            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
+        eng.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name in P:
+            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name
+            assert rel_fro(eng.m[name].cpu().numpy(), opt["m"][name]) < TOL, name
+            assert rel_fro(eng.v[name].cpu().numpy(), opt["v"][name]) < 2 * TOL, name
+        assert np.array_equal(eng.act_freq_scores.cpu().numpy(), stats["act_freq_scores"])
+        assert np.array_equal(eng.n_fwd_since_fired.cpu().numpy(), stats["n_fwd_since_fired"])
+
+
+def test_native_config3_vs_reference_golden():
+    """BASELINE config 3 (768 -> 24576, k = 32, N = 4096): losses / parameters of the reference's own
+    VisionSAETrainer.train_step, 3 consecutive steps."""
+    with open(os.path.join(GOLDEN, "sae_b32_steps.json")) as f:
+        G = json.load(f)
+    c = G["config"]
+    _, _, _, T = fresh(c["d_in"], c["d_sae"])
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], c["k"], True, c["n_tokens"])
+    for t, want in enumerate(G["steps"]):
+        eng.train_step(torch.from_numpy(synth_sae_batch(c["n_tokens"], c["d_in"], seed=t)).cuda(), c["lr"], 1.0)
+        torch.cuda.synchronize()
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - want["loss"]) <= TOL * want["loss"], (t, sc[0], want["loss"])
+        assert sc[2] == want["l0"]
+        # the reference's clip norm is itself only good to ~1e-3 (torch CPU vector_norm, see the oracle test)
+        assert abs(np.sqrt(sc[3]) - want["grad_norm"]) <= 2e-3 * want["grad_norm"]
+        for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            fp = fingerprint(eng.params[name].cpu().numpy())
+            assert abs(fp["l2"] - want["params"][name]["l2"]) <= 1e-5 * want["params"][name]["l2"], (t, name)
+            assert np.max(np.abs(np.array(fp["vals"]) - np.array(want["params"][name]["vals"]))) < 1e-4, (t, name)
+        assert abs(float(eng.act_freq_scores.sum()) - want["act_freq"]["sum"]) < 0.5
+
+
+def test_topk_edge_cases_ties_and_negatives():
+    """Rows with massive ties (fallback radix path), all-negative rows (ReLU zeroes the kept values) and
+    k larger than the positives."""
+    d_in, d_sae, k, n = 64, 512, 8, 8
+    _, _, _, T = fresh(d_in, d_sae)
+    T["W_enc"].zero_()                                  # hidden_pre == b_enc for every token: 512-way ties per value
+    T["b_enc"].copy_(torch.linspace(-1.0, 0.5, d_sae).cuda().round(decimals=1))
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+    idx, val, mu, sd = eng.encode_topk(torch.from_numpy(synth_sae_batch(n, d_in, 0)).cuda())
+    torch.cuda.synchronize()
+    b = T["b_enc"].cpu().numpy()
+    kth = np.sort(b)[-k]
+    for r in range(n):
+        sel = idx[r].cpu().numpy()
+        assert len(set(sel.tolist())) == k                                     # k distinct indices
+        assert np.all(b[sel] >= kth) and np.allclose(val[r].cpu().numpy(), np.maximum(b[sel], 0))
+    T["b_enc"].fill_(-1.0)                                                     # every pre-activation negative
+    idx, val, _, _ = eng.encode_topk(torch.from_numpy(synth_sae_batch(n, d_in, 0)).cuda())
+    assert float(val.abs().max()) == 0.0 and len(set(idx[0].cpu().tolist())) == k
+    # > 1024 candidates (4096-way tie): the radix-select fallback (which of the tied columns are kept is
+    # arbitrary, as in torch.topk, but deterministic)
+    _, _, _, T2 = fresh(d_in, 4096)
+    T2["W_enc"].zero_()
+    T2["b_enc"].fill_(0.25)
+    T2["b_enc"][100] = 0.75
+    eng2 = NativeSAE(T2["W_enc"], T2["W_dec"], T2["b_enc"], T2["b_dec"], k, True, n)
+    idx, val, _, _ = eng2.encode_topk(torch.from_numpy(synth_sae_batch(n, d_in, 0)).cuda())
+    torch.cuda.synchronize()
+    sel = idx[3].cpu().tolist()
+    assert 100 in sel and len(set(sel)) == k and all(0 <= c < 4096 for c in sel)
+    assert sorted(val[3].cpu().tolist()) == [0.25] * 7 + [0.75]
+    idx_b, _, _, _ = eng2.encode_topk(torch.from_numpy(synth_sae_batch(n, d_in, 0)).cuda())
+    assert torch.equal(idx_b.clone(), idx)                                      # run-to-run deterministic
+
+
+def test_trainer_native_path_matches_reference_and_store_harvests_natively():
+    g = np.load(os.path.join(GOLDEN, "sae_small_steps.npz"))
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=8, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", b_dec_init_method="mean",
+        train_batch_size=256, lr=1e-3, max_grad_norm=1.0, _device="cuda", log_to_wandb=False,
+        lr_scheduler_name="constant", n_checkpoints=0, context_size=17, store_batch_size=4, n_batches_in_buffer=4)
+    sae = StandardSparseAutoencoder(cfg)
+    with torch.no_grad():
+        for n, v in synth_sae_state(64, 512, 0).items():
+            getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae)
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(256, 64, seed=t)).cuda()[:, None, :]
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act,
+            n_forward_passes_since_fired=since, n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t,
+            n_training_tokens=t * 256)
+        assert tr.last_step_native and l1 is None
+        want = g[f"s{t}_scalars"]
+        assert abs(float(loss) - want[0]) <= TOL * want[0] and float(l0) == want[2]
+        for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            assert rel_fro(getattr(sae, n).detach().cpu().numpy(), g[f"s{t}_param_{n}"]) < TOL, (t, n)
+        assert np.array_equal(act.cpu().numpy(), g[f"s{t}_act_freq"])
+        assert np.array_equal(since.cpu().numpy(), g[f"s{t}_n_since"])
+
+    # the store: harvest blocks.1.hook_resid_post of the tiny ViT through the native plan
+    arch = ARCHS["tiny"]
+    vit = HookedViT(HookedViTConfig(**arch, device="cuda"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()})
+    vit = vit.cuda().eval()
+    images = torch.from_numpy(synth_images(arch, 32, 3))
+    ds = [(images[i], 0) for i in range(32)]
+    store = VisionActivationsStore(cfg, vit, ds)
+    assert vit.last_run_native
+    assert store.storage_buffer.shape == ((16 + 8) * 17 // 2, 1, 64)          # kept half of the mixed buffer
+    batch = store.next_batch()
+    assert batch.shape[1:] == (1, 64) and batch.is_cuda
+    acts = store.get_activations(images[:4].cuda())
+    from oracle.vit_oracle import vit_forward
+    _, c = vit_forward(synth_vit_state(arch, 0), arch, images[:4].numpy(), stop_at_layer=2,
+                       names_filter=["blocks.1.hook_resid_post"])
+    assert rel_fro(acts[:, :, 0].cpu().numpy(), c["blocks.1.hook_resid_post"]) < TOL

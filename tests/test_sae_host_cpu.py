@@ -1,0 +1,125 @@
+"""CPU tests of the SAE host side: module + trainer (PyTorch path) against what the reference's real
+train_step produced, config round trip, and the data-parallel algebra over a 2-process gloo group."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import sae_oracle as O
+from vit_prisma_amd.sae import (StandardSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer)
+from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state
+
+from conftest import GOLDEN, rel_fro
+
+
+def make_cfg(d_in=64, expansion=8, k=8, n=256, **kw):
+    base = dict(hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=expansion,
+                activation_fn_str="topk", activation_fn_kwargs={"k": k}, normalize_activations="layer_norm",
+                initialization_method="independent", b_dec_init_method="mean", train_batch_size=n, lr=1e-3,
+                max_grad_norm=1.0, _device="cpu", _dtype="float32", log_to_wandb=False, lr_scheduler_name="constant",
+                n_checkpoints=0)
+    base.update(kw)
+    return VisionModelSAERunnerConfig(**base)
+
+
+def test_config_json_round_trip_and_derived():
+    cfg = make_cfg(768, 32, 32, 4096)
+    assert cfg.hook_point == "blocks.6.hook_resid_post" and cfg.d_sae == 24576
+    assert cfg.total_training_tokens == 1_300_000 * 50 and cfg.total_training_steps == 65_000_000 // 4096
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "config.json")
+        cfg.save_config(p)
+        assert VisionModelSAERunnerConfig.load_config(p) == cfg
+    with pytest.raises(ValueError):
+        make_cfg(b_dec_init_method="bogus")
+
+
+def test_module_and_trainer_torch_path_match_reference_three_steps():
+    g = np.load(os.path.join(GOLDEN, "sae_small_steps.npz"))
+    cfg = make_cfg()
+    sae = StandardSparseAutoencoder(cfg)
+    assert list(sae.state_dict().keys()) == ["W_dec", "W_enc", "b_enc", "b_dec"]
+    assert list(sae.hook_dict.keys()) == ["hook_sae_in", "hook_hidden_pre", "hook_hidden_post", "hook_sae_out"]
+    with torch.no_grad():
+        for n, v in synth_sae_state(64, 512, 0).items():
+            getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae)
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(256, 64, seed=t))[:, None, :]
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act,
+            n_forward_passes_since_fired=since, n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t,
+            n_training_tokens=t * 256)
+        want = g[f"s{t}_scalars"]
+        assert l1 is None and not tr.last_step_native
+        assert abs(float(loss) - want[0]) <= 1e-5 * want[0] and float(l0) == want[2]
+        for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            assert rel_fro(getattr(sae, n).detach().numpy(), g[f"s{t}_param_{n}"]) < 1e-5, (t, n)
+        assert np.array_equal(act.numpy(), g[f"s{t}_act_freq"]) and np.array_equal(since.numpy(), g[f"s{t}_n_since"])
+    assert frac == 3 * 256
+    # 7-tuple contract of forward (sae.py:637-645)
+    out = sae(torch.from_numpy(synth_sae_batch(8, 64, 9)))
+    assert len(out) == 7 and out[0].shape == (8, 64) and out[1].shape == (8, 512) and out[4] is None
+    assert int((out[1] > 0).sum(-1).max()) <= 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d_in, d_sae, k, N = 64, 512, 8, 256
+    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    O.renorm_decoder(P)
+    x = synth_sae_batch(N, d_in, seed=0)
+    xs = x[rank * (N // world):(rank + 1) * (N // world)]
+    # the two pre-reductions of SURVEY.md 8e, exactly as VisionSAETrainer._native_step issues them
+    bm = torch.from_numpy(xs.sum(axis=0))
+    dist.all_reduce(bm)
+    fw = O.sae_forward(P, xs, k, batch_mean=(bm / N).numpy(), n_global=N)
+    g = O.sae_backward(P, xs, fw, n_global=N)
+    flat = torch.from_numpy(np.concatenate([g[n].ravel() for n in ("W_enc", "W_dec", "b_enc", "b_dec")]))
+    dist.all_reduce(flat)                                    # ONE collective for all four gradients
+    loss = torch.tensor([float(fw["loss"])], dtype=torch.float64)
+    dist.all_reduce(loss)
+    if rank == 0:
+        q.put((flat.numpy(), float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_algebra_equals_single_process_gloo_world2():
+    """Sum over ranks of shard gradients computed with the GLOBAL batch mean and 1/N_global scaling ==
+    the single-process gradient at the global batch (the oracle for the 8-GPU path)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat, loss = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d_in, d_sae, k, N = 64, 512, 8, 256
+    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    O.renorm_decoder(P)
+    x = synth_sae_batch(N, d_in, seed=0)
+    fw = O.sae_forward(P, x, k)
+    g = O.sae_backward(P, x, fw)
+    ref = np.concatenate([g[n].ravel() for n in ("W_enc", "W_dec", "b_enc", "b_dec")])
+    assert rel_fro(flat, ref) < 1e-5
+    assert abs(loss - float(fw["loss"])) <= 1e-5 * float(fw["loss"])

@@ -196,6 +196,73 @@ def l14():
     RES["l14_perf"] = 32 / dt
 
 
+def sae():
+    from oracle import sae_oracle as O
+    from vit_prisma_amd.sae.native_sae import NativeSAE
+    from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state
+    r = {}
+    for (d_in, d_sae, k, Ntok, nsteps) in ((64, 512, 8, 256, 3), (96, 1024, 16, 300, 2), (768, 24576, 32, 4096, 2)):
+        tag = f"{d_in}x{d_sae}k{k}N{Ntok}"
+        sd = synth_sae_state(d_in, d_sae, 0)
+        P = {kk: v.copy() for kk, v in sd.items()}
+        opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+        stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+        T = {kk: torch.from_numpy(v.copy()).to(dev) for kk, v in sd.items()}
+        eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, Ntok)
+        for t in range(nsteps):
+            x = synth_sae_batch(Ntok, d_in, seed=t)
+            # oracle pieces
+            Pc = {kk: v.copy() for kk, v in P.items()}
+            O.renorm_decoder(Pc)
+            fw = O.sae_forward(Pc, x, k)
+            gr = O.sae_backward(Pc, x, fw)
+            out = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1)
+            xg = torch.from_numpy(x).to(dev)
+            eng.renorm_decoder()
+            eng.step(xg, want_out=True)
+            eng.grad_sqnorm()
+            torch.cuda.synchronize()
+            sc = eng.scalars.cpu().numpy()
+            idx = eng.topk_idx[:Ntok].cpu().numpy()
+            same_set = float(np.mean([set(a.tolist()) == set(b.tolist()) for a, b in zip(idx, fw["idx"])]))
+            e = {
+                "loss_rel": abs(sc[0] - out["loss"]) / out["loss"], "l0": float(sc[2]), "l0_ref": out["l0"],
+                "gnorm_rel": abs(np.sqrt(sc[3]) - out["grad_norm"]) / out["grad_norm"], "topk_set_match": same_set,
+                "sae_out": rel(eng.sae_out[:Ntok].cpu().numpy(), fw["sae_out"]),
+                "gW_enc": rel(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]), "gW_dec": rel(eng.g["W_dec"].cpu().numpy(), gr["W_dec"]),
+                "gb_enc": rel(eng.g["b_enc"].cpu().numpy(), gr["b_enc"]), "gb_dec": rel(eng.g["b_dec"].cpu().numpy(), gr["b_dec"]),
+            }
+            eng.apply(1e-3, 1.0)
+            torch.cuda.synchronize()
+            for kk in P:
+                e["p_" + kk] = rel(eng.params[kk].cpu().numpy(), P[kk])
+                e["m_" + kk] = rel(eng.m[kk].cpu().numpy(), opt["m"][kk])
+            e["act_freq_eq"] = bool(np.array_equal(eng.act_freq_scores.cpu().numpy(), stats["act_freq_scores"]))
+            e["n_since_eq"] = bool(np.array_equal(eng.n_fwd_since_fired.cpu().numpy(), stats["n_fwd_since_fired"]))
+            r[f"{tag}_s{t}"] = e
+            print(f"[sae {tag} step {t}]", {kk: (f"{v:.2e}" if isinstance(v, float) else v) for kk, v in e.items()}, flush=True)
+        if d_in == 768:
+            xs = [torch.from_numpy(synth_sae_batch(Ntok, d_in, seed=100 + i)).to(dev) for i in range(4)]
+            for i in range(3):
+                eng.train_step(xs[i % 4], 1e-3)
+            torch.cuda.synchronize()
+            N.prof_reset(); N.prof_enable(True)
+            t0 = time.time()
+            n = 20
+            for i in range(n):
+                eng.train_step(xs[i % 4], 1e-3)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / n
+            N.prof_enable(False)
+            r["perf_tokens_per_s"] = Ntok / dt
+            print(f"sae perf: {dt * 1e3:.3f} ms/step  {Ntok / dt:.0f} tokens/s", flush=True)
+            for kind in ("sae_encode_topk", "sae_backward", "sae_apply", "gemm"):
+                pr = N.prof_read(kind)
+                print("   ", kind, {kk: (round(v, 3) if isinstance(v, float) else v) for kk, v in pr.items()},
+                      "avg_us", round(pr["ms"] * 1e3 / max(pr["launches"], 1), 1), flush=True)
+    RES["sae"] = r
+
+
 if __name__ == "__main__":
     sections = sys.argv[1:] or ["unit", "tiny", "b32", "bf16", "perf"]
     print(torch.cuda.get_device_name(0), flush=True)

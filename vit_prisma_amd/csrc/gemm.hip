@@ -18,6 +18,8 @@
 //   costs one HBM store, nothing is re-read).
 //   blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (which share the A rows)
 //   are placed on the same XCD so the A slab is served from that XCD's L2.
+#include <stdlib.h>
+
 #include "gemm.hpp"
 #include "prof.hpp"
 
@@ -172,6 +174,40 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
     }
 }
 
+// accumulators -> per-wave LDS staging (reusing the operand buffers; caller has passed a barrier after
+// the last LDS read) -> each lane owns 8 consecutive columns of a row -> fused epilogue + tap stores
+template <typename T>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], unsigned char* smem, int m0, int n0,
+                                              int wave, int lane, int wm, int wn) {
+    float* Cs = reinterpret_cast<float*>(smem) + wave * (64 * CS_LD);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int col = ni * 32 + (lane & 31);
+                Cs[row * CS_LD + col] = acc[mi][ni][e];
+            }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int cc = (lane & 7) * 8;
+        const int gm = m0 + wm * 64 + row;
+        const int gn = n0 + wn * 64 + cc;
+        if (gm < p.M && gn < p.N) {
+            float v[8];
+            const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc);
+            const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            epilogue8<T>(p, v, gm, gn);
+        }
+    }
+}
+
 constexpr int BKN_ROW = 528;         // [K][N]-layout B tile: 128 floats + 16 pad bytes per k row
 
 template <typename T, int AMODE, bool VEC, bool BKN = false>
@@ -300,34 +336,163 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS (per wave) -> row-major 8-column chunks per lane
-    float* Cs = reinterpret_cast<float*>(smem) + wave * (64 * CS_LD);
+    tile_epilogue<T>(p, acc, smem, m0, n0, wave, lane, wm, wn);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v2 mainloop for the common case (plain row-major A, [N][K] B, 16-byte aligned rows): branch-free
+// buffer loads (the hardware range check returns 0 for rows past M / N, so ragged tiles need no exec
+// masking) and a TWO-slab-deep register prefetch: the loads of slab k+2 are issued before the MFMAs of
+// slab k, and slab k+1 (issued one full iteration earlier) is written to LDS after them, so a global
+// load has ~2 slabs of MFMA time to land instead of 1.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * TILE_BYTES;
+    constexpr int EB = DT<T>::kBytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + SLAB - 1) / SLAB);
+    const bool ktail = (Kb % SLAB) != 0;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    unsigned offA[4], offB[4], kcb[4];
+    int ldsoff[4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const int col = ni * 32 + (lane & 31);
-                Cs[row * CS_LD + col] = acc[mi][ni][e];
-            }
-    __syncthreads();
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int cc = (lane & 7) * 8;
-        const int gm = m0 + wm * 64 + row;
-        const int gn = n0 + wn * 64 + cc;
-        if (gm < p.M && gn < p.N) {
-            float v[8];
-            const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc);
-            const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc + 4);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-            v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-            epilogue8<T>(p, v, gm, gn);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 3, kc = c & 7;
+        kcb[i] = kc * 16;
+        offA[i] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;    // >= num_records when m0+row >= M
+        offB[i] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+        ldsoff[i] = row * ROWB + kc * 16;
     }
+    auto issue = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+        const unsigned kbase = (unsigned)kt * SLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned oa = offA[i] + kbase, ob = offB[i] + kbase;
+            // past K (ragged last slab, or the unconditional prefetch running off the end): force the
+            // offset out of range -> the buffer unit returns 0 without touching memory
+            if (kt >= nk || (ktail && kbase + kcb[i] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ob, 0, 0);
+        }
+    };
+    auto stash = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + ldsoff[i]) = ra[i];
+            *reinterpret_cast<u32x4*>(Bs + buf * TILE_BYTES + ldsoff[i]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int a_off = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    const int b_off = (wn * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = As + buf * TILE_BYTES;
+        const unsigned char* Bb = Bs + buf * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 a[2], b[2];
+            a[0] = *reinterpret_cast<const uint4*>(Ab + a_off + j * 32);
+            a[1] = *reinterpret_cast<const uint4*>(Ab + a_off + 32 * ROWB + j * 32);
+            b[0] = *reinterpret_cast<const uint4*>(Bb + b_off + j * 32);
+            b[1] = *reinterpret_cast<const uint4*>(Bb + b_off + 32 * ROWB + j * 32);
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+            } else {
+                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+
+    u32x4 r0a[4], r0b[4], r1a[4], r1b[4];
+    // NB: issue / stash are unconditional (off-the-end prefetches are turned into out-of-range, zero-
+    // returning loads): with a branch around them the compiler's waitcnt pass merges the two paths and
+    // falls back to vmcnt(0) before the LDS writes, which would drain the slab that was just issued.
+    issue(0, r0a, r0b);
+    issue(1, r1a, r1b);
+    stash(0, r0a, r0b);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: LDS[0] = slab kt, register set 1 = slab kt+1 (in flight), set 0 free
+        issue(kt + 2, r0a, r0b);
+        compute(0);
+        stash(1, r1a, r1b);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: LDS[1] = slab kt+1, set 0 = slab kt+2 (in flight), set 1 free
+        issue(kt + 3, r1a, r1b);
+        compute(1);
+        stash(0, r0a, r0b);
+        __syncthreads();
+    }
+    tile_epilogue<T>(p, acc, smem, m0, n0, wave, lane, wm, wn);
+}
+
+template <typename T>
+int launch_v2(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_v2<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+        attr_done = true;
+    }
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v2<T>), dim3(ntm * ntn), dim3(256), GEMM_LDS, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v2");
+    return PV_OK;
 }
 
 template <typename T, int AMODE, bool VEC, bool BKN = false>
@@ -370,6 +535,10 @@ int dispatch(GemmParams& p, hipStream_t stream) {
     if (p.epi == PV_EPI_RESID) vo = vo && (p.ldr * EB) % 16 == 0 && pv_aligned16(p.resid);
     if (p.epi == PV_EPI_QKV) vo = vo && (p.nsplit % 8) == 0;
     p.vec_out = vo ? 1 : 0;
+    if (p.a_mode == PV_A_PLAIN && vec) {
+        const uint64_t spanA = ((uint64_t)p.M + BM) * (uint64_t)p.lda * EB, spanB = ((uint64_t)p.N + BN) * (uint64_t)p.ldb * EB;
+        if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !getenv("PV_GEMM_V1")) return launch_v2<T>(p, stream);
+    }
     if (p.a_mode == PV_A_PLAIN) {
         return vec ? launch<T, PV_A_PLAIN, true>(p, stream) : launch<T, PV_A_PLAIN, false>(p, stream);
     }

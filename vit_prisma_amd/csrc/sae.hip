@@ -107,30 +107,87 @@ __device__ __forceinline__ uint32_t f2ord(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int PER>   // values per thread: d_sae <= 256 * PER
+constexpr int TOPK_CAP = 1024;   // candidate list capacity of the fast path
+
+// Per-row exact top-k, streaming (no per-thread value cache -> ~40 VGPRs, full occupancy):
+//   pass 1  each thread streams its share of the row keeping only its maximum
+//   T0      the k-th largest of the 256 per-thread maxima is a lower bound of the global k-th largest
+//           value (every maximum is an element), found by an all-pairs rank over 256 LDS values
+//   pass 2  the row is streamed again (it is L2-resident: 96 KB just read) and the few elements >= T0
+//           are compacted into LDS
+//   rank    exact rank of every candidate by (value desc, column asc): rank < k -> output slot = rank, so
+//           the result is sorted by value like torch.topk and run-to-run deterministic
+// Fallback (more than TOPK_CAP candidates: massive ties at the top, e.g. constant rows): MSB-first radix
+// select that re-streams the row once per digit.
 __global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__ hidden, int32_t* __restrict__ idx_out,
                                                        float* __restrict__ val_out, int d_sae, int k) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh_prefix, sh_k, sh_wcnt[4], sh_eqcnt[4];
+    __shared__ uint32_t sh_T0, sh_ncand, sh_prefix, sh_k, sh_wcnt[4];
+    __shared__ uint32_t cand_key[TOPK_CAP];
+    __shared__ int32_t cand_idx[TOPK_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const float* h = hidden + row * d_sae;
-    uint32_t key[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + 256 * i;
-        key[i] = (c < d_sae) ? f2ord(h[c]) : 0u;        // 0 sorts below every real float
+    const int nvec = d_sae >> 2;                     // d_sae % 4 == 0 (checked at plan creation)
+
+    uint32_t lmax = 0;
+    for (int v = tid; v < nvec; v += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(h + 4 * v);
+        lmax = max(max(lmax, f2ord(x.x)), max(f2ord(x.y), max(f2ord(x.z), f2ord(x.w))));
     }
+    hist[tid] = lmax;
+    if (tid == 0) { sh_T0 = 0u; sh_ncand = 0u; }
+    __syncthreads();
+    if (k <= 256) {
+        uint32_t rank = 0;
+        for (int u = 0; u < 256; ++u) {
+            const uint32_t o = hist[u];               // same address for all lanes: LDS broadcast
+            rank += (o > lmax) || (o == lmax && u < tid);
+        }
+        if (rank == (uint32_t)(k - 1)) sh_T0 = lmax;
+    }
+    __syncthreads();
+    const uint32_t T0 = sh_T0;
+    for (int v = tid; v < nvec; v += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(h + 4 * v);
+        const uint32_t kx[4] = {f2ord(x.x), f2ord(x.y), f2ord(x.z), f2ord(x.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kx[e] >= T0) {
+                const uint32_t pos = atomicAdd(&sh_ncand, 1u);
+                if (pos < TOPK_CAP) { cand_key[pos] = kx[e]; cand_idx[pos] = 4 * v + e; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t ncand = sh_ncand;
+    if (ncand <= TOPK_CAP) {
+        for (uint32_t c = tid; c < ncand; c += 256) {
+            const uint32_t kc = cand_key[c];
+            const int32_t ic = cand_idx[c];
+            uint32_t rank = 0;
+            for (uint32_t o = 0; o < ncand; ++o) {
+                const uint32_t ko = cand_key[o];
+                rank += (ko > kc) || (ko == kc && cand_idx[o] < ic);
+            }
+            if (rank < (uint32_t)k) {
+                idx_out[row * k + rank] = ic;
+                val_out[row * k + rank] = fmaxf(h[ic], 0.f);      // postact_fn = ReLU (sae.py:806)
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------- fallback: radix select, re-streaming the row
     uint32_t prefix = 0, kk = (uint32_t)k;
-    // MSB-first radix select: after the 4 passes `prefix` is the k-th largest key
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
+        __syncthreads();
         hist[tid] = 0;
         __syncthreads();
         const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            if ((key[i] & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key[i] >> shift) & 255u], 1u);
+        for (int c = tid; c < d_sae; c += 256) {
+            const uint32_t key = f2ord(h[c]);
+            if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
         if (tid == 0) {
@@ -146,40 +203,43 @@ __global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__
         __syncthreads();
         prefix = sh_prefix;
         kk = sh_k;
-        __syncthreads();
     }
-    // kk = how many elements EQUAL to the threshold are taken (ties: lowest (thread, slot) order first)
+    // prefix = k-th largest key; take everything above it and the first kk (lowest column) ties
     uint32_t ngt = 0, neq = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        ngt += key[i] > prefix;
-        neq += key[i] == prefix;
+    for (int c = tid; c < d_sae; c += 256) {
+        const uint32_t key = f2ord(h[c]);
+        ngt += key > prefix;
+        neq += key == prefix;
     }
-    // exclusive scans over threads of (ngt) and (neq) -> deterministic output slots
-    uint32_t inc_gt = ngt, inc_eq = neq;
+    auto block_scan = [&](uint32_t cnt, uint32_t& total) -> uint32_t {
+        uint32_t inc = cnt;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t a = __shfl_up(inc_gt, o, 64), b = __shfl_up(inc_eq, o, 64);
-        if (lane >= o) { inc_gt += a; inc_eq += b; }
-    }
-    if (lane == 63) { sh_wcnt[wave] = inc_gt; sh_eqcnt[wave] = inc_eq; }
-    __syncthreads();
-    uint32_t base_gt = 0, base_eq = 0, tot_gt = 0;
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) { base_gt += sh_wcnt[w]; base_eq += sh_eqcnt[w]; }
-        tot_gt += sh_wcnt[w];
-    }
-    uint32_t pos_gt = base_gt + inc_gt - ngt;     // exclusive
-    uint32_t pos_eq = base_eq + inc_eq - neq;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + 256 * i;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += a;
+        }
+        __syncthreads();
+        if (lane == 63) sh_wcnt[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) base += sh_wcnt[w];
+            total += sh_wcnt[w];
+        }
+        return base + inc - cnt;
+    };
+    uint32_t tot_gt, tot_eq;
+    uint32_t pos_gt = block_scan(ngt, tot_gt);
+    uint32_t pos_eq = block_scan(neq, tot_eq);
+    for (int c = tid; c < d_sae; c += 256) {
+        const uint32_t key = f2ord(h[c]);
         int slot = -1;
-        if (key[i] > prefix) slot = (int)pos_gt++;
-        else if (key[i] == prefix) { if (pos_eq < kk) slot = (int)(tot_gt + pos_eq); pos_eq++; }
+        if (key > prefix) slot = (int)pos_gt++;
+        else if (key == prefix) { if (pos_eq < kk) slot = (int)(tot_gt + pos_eq); pos_eq++; }
         if (slot >= 0 && slot < k) {
             idx_out[row * k + slot] = c;
-            val_out[row * k + slot] = fmaxf(h[c], 0.f);      // postact_fn = ReLU (sae.py:806)
+            val_out[row * k + slot] = fmaxf(h[c], 0.f);
         }
     }
 }
@@ -268,7 +328,8 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restric
 }
 // single-workgroup exclusive scan over d_sae counts (d_sae ~ 25k: 96 per thread)
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ cursor, int d_sae) {
+                                                        uint32_t* __restrict__ cursor, int d_sae, float* __restrict__ scalars,
+                                                        float inv_tokens) {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (d_sae + 1023) / 1024;
@@ -289,7 +350,10 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         cursor[i] = run;
         run += cnt[i];
     }
-    if (tid == 1023) offs[d_sae] = part[1023];
+    if (tid == 1023) {
+        offs[d_sae] = part[1023];
+        if (scalars) scalars[2] = (float)part[1023] * inv_tokens;       // l0 = mean_n #(val > 0), train_sae.py:364
+    }
 }
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
                                                        uint32_t* __restrict__ cursor, int32_t* __restrict__ pairs, int n_pairs) {
@@ -298,26 +362,60 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse backward, one wave per feature (writes EVERY row: doubles as zero_grad)
+// sparse backward.  Work is split by PAIRS, not by feature: wave w owns the CSR-ordered pair range
+// [w*BWD_CH, (w+1)*BWD_CH) -- perfectly balanced even when a few dense features fire on most tokens
+// (one-wave-per-feature measured 8.6 ms/step on such data).  A wave walks its range, accumulates per
+// feature and flushes a row when the feature changes: plain stores when the feature's whole list lies
+// inside this wave's range, hardware float atomics otherwise (rows are zeroed beforehand).
 // ------------------------------------------------------------------------------------------------
+constexpr int BWD_CH = 16;
+
 template <int DPL>
 __global__ __launch_bounds__(256) void sae_backward_kernel(
-    const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs, const float* __restrict__ val,
-    const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in,
-    float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    float* __restrict__ act_freq, float* __restrict__ n_since_fired, float* __restrict__ fire_count, int d_sae, int d, int k,
-    int update_stats) {
+    const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
+    const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
+    const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+    int d_sae, int d, int k) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= d_sae) return;
-    const uint32_t lo = offs[j], hi = offs[j + 1];
-    const int cnt = (int)(hi - lo);
+    const uint32_t n_active = offs[d_sae];
+    const uint32_t q0 = (uint32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * BWD_CH;
+    if (q0 >= n_active) return;
+    const uint32_t q1 = min(q0 + BWD_CH, n_active);
     float gd[DPL], ge[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) { gd[i] = 0.f; ge[i] = 0.f; }
     float gb = 0.f;
-    for (uint32_t q = lo; q < hi; ++q) {
+    int cur = idx[pairs[q0]];
+    auto flush = [&](int j) {
+        const bool whole = offs[j] >= q0 && offs[j + 1] <= q1;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < d) {
+                if (whole) {
+                    gW_dec[(int64_t)j * d + c] = gd[i];
+                    gW_encT[(int64_t)j * d + c] = ge[i];
+                } else {
+                    unsafeAtomicAdd(&gW_dec[(int64_t)j * d + c], gd[i]);
+                    unsafeAtomicAdd(&gW_encT[(int64_t)j * d + c], ge[i]);
+                }
+            }
+            gd[i] = 0.f;
+            ge[i] = 0.f;
+        }
+        if (lane == 0) {
+            if (whole) gb_enc[j] = gb;
+            else unsafeAtomicAdd(&gb_enc[j], gb);
+        }
+        gb = 0.f;
+    };
+    for (uint32_t q = q0; q < q1; ++q) {
         const int32_t p = pairs[q];
+        const int j = idx[p];
+        if (j != cur) {
+            flush(cur);
+            cur = j;
+        }
         const int n = p / k;
         const float a = val[p], g = dh[p];
         const float* dy = dY + (int64_t)n * d;
@@ -332,22 +430,20 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
         }
         gb += g;
     }
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < d) {
-            gW_dec[(int64_t)j * d + c] = gd[i];
-            gW_encT[(int64_t)j * d + c] = ge[i];
-        }
-    }
-    if (lane == 0) {
-        gb_enc[j] = gb;
-        if (fire_count) fire_count[j] = (float)cnt;
-        if (update_stats) {
-            // train_sae.py:356-361
-            act_freq[j] += (float)cnt;
-            n_since_fired[j] = cnt > 0 ? 0.f : n_since_fired[j] + 1.f;
-        }
+    flush(cur);
+}
+
+// firing statistics per feature (train_sae.py:356-361) from the CSR offsets
+__global__ __launch_bounds__(256) void sae_stats_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
+                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
+                                                        int d_sae, int update_stats) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d_sae) return;
+    const float cnt = (float)(offs[j + 1] - offs[j]);
+    if (fire_count) fire_count[j] = cnt;
+    if (update_stats) {
+        act_freq[j] += cnt;
+        n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
     }
 }
 
@@ -366,16 +462,6 @@ __global__ __launch_bounds__(256) void sae_gbdec_kernel(const float* __restrict_
     }
     s = block_sum_256(s, red);
     if (threadIdx.x == 0) gb_dec[i] = dy_colsum[i] - s;
-}
-
-// l0 = mean_n count(val > 0)   (train_sae.py:364)
-__global__ __launch_bounds__(256) void sae_l0_kernel(const float* __restrict__ val, float* __restrict__ scalars, int n_pairs,
-                                                     float inv_tokens) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n_pairs; i += 256) s += val[i] > 0.f ? 1.f : 0.f;
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) scalars[2] = s * inv_tokens;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,11 +698,7 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
         int rc = pv_launch_gemm(PV_DTYPE_F32, g, stream);
         if (rc) return rc;
         const float* hid = (const float*)(wsb + ws.hidden);
-        const int per = (d.d_sae + 255) / 256;
-        if (per <= 8) hipLaunchKernelGGL((sae_topk_kernel<8>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
-        else if (per <= 32) hipLaunchKernelGGL((sae_topk_kernel<32>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
-        else if (per <= 96) hipLaunchKernelGGL((sae_topk_kernel<96>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
-        else hipLaunchKernelGGL((sae_topk_kernel<128>), dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+        hipLaunchKernelGGL(sae_topk_kernel, dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
     }
     PV_LAUNCH_CHECK("sae_topk_kernel");
     return PV_OK;
@@ -676,8 +758,6 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
                            1.0f / ((float)n_global * (float)d.d_in), 1);
-        hipLaunchKernelGGL(sae_l0_kernel, dim3(1), dim3(256), 0, stream, (const float*)out->topk_val, out->scalars, n_pairs,
-                           1.0f / (float)N);
         // CSR by feature
         uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
@@ -686,18 +766,27 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         PV_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)d.d_sae * 4, stream));
         hipLaunchKernelGGL(csr_count_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const float*)out->topk_val, cnt, n_pairs);
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, cursor, d.d_sae);
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, cursor, d.d_sae,
+                           out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const float*)out->topk_val, cursor, pairs, n_pairs);
         PV_LAUNCH_CHECK("csr kernels");
-        const dim3 gridf((d.d_sae + 3) / 4);
+        // rows are zeroed first: features with no active pair keep a zero gradient (this IS zero_grad), and
+        // features whose pair list spans several waves accumulate through atomics
+        PV_HIP_CHECK(hipMemsetAsync(st->gW_dec, 0, (size_t)d.d_sae * d.d_in * 4, stream));
+        PV_HIP_CHECK(hipMemsetAsync(st->gW_enc, 0, (size_t)d.d_sae * d.d_in * 4, stream));
+        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)d.d_sae * 4, stream));
+        const int n_waves = (n_pairs + BWD_CH - 1) / BWD_CH;
+        const dim3 gridf((n_waves + 3) / 4);
 #define CALL(D)                                                                                                        \
-    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, pairs,                \
-                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, st->gW_dec, \
-                       st->gW_enc, st->gb_enc, st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, d.d_in, k, update_stats)
+    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const int32_t*)pairs, \
+                       (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, (const float*)dY, \
+                       (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae, d.d_in, k)
         DPL_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
+        hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
+                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, update_stats);
         // gb_dec = colsum(dY) - W_enc @ gb_enc
         const int nblk = (N + 63) / 64;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);

@@ -1,0 +1,116 @@
+"""SAE half of the headline metric: train-step tokens/s (BASELINE.json configs[2] / [3]).
+
+Step-only measurement: batches are pre-staged in HBM (``randn(4096, 768) * 3 + per-dim offset``), a
+step is the full reference ``train_step`` (renorm decoder -> forward -> stats -> backward -> clip ->
+project -> Adam), fp32 master weights, d_in = 768, d_sae = 24576 (32x), top-k = 32.
+With a process group the GLOBAL batch stays 4096 tokens (strong scaling): each rank takes 4096 / W
+tokens, gradients are summed with ONE RCCL all-reduce over the flat gradient buffer.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from ..synth import synth_sae_batch, synth_sae_state
+from .native_sae import NativeSAE
+
+D_IN, D_SAE, TOPK, N_TOKENS = 768, 24576, 32, 4096
+PEAK_HBM_GBS = 8000.0
+PEAK_F32_TFLOPS = 157.3
+
+
+def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, cpu_seconds: float = 10.0) -> dict:
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    sd = synth_sae_state(D_IN, D_SAE, 0)
+    T = {k: torch.from_numpy(v.copy()).to(dev) for k, v in sd.items()}
+    n_local = N_TOKENS // world
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], TOPK, True, n_local)
+    batches = [torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=i)).to(dev)[rank * n_local:(rank + 1) * n_local].contiguous()
+               for i in range(4)]
+
+    def step(x: torch.Tensor) -> None:
+        eng.renorm_decoder()
+        if dist is None:
+            eng.step(x)
+        else:
+            bm = x.sum(dim=0)
+            dist.all_reduce(bm)                       # 768 floats: global batch mean for the loss normaliser
+            eng.step(x, batch_mean=bm / N_TOKENS, n_global=N_TOKENS, update_stats=False)
+            dist.all_reduce(eng.flat_g)               # ONE collective: 37.77 M fp32 gradients over xGMI
+        eng.grad_sqnorm()
+        eng.apply(1e-3, 1.0)
+
+    for i in range(warmup):
+        step(batches[i % 4])
+    torch.cuda.synchronize(dev)
+    N.prof_reset()
+    N.prof_enable(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(batches[i % 4])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    N.prof_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(eng.scalars[0].item())
+    enc = N.prof_read("sae_encode_topk")
+    bwd = N.prof_read("sae_backward")
+    app = N.prof_read("sae_apply")
+    ms_step = elapsed / steps * 1e3
+    # algorithmic HBM bytes of one step: Adam 7 x params + W_enc / W_dec reads + x / out
+    n_params = 2 * D_IN * D_SAE + D_SAE + D_IN
+    alg_bytes = 7 * 4 * n_params + 2 * 4 * D_IN * D_SAE + 2 * 4 * N_TOKENS * D_IN
+    res = {
+        "metric": "SAE train-step tokens/sec (step-only, batches resident in HBM)",
+        "value": round(N_TOKENS * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_step, 3), "scaling": "strong" if world > 1 else "n/a", "dtype": "f32",
+        "config": {"workload": f"top-k SAE 768 -> 24576 (32x), k=32, global batch {N_TOKENS} tokens, Adam, clip 1.0",
+                   "tokens_per_gpu_per_step": n_local},
+        "final_loss": loss,
+        "roofline": {"kernel": "whole step vs algorithmic HBM bytes (Adam 7x params + weight reads)", "bound": "hbm",
+                     "achieved": round(alg_bytes / (ms_step * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None},
+        "kernels": {
+            "encode_gemm_topk": {"avg_us": round(enc["ms"] * 1e3 / max(enc["launches"], 1), 1),
+                                 "gemm_TFLOPs_incl_topk": round(enc["flops"] / max(enc["ms"], 1e-9) / 1e9, 1),
+                                 "peak_TFLOPs_f32_mfma": PEAK_F32_TFLOPS},
+            "decode_csr_backward": {"avg_us": round(bwd["ms"] * 1e3 / max(bwd["launches"], 1), 1)},
+            "clip_project_adam": {"avg_us": round(app["ms"] * 1e3 / max(app["launches"], 1), 1),
+                                  "GBps": round(app["bytes"] / max(app["ms"], 1e-9) / 1e6, 1)},
+        },
+    }
+    if rank == 0 and world == 1 and cpu_seconds > 0:
+        res["cpu_baseline"] = _cpu_baseline(cpu_seconds)
+    return res
+
+
+def _cpu_baseline(seconds: float) -> dict:
+    """The oracle's full train step (numpy port of the reference algorithm) on the host cores."""
+    import os
+    from oracle import sae_oracle as O
+    P = {k: v.copy() for k, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    x = synth_sae_batch(N_TOKENS, D_IN, seed=0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(P, opt, stats, x, TOPK, lr=1e-3, step=n + 1)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 8:
+            break
+    return {"value": N_TOKENS * n / dt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} full train steps of {N_TOKENS} tokens, fp32 numpy oracle, {dt:.1f} s"}

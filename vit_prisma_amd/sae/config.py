@@ -1,0 +1,238 @@
+"""VisionModelSAERunnerConfig -- field-compatible with the reference's runner config
+(/root/reference/src/vit_prisma/sae/config.py:287-663): same field names and defaults, same derived
+properties, same JSON ``save_config`` / ``load_config`` round trip, so existing SAE configs (python or
+JSON) drop in unchanged.  Two reference quirks are NOT reproduced because they are plain bugs:
+``num_patch`` needs ``math`` (never imported there, config.py:489-491) and the ``hook_point`` setter is
+ignored by the getter (:428-436) -- here a custom hook point set through the setter is honoured.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import logging
+import math
+import os
+from dataclasses import asdict, dataclass, field, fields
+from typing import Any, Literal, Optional
+
+import torch
+
+from ..configs import HookedViTConfig
+
+_TORCH_DTYPES = {
+    "float32": torch.float32, "float": torch.float32, "float64": torch.float64, "double": torch.float64,
+    "float16": torch.float16, "half": torch.float16, "bfloat16": torch.bfloat16,
+    "int64": torch.int64, "long": torch.int64, "int32": torch.int32, "int": torch.int32,
+    "int16": torch.int16, "short": torch.int16, "int8": torch.int8, "uint8": torch.uint8, "bool": torch.bool,
+}
+dtype_mapping = dict(_TORCH_DTYPES)
+dtype_mapping.update({"torch." + k: v for k, v in _TORCH_DTYPES.items()})
+
+
+@dataclass
+class VisionModelSAERunnerConfig:
+    # ---- which activations ----
+    model_class_name: str = "HookedViT"
+    model_name: str = "open-clip:laion/CLIP-ViT-B-32-DataComp.XL-s13B-b90K"
+    vit_model_cfg: Optional[HookedViTConfig] = None
+    model_path: str = None
+    hook_point_layer: int = 9
+    layer_subtype: str = "ln2.hook_normalized"
+    hook_point_head_index: Optional[int] = None
+    context_size: int = 50
+    use_cached_activations: bool = False
+    use_patches_only: bool = False
+    cached_activations_path: Optional[str] = None
+    image_size: int = 224
+    architecture: Literal["standard", "gated", "jumprelu"] = "standard"
+    # ---- SAE ----
+    b_dec_init_method: str = "geometric_median"
+    expansion_factor: int = 16
+    from_pretrained_path: Optional[str] = None
+    # ---- transcoder (not on the MI355X hot path) ----
+    is_transcoder: bool = False
+    transcoder_with_skip_connection: bool = True
+    out_hook_point_layer: int = 9
+    layer_out_subtype: str = "hook_mlp_out"
+    d_out: int = 768
+    # ---- misc ----
+    _device: str = "cuda"
+    seed: int = 42
+    _dtype: str = "float32"
+    d_in: int = 768
+    activation_fn_str: str = "topk"
+    activation_fn_kwargs: dict = field(default_factory=dict)
+    cls_token_only: bool = False
+    max_grad_norm: float = 1.0
+    initialization_method: str = "independent"
+    normalize_activations: str = "layer_norm"
+    is_training = True
+    # ---- activation store ----
+    n_batches_in_buffer: int = 20
+    store_batch_size: int = 32
+    num_workers: int = 16
+    num_epochs: int = 1
+    verbose: bool = False
+    # ---- optimisation ----
+    l1_coefficient: float = 0.0002
+    lp_norm: float = 1
+    lr: float = 0.001
+    lr_scheduler_name: str = "cosineannealingwarmup"
+    lr_warm_up_steps: int = 500
+    train_batch_size: int = 1024 * 4
+    min_l0 = None
+    min_explained_variance = None
+    # ---- dataset ----
+    dataset_name: str = "imgnet"
+    dataset_path: str = "/network/scratch/s/sonia.joseph/datasets/kaggle_datasets"
+    dataset_train_path: str = "/network/scratch/s/sonia.joseph/datasets/kaggle_datasets/ILSVRC/Data/CLS-LOC/train"
+    dataset_val_path: str = "/network/scratch/s/sonia.joseph/datasets/kaggle_datasets/ILSVRC/Data/CLS-LOC/val"
+    # ---- resampling ----
+    use_ghost_grads: bool = False
+    feature_sampling_window: int = 1000
+    dead_feature_window: int = 5000
+    dead_feature_threshold: float = 1e-8
+    # ---- logging / checkpoints ----
+    log_to_wandb: bool = True
+    wandb_project: str = "tinyclip_sae_16_hyperparam_sweep_lr"
+    wandb_entity: Optional[str] = None
+    wandb_log_frequency: int = 10
+    n_validation_runs: int = 0
+    n_checkpoints: int = 10
+    checkpoint_path: str = "/network/scratch/p/praneet.suresh/open_clip_celeba_checkpoints/"
+
+    # ---- derived ----------------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return torch.device(self._device) if isinstance(self._device, str) else self._device
+
+    @device.setter
+    def device(self, value) -> None:
+        self._device = value
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return dtype_mapping[self._dtype]
+
+    @dtype.setter
+    def dtype(self, value) -> None:
+        self._dtype = value
+
+    @property
+    def hook_point(self) -> str:
+        custom = getattr(self, "_custom_hook_point", None)
+        return custom if custom else f"blocks.{self.hook_point_layer}.{self.layer_subtype}"
+
+    @hook_point.setter
+    def hook_point(self, value) -> None:
+        self._custom_hook_point = value
+
+    @property
+    def out_hook_point(self) -> str:
+        return f"blocks.{self.out_hook_point_layer}.{self.layer_out_subtype}"
+
+    def _tokens_per_image(self) -> int:
+        if self.cls_token_only:
+            return 1
+        return self.context_size - 1 if self.use_patches_only else self.context_size
+
+    @property
+    def tokens_per_buffer(self) -> int:
+        return self.train_batch_size * self._tokens_per_image() * self.n_batches_in_buffer
+
+    @property
+    def total_training_images(self) -> int:
+        return int(1_300_000 * self.num_epochs)            # config.py:472-481 hard-codes ImageNet-1k
+
+    @property
+    def total_training_tokens(self) -> int:
+        return self.total_training_images * self._tokens_per_image()
+
+    @property
+    def total_training_steps(self) -> int:
+        return self.total_training_tokens // self.train_batch_size
+
+    @property
+    def d_sae(self) -> int:
+        return self.d_in * self.expansion_factor
+
+    @property
+    def num_patch(self) -> int:
+        return int(math.sqrt(self.context_size - 1))
+
+    def __post_init__(self):
+        if self.b_dec_init_method not in ("geometric_median", "mean", "zeros"):
+            raise ValueError(f"b_dec_init_method must be geometric_median, mean, or zeros. Got {self.b_dec_init_method}")
+        if self.b_dec_init_method == "zeros":
+            logging.warning("Warning: We are initializing b_dec to zeros. This is probably not what you want.")
+        if self.cls_token_only and self.use_patches_only:
+            raise ValueError("cls_token_only and use_patches_only are exclusive.")
+        if self.cached_activations_path is None:
+            path = f"activations/{self.dataset_path.replace('/', '_')}/{self.model_name.replace('/', '_')}/{self.hook_point}"
+            if self.hook_point_head_index is not None:
+                path += f"_{self.hook_point_head_index}"
+            self.cached_activations_path = path
+        if os.getenv("EVAL_MODE", "false").lower() in {"true", "1"}:
+            self.is_training = False
+        logging.info(f"Total training steps: {self.total_training_steps}; expansion factor: {self.expansion_factor}; "
+                     f"SAE initialization method: {self.initialization_method}")
+
+    # ---- JSON round trip ------------------------------------------------------------------------
+    def is_property(self, attr_name: str) -> bool:
+        return isinstance(getattr(self.__class__, attr_name, None), property)
+
+    def save_config(self, path: str) -> None:
+        def clean(obj: Any) -> Any:
+            if inspect.isdatadescriptor(obj):
+                return None
+            if isinstance(obj, (list, tuple)):
+                return [clean(o) for o in obj]
+            if isinstance(obj, dict):
+                return {k: clean(v) for k, v in obj.items() if not self.is_property(k)}
+            if isinstance(obj, (torch.dtype, torch.device)):
+                return str(obj)
+            return obj
+
+        data = clean(asdict(self))
+        data["_dtype"] = self._dtype
+        data["_device"] = str(self._device)
+        with open(path, "w") as f:
+            json.dump(data, f, indent=4)
+
+    @classmethod
+    def load_config(cls, path: str) -> "VisionModelSAERunnerConfig":
+        with open(path, "r") as f:
+            data = json.load(f)
+
+        def restore(obj: Any) -> Any:
+            if isinstance(obj, dict):
+                if "__type__" in obj:
+                    return obj["value"]
+                return {k: restore(v) for k, v in obj.items()}
+            if isinstance(obj, list):
+                return [restore(o) for o in obj]
+            return obj
+
+        data = restore(data)
+        for legacy in ("total_training_images", "total_training_tokens", "d_sae"):
+            if legacy in data:
+                logging.warning(f"Deprecated field '{legacy}' found in config. It will be ignored.")
+                del data[legacy]
+        known = {f.name for f in fields(cls)}
+        kw = {k: v for k, v in data.items() if k in known}
+        if isinstance(kw.get("vit_model_cfg"), dict):
+            vc = dict(kw["vit_model_cfg"])
+            if isinstance(vc.get("dtype"), str):
+                vc["dtype"] = dtype_mapping.get(vc["dtype"], torch.float32)
+            kw["vit_model_cfg"] = HookedViTConfig(**{k: v for k, v in vc.items() if k in {f.name for f in fields(HookedViTConfig)}})
+        return cls(**kw)
+
+    def pretty_print(self) -> None:
+        print("Configuration:")
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if isinstance(v, torch.dtype):
+                v = str(v).split(".")[-1]
+            elif isinstance(v, torch.device):
+                v = str(v)
+            print(f"  {f.name}: {v}")

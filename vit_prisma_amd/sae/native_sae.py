@@ -1,0 +1,148 @@
+"""Host driver of the native SAE train step (pv_sae_* in include/pv_native.h).
+
+All state lives in caller-owned torch tensors (plumbing): fp32 master parameters are the SAE
+module's own ``nn.Parameter`` storage, gradients sit in ONE flat buffer (so the data-parallel
+all-reduce and the clip-norm pass are one call each), Adam moments in two flat buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from .. import _native as N
+
+
+class NativeSAE:
+    def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
+                 layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5):
+        for t in (W_enc, W_dec, b_enc, b_dec):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise N.NativeError("native SAE needs contiguous fp32 CUDA parameters")
+        self.lib = N.lib()
+        self.device = W_enc.device
+        self.d_in, self.d_sae = W_enc.shape
+        assert tuple(W_dec.shape) == (self.d_sae, self.d_in)
+        self.k = int(k)
+        self.max_tokens = int(max_tokens)
+        self.params = dict(W_enc=W_enc, W_dec=W_dec, b_enc=b_enc, b_dec=b_dec)
+        desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
+                         max_tokens=self.max_tokens, ln_eps=ln_eps)
+        self._plan = C.c_void_p()
+        N.check(self.lib.pv_sae_plan_create(C.byref(desc), C.byref(self._plan)), "pv_sae_plan_create")
+        dev = self.device
+        nW = self.d_in * self.d_sae
+        self.n_flat = 2 * nW + self.d_sae + self.d_in
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self.n_flat, **f32)
+        self.flat_m = torch.zeros(self.n_flat, **f32)
+        self.flat_v = torch.zeros(self.n_flat, **f32)
+
+        def views(flat: torch.Tensor, enc_transposed: bool) -> Dict[str, torch.Tensor]:
+            o = 0
+            out = {}
+            out["W_enc"] = flat[o:o + nW].view((self.d_sae, self.d_in) if enc_transposed else (self.d_in, self.d_sae)); o += nW
+            out["W_dec"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
+            out["b_enc"] = flat[o:o + self.d_sae]; o += self.d_sae
+            out["b_dec"] = flat[o:o + self.d_in]
+            return out
+
+        self.g = views(self.flat_g, True)        # NB: g["W_enc"] is the TRANSPOSED gradient [d_sae, d_in]
+        self.m = views(self.flat_m, False)
+        self.v = views(self.flat_v, False)
+        self.act_freq_scores = torch.zeros(self.d_sae, **f32)
+        self.n_fwd_since_fired = torch.zeros(self.d_sae, **f32)
+        self.fire_count = torch.zeros(self.d_sae, **f32)
+        self.scalars = torch.zeros(8, **f32)
+        self.sq_partial = torch.zeros(1024, **f32)
+        self.topk_idx = torch.zeros(self.max_tokens, self.k, dtype=torch.int32, device=dev)
+        self.topk_val = torch.zeros(self.max_tokens, self.k, **f32)
+        self.sae_out = torch.zeros(self.max_tokens, self.d_in, **f32)
+        self.workspace = torch.empty(self.lib.pv_sae_workspace_bytes(self._plan), dtype=torch.uint8, device=dev)
+        self.adam_step = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None) is not None and self._plan.value:
+                self.lib.pv_sae_plan_destroy(self._plan)
+                self._plan = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _state(self) -> N.SaeState:
+        P, g, m, v = self.params, self.g, self.m, self.v
+        return N.SaeState(
+            W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(), b_dec=P["b_dec"].data_ptr(),
+            gW_enc=g["W_enc"].data_ptr(), gW_dec=g["W_dec"].data_ptr(), gb_enc=g["b_enc"].data_ptr(), gb_dec=g["b_dec"].data_ptr(),
+            mW_enc=m["W_enc"].data_ptr(), mW_dec=m["W_dec"].data_ptr(), mb_enc=m["b_enc"].data_ptr(), mb_dec=m["b_dec"].data_ptr(),
+            vW_enc=v["W_enc"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
+            act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr())
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check_x(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        if x.ndim != 2 or x.shape[1] != self.d_in or x.shape[0] > self.max_tokens or x.device != self.device:
+            raise ValueError(f"expected [N<={self.max_tokens}, {self.d_in}] on {self.device}, got {tuple(x.shape)} on {x.device}")
+        return x
+
+    def renorm_decoder(self) -> None:
+        st = self._state()
+        N.check(self.lib.pv_sae_renorm_decoder(self._plan, C.byref(st), self._stream()), "pv_sae_renorm_decoder")
+
+    def step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
+             update_stats: bool = True, want_out: bool = False) -> None:
+        """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
+        loss, mse_loss, l0 (device)."""
+        x = self._check_x(x)
+        n = x.shape[0]
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=self.topk_idx.data_ptr(),
+                       topk_val=self.topk_val.data_ptr(), scalars=self.scalars.data_ptr(),
+                       fire_count=self.fire_count.data_ptr())
+        bm = None
+        if batch_mean is not None:
+            bm = batch_mean.to(torch.float32).contiguous()
+        N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                     int(n_global if n_global is not None else n), int(update_stats), C.byref(out),
+                                     self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_step")
+
+    def grad_sqnorm(self) -> None:
+        N.check(self.lib.pv_sae_grad_sqnorm(self.flat_g.data_ptr(), self.n_flat, self.sq_partial.data_ptr(),
+                                            self.scalars.data_ptr(), self._stream()), "pv_sae_grad_sqnorm")
+
+    def apply(self, lr: float, max_grad_norm: Optional[float]) -> None:
+        self.adam_step += 1
+        st = self._state()
+        N.check(self.lib.pv_sae_apply(self._plan, C.byref(st), self.scalars.data_ptr(),
+                                      float(max_grad_norm) if max_grad_norm else -1.0, float(lr), self.adam_step,
+                                      self._stream()), "pv_sae_apply")
+
+    def encode_topk(self, x: torch.Tensor):
+        """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts."""
+        x = self._check_x(x)
+        n = x.shape[0]
+        st = self._state()
+        mu = torch.empty(n, dtype=torch.float32, device=self.device)
+        sd = torch.empty(n, dtype=torch.float32, device=self.device)
+        N.check(self.lib.pv_sae_encode_topk(self._plan, C.byref(st), x.data_ptr(), n, self.topk_idx.data_ptr(),
+                                            self.topk_val.data_ptr(), mu.data_ptr(), sd.data_ptr(),
+                                            self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
+                "pv_sae_encode_topk")
+        return self.topk_idx[:n], self.topk_val[:n], mu, sd
+
+    # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
+    def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:
+        self.renorm_decoder()
+        self.step(x)
+        self.grad_sqnorm()
+        self.apply(lr, max_grad_norm)
+
+    def grad_W_enc(self) -> torch.Tensor:
+        """Gradient of W_enc in the parameter's own [d_in, d_sae] layout (a transposed view)."""
+        return self.g["W_enc"].t()

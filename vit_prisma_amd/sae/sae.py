@@ -1,0 +1,257 @@
+"""Sparse autoencoders behind the reference's module API.
+
+Drop-in for /root/reference/src/vit_prisma/sae/sae.py: ``SparseAutoencoder`` (:29-533),
+``StandardSparseAutoencoder`` (:535-645), ``TopK`` (:795-810), ``get_activation_fn`` (:813-839):
+same parameter names / layouts (``W_enc [d_in,d_sae]``, ``W_dec [d_sae,d_in]``, ``b_enc``, ``b_dec``),
+same HookPoints, same 7-tuple from ``forward``.
+
+The module's ``forward`` is the faithful PyTorch implementation (hooks, autograd, every activation /
+normalisation variant).  Training on an MI355X does not go through it: ``VisionSAETrainer`` drives
+``native_sae.NativeSAE`` (HIP kernels) directly on this module's parameter storage.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import pickle
+from abc import ABC, abstractmethod
+from typing import Any, Callable, Optional
+
+import torch
+from torch import nn
+
+from ..hook_points import HookPoint
+from ..hooked_root_module import HookedRootModule
+from .config import VisionModelSAERunnerConfig
+
+
+class TopK(nn.Module):
+    """Keep the k largest pre-activations per row, apply ``postact_fn`` (ReLU), zero the rest."""
+
+    def __init__(self, k: int, postact_fn: Callable[[torch.Tensor], torch.Tensor] = nn.ReLU()):
+        super().__init__()
+        self.k = k
+        self.postact_fn = postact_fn
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        top = torch.topk(x, k=self.k, dim=-1)
+        out = torch.zeros_like(x)
+        out.scatter_(-1, top.indices, self.postact_fn(top.values))
+        return out
+
+
+def get_activation_fn(activation_fn: str, **kwargs: Any) -> Callable[[torch.Tensor], torch.Tensor]:
+    if activation_fn == "relu":
+        return nn.ReLU()
+    if activation_fn == "tanh-relu":
+        return lambda x: torch.tanh(torch.relu(x))
+    if activation_fn == "topk":
+        assert "k" in kwargs, "TopK activation function requires a k value."
+        return TopK(kwargs.get("k", 64), kwargs.get("postact_fn", nn.ReLU()))
+    raise ValueError(f"Unknown activation function: {activation_fn}")
+
+
+class SparseAutoencoder(HookedRootModule, ABC):
+    def __init__(self, cfg: VisionModelSAERunnerConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.d_in = cfg.d_in
+        if not isinstance(self.d_in, int):
+            raise ValueError(f"d_in must be an int but was {self.d_in}; {type(self.d_in)}")
+        assert cfg.d_sae is not None
+        self.d_sae = cfg.d_sae
+        self.l1_coefficient = cfg.l1_coefficient
+        self.lp_norm = cfg.lp_norm
+        self.dtype = cfg.dtype
+        self.device = cfg.device
+        self.initialization_method = cfg.initialization_method
+        self.zero_loss = torch.tensor(0.0, dtype=self.dtype, device=self.device)
+        self.initialize_sae_weights()
+        self.hook_sae_in = HookPoint()
+        self.hook_hidden_pre = HookPoint()
+        self.hook_hidden_post = HookPoint()
+        self.hook_sae_out = HookPoint()
+        self.activation_fn = get_activation_fn(cfg.activation_fn_str, **cfg.activation_fn_kwargs)
+        self.setup()
+
+    # ---- run-time input normalisation (sae.py:59-96) --------------------------------------------
+    def run_time_activation_norm_fn_in(self, x: torch.Tensor) -> torch.Tensor:
+        mode = self.cfg.normalize_activations
+        if mode == "constant_norm_rescale":
+            self.x_norm_coeff = (self.cfg.d_in ** 0.5) / x.norm(dim=-1, keepdim=True)
+            return x * self.x_norm_coeff
+        if mode == "layer_norm":
+            mu = x.mean(dim=-1, keepdim=True)
+            x = x - mu
+            std = x.std(dim=-1, keepdim=True)          # unbiased
+            self.ln_mu, self.ln_std = mu, std
+            return x / (std + 1e-5)
+        return x
+
+    def run_time_activation_norm_fn_out(self, x: torch.Tensor) -> torch.Tensor:
+        mode = self.cfg.normalize_activations
+        if mode == "constant_norm_rescale":
+            x = x / self.x_norm_coeff
+            del self.x_norm_coeff
+            return x
+        if mode == "layer_norm":
+            return x * self.ln_std + self.ln_mu
+        return x
+
+    def initialize_weights(self, out_features: int, in_features: int) -> torch.Tensor:
+        """Kaiming-uniform rows normalised to unit L2 norm (sae.py:104-130)."""
+        w = torch.empty(out_features, in_features, dtype=self.dtype, device=self.device)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        with torch.no_grad():
+            w /= torch.norm(w, dim=1, keepdim=True)
+        return w
+
+    @abstractmethod
+    def encode(self, x: torch.Tensor): ...
+
+    @abstractmethod
+    def decode(self, features: torch.Tensor): ...
+
+    @abstractmethod
+    def initialize_sae_weights(self): ...
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor, dead_neuron_mask: torch.Tensor = None): ...
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def _compute_mse_loss(self, x: torch.Tensor, sae_out: torch.Tensor) -> torch.Tensor:
+        """Per-token squared error normalised by ||x - mean_batch(x)||_2, averaged over everything
+        (sae.py:144-149)."""
+        centred = x - x.mean(dim=0, keepdim=True)
+        err = torch.nn.functional.mse_loss(sae_out, x.detach(), reduction="none")
+        return (err / torch.norm(centred, p=2, dim=-1, keepdim=True)).mean()
+
+    def _compute_ghost_residual_loss(self, x, sae_out, hidden_pre, dead_neuron_mask) -> torch.Tensor:
+        """Ghost gradients (sae.py:151-179); PyTorch path only."""
+        residual = x - sae_out
+        residual_centred = residual - residual.mean(dim=0, keepdim=True)
+        l2_resid = torch.norm(residual, dim=-1)
+        dead_acts = torch.exp(hidden_pre[:, dead_neuron_mask])
+        ghost_out = dead_acts @ self.W_dec[dead_neuron_mask, :]
+        scale = l2_resid / (1e-6 + torch.norm(ghost_out, dim=-1) * 2)
+        ghost_out = ghost_out * scale[:, None].detach()
+        ghost = torch.pow(ghost_out - residual.detach().float(), 2) / (residual_centred.detach() ** 2).sum(dim=-1, keepdim=True).sqrt()
+        rescale = (self._compute_mse_loss(x, sae_out) / (ghost + 1e-6)).detach()
+        return (rescale * ghost).mean()
+
+    # ---- decoder bias initialisation (sae.py:181-242) -------------------------------------------
+    @torch.no_grad()
+    def initialize_b_dec_with_precalculated(self, origin: torch.Tensor, transcoder_dec_b: torch.Tensor = None):
+        self.b_dec.data = origin.clone().detach().to(dtype=self.dtype, device=self.device)
+
+    @torch.no_grad()
+    def initialize_b_dec_with_mean(self, all_activations: torch.Tensor):
+        self.b_dec.data = all_activations.mean(dim=0).to(self.dtype).to(self.device)
+
+    @torch.no_grad()
+    def initialize_b_dec(self, all_activations: torch.Tensor):
+        method = self.cfg.b_dec_init_method
+        if method == "geometric_median":
+            from .geometric_median import compute_geometric_median
+            self.initialize_b_dec_with_precalculated(compute_geometric_median(all_activations, maxiter=100).median)
+        elif method == "mean":
+            self.initialize_b_dec_with_mean(all_activations)
+        elif method != "zeros":
+            raise ValueError(f"Unexpected b_dec_init_method: {method}")
+
+    # ---- decoder constraints (sae.py:275-297) ---------------------------------------------------
+    @torch.no_grad()
+    def set_decoder_norm_to_unit_norm(self):
+        self.W_dec.data /= torch.norm(self.W_dec.data, dim=1, keepdim=True)
+
+    @torch.no_grad()
+    def remove_gradient_parallel_to_decoder_directions(self):
+        parallel = (self.W_dec.grad * self.W_dec.data).sum(dim=1, keepdim=True)
+        self.W_dec.grad -= parallel * self.W_dec.data
+
+    # ---- persistence (sae.py:299-320, 410-528: the pickled {"cfg", "state_dict"} format) --------
+    def save_model(self, path: str):
+        folder = os.path.dirname(path)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        blob = {"cfg": self.cfg, "state_dict": self.state_dict()}
+        if path.endswith(".pt"):
+            torch.save(blob, path)
+        elif path.endswith(".pkl.gz"):
+            import gzip
+            with gzip.open(path, "wb") as f:
+                pickle.dump(blob, f)
+        else:
+            raise ValueError(f"Unexpected file extension: {path}, supported extensions are .pt and .pkl.gz")
+        logging.info(f"Saved model to {path}")
+
+    @classmethod
+    def load_from_pretrained(cls, weights_path: str, config_path: Optional[str] = None, current_cfg=None):
+        if not os.path.isfile(weights_path):
+            raise FileNotFoundError(f"No file found at specified path: {weights_path}")
+        if weights_path.endswith(".pkl.gz"):
+            import gzip
+            with gzip.open(weights_path, "rb") as f:
+                blob = pickle.load(f)
+        else:
+            blob = torch.load(weights_path, map_location="cpu", weights_only=False)
+        if isinstance(blob, dict) and "state_dict" in blob:
+            state_dict = blob["state_dict"]
+            cfg = blob.get("cfg") or blob.get("config")
+        else:
+            state_dict, cfg = blob, None
+        if config_path is not None:
+            cfg = VisionModelSAERunnerConfig.load_config(config_path)
+        if cfg is None:
+            raise ValueError("no config found: pass config_path for split weights/config checkpoints")
+        if current_cfg is not None:
+            cfg.device = current_cfg.device
+        inst = cls(cfg)
+        inst.load_state_dict(state_dict)
+        return inst
+
+    def get_name(self) -> str:
+        return f"sparse_autoencoder_{self.cfg.model_name}_{self.cfg.hook_point}_{self.cfg.d_sae}"
+
+
+class StandardSparseAutoencoder(SparseAutoencoder):
+    def initialize_sae_weights(self):
+        self.W_dec = nn.Parameter(self.initialize_weights(self.d_sae, self.d_in))
+        if self.initialization_method == "independent":
+            self.W_enc = nn.Parameter(self.initialize_weights(self.d_in, self.d_sae))
+        elif self.initialization_method == "encoder_transpose_decoder":
+            self.W_enc = nn.Parameter(self.W_dec.data.t().clone())
+        else:
+            raise ValueError(f"Unknown initialization method: {self.initialization_method}")
+        self.b_enc = nn.Parameter(torch.zeros(self.d_sae, dtype=self.dtype, device=self.device))
+        self.b_dec = nn.Parameter(torch.zeros(self.d_in, dtype=self.dtype, device=self.device))
+
+    def encode(self, x: torch.Tensor, return_hidden_pre: bool = False):
+        x = x.to(self.dtype)
+        sae_in = self.hook_sae_in(self.run_time_activation_norm_fn_in(x) - self.b_dec)
+        hidden_pre = self.hook_hidden_pre(sae_in @ self.W_enc + self.b_enc)
+        feature_acts = self.hook_hidden_post(self.activation_fn(hidden_pre))
+        if return_hidden_pre:
+            return sae_in, feature_acts, hidden_pre
+        return sae_in, feature_acts
+
+    def decode(self, features: torch.Tensor) -> torch.Tensor:
+        sae_out = self.hook_sae_out(features @ self.W_dec + self.b_dec)
+        return self.run_time_activation_norm_fn_out(sae_out)
+
+    def forward(self, x: torch.Tensor, dead_neuron_mask: torch.Tensor = None, *args, **kwargs):
+        _, feature_acts, hidden_pre = self.encode(x, return_hidden_pre=True)
+        sae_out = self.decode(feature_acts)
+        mse_loss = self._compute_mse_loss(x, sae_out)
+        if self.cfg.use_ghost_grads and self.training and dead_neuron_mask is not None:
+            ghost = self._compute_ghost_residual_loss(x, sae_out, hidden_pre, dead_neuron_mask)
+        else:
+            ghost = self.zero_loss
+        sparsity = feature_acts.norm(p=self.lp_norm, dim=1).mean(dim=(0,))
+        l1_loss = self.l1_coefficient * sparsity if self.cfg.activation_fn_str != "topk" else None
+        loss = mse_loss + (l1_loss if l1_loss is not None else 0) + ghost
+        aux = torch.tensor(0.0)
+        if getattr(self.cfg, "return_out_only", False):
+            return sae_out
+        return sae_out, feature_acts, loss, mse_loss, l1_loss, ghost, aux

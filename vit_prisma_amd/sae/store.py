@@ -1,0 +1,154 @@
+"""VisionActivationsStore: streams images through the ViT and serves shuffled token batches.
+
+Same constructor, attributes and buffer algorithm as the reference's
+/root/reference/src/vit_prisma/sae/training/activations_store.py:176-503 (half-buffer shuffle-mix,
+inner DataLoader of ``[train_batch_size, n_layers, d_in]`` batches).  The producer call is
+``model.run_with_cache(batch, names_filter=[hook_point...], stop_at_layer=L+1)`` under ``no_grad`` --
+on an MI355X that dispatches to the native HIP plan, which runs only blocks 0..L and writes the single
+requested activation straight into the tap slab.
+
+Data-parallel harvesting: with ``torch.distributed`` initialised every rank
+draws a disjoint shard of each epoch's images (DistributedSampler) and fills its own local buffer; no
+collective is involved in harvesting.
+"""
+from __future__ import annotations
+
+from typing import Any, Iterator, List, Optional
+
+import torch
+from torch.utils.data import DataLoader
+
+
+def collate_fn(data):
+    return torch.stack([d[0] for d in data], dim=0)
+
+
+def collate_fn_eval(data):
+    return torch.stack([d[0] for d in data], dim=0), torch.tensor([d[1] for d in data])
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class VisionActivationsStore:
+    def __init__(self, cfg, model, dataset, create_dataloader: bool = True, eval_dataset=None, num_workers: int = 0):
+        self.cfg = cfg
+        self.model = model.to(cfg.device)
+        self.dataset = dataset
+        if hasattr(self.model, "freeze_native_weights"):
+            self.model.freeze_native_weights(True)          # the ViT is constant while harvesting
+        rank, world = _dist_info()
+        sampler = None
+        if world > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+        self.image_dataloader = DataLoader(dataset, shuffle=sampler is None, sampler=sampler, num_workers=num_workers,
+                                           batch_size=cfg.store_batch_size, collate_fn=collate_fn, drop_last=True)
+        if eval_dataset is not None:
+            self.image_dataloader_eval = DataLoader(eval_dataset, shuffle=True, num_workers=num_workers,
+                                                    batch_size=cfg.store_batch_size, collate_fn=collate_fn_eval,
+                                                    drop_last=True)
+            self.image_dataloader_eval_iter = self._eval_batch_stream(self.image_dataloader_eval, cfg.device)
+        self.image_dataloader_iter = self._batch_stream(self.image_dataloader, cfg.device)
+        if create_dataloader:
+            if cfg.is_transcoder:
+                raise NotImplementedError("transcoder buffers are outside the MI355X hot path")
+            self.storage_buffer = self.get_buffer(cfg.n_batches_in_buffer)
+            self.dataloader = self.get_data_loader()
+
+    # ---- image streams ----------------------------------------------------------------------------
+    def _batch_stream(self, dataloader: DataLoader, device) -> Iterator[torch.Tensor]:
+        epoch = 0
+        while True:
+            if hasattr(dataloader.sampler, "set_epoch"):
+                dataloader.sampler.set_epoch(epoch)
+            for batch in dataloader:
+                batch.requires_grad_(False)
+                yield batch.to(device, non_blocking=True)
+            epoch += 1
+
+    def _eval_batch_stream(self, dataloader: DataLoader, device):
+        while True:
+            for images, labels in dataloader:
+                yield images.to(device), labels.to(device)
+
+    # ---- harvesting -------------------------------------------------------------------------------
+    def _layers(self) -> List[int]:
+        hl = self.cfg.hook_point_layer
+        return list(hl) if isinstance(hl, list) else [hl]
+
+    @torch.no_grad()
+    def get_activations(self, batch_tokens: torch.Tensor) -> torch.Tensor:
+        """[B, ctx, n_layers, d_in] activations of the configured hook point(s)
+        (activations_store.py:251-296)."""
+        cfg = self.cfg
+        layers = self._layers()
+        if isinstance(cfg.hook_point_layer, list):
+            names = [cfg.hook_point.format(layer=layer) for layer in layers]
+        else:
+            names = [cfg.hook_point]
+        _, cache = self.model.run_with_cache(batch_tokens, names_filter=names, stop_at_layer=max(layers) + 1)
+        acts = []
+        for name in names:
+            a = cache[name]
+            if cfg.hook_point_head_index is not None:
+                a = a[:, :, cfg.hook_point_head_index]
+            if cfg.cls_token_only:
+                a = a[:, 0:1]
+            acts.append(a)
+        return torch.stack(acts, dim=2)
+
+    def get_buffer(self, n_batches_in_buffer: int) -> torch.Tensor:
+        """[bs * n_batches * ctx, n_layers, d_in], rows shuffled (activations_store.py:298-362)."""
+        cfg = self.cfg
+        bs = cfg.store_batch_size
+        total = bs * n_batches_in_buffer
+        n_layers = len(self._layers())
+        ctx = cfg.context_size
+        buf = torch.zeros((total, ctx, n_layers, cfg.d_in), dtype=cfg.dtype, device=cfg.device)
+        for start in range(0, total, bs):
+            acts = self.get_activations(next(self.image_dataloader_iter))
+            if cfg.use_patches_only:
+                acts = acts[:, 1:, :, :]
+            buf[start:start + bs, : acts.shape[1]] = acts
+        buf = buf.reshape(-1, n_layers, cfg.d_in)
+        return buf[torch.randperm(buf.shape[0], device=buf.device)]
+
+    def get_data_loader(self) -> Iterator[Any]:
+        """Mix a fresh half buffer into the stored one, keep half, serve the other half
+        (activations_store.py:445-492)."""
+        cfg = self.cfg
+        mix = torch.cat([self.get_buffer(cfg.n_batches_in_buffer // 2), self.storage_buffer], dim=0)
+        mix = mix[torch.randperm(mix.shape[0], device=mix.device)]
+        half = mix.shape[0] // 2
+        self.storage_buffer = mix[:half]
+        serve = mix[half:]
+        _, world = _dist_info()
+        local_bs = max(cfg.train_batch_size // world, 1)
+        return iter(_TensorBatches(serve, local_bs))
+
+    def next_batch(self) -> torch.Tensor:
+        try:
+            return next(self.dataloader)
+        except StopIteration:
+            self.dataloader = self.get_data_loader()
+            return next(self.dataloader)
+
+
+class _TensorBatches:
+    """Shuffled fixed-size batches of a device-resident tensor (what ``DataLoader(tensor,
+    batch_size, shuffle=True)`` yields in the reference, without the per-row Python collate; the last
+    partial batch is served too, like DataLoader's default ``drop_last=False``)."""
+
+    def __init__(self, data: torch.Tensor, batch_size: int):
+        self.data = data
+        self.batch_size = batch_size
+
+    def __iter__(self):
+        perm = torch.randperm(self.data.shape[0], device=self.data.device)
+        for i in range(0, self.data.shape[0], self.batch_size):
+            yield self.data[perm[i:i + self.batch_size]]
