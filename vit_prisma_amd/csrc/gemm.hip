@@ -495,6 +495,151 @@ int launch_v2(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v3 mainloop: operands go HBM/L2 -> LDS directly (buffer_load ... lds, 16 bytes per lane, 1 KiB per
+// wave-instruction), no VGPR staging and no ds_write: with 128 x 128 tiles the VGPR->LDS write path
+// (ds_write_b128, ~78 B/clk/CU) was the busiest unit of the CU (32 KB written per 2.1 MFLOP slab).
+// The LDS image must be lane-linear per instruction (rows of exactly 128 bytes, no padding), so bank
+// conflicts are avoided by an XOR swizzle applied on the SOURCE address: the 16-byte chunk stored at
+// position c of tile row r holds K-chunk c ^ ((r >> 1) & 7); fragment reads apply the same involution
+// (conflict-free for every 16-lane ds_read_b128 service group).  Rows past M / N and K-chunks past K
+// resolve to out-of-range buffer offsets, which the hardware returns as zeros.
+// ---------------------------------------------------------------------------------------------------
+constexpr int V3_TILE = 128 * 128;          // bytes per operand tile (128 rows x 128 bytes)
+constexpr int V3_STAGE = 2 * V3_TILE;       // A + B
+constexpr int V3_NSTAGE = 2;
+constexpr int V3_LDS = (V3_NSTAGE * V3_STAGE > 4 * 64 * CS_LD * 4) ? V3_NSTAGE * V3_STAGE : 4 * 64 * CS_LD * 4;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v3(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EB = DT<T>::kBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + SLAB - 1) / SLAB);
+    const bool ktail = (Kb % SLAB) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    // this lane's source chunk for the 4 (A) + 4 (B) wave-instructions of a slab
+    unsigned offA[4], offB[4], kcb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);         // tile row written by this lane
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);             // K-chunk that belongs at position lane & 7
+        kcb[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        const unsigned kbase = (unsigned)kt * SLAB;
+        unsigned char* Ab = smem + buf * V3_STAGE + wave * 4096;
+        unsigned char* Bb = Ab + V3_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned oa = offA[j] + kbase, ob = offB[j] + kbase;
+            if (kt >= nk || (ktail && kbase + kcb[j] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 1) & 7;                                // (row >> 1) & 7 of every row this lane reads
+    int co[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) co[j] = ((2 * j + half) ^ sw) * 16;
+    const int a_row = (wm * 64 + l31) * 128;
+    const int b_row = (wn * 64 + l31) * 128;
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = smem + buf * V3_STAGE;
+        const unsigned char* Bb = Ab + V3_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 a[2], b[2];
+            a[0] = *reinterpret_cast<const uint4*>(Ab + a_row + co[j]);
+            a[1] = *reinterpret_cast<const uint4*>(Ab + a_row + 32 * 128 + co[j]);
+            b[0] = *reinterpret_cast<const uint4*>(Bb + b_row + co[j]);
+            b[1] = *reinterpret_cast<const uint4*>(Bb + b_row + 32 * 128 + co[j]);
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+            } else {
+                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // the DMA of slab kt (issued one iteration ago) must have landed for EVERY wave, and every wave
+        // must be done reading the buffer slab kt+1 is about to overwrite: vmcnt(0) + barrier
+        __syncthreads();
+        issue(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+    }
+    __syncthreads();     // last reads done (and the off-the-end prefetch drained) before the staging reuse
+    tile_epilogue<T>(p, acc, smem, m0, n0, wave, lane, wm, wn);
+}
+
+template <typename T>
+int launch_v3(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_v3<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS));
+        attr_done = true;
+    }
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v3<T>), dim3(ntm * ntn), dim3(256), V3_LDS, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v3");
+    return PV_OK;
+}
+
 template <typename T, int AMODE, bool VEC, bool BKN = false>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -537,7 +682,12 @@ int dispatch(GemmParams& p, hipStream_t stream) {
     p.vec_out = vo ? 1 : 0;
     if (p.a_mode == PV_A_PLAIN && vec) {
         const uint64_t spanA = ((uint64_t)p.M + BM) * (uint64_t)p.lda * EB, spanB = ((uint64_t)p.N + BN) * (uint64_t)p.ldb * EB;
-        if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !getenv("PV_GEMM_V1")) return launch_v2<T>(p, stream);
+        if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !getenv("PV_GEMM_V1")) {
+            // v3 (direct-to-LDS DMA, 2 stages) measured 12.5 ms/step vs 11.1-11.4 ms for v2 on the bs=512
+            // B/32 forward (profiles/r01_notes.md): with only 2 stages the DMA has one slab of MFMA time to
+            // land; kept selectable for the 3-stage follow-up
+            return getenv("PV_GEMM_V3") ? launch_v3<T>(p, stream) : launch_v2<T>(p, stream);
+        }
     }
     if (p.a_mode == PV_A_PLAIN) {
         return vec ? launch<T, PV_A_PLAIN, true>(p, stream) : launch<T, PV_A_PLAIN, false>(p, stream);
