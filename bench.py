@@ -53,25 +53,86 @@ def parse():
 
 
 def cpu_baseline(seconds: float) -> dict:
-    """Oracle (port of the reference algorithm) on the host cores, same workload at bs=16
-    (images/s is flat in batch size on CPU)."""
+    """Oracle (port of the reference algorithm) on the host cores, same workload at bs=16 per worker
+    (images/s is flat in batch size on CPU).  numpy's elementwise kernels are
+    single-threaded, so the host is filled with several concurrent forwards (numpy releases the GIL)
+    each with a bounded BLAS thread pool; `cores` = worker threads x BLAS threads actually used."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle.vit_oracle import vit_forward
     from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
     arch = ARCHS["clip-vit-b32"]
     sd = synth_vit_state(arch, 0)
     imgs = synth_images(arch, 16, 1)
-    vit_forward(sd, arch, imgs)          # warm-up
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(16, ncpu // 4))
+    blas = max(1, min(8, ncpu // workers))
+
+    def one(_):
+        _, cache = vit_forward(sd, arch, imgs)
+        return len(cache)
+
+    def run():
+        vit_forward(sd, arch, imgs)          # warm-up
+        n, t0 = 0, time.perf_counter()
+        with ThreadPoolExecutor(workers) as ex:
+            while True:
+                assert all(k == 214 for k in ex.map(one, range(workers)))
+                n += workers
+                dt = time.perf_counter() - t0
+                if dt >= seconds or n >= 64 * workers:
+                    break
+        return n, dt
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=blas):
+            n, dt = run()
+    else:
+        n, dt = run()
+    return {"value": 16 * n / dt, "unit": "images/s", "cores": workers * blas, "kind": "port",
+            "sample": f"{n} x run_with_cache(all 214 hooks) of CLIP ViT-B/32 at bs=16, fp32 numpy oracle, {workers} concurrent "
+                      f"forwards x {blas} BLAS threads, {dt:.1f} s on a {ncpu}-thread host"}
+
+
+def sae_cpu_baseline(seconds: float) -> dict:
+    """The oracle's full SAE train step (numpy port of the reference algorithm) on the host cores."""
+    from oracle import sae_oracle as O
+    from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state
+    d_in, d_sae, k, n_tok = 768, 24576, 32, 4096
+    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    x = synth_sae_batch(n_tok, d_in, seed=0)
     n, t0 = 0, time.perf_counter()
     while True:
-        _, cache = vit_forward(sd, arch, imgs)
+        O.train_step(P, opt, stats, x, k, lr=1e-3, step=n + 1)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 64:
+        if dt >= seconds or n >= 8:
             break
-    assert len(cache) == 214
-    return {"value": 16 * n / dt, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} x run_with_cache(all 214 hooks) of CLIP ViT-B/32 at bs=16, fp32 numpy oracle, "
-                      f"{dt:.1f} s on {os.cpu_count()} host threads"}
+    return {"value": n_tok * n / dt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} full train steps of {n_tok} tokens (768 -> 24576, k=32), fp32 numpy oracle (BLAS-threaded), {dt:.1f} s"}
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction);
+    None when no PMC summary is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for k, v in d.get("kernels", {}).items():
+                if k.startswith(kernel_prefix) and "hbm_bytes_per_launch_corrected" in v:
+                    best = {"bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path), "kernel": k}
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -84,11 +145,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        # launched by torch.distributed.run (also with a single rank, so the RCCL path is exercised on 1 GPU)
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from vit_prisma_amd import HookedViT, HookedViTConfig, _native as N
@@ -151,6 +214,10 @@ def main():
         "share_of_step": round(gemm["ms"] / (ms_per_step * a.steps), 4),
         "traffic": None,
     }
+    tr = pmc_traffic("gemm_kernel_v") if a.dtype == "bf16" and a.batch == 512 else None
+    if tr is not None:
+        roofline["traffic"] = tr["bytes_per_launch"]
+        roofline["traffic_source"] = f"{tr['source']} ({tr['kernel']}); algorithmic bytes per launch = {gemm['bytes'] / max(gemm['launches'], 1):.4g}"
     kernels = {}
     for nm, k in (("attention", attn), ("layernorm", ln)):
         kernels[nm] = {
@@ -175,20 +242,15 @@ def main():
         "roofline": roofline, "kernels": kernels, "whole_forward": whole,
     }
 
-    if rank == 0 and world == 1 and not a.no_sae:
-        try:
-            from vit_prisma_amd.sae.bench_leg import sae_bench_leg
-            line["sae"] = sae_bench_leg(dev)
-        except ImportError:
-            line["sae"] = None
-    elif world > 1 and not a.no_sae:
-        try:
-            from vit_prisma_amd.sae.bench_leg import sae_bench_leg
-            sae = sae_bench_leg(dev, dist=dist)
-            if rank == 0:
-                line["sae"] = sae
-        except ImportError:
-            pass
+    if not a.no_sae:
+        from vit_prisma_amd.sae.bench_leg import sae_bench_leg
+        del model, images
+        torch.cuda.empty_cache()
+        sae = sae_bench_leg(dev, dist=dist)
+        if rank == 0:
+            line["sae"] = sae
+            if world == 1 and not a.no_cpu_baseline:
+                sae["cpu_baseline"] = sae_cpu_baseline(10.0)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 1)

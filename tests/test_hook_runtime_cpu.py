@@ -1,0 +1,175 @@
+"""Hook-runtime semantics of HookedRootModule / HookPoint (CPU).  Coverage follows the reference's own
+strategy (/root/reference/tests/test_hooks.py: attach/detach, perma hooks, nested hooks() contexts incl.
+failure unwinding, reset inside a context, flag-gated hooks + cached shapes, prepend ordering) plus the
+cache-key order test (/root/reference/tests/test_cache_hook_names.py) and the fine print of
+SURVEY.md section 8b."""
+import pytest
+import torch
+
+from vit_prisma_amd import HookedViT, HookedViTConfig
+
+B, S, P = 2, 32, 8
+T = (S // P) ** 2 + 1
+
+
+@pytest.fixture()
+def model():
+    torch.manual_seed(0)
+    cfg = HookedViTConfig(n_layers=2, d_model=16, d_head=8, d_mlp=32, n_heads=2, patch_size=P, image_size=S,
+                          n_classes=5, return_type="logits")
+    return HookedViT(cfg).eval()
+
+
+@pytest.fixture()
+def x():
+    return torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+
+
+class Tally:
+    def __init__(self):
+        self.n = 0
+        self.order = []
+
+    def __call__(self, t, hook):
+        self.n += 1
+        self.order.append(hook.name)
+
+
+def n_fwd(model, name="hook_embed"):
+    return len(model.hook_dict[name].fwd_hooks)
+
+
+def test_run_with_hooks_attaches_and_detaches(model, x):
+    t = Tally()
+    model.run_with_hooks(x, fwd_hooks=[(lambda n: n == "hook_embed", t)])
+    assert t.n == 1 and all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+    model.run_with_hooks(x, fwd_hooks=[("blocks.1.hook_resid_post", t)], reset_hooks_end=False)
+    assert n_fwd(model, "blocks.1.hook_resid_post") == 1
+    model.reset_hooks()
+    assert n_fwd(model, "blocks.1.hook_resid_post") == 0
+
+
+def test_permanent_hooks_survive_resets(model, x):
+    t = Tally()
+    model.add_perma_hook("hook_embed", t)
+    model.run_with_hooks(x, fwd_hooks=[])
+    model.reset_hooks()
+    model.remove_all_hook_fns()
+    assert n_fwd(model) == 1 and t.n == 1
+    with model.hooks(fwd_hooks=[("hook_embed", t)]):
+        assert n_fwd(model) == 2
+        model(x)
+    assert n_fwd(model) == 1 and t.n == 3
+    model.remove_all_hook_fns(including_permanent=True)
+    assert n_fwd(model) == 0
+
+
+def test_nested_contexts_and_failure_unwinding(model, x):
+    t = Tally()
+
+    def boom(z, hook):
+        raise ValueError("fail")
+
+    with model.hooks(fwd_hooks=[("hook_embed", t)]):
+        assert model.context_level == 1
+        model(x)
+        with model.hooks(fwd_hooks=[("hook_embed", t)]):
+            assert n_fwd(model) == 2 and model.context_level == 2
+            model(x)
+        assert n_fwd(model) == 1 and t.n == 3
+        with pytest.raises(ValueError):
+            with model.hooks(fwd_hooks=[("hook_embed", boom)]):
+                model(x)
+        assert n_fwd(model) == 1 and model.context_level == 1      # inner level removed, outer intact
+        model.run_with_cache(x)                                      # its own level, leaves ours alone
+        assert n_fwd(model) == 1
+        model.reset_hooks()                                          # level=None: removes everything non-permanent
+        assert n_fwd(model) == 0
+    assert model.context_level == 0
+
+
+def test_flag_gated_hooks_and_their_cached_shapes(model, x):
+    ident = lambda z, hook: z  # noqa: E731
+    for name, setter in [("blocks.0.attn.hook_result", model.set_use_attn_result),
+                         ("blocks.0.hook_q_input", model.set_use_split_qkv_input),
+                         ("blocks.0.hook_mlp_in", model.set_use_hook_mlp_in),
+                         ("blocks.0.hook_attn_in", model.set_use_attn_in)]:
+        model.reset_hooks()
+        setter(False)
+        with pytest.raises(AssertionError):
+            model.add_hook(name, ident)
+        setter(True)
+        model.add_hook(name, ident)
+        setter(False)
+    model.reset_hooks()
+    d, H = model.cfg.d_model, model.cfg.n_heads
+    for name, setter, shape in [("blocks.0.hook_q_input", model.set_use_split_qkv_input, (B, T, H, d)),
+                                ("blocks.0.hook_attn_in", model.set_use_attn_in, (B, T, H, d)),
+                                ("blocks.0.hook_mlp_in", model.set_use_hook_mlp_in, (B, T, d)),
+                                ("blocks.0.attn.hook_result", model.set_use_attn_result, (B, T, H, d))]:
+        setter(True)
+        _, cache = model.run_with_cache(x, names_filter=lambda n: n == name)
+        assert list(cache.keys()) == [name] and tuple(cache[name].shape) == shape
+        setter(False)
+    # per-head result sums to the fused O-projection
+    model.set_use_attn_result(True)
+    with torch.no_grad():
+        _, c = model.run_with_cache(x)
+        assert torch.allclose(c["blocks.0.attn.hook_result"].sum(2) + model.blocks[0].attn.b_O, c["blocks.0.hook_attn_out"], atol=1e-5)
+    model.set_use_attn_result(False)
+
+
+@pytest.mark.parametrize("zero_pos", [0, 1])
+@pytest.mark.parametrize("prepend", [True, False])
+def test_prepend_controls_execution_order(model, x, zero_pos, prepend):
+    """Two replacing hooks on the last residual: zeros and noise.  The output equals what zeros alone give
+    exactly when the zero hook runs LAST."""
+    def zero(z, hook):
+        return torch.zeros_like(z)
+
+    def noise(z, hook):
+        return torch.randn_like(z)
+
+    with torch.no_grad():
+        with model.hooks(fwd_hooks=[("blocks.1.hook_resid_post", zero)]):
+            want = model(x[:1])
+        model.reset_hooks()
+        for i in range(2):
+            model.add_hook("blocks.1.hook_resid_post", zero if i == zero_pos else noise, prepend=prepend)
+        got = model(x[:1])
+        model.reset_hooks()
+    zero_runs_last = (zero_pos == 1) != prepend
+    assert torch.allclose(got, want, atol=1e-6) == zero_runs_last
+
+
+def test_cache_key_order_and_observe_only_points(model, x):
+    with torch.no_grad():
+        _, cache = model.run_with_cache(x)
+    keys = list(cache.keys())
+    assert keys[:4] == ["hook_embed", "hook_pos_embed", "hook_full_embed", "blocks.0.hook_resid_pre"]   # no ln_pre here
+    per_block = ["hook_resid_pre", "ln1.hook_scale", "ln1.hook_normalized", "attn.hook_q", "attn.hook_k", "attn.hook_v",
+                 "attn.hook_attn_scores", "attn.hook_pattern", "attn.hook_z", "hook_attn_out", "hook_resid_mid",
+                 "ln2.hook_scale", "ln2.hook_normalized", "mlp.hook_pre", "mlp.hook_post", "hook_mlp_out", "hook_resid_post"]
+    assert keys[3:3 + 17] == ["blocks.0." + s for s in per_block]
+    assert keys[-4:] == ["ln_final.hook_scale", "ln_final.hook_normalized", "hook_ln_final", "hook_post_head_pre_normalize"]
+    assert len(keys) == 3 + 17 * 2 + 4 and len(model.hook_dict) == 3 + 23 * 2 + 4       # 286-style inventory: 23 per block
+    assert cache["hook_embed"].shape == (B, T - 1, 16) and cache["hook_pos_embed"].stride(0) == 0
+    # hook_full_embed / hook_ln_final / hook_post_head_pre_normalize are observe-only: a replacing hook there
+    # must NOT change the output; the same hook on a data-flow point must
+    with torch.no_grad():
+        base = model(x)
+        for name in ("hook_full_embed", "hook_ln_final", "hook_post_head_pre_normalize"):
+            out = model.run_with_hooks(x, fwd_hooks=[(name, lambda z, hook: torch.zeros_like(z))])
+            assert torch.equal(out, base), name
+        out = model.run_with_hooks(x, fwd_hooks=[("hook_embed", lambda z, hook: torch.zeros_like(z))])
+        assert not torch.equal(out, base)
+        # user hooks run BEFORE the caching hooks: the cache holds the post-hook value
+        _, c = model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_attn_out", lambda z, hook: z * 0 + 7.0)])
+        assert float(c["blocks.0.hook_attn_out"].min()) == 7.0
+        # stop_at_layer semantics incl. negative index; incl_bwd caches *_grad entries
+        r, c = model.run_with_cache(x, stop_at_layer=-1)
+        assert r.shape == (B, T, 16) and "blocks.1.hook_resid_pre" not in c and "ln_final.hook_scale" not in c
+    model.zero_grad()
+    out, c = model.run_with_cache(x[:1].requires_grad_(False), incl_bwd=False)
+    assert not any(k.endswith("_grad") for k in c.keys())
+    assert model.hook_dict["blocks.1.mlp.hook_post"].layer() == 1

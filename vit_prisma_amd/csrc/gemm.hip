@@ -142,7 +142,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
             for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
             if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = pv_act(v[i], p.act);
+            for (int i = 0; i < 8; ++i) v[i] = pv_act<sizeof(T) == 2>(v[i], p.act);
             store8(out1 + (int64_t)gm * p.ldo + gn, v);
         }
     } else {
@@ -168,7 +168,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
             } else {
                 x = DT<T>::round(x);
                 if (o0) DT<T>::store(o0 + (int64_t)gm * p.ldo + g, x);
-                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, pv_act(x, p.act));
+                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, pv_act<sizeof(T) == 2>(x, p.act));
             }
         }
     }
@@ -640,6 +640,206 @@ int launch_v3(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v4 mainloop: the v3 DMA idea with the latency problem fixed.
+//   * K slabs of 64 BYTES per row (32 bf16 / 16 fp32): a stage is 8 KB (A) + 8 KB (B)
+//   * THREE-stage LDS ring (48 KB) -> 3 workgroups per CU (12 waves): while one workgroup sits at its
+//     barrier or in its store epilogue the other two keep the matrix pipe busy
+//   * slab k+2 is issued while slab k is multiplied; the wait before the barrier is a COUNTED
+//     s_waitcnt vmcnt(4) (only slab k has to have landed, the 4 DMA instructions of slab k+1 stay in
+//     flight across the raw s_barrier) -- __syncthreads() would drain the queue
+//   * 64-byte rows: 4 chunks per row, 4 rows per 256-byte bank row; chunk position = k-chunk ^ ((row>>2)&3)
+//     applied on the DMA source address and on the fragment reads (conflict-free ds_read_b128)
+//   * epilogue staged through LDS in two 32-row halves per wave (34.8 KB <= the ring) 
+// ---------------------------------------------------------------------------------------------------
+constexpr int V4_SLAB = 64;                 // bytes of K per row per stage
+constexpr int V4_TILE = 128 * V4_SLAB;      // 8 KB per operand
+constexpr int V4_STAGE = 2 * V4_TILE;
+constexpr int V4_NSTAGE = 3;
+static_assert(V4_NSTAGE * V4_STAGE == 49152, "three 16 KB ring slots -> 3 workgroups per CU");
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
+    // One static __shared__ object per ring slot: hipcc's waitcnt pass can then prove that the ds_reads of
+    // slot i do not alias the DMA writes in flight to slots i+1 / i+2 (alias scopes per LDS variable); with a
+    // single array it inserts s_waitcnt vmcnt(0) before the first ds_read of every step and drains the ring.
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[V4_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[V4_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[V4_STAGE];
+    constexpr int EB = DT<T>::kBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // tile order: column blocks of <= 8 N-tiles, M-major inside a block.  The B panel of a block
+    // (8 x 128 rows x K) stays resident in the XCD's 4 MB L2 while the M range streams past once per block,
+    // instead of the whole weight matrix being re-streamed every few M-tiles (PMC: L2-miss reads were 4x the
+    // algorithmic bytes with plain N-fastest order).
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    const int blk = swz / (ntm * wblk);
+    const int rem = swz - blk * (ntm * wblk);
+    const int wcur = min(wblk, ntn - blk * wblk);
+    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + V4_SLAB - 1) / V4_SLAB);
+    const bool ktail = (Kb % V4_SLAB) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    // 8 wave-instructions (1 KiB = 16 rows x 64 B) per operand per slab; wave w issues instructions 2w, 2w+1
+    unsigned offA[2], offB[2], kcb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcb[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+    }
+    auto issue = [&](int kt, unsigned char* slot) {
+        const unsigned kbase = (unsigned)kt * V4_SLAB;
+        unsigned char* Ab = slot + wave * 2048;
+        unsigned char* Bb = Ab + V4_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned oa = offA[j] + kbase, ob = offB[j] + kbase;
+            if (kt >= nk || (ktail && kbase + kcb[j] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
+    const int a_row = (wm * 64 + l31) * V4_SLAB;
+    const int b_row = (wn * 64 + l31) * V4_SLAB;
+    auto compute = [&](const unsigned char* slot) {
+        const unsigned char* Ab = slot;
+        const unsigned char* Bb = slot + V4_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = j == 0 ? co0 : co1;
+            uint4 a[2], b[2];
+            a[0] = *reinterpret_cast<const uint4*>(Ab + a_row + co);
+            a[1] = *reinterpret_cast<const uint4*>(Ab + a_row + 32 * V4_SLAB + co);
+            b[0] = *reinterpret_cast<const uint4*>(Bb + b_row + co);
+            b[1] = *reinterpret_cast<const uint4*>(Bb + b_row + 32 * V4_SLAB + co);
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+            } else {
+                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+    // one pipeline step: slab kt lives in `cur`, slab kt+2 is issued into `nxt2` (the slot multiplied in step kt-1)
+    //   s_waitcnt vmcnt(4): this wave's 4 DMA instructions of slab kt have landed, the 4 of slab kt+1 may
+    //   still be in flight (simm16 0x0F74 = vmcnt 4, expcnt 7, lgkmcnt 15: only vmcnt is waited on)
+#define PV_V4_STEP(KT, CUR, NXT2)                      \
+    __builtin_amdgcn_s_waitcnt(0x0F74);                \
+    __builtin_amdgcn_s_barrier();                      \
+    if (!(p.dbg & 1)) issue((KT) + 2, NXT2);           \
+    compute(CUR);
+
+    issue(0, ring0);
+    issue(1, ring1);
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        PV_V4_STEP(kt, ring0, ring2)
+        PV_V4_STEP(kt + 1, ring1, ring0)
+        PV_V4_STEP(kt + 2, ring2, ring1)
+    }
+    if (kt < nk) { PV_V4_STEP(kt, ring0, ring2) }
+    if (kt + 1 < nk) { PV_V4_STEP(kt + 1, ring1, ring0) }
+#undef PV_V4_STEP
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
+    __syncthreads();
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+        return;
+    }
+
+    // ---- epilogue in two 32-row halves per wave; staging 32 x 64 floats per wave (waves 0,1 in ring0,
+    //      waves 2,3 in ring1)
+    constexpr int CLD = 64;
+    float* Cs = reinterpret_cast<float*>((wave < 2 ? ring0 : ring1) + (wave & 1) * (32 * CLD * 4));
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int cc = (lane & 7) * 8;
+            const int gm = m0 + wm * 64 + mi * 32 + row;
+            const int gn = n0 + wn * 64 + cc;
+            if (gm < p.M && gn < p.N) {
+                float v[8];
+                const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
+                const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+                v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                epilogue8<T>(p, v, gm, gn);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+int launch_v4(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v4<T>), dim3(ntm * ntn), dim3(256), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v4");
+    return PV_OK;
+}
+
 template <typename T, int AMODE, bool VEC, bool BKN = false>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -686,7 +886,10 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             // v3 (direct-to-LDS DMA, 2 stages) measured 12.5 ms/step vs 11.1-11.4 ms for v2 on the bs=512
             // B/32 forward (profiles/r01_notes.md): with only 2 stages the DMA has one slab of MFMA time to
             // land; kept selectable for the 3-stage follow-up
-            return getenv("PV_GEMM_V3") ? launch_v3<T>(p, stream) : launch_v2<T>(p, stream);
+            // default: v4 (3-stage LDS-DMA ring, 3 workgroups / CU); measured on the bs=512 B/32 forward:
+            // v1 12.6 ms, v2 11.1 ms, v3 12.5 ms, v4 10.5 ms per step (profiles/r01_notes.md)
+            if (getenv("PV_GEMM_V3")) return launch_v3<T>(p, stream);
+            return getenv("PV_GEMM_V2") ? launch_v2<T>(p, stream) : launch_v4<T>(p, stream);
         }
     }
     if (p.a_mode == PV_A_PLAIN) {
@@ -698,6 +901,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
+    if (const char* e = getenv("PV_GEMM_DBG")) p.dbg = atoi(e);
     PV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm dims must be positive");
     PV_REQUIRE(p.A && p.Bt, "gemm operands must be non-null");
     if (p.epi == PV_EPI_BIAS) PV_REQUIRE(p.out0, "EPI_BIAS needs out0");

@@ -32,6 +32,7 @@ struct GemmParams {
     const void* resid;       // RESID: [M][ldr]
     int64_t ldr;
     int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
+    int32_t dbg;             // ablation switches for kernel tuning (PV_GEMM_DBG): 1 = no DMA in the loop, 2 = no epilogue
 };
 
 // dtype: PV_DTYPE_*.  Returns PV_OK / error code (pv_last_error has the message).

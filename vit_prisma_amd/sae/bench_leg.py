@@ -23,7 +23,7 @@ PEAK_HBM_GBS = 8000.0
 PEAK_F32_TFLOPS = 157.3
 
 
-def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, cpu_seconds: float = 10.0) -> dict:
+def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5) -> dict:
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     sd = synth_sae_state(D_IN, D_SAE, 0)
@@ -92,25 +92,4 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
                                   "GBps": round(app["bytes"] / max(app["ms"], 1e-9) / 1e6, 1)},
         },
     }
-    if rank == 0 and world == 1 and cpu_seconds > 0:
-        res["cpu_baseline"] = _cpu_baseline(cpu_seconds)
     return res
-
-
-def _cpu_baseline(seconds: float) -> dict:
-    """The oracle's full train step (numpy port of the reference algorithm) on the host cores."""
-    import os
-    from oracle import sae_oracle as O
-    P = {k: v.copy() for k, v in synth_sae_state(D_IN, D_SAE, 0).items()}
-    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
-    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
-    x = synth_sae_batch(N_TOKENS, D_IN, seed=0)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.train_step(P, opt, stats, x, TOPK, lr=1e-3, step=n + 1)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 8:
-            break
-    return {"value": N_TOKENS * n / dt, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} full train steps of {N_TOKENS} tokens, fp32 numpy oracle, {dt:.1f} s"}
