@@ -37,13 +37,45 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int q0 = qb * QB;
     const int Tpad = p.Tpad;
     const int srow = Tpad * 4 + 16;                 // bytes
+    // FLAT (QB == 64: the whole T x T matrix of this head lives in the workgroup): the fp32 scores stay
+    // intact in S, P goes to its own region, and both taps are stored afterwards as ONE flat contiguous
+    // range per (image, head) (256 B per wave-instruction instead of one <= 100-byte row per instruction)
+    constexpr bool FLAT = QB == 64;
+    const int prow = FLAT ? Tpad * EB + 16 : srow;  // bytes, row stride of P
     unsigned char* S = smem;                        // [QB][srow]
-    unsigned char* Vt = smem + QB * srow;           // bf16 only: [DH][VT_ROW]
+    unsigned char* Pb = FLAT ? smem + QB * srow : smem;           // [QB][prow] (in place over S otherwise)
+    unsigned char* Vt = Pb + (FLAT ? QB * prow : QB * srow);      // bf16 only: [DH][VT_ROW]
 
     const int64_t tok_stride = (int64_t)H * DH;     // elements between tokens of one head
     const T* qbase = reinterpret_cast<const T*>(p.q) + ((int64_t)b * T_ * H + h) * DH;
     const T* kbase = reinterpret_cast<const T*>(p.k) + ((int64_t)b * T_ * H + h) * DH;
     const T* vbase = reinterpret_cast<const T*>(p.v) + ((int64_t)b * T_ * H + h) * DH;
+
+    // V^T staging (bf16): item -> (key pair kp, 8-wide d_head chunk ch); lanes 0-15 take 16 key pairs of one
+    // chunk (conflict-free ds_write_b32 rows), the next 16 lanes the next chunk
+    auto stage_v = [&](int kb0, int nkeys) {
+        constexpr int NCH = DH / 8;
+        for (int item = tid; item < (nkeys / 2) * NCH; item += 256) {
+            const int kp = (item & 15) | ((item / (16 * NCH)) << 4);
+            const int ch = (item >> 4) % NCH;
+            const int k0 = kb0 + 2 * kp, k1 = k0 + 1;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+            if (k0 < T_) v0 = *reinterpret_cast<const uint4*>(vbase + k0 * tok_stride + ch * 8);
+            if (k1 < T_) v1 = *reinterpret_cast<const uint4*>(vbase + k1 * tok_stride + ch * 8);
+            const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w};
+            const uint32_t a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);            // element 2e
+                const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);        // element 2e+1
+                *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e) * VT_ROW + kp * 4) = lo;
+                *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e + 1) * VT_ROW + kp * 4) = hi;
+            }
+        }
+    };
+    // whole-head variant: V^T has its own LDS region, so its global loads are issued FIRST and their latency
+    // overlaps the Q / K fragment loads and the QK^T phase (one exposed HBM latency instead of two)
+    if constexpr (FLAT && EB == 2) stage_v(0, Tpad);
 
     // ------------------------------------------------------------------ phase 1: scores
     const int ntk = Tpad / 32;
@@ -110,8 +142,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         }
         sum = wave_sum(sum);
         const int64_t grow = (((int64_t)b * H + h) * T_ + qi) * T_;
-        T* sc_out = p.scores ? reinterpret_cast<T*>(p.scores) + grow : nullptr;
-        T* pt_out = p.pattern ? reinterpret_cast<T*>(p.pattern) + grow : nullptr;
+        T* sc_out = (!FLAT && p.scores) ? reinterpret_cast<T*>(p.scores) + grow : nullptr;
+        T* pt_out = (!FLAT && p.pattern) ? reinterpret_cast<T*>(p.pattern) + grow : nullptr;
+        unsigned char* prowp = Pb + r * prow;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int col = lane + 64 * c;
@@ -125,8 +158,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 }
                 // P for the PV product, in the storage dtype, in place (all of this row's fp32
                 // scores were read into registers above; the row belongs to this wave only)
-                if constexpr (EB == 2) reinterpret_cast<bf16_t*>(srowp)[col] = f32_to_bf16(pr);
-                else srowp[col] = pr;
+                if constexpr (EB == 2) reinterpret_cast<bf16_t*>(prowp)[col] = f32_to_bf16(pr);
+                else reinterpret_cast<float*>(prowp)[col] = pr;
+            }
+        }
+    }
+
+    if constexpr (FLAT) {
+        if (p.scores || p.pattern) {
+            __syncthreads();
+            const int TT = T_ * T_;
+            const int64_t gbase = ((int64_t)b * H + h) * TT;
+            T* sc = p.scores ? reinterpret_cast<T*>(p.scores) + gbase : nullptr;
+            T* pt = p.pattern ? reinterpret_cast<T*>(p.pattern) + gbase : nullptr;
+            if (EB == 2 && (T_ & 1) == 0) {
+                // pairs of bf16: T even -> a pair never straddles rows and every head starts 4-byte aligned
+                for (int f2 = tid; f2 < (TT >> 1); f2 += 256) {
+                    const int f = f2 * 2, i = f / T_, j = f - i * T_;
+                    if (sc) {
+                        const float* sr = reinterpret_cast<const float*>(S + i * srow) + j;
+                        reinterpret_cast<uint32_t*>(sc)[f2] = pack_bf16x2(sr[0], sr[1]);
+                    }
+                    if (pt) reinterpret_cast<uint32_t*>(pt)[f2] = *reinterpret_cast<const uint32_t*>(Pb + i * prow + j * 2);
+                }
+            } else {
+                for (int f = tid; f < TT; f += 256) {
+                    const int i = f / T_, j = f - i * T_;
+                    if (sc) DT<T>::store(sc + f, reinterpret_cast<const float*>(S + i * srow)[j]);
+                    if (pt) pt[f] = reinterpret_cast<const T*>(Pb + i * prow)[j];
+                }
             }
         }
     }
@@ -141,35 +201,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     if constexpr (EB == 2) {
         for (int kb0 = 0; kb0 < Tpad; kb0 += KBLK) {
             __syncthreads();   // P rows visible (first block) / previous V^T block fully consumed
-            // stage V^T: item -> (key pair kp, 8-wide d_head chunk ch); lanes 0-15 take 16 key
-            // pairs of one chunk (conflict-free ds_write_b32 rows), next 16 lanes the next chunk
-            constexpr int NCH = DH / 8;
-            for (int item = tid; item < (KBLK / 2) * NCH; item += 256) {
-                const int kp = (item & 15) | ((item / (16 * NCH)) << 4);
-                const int ch = (item >> 4) % NCH;
-                const int k0 = kb0 + 2 * kp, k1 = k0 + 1;
-                uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-                if (k0 < T_) v0 = *reinterpret_cast<const uint4*>(vbase + k0 * tok_stride + ch * 8);
-                if (k1 < T_) v1 = *reinterpret_cast<const uint4*>(vbase + k1 * tok_stride + ch * 8);
-                const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w};
-                const uint32_t a1[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);            // element 2e
-                    const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);        // element 2e+1
-                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e) * VT_ROW + kp * 4) = lo;
-                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + 2 * e + 1) * VT_ROW + kp * 4) = hi;
-                }
+            if constexpr (!FLAT) {
+                stage_v(kb0, KBLK);
+                __syncthreads();
             }
-            __syncthreads();
             const int ksteps = min(KBLK, Tpad - kb0) / 16;
             int t = 0;
             for (int id = wave; id < NTQ * NTN; id += 4, ++t) {
                 const int tq = id % NTQ, tn = id / NTQ;
-                const unsigned char* prow = S + (tq * 32 + l31) * srow + (kb0 + half * 8) * 2;
+                const unsigned char* pfrag = Pb + (tq * 32 + l31) * prow + (kb0 + half * 8) * 2;
                 const unsigned char* vrow = Vt + (tn * 32 + l31) * VT_ROW + half * 16;
                 for (int ks = 0; ks < ksteps; ++ks) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(prow + ks * 32);
+                    const uint4 a = *reinterpret_cast<const uint4*>(pfrag + ks * 32);
                     const uint4 bb = *reinterpret_cast<const uint4*>(vrow + ks * 32);
                     zacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                                       __builtin_bit_cast(bf16x8, bb), zacc[t], 0, 0, 0);
@@ -181,11 +224,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         int t = 0;
         for (int id = wave; id < NTQ * NTN; id += 4, ++t) {
             const int tq = id % NTQ, tn = id / NTQ;
-            const float* prow = reinterpret_cast<const float*>(S + (tq * 32 + l31) * srow);
+            const float* pfrag = reinterpret_cast<const float*>(Pb + (tq * 32 + l31) * prow);
             const T* vcol = vbase + tn * 32 + l31;
             for (int kb0 = 0; kb0 < Tpad; kb0 += 8) {
                 const int kk = kb0 + half * 4;
-                const float4 a = *reinterpret_cast<const float4*>(prow + kk);
+                const float4 a = *reinterpret_cast<const float4*>(pfrag + kk);
                 float bv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[e] = (kk + e < T_) ? DT<T>::load(vcol + (kk + e) * tok_stride) : 0.f;
@@ -216,7 +259,7 @@ template <typename T, int QB, int DH, int MAXC>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int EB = DT<T>::kBytes;
     const int srow = p.Tpad * 4 + 16;
-    const int lds = QB * srow + (EB == 2 ? DH * VT_ROW : 0);
+    const int lds = QB * srow + (QB == 64 ? QB * (p.Tpad * EB + 16) : 0) + (EB == 2 ? DH * VT_ROW : 0);
     PV_REQUIRE(lds <= 160 * 1024, "attention LDS footprint exceeds 160 KiB");
     static int max_set = 0;
     if (lds > max_set) {

@@ -714,6 +714,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
         for (int j = 0; j < 2; ++j) {
             unsigned oa = offA[j] + kbase, ob = offB[j] + kbase;
             if (kt >= nk || (ktail && kbase + kcb[j] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
+            if (p.dbg & 4) { oa = lane * 16; ob = lane * 16; }      // ablation: every DMA hits the same cached 1 KiB
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
         }
