@@ -176,6 +176,41 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
 
 // accumulators -> per-wave LDS staging (reusing the operand buffers; caller has passed a barrier after
 // the last LDS read) -> each lane owns 8 consecutive columns of a row -> fused epilogue + tap stores
+// epilogue8 with the bias values and the residual chunk already in registers (bf16 storage; the full-chunk
+// vector case only).  Same arithmetic, same rounding points as epilogue8.
+template <typename T>
+__device__ __forceinline__ void epilogue8_pre(const GemmParams& p, float (&v)[8], int gm, int gn, int col, T* out0,
+                                              const uint4& braw, const uint4& res) {
+    T* out1 = reinterpret_cast<T*>(p.out1);
+    const uint32_t bw[4] = {braw.x, braw.y, braw.z, braw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] += __uint_as_float(bw[i] << 16);
+        v[2 * i + 1] += __uint_as_float(bw[i] & 0xffff0000u);
+    }
+    if (p.epi == PV_EPI_BIAS || p.epi == PV_EPI_QKV) {
+        store8(out0 + (int64_t)gm * p.ldo + col, v);
+    } else if (p.epi == PV_EPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
+        if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
+        const uint32_t rw[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] += __uint_as_float(rw[i] << 16);
+            v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+        }
+        store8(out1 + (int64_t)gm * p.ldo + gn, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
+        if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pv_act<sizeof(T) == 2>(v[i], p.act);
+        store8(out1 + (int64_t)gm * p.ldo + gn, v);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], unsigned char* smem, int m0, int n0,
                                               int wave, int lane, int wm, int wn) {
@@ -713,8 +748,14 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             unsigned oa = offA[j] + kbase, ob = offB[j] + kbase;
-            if (kt >= nk || (ktail && kbase + kcb[j] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
-            if (p.dbg & 4) { oa = lane * 16; ob = lane * 16; }      // ablation: every DMA hits the same cached 1 KiB
+            // NOTE: no branch may surround these DMA instructions -- hipcc's waitcnt pass answers a
+            // conditionally executed LDS-DMA with s_waitcnt vmcnt(0) before the next ds_read (ring drained)
+            // (bitwise, not short-circuit: it has to compile to selects)
+            const bool oob = (kt >= nk) | (ktail & (kbase + kcb[j] >= Kb)) | (((p.dbg & 1) != 0) & (kt >= 2));
+            oa = oob ? 0xffffff00u : oa;
+            ob = oob ? 0xffffff00u : ob;
+            oa = (p.dbg & 4) ? lane * 16u : oa;                     // ablation: every DMA hits the same cached 1 KiB
+            ob = (p.dbg & 4) ? lane * 16u : ob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
         }
@@ -771,8 +812,45 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
 #define PV_V4_STEP(KT, CUR, NXT2)                      \
     __builtin_amdgcn_s_waitcnt(0x0F74);                \
     __builtin_amdgcn_s_barrier();                      \
-    if (!(p.dbg & 1)) issue((KT) + 2, NXT2);           \
+    issue((KT) + 2, NXT2);                             \
     compute(CUR);
+
+    // Epilogue operands fetched BEFORE the K loop (bf16 only: 40 VGPRs): this lane's 8 bias values and, for the
+    // residual epilogues, its 8 x 16 B of residual-stream rows.  They are older than every DMA in the vmcnt
+    // queue, so the counted waits of the loop retire them for free and the store epilogue never waits on HBM.
+    const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
+    const bool e_fast = EB == 2 && p.vec_out && e_gn + 8 <= p.N && !(p.dbg & 8);
+    uint4 e_bias = make_uint4(0, 0, 0, 0);        // 8 raw bf16 (converted in the epilogue: no wait up here)
+    uint4 e_res[2][4];
+    int e_col = e_gn;
+    T* e_out0 = reinterpret_cast<T*>(p.out0);
+    if constexpr (EB == 2) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
+        if (e_fast) {
+            const T* bias = reinterpret_cast<const T*>(p.bias0);
+            if (p.epi == PV_EPI_QKV) {
+                const int which = e_gn / p.nsplit;
+                e_col = e_gn - which * p.nsplit;
+                if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
+                if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
+            }
+            if (bias) e_bias = *reinterpret_cast<const uint4*>(bias + e_col);
+            if (p.epi == PV_EPI_RESID) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int gm = m0 + wm * 64 + mi * 32 + it * 8 + (lane >> 3);
+                        if (gm < p.M)
+                            e_res[mi][it] = *reinterpret_cast<const uint4*>(
+                                reinterpret_cast<const T*>(p.resid) + (int64_t)gm * p.ldr + e_gn);
+                    }
+            }
+        }
+    }
 
     issue(0, ring0);
     issue(1, ring1);
@@ -806,6 +884,211 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
                 Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
             }
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const int cc = (lane & 7) * 8;
+            const int gm = m0 + wm * 64 + mi * 32 + row;
+            const int gn = n0 + wn * 64 + cc;
+            if (gm < p.M && gn < p.N) {
+                float v[8];
+                const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
+                const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+                v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                if constexpr (EB == 2) {
+                    if (e_fast) epilogue8_pre<T>(p, v, gm, gn, e_col, e_out0, e_bias, e_res[mi][it]);
+                    else epilogue8<T>(p, v, gm, gn);
+                } else {
+                    epilogue8<T>(p, v, gm, gn);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+int launch_v4(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v4<T>), dim3(ntm * ntn), dim3(256), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v4");
+    return PV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v5 mainloop: v4's counted-vmcnt DMA ring with FULL cache lines.
+//   v4's 64-byte slabs make every DMA wave-instruction touch 16 half lines, and the ablations
+//   (profiles/r01_notes.md) show that the vector-memory path -- not LDS write bandwidth -- is what the operand
+//   stream is bound by.  Here a slab is 128 bytes of K per row (8 full lines per wave-instruction) and the ring
+//   is kept at OPERAND granularity: five 16 KB slots (80 KB -> 2 workgroups per CU) hold the sequence
+//   A0 B0 A1 B1 A2 | B2 A3 ... (item i -> slot i % 5).  Step k multiplies items 2k, 2k+1 and, right after its
+//   barrier, issues items 2k+3 (B of slab k+1) and 2k+4 (A of slab k+2): 1.5 slabs = 48 KB per workgroup stay
+//   in flight, the same as v4, with half the line requests per byte and half the barriers per flop.
+//   s_waitcnt vmcnt(4): items <= 2k+1 have landed, item 2k+2 (4 instructions per wave) may still be in flight.
+// ---------------------------------------------------------------------------------------------------
+constexpr int V5_SLOT = 128 * 128;          // 16 KB: 128 rows x 128 bytes
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v5(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char slot0[V5_SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char slot1[V5_SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char slot2[V5_SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char slot3[V5_SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char slot4[V5_SLOT];
+    constexpr int EB = DT<T>::kBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    const int blk = swz / (ntm * wblk);
+    const int rem = swz - blk * (ntm * wblk);
+    const int wcur = min(wblk, ntn - blk * wblk);
+    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + SLAB - 1) / SLAB);
+    const bool ktail = (Kb % SLAB) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    // 16 wave-instructions (1 KiB = 8 rows x 128 B) per operand item; wave w issues instructions 4w .. 4w+3
+    unsigned offA[4], offB[4], kcb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((row >> 1) & 7);
+        kcb[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+    }
+    auto issue_a = [&](int slab, unsigned char* slot) {
+        const unsigned kbase = (unsigned)slab * SLAB;
+        unsigned char* dst = slot + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned o = offA[j] + kbase;
+            o = ((slab >= nk) | (ktail & (kbase + kcb[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + j * 1024), 16, o, 0, 0, 0);
+        }
+    };
+    auto issue_b = [&](int slab, unsigned char* slot) {
+        const unsigned kbase = (unsigned)slab * SLAB;
+        unsigned char* dst = slot + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned o = offB[j] + kbase;
+            o = ((slab >= nk) | (ktail & (kbase + kcb[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + j * 1024), 16, o, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 1) & 7;
+    int co[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) co[j] = ((2 * j + half) ^ sw) * 16;
+    const int a_row = (wm * 64 + l31) * 128;
+    const int b_row = (wn * 64 + l31) * 128;
+    auto compute = [&](const unsigned char* Ab, const unsigned char* Bb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 a[2], b[2];
+            a[0] = *reinterpret_cast<const uint4*>(Ab + a_row + co[j]);
+            a[1] = *reinterpret_cast<const uint4*>(Ab + a_row + 32 * 128 + co[j]);
+            b[0] = *reinterpret_cast<const uint4*>(Bb + b_row + co[j]);
+            b[1] = *reinterpret_cast<const uint4*>(Bb + b_row + 32 * 128 + co[j]);
+            if constexpr (EB == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+            } else {
+                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
+            }
+        }
+    };
+    // step KT: operands in (SA, SB); afterwards issue B of slab KT+1 into SN1 and A of slab KT+2 into SN2
+#define PV_V5_STEP(KT, SA, SB, SN1, SN2)               \
+    __builtin_amdgcn_s_waitcnt(0x0F74);                \
+    __builtin_amdgcn_s_barrier();                      \
+    issue_b((KT) + 1, SN1);                            \
+    issue_a((KT) + 2, SN2);                            \
+    compute(SA, SB);
+
+    issue_a(0, slot0);
+    issue_b(0, slot1);
+    issue_a(1, slot2);
+    int kt = 0;
+    for (; kt + 5 <= nk; kt += 5) {
+        PV_V5_STEP(kt, slot0, slot1, slot3, slot4)
+        PV_V5_STEP(kt + 1, slot2, slot3, slot0, slot1)
+        PV_V5_STEP(kt + 2, slot4, slot0, slot2, slot3)
+        PV_V5_STEP(kt + 3, slot1, slot2, slot4, slot0)
+        PV_V5_STEP(kt + 4, slot3, slot4, slot1, slot2)
+    }
+    if (kt < nk) { PV_V5_STEP(kt, slot0, slot1, slot3, slot4) }
+    if (kt + 1 < nk) { PV_V5_STEP(kt + 1, slot2, slot3, slot0, slot1) }
+    if (kt + 2 < nk) { PV_V5_STEP(kt + 2, slot4, slot0, slot2, slot3) }
+    if (kt + 3 < nk) { PV_V5_STEP(kt + 3, slot1, slot2, slot4, slot0) }
+#undef PV_V5_STEP
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
+    __syncthreads();
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+        return;
+    }
+
+    // ---- epilogue in two 32-row halves per wave; staging 32 x 64 floats per wave (waves 0,1 in slot0, 2,3 in slot1)
+    constexpr int CLD = 64;
+    float* Cs = reinterpret_cast<float*>((wave < 2 ? slot0 : slot1) + (wave & 1) * (32 * CLD * 4));
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
+            }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3);
@@ -826,7 +1109,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
 }
 
 template <typename T>
-int launch_v4(const GemmParams& p, hipStream_t stream) {
+int launch_v5(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
     {
         constexpr double EBd = DT<T>::kBytes;
@@ -835,9 +1118,9 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
         if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
         ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v4<T>), dim3(ntm * ntn), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_kernel_v5<T>), dim3(ntm * ntn), dim3(256), 0, stream, p);
     }
-    PV_LAUNCH_CHECK("gemm_kernel_v4");
+    PV_LAUNCH_CHECK("gemm_kernel_v5");
     return PV_OK;
 }
 
@@ -890,6 +1173,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             // default: v4 (3-stage LDS-DMA ring, 3 workgroups / CU); measured on the bs=512 B/32 forward:
             // v1 12.6 ms, v2 11.1 ms, v3 12.5 ms, v4 10.5 ms per step (profiles/r01_notes.md)
             if (getenv("PV_GEMM_V3")) return launch_v3<T>(p, stream);
+            if (getenv("PV_GEMM_V5")) return launch_v5<T>(p, stream);
             return getenv("PV_GEMM_V2") ? launch_v2<T>(p, stream) : launch_v4<T>(p, stream);
         }
     }
