@@ -25,6 +25,15 @@
 
 namespace {
 
+// debug tracing (pv_debug_gemm_trace_*): stamps on the 100 MHz wall clock, written by thread 0 of each workgroup
+__device__ __forceinline__ void trace_stamp(uint64_t* trace, int bid, int slot) {
+    if (trace && threadIdx.x == 0) {
+        trace[(int64_t)bid * 4 + slot] = wall_clock64();
+        if (slot == 0) trace[(int64_t)bid * 4 + 3] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                                      (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+}
+
 constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int SLAB = 128;            // bytes of K per row per stage
@@ -722,6 +731,14 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
     const int wcur = min(wblk, ntn - blk * wblk);
     const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    trace_stamp(p.trace, bid, 0);
+    if (p.stagger_us > 0 && bid >= 256 && bid < 256 * 3) {
+        // phase offset between the workgroups that share a CU (first resident wave only; later workgroups
+        // inherit it): without it they all compute together and then all store together
+        const uint64_t t0 = wall_clock64();
+        const uint64_t ticks = (uint64_t)p.stagger_us * 100u * (uint64_t)(bid >> 8);     // 100 MHz constant clock
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
 
     const unsigned Kb = (unsigned)p.K * EB;
     const int nk = (int)((Kb + V4_SLAB - 1) / V4_SLAB);
@@ -865,6 +882,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
 #undef PV_V4_STEP
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
     __syncthreads();
+    trace_stamp(p.trace, bid, 1);
     if (p.dbg & 2) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
         return;
@@ -906,6 +924,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    trace_stamp(p.trace, bid, 2);
 }
 
 template <typename T>
@@ -1146,6 +1165,462 @@ int launch(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v6 mainloop: v4's counted-vmcnt ring with a TALLER tile.
+//   v4's 64 x 64 wave tile reads 4 KiB of LDS per 4 MFMAs: at the MFMA rate that is LDS-array time equal to
+//   half the matrix-pipe time, plus the DMA writes of a 16 KB slab every 256 MFMA cycles (L2 -> LDS traffic of
+//   1/64 B per flop: 39 TB/s chip-wide at the bf16 peak -- more than the L2s deliver).  Here a wave owns
+//   (32*MB) x 64 outputs (MB = 4: 128 x 64, 128 accumulator registers), the workgroup (64*MB) x 128:
+//     * LDS reads per MFMA  x 0.75, L2 -> LDS bytes per flop x 0.75 (MB = 4)
+//     * slot = (64*MB + 128) rows x 64 B = 24 KB, three slots = 72 KB -> 2 workgroups (8 waves) per CU
+//     * wave w issues MB A-instructions + 2 B-instructions per slab -> the counted wait is vmcnt(MB + 2)
+//   Epilogue as v4, with the residual rows of block mi+1 fetched while block mi is stored.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_v6(const GemmParams p) {
+    constexpr int TM = 64 * MB;
+    constexpr int A_BYTES = TM * 64, B_BYTES = 128 * 64, SLOT = A_BYTES + B_BYTES;
+    static_assert(3 * SLOT <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
+    constexpr int EB = DT<T>::kBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + TM - 1) / TM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    const int blk = swz / (ntm * wblk);
+    const int rem = swz - blk * (ntm * wblk);
+    const int wcur = min(wblk, ntn - blk * wblk);
+    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
+    const int m0 = tile_m * TM, n0 = tile_n * BN;
+    if (p.stagger_us > 0 && bid >= 256 && bid < 256 * 2) {
+        // phase offset between the workgroups that share a CU (first resident wave only; later workgroups
+        // inherit it): without it they all compute together and then all store together
+        const uint64_t t0 = wall_clock64();
+        const uint64_t ticks = (uint64_t)p.stagger_us * 100u * (uint64_t)(bid >> 8);     // 100 MHz constant clock
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + 63) / 64);
+    const bool ktail = (Kb % 64) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    // a wave-instruction moves 16 rows x 64 B; A has 4*MB of them per slab (wave w: MB), B has 8 (wave w: 2)
+    unsigned offA[MB], kcA[MB], offB[2], kcB[2];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int row = (wave * MB + j) * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcA[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcB[j] = kc * 16;
+        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+    }
+    auto issue = [&](int kt, unsigned char* slot) {
+        const unsigned kbase = (unsigned)kt * 64;
+        const bool dead = (kt >= nk) | (((p.dbg & 1) != 0) & (kt >= 2));
+        // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            unsigned o = offA[j] + kbase;
+            o = (dead | (ktail & (kbase + kcA[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (wave * MB + j) * 1024), 16, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = offB[j] + kbase;
+            o = (dead | (ktail & (kbase + kcB[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (wave * 2 + j) * 1024), 16, o, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
+    const int a_row = (wm * 32 * MB + l31) * 64;
+    const int b_row = A_BYTES + (wn * 64 + l31) * 64;
+    auto compute = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = j == 0 ? co0 : co1;
+            uint4 a[MB], b[2];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
+            b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
+            b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0
+    const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
+    const bool e_fast = e_gn < p.N;          // the launcher guarantees vec_out and N % 8 == 0: whole chunks only
+    uint4 e_bias = make_uint4(0, 0, 0, 0);
+    uint4 e_res[MB][4];
+    int e_col = e_gn;
+    T* e_out0 = reinterpret_cast<T*>(p.out0);
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
+    const bool e_resid = e_fast && p.epi == PV_EPI_RESID;
+    const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldr + e_gn;
+    const int e_rows_left = p.M - (m0 + wm * 32 * MB + (lane >> 3));      // rows gm < M  <=>  mi*32 + it*8 < e_rows_left
+#define PV_V6_FETCH_RES(MI)                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                 \
+        if (e_resid && (MI) * 32 + it * 8 < e_rows_left)                                             \
+            e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr);
+    if (e_fast) {
+        const T* bias = reinterpret_cast<const T*>(p.bias0);
+        if (p.epi == PV_EPI_QKV) {
+            const int which = e_gn / p.nsplit;
+            e_col = e_gn - which * p.nsplit;
+            if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
+            if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
+        }
+        if (bias) e_bias = *reinterpret_cast<const uint4*>(bias + e_col);
+    }
+    PV_V6_FETCH_RES(0)
+
+#define PV_V6_STEP(KT, CUR, NXT2)                         \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (MB + 2));        \
+    __builtin_amdgcn_s_barrier();                         \
+    issue((KT) + 2, NXT2);                                \
+    compute(CUR);
+
+    issue(0, ring0);
+    issue(1, ring1);
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        PV_V6_STEP(kt, ring0, ring2)
+        PV_V6_STEP(kt + 1, ring1, ring0)
+        PV_V6_STEP(kt + 2, ring2, ring1)
+    }
+    if (kt < nk) { PV_V6_STEP(kt, ring0, ring2) }
+    if (kt + 1 < nk) { PV_V6_STEP(kt + 1, ring1, ring0) }
+#undef PV_V6_STEP
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
+    __syncthreads();
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+        return;
+    }
+
+    constexpr int CLD = 64;
+    float* Cs = reinterpret_cast<float*>((wave < 2 ? ring0 : ring1) + (wave & 1) * (32 * CLD * 4));
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (mi + 1 < MB) { PV_V6_FETCH_RES((mi + 1 < MB ? mi + 1 : 0)) }     // (index kept in range: an OOB index in the dead arm defeats SROA)
+        if (e_fast) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int cc = (lane & 7) * 8;
+                const int gm = m0 + wm * 32 * MB + mi * 32 + row;
+                if (gm < p.M) {
+                    float v[8];
+                    const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+                    v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                    epilogue8_pre<T>(p, v, gm, e_gn, e_col, e_out0, e_bias, e_res[mi][it]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef PV_V6_FETCH_RES
+}
+
+template <typename T, int MB>
+int launch_v6(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + 64 * MB - 1) / (64 * MB), ntn = (p.N + BN - 1) / BN;
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v6<T, MB>), dim3(ntm * ntn), dim3(256), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v6");
+    return PV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// v7 mainloop: ONE 512-thread workgroup per CU, (64*MB) x 256 tile (MB = 4: 256 x 256, MB = 5: 320 x 256).
+//   The 128 x 128 tiles of v4 pull 1/64 byte of operand per flop out of L2: 68 GB per bs=512 B/32 forward,
+//   ~15 TB/s sustained at v4's speed -- the L2 -> LDS path, not the matrix pipe, is what v4 saturates
+//   (profiles/r01_notes.md).  Here the byte/flop ratio is 1/128 (MB = 4) or 1/142 (MB = 5):
+//     * 8 waves as 2 (M) x 4 (N); a wave owns (32*MB) x 64 outputs (v6's wave tile: 14 ds_read_b128 per 20 MFMAs)
+//     * slot = (64*MB + 256) rows x 64 B (36 KB at MB = 5); FOUR slots (144 KB of the 160 KB) -> slab k+3 is
+//       issued while slab k is multiplied, three slabs (108 KB per CU) in flight
+//     * per slab a wave issues NA = ceil(4*MB / 8) A-instructions + 2 B-instructions; at MB = 5 waves 4..7 have
+//       only 2 real A pieces -- their third is an out-of-range (zero-fill) DMA into a pad, so that every
+//       wave retires the same number and the counted wait stays a compile-time vmcnt(2 * (NA + 2))
+//     * MB = 5 makes M = 25600 (512 images x 50 tokens) exactly 80 row tiles: the N = 768 GEMMs (O-projection,
+//       MLP-2) are 240 tiles = ONE round of the 256 CUs, the QKV GEMM 720 = three
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MB>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
+    constexpr int TM = 64 * MB;
+    constexpr int TN = 256;
+    constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
+    constexpr int NA = (4 * MB + 7) / 8;                  // A wave-instructions per wave per slab
+    constexpr bool PAD = (4 * MB) % 8 != 0;
+    static_assert(4 * SLOT + (PAD ? 8192 : 0) <= 160 * 1024, "one workgroup per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring3[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char pad[PAD ? 8192 : 16];
+    constexpr int EB = DT<T>::kBytes;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    const int blk = swz / (ntm * wblk);
+    const int rem = swz - blk * (ntm * wblk);
+    const int wcur = min(wblk, ntn - blk * wblk);
+    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+    trace_stamp(p.trace, bid, 0);
+
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk = (int)((Kb + 63) / 64);
+    const bool ktail = (Kb % 64) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
+
+    // a wave-instruction moves 16 rows x 64 B; A has 4*MB of them per slab (instruction j*8 + wave), B has 16
+    unsigned offA[NA], kcA[NA], offB[2], kcB[2];
+    bool realA[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int ia = j * 8 + wave;
+        realA[j] = ia < 4 * MB;
+        const int row = ia * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcA[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcB[j] = kc * 16;
+        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
+    }
+    auto issue = [&](int kt, unsigned char* slot) {
+        const unsigned kbase = (unsigned)kt * 64;
+        const bool dead = (kt >= nk) | (((p.dbg & 1) != 0) & (kt >= 3));
+        // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            unsigned o = offA[j] + kbase;
+            o = (dead | !realA[j] | (ktail & (kbase + kcA[j] >= Kb))) ? 0xffffff00u : o;
+            unsigned char* dst = slot + (j * 8 + wave) * 1024;
+            if constexpr (PAD) { if (j == NA - 1) dst = realA[j] ? dst : pad + wave * 1024; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = offB[j] + kbase;
+            o = (dead | (ktail & (kbase + kcB[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
+    const int a_row = (wm * 32 * MB + l31) * 64;
+    const int b_row = A_BYTES + (wn * 64 + l31) * 64;
+    auto compute = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = j == 0 ? co0 : co1;
+            uint4 a[MB], b[2];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
+            b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
+            b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0
+    const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
+    const bool e_fast = e_gn < p.N;          // the launcher guarantees vec_out and N % 8 == 0: whole chunks only
+    uint4 e_bias = make_uint4(0, 0, 0, 0);
+    uint4 e_res[MB][4];
+    int e_col = e_gn;
+    T* e_out0 = reinterpret_cast<T*>(p.out0);
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
+    const bool e_resid = e_fast && p.epi == PV_EPI_RESID;
+    const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldr + e_gn;
+    const int e_rows_left = p.M - (m0 + wm * 32 * MB + (lane >> 3));      // rows gm < M  <=>  mi*32 + it*8 < e_rows_left
+#define PV_V7_FETCH_RES(MI)                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                 \
+        if (e_resid && (MI) * 32 + it * 8 < e_rows_left)                                             \
+            e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr);
+    if (e_fast) {
+        const T* bias = reinterpret_cast<const T*>(p.bias0);
+        if (p.epi == PV_EPI_QKV) {
+            const int which = e_gn / p.nsplit;
+            e_col = e_gn - which * p.nsplit;
+            if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
+            if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
+        }
+        if (bias) e_bias = *reinterpret_cast<const uint4*>(bias + e_col);
+    }
+    PV_V7_FETCH_RES(0)
+
+    // step kt: slab kt must have landed -- the 2 * (NA + 2) DMA instructions of slabs kt+1, kt+2 may stay in flight
+    static_assert(2 * (NA + 2) <= 15, "vmcnt immediate below uses the low 4 bits only");
+#define PV_V7_STEP(KT, CUR, NXT3)                               \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NA + 2)));        \
+    __builtin_amdgcn_s_barrier();                               \
+    issue((KT) + 3, NXT3);                                      \
+    compute(CUR);
+
+    issue(0, ring0);
+    issue(1, ring1);
+    issue(2, ring2);
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+        PV_V7_STEP(kt, ring0, ring3)
+        PV_V7_STEP(kt + 1, ring1, ring0)
+        PV_V7_STEP(kt + 2, ring2, ring1)
+        PV_V7_STEP(kt + 3, ring3, ring2)
+    }
+    if (kt < nk) { PV_V7_STEP(kt, ring0, ring3) }
+    if (kt + 1 < nk) { PV_V7_STEP(kt + 1, ring1, ring0) }
+    if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
+#undef PV_V7_STEP
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
+    __syncthreads();
+    trace_stamp(p.trace, bid, 1);
+    if (p.dbg & 2) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+        return;
+    }
+
+    constexpr int CLD = 64;
+    float* Cs = reinterpret_cast<float*>((wave < 4 ? ring0 : ring1) + (wave & 3) * (32 * CLD * 4));
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (mi + 1 < MB) { PV_V7_FETCH_RES((mi + 1 < MB ? mi + 1 : 0)) }     // (index kept in range: an OOB index in the dead arm defeats SROA)
+        if (e_fast) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const int cc = (lane & 7) * 8;
+                const int gm = m0 + wm * 32 * MB + mi * 32 + row;
+                if (gm < p.M) {
+                    float v[8];
+                    const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
+                    const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+                    v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                    epilogue8_pre<T>(p, v, gm, e_gn, e_col, e_out0, e_bias, e_res[mi][it]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef PV_V7_FETCH_RES
+    trace_stamp(p.trace, bid, 2);
+}
+
+template <typename T, int MB>
+int launch_v7(const GemmParams& p, hipStream_t stream) {
+    const int ntm = (p.M + 64 * MB - 1) / (64 * MB), ntn = (p.N + 255) / 256;
+    {
+        constexpr double EBd = DT<T>::kBytes;
+        const double mn = (double)p.M * p.N;
+        double outs = 1.0;
+        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
+        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
+        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+        hipLaunchKernelGGL((gemm_kernel_v7<T, MB>), dim3(ntm * ntn), dim3(512), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("gemm_kernel_v7");
+    return PV_OK;
+}
+
 template <typename T>
 int dispatch(GemmParams& p, hipStream_t stream) {
     constexpr int EB = DT<T>::kBytes;
@@ -1174,6 +1649,12 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             // v1 12.6 ms, v2 11.1 ms, v3 12.5 ms, v4 10.5 ms per step (profiles/r01_notes.md)
             if (getenv("PV_GEMM_V3")) return launch_v3<T>(p, stream);
             if (getenv("PV_GEMM_V5")) return launch_v5<T>(p, stream);
+            if constexpr (EB == 2) {
+                if (getenv("PV_GEMM_V6") && p.vec_out && p.N % 8 == 0) return launch_v6<T, 4>(p, stream);
+                if (const char* e7 = getenv("PV_GEMM_V7")) {
+                    if (p.vec_out && p.N % 8 == 0) return atoi(e7) == 5 ? launch_v7<T, 5>(p, stream) : launch_v7<T, 4>(p, stream);
+                }
+            }
             return getenv("PV_GEMM_V2") ? launch_v2<T>(p, stream) : launch_v4<T>(p, stream);
         }
     }
@@ -1185,8 +1666,45 @@ int dispatch(GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+uint64_t* g_trace_dev = nullptr;
+int g_trace_countdown = -1;
+int32_t g_trace_info[6] = {0, 0, 0, 0, 0, 0};
+constexpr int TRACE_MAX_WG = 8192;
+}  // namespace
+
+extern "C" int pv_debug_gemm_trace_arm(int32_t launch_idx) {
+    if (!g_trace_dev) {
+        PV_HIP_CHECK(hipMalloc(&g_trace_dev, (size_t)TRACE_MAX_WG * 4 * sizeof(uint64_t)));
+    }
+    PV_HIP_CHECK(hipMemset(g_trace_dev, 0, (size_t)TRACE_MAX_WG * 4 * sizeof(uint64_t)));
+    g_trace_countdown = launch_idx;
+    return PV_OK;
+}
+
+extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6) {
+    PV_REQUIRE(g_trace_dev && host_out && info6, "trace not armed");
+    PV_HIP_CHECK(hipDeviceSynchronize());
+    const int n = max_wg < g_trace_info[4] ? max_wg : g_trace_info[4];
+    PV_HIP_CHECK(hipMemcpy(host_out, g_trace_dev, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) info6[i] = g_trace_info[i];
+    return PV_OK;
+}
+
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     if (const char* e = getenv("PV_GEMM_DBG")) p.dbg = atoi(e);
+    if (const char* e = getenv("PV_GEMM_STAGGER")) p.stagger_us = atoi(e);
+    p.trace = nullptr;
+    if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {
+        if (g_trace_countdown-- == 0) {
+            p.trace = g_trace_dev;
+            const int v7 = getenv("PV_GEMM_V7") ? atoi(getenv("PV_GEMM_V7")) : 0;
+            const int tm = v7 == 5 ? 320 : (v7 ? 256 : 128), tn = v7 ? 256 : 128;
+            g_trace_info[0] = p.M; g_trace_info[1] = p.N; g_trace_info[2] = p.K; g_trace_info[3] = p.epi;
+            g_trace_info[4] = ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn); g_trace_info[5] = v7 ? 70 + v7 : 4;
+            if (g_trace_info[4] > TRACE_MAX_WG) p.trace = nullptr;
+        }
+    }
     PV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm dims must be positive");
     PV_REQUIRE(p.A && p.Bt, "gemm operands must be non-null");
     if (p.epi == PV_EPI_BIAS) PV_REQUIRE(p.out0, "EPI_BIAS needs out0");

@@ -32,8 +32,15 @@ struct GemmParams {
     const void* resid;       // RESID: [M][ldr]
     int64_t ldr;
     int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
+    int32_t stagger_us;      // experiment: start delay (us) x (blockIdx / 256) for the first resident wave of workgroups
+    uint64_t* trace;         // debug: per-workgroup {t_start, t_loop_end, t_end, hw_id} (100 MHz wall clock) or NULL
     int32_t dbg;             // ablation switches for kernel tuning (PV_GEMM_DBG): 1 = no DMA in the loop, 2 = no epilogue
 };
 
 // dtype: PV_DTYPE_*.  Returns PV_OK / error code (pv_last_error has the message).
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream);
+
+// debug: arm per-workgroup phase tracing for the `launch_idx`-th GEMM launch from now (0 = next), read it back
+// (blocks until the device is idle).  info = {M, N, K, epi, n_workgroups, kernel version}.
+extern "C" int pv_debug_gemm_trace_arm(int32_t launch_idx);
+extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6);
