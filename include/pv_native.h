@@ -176,7 +176,9 @@ int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t 
 /* Opt-in per-kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).
  * kind: 0 GEMM, 1 attention, 2 layernorm/embed, 3 SAE encoder+topk, 4 SAE backward, 5 SAE apply, 6 misc.
  * pv_prof_read synchronises the events and returns launch count, summed kernel milliseconds and the
- * summed ALGORITHMIC flops / bytes of those launches. */
+ * summed ALGORITHMIC flops / bytes of those launches.
+ * pv_prof_enable(on): bit 0 = on/off; bits 8.. = mask of kinds to time (bit 8+kind), 0 = all kinds -- every
+ * timed launch costs two event records on the stream, so a throughput run times only the kernel it reports. */
 int pv_prof_enable(int32_t on);
 int pv_prof_reset(void);
 int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flops, double* bytes);

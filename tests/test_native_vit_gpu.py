@@ -240,3 +240,29 @@ def test_bf16_full_size_properties_bs512():
     with torch.no_grad():
         out1, _ = model.run_with_cache(x[17:18], names_filter="hook_embed")
     assert torch.equal(out1[0], out[17])
+
+
+@pytest.mark.parametrize("arch_name,bs", [("clip-vit-b32", 5), ("tiny-ragged", 3)])
+def test_bf16_attention_core_against_fp32_recompute_of_its_own_inputs(arch_name, bs):
+    """The attention kernels in isolation: scores / pattern / z recomputed in fp32 torch from the q, k, v the
+    same run cached (so every input is bit-identical), against the bf16 taps.  Both arches have an even token
+    count (50, 10): the one-head-per-wave kernel; bound = one bf16 rounding of each stage (2^-8 relative),
+    attention.py:246-281."""
+    model, arch, sd = build(arch_name, torch.bfloat16)
+    out, cache = run(model, synth_images(arch, bs, 3), torch.bfloat16)
+    for layer in range(arch["n_layers"]):
+        pre = f"blocks.{layer}.attn."
+        q, k, v = (cache[pre + n].float() for n in ("hook_q", "hook_k", "hook_v"))          # [B, T, H, dh]
+        scale = float(arch["d_head"]) ** 0.5
+        s_ref = torch.einsum("bqhd,bkhd->bhqk", q, k) / scale
+        s_got = cache[pre + "hook_attn_scores"].float()
+        assert s_got.shape == s_ref.shape
+        assert float((s_got - s_ref).abs().max()) <= 2 ** -8 * float(s_ref.abs().max()) + 1e-6, layer
+        # softmax of the STORED (bf16) scores, as the reference does
+        p_ref = torch.softmax(s_got, dim=-1)
+        p_got = cache[pre + "hook_pattern"].float()
+        assert float((p_got - p_ref).abs().max()) <= 2 ** -8, layer
+        assert torch.allclose(p_got.sum(-1), torch.ones_like(p_got.sum(-1)), atol=2e-2)
+        z_ref = torch.einsum("bhqk,bkhd->bqhd", p_got, v)
+        z_got = cache[pre + "hook_z"].float()
+        assert float((z_got - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6, layer

@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpvnative.so")
+LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
 ABI_VERSION = 4
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
@@ -146,8 +146,12 @@ PROF_KINDS = {"gemm": 0, "attention": 1, "layernorm": 2, "sae_encode_topk": 3, "
               "sae_apply": 5, "misc": 6}
 
 
-def prof_enable(on: bool = True) -> None:
-    lib().pv_prof_enable(int(on))
+def prof_enable(on: bool = True, kinds=None) -> None:
+    """HIP-event timing of the kernel families in ``kinds`` (names of PROF_KINDS; None = all)."""
+    mask = 0
+    for k in kinds or ():
+        mask |= 1 << PROF_KINDS[k]
+    lib().pv_prof_enable(int(bool(on)) | (mask << 8))
 
 
 def prof_reset() -> None:

@@ -15,6 +15,8 @@
 //   phase 3  z = P V on MFMA; bf16: V^T blocks staged through LDS so the B fragment is k-contiguous,
 //            fp32: V rows read directly (the f32 MFMA takes one float per lane)
 #include "attention.hpp"
+
+#include <cstdlib>
 #include "prof.hpp"
 
 namespace {
@@ -278,9 +280,238 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Whole-head-per-WAVE variant (bf16, T <= 64, T even): the B/32 shape (T = 50, 6144 heads at bs = 512).
+//   The workgroup kernel above spends its time in barriers between four waves that share one 50 x 50
+//   problem (112 us per layer at bs = 512 against ~45 us of HBM time).  Here a wave owns one (image, head):
+//   no workgroup barrier anywhere, 9 KB of LDS per wave (16 waves per CU), every phase ordered by the wave's
+//   own in-order LDS queue:
+//     1  K, Q fragments straight from global (buffer loads clipped to the head's T rows: pad rows read 0)
+//     2  S = Q K^T on MFMA, scaled + rounded to bf16 -> LDS [64][72] (144-byte rows)
+//     3  hook_attn_scores: the head's T*T bf16 block leaves as flat 16-byte chunks (it is contiguous in HBM)
+//     4  softmax with lane r owning row r (8 ds_read_b128, all math in registers), P written back in place
+//     5  hook_pattern: flat copy as in 3
+//     6  z = P V on MFMA: P fragments from LDS, V fragments as 2-byte buffer loads (a lane needs 8 keys of
+//        ONE d_head column: k-strided in HBM, but 32 lanes cover 64 contiguous bytes of each key row)
+//     7  z staged through the same LDS rows -> 16-byte row stores
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int AW_ROW = 144;                 // bytes per LDS row: 64 bf16 + 16 pad (conflict-free b128 rows)
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][64 * AW_ROW];
+    constexpr int NKS = DH / 16;            // k16 steps of Q K^T
+    constexpr int NTN = DH / 32;            // 32-wide d_head tiles of P V
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x * 4 + wave;    // (image, head)
+    if (g >= p.B * p.H) return;             // the whole wave leaves; nothing below synchronises across waves
+    const int T_ = p.T, H = p.H;
+    const int b = g / H, h = g - b * H;
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned char* SP = smem[wave];
+    const unsigned tokb = (unsigned)H * DH * 2u;                          // bytes between tokens of one head
+    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;              // elements
+    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);          // this head's rows; beyond -> 0
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
+
+    // ---- 1, 2: scores
+    u32x4_t kf[2][NKS];
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            kf[ki][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(ki * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+    const float inv_scale = 1.0f / p.attn_scale;
+    (void)inv_scale;
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq) {
+        u32x4_t qf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(tq * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+        f32x16 acc[2];
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ki][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int ki = 0; ki < 2; ++ki)
+                acc[ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf[ks]),
+                                                                  __builtin_bit_cast(bf16x8, kf[ki][ks]), acc[ki], 0, 0, 0);
+        // C layout: col = lane & 31 (key), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (query)
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                *reinterpret_cast<bf16_t*>(SP + row * AW_ROW + (ki * 32 + l31) * 2) = f32_to_bf16(acc[ki][e] / p.attn_scale);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // flat copy of the head's [T][T] bf16 block out of the LDS rows: chunk c = elements 8c .. 8c+7 (T even: a pair
+    // of elements never straddles a row); the last chunk may be short
+    const int TT = T_ * T_;
+    const float inv_T = 1.0f / (float)T_;
+    auto flat_store = [&](void* dst_base) {
+        unsigned char* dst = reinterpret_cast<unsigned char*>(dst_base) + (int64_t)g * TT * 2;
+        for (int c = lane; c * 8 < TT; c += 64) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const int f = c * 8 + q2 * 2;
+                const int i = (int)(((float)f + 0.5f) * inv_T);
+                const int j = f - i * T_;
+                w[q2] = (f < TT) ? *reinterpret_cast<const uint32_t*>(SP + i * AW_ROW + j * 2) : 0u;
+            }
+            unsigned char* d = dst + (int64_t)c * 16;
+            if (c * 8 + 8 <= TT) {
+                *reinterpret_cast<uint4*>(d) = make_uint4(w[0], w[1], w[2], w[3]);      // 4-byte aligned is enough
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2)
+                    if (c * 8 + q2 * 2 < TT) *reinterpret_cast<uint32_t*>(d + q2 * 4) = w[q2];
+            }
+        }
+    };
+    if (p.scores) flat_store(p.scores);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 4: softmax, lane r = query row r (attention.py:148-152: softmax, NaN -> 0, cast to the model dtype)
+    {
+        uint4 raw[8];
+        unsigned char* rowp = SP + lane * AW_ROW;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) raw[c8] = *reinterpret_cast<const uint4*>(rowp + c8 * 16);
+        float e_[64];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const uint32_t w[4] = {raw[c8].x, raw[c8].y, raw[c8].z, raw[c8].w};
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const int j = c8 * 8 + q2 * 2;
+                e_[j] = __uint_as_float(w[q2] << 16);
+                e_[j + 1] = __uint_as_float(w[q2] & 0xffff0000u);
+                if (j < T_) m = fmaxf(m, e_[j]);
+                if (j + 1 < T_) m = fmaxf(m, e_[j + 1]);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            e_[j] = (j < T_) ? __expf(e_[j] - m) : 0.f;
+            sum += e_[j];
+        }
+        const float rs = 1.0f / sum;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                float p0 = e_[c8 * 8 + q2 * 2] * rs, p1 = e_[c8 * 8 + q2 * 2 + 1] * rs;
+                if (p0 != p0) p0 = 0.f;
+                if (p1 != p1) p1 = 0.f;
+                w[q2] = (lane < T_) ? pack_bf16x2(p0, p1) : 0u;          // pad rows: finite zeros for the MFMA
+            }
+            *reinterpret_cast<uint4*>(rowp + c8 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (p.pattern) flat_store(p.pattern);
+
+    // ---- 6: z = P V
+    f32x16 zacc[2][NTN];
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zacc[tq][tn][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks * 16 >= T_) break;                                        // keys beyond T: P and V are zero there
+        u32x4_t vf[NTN];
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const unsigned key = ks * 16 + half * 8 + q2 * 2;
+                const unsigned o = key * tokb + (tn * 32 + l31) * 2;
+                const uint32_t lo = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsV, o, 0, 0);
+                const uint32_t hi = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsV, o + tokb, 0, 0);
+                w[q2] = lo | (hi << 16);
+            }
+            vf[tn] = u32x4_t{w[0], w[1], w[2], w[3]};
+        }
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+            const uint4 pa = *reinterpret_cast<const uint4*>(SP + (tq * 32 + l31) * AW_ROW + ks * 32 + half * 16);
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn)
+                zacc[tq][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa),
+                                                                       __builtin_bit_cast(bf16x8, vf[tn]), zacc[tq][tn], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 7: z -> LDS rows [64][DH] -> 16-byte row stores into [B, T, H, dh]
+#pragma unroll
+    for (int tq = 0; tq < 2; ++tq)
+#pragma unroll
+        for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                *reinterpret_cast<bf16_t*>(SP + row * AW_ROW + (tn * 32 + l31) * 2) = f32_to_bf16(zacc[tq][tn][e]);
+            }
+    __builtin_amdgcn_wave_barrier();
+    {
+        constexpr int CPR = DH / 8;                                      // 16-byte chunks per row
+        bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
+        for (int c = lane; c < T_ * CPR; c += 64) {
+            const int row = c / CPR, ch = c - row * CPR;
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(zb) + (int64_t)row * tokb + ch * 16) =
+                *reinterpret_cast<const uint4*>(SP + row * AW_ROW + ch * 16);
+        }
+    }
+}
+
+template <int DH>
+int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
+    const int heads = p.B * p.H;
+    {
+        const double bh = (double)heads, tt = (double)p.T * p.T;
+        const double bytes = (4.0 * bh * p.T * DH + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
+        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * DH, bytes);
+        hipLaunchKernelGGL((attn_wave_kernel<DH>), dim3((heads + 3) / 4), dim3(256), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("attn_wave_kernel");
+    return PV_OK;
+}
+
 template <typename T>
 int dispatch_attn(AttnParams& p, hipStream_t stream) {
     p.Tpad = (p.T + 31) / 32 * 32;
+    if constexpr (sizeof(T) == 2) {
+        // one head per wave: needs whole bf16 pairs per row and 4-byte aligned head blocks in the taps
+        const bool taps_ok = (reinterpret_cast<uintptr_t>(p.scores) % 4 == 0) && (reinterpret_cast<uintptr_t>(p.pattern) % 4 == 0);
+        if (p.T <= 64 && p.T % 2 == 0 && taps_ok && pv_aligned16(p.z) && !getenv("PV_ATTN_WG") &&
+            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31)) {
+            if (p.dh == 64) return launch_attn_wave<64>(p, stream);
+            if (p.dh == 32) return launch_attn_wave<32>(p, stream);
+        }
+    }
     if (p.T <= 64) {
         if (p.dh == 64) return launch_attn<T, 64, 64, 1>(p, stream);
         if (p.dh == 32) return launch_attn<T, 64, 32, 1>(p, stream);

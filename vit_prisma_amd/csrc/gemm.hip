@@ -384,307 +384,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// v2 mainloop for the common case (plain row-major A, [N][K] B, 16-byte aligned rows): branch-free
-// buffer loads (the hardware range check returns 0 for rows past M / N, so ragged tiles need no exec
-// masking) and a TWO-slab-deep register prefetch: the loads of slab k+2 are issued before the MFMAs of
-// slab k, and slab k+1 (issued one full iteration earlier) is written to LDS after them, so a global
-// load has ~2 slabs of MFMA time to land instead of 1.
-// ---------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v2(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + 2 * TILE_BYTES;
-    constexpr int EB = DT<T>::kBytes;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ntn = (p.N + BN - 1) / BN;
-    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk = (int)((Kb + SLAB - 1) / SLAB);
-    const bool ktail = (Kb % SLAB) != 0;
-
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
-
-    unsigned offA[4], offB[4], kcb[4];
-    int ldsoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const int row = c >> 3, kc = c & 7;
-        kcb[i] = kc * 16;
-        offA[i] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;    // >= num_records when m0+row >= M
-        offB[i] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
-        ldsoff[i] = row * ROWB + kc * 16;
-    }
-    auto issue = [&](int kt, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
-        const unsigned kbase = (unsigned)kt * SLAB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned oa = offA[i] + kbase, ob = offB[i] + kbase;
-            // past K (ragged last slab, or the unconditional prefetch running off the end): force the
-            // offset out of range -> the buffer unit returns 0 without touching memory
-            if (kt >= nk || (ktail && kbase + kcb[i] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ob, 0, 0);
-        }
-    };
-    auto stash = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(As + buf * TILE_BYTES + ldsoff[i]) = ra[i];
-            *reinterpret_cast<u32x4*>(Bs + buf * TILE_BYTES + ldsoff[i]) = rb[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int a_off = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-    const int b_off = (wn * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-    auto compute = [&](int buf) {
-        const unsigned char* Ab = As + buf * TILE_BYTES;
-        const unsigned char* Bb = Bs + buf * TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 a[2], b[2];
-            a[0] = *reinterpret_cast<const uint4*>(Ab + a_off + j * 32);
-            a[1] = *reinterpret_cast<const uint4*>(Ab + a_off + 32 * ROWB + j * 32);
-            b[0] = *reinterpret_cast<const uint4*>(Bb + b_off + j * 32);
-            b[1] = *reinterpret_cast<const uint4*>(Bb + b_off + 32 * ROWB + j * 32);
-            if constexpr (EB == 2) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-            } else {
-                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
-            }
-        }
-    };
-
-    u32x4 r0a[4], r0b[4], r1a[4], r1b[4];
-    // NB: issue / stash are unconditional (off-the-end prefetches are turned into out-of-range, zero-
-    // returning loads): with a branch around them the compiler's waitcnt pass merges the two paths and
-    // falls back to vmcnt(0) before the LDS writes, which would drain the slab that was just issued.
-    issue(0, r0a, r0b);
-    issue(1, r1a, r1b);
-    stash(0, r0a, r0b);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        // even step: LDS[0] = slab kt, register set 1 = slab kt+1 (in flight), set 0 free
-        issue(kt + 2, r0a, r0b);
-        compute(0);
-        stash(1, r1a, r1b);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        // odd step: LDS[1] = slab kt+1, set 0 = slab kt+2 (in flight), set 1 free
-        issue(kt + 3, r1a, r1b);
-        compute(1);
-        stash(0, r0a, r0b);
-        __syncthreads();
-    }
-    tile_epilogue<T>(p, acc, smem, m0, n0, wave, lane, wm, wn);
-}
-
-template <typename T>
-int launch_v2(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_v2<T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-        attr_done = true;
-    }
-    {
-        constexpr double EBd = DT<T>::kBytes;
-        const double mn = (double)p.M * p.N;
-        double outs = 1.0;
-        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v2<T>), dim3(ntm * ntn), dim3(256), GEMM_LDS, stream, p);
-    }
-    PV_LAUNCH_CHECK("gemm_kernel_v2");
-    return PV_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// v3 mainloop: operands go HBM/L2 -> LDS directly (buffer_load ... lds, 16 bytes per lane, 1 KiB per
-// wave-instruction), no VGPR staging and no ds_write: with 128 x 128 tiles the VGPR->LDS write path
-// (ds_write_b128, ~78 B/clk/CU) was the busiest unit of the CU (32 KB written per 2.1 MFLOP slab).
-// The LDS image must be lane-linear per instruction (rows of exactly 128 bytes, no padding), so bank
-// conflicts are avoided by an XOR swizzle applied on the SOURCE address: the 16-byte chunk stored at
-// position c of tile row r holds K-chunk c ^ ((r >> 1) & 7); fragment reads apply the same involution
-// (conflict-free for every 16-lane ds_read_b128 service group).  Rows past M / N and K-chunks past K
-// resolve to out-of-range buffer offsets, which the hardware returns as zeros.
-// ---------------------------------------------------------------------------------------------------
-constexpr int V3_TILE = 128 * 128;          // bytes per operand tile (128 rows x 128 bytes)
-constexpr int V3_STAGE = 2 * V3_TILE;       // A + B
-constexpr int V3_NSTAGE = 2;
-constexpr int V3_LDS = (V3_NSTAGE * V3_STAGE > 4 * 64 * CS_LD * 4) ? V3_NSTAGE * V3_STAGE : 4 * 64 * CS_LD * 4;
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v3(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int EB = DT<T>::kBytes;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ntn = (p.N + BN - 1) / BN;
-    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk = (int)((Kb + SLAB - 1) / SLAB);
-    const bool ktail = (Kb % SLAB) != 0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
-
-    // this lane's source chunk for the 4 (A) + 4 (B) wave-instructions of a slab
-    unsigned offA[4], offB[4], kcb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);         // tile row written by this lane
-        const int kc = (lane & 7) ^ ((row >> 1) & 7);             // K-chunk that belongs at position lane & 7
-        kcb[j] = kc * 16;
-        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
-        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
-    }
-    auto issue = [&](int kt, int buf) {
-        const unsigned kbase = (unsigned)kt * SLAB;
-        unsigned char* Ab = smem + buf * V3_STAGE + wave * 4096;
-        unsigned char* Bb = Ab + V3_TILE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned oa = offA[j] + kbase, ob = offB[j] + kbase;
-            if (kt >= nk || (ktail && kbase + kcb[j] >= Kb)) { oa = 0xffffff00u; ob = 0xffffff00u; }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int sw = (l31 >> 1) & 7;                                // (row >> 1) & 7 of every row this lane reads
-    int co[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) co[j] = ((2 * j + half) ^ sw) * 16;
-    const int a_row = (wm * 64 + l31) * 128;
-    const int b_row = (wn * 64 + l31) * 128;
-    auto compute = [&](int buf) {
-        const unsigned char* Ab = smem + buf * V3_STAGE;
-        const unsigned char* Bb = Ab + V3_TILE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 a[2], b[2];
-            a[0] = *reinterpret_cast<const uint4*>(Ab + a_row + co[j]);
-            a[1] = *reinterpret_cast<const uint4*>(Ab + a_row + 32 * 128 + co[j]);
-            b[0] = *reinterpret_cast<const uint4*>(Bb + b_row + co[j]);
-            b[1] = *reinterpret_cast<const uint4*>(Bb + b_row + 32 * 128 + co[j]);
-            if constexpr (EB == 2) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-            } else {
-                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
-            }
-        }
-    };
-
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        // the DMA of slab kt (issued one iteration ago) must have landed for EVERY wave, and every wave
-        // must be done reading the buffer slab kt+1 is about to overwrite: vmcnt(0) + barrier
-        __syncthreads();
-        issue(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
-    }
-    __syncthreads();     // last reads done (and the off-the-end prefetch drained) before the staging reuse
-    tile_epilogue<T>(p, acc, smem, m0, n0, wave, lane, wm, wn);
-}
-
-template <typename T>
-int launch_v3(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel_v3<T>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS));
-        attr_done = true;
-    }
-    {
-        constexpr double EBd = DT<T>::kBytes;
-        const double mn = (double)p.M * p.N;
-        double outs = 1.0;
-        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v3<T>), dim3(ntm * ntn), dim3(256), V3_LDS, stream, p);
-    }
-    PV_LAUNCH_CHECK("gemm_kernel_v3");
-    return PV_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // v4 mainloop: the v3 DMA idea with the latency problem fixed.
 //   * K slabs of 64 BYTES per row (32 bf16 / 16 fp32): a stage is 8 KB (A) + 8 KB (B)
 //   * THREE-stage LDS ring (48 KB) -> 3 workgroups per CU (12 waves): while one workgroup sits at its
@@ -696,6 +395,7 @@ int launch_v3(const GemmParams& p, hipStream_t stream) {
 //     applied on the DMA source address and on the fragment reads (conflict-free ds_read_b128)
 //   * epilogue staged through LDS in two 32-row halves per wave (34.8 KB <= the ring) 
 // ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;      // destination of an LDS-DMA (buffer_load ... lds)
 constexpr int V4_SLAB = 64;                 // bytes of K per row per stage
 constexpr int V4_TILE = 128 * V4_SLAB;      // 8 KB per operand
 constexpr int V4_STAGE = 2 * V4_TILE;
@@ -943,206 +643,6 @@ int launch_v4(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// v5 mainloop: v4's counted-vmcnt DMA ring with FULL cache lines.
-//   v4's 64-byte slabs make every DMA wave-instruction touch 16 half lines, and the ablations
-//   (profiles/r01_notes.md) show that the vector-memory path -- not LDS write bandwidth -- is what the operand
-//   stream is bound by.  Here a slab is 128 bytes of K per row (8 full lines per wave-instruction) and the ring
-//   is kept at OPERAND granularity: five 16 KB slots (80 KB -> 2 workgroups per CU) hold the sequence
-//   A0 B0 A1 B1 A2 | B2 A3 ... (item i -> slot i % 5).  Step k multiplies items 2k, 2k+1 and, right after its
-//   barrier, issues items 2k+3 (B of slab k+1) and 2k+4 (A of slab k+2): 1.5 slabs = 48 KB per workgroup stay
-//   in flight, the same as v4, with half the line requests per byte and half the barriers per flop.
-//   s_waitcnt vmcnt(4): items <= 2k+1 have landed, item 2k+2 (4 instructions per wave) may still be in flight.
-// ---------------------------------------------------------------------------------------------------
-constexpr int V5_SLOT = 128 * 128;          // 16 KB: 128 rows x 128 bytes
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v5(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char slot0[V5_SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char slot1[V5_SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char slot2[V5_SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char slot3[V5_SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char slot4[V5_SLOT];
-    constexpr int EB = DT<T>::kBytes;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-    const int nblk = (ntn + 7) / 8;
-    const int wblk = (ntn + nblk - 1) / nblk;
-    const int blk = swz / (ntm * wblk);
-    const int rem = swz - blk * (ntm * wblk);
-    const int wcur = min(wblk, ntn - blk * wblk);
-    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk = (int)((Kb + SLAB - 1) / SLAB);
-    const bool ktail = (Kb % SLAB) != 0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
-
-    // 16 wave-instructions (1 KiB = 8 rows x 128 B) per operand item; wave w issues instructions 4w .. 4w+3
-    unsigned offA[4], offB[4], kcb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + (lane >> 3);
-        const int kc = (lane & 7) ^ ((row >> 1) & 7);
-        kcb[j] = kc * 16;
-        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
-        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
-    }
-    auto issue_a = [&](int slab, unsigned char* slot) {
-        const unsigned kbase = (unsigned)slab * SLAB;
-        unsigned char* dst = slot + wave * 4096;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned o = offA[j] + kbase;
-            o = ((slab >= nk) | (ktail & (kbase + kcb[j] >= Kb))) ? 0xffffff00u : o;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + j * 1024), 16, o, 0, 0, 0);
-        }
-    };
-    auto issue_b = [&](int slab, unsigned char* slot) {
-        const unsigned kbase = (unsigned)slab * SLAB;
-        unsigned char* dst = slot + wave * 4096;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned o = offB[j] + kbase;
-            o = ((slab >= nk) | (ktail & (kbase + kcb[j] >= Kb))) ? 0xffffff00u : o;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + j * 1024), 16, o, 0, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int sw = (l31 >> 1) & 7;
-    int co[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) co[j] = ((2 * j + half) ^ sw) * 16;
-    const int a_row = (wm * 64 + l31) * 128;
-    const int b_row = (wn * 64 + l31) * 128;
-    auto compute = [&](const unsigned char* Ab, const unsigned char* Bb) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 a[2], b[2];
-            a[0] = *reinterpret_cast<const uint4*>(Ab + a_row + co[j]);
-            a[1] = *reinterpret_cast<const uint4*>(Ab + a_row + 32 * 128 + co[j]);
-            b[0] = *reinterpret_cast<const uint4*>(Bb + b_row + co[j]);
-            b[1] = *reinterpret_cast<const uint4*>(Bb + b_row + 32 * 128 + co[j]);
-            if constexpr (EB == 2) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-            } else {
-                const uint32_t au[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-                const uint32_t bu[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __uint_as_float(au[mi][e]), __uint_as_float(bu[ni][e]), acc[mi][ni], 0, 0, 0);
-            }
-        }
-    };
-    // step KT: operands in (SA, SB); afterwards issue B of slab KT+1 into SN1 and A of slab KT+2 into SN2
-#define PV_V5_STEP(KT, SA, SB, SN1, SN2)               \
-    __builtin_amdgcn_s_waitcnt(0x0F74);                \
-    __builtin_amdgcn_s_barrier();                      \
-    issue_b((KT) + 1, SN1);                            \
-    issue_a((KT) + 2, SN2);                            \
-    compute(SA, SB);
-
-    issue_a(0, slot0);
-    issue_b(0, slot1);
-    issue_a(1, slot2);
-    int kt = 0;
-    for (; kt + 5 <= nk; kt += 5) {
-        PV_V5_STEP(kt, slot0, slot1, slot3, slot4)
-        PV_V5_STEP(kt + 1, slot2, slot3, slot0, slot1)
-        PV_V5_STEP(kt + 2, slot4, slot0, slot2, slot3)
-        PV_V5_STEP(kt + 3, slot1, slot2, slot4, slot0)
-        PV_V5_STEP(kt + 4, slot3, slot4, slot1, slot2)
-    }
-    if (kt < nk) { PV_V5_STEP(kt, slot0, slot1, slot3, slot4) }
-    if (kt + 1 < nk) { PV_V5_STEP(kt + 1, slot2, slot3, slot0, slot1) }
-    if (kt + 2 < nk) { PV_V5_STEP(kt + 2, slot4, slot0, slot2, slot3) }
-    if (kt + 3 < nk) { PV_V5_STEP(kt + 3, slot1, slot2, slot4, slot0) }
-#undef PV_V5_STEP
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
-    __syncthreads();
-    if (p.dbg & 2) {
-        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
-        return;
-    }
-
-    // ---- epilogue in two 32-row halves per wave; staging 32 x 64 floats per wave (waves 0,1 in slot0, 2,3 in slot1)
-    constexpr int CLD = 64;
-    float* Cs = reinterpret_cast<float*>((wave < 2 ? slot0 : slot1) + (wave & 1) * (32 * CLD * 4));
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const int cc = (lane & 7) * 8;
-            const int gm = m0 + wm * 64 + mi * 32 + row;
-            const int gn = n0 + wn * 64 + cc;
-            if (gm < p.M && gn < p.N) {
-                float v[8];
-                const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
-                const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
-                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-                v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-                epilogue8<T>(p, v, gm, gn);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-template <typename T>
-int launch_v5(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    {
-        constexpr double EBd = DT<T>::kBytes;
-        const double mn = (double)p.M * p.N;
-        double outs = 1.0;
-        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v5<T>), dim3(ntm * ntn), dim3(256), 0, stream, p);
-    }
-    PV_LAUNCH_CHECK("gemm_kernel_v5");
-    return PV_OK;
-}
-
 template <typename T, int AMODE, bool VEC, bool BKN = false>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
@@ -1166,224 +666,76 @@ int launch(const GemmParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// v6 mainloop: v4's counted-vmcnt ring with a TALLER tile.
-//   v4's 64 x 64 wave tile reads 4 KiB of LDS per 4 MFMAs: at the MFMA rate that is LDS-array time equal to
-//   half the matrix-pipe time, plus the DMA writes of a 16 KB slab every 256 MFMA cycles (L2 -> LDS traffic of
-//   1/64 B per flop: 39 TB/s chip-wide at the bf16 peak -- more than the L2s deliver).  Here a wave owns
-//   (32*MB) x 64 outputs (MB = 4: 128 x 64, 128 accumulator registers), the workgroup (64*MB) x 128:
-//     * LDS reads per MFMA  x 0.75, L2 -> LDS bytes per flop x 0.75 (MB = 4)
-//     * slot = (64*MB + 128) rows x 64 B = 24 KB, three slots = 72 KB -> 2 workgroups (8 waves) per CU
-//     * wave w issues MB A-instructions + 2 B-instructions per slab -> the counted wait is vmcnt(MB + 2)
-//   Epilogue as v4, with the residual rows of block mi+1 fetched while block mi is stored.
+// bf16 store epilogue with everything known at compile time (v7).  The phase trace (tools/gemm_trace.py)
+// showed the generic epilogue8 to be VALU-bound, not store-bound: the MLP-1 tile spent 35 us in it against
+// 28 us in its K loop (IEEE division + three activation arms + per-call pointer math, ~100 VALU per element
+// for 8 waves per CU).  Here: packed fp32 math (v_pk_*), v_exp / v_rcp instead of expf / division (the value
+// is rounded to bf16 two instructions later), no run-time switches.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MB>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v6(const GemmParams p) {
-    constexpr int TM = 64 * MB;
-    constexpr int A_BYTES = TM * 64, B_BYTES = 128 * 64, SLOT = A_BYTES + B_BYTES;
-    static_assert(3 * SLOT <= 80 * 1024, "two workgroups per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
-    constexpr int EB = DT<T>::kBytes;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + TM - 1) / TM;
-    const int nblk = (ntn + 7) / 8;
-    const int wblk = (ntn + nblk - 1) / nblk;
-    const int blk = swz / (ntm * wblk);
-    const int rem = swz - blk * (ntm * wblk);
-    const int wcur = min(wblk, ntn - blk * wblk);
-    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
-    const int m0 = tile_m * TM, n0 = tile_n * BN;
-    if (p.stagger_us > 0 && bid >= 256 && bid < 256 * 2) {
-        // phase offset between the workgroups that share a CU (first resident wave only; later workgroups
-        // inherit it): without it they all compute together and then all store together
-        const uint64_t t0 = wall_clock64();
-        const uint64_t ticks = (uint64_t)p.stagger_us * 100u * (uint64_t)(bid >> 8);     // 100 MHz constant clock
-        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+typedef float pv_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pv_f32x2 unpack2(uint32_t w) {
+    return pv_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint32_t pack2(pv_f32x2 v) { return pack_bf16x2(v.x, v.y); }
+
+template <int ACT>
+__device__ __forceinline__ pv_f32x2 act2(pv_f32x2 x) {
+    if constexpr (ACT == PV_ACT_QUICK_GELU) {                // x * sigmoid(1.702 x), models/activation_fns.py:19
+        const pv_f32x2 t = x * (-1.702f * 1.4426950408889634f);
+        pv_f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        d = d + 1.0f;
+        const pv_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        return x * r;
+    } else if constexpr (ACT == PV_ACT_GELU) {               // 0.5 x (1 + erf(x / sqrt 2)); erf: Abramowitz-Stegun 7.1.26
+        const pv_f32x2 z = x * 0.70710678118654752440f;
+        const pv_f32x2 az = __builtin_elementwise_abs(z);
+        const pv_f32x2 den = __builtin_elementwise_fma(az, pv_f32x2{0.3275911f, 0.3275911f}, pv_f32x2{1.0f, 1.0f});
+        const pv_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        pv_f32x2 q = __builtin_elementwise_fma(t, pv_f32x2{1.061405429f, 1.061405429f}, pv_f32x2{-1.453152027f, -1.453152027f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{1.421413741f, 1.421413741f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{-0.284496736f, -0.284496736f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{0.254829592f, 0.254829592f});
+        q = q * t;
+        const pv_f32x2 a2 = az * az * (-1.4426950408889634f);
+        const pv_f32x2 e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+        pv_f32x2 r = __builtin_elementwise_fma(-q, e, pv_f32x2{1.0f, 1.0f});
+        r = __builtin_elementwise_copysign(r, z);
+        const pv_f32x2 hx = x * 0.5f;
+        return __builtin_elementwise_fma(hx, r, hx);
+    } else {
+        return __builtin_elementwise_max(x, pv_f32x2{0.0f, 0.0f});
     }
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk = (int)((Kb + 63) / 64);
-    const bool ktail = (Kb % 64) != 0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
-
-    // a wave-instruction moves 16 rows x 64 B; A has 4*MB of them per slab (wave w: MB), B has 8 (wave w: 2)
-    unsigned offA[MB], kcA[MB], offB[2], kcB[2];
-#pragma unroll
-    for (int j = 0; j < MB; ++j) {
-        const int row = (wave * MB + j) * 16 + (lane >> 2);
-        const int kc = (lane & 3) ^ ((row >> 2) & 3);
-        kcA[j] = kc * 16;
-        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 16 + (lane >> 2);
-        const int kc = (lane & 3) ^ ((row >> 2) & 3);
-        kcB[j] = kc * 16;
-        offB[j] = (unsigned)(n0 + row) * (unsigned)p.ldb * EB + kc * 16;
-    }
-    auto issue = [&](int kt, unsigned char* slot) {
-        const unsigned kbase = (unsigned)kt * 64;
-        const bool dead = (kt >= nk) | (((p.dbg & 1) != 0) & (kt >= 2));
-        // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
-#pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            unsigned o = offA[j] + kbase;
-            o = (dead | (ktail & (kbase + kcA[j] >= Kb))) ? 0xffffff00u : o;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (wave * MB + j) * 1024), 16, o, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned o = offB[j] + kbase;
-            o = (dead | (ktail & (kbase + kcB[j] >= Kb))) ? 0xffffff00u : o;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (wave * 2 + j) * 1024), 16, o, 0, 0, 0);
-        }
-    };
-
-    f32x16 acc[MB][2];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int sw = (l31 >> 2) & 3;
-    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
-    const int a_row = (wm * 32 * MB + l31) * 64;
-    const int b_row = A_BYTES + (wn * 64 + l31) * 64;
-    auto compute = [&](const unsigned char* slot) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int co = j == 0 ? co0 : co1;
-            uint4 a[MB], b[2];
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
-            b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
-            b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-        }
-    };
-
-    // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0
-    const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
-    const bool e_fast = e_gn < p.N;          // the launcher guarantees vec_out and N % 8 == 0: whole chunks only
-    uint4 e_bias = make_uint4(0, 0, 0, 0);
-    uint4 e_res[MB][4];
-    int e_col = e_gn;
-    T* e_out0 = reinterpret_cast<T*>(p.out0);
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
-    const bool e_resid = e_fast && p.epi == PV_EPI_RESID;
-    const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldr + e_gn;
-    const int e_rows_left = p.M - (m0 + wm * 32 * MB + (lane >> 3));      // rows gm < M  <=>  mi*32 + it*8 < e_rows_left
-#define PV_V6_FETCH_RES(MI)                                                                          \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                 \
-        if (e_resid && (MI) * 32 + it * 8 < e_rows_left)                                             \
-            e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr);
-    if (e_fast) {
-        const T* bias = reinterpret_cast<const T*>(p.bias0);
-        if (p.epi == PV_EPI_QKV) {
-            const int which = e_gn / p.nsplit;
-            e_col = e_gn - which * p.nsplit;
-            if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
-            if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
-        }
-        if (bias) e_bias = *reinterpret_cast<const uint4*>(bias + e_col);
-    }
-    PV_V6_FETCH_RES(0)
-
-#define PV_V6_STEP(KT, CUR, NXT2)                         \
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (MB + 2));        \
-    __builtin_amdgcn_s_barrier();                         \
-    issue((KT) + 2, NXT2);                                \
-    compute(CUR);
-
-    issue(0, ring0);
-    issue(1, ring1);
-    int kt = 0;
-    for (; kt + 3 <= nk; kt += 3) {
-        PV_V6_STEP(kt, ring0, ring2)
-        PV_V6_STEP(kt + 1, ring1, ring0)
-        PV_V6_STEP(kt + 2, ring2, ring1)
-    }
-    if (kt < nk) { PV_V6_STEP(kt, ring0, ring2) }
-    if (kt + 1 < nk) { PV_V6_STEP(kt + 1, ring1, ring0) }
-#undef PV_V6_STEP
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
-    __syncthreads();
-    if (p.dbg & 2) {
-        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
-        return;
-    }
-
-    constexpr int CLD = 64;
-    float* Cs = reinterpret_cast<float*>((wave < 2 ? ring0 : ring1) + (wave & 1) * (32 * CLD * 4));
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
-            }
-        __builtin_amdgcn_wave_barrier();
-        if (mi + 1 < MB) { PV_V6_FETCH_RES((mi + 1 < MB ? mi + 1 : 0)) }     // (index kept in range: an OOB index in the dead arm defeats SROA)
-        if (e_fast) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + (lane >> 3);
-                const int cc = (lane & 7) * 8;
-                const int gm = m0 + wm * 32 * MB + mi * 32 + row;
-                if (gm < p.M) {
-                    float v[8];
-                    const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
-                    const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
-                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-                    v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-                    epilogue8_pre<T>(p, v, gm, e_gn, e_col, e_out0, e_bias, e_res[mi][it]);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef PV_V6_FETCH_RES
 }
 
-template <typename T, int MB>
-int launch_v6(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + 64 * MB - 1) / (64 * MB), ntn = (p.N + BN - 1) / BN;
-    {
-        constexpr double EBd = DT<T>::kBytes;
-        const double mn = (double)p.M * p.N;
-        double outs = 1.0;
-        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v6<T, MB>), dim3(ntm * ntn), dim3(256), 0, stream, p);
+// one 8-element chunk: acc + bias -> (rounded) outputs.  o0 / o1 point at the chunk; b = unpacked bias.
+template <int EPI, int ACT>
+__device__ __forceinline__ void epi8_bf16(const float4& x0, const float4& x1, const pv_f32x2 (&b)[4], bf16_t* o0, bf16_t* o1,
+                                          const uint4& res) {
+    pv_f32x2 v[4] = {{x0.x, x0.y}, {x0.z, x0.w}, {x1.x, x1.y}, {x1.z, x1.w}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] + b[i];
+    uint4 r;
+    r.x = pack2(v[0]); r.y = pack2(v[1]); r.z = pack2(v[2]); r.w = pack2(v[3]);
+    if constexpr (EPI == PV_EPI_BIAS || EPI == PV_EPI_QKV) {
+        *reinterpret_cast<uint4*>(o0) = r;
+    } else {
+        // the stored (bf16-rounded) value is what the reference carries on: transformer_block.py:122-124, :134;
+        // mlp.py:67-72
+        if (o0) *reinterpret_cast<uint4*>(o0) = r;
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+        uint4 y;
+        if constexpr (EPI == PV_EPI_RESID) {
+            const uint32_t sw[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = unpack2(rw[i]) + unpack2(sw[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = act2<ACT>(unpack2(rw[i]));
+        }
+        y.x = pack2(v[0]); y.y = pack2(v[1]); y.z = pack2(v[2]); y.w = pack2(v[3]);
+        *reinterpret_cast<uint4*>(o1) = y;
     }
-    PV_LAUNCH_CHECK("gemm_kernel_v6");
-    return PV_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1400,8 +752,9 @@ int launch_v6(const GemmParams& p, hipStream_t stream) {
 //     * MB = 5 makes M = 25600 (512 images x 50 tokens) exactly 80 row tiles: the N = 768 GEMMs (O-projection,
 //       MLP-2) are 240 tiles = ONE round of the 256 CUs, the QKV GEMM 720 = three
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MB>
+template <typename T, int MB, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
+    static_assert(sizeof(T) == 2, "v7 is the bf16 kernel");
     constexpr int TM = 64 * MB;
     constexpr int TN = 256;
     constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
@@ -1493,6 +846,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     const int a_row = (wm * 32 * MB + l31) * 64;
     const int b_row = A_BYTES + (wn * 64 + l31) * 64;
     auto compute = [&](const unsigned char* slot) {
+#ifdef PV_EXP_IGLP
+        __builtin_amdgcn_iglp_opt(PV_EXP_IGLP);
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int co = j == 0 ? co0 : co1;
@@ -1501,36 +857,64 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
             for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
             b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
             b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
+#ifdef PV_EXP_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+#ifdef PV_EXP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
+#ifdef PV_EXP_SGB
+        // instruction order inside one pipeline step (scheduling hints, see the guide's sched_group_barrier masks:
+        // 0x008 MFMA, 0x020 VMEM read (the LDS-DMA issues of slab k+3), 0x100 DS read):
+        //   7 fragment reads of k16 #0 | per row block: 2 MFMA + the k16 #1 read of the fragment just retired |
+        //   k16 #1: 2 MFMA + one DMA issue, MB times
+        __builtin_amdgcn_sched_group_barrier(0x100, MB + 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int mi = 1; mi < MB; ++mi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
     };
 
-    // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0
+    // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0.
+    // The launcher guarantees vec_out and N % 8 == 0: whole 8-element chunks only.
     const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
-    const bool e_fast = e_gn < p.N;          // the launcher guarantees vec_out and N % 8 == 0: whole chunks only
+    const bool e_live = e_gn < p.N;
+    const int e_rows_left = e_live ? p.M - (m0 + wm * 32 * MB + (lane >> 3)) : 0;    // row mi*32 + it*8 of this lane is real iff < e_rows_left
     uint4 e_bias = make_uint4(0, 0, 0, 0);
-    uint4 e_res[MB][4];
-    int e_col = e_gn;
-    T* e_out0 = reinterpret_cast<T*>(p.out0);
+    constexpr int NRES = EPI == PV_EPI_RESID ? MB : 1;
+    uint4 e_res[NRES][4];
 #pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
+    for (int mi = 0; mi < NRES; ++mi)
 #pragma unroll
         for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
-    const bool e_resid = e_fast && p.epi == PV_EPI_RESID;
+    int e_col = e_gn;
+    T* e_out0 = reinterpret_cast<T*>(p.out0);
     const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldr + e_gn;
-    const int e_rows_left = p.M - (m0 + wm * 32 * MB + (lane >> 3));      // rows gm < M  <=>  mi*32 + it*8 < e_rows_left
 #define PV_V7_FETCH_RES(MI)                                                                          \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                 \
-        if (e_resid && (MI) * 32 + it * 8 < e_rows_left)                                             \
-            e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr);
-    if (e_fast) {
+    if constexpr (EPI == PV_EPI_RESID) {                                                             \
+        _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
+            if ((MI) * 32 + it * 8 < e_rows_left)                                                    \
+                e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr); \
+    }
+    if (e_live) {
         const T* bias = reinterpret_cast<const T*>(p.bias0);
-        if (p.epi == PV_EPI_QKV) {
+        if constexpr (EPI == PV_EPI_QKV) {
             const int which = e_gn / p.nsplit;
             e_col = e_gn - which * p.nsplit;
             if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
@@ -1572,6 +956,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
 
     constexpr int CLD = 64;
     float* Cs = reinterpret_cast<float*>((wave < 4 ? ring0 : ring1) + (wave & 3) * (32 * CLD * 4));
+    const pv_f32x2 e_b[4] = {unpack2(e_bias.x), unpack2(e_bias.y), unpack2(e_bias.z), unpack2(e_bias.w)};
+    const int64_t e_row0 = (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldo;
+    T* const o0_base = e_out0 ? e_out0 + e_row0 + e_col : nullptr;
+    T* const o1_base = reinterpret_cast<T*>(p.out1) + e_row0 + e_gn;
+    const float* Cr = Cs + (lane >> 3) * CLD + (lane & 7) * 8;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
 #pragma unroll
@@ -1582,21 +971,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
                 Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
             }
         __builtin_amdgcn_wave_barrier();
-        if (mi + 1 < MB) { PV_V7_FETCH_RES((mi + 1 < MB ? mi + 1 : 0)) }     // (index kept in range: an OOB index in the dead arm defeats SROA)
-        if (e_fast) {
+        // residual rows two blocks ahead: staging block mi freed 32 accumulator registers, which now carry the
+        // rows of blocks 2mi+1 and 2mi+2 -- from block 2 on a load has two blocks of stores to land behind
+        // (indices kept in range: an OOB index in a dead arm defeats SROA)
+        if (2 * mi + 1 < MB) { PV_V7_FETCH_RES((2 * mi + 1 < MB ? 2 * mi + 1 : 0)) }
+        if (2 * mi + 2 < MB) { PV_V7_FETCH_RES((2 * mi + 2 < MB ? 2 * mi + 2 : 0)) }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = it * 8 + (lane >> 3);
-                const int cc = (lane & 7) * 8;
-                const int gm = m0 + wm * 32 * MB + mi * 32 + row;
-                if (gm < p.M) {
-                    float v[8];
-                    const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
-                    const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
-                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
-                    v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-                    epilogue8_pre<T>(p, v, gm, e_gn, e_col, e_out0, e_bias, e_res[mi][it]);
-                }
+        for (int it = 0; it < 4; ++it) {
+            if (mi * 32 + it * 8 < e_rows_left) {
+                const float4 x0 = *reinterpret_cast<const float4*>(Cr + it * 8 * CLD);
+                const float4 x1 = *reinterpret_cast<const float4*>(Cr + it * 8 * CLD + 4);
+                const int64_t ro = (int64_t)(mi * 32 + it * 8) * p.ldo;
+                epi8_bf16<EPI, ACT>(x0, x1, e_b, o0_base ? o0_base + ro : nullptr, o1_base + ro,
+                                    e_res[EPI == PV_EPI_RESID ? mi : 0][it]);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1615,10 +1002,32 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
         ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-        hipLaunchKernelGGL((gemm_kernel_v7<T, MB>), dim3(ntm * ntn), dim3(512), 0, stream, p);
+        const dim3 grid(ntm * ntn), block(512);
+#define PV_V7_LAUNCH(EPI, ACT) hipLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, p)
+        if (p.epi == PV_EPI_BIAS) PV_V7_LAUNCH(PV_EPI_BIAS, 0);
+        else if (p.epi == PV_EPI_QKV) PV_V7_LAUNCH(PV_EPI_QKV, 0);
+        else if (p.epi == PV_EPI_RESID) PV_V7_LAUNCH(PV_EPI_RESID, 0);
+        else if (p.act == PV_ACT_GELU) PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_GELU);
+        else if (p.act == PV_ACT_QUICK_GELU) PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_QUICK_GELU);
+        else PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_RELU);
+#undef PV_V7_LAUNCH
     }
     PV_LAUNCH_CHECK("gemm_kernel_v7");
     return PV_OK;
+}
+
+// v4 or v7 for this shape?  Cost model = rounds over the chip x time of one round, the round times being the
+// measured per-tile K-loop + epilogue of the two kernels at K = 768 on the B/32 shapes (tools/gemm_trace.py):
+// v4 25 us for 3 x (128 x 128) per CU, v7 26.5 us (MB = 4) / 32 us (MB = 5) for one (64*MB) x 256 per CU.
+inline int pick_v7(const GemmParams& p) {
+    if (const char* e = getenv("PV_GEMM_TILE")) return atoi(e);          // 0 = v4, 4 / 5 = v7<MB>
+    auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
+    const int64_t M = p.M, N = p.N;
+    const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 768) * 25.0;
+    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5;
+    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0;
+    if (c4 <= c74 && c4 <= c75) return 0;
+    return c75 <= c74 ? 5 : 4;
 }
 
 template <typename T>
@@ -1642,20 +1051,16 @@ int dispatch(GemmParams& p, hipStream_t stream) {
     if (p.a_mode == PV_A_PLAIN && vec) {
         const uint64_t spanA = ((uint64_t)p.M + BM) * (uint64_t)p.lda * EB, spanB = ((uint64_t)p.N + BN) * (uint64_t)p.ldb * EB;
         if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !getenv("PV_GEMM_V1")) {
-            // v3 (direct-to-LDS DMA, 2 stages) measured 12.5 ms/step vs 11.1-11.4 ms for v2 on the bs=512
-            // B/32 forward (profiles/r01_notes.md): with only 2 stages the DMA has one slab of MFMA time to
-            // land; kept selectable for the 3-stage follow-up
-            // default: v4 (3-stage LDS-DMA ring, 3 workgroups / CU); measured on the bs=512 B/32 forward:
-            // v1 12.6 ms, v2 11.1 ms, v3 12.5 ms, v4 10.5 ms per step (profiles/r01_notes.md)
-            if (getenv("PV_GEMM_V3")) return launch_v3<T>(p, stream);
-            if (getenv("PV_GEMM_V5")) return launch_v5<T>(p, stream);
+            // 128 x 128 tiles, 3 workgroups / CU (v4) or one 8-wave workgroup with a (64*MB) x 256 tile (v7);
+            // history and measurements of the variants in between: profiles/r01_notes.md
             if constexpr (EB == 2) {
-                if (getenv("PV_GEMM_V6") && p.vec_out && p.N % 8 == 0) return launch_v6<T, 4>(p, stream);
-                if (const char* e7 = getenv("PV_GEMM_V7")) {
-                    if (p.vec_out && p.N % 8 == 0) return atoi(e7) == 5 ? launch_v7<T, 5>(p, stream) : launch_v7<T, 4>(p, stream);
+                if (p.vec_out && p.N % 8 == 0) {
+                    const int pick = pick_v7(p);
+                    if (pick == 5) return launch_v7<T, 5>(p, stream);
+                    if (pick == 4) return launch_v7<T, 4>(p, stream);
                 }
             }
-            return getenv("PV_GEMM_V2") ? launch_v2<T>(p, stream) : launch_v4<T>(p, stream);
+            return launch_v4<T>(p, stream);
         }
     }
     if (p.a_mode == PV_A_PLAIN) {

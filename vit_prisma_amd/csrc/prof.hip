@@ -10,10 +10,12 @@ struct Pool {
 };
 Pool g_pool[PV_PROF__COUNT];
 bool g_on = false;
+uint32_t g_mask = 0xffffffffu;
 constexpr size_t kMaxEvents = 16384;
 }  // namespace
 
 bool pv_prof_on() { return g_on; }
+bool pv_prof_on(int kind) { return g_on && ((g_mask >> kind) & 1u); }
 
 int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes) {
     Pool& p = g_pool[kind];
@@ -34,7 +36,8 @@ int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes) {
 void pv_prof_end(int kind, int token, hipStream_t stream) { (void)hipEventRecord(g_pool[kind].stop[token], stream); }
 
 extern "C" int pv_prof_enable(int32_t on) {
-    g_on = on != 0;
+    g_on = (on & 1) != 0;
+    g_mask = (on >> 8) ? (uint32_t)(on >> 8) : 0xffffffffu;      // bits 8.. = kernel families to time (0 = all)
     return PV_OK;
 }
 

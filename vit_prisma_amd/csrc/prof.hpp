@@ -15,6 +15,7 @@ enum {
 };
 
 bool pv_prof_on();
+bool pv_prof_on(int kind);      // enabled AND this kernel family selected (pv_prof_enable's mask)
 // Records a start event on `stream`; returns a token (< 0 when disabled / pool exhausted).
 int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes);
 void pv_prof_end(int kind, int token, hipStream_t stream);
@@ -23,7 +24,7 @@ struct ProfScope {
     int kind, token;
     hipStream_t stream;
     ProfScope(int k, hipStream_t s, double flops, double bytes) : kind(k), token(-1), stream(s) {
-        if (pv_prof_on()) token = pv_prof_begin(k, s, flops, bytes);
+        if (pv_prof_on(k)) token = pv_prof_begin(k, s, flops, bytes);
     }
     ~ProfScope() {
         if (token >= 0) pv_prof_end(kind, token, stream);
