@@ -1,6 +1,9 @@
-for v in base nob; do
-  lib=$PWD/tools/variants/libpvnative_$v.so; [ $v = base ] && lib=$PWD/vit_prisma_amd/libpvnative.so
-  for t in 5 4; do for d in 2 3; do
-    echo "== $v tile=$t dbg=$d"; PV_NATIVE_LIB=$lib PV_GEMM_DBG=$d PV_GEMM_TILE=$t REPS=20 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids | awk '{printf "%s %s us %s TF | ", $1, $3, $5} END {print ""}'
-  done; done
-done
+python -m pytest tests/test_native_vit_gpu.py -m gpu -x -q 2>&1 | tail -3
+for r in 1 2; do
+for v in v8 v7; do
+  e=A=1; [ $v = v7 ] && e=PV_GEMM_NO_V8=1
+  env $e python bench.py --no-sae --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v bench', j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['avg_launch_us'])"
+done; done
+python tools/gemm_trace.py 2>&1 | grep -v "amdgpu.ids\|timeline\|avg resident"

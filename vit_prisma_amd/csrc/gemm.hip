@@ -432,13 +432,6 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
     const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     trace_stamp(p.trace, bid, 0);
-    if (p.stagger_us > 0 && bid >= 256 && bid < 256 * 3) {
-        // phase offset between the workgroups that share a CU (first resident wave only; later workgroups
-        // inherit it): without it they all compute together and then all store together
-        const uint64_t t0 = wall_clock64();
-        const uint64_t ticks = (uint64_t)p.stagger_us * 100u * (uint64_t)(bid >> 8);     // 100 MHz constant clock
-        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-    }
 
     const unsigned Kb = (unsigned)p.K * EB;
     const int nk = (int)((Kb + V4_SLAB - 1) / V4_SLAB);
@@ -824,14 +817,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
             if constexpr (PAD) { if (j == NA - 1) dst = realA[j] ? dst : pad + wave * 1024; }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, o, 0, 0, 0);
         }
-#ifndef PV_EXP_NOB
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             unsigned o = offB[j] + kbase;
             o = (dead | (ktail & (kbase + kcB[j] >= Kb))) ? 0xffffff00u : o;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
         }
-#endif
     };
 
     f32x16 acc[MB][2];
@@ -848,64 +839,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     const int a_row = (wm * 32 * MB + l31) * 64;
     const int b_row = A_BYTES + (wn * 64 + l31) * 64;
     auto compute = [&](const unsigned char* slot) {
-#ifdef PV_EXP_IGLP
-        __builtin_amdgcn_iglp_opt(PV_EXP_IGLP);
-#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int co = j == 0 ? co0 : co1;
             uint4 a[MB], b[2];
-#ifdef PV_EXP_NOLDS
-            // loop ablation: fragments fabricated in registers, no ds_read at all
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi) a[mi] = make_uint4(co + mi, lane, co, mi);
-            b[0] = make_uint4(lane, co, 1, 2);
-            b[1] = make_uint4(co, lane, 3, 4);
-            asm volatile("" : "+v"(b[0].x), "+v"(b[1].x));
-#else
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
-#ifdef PV_EXP_NOB
-            b[0] = make_uint4(lane, co, 1, 2);
-            b[1] = make_uint4(co, lane, 3, 4);
-            asm volatile("" : "+v"(b[0].x), "+v"(b[1].x));
-#else
             b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
             b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
-#endif
-#endif
-#ifdef PV_EXP_PRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-#ifdef PV_EXP_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
-#ifdef PV_EXP_SGB
-        // instruction order inside one pipeline step (scheduling hints, see the guide's sched_group_barrier masks:
-        // 0x008 MFMA, 0x020 VMEM read (the LDS-DMA issues of slab k+3), 0x100 DS read):
-        //   7 fragment reads of k16 #0 | per row block: 2 MFMA + the k16 #1 read of the fragment just retired |
-        //   k16 #1: 2 MFMA + one DMA issue, MB times
-        __builtin_amdgcn_sched_group_barrier(0x100, MB + 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-        for (int mi = 1; mi < MB; ++mi) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#endif
     };
 
     // epilogue operands in flight before the K loop (see v4): bias chunk + residual rows of block 0.
@@ -941,97 +889,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     }
     PV_V7_FETCH_RES(0)
 
-#ifdef PV_V7_PINGPONG
-    // Ping-pong K loop: the two waves that share a SIMD (w and w + 4) never run the same kind of segment at the
-    // same time.  A wave alternates  LOAD(k): issue the DMA of slab k+3, read ALL fragments of slab k into
-    // registers (14 ds_read_b128 at MB = 5)  and  COMPUTE(k): 4*MB MFMAs out of registers, nothing else --
-    // separated by workgroup barriers, waves 4..7 one segment behind waves 0..3:
-    //      waves 0-3:  L0 | C0 | L1 | C1 | ...        waves 4-7:  -- | L0 | C0 | L1 | ...
-    // so the matrix pipe always sees one wave streaming MFMAs while its partner does the LDS / DMA work
-    // (an LDS-DMA issue costs 100-185 cycles next to ds_reads of the same wave, MI355X_MICROARCH.md).
-    // Slot safety: slab k+3 goes to the slot of slab k-1, whose last reader (waves 4-7, LOAD(k-1)) finished before
-    // the barrier that opens this segment.  Both barriers wait vmcnt(2*(NA+2)): own pieces of slab k (before
-    // LOAD(k)) resp. k+1 (before COMPUTE(k), which is the partner group's "before LOAD(k+1)") have landed.
-    uint4 fa[2][MB], fb[2][2];
-    auto load_frags = [&](const unsigned char* slot) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int co = j == 0 ? co0 : co1;
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi) fa[j][mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
-            fb[j][0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
-            fb[j][1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
-        }
-    };
-    auto mfma_slab = [&]() {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, fa[j][mi]), __builtin_bit_cast(bf16x8, fb[j][ni]), acc[mi][ni], 0, 0, 0);
-    };
-    static_assert(2 * (NA + 2) <= 15, "vmcnt immediate below uses the low 4 bits only");
-#define PV_V7_STEP(KT, CUR, NXT3)                                          \
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NA + 2)));                   \
-    __builtin_amdgcn_s_barrier();                                          \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    issue((KT) + 3, NXT3);                                                 \
-    load_frags(CUR);                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    __builtin_amdgcn_s_waitcnt(0x0070 | (2 * (NA + 2)));                   \
-    __builtin_amdgcn_s_barrier();                                          \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    mfma_slab();                                                           \
-    __builtin_amdgcn_sched_barrier(0);
-
-    issue(0, ring0);
-    issue(1, ring1);
-    issue(2, ring2);
-    if (wave >= 4) {                       // the trailing group starts one segment late
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (NA + 2)));
-        __builtin_amdgcn_s_barrier();
-    }
-    int kt = 0;
-    for (; kt + 4 <= nk; kt += 4) {
-        PV_V7_STEP(kt, ring0, ring3)
-        PV_V7_STEP(kt + 1, ring1, ring0)
-        PV_V7_STEP(kt + 2, ring2, ring1)
-        PV_V7_STEP(kt + 3, ring3, ring2)
-    }
-    if (kt < nk) { PV_V7_STEP(kt, ring0, ring3) }
-    if (kt + 1 < nk) { PV_V7_STEP(kt + 1, ring1, ring0) }
-    if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
-#undef PV_V7_STEP
-    if (wave < 4) __builtin_amdgcn_s_barrier();          // the leading group's closing barrier
-#else
     // step kt: slab kt must have landed -- the 2 * (NA + 2) DMA instructions of slabs kt+1, kt+2 may stay in flight
-#ifdef PV_EXP_NOB
-    constexpr int NPIECE = NA;
-#else
     constexpr int NPIECE = NA + 2;
-#endif
     static_assert(2 * NPIECE <= 15, "vmcnt immediate below uses the low 4 bits only");
-#ifdef PV_EXP_NOBAR
-#define PV_V7_SYNC()
-#else
 #define PV_V7_SYNC() __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPIECE)); __builtin_amdgcn_s_barrier();
-#endif
-#if defined(PV_EXP_DMA_LATE)
-#define PV_V7_STEP(KT, CUR, NXT3)                               \
-    PV_V7_SYNC()                                                \
-    compute(CUR);                                               \
-    __builtin_amdgcn_sched_barrier(0);                          \
-    issue((KT) + 3, NXT3);                                      \
-    __builtin_amdgcn_sched_barrier(0);
-#else
 #define PV_V7_STEP(KT, CUR, NXT3)                               \
     PV_V7_SYNC()                                                \
     issue((KT) + 3, NXT3);                                      \
     compute(CUR);
-#endif
 
     issue(0, ring0);
     issue(1, ring1);
@@ -1048,7 +913,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
 #undef PV_V7_STEP
 #undef PV_V7_SYNC
-#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
     __syncthreads();
     trace_stamp(p.trace, bid, 1);
@@ -1201,7 +1065,6 @@ extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int3
 
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     if (const char* e = getenv("PV_GEMM_DBG")) p.dbg = atoi(e);
-    if (const char* e = getenv("PV_GEMM_STAGGER")) p.stagger_us = atoi(e);
     p.trace = nullptr;
     if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {
         if (g_trace_countdown-- == 0) {

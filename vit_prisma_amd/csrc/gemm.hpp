@@ -32,7 +32,6 @@ struct GemmParams {
     const void* resid;       // RESID: [M][ldr]
     int64_t ldr;
     int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
-    int32_t stagger_us;      // experiment: start delay (us) x (blockIdx / 256) for the first resident wave of workgroups
     uint64_t* trace;         // debug: per-workgroup {t_start, t_loop_end, t_end, hw_id} (100 MHz wall clock) or NULL
     int32_t dbg;             // ablation switches for kernel tuning (PV_GEMM_DBG): 1 = no DMA in the loop, 2 = no epilogue
 };
