@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sae", action="store_true")
+    ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -118,21 +119,76 @@ def sae_cpu_baseline(seconds: float) -> dict:
 
 
 def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 2x FETCH correction);
-    None when no PMC summary is committed."""
+    """HBM bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_traffic*.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x FETCH correction), as the
+    launch-weighted mean over every kernel of the family (the GEMM family = all its template instances: what the
+    HIP events of the timed region bracket).  None when no PMC summary is committed."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), key=os.path.getmtime)
+    for path in reversed(paths):
         try:
             with open(path) as f:
                 d = json.load(f)
-            for k, v in d.get("kernels", {}).items():
-                if k.startswith(kernel_prefix) and "hbm_bytes_per_launch_corrected" in v:
-                    best = {"bytes_per_launch": v["hbm_bytes_per_launch_corrected"], "source": os.path.basename(path), "kernel": k}
         except Exception:
-            pass
-    return best
+            continue
+        tot = n = 0
+        names = []
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith(kernel_prefix) and "hbm_bytes_per_launch_corrected" in v:
+                tot += v["hbm_bytes_per_launch_corrected"] * v.get("launches", 1)
+                n += v.get("launches", 1)
+                names.append(k)
+        if n:
+            return {"bytes_per_launch": int(tot / n), "source": os.path.basename(path), "kernel": ", ".join(names)}
+    return None
+
+
+def l14_pattern_leg(dev, dist, batch: int = 128, steps: int = 3, warmup: int = 1) -> dict:
+    """BASELINE.json configs[4] / SURVEY.md 8d config 5: CLIP ViT-L/14 @336, bs = 128, bf16, only the 24
+    ``attn.hook_pattern`` tensors tapped ([128, 16, 577, 577] each = 32.7 GB of taps per step)."""
+    import time as _t
+    import torch
+    from vit_prisma_amd import HookedViT, HookedViTConfig
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    arch = ARCHS["clip-vit-l14-336"]
+    model = HookedViT(HookedViTConfig(**arch, dtype=torch.bfloat16, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.to(torch.bfloat16).to(dev).eval().use_native(True)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    images = torch.randn(batch, 3, 336, 336, device=dev, generator=g).to(torch.bfloat16)
+    keep = lambda n: n.endswith("attn.hook_pattern")  # noqa: E731
+    n_keys = 0
+    with torch.no_grad():
+        for _ in range(warmup):
+            out, cache = model.run_with_cache(images, names_filter=keep)
+            n_keys = len(cache)
+            del out, cache
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            out, cache = model.run_with_cache(images, names_filter=keep)
+            del out, cache
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = _t.perf_counter() - t0
+    assert model.last_run_native and n_keys == arch["n_layers"], (model.native_fallback_reason, n_keys)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ips = batch * steps * world / elapsed
+    flop_img, bytes_img = 381.92e9, 255.7e6                      # SURVEY.md 8d, algorithmic work per image
+    return {"metric": "images/sec run_with_cache (attn.hook_pattern only) CLIP ViT-L/14 @336", "value": round(ips, 1),
+            "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
+            "dtype": "bf16", "config": {"workload": f"CLIP ViT-L/14@336, bs={batch}/GPU, 24 pattern taps"},
+            "roofline": {"bound": "mfma", "achieved": round(ips / world * flop_img / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ips / world * flop_img / 1e12 / PEAK_BF16_TFLOPS, 4),
+                         "hbm_GBps_algorithmic": round(ips / world * bytes_img / 1e9, 1)}}
 
 
 def main():
@@ -212,7 +268,7 @@ def main():
     peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
     gemm_tf = gemm["flops"] / max(gemm["ms"], 1e-9) / 1e9
     roofline = {
-        "kernel": "gemm_kernel (MFMA GEMM + fused bias/GELU/residual/tap epilogue)",
+        "kernel": "gemm_kernel_v7 family (bf16 MFMA GEMM, 320x256 tile per CU, fused bias / activation / residual / tap-store epilogues; + the patch-embed and head GEMMs)",
         "bound": "mfma", "achieved": round(gemm_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
         "frac": round(gemm_tf / peak_tf, 4),
         "launches": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),
@@ -221,7 +277,7 @@ def main():
         "share_of_step": round(gemm["ms"] / (ms_per_step * a.steps), 4),
         "traffic": None,
     }
-    tr = pmc_traffic("gemm_kernel_v") if a.dtype == "bf16" and a.batch == 512 else None
+    tr = pmc_traffic("gemm_kernel") if a.dtype == "bf16" and a.batch == 512 else None
     if tr is not None:
         roofline["traffic"] = tr["bytes_per_launch"]
         roofline["traffic_source"] = f"{tr['source']} ({tr['kernel']}); algorithmic bytes per launch = {gemm['bytes'] / max(gemm['launches'], 1):.4g}"
@@ -254,10 +310,19 @@ def main():
         del model, images
         torch.cuda.empty_cache()
         sae = sae_bench_leg(dev, dist=dist)
+        torch.cuda.empty_cache()
+        from vit_prisma_amd.sae.bench_leg import sae_end_to_end_leg
+        e2e = sae_end_to_end_leg(dev, dist=dist)
         if rank == 0:
             line["sae"] = sae
+            sae["end_to_end"] = e2e
             if world == 1 and not a.no_cpu_baseline:
                 sae["cpu_baseline"] = sae_cpu_baseline(10.0)
+    if not a.no_l14:
+        torch.cuda.empty_cache()
+        l14 = l14_pattern_leg(dev, dist)
+        if rank == 0:
+            line["l14_336_pattern"] = l14
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         line["speedup_vs_cpu_port"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -242,12 +242,12 @@ def test_bf16_full_size_properties_bs512():
     assert torch.equal(out1[0], out[17])
 
 
-@pytest.mark.parametrize("arch_name,bs", [("clip-vit-b32", 5), ("tiny-ragged", 3)])
+@pytest.mark.parametrize("arch_name,bs", [("clip-vit-b32", 5), ("tiny-ragged", 3), ("clip-vit-l14-336", 1)])
 def test_bf16_attention_core_against_fp32_recompute_of_its_own_inputs(arch_name, bs):
     """The attention kernels in isolation: scores / pattern / z recomputed in fp32 torch from the q, k, v the
-    same run cached (so every input is bit-identical), against the bf16 taps.  Both arches have an even token
-    count (50, 10): the one-head-per-wave kernel; bound = one bf16 rounding of each stage (2^-8 relative),
-    attention.py:246-281."""
+    same run cached (so every input is bit-identical), against the bf16 taps.  Token counts 50 and 10 (even): the
+    one-head-per-wave kernel; 577 (L/14@336): the query-block kernel with its bf16 score block in LDS.
+    Bound = one bf16 rounding of each stage (2^-8 relative), attention.py:246-281."""
     model, arch, sd = build(arch_name, torch.bfloat16)
     out, cache = run(model, synth_images(arch, bs, 3), torch.bfloat16)
     for layer in range(arch["n_layers"]):

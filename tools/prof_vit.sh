@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_vit
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vit -o vit -- python $R/bench.py --no-sae --no-cpu-baseline --steps 10 --warmup 3 > $R/gpurun_out/prof_vit_bench.json 2> $R/gpurun_out/prof_vit.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vit -o vit -- python $R/bench.py --no-sae --no-l14 --no-cpu-baseline --steps 10 --warmup 3 > $R/gpurun_out/prof_vit_bench.json 2> $R/gpurun_out/prof_vit.err
 ls -la $R/gpurun_out/prof_vit/
 head -30 $R/gpurun_out/prof_vit/*kernel_stats.csv
 python - <<'PY'

@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int T_ = p.T, H = p.H;
     const int q0 = qb * QB;
     const int Tpad = p.Tpad;
-    const int srow = Tpad * 4 + 16;                 // bytes
+    // S element: fp32 in the whole-head (FLAT) variant, the storage dtype otherwise -- the scores are rounded to
+    // it anyway before the softmax (like the reference's bf16 tensor), and at T = 577 a bf16 S block is 41 KB
+    // instead of 82 KB: two workgroups per CU instead of one
+    constexpr int SB = QB == 64 ? 4 : EB;
+    const int srow = Tpad * SB + 16;                // bytes
     // FLAT (QB == 64: the whole T x T matrix of this head lives in the workgroup): the fp32 scores stay
     // intact in S, P goes to its own region, and both taps are stored afterwards as ONE flat contiguous
     // range per (image, head) (256 B per wave-instruction instead of one <= 100-byte row per instruction)
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) {
             const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
             const float s = DT<T>::round(acc[e] / p.attn_scale);
-            *reinterpret_cast<float*>(S + row * srow + (tk * 32 + l31) * 4) = s;
+            if constexpr (SB == 4) *reinterpret_cast<float*>(S + row * srow + (tk * 32 + l31) * 4) = s;
+            else DT<T>::store(reinterpret_cast<T*>(S + row * srow) + tk * 32 + l31, s);
         }
     }
     __syncthreads();
@@ -124,13 +129,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     for (int r = wave; r < QB; r += 4) {
         const int qi = q0 + r;
         if (qi >= T_) continue;                      // pad rows: never stored, never normalised
-        float* srowp = reinterpret_cast<float*>(S + r * srow);
+        const unsigned char* srowp = S + r * srow;
         float v[MAXC];
         float m = -INFINITY;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int col = lane + 64 * c;
-            v[c] = (col < Tpad) ? srowp[col] : 0.f;
+            if constexpr (SB == 4) v[c] = (col < Tpad) ? reinterpret_cast<const float*>(srowp)[col] : 0.f;
+            else v[c] = (col < Tpad) ? DT<T>::load(reinterpret_cast<const T*>(srowp) + col) : 0.f;
             if (col < T_) m = fmaxf(m, v[c]);
         }
         m = wave_max(m);
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 template <typename T, int QB, int DH, int MAXC>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
     constexpr int EB = DT<T>::kBytes;
-    const int srow = p.Tpad * 4 + 16;
+    const int srow = p.Tpad * (QB == 64 ? 4 : EB) + 16;
     const int lds = QB * srow + (QB == 64 ? QB * (p.Tpad * EB + 16) : 0) + (EB == 2 ? DH * VT_ROW : 0);
     PV_REQUIRE(lds <= 160 * 1024, "attention LDS footprint exceeds 160 KiB");
     static int max_set = 0;

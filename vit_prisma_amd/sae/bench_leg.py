@@ -93,3 +93,89 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
         },
     }
     return res
+
+
+class _ResidentImages(torch.utils.data.Dataset):
+    """Synthetic image set that lives in HBM: items are (image view, label) like the reference's datasets."""
+
+    def __init__(self, n: int, dev: torch.device, dtype: torch.dtype, seed: int):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.x = torch.randn(n, 3, 224, 224, device=dev, generator=g).to(dtype)
+
+    def __len__(self) -> int:
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return self.x[i], 0
+
+
+def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 40, warmup: int = 4) -> dict:
+    """Config 3, second number: the training loop the reference runs -- VisionActivationsStore
+    harvesting ``blocks.6.hook_resid_post`` from randn images through ViT blocks 0..6 (native run_with_cache,
+    names_filter + stop_at_layer), half-buffer shuffle-mix, VisionSAETrainer.train_step on the fused native step.
+    ViT weights / activations bf16, SAE master weights fp32.  One-time work (first buffer fill, b_dec init, plan
+    and engine creation) is outside the timed region; buffer refills are inside it."""
+    from .. import HookedViT, HookedViTConfig
+    from ..synth import ARCHS, synth_vit_state
+    from .config import VisionModelSAERunnerConfig
+    from .sae import StandardSparseAutoencoder
+    from .trainer import VisionSAETrainer
+
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    arch = ARCHS["clip-vit-b32"]
+    model = HookedViT(HookedViTConfig(**arch, dtype=torch.bfloat16, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.to(torch.bfloat16).to(dev).eval().use_native(True)
+    store_bs, n_buf = 256, 8
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
+        activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, normalize_activations="layer_norm",
+        initialization_method="independent", b_dec_init_method="mean", train_batch_size=N_TOKENS, lr=1e-3,
+        max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
+        context_size=50, store_batch_size=store_bs, n_batches_in_buffer=n_buf)
+    data = _ResidentImages(4 * store_bs, dev, torch.bfloat16, seed=77 + rank)
+    sae = StandardSparseAutoencoder(cfg)
+    tr = VisionSAETrainer(cfg, model=model, dataset=data, sparse_coder=sae)
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    tr.initialize_geometric_medians()
+    store = tr.activations_store
+    n_steps = 0
+
+    def one():
+        nonlocal act, since, frac, n_steps
+        x = store.next_batch()
+        _, _, _, _, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act,
+            n_forward_passes_since_fired=since, n_frac_active_tokens=frac, layer_acts=x,
+            n_training_steps=n_steps, n_training_tokens=n_steps * N_TOKENS)
+        n_steps += 1
+        return x.shape[0]
+
+    for _ in range(warmup):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(steps):
+        tokens += one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert model.last_run_native, model.native_fallback_reason
+    return {
+        "metric": "SAE training tokens/sec end to end (harvest blocks 0..6 + shuffle buffer + train step)",
+        "value": round(tokens * world / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "bf16 ViT / f32 SAE",
+        "config": {"workload": f"VisionSAETrainer loop: store_batch_size {store_bs} x n_batches_in_buffer {n_buf}, "
+                               f"global train batch {N_TOKENS} tokens, hook blocks.6.hook_resid_post, images resident in HBM",
+                   "tokens_per_gpu_per_step": N_TOKENS // world},
+        "flop_per_token": {"harvest": 104.8e6, "sae_step": 37.95e6},
+    }
