@@ -183,6 +183,12 @@ int pv_prof_enable(int32_t on);
 int pv_prof_reset(void);
 int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* Debug only (tools/gemm_trace.py): per-workgroup phase stamps {t_start, t_loop_end, t_end, hw_id} (100 MHz wall
+ * clock) of the launch_idx-th plain GEMM launch from now; read blocks until the device is idle.
+ * info6 = {M, N, K, epilogue, n_workgroups, kernel id}. */
+int pv_debug_gemm_trace_arm(int32_t launch_idx);
+int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6);
+
 /* ------------------------------------------------------------------------------------------ */
 /* SAE training step (sae/sae.py:557-645 forward; sae/train_sae.py:278-411 step)                */
 /* ------------------------------------------------------------------------------------------ */

@@ -80,6 +80,7 @@ EXPORTS = [
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_apply", "pv_sae_encode_topk",
+    "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read",
 ]
 
 
