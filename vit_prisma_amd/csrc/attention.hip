@@ -17,6 +17,7 @@
 #include "attention.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 #include "prof.hpp"
 
 namespace {
@@ -506,6 +507,271 @@ int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Long-sequence variant (bf16, T > 64: L/14@336 has T = 577): a WAVE owns 32 query rows of one (image, head) and
+// streams the keys twice, with the product SWAPPED (S^T = K Q^T) so that a lane holds 16 keys of ONE query:
+//   pass 1  per 32-key tile: S^T tile on MFMA (K rows and the wave's Q rows straight from global, pad rows read 0),
+//           scaled + rounded to bf16 like the reference's score tensor, online (max, sum) per lane; the two lanes of
+//           a query (halves of the wave) are merged at the end
+//   pass 2  the same tiles again: p = exp(s - max) / sum, rounded; (a) hook_pattern: the 32 x 32 tile goes through
+//           2.5 KB of LDS to become 32-byte row pieces -> dword stores (the [T][T] block of a head is only 2-byte
+//           aligned when T is odd: odd-address rows are shifted one element with funnel shifts);
+//           (b) z += P V on MFMA -- P moves from the C layout to the A-operand layout with one cross-half
+//           exchange per k16 step, V fragments are 2-byte buffer loads (32 lanes = 64 contiguous bytes of a key row)
+//   The four waves of a workgroup (128 consecutive queries of one head) share each 32-key K (and V) tile: fetched
+//   cooperatively as full 128-byte rows into registers one tile ahead, parked in 4.5 KB of LDS between two barriers.
+//   No [QB][T] score block in LDS (the workgroup kernel above needs 41 KB of it and runs 8 waves per CU);
+//   hook_attn_scores, when tapped, is written from pass 1 the same way as the pattern.
+// ---------------------------------------------------------------------------------------------------
+constexpr int AS_PROW = 80;                 // bytes per LDS row of a 32 x 32 bf16 tile (64 + 16 pad)
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
+    static_assert(DH == 64, "d_head 64");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * 144];      // per wave: P tile (2.5 KB) / z staging (4.5 KB)
+    __shared__ __attribute__((aligned(16))) unsigned char Kst[32 * 144];          // the workgroup's current key tile   [32][d_head] (+16 B pad)
+    __shared__ __attribute__((aligned(16))) unsigned char Vst[32 * 144];          // ... and value tile (pass 2)
+    constexpr int NKS = DH / 16;
+    constexpr int NTN = DH / 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T_ = p.T, H = p.H;
+    const int qblocks = (T_ + 127) / 128;
+    const int g = blockIdx.x / qblocks;                     // (image, head)
+    const int q0 = (blockIdx.x - g * qblocks) * 128 + wave * 32;
+    const bool active = q0 < T_;                            // idle waves of a head's last block still load tiles and meet the barriers
+    const int b = g / H, h = g - b * H;
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned char* L = smem[wave];
+    const unsigned tokb = (unsigned)H * DH * 2u;
+    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;
+    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
+    const int ntile = (T_ + 31) / 32;
+    const float inv_scale = 1.0f / p.attn_scale;     // (a power of two for every d_head in use; the product is rounded to bf16 next)
+
+    // Q as the B operand (columns = this wave's queries): lane (query l31, half) holds d-chunk (2 ks + half)
+    u32x4_t qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+
+    // S^T tile kt: acc[e] = score(query q0 + l31, key kt*32 + (e & 3) + 8 * (e >> 2) + 4 * half), bf16-rounded
+    // cooperative tile fetch: thread t moves 16 B of key row t / 8 (one full 128-byte row per 8 lanes; rows >= T read 0)
+    const unsigned tile_off = (unsigned)(threadIdx.x >> 3) * tokb + (threadIdx.x & 7) * 16;
+    const int tile_lds = (threadIdx.x >> 3) * 144 + (threadIdx.x & 7) * 16;
+    auto score_tile = [&](int kt, float (&sc)[16]) {
+        uint4 kf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(Kst + l31 * 144 + (2 * ks + half) * 16);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = bf16_to_f32(f32_to_bf16(acc[e] * inv_scale));
+    };
+    // a 32 x 32 bf16 tile held as 8 packed dwords per lane (pk[i] = keys (4 i' .. ) see above) -> LDS -> row-piece stores
+    // into the head's [T][T] block `dst` (element (q, key)); lane handles row lane >> 1, 16 elements from key (lane & 1) * 16
+    auto store_tile = [&](bf16_t* dst, int kt, const uint32_t (&pk)[8]) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)          // keys 8 gq + 4 half + 0..3 of query l31: 8 contiguous bytes
+            *reinterpret_cast<uint2*>(L + l31 * AS_PROW + (8 * gq + 4 * half) * 2) = make_uint2(pk[2 * gq], pk[2 * gq + 1]);
+        __builtin_amdgcn_wave_barrier();
+        const int row = lane >> 1, k0 = kt * 32 + (lane & 1) * 16;
+        const uint4 r0 = *reinterpret_cast<const uint4*>(L + row * AS_PROW + (lane & 1) * 32);
+        const uint4 r1 = *reinterpret_cast<const uint4*>(L + row * AS_PROW + (lane & 1) * 32 + 16);
+        __builtin_amdgcn_wave_barrier();
+        const int q = q0 + row;
+        const int nv = min(16, T_ - k0);
+        if (q < T_ && nv > 0) {
+            const int64_t gidx = (int64_t)q * T_ + k0;                 // element index inside the head's block
+            unsigned char* d = reinterpret_cast<unsigned char*>(dst) + gidx * 2;
+            const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const bool odd = (reinterpret_cast<uintptr_t>(d) & 2) != 0;
+            if (nv == 16 && !odd) {
+                *reinterpret_cast<uint4*>(d) = r0;                     // dword-aligned 16-byte stores
+                *reinterpret_cast<uint4*>(d + 16) = r1;
+            } else if (nv == 16) {
+                *reinterpret_cast<unsigned short*>(d) = (unsigned short)(w[0] & 0xffffu);
+                uint32_t o[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) o[i] = (w[i] >> 16) | (w[i + 1] << 16);
+                *reinterpret_cast<uint4*>(d + 2) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint2*>(d + 18) = make_uint2(o[4], o[5]);
+                *reinterpret_cast<uint32_t*>(d + 26) = o[6];
+                *reinterpret_cast<unsigned short*>(d + 30) = (unsigned short)(w[7] >> 16);
+            } else {
+                for (int i = 0; i < nv; ++i)
+                    *reinterpret_cast<unsigned short*>(d + 2 * i) = (unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
+            }
+        }
+    };
+
+    // ---- pass 1: online max / sum (and the score tap)
+    bf16_t* sc_dst = p.scores ? reinterpret_cast<bf16_t*>(p.scores) + (int64_t)g * T_ * T_ : nullptr;
+    float m = -INFINITY, l = 0.f;
+    auto pass1_tile = [&](int kt, auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
+        float sc[16];
+        score_tile(kt, sc);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (!MASK || key < T_) tm = fmaxf(tm, sc[e]);
+        }
+        const float mn = fmaxf(m, tm);
+        float add = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (!MASK || key < T_) add += __expf(sc[e] - mn);
+        }
+        l = (mn == -INFINITY) ? 0.f : l * __expf(m - mn) + add;
+        m = mn;
+        if (sc_dst) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(sc[2 * i], sc[2 * i + 1]);
+            store_tile(sc_dst, kt, pk);
+        }
+    };
+    // tile kt+1 is fetched into registers while tile kt is consumed out of LDS (only the last tile can hold keys >= T)
+    *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        u32x4_t kn = {0, 0, 0, 0};
+        if (kt + 1 < ntile) kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+        if (active) {
+            if (kt + 1 < ntile) pass1_tile(kt, std::false_type{});
+            else pass1_tile(kt, std::true_type{});
+        }
+        __syncthreads();
+        *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = kn;
+        __syncthreads();
+    }
+    {   // merge the two lanes of a query
+        const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, mo);
+        l = (M == -INFINITY) ? 0.f : l * __expf(m - M) + lo * __expf(mo - M);
+        m = M;
+    }
+    const float rl = active ? 1.0f / l : 0.f;
+
+    // ---- pass 2: pattern tap + z
+    bf16_t* pt_dst = p.pattern ? reinterpret_cast<bf16_t*>(p.pattern) + (int64_t)g * T_ * T_ : nullptr;
+    f32x16 zacc[NTN];
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zacc[tn][e] = 0.f;
+    auto pass2_tile = [&](int kt, auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
+        float sc[16];
+        score_tile(kt, sc);
+        uint32_t pk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float pv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = 2 * i + u;
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                float x = (!MASK || key < T_) ? __expf(sc[e] - m) * rl : 0.f;
+                if (x != x) x = 0.f;                                     // attention.py:149
+                pv[u] = x;
+            }
+            pk[i] = pack_bf16x2(pv[0], pv[1]);
+        }
+        if (pt_dst) store_tile(pt_dst, kt, pk);
+        // P from the C layout (this lane: keys 4 half + 8 j + 0..3, j = 0..3, as pk[2j], pk[2j+1]) to the A operand
+        // (lane needs keys ks*16 + half*8 + 0..7): per k16 step the halves swap one group of four keys
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // half 0 keeps group 2ks, sends group 2ks+1, receives the partner's group 2ks; half 1 the mirror image
+            const uint32_t s0 = half ? pk[4 * ks + 0] : pk[4 * ks + 2];
+            const uint32_t s1 = half ? pk[4 * ks + 1] : pk[4 * ks + 3];
+            const uint32_t r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+            u32x4_t pa;
+            if (half) pa = u32x4_t{r0, r1, pk[4 * ks + 2], pk[4 * ks + 3]};
+            else pa = u32x4_t{pk[4 * ks + 0], pk[4 * ks + 1], r0, r1};
+#pragma unroll
+            for (int tn = 0; tn < NTN; ++tn) {
+                uint32_t w[4];
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    const unsigned char* vp = Vst + (ks * 16 + half * 8 + q2 * 2) * 144 + (tn * 32 + l31) * 2;
+                    const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(vp);
+                    const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(vp + 144);
+                    w[q2] = lo16 | (hi16 << 16);
+                }
+                zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa),
+                                                                   __builtin_bit_cast(bf16x8, u32x4_t{w[0], w[1], w[2], w[3]}), zacc[tn], 0, 0, 0);
+            }
+        }
+    };
+    *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
+    *reinterpret_cast<u32x4_t*>(Vst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsV, tile_off, 0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        u32x4_t kn = {0, 0, 0, 0}, vn = {0, 0, 0, 0};
+        if (kt + 1 < ntile) {
+            kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+            vn = __builtin_amdgcn_raw_buffer_load_b128(rsV, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+        }
+        if (active) {
+            if (kt + 1 < ntile) pass2_tile(kt, std::false_type{});
+            else pass2_tile(kt, std::true_type{});
+        }
+        __syncthreads();
+        *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = kn;
+        *reinterpret_cast<u32x4_t*>(Vst + tile_lds) = vn;
+        __syncthreads();
+    }
+    if (!active) return;
+
+    // ---- z: C layout (col = d, rows = queries) -> LDS rows [32][DH] -> 16-byte row stores
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            *reinterpret_cast<bf16_t*>(L + row * 144 + (tn * 32 + l31) * 2) = f32_to_bf16(zacc[tn][e]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    {
+        constexpr int CPR = DH / 8;
+        bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
+        for (int c = lane; c < 32 * CPR; c += 64) {
+            const int row = c / CPR, ch = c - row * CPR;
+            if (q0 + row < T_)
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(zb) + (int64_t)(q0 + row) * tokb + ch * 16) =
+                    *reinterpret_cast<const uint4*>(L + row * 144 + ch * 16);
+        }
+    }
+}
+
+int launch_attn_stream(const AttnParams& p, hipStream_t stream) {
+    const int heads = p.B * p.H, qblocks = (p.T + 127) / 128;
+    {
+        const double bh = (double)heads, tt = (double)p.T * p.T;
+        const double bytes = (4.0 * bh * p.T * p.dh + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
+        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
+        hipLaunchKernelGGL((attn_stream_kernel<64>), dim3(heads * qblocks), dim3(256), 0, stream, p);
+    }
+    PV_LAUNCH_CHECK("attn_stream_kernel");
+    return PV_OK;
+}
+
 template <typename T>
 int dispatch_attn(AttnParams& p, hipStream_t stream) {
     p.Tpad = (p.T + 31) / 32 * 32;
@@ -517,6 +783,11 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
             if (p.dh == 64) return launch_attn_wave<64>(p, stream);
             if (p.dh == 32) return launch_attn_wave<32>(p, stream);
         }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !getenv("PV_ATTN_WG") &&
+            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31))
+            return launch_attn_stream(p, stream);
     }
     if (p.T <= 64) {
         if (p.dh == 64) return launch_attn<T, 64, 64, 1>(p, stream);
