@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 4
+#define PV_ABI_VERSION 5
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -163,6 +163,17 @@ size_t pv_vit_workspace_bytes(const pv_vit_plan* plan, int32_t batch);
 int pv_vit_forward(pv_vit_plan* plan, const void* images, int32_t batch, int32_t n_blocks,
                    int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                    size_t workspace_bytes, void* out, void* stream);
+
+/* The same forward RESUMED at a block boundary: a Python forward hook on blocks.{L}.hook_resid_post /
+ * blocks.{L+1}.hook_resid_pre (SAE substitution, zero-ablation: sae/evals/evals.py:321-392) sees the residual the
+ * first call tapped, may return a replacement, and the blocks [first_block, n_blocks) (+ head) continue from it --
+ * hooked_root_module.py:176-210 semantics ("split the plan at the hook point -> Python -> resume").
+ *   resid_in       [B, n_tokens, d_model] T, the residual stream entering block `first_block`
+ *                  (first_block == n_layers: only ln_final + head run)
+ * Taps of stages before first_block are ignored. */
+int pv_vit_forward_from(pv_vit_plan* plan, const void* resid_in, int32_t batch, int32_t first_block,
+                        int32_t n_blocks, int32_t run_head, const pv_tap* taps, int32_t n_taps,
+                        void* workspace, size_t workspace_bytes, void* out, void* stream);
 
 /* Kernel-level entry points (used by the unit tests and by bench.py's roofline leg). */
 /* C[M,N] = A[M,K] @ Bt[N,K]^T + bias[N]; dtype T for A, Bt, bias, C. */

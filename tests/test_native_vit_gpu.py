@@ -266,3 +266,82 @@ def test_bf16_attention_core_against_fp32_recompute_of_its_own_inputs(arch_name,
         z_ref = torch.einsum("bhqk,bkhd->bqhd", p_got, v)
         z_got = cache[pre + "hook_z"].float()
         assert float((z_got - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6, layer
+
+
+def _pytorch_twin(model):
+    """Same weights, PyTorch hook path only."""
+    import copy
+    twin = copy.deepcopy(model)
+    twin._native = None
+    return twin.use_native(False)
+
+
+@pytest.mark.parametrize("arch_name", ["tiny", "tiny-ragged"])
+def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
+    """replacement / ablation hooks on blocks.L.hook_resid_post|pre keep the HIP path (the plan is
+    split at the hook, Python sees the tensor, the rest resumes from what it returned); every result must equal the
+    PyTorch hook path of the same model (hooked_root_module.py:176-210), cache included."""
+    model, arch, sd = build(arch_name, torch.float32)
+    ref = _pytorch_twin(model)
+    x = torch.from_numpy(synth_images(arch, 3, 5)).cuda()
+    nl = arch["n_layers"]
+
+    def scale_shift(t, hook):
+        return t * 0.5 + 1.0
+
+    def zero_cls(t, hook):                # in-place edit, returns None
+        t[:, 0] = 0.0
+
+    cases = [
+        [("blocks.0.hook_resid_post", scale_shift)],
+        [(f"blocks.{nl - 1}.hook_resid_post", zero_cls)],
+        [("blocks.1.hook_resid_pre", scale_shift), ("blocks.0.hook_resid_post", zero_cls)],
+        [(lambda n: n.endswith("hook_resid_post"), scale_shift)],
+    ]
+    with torch.no_grad():
+        for hooks in cases:
+            want = ref.run_with_hooks(x.clone(), fwd_hooks=hooks)
+            got = model.run_with_hooks(x.clone(), fwd_hooks=hooks)
+            assert model.last_run_native, model.native_fallback_reason
+            assert rel_fro(got.cpu().numpy(), want.cpu().numpy()) < FP32_TOL
+            assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())          # context cleaned up
+            # with caching, with a filter and with stop_at_layer
+            for kw in ({}, {"names_filter": lambda n: "resid" in n or n.endswith("hook_pattern")}, {"stop_at_layer": nl - 1}):
+                w_out, w_cache = ref.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                assert model.last_run_native, model.native_fallback_reason
+                assert list(g_cache.keys()) == list(w_cache.keys())
+                assert rel_fro(g_out.cpu().numpy(), w_out.cpu().numpy()) < FP32_TOL
+                for k in w_cache.keys():
+                    a, b = g_cache[k].float().cpu().numpy(), w_cache[k].float().cpu().numpy()
+                    assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
+        # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
+        model.use_native(None)
+        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+        assert not model.last_run_native and "not a block boundary" in model.native_fallback_reason
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)]).cpu().numpy()) < FP32_TOL
+        model.use_native(True)
+        with pytest.raises(_native.NativeError):
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+        with pytest.raises(_native.NativeError):
+            model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+        assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+
+
+def test_sae_substitution_style_eval_on_b32_bf16():
+    """The shape of sae/evals/evals.py:321-392 (clean / substituted / zero-ablated forward of the same batch) at the
+    real size: all three run natively, substitution with the identity reproduces the clean output bit for bit."""
+    model, arch, sd = build("clip-vit-b32", torch.bfloat16)
+    x = torch.from_numpy(synth_images(arch, 8, 2)).cuda().bfloat16()
+    name = "blocks.6.hook_resid_post"
+    with torch.no_grad():
+        clean, _ = model.run_with_cache(x, names_filter=[])            # (an un-hooked forward() stays on PyTorch)
+        assert model.last_run_native
+        same = model.run_with_hooks(x, fwd_hooks=[(name, lambda t, hook: t.clone())])
+        assert model.last_run_native and torch.equal(same, clean)
+        zero = model.run_with_hooks(x, fwd_hooks=[(name, lambda t, hook: torch.zeros_like(t))])
+        assert model.last_run_native and not torch.equal(zero, clean)
+        _, c = model.run_with_cache(x, fwd_hooks=[(name, lambda t, hook: torch.zeros_like(t))],
+                                    names_filter=[name, "blocks.7.hook_resid_pre", "blocks.7.hook_resid_post"])
+        assert float(c[name].abs().max()) == 0.0 and float(c["blocks.7.hook_resid_pre"].abs().max()) == 0.0
+        assert float(c["blocks.7.hook_resid_post"].abs().max()) > 0.0

@@ -159,10 +159,32 @@ extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
     return carve(p, batch).total;
 }
 
+namespace {
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
+                     int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                     size_t workspace_bytes, void* out, void* stream_);
+}  // namespace
+
 extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int32_t n_blocks,
                               int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                               size_t workspace_bytes, void* out, void* stream_) {
-    PV_REQUIRE(p && images && workspace, "null argument");
+    PV_REQUIRE(images, "null argument");
+    return vit_forward_impl(p, images, nullptr, B, 0, n_blocks, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+}
+
+extern "C" int pv_vit_forward_from(pv_vit_plan* p, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
+                                   int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                                   size_t workspace_bytes, void* out, void* stream_) {
+    PV_REQUIRE(resid_in && pv_aligned16(resid_in), "resid_in must be a 16-byte aligned device pointer");
+    PV_REQUIRE(p && first_block >= 0 && first_block <= p->d.n_layers && first_block <= n_blocks, "first_block out of range");
+    return vit_forward_impl(p, nullptr, resid_in, B, first_block, n_blocks, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+}
+
+namespace {
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
+                     int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                     size_t workspace_bytes, void* out, void* stream_) {
+    PV_REQUIRE(p && (images || resid_in) && workspace, "null argument");
     PV_REQUIRE(p->weights_set, "pv_vit_plan_set_weights has not been called");
     PV_REQUIRE(B > 0, "batch must be positive");
     const pv_vit_desc& d = p->d;
@@ -170,7 +192,7 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
     PV_REQUIRE(!run_head || n_blocks == d.n_layers, "run_head requires all blocks");
     PV_REQUIRE(!run_head || out, "run_head requires an output buffer");
     PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
-    PV_REQUIRE(pv_aligned16(images), "images must be 16-byte aligned");
+    PV_REQUIRE(!images || pv_aligned16(images), "images must be 16-byte aligned");
     const Workspace ws = carve(p, B);
     PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
@@ -201,6 +223,12 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
     };
     int rc;
 
+    void* resid;
+    if (resid_in) {
+        // resumed forward (pv_vit_forward_from): the caller hands in the residual stream entering `first_block`
+        // (the value a Python hook at a block boundary returned); the embedding stages are skipped
+        resid = const_cast<void*>(resid_in);
+    } else {
     // ---- patch embedding: stride-p conv as an im2col-free GEMM (patch_embedding.py:26-32)
     void* embed = pick(PV_SLOT_EMBED, 0, ws.embed);
     {
@@ -212,7 +240,6 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
         if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
     }
     // ---- cls + pos (+ ln_pre) (base_vit.py:171-185)
-    void* resid;
     {
         LnParams L = {};
         L.x = embed; L.rows = M; L.d = dm; L.eps = d.eps; L.embed = 1; L.T = T; L.use_cls = d.use_cls_token ? 1 : 0;
@@ -231,9 +258,10 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
         }
         if ((rc = pv_launch_ln(dt, L, stream))) return rc;
     }
+    }
     bool resid_in_a = true;   // which workspace residual buffer may hold `resid`
 
-    for (int l = 0; l < n_blocks; ++l) {
+    for (int l = first_block; l < n_blocks; ++l) {
         const pv_vit_layer_weights& W = p->lw[l];
         const LayerShadow& S = p->sh[l];
         void* resid_pre = resid;
@@ -355,6 +383,7 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
     }
     return PV_OK;
 }
+}  // namespace
 
 // ---- kernel-level entry points -------------------------------------------------------------
 extern "C" int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const void* Bt, int64_t ldb,

@@ -218,20 +218,32 @@ class NativeViT:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def forward(self, model, images: torch.Tensor, names: Sequence[str], n_blocks: int, run_head: bool,
-                cache_device=None, remove_batch_dim: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    def forward(self, model, images: Optional[torch.Tensor], names: Sequence[str], n_blocks: int, run_head: bool,
+                cache_device=None, remove_batch_dim: bool = False, first_block: int = 0,
+                resid_in: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
+        With ``resid_in`` ([B, T, d_model]) the forward is RESUMED at block ``first_block`` from that residual
+        (pv_vit_forward_from; ``images`` is ignored, names of earlier stages must not be requested).
         Returns (model_out, {name: tensor})."""
         cfg = self.cfg
-        if images.device != self.device:
-            raise N.NativeError(f"input on {images.device}, model on {self.device}")
-        if images.dtype != cfg.dtype:
-            images = images.to(cfg.dtype)
-        images = images.contiguous()
-        B = images.shape[0]
-        if tuple(images.shape[1:]) != (cfg.n_channels, cfg.image_size, cfg.image_size):
-            raise ValueError(f"expected images [B,{cfg.n_channels},{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
         T = self.n_tokens
+        if resid_in is not None:
+            if resid_in.device != self.device:
+                raise N.NativeError(f"residual on {resid_in.device}, model on {self.device}")
+            if tuple(resid_in.shape[1:]) != (T, cfg.d_model):
+                raise ValueError(f"expected a residual [B,{T},{cfg.d_model}], got {tuple(resid_in.shape)}")
+            resid_in = resid_in.to(cfg.dtype).contiguous()
+            images = resid_in                       # (only .element_size() / batch are read below)
+            B = resid_in.shape[0]
+        else:
+            if images.device != self.device:
+                raise N.NativeError(f"input on {images.device}, model on {self.device}")
+            if images.dtype != cfg.dtype:
+                images = images.to(cfg.dtype)
+            images = images.contiguous()
+            B = images.shape[0]
+            if tuple(images.shape[1:]) != (cfg.n_channels, cfg.image_size, cfg.image_size):
+                raise ValueError(f"expected images [B,{cfg.n_channels},{cfg.image_size},{cfg.image_size}], got {tuple(images.shape)}")
         self.sync_weights(model)
 
         specs: Dict[str, TapSpec] = {n: tap_spec(n, cfg, B, T) for n in names}
@@ -265,9 +277,15 @@ class NativeViT:
             taps[i] = N.Tap(slot=slot, layer=layer, dst=base + off)
         ws = self._get_workspace(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
-                                        ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
-                "pv_vit_forward")
+        if resid_in is None:
+            N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
+                                            ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
+                    "pv_vit_forward")
+        else:
+            N.check(self.lib.pv_vit_forward_from(self._plan, resid_in.data_ptr(), B, first_block, n_blocks, int(run_head),
+                                                 taps, len(offsets), ws.data_ptr(), ws.numel(),
+                                                 (base + out_off) if run_head else None, stream),
+                    "pv_vit_forward_from")
         self.n_forward += 1
 
         def view(src: torch.Tensor, off: int, s_dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:

@@ -21,6 +21,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional, Tuple, Union
 
+import re
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -309,6 +311,21 @@ class HookedViT(HookedRootModule):
     # ------------------------------------------------------------------------------ PyTorch path
     def forward(self, input: torch.Tensor, stop_at_layer: Optional[int] = None) -> torch.Tensor:
         cfg = self.cfg
+        if self.native_mode != "off" and isinstance(input, torch.Tensor) and input.is_cuda:
+            # run_with_hooks / `with model.hooks(...)` whose hooks all sit on block boundaries (SAE substitution,
+            # zero-ablation: sae/evals/evals.py:321-392): the HIP plan runs in segments, Python only at the hooks
+            bh = self._boundary_hooks()
+            if bh != {} and not getattr(self, "_in_cache_fallback", False):
+                reason = self._native_reason((input,), {"stop_at_layer": stop_at_layer})
+                if reason is None:
+                    out, _ = self._run_with_cache_native(input, False, names_filter=[], stop_at_layer=stop_at_layer)
+                    self.last_run_native = True
+                    self.native_fallback_reason = None
+                    return out
+                if self.native_mode == "force":
+                    raise _native.NativeError(f"native forward with hooks impossible: {reason}")
+                self.last_run_native = False
+                self.native_fallback_reason = reason
         embed = self.hook_embed(self.embed(input))
         if cfg.use_cls_token:
             embed = torch.cat((self.cls_token.expand(input.shape[0], -1, -1), embed), dim=1)
@@ -397,8 +414,6 @@ class HookedViT(HookedRootModule):
             return f"unsupported kwargs {sorted(extra)}"
         if kwargs.get("incl_bwd", False) or kwargs.get("bwd_hooks"):
             return "backward hooks requested"
-        if kwargs.get("fwd_hooks"):
-            return "user forward hooks must run as Python callbacks"
         if not x.is_cuda:
             return "input is not on a GPU"
         p0 = self.cls_token
@@ -413,13 +428,34 @@ class HookedViT(HookedRootModule):
             return "dropout active in training mode"
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
-        for hp in self.hook_dict.values():
-            if hp._forward_hooks or hp._backward_hooks:
-                return f"hook registered on {hp.name}"
+        if self._boundary_hooks() is None:
+            return "a hook is registered on a point that is not a block boundary (blocks.L.hook_resid_pre/post)"
         for mod in self.modules():
             if not isinstance(mod, HookPoint) and (mod._forward_hooks or mod._forward_pre_hooks):
                 return "nn.Module hooks registered"
         return None
+
+    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_resid_(pre|post)$")
+
+    def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
+        """{boundary b: {"post": HookPoint of blocks.{b-1}.hook_resid_post, "pre": ... of blocks.{b}.hook_resid_pre}}
+        for every HookPoint that carries a forward hook -- boundary b = the residual stream entering block b --
+        or None when some hook (forward elsewhere, or any backward hook) cannot be served by splitting the plan."""
+        out: Dict[int, Dict[str, HookPoint]] = {}
+        for name, hp in self.hook_dict.items():
+            if hp._backward_hooks:
+                return None
+            if not hp._forward_hooks:
+                continue
+            m = self._BOUNDARY_RE.fullmatch(name)
+            if m is None:
+                return None
+            layer, kind = int(m.group(1)), m.group(2)
+            b = layer + 1 if kind == "post" else layer
+            if b == 0:
+                return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
+            out.setdefault(b, {})[kind] = hp
+        return out
 
     def _get_native(self, device: torch.device):
         from .native_vit import NativeViT
@@ -435,9 +471,23 @@ class HookedViT(HookedRootModule):
         """Same contract as base_vit.py:245-269 + hooked_root_module.py:255-287.  Pure caching
         calls on a GPU run on the native HIP plan: every requested activation is written once by
         the kernel that produces it into one HBM slab (no Python hook callbacks, no extra copies)."""
-        reason = "native_mode == 'off'" if self.native_mode == "off" else self._native_reason(model_args, kwargs)
+        user_hooks = kwargs.get("fwd_hooks") or []
+        if self.native_mode == "off":
+            reason = "native_mode == 'off'"
+        elif user_hooks:
+            # attach the caller's hooks exactly as the PyTorch path would, then see whether the plan can be split
+            # at them; they stay attached for the native run and are removed by the context manager
+            reason = "unset"
+            with self.hooks(fwd_hooks=user_hooks, bwd_hooks=[], reset_hooks_end=kwargs.get("reset_hooks_end", True),
+                            clear_contexts=kwargs.get("clear_contexts", False)):
+                reason = self._native_reason(model_args, kwargs)
+                if reason is None:
+                    out, cache_dict = self._run_with_cache_native(model_args[0], remove_batch_dim, **kwargs)
+        else:
+            reason = self._native_reason(model_args, kwargs)
+            if reason is None:
+                out, cache_dict = self._run_with_cache_native(model_args[0], remove_batch_dim, **kwargs)
         if reason is None:
-            out, cache_dict = self._run_with_cache_native(model_args[0], remove_batch_dim, **kwargs)
             self.last_run_native = True
             self.native_fallback_reason = None
         else:
@@ -445,7 +495,11 @@ class HookedViT(HookedRootModule):
                 raise _native.NativeError(f"native run_with_cache impossible: {reason}")
             self.last_run_native = False
             self.native_fallback_reason = reason
-            out, cache_dict = super().run_with_cache(*model_args, remove_batch_dim=remove_batch_dim, **kwargs)
+            self._in_cache_fallback = True
+            try:
+                out, cache_dict = super().run_with_cache(*model_args, remove_batch_dim=remove_batch_dim, **kwargs)
+            finally:
+                self._in_cache_fallback = False
         if return_cache_object:
             return out, ActivationCache(cache_dict, self, has_batch_dim=not remove_batch_dim)
         return out, cache_dict
@@ -458,8 +512,62 @@ class HookedViT(HookedRootModule):
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
         nv = self._get_native(x.device)
-        return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
-                          remove_batch_dim=remove_batch_dim)
+        bh = self._boundary_hooks() or {}
+        bounds = sorted(b for b in bh if b <= n_blocks and (b < n_blocks or "post" in bh[b]))
+        if not bounds:
+            return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
+                              remove_batch_dim=remove_batch_dim)
+        # ---- split plan: [0, b1) -> hooks -> [b1, b2) -> ... -> [bk, n_blocks) (+ head)
+        wanted = set(names)
+        cache: Dict[str, torch.Tensor] = {}
+
+        def stage_of(name: str) -> int:
+            """block index whose segment produces `name` (-1: embedding stage, n_layers: final stage)"""
+            if name.startswith("blocks."):
+                return int(name.split(".")[1])
+            return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
+                else cfg.n_layers
+
+        first, resid, out = 0, None, None
+        for end in bounds + [None]:
+            last = end is None
+            stop = n_blocks if last else end
+            seg = [n for n in names if (first == 0 or stage_of(n) >= first) and stage_of(n) < (cfg.n_layers + 1 if last else stop)
+                   and (first == 0 or n != f"blocks.{first}.hook_resid_pre")]      # (set by hand at the boundary)
+            post_name = f"blocks.{stop - 1}.hook_resid_post"
+            if first == stop and not (last and run_head):
+                out = resid                                   # nothing left to run: the hooked residual is the output
+            else:
+                req = seg if (last or post_name in seg) else seg + [post_name]
+                out, c = nv.forward(self, x if first == 0 else None, req, stop, last and run_head,
+                                    first_block=first, resid_in=resid if first > 0 else None)
+                cache.update({k: v for k, v in c.items() if k in wanted})
+                if not last:
+                    resid = c[post_name]
+            if last:
+                break
+            hp = bh[end].get("post")
+            if hp is not None:
+                resid = hp(resid)
+            if post_name in wanted:
+                cache[post_name] = resid
+            if end < n_blocks:
+                pre_name = f"blocks.{end}.hook_resid_pre"
+                hp = bh[end].get("pre")
+                if hp is not None:
+                    resid = hp(resid)
+                if pre_name in wanted:
+                    cache[pre_name] = resid
+            first = end
+        if out is None:
+            out = resid
+        ordered: Dict[str, torch.Tensor] = {}
+        for n in names:
+            t = cache[n]
+            if device is not None:
+                t = t.to(device)
+            ordered[n] = t[0] if remove_batch_dim else t
+        return out, ordered
 
     # ------------------------------------------------------------------------------ flag setters
     def set_use_attn_result(self, use_attn_result: bool):
