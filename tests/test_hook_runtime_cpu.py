@@ -173,3 +173,24 @@ def test_cache_key_order_and_observe_only_points(model, x):
     out, c = model.run_with_cache(x[:1].requires_grad_(False), incl_bwd=False)
     assert not any(k.endswith("_grad") for k in c.keys())
     assert model.hook_dict["blocks.1.mlp.hook_post"].layer() == 1
+
+
+def test_boundary_hook_classification_for_the_split_native_plan(model, x):
+    """Which registered hooks the HIP plan can serve by splitting at a block boundary (HookedViT._boundary_hooks):
+    forward hooks on blocks.L.hook_resid_post / blocks.L>=1.hook_resid_pre only; anything else (other points,
+    backward hooks, block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself always runs in PyTorch."""
+    ident = lambda t, hook: t  # noqa: E731
+    assert model._boundary_hooks() == {}
+    with model.hooks(fwd_hooks=[("blocks.0.hook_resid_post", ident), ("blocks.1.hook_resid_pre", ident),
+                                ("blocks.1.hook_resid_post", ident)]):
+        bh = model._boundary_hooks()
+        assert sorted(bh) == [1, 2] and sorted(bh[1]) == ["post", "pre"] and sorted(bh[2]) == ["post"]
+        assert bh[1]["post"] is model.hook_dict["blocks.0.hook_resid_post"]
+        out = model(x)                                   # CPU input: PyTorch path, result defined by the hooks
+        assert out.shape[0] == B and not model.last_run_native
+    assert model._boundary_hooks() == {}
+    for bad in ("blocks.0.hook_resid_pre", "blocks.0.hook_mlp_out", "hook_embed", "blocks.1.attn.hook_pattern"):
+        with model.hooks(fwd_hooks=[(bad, ident)]):
+            assert model._boundary_hooks() is None, bad
+    with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):
+        assert model._boundary_hooks() is None

@@ -1069,7 +1069,8 @@ int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {
         if (g_trace_countdown-- == 0) {
             p.trace = g_trace_dev;
-            const int v7 = getenv("PV_GEMM_V7") ? atoi(getenv("PV_GEMM_V7")) : 0;
+            const bool bf16_big = dtype == PV_DTYPE_BF16 && p.M > 0 && (p.ldo * 2) % 16 == 0 && p.N % 8 == 0;
+            const int v7 = bf16_big ? pick_v7(p) : 0;           // (mirrors dispatch(): which kernel will trace this launch)
             const int tm = v7 == 5 ? 320 : (v7 ? 256 : 128), tn = v7 ? 256 : 128;
             g_trace_info[0] = p.M; g_trace_info[1] = p.N; g_trace_info[2] = p.K; g_trace_info[3] = p.epi;
             g_trace_info[4] = ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn); g_trace_info[5] = v7 ? 70 + v7 : 4;
