@@ -169,3 +169,74 @@ def test_trainer_native_path_matches_reference_and_store_harvests_natively():
     _, c = vit_forward(synth_vit_state(arch, 0), arch, images[:4].numpy(), stop_at_layer=2,
                        names_filter=["blocks.1.hook_resid_post"])
     assert rel_fro(acts[:, :, 0].cpu().numpy(), c["blocks.1.hook_resid_post"]) < TOL
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    """One of two processes that share cuda:0 over a gloo group (RCCL wants one device per rank; gloo moves the same
+    tensors through the host) and run exactly what a rank of the 8-GPU job runs."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    d_in, d_sae, k, N = 64, 512, 8, 256
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in, activation_fn_str="topk",
+        activation_fn_kwargs={"k": k}, normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N,
+        lr=1e-3, max_grad_norm=1.0, _device="cuda", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0)
+    sae = StandardSparseAutoencoder(cfg)
+    with torch.no_grad():
+        for n, v in synth_sae_state(d_in, d_sae, 0).items():
+            getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae)
+    assert tr.world == world
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    losses = []
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(N, d_in, seed=t)).to(dev)
+        xs = x[rank * (N // world):(rank + 1) * (N // world)][:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
+        losses.append(float(loss))
+    assert tr._engine is not None, "the native engine did not run"
+    # the bench legs a rank of the scaling run executes (tiny step counts: this is a does-it-complete check)
+    from vit_prisma_amd.sae.bench_leg import sae_bench_leg, sae_end_to_end_leg
+    leg = sae_bench_leg(dev, dist=dist, steps=2, warmup=1)
+    e2e = sae_end_to_end_leg(dev, dist=dist, steps=3, warmup=1)
+    if rank == 0:
+        q.put(({n: getattr(sae, n).detach().cpu().numpy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}, losses,
+               act.cpu().numpy(), leg["value"], e2e["value"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_native_data_parallel_world2_equals_single_process_oracle():
+    """The multi-GPU path on real kernels: two ranks (sharing the one GPU of the test box, gloo collectives) each take
+    half of every 256-token batch through VisionSAETrainer's native step -- global batch mean pre-reduction, ONE
+    all-reduce of the flat gradient buffer, global clip, replicated Adam -- and must land on the oracle's
+    single-process parameters after three steps.  The bench's DP legs must complete too."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    params, losses, act, leg_tps, e2e_tps = q.get(timeout=800)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    d_in, d_sae, k, N = 64, 512, 8, 256
+    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    for t in range(3):
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), k, lr=1e-3, step=t + 1)
+        assert abs(losses[t] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (t, losses[t], ref["loss"])
+    for n in P:
+        assert rel_fro(params[n], P[n]) < 1e-4, n
+    assert np.array_equal(act, stats["act_freq_scores"])
+    assert leg_tps > 0 and e2e_tps > 0

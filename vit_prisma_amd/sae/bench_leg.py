@@ -134,7 +134,8 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 40, warmup: in
         initialization_method="independent", b_dec_init_method="mean", train_batch_size=N_TOKENS, lr=1e-3,
         max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
         context_size=50, store_batch_size=store_bs, n_batches_in_buffer=n_buf)
-    data = _ResidentImages(4 * store_bs, dev, torch.bfloat16, seed=77 + rank)
+    # every rank holds the same index space; the store's DistributedSampler hands each rank 4 store batches per epoch
+    data = _ResidentImages(4 * store_bs * world, dev, torch.bfloat16, seed=77)
     sae = StandardSparseAutoencoder(cfg)
     tr = VisionSAETrainer(cfg, model=model, dataset=data, sparse_coder=sae)
     act, since, frac, opt, sched = tr.initialize_training_variables()
