@@ -123,3 +123,39 @@ def test_data_parallel_algebra_equals_single_process_gloo_world2():
     ref = np.concatenate([g[n].ravel() for n in ("W_enc", "W_dec", "b_enc", "b_dec")])
     assert rel_fro(flat, ref) < 1e-5
     assert abs(loss - float(fw["loss"])) <= 1e-5 * float(fw["loss"])
+
+
+def test_on_disk_activation_cache_format_matches_the_reference(tmp_path):
+    """SURVEY.md 8f row 2.  tests/golden/act_cache_tiny/ holds the {idx}.pt shards the REFERENCE's writer produced for
+    the tiny model (7 images, blocks.1.hook_resid_post, 50 tokens per file) and what the reference's
+    CacheVisionActivationStore read back (gen_golden_act_cache.py).  Our writer must produce the same files, our
+    reader the same buffer."""
+    from vit_prisma_amd import HookedViT, HookedViTConfig
+    from vit_prisma_amd.sae import CacheVisionActivationStore, VisionActivationsStore
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    gold = os.path.join(GOLDEN, "act_cache_tiny")
+    ref = np.load(os.path.join(gold, "reference_reader.npz"))
+    arch = ARCHS["tiny"]
+    model = HookedViT(HookedViTConfig(**arch, device="cpu"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model.eval()
+    imgs = torch.from_numpy(ref["images"])
+    ds = torch.utils.data.TensorDataset(imgs, torch.zeros(len(imgs), dtype=torch.long))
+    cfg = make_cfg(hook_point_layer=1, context_size=17, store_batch_size=2, n_batches_in_buffer=4, train_batch_size=16,
+                   cached_activations_path=str(tmp_path / "cache"), use_cached_activations=True)
+    store = VisionActivationsStore(cfg, model, ds, create_dataloader=False)
+    assert store.generate_cached_activations_from_dataset(tokens_per_file=50) == 3
+    for i, rows in enumerate((50, 50, 19)):
+        ours, theirs = torch.load(tmp_path / "cache" / f"{i}.pt"), torch.load(os.path.join(gold, f"{i}.pt"))
+        assert ours.dtype == torch.float16 and tuple(ours.shape) == (rows, 1, 64) == tuple(theirs.shape)
+        assert torch.allclose(ours.float(), theirs.float(), atol=4e-3, rtol=2e-3), i       # one fp16 ulp at |x| ~ 4
+    # reader: on the reference's own shards, bit-identical to the reference's reader; then the served batches
+    rcfg = make_cfg(hook_point_layer=1, context_size=17, store_batch_size=2, n_batches_in_buffer=4, train_batch_size=16,
+                    cached_activations_path=gold, use_cached_activations=True)
+    reader = CacheVisionActivationStore(rcfg)
+    assert np.array_equal(reader.get_buffer(2).numpy(), ref["buffer_2_batches"])
+    assert reader.storage_buffer.shape[1:] == (1, 64) and reader.next_batch().shape == (16, 1, 64)
+    seen = sum(reader.next_batch().shape[0] for _ in range(12))                              # crosses several refills
+    assert seen > 0
+    with pytest.raises(ValueError):
+        CacheVisionActivationStore(make_cfg(use_cached_activations=False))

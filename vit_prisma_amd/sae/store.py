@@ -13,6 +13,7 @@ collective is involved in harvesting.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Iterator, List, Optional
 
 import torch
@@ -130,6 +131,117 @@ class VisionActivationsStore:
         _, world = _dist_info()
         local_bs = max(cfg.train_batch_size // world, 1)
         return iter(_TensorBatches(serve, local_bs))
+
+    def next_batch(self) -> torch.Tensor:
+        try:
+            return next(self.dataloader)
+        except StopIteration:
+            self.dataloader = self.get_data_loader()
+            return next(self.dataloader)
+
+
+    # ---- on-disk activation cache -----------------------------------------------
+    @torch.no_grad()
+    def generate_cached_activations_from_dataset(self, tokens_per_file: int = 1_000_000, shuffle_data: bool = False) -> int:
+        """Harvest the whole dataset once and write ``{idx}.pt`` shards of ``[tokens, n_layers, d_in]`` **fp16**
+        tensors (``tokens_per_file`` rows each, the last one shorter) under ``cfg.cached_activations_path`` -- the
+        format ``CacheVisionActivationStore`` (here and in the reference) reads back
+        (activations_store.py:505-575; ``.half()`` :546).  The producer is the same native
+        ``run_with_cache(names_filter, stop_at_layer)`` call as live harvesting; a shard is assembled in HBM and
+        leaves the GPU in one copy.  Returns the number of files written."""
+        cfg = self.cfg
+        save_dir = cfg.cached_activations_path
+        os.makedirs(save_dir, exist_ok=True)
+        loader = DataLoader(self.dataset, batch_size=cfg.store_batch_size, shuffle=shuffle_data, num_workers=0,
+                            drop_last=False)
+        n_layers = len(self._layers())
+        pending: List[torch.Tensor] = []
+        n_pending = 0
+        file_idx = 0
+
+        def flush(rows: torch.Tensor) -> None:
+            nonlocal file_idx
+            torch.save(rows.cpu(), os.path.join(save_dir, f"{file_idx}.pt"))
+            file_idx += 1
+
+        for batch in loader:
+            images = batch[0] if isinstance(batch, (list, tuple)) else batch
+            acts = self.get_activations(images.to(cfg.device)).half()
+            if cfg.use_patches_only:
+                acts = acts[:, 1:, :, :]
+            flat = acts.reshape(-1, n_layers, cfg.d_in)
+            pending.append(flat)
+            n_pending += flat.shape[0]
+            while n_pending >= tokens_per_file:
+                combined = torch.cat(pending, dim=0)
+                flush(combined[:tokens_per_file])
+                combined = combined[tokens_per_file:]
+                n_pending = combined.shape[0]
+                pending = [combined] if n_pending > 0 else []
+        if n_pending > 0:
+            flush(torch.cat(pending, dim=0))
+        return file_idx
+
+
+class CacheVisionActivationStore:
+    """Serves training batches from the ``{idx}.pt`` shards instead of a live model
+    (activations_store.py:21-152): same constructor (``cfg`` only, ``cfg.use_cached_activations`` must be set), same
+    ``storage_buffer`` / ``get_buffer`` / ``get_data_loader`` / ``next_batch`` and the same half-buffer shuffle-mix.
+    Like the reference, every refill starts reading at shard 0 (its ``next_cache_idx`` is a local of
+    ``_load_cached_activations``): the cache is meant to be at least one buffer long."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        if not cfg.use_cached_activations:
+            raise ValueError("CacheVisionActivationStore cannot be initialized with cfg.use_cached_activations = False ")
+        self._files = {}
+        self.next_idx_within_buffer = 0
+        half = cfg.n_batches_in_buffer // 2
+        self.storage_buffer = self.get_buffer(half)
+        self.dataloader = self.get_data_loader()
+
+    def load_file_cached(self, file: str) -> torch.Tensor:
+        if file not in self._files:
+            if len(self._files) >= 2:                       # the reference keeps an lru_cache(maxsize=2)
+                self._files.pop(next(iter(self._files)))
+            self._files[file] = torch.load(file)
+        return self._files[file]
+
+    def _load_cached_activations(self, total_size: int, context_size: int, num_layers: int, d_in: int) -> torch.Tensor:
+        cfg = self.cfg
+        buffer_size = total_size * context_size
+        buf = torch.zeros((buffer_size, num_layers, d_in), dtype=cfg.dtype, device=cfg.device)
+        filled = 0
+        idx = 0
+        while filled < buffer_size:
+            path = f"{cfg.cached_activations_path}/{idx}.pt"
+            if not os.path.exists(path):
+                return buf[:filled]
+            acts = self.load_file_cached(path)
+            partial = filled + acts.shape[0] > buffer_size
+            if partial:
+                acts = acts[: buffer_size - filled]
+            buf[filled:filled + acts.shape[0]] = acts.to(cfg.device)
+            filled += acts.shape[0]
+            if partial:
+                self.next_idx_within_buffer = acts.shape[0]
+            else:
+                idx += 1
+                self.next_idx_within_buffer = 0
+        return buf
+
+    def get_buffer(self, n_batches_in_buffer: int) -> torch.Tensor:
+        cfg = self.cfg
+        n_layers = len(cfg.hook_point_layer) if isinstance(cfg.hook_point_layer, list) else 1
+        return self._load_cached_activations(cfg.store_batch_size * n_batches_in_buffer, cfg.context_size, n_layers, cfg.d_in)
+
+    def get_data_loader(self) -> Iterator[Any]:
+        cfg = self.cfg
+        mix = torch.cat([self.get_buffer(cfg.n_batches_in_buffer // 2), self.storage_buffer], dim=0)
+        mix = mix[torch.randperm(mix.shape[0], device=mix.device)]
+        half = mix.shape[0] // 2
+        self.storage_buffer = mix[:half]
+        return iter(_TensorBatches(mix[half:], cfg.train_batch_size))
 
     def next_batch(self) -> torch.Tensor:
         try:
