@@ -100,7 +100,13 @@ def test_fp32_b32_bs16_all_hooks_vs_oracle_and_golden():
     assert cache["hook_pos_embed"].stride(0) == 0
 
 
-def test_bf16_b32_within_reference_bf16_budget():
+@pytest.mark.parametrize("tile", [None, "5", "4", "0"])
+def test_bf16_b32_within_reference_bf16_budget(tile, monkeypatch):
+    """tile: the GEMM kernel the library would pick by itself at this size (128 x 128, 3 workgroups per CU), then the
+    large-batch kernels forced onto the same small problem (PV_GEMM_TILE: 320 x 256 / 256 x 256 tile, one 8-wave
+    workgroup per CU, compile-time epilogues) -- every variant has to meet the same budget."""
+    if tile is not None:
+        monkeypatch.setenv("PV_GEMM_TILE", tile)
     with open(os.path.join(GOLDEN, "vit_b32_bf16_budget.json")) as f:
         budget = json.load(f)["budget"]
     model, arch, sd = build("clip-vit-b32", torch.bfloat16)
@@ -345,3 +351,25 @@ def test_sae_substitution_style_eval_on_b32_bf16():
                                     names_filter=[name, "blocks.7.hook_resid_pre", "blocks.7.hook_resid_post"])
         assert float(c[name].abs().max()) == 0.0 and float(c["blocks.7.hook_resid_pre"].abs().max()) == 0.0
         assert float(c["blocks.7.hook_resid_post"].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("tile", ["5", "4", "0"])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40)])
+def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, monkeypatch):
+    """pv_gemm_bias against an fp32 torch reference on shapes that are multiples of nothing: partial row / column
+    tiles, K that ends inside a 64-byte slab (K = 200, 72, 40), N = 8 (one 16-byte chunk)."""
+    import ctypes as C
+    monkeypatch.setenv("PV_GEMM_TILE", tile)
+    L = _native.lib()
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    Bt = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g).bfloat16()
+    out = torch.full((M + 1, N), 7.0, device="cuda", dtype=torch.bfloat16)            # the extra row must stay untouched
+    st = torch.cuda.current_stream().cuda_stream
+    _native.check(L.pv_gemm_bias(1, A.data_ptr(), K, Bt.data_ptr(), K, bias.data_ptr(), out.data_ptr(), N, M, N, K, st), "pv_gemm_bias")
+    torch.cuda.synchronize()
+    ref = A.float() @ Bt.float().T + bias.float()
+    err = float((out[:M].float() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2 ** -7, err                                                         # one bf16 rounding of the result
+    assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0
