@@ -1,6 +1,8 @@
+python -m pytest tests/test_native_vit_gpu.py -m gpu -x -q -k "within_reference_bf16_budget or full_size or fp32_b32" 2>&1 | tail -3
 for r in 1 2; do
-for w in 8 12 16; do
-  PV_V7_WBLK=$w python bench.py --no-sae --no-l14 --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "
+for v in new v1patch; do
+  e=A=1; [ $v = v1patch ] && e=PV_GEMM_V1PATCH=1
+  env $e python bench.py --no-sae --no-l14 --no-cpu-baseline --steps 30 --warmup 8 2>/dev/null | python -c "
 import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('wblk $w bench', j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['avg_launch_us'])"
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v bench', j['value'], j['ms_per_step'], j['roofline']['achieved'], j['roofline']['avg_launch_us'])"
 done; done

@@ -781,8 +781,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     const unsigned Kb = (unsigned)p.K * EB;
     const int nk = (int)((Kb + 63) / 64);
     const bool ktail = (Kb % 64) != 0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
+    // PATCH A operand (patch size 32, bf16): the 64 bytes of K that slab kt covers are ONE contiguous run of the
+    // NCHW image -- channel kt / 32, patch row kt % 32 -- so the im2col-free gather is only a different row base and
+    // slab offset for the same DMA (patch_embedding.py:26-32)
+    const bool patch = p.a_mode == PV_A_PATCH;
+    const unsigned a_span = patch ? (unsigned)(p.M / (p.pG * p.pG)) * (unsigned)p.pC * (unsigned)p.pS * (unsigned)p.pS * EB
+                                  : (unsigned)p.M * (unsigned)p.lda * EB;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)a_span, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
 
@@ -796,7 +801,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
         const int row = ia * 16 + (lane >> 2);
         const int kc = (lane & 3) ^ ((row >> 2) & 3);
         kcA[j] = kc * 16;
-        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+        if (patch) {
+            const int gm = m0 + row, np = p.pG * p.pG;
+            const int b = gm / np, pidx = gm - b * np;
+            const int py = pidx / p.pG, px = pidx - py * p.pG;
+            offA[j] = (unsigned)(((b * p.pC) * p.pS + py * p.pP) * p.pS + px * p.pP) * EB + kc * 16;      // image b >= B: past the range -> 0
+        } else {
+            offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * EB + kc * 16;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -809,9 +821,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
         const unsigned kbase = (unsigned)kt * 64;
         const bool dead = (kt >= nk) | (((p.dbg & 1) != 0) & (kt >= 3));
         // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
+        const unsigned kbaseA = patch ? (unsigned)((kt >> 5) * p.pS * p.pS + (kt & 31) * p.pS) * EB : kbase;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            unsigned o = offA[j] + kbase;
+            unsigned o = offA[j] + kbaseA;
             o = (dead | !realA[j] | (ktail & (kbase + kcA[j] >= Kb))) ? 0xffffff00u : o;
             unsigned char* dst = slot + (j * 8 + wave) * 1024;
             if constexpr (PAD) { if (j == NA - 1) dst = realA[j] ? dst : pad + wave * 1024; }
@@ -1028,6 +1041,17 @@ int dispatch(GemmParams& p, hipStream_t stream) {
                 }
             }
             return launch_v4<T>(p, stream);
+        }
+    }
+    if constexpr (EB == 2) {
+        // patch embedding at patch size 32: the tiled kernel gathers the patches itself (see gemm_kernel_v7)
+        const uint64_t img_bytes = (uint64_t)(p.pG ? p.M / (p.pG * p.pG) : 0) * p.pC * p.pS * p.pS * EB;
+        if (p.a_mode == PV_A_PATCH && vec && p.vec_out && p.N % 8 == 0 && p.pP == 32 && p.K == p.pC * 1024 && p.pG > 0 &&
+            p.M % (p.pG * p.pG) == 0 && img_bytes < 0xffffff00ull && (uint64_t)(p.N + 256) * p.ldb * EB < 0xffffff00ull &&
+            !getenv("PV_GEMM_V1") && !getenv("PV_GEMM_V1PATCH")) {
+            const int pick = pick_v7(p);
+            if (pick == 5) return launch_v7<T, 5>(p, stream);
+            if (pick == 4) return launch_v7<T, 4>(p, stream);
         }
     }
     if (p.a_mode == PV_A_PLAIN) {
