@@ -39,25 +39,35 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// column sums of a [rows][d] fp32 matrix, stage 1: partial[blk][c] over 64-row blocks
+// column sums of a [rows][d] fp32 matrix (deterministic two-stage reduction).
+// stage 1: partial[blk][c] over CS_ROWS-row blocks -- rows / 16 workgroups (256 at N = 4096: every CU busy), 16
+// independent loads in flight per thread
+constexpr int CS_ROWS = 16;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                              int rows, int d) {
-    const int r0 = blockIdx.x * 64;
-    const int r1 = min(r0 + 64, rows);
+    const int r0 = blockIdx.x * CS_ROWS;
     for (int c = threadIdx.x; c < d; c += 256) {
+        float v[CS_ROWS];
+#pragma unroll
+        for (int i = 0; i < CS_ROWS; ++i) v[i] = (r0 + i < rows) ? x[(int64_t)(r0 + i) * d + c] : 0.f;
         float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += x[(int64_t)r * d + c];
+#pragma unroll
+        for (int i = 0; i < CS_ROWS; ++i) s += v[i];          // fixed order
         partial[(int64_t)blockIdx.x * d + c] = s;
     }
 }
-// stage 2: out[c] = scale * sum_blk partial[blk][c]  (+ add[c] if given)
+// stage 2: out[c] = scale * sum_blk partial[blk][c]; one wave per column group of 64, 4 partial streams per lane
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                            int nblk, int d, float scale) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * d + c];
-    out[c] = s * scale;
+    if (c < d)
+        for (int b = part; b < nblk; b += 4) s += partial[(int64_t)b * d + c];
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && c < d) out[c] = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) * scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,29 +340,36 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restric
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ cursor, int d_sae, float* __restrict__ scalars,
                                                         float inv_tokens) {
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (d_sae + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, d_sae);
     uint32_t s = 0;
     for (int i = lo; i < hi; ++i) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t a = tid >= o ? part[tid - o] : 0u;
-        __syncthreads();
-        part[tid] += a;
-        __syncthreads();
+    // inclusive scan of the 1024 per-thread sums: shuffles inside a wave, 16 wave totals through LDS (one barrier
+    // instead of the 20 of a Hillis-Steele scan over LDS)
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += a;
     }
-    uint32_t run = part[tid] - s;
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    uint32_t total = 0;
+    for (int w = 0; w < 16; ++w) total += wsum[w];
+    uint32_t part_tid = base + inc;                 // inclusive prefix of this thread
+    uint32_t run = part_tid - s;
     for (int i = lo; i < hi; ++i) {
         offs[i] = run;
         cursor[i] = run;
         run += cnt[i];
     }
     if (tid == 1023) {
-        offs[d_sae] = part[1023];
-        if (scalars) scalars[2] = (float)part[1023] * inv_tokens;       // l0 = mean_n #(val > 0), train_sae.py:364
+        offs[d_sae] = total;
+        if (scalars) scalars[2] = (float)total * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
     }
 }
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
@@ -630,7 +647,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.offs = take(((size_t)d.d_sae + 1) * 4);
     w.cursor = take((size_t)d.d_sae * 4);
     w.pairs = take(N * (size_t)d.k * 4);
-    w.colpart = take((size_t)w.nblk64 * d.d_in * 4);
+    w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS) * d.d_in * 4);
     w.colsum = take((size_t)d.d_in * 4);
     w.batch_mean = take((size_t)d.d_in * 4);
     w.sqpart = take((size_t)w.sq_blocks * 4);
@@ -679,9 +696,9 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     if (batch_mean) {
         PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
     } else {
-        const int nblk = (N + 63) / 64;
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 255) / 256), dim3(256), 0, stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(256), 0, stream,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
     hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, st->b_dec, bmean,
@@ -788,9 +805,9 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
                            st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, update_stats);
         // gb_dec = colsum(dY) - W_enc @ gb_enc
-        const int nblk = (N + 63) / 64;
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 255) / 256), dim3(256), 0, stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(256), 0, stream,
                            (const float*)(wsb + ws.colpart), (float*)(wsb + ws.colsum), nblk, d.d_in, 1.0f);
         hipLaunchKernelGGL(sae_gbdec_kernel, dim3(d.d_in), dim3(256), 0, stream, (const float*)st->W_enc, (const float*)st->gb_enc,
                            (const float*)(wsb + ws.colsum), st->gb_dec, d.d_sae);
