@@ -177,7 +177,7 @@ def test_cache_key_order_and_observe_only_points(model, x):
 
 def test_boundary_hook_classification_for_the_split_native_plan(model, x):
     """Which registered hooks the HIP plan can serve by splitting at a block boundary (HookedViT._boundary_hooks):
-    forward hooks on blocks.L.hook_resid_post / blocks.L>=1.hook_resid_pre only; anything else (other points,
+    forward hooks on blocks.L.hook_mlp_out / hook_resid_post / blocks.L>=1.hook_resid_pre only; anything else (other points,
     backward hooks, block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself always runs in PyTorch."""
     ident = lambda t, hook: t  # noqa: E731
     assert model._boundary_hooks() == {}
@@ -189,7 +189,9 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
         out = model(x)                                   # CPU input: PyTorch path, result defined by the hooks
         assert out.shape[0] == B and not model.last_run_native
     assert model._boundary_hooks() == {}
-    for bad in ("blocks.0.hook_resid_pre", "blocks.0.hook_mlp_out", "hook_embed", "blocks.1.attn.hook_pattern"):
+    with model.hooks(fwd_hooks=[("blocks.0.hook_mlp_out", ident)]):
+        assert sorted(model._boundary_hooks()[1]) == ["mlp"]
+    for bad in ("blocks.0.hook_resid_pre", "blocks.0.hook_attn_out", "hook_embed", "blocks.1.attn.hook_pattern"):
         with model.hooks(fwd_hooks=[(bad, ident)]):
             assert model._boundary_hooks() is None, bad
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):

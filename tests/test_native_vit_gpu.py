@@ -303,6 +303,8 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
         [(f"blocks.{nl - 1}.hook_resid_post", zero_cls)],
         [("blocks.1.hook_resid_pre", scale_shift), ("blocks.0.hook_resid_post", zero_cls)],
         [(lambda n: n.endswith("hook_resid_post"), scale_shift)],
+        [("blocks.0.hook_mlp_out", scale_shift)],
+        [(f"blocks.{nl - 1}.hook_mlp_out", zero_cls), (f"blocks.{nl - 1}.hook_resid_post", scale_shift), ("blocks.1.hook_resid_pre", zero_cls)],
     ]
     with torch.no_grad():
         for hooks in cases:
@@ -323,14 +325,14 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
         # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
         model.use_native(None)
-        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
         assert not model.last_run_native and "not a block boundary" in model.native_fallback_reason
-        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)]).cpu().numpy()) < FP32_TOL
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)]).cpu().numpy()) < FP32_TOL
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
         with pytest.raises(_native.NativeError):
-            model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_out", scale_shift)])
+            model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
 
 

@@ -429,18 +429,19 @@ class HookedViT(HookedRootModule):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
         if self._boundary_hooks() is None:
-            return "a hook is registered on a point that is not a block boundary (blocks.L.hook_resid_pre/post)"
+            return "a hook is registered on a point that is not a block boundary (blocks.L.hook_mlp_out / hook_resid_post / hook_resid_pre)"
         for mod in self.modules():
             if not isinstance(mod, HookPoint) and (mod._forward_hooks or mod._forward_pre_hooks):
                 return "nn.Module hooks registered"
         return None
 
-    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_resid_(pre|post)$")
+    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_(resid_pre|resid_post|mlp_out)$")
 
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
-        """{boundary b: {"post": HookPoint of blocks.{b-1}.hook_resid_post, "pre": ... of blocks.{b}.hook_resid_pre}}
-        for every HookPoint that carries a forward hook -- boundary b = the residual stream entering block b --
-        or None when some hook (forward elsewhere, or any backward hook) cannot be served by splitting the plan."""
+        """{boundary b: {"mlp": HookPoint of blocks.{b-1}.hook_mlp_out, "post": ... of blocks.{b-1}.hook_resid_post,
+        "pre": ... of blocks.{b}.hook_resid_pre}} for every HookPoint that carries a forward hook -- boundary b = the
+        residual stream entering block b; the three fire in that order -- or None when some hook (forward elsewhere,
+        or any backward hook) cannot be served by splitting the plan there."""
         out: Dict[int, Dict[str, HookPoint]] = {}
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -450,8 +451,8 @@ class HookedViT(HookedRootModule):
             m = self._BOUNDARY_RE.fullmatch(name)
             if m is None:
                 return None
-            layer, kind = int(m.group(1)), m.group(2)
-            b = layer + 1 if kind == "post" else layer
+            layer, kind = int(m.group(1)), {"resid_pre": "pre", "resid_post": "post", "mlp_out": "mlp"}[m.group(2)]
+            b = layer if kind == "pre" else layer + 1
             if b == 0:
                 return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
             out.setdefault(b, {})[kind] = hp
@@ -513,7 +514,7 @@ class HookedViT(HookedRootModule):
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
         nv = self._get_native(x.device)
         bh = self._boundary_hooks() or {}
-        bounds = sorted(b for b in bh if b <= n_blocks and (b < n_blocks or "post" in bh[b]))
+        bounds = sorted(b for b in bh if b <= n_blocks and (b < n_blocks or "post" in bh[b] or "mlp" in bh[b]))
         if not bounds:
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
                               remove_batch_dim=remove_batch_dim)
@@ -535,10 +536,13 @@ class HookedViT(HookedRootModule):
             seg = [n for n in names if (first == 0 or stage_of(n) >= first) and stage_of(n) < (cfg.n_layers + 1 if last else stop)
                    and (first == 0 or n != f"blocks.{first}.hook_resid_pre")]      # (set by hand at the boundary)
             post_name = f"blocks.{stop - 1}.hook_resid_post"
+            mlp_name, mid_name = f"blocks.{stop - 1}.hook_mlp_out", f"blocks.{stop - 1}.hook_resid_mid"
+            mlp_hp = None if last else bh[end].get("mlp")
             if first == stop and not (last and run_head):
                 out = resid                                   # nothing left to run: the hooked residual is the output
             else:
-                req = seg if (last or post_name in seg) else seg + [post_name]
+                forced = [] if last else [post_name] + ([mlp_name, mid_name] if mlp_hp is not None else [])
+                req = seg + [n for n in forced if n not in seg]
                 out, c = nv.forward(self, x if first == 0 else None, req, stop, last and run_head,
                                     first_block=first, resid_in=resid if first > 0 else None)
                 cache.update({k: v for k, v in c.items() if k in wanted})
@@ -546,6 +550,13 @@ class HookedViT(HookedRootModule):
                     resid = c[post_name]
             if last:
                 break
+            if mlp_hp is not None:
+                # blocks.L.hook_mlp_out: the block's output is rebuilt from what the hook returns, with the kernel's
+                # own rounding (resid_post = round(resid_mid + mlp_out), transformer_block.py:131-134)
+                mlp_out = mlp_hp(c[mlp_name])
+                if mlp_name in wanted:
+                    cache[mlp_name] = mlp_out
+                resid = c[mid_name] + mlp_out.to(c[mid_name].dtype)
             hp = bh[end].get("post")
             if hp is not None:
                 resid = hp(resid)
