@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 5
+#define PV_ABI_VERSION 6
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -174,6 +174,19 @@ int pv_vit_forward(pv_vit_plan* plan, const void* images, int32_t batch, int32_t
 int pv_vit_forward_from(pv_vit_plan* plan, const void* resid_in, int32_t batch, int32_t first_block,
                         int32_t n_blocks, int32_t run_head, const pv_tap* taps, int32_t n_taps,
                         void* workspace, size_t workspace_bytes, void* out, void* stream);
+
+/* General form of the two calls above: one SEGMENT of the forward, for hooks that sit in the middle of a block too
+ * (blocks.L.hook_attn_out / hook_resid_mid).  Positions are (block, half): half 0 = the block's entry, half 1 = after
+ * its attention half (the residual stream is resid_mid there).
+ *   images / resid_in   exactly one is non-NULL: start from the pixels (first_block = entry_mid = 0) or resume from a
+ *                       residual -- the one entering block first_block, or with entry_mid = 1 its resid_mid
+ *   end_block, exit_mid run up to the entry of block end_block, or with exit_mid = 1 also through the attention half of
+ *                       block end_block (tap PV_SLOT_RESID_MID there to get the result)
+ *   run_head            only with end_block == n_layers and exit_mid == 0 */
+int pv_vit_forward_seg(pv_vit_plan* plan, const void* images, const void* resid_in, int32_t batch,
+                       int32_t first_block, int32_t entry_mid, int32_t end_block, int32_t exit_mid,
+                       int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                       size_t workspace_bytes, void* out, void* stream);
 
 /* Kernel-level entry points (used by the unit tests and by bench.py's roofline leg). */
 /* C[M,N] = A[M,K] @ Bt[N,K]^T + bias[N]; dtype T for A, Bt, bias, C. */

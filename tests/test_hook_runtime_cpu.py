@@ -176,22 +176,23 @@ def test_cache_key_order_and_observe_only_points(model, x):
 
 
 def test_boundary_hook_classification_for_the_split_native_plan(model, x):
-    """Which registered hooks the HIP plan can serve by splitting at a block boundary (HookedViT._boundary_hooks):
-    forward hooks on blocks.L.hook_mlp_out / hook_resid_post / blocks.L>=1.hook_resid_pre only; anything else (other points,
-    backward hooks, block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself always runs in PyTorch."""
+    """Which registered hooks the HIP plan can serve by splitting (HookedViT._boundary_hooks): forward hooks on the
+    residual-stream points of a block -- hook_resid_pre (block >= 1), hook_attn_out, hook_resid_mid, hook_mlp_out,
+    hook_resid_post -- keyed by half-block position; anything else (points inside the attention / MLP, backward hooks,
+    block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself always runs in PyTorch."""
     ident = lambda t, hook: t  # noqa: E731
     assert model._boundary_hooks() == {}
     with model.hooks(fwd_hooks=[("blocks.0.hook_resid_post", ident), ("blocks.1.hook_resid_pre", ident),
-                                ("blocks.1.hook_resid_post", ident)]):
+                                ("blocks.1.hook_resid_post", ident), ("blocks.0.hook_mlp_out", ident),
+                                ("blocks.1.hook_attn_out", ident), ("blocks.0.hook_resid_mid", ident)]):
         bh = model._boundary_hooks()
-        assert sorted(bh) == [1, 2] and sorted(bh[1]) == ["post", "pre"] and sorted(bh[2]) == ["post"]
-        assert bh[1]["post"] is model.hook_dict["blocks.0.hook_resid_post"]
+        assert sorted(bh) == [1, 2, 3, 4]
+        assert sorted(bh[1]) == ["mid"] and sorted(bh[2]) == ["mlp", "post", "pre"] and sorted(bh[3]) == ["attn"] and sorted(bh[4]) == ["post"]
+        assert bh[2]["post"] is model.hook_dict["blocks.0.hook_resid_post"]
         out = model(x)                                   # CPU input: PyTorch path, result defined by the hooks
         assert out.shape[0] == B and not model.last_run_native
     assert model._boundary_hooks() == {}
-    with model.hooks(fwd_hooks=[("blocks.0.hook_mlp_out", ident)]):
-        assert sorted(model._boundary_hooks()[1]) == ["mlp"]
-    for bad in ("blocks.0.hook_resid_pre", "blocks.0.hook_attn_out", "hook_embed", "blocks.1.attn.hook_pattern"):
+    for bad in ("blocks.0.hook_resid_pre", "blocks.0.attn.hook_z", "hook_embed", "blocks.1.attn.hook_pattern", "blocks.0.mlp.hook_post"):
         with model.hooks(fwd_hooks=[(bad, ident)]):
             assert model._boundary_hooks() is None, bad
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):

@@ -284,9 +284,10 @@ def _pytorch_twin(model):
 
 @pytest.mark.parametrize("arch_name", ["tiny", "tiny-ragged"])
 def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
-    """replacement / ablation hooks on blocks.L.hook_resid_post|pre keep the HIP path (the plan is
-    split at the hook, Python sees the tensor, the rest resumes from what it returned); every result must equal the
-    PyTorch hook path of the same model (hooked_root_module.py:176-210), cache included."""
+    """replacement / ablation hooks on a block's residual-stream points (hook_resid_pre, hook_attn_out,
+    hook_resid_mid, hook_mlp_out, hook_resid_post) keep the HIP path: the plan is split at the hook -- at a block
+    boundary or after the attention half -- Python sees the tensor, the rest resumes from what it returned; every
+    result must equal the PyTorch hook path of the same model (hooked_root_module.py:176-210), cache included."""
     model, arch, sd = build(arch_name, torch.float32)
     ref = _pytorch_twin(model)
     x = torch.from_numpy(synth_images(arch, 3, 5)).cuda()
@@ -304,6 +305,9 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
         [("blocks.1.hook_resid_pre", scale_shift), ("blocks.0.hook_resid_post", zero_cls)],
         [(lambda n: n.endswith("hook_resid_post"), scale_shift)],
         [("blocks.0.hook_mlp_out", scale_shift)],
+        [("blocks.0.hook_attn_out", scale_shift)],
+        [("blocks.1.hook_resid_mid", zero_cls), ("blocks.1.hook_attn_out", scale_shift)],
+        [(lambda n: n.endswith(("hook_attn_out", "hook_resid_mid", "hook_mlp_out", "hook_resid_post")) or n == "blocks.1.hook_resid_pre", scale_shift)],
         [(f"blocks.{nl - 1}.hook_mlp_out", zero_cls), (f"blocks.{nl - 1}.hook_resid_post", scale_shift), ("blocks.1.hook_resid_pre", zero_cls)],
     ]
     with torch.no_grad():
@@ -325,14 +329,14 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
         # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
         model.use_native(None)
-        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
-        assert not model.last_run_native and "not a block boundary" in model.native_fallback_reason
-        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)]).cpu().numpy()) < FP32_TOL
+        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
+        assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)]).cpu().numpy()) < FP32_TOL
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
         with pytest.raises(_native.NativeError):
-            model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_attn_out", scale_shift)])
+            model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
 
 

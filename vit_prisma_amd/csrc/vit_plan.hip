@@ -160,8 +160,8 @@ extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
 }
 
 namespace {
-int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
-                     int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t entry_mid,
+                     int32_t n_blocks, int32_t exit_mid, int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                      size_t workspace_bytes, void* out, void* stream_);
 }  // namespace
 
@@ -169,7 +169,21 @@ extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int
                               int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                               size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(images, "null argument");
-    return vit_forward_impl(p, images, nullptr, B, 0, n_blocks, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+    return vit_forward_impl(p, images, nullptr, B, 0, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+}
+
+extern "C" int pv_vit_forward_seg(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block,
+                                  int32_t entry_mid, int32_t end_block, int32_t exit_mid, int32_t run_head, const pv_tap* taps,
+                                  int32_t n_taps, void* workspace, size_t workspace_bytes, void* out, void* stream_) {
+    PV_REQUIRE(p && ((images != nullptr) != (resid_in != nullptr)), "exactly one of images / resid_in");
+    PV_REQUIRE(!resid_in || pv_aligned16(resid_in), "resid_in must be 16-byte aligned");
+    PV_REQUIRE(images ? (first_block == 0 && !entry_mid) : (first_block >= 0 && first_block <= p->d.n_layers), "segment start");
+    PV_REQUIRE(first_block <= end_block && end_block <= p->d.n_layers, "segment end");
+    PV_REQUIRE(!entry_mid || first_block < p->d.n_layers, "entry_mid needs a block to resume");
+    PV_REQUIRE(!exit_mid || (end_block < p->d.n_layers && !run_head), "exit_mid stops inside block end_block");
+    PV_REQUIRE(!(entry_mid && first_block == end_block && !exit_mid), "a mid-block entry must finish its block");
+    return vit_forward_impl(p, images, resid_in, B, first_block, entry_mid, end_block, exit_mid, run_head, taps, n_taps, workspace,
+                            workspace_bytes, out, stream_);
 }
 
 extern "C" int pv_vit_forward_from(pv_vit_plan* p, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
@@ -177,12 +191,12 @@ extern "C" int pv_vit_forward_from(pv_vit_plan* p, const void* resid_in, int32_t
                                    size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(resid_in && pv_aligned16(resid_in), "resid_in must be a 16-byte aligned device pointer");
     PV_REQUIRE(p && first_block >= 0 && first_block <= p->d.n_layers && first_block <= n_blocks, "first_block out of range");
-    return vit_forward_impl(p, nullptr, resid_in, B, first_block, n_blocks, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+    return vit_forward_impl(p, nullptr, resid_in, B, first_block, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
 }
 
 namespace {
-int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
-                     int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t entry_mid,
+                     int32_t n_blocks, int32_t exit_mid, int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                      size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(p && (images || resid_in) && workspace, "null argument");
     PV_REQUIRE(p->weights_set, "pv_vit_plan_set_weights has not been called");
@@ -261,10 +275,17 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
     }
     bool resid_in_a = true;   // which workspace residual buffer may hold `resid`
 
-    for (int l = first_block; l < n_blocks; ++l) {
+    // blocks [first_block, n_blocks) in full; with exit_mid also the attention half of block n_blocks (the segment
+    // then ends on its resid_mid); with entry_mid `resid` IS the resid_mid of first_block and its attention half is skipped
+    const int last_block = exit_mid ? n_blocks + 1 : n_blocks;
+    for (int l = first_block; l < last_block; ++l) {
         const pv_vit_layer_weights& W = p->lw[l];
         const LayerShadow& S = p->sh[l];
         void* resid_pre = resid;
+        void* resid_mid;
+        if (l == first_block && entry_mid) {
+            resid_mid = resid;
+        } else {
         // ln1 (transformer_block.py:106-109 ; layer_norm.py:75-93)
         void* ln1 = pick(PV_SLOT_LN1_OUT, l, ws.ln_out);
         {
@@ -297,13 +318,18 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             if ((rc = pv_launch_attention(dt, a, stream))) return rc;
         }
         // attn_out = z W_O + b_O ; resid_mid = resid_pre + attn_out (attention.py:155-167 ; block :117-124)
-        void* resid_mid = pick(PV_SLOT_RESID_MID, l, ws.resid_mid);
+        resid_mid = pick(PV_SLOT_RESID_MID, l, ws.resid_mid);
         {
             GemmParams g = {};
             g.A = z; g.lda = HD; g.a_mode = PV_A_PLAIN; g.Bt = S.WoT; g.ldb = HD;
             g.M = M; g.N = dm; g.K = HD; g.epi = PV_EPI_RESID; g.bias0 = W.b_O;
             g.out0 = tap_at(PV_SLOT_ATTN_OUT, l); g.out1 = resid_mid; g.ldo = dm; g.resid = resid_pre; g.ldr = dm;
             if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
+        }
+        }
+        if (exit_mid && l == n_blocks) {
+            resid = resid_mid;
+            break;
         }
         // ln2 (block :130)
         void* ln2 = pick(PV_SLOT_LN2_OUT, l, ws.ln_out);

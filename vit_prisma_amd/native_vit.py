@@ -220,10 +220,13 @@ class NativeViT:
 
     def forward(self, model, images: Optional[torch.Tensor], names: Sequence[str], n_blocks: int, run_head: bool,
                 cache_device=None, remove_batch_dim: bool = False, first_block: int = 0,
-                resid_in: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                resid_in: Optional[torch.Tensor] = None, entry_mid: bool = False,
+                exit_mid: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
         With ``resid_in`` ([B, T, d_model]) the forward is RESUMED at block ``first_block`` from that residual
-        (pv_vit_forward_from; ``images`` is ignored, names of earlier stages must not be requested).
+        (``images`` is ignored, names of earlier stages must not be requested); ``entry_mid``: the residual is the
+        resid_mid of ``first_block`` (its attention half is skipped); ``exit_mid``: the segment also runs the
+        attention half of block ``n_blocks`` and returns its resid_mid (pv_vit_forward_seg).
         Returns (model_out, {name: tensor})."""
         cfg = self.cfg
         T = self.n_tokens
@@ -249,7 +252,7 @@ class NativeViT:
         specs: Dict[str, TapSpec] = {n: tap_spec(n, cfg, B, T) for n in names}
         out_name = None
         if not run_head:
-            out_name = final_residual_name(cfg, n_blocks)
+            out_name = f"blocks.{n_blocks}.hook_resid_mid" if exit_mid else final_residual_name(cfg, n_blocks)
             if out_name not in specs:
                 specs[out_name] = tap_spec(out_name, cfg, B, T)
         # unique buffers -> slab offsets
@@ -277,15 +280,16 @@ class NativeViT:
             taps[i] = N.Tap(slot=slot, layer=layer, dst=base + off)
         ws = self._get_workspace(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        if resid_in is None:
+        if resid_in is None and not exit_mid:
             N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
                                             ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
                     "pv_vit_forward")
         else:
-            N.check(self.lib.pv_vit_forward_from(self._plan, resid_in.data_ptr(), B, first_block, n_blocks, int(run_head),
-                                                 taps, len(offsets), ws.data_ptr(), ws.numel(),
-                                                 (base + out_off) if run_head else None, stream),
-                    "pv_vit_forward_from")
+            N.check(self.lib.pv_vit_forward_seg(self._plan, images.data_ptr() if resid_in is None else None,
+                                                None if resid_in is None else resid_in.data_ptr(), B, first_block,
+                                                int(entry_mid), n_blocks, int(exit_mid), int(run_head), taps, len(offsets),
+                                                ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
+                    "pv_vit_forward_seg")
         self.n_forward += 1
 
         def view(src: torch.Tensor, off: int, s_dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:

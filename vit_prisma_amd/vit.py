@@ -429,19 +429,22 @@ class HookedViT(HookedRootModule):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
         if self._boundary_hooks() is None:
-            return "a hook is registered on a point that is not a block boundary (blocks.L.hook_mlp_out / hook_resid_post / hook_resid_pre)"
+            return "a hook is registered on a point the plan cannot be split at (supported: blocks.L.hook_resid_pre / hook_attn_out / hook_resid_mid / hook_mlp_out / hook_resid_post)"
         for mod in self.modules():
             if not isinstance(mod, HookPoint) and (mod._forward_hooks or mod._forward_pre_hooks):
                 return "nn.Module hooks registered"
         return None
 
-    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_(resid_pre|resid_post|mlp_out)$")
+    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_(resid_pre|attn_out|resid_mid|mlp_out|resid_post)$")
+    # firing order of the hookable residual-stream points at a split position
+    _KINDS_AT_ENTRY = ("mlp", "post", "pre")       # position 2b: hook_mlp_out / hook_resid_post of block b-1, hook_resid_pre of b
+    _KINDS_AT_MID = ("attn", "mid")                # position 2b+1: hook_attn_out, hook_resid_mid of block b
 
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
-        """{boundary b: {"mlp": HookPoint of blocks.{b-1}.hook_mlp_out, "post": ... of blocks.{b-1}.hook_resid_post,
-        "pre": ... of blocks.{b}.hook_resid_pre}} for every HookPoint that carries a forward hook -- boundary b = the
-        residual stream entering block b; the three fire in that order -- or None when some hook (forward elsewhere,
-        or any backward hook) cannot be served by splitting the plan there."""
+        """{position: {kind: HookPoint}} for every HookPoint that carries a forward hook, or None when some hook (a
+        forward hook elsewhere, any backward hook) cannot be served by splitting the native plan.  Positions count
+        half blocks: 2b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
+        fire there, in that order), 2b+1 = after block b's attention half ("attn", then "mid")."""
         out: Dict[int, Dict[str, HookPoint]] = {}
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -451,11 +454,12 @@ class HookedViT(HookedRootModule):
             m = self._BOUNDARY_RE.fullmatch(name)
             if m is None:
                 return None
-            layer, kind = int(m.group(1)), {"resid_pre": "pre", "resid_post": "post", "mlp_out": "mlp"}[m.group(2)]
-            b = layer if kind == "pre" else layer + 1
-            if b == 0:
+            layer = int(m.group(1))
+            kind = {"resid_pre": "pre", "attn_out": "attn", "resid_mid": "mid", "mlp_out": "mlp", "resid_post": "post"}[m.group(2)]
+            pos = {"pre": 2 * layer, "attn": 2 * layer + 1, "mid": 2 * layer + 1, "mlp": 2 * layer + 2, "post": 2 * layer + 2}[kind]
+            if pos == 0:
                 return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
-            out.setdefault(b, {})[kind] = hp
+            out.setdefault(pos, {})[kind] = hp
         return out
 
     def _get_native(self, device: torch.device):
@@ -514,62 +518,92 @@ class HookedViT(HookedRootModule):
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
         nv = self._get_native(x.device)
         bh = self._boundary_hooks() or {}
-        bounds = sorted(b for b in bh if b <= n_blocks and (b < n_blocks or "post" in bh[b] or "mlp" in bh[b]))
+        end_pos = 2 * n_blocks
+        # a hook at the very end fires only if its point is produced: "pre" of block n_blocks is not
+        bounds = sorted(q for q in bh if q < end_pos or (q == end_pos and ("post" in bh[q] or "mlp" in bh[q])))
         if not bounds:
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
                               remove_batch_dim=remove_batch_dim)
-        # ---- split plan: [0, b1) -> hooks -> [b1, b2) -> ... -> [bk, n_blocks) (+ head)
+        # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count half blocks
         wanted = set(names)
         cache: Dict[str, torch.Tensor] = {}
+        first_half = ("hook_resid_pre", "ln1.", "attn.", "hook_attn_out", "hook_resid_mid")
 
-        def stage_of(name: str) -> int:
-            """block index whose segment produces `name` (-1: embedding stage, n_layers: final stage)"""
+        def pos_of(name: str) -> int:
+            """the half block that produces `name` (-1: embedding stage, 2 * n_layers: final stage)"""
             if name.startswith("blocks."):
-                return int(name.split(".")[1])
+                _, l, rest = name.split(".", 2)
+                return 2 * int(l) + (0 if rest.startswith(first_half) else 1)
             return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
-                else cfg.n_layers
+                else 2 * cfg.n_layers
 
-        first, resid, out = 0, None, None
-        for end in bounds + [None]:
-            last = end is None
-            stop = n_blocks if last else end
-            seg = [n for n in names if (first == 0 or stage_of(n) >= first) and stage_of(n) < (cfg.n_layers + 1 if last else stop)
-                   and (first == 0 or n != f"blocks.{first}.hook_resid_pre")]      # (set by hand at the boundary)
-            post_name = f"blocks.{stop - 1}.hook_resid_post"
-            mlp_name, mid_name = f"blocks.{stop - 1}.hook_mlp_out", f"blocks.{stop - 1}.hook_resid_mid"
-            mlp_hp = None if last else bh[end].get("mlp")
-            if first == stop and not (last and run_head):
+        p0, resid, out = 0, None, None
+        for q in bounds + [None]:
+            last = q is None
+            p1 = end_pos if last else q
+            blk = (p1 - 1) // 2                                 # the block whose half ends at p1
+            seg = [n for n in names if (p0 == 0 or pos_of(n) >= p0) and pos_of(n) < (2 * cfg.n_layers + 1 if last else p1)
+                   and not (p0 > 0 and p0 % 2 == 0 and n == f"blocks.{p0 // 2}.hook_resid_pre")]     # (the resumed tensor: set by hand)
+            hooks = {} if last else bh[q]
+            c: Dict[str, torch.Tensor] = {}
+            seg_in = resid
+            if p0 == p1 and not (last and run_head):
                 out = resid                                   # nothing left to run: the hooked residual is the output
             else:
-                forced = [] if last else [post_name] + ([mlp_name, mid_name] if mlp_hp is not None else [])
-                req = seg + [n for n in forced if n not in seg]
-                out, c = nv.forward(self, x if first == 0 else None, req, stop, last and run_head,
-                                    first_block=first, resid_in=resid if first > 0 else None)
-                cache.update({k: v for k, v in c.items() if k in wanted})
+                forced = []
                 if not last:
-                    resid = c[post_name]
+                    if p1 % 2 == 0:
+                        forced = [f"blocks.{blk}.hook_resid_post"]
+                        if "mlp" in hooks:
+                            forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= 2 * blk else [])
+                    else:
+                        forced = [f"blocks.{blk}.hook_resid_mid"]
+                        if "attn" in hooks:
+                            forced += [f"blocks.{blk}.hook_attn_out"] + ([f"blocks.{blk}.hook_resid_pre"] if (p0 < 2 * blk or p0 == 0) else [])
+                req = seg + [n for n in forced if n not in seg]
+                out, c = nv.forward(self, x if p0 == 0 else None, req, p1 // 2, last and run_head, first_block=p0 // 2,
+                                    resid_in=resid if p0 > 0 else None, entry_mid=bool(p0 % 2), exit_mid=bool(p1 % 2))
+                cache.update({k: v for k, v in c.items() if k in wanted})
             if last:
                 break
-            if mlp_hp is not None:
-                # blocks.L.hook_mlp_out: the block's output is rebuilt from what the hook returns, with the kernel's
-                # own rounding (resid_post = round(resid_mid + mlp_out), transformer_block.py:131-134)
-                mlp_out = mlp_hp(c[mlp_name])
-                if mlp_name in wanted:
-                    cache[mlp_name] = mlp_out
-                resid = c[mid_name] + mlp_out.to(c[mid_name].dtype)
-            hp = bh[end].get("post")
-            if hp is not None:
-                resid = hp(resid)
-            if post_name in wanted:
-                cache[post_name] = resid
-            if end < n_blocks:
-                pre_name = f"blocks.{end}.hook_resid_pre"
-                hp = bh[end].get("pre")
-                if hp is not None:
-                    resid = hp(resid)
-                if pre_name in wanted:
-                    cache[pre_name] = resid
-            first = end
+            if p1 % 2 == 1:
+                # after block blk's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
+                # kernel's rounding (transformer_block.py:117-124), then hook_resid_mid
+                resid = c[f"blocks.{blk}.hook_resid_mid"]
+                if "attn" in hooks:
+                    a_name = f"blocks.{blk}.hook_attn_out"
+                    attn_out = hooks["attn"](c[a_name])
+                    if a_name in wanted:
+                        cache[a_name] = attn_out
+                    pre = c.get(f"blocks.{blk}.hook_resid_pre", seg_in)
+                    resid = pre + attn_out.to(pre.dtype)
+                if "mid" in hooks:
+                    resid = hooks["mid"](resid)
+                if f"blocks.{blk}.hook_resid_mid" in wanted:
+                    cache[f"blocks.{blk}.hook_resid_mid"] = resid
+            else:
+                # entering block blk+1: hook_mlp_out rebuilds resid_post = resid_mid + mlp_out (block :131-134), then
+                # hook_resid_post, then the next block's hook_resid_pre
+                post_name = f"blocks.{blk}.hook_resid_post"
+                resid = c[post_name]
+                if "mlp" in hooks:
+                    m_name = f"blocks.{blk}.hook_mlp_out"
+                    mlp_out = hooks["mlp"](c[m_name])
+                    if m_name in wanted:
+                        cache[m_name] = mlp_out
+                    mid = c.get(f"blocks.{blk}.hook_resid_mid", seg_in)
+                    resid = mid + mlp_out.to(mid.dtype)
+                if "post" in hooks:
+                    resid = hooks["post"](resid)
+                if post_name in wanted:
+                    cache[post_name] = resid
+                if p1 < end_pos:
+                    pre_name = f"blocks.{blk + 1}.hook_resid_pre"
+                    if "pre" in hooks:
+                        resid = hooks["pre"](resid)
+                    if pre_name in wanted:
+                        cache[pre_name] = resid
+            p0 = p1
         if out is None:
             out = resid
         ordered: Dict[str, torch.Tensor] = {}
