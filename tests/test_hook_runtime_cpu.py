@@ -197,3 +197,20 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
             assert model._boundary_hooks() is None, bad
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):
         assert model._boundary_hooks() is None
+
+
+def test_spliced_modules_disable_the_native_plan(model, x):
+    """HookedSAEViT.add_sae-style surgery (a module set in place of a HookPoint, base_vit.py:850-873) changes what the
+    forward computes: the dispatcher must notice and keep such a model on the PyTorch path."""
+    import torch.nn as nn
+    assert "module tree" not in model._native_reason((x,), {})          # (CPU input: refused for the device only)
+
+    class Doubler(nn.Module):
+        def forward(self, t):
+            return 2.0 * t
+
+    base = model(x)
+    model.blocks[0].hook_resid_post = Doubler()
+    model.setup()
+    assert not torch.allclose(model(x), base)
+    assert "module tree was modified" in model._native_reason((x,), {})

@@ -303,6 +303,7 @@ class HookedViT(HookedRootModule):
         self.init_weights()
         self.setup()
         # native (HIP) execution state
+        self._module_signature = tuple((n, type(m)) for n, m in self.named_modules())
         self.native_mode = "auto"            # "auto" | "off" | "force"
         self._native = None
         self.last_run_native = False
@@ -414,6 +415,12 @@ class HookedViT(HookedRootModule):
             return f"unsupported kwargs {sorted(extra)}"
         if kwargs.get("incl_bwd", False) or kwargs.get("bwd_hooks"):
             return "backward hooks requested"
+        # structure check: the plan computes THE reference forward -- a module tree that was edited after
+        # construction (an SAE spliced in place of a HookPoint as HookedSAEViT.add_sae does, a swapped block, an
+        # extra layer) must go through PyTorch.  named_modules() is compared with the tree this object was built with.
+        sig = tuple((n, type(m)) for n, m in self.named_modules())
+        if sig != self._module_signature:
+            return "the module tree was modified after construction (spliced / replaced sub-modules)"
         if not x.is_cuda:
             return "input is not on a GPU"
         p0 = self.cls_token
