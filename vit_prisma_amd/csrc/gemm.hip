@@ -384,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// v4 mainloop: the v3 DMA idea with the latency problem fixed.
+// v4 mainloop: operands DMA'd straight into LDS (buffer_load ... lds), deep enough to cover the latency
+// (history of the variants in between -- register staging, 2-stage DMA, 128-byte slabs -- in profiles/r01_notes.md).
 //   * K slabs of 64 BYTES per row (32 bf16 / 16 fp32): a stage is 8 KB (A) + 8 KB (B)
 //   * THREE-stage LDS ring (48 KB) -> 3 workgroups per CU (12 waves): while one workgroup sits at its
 //     barrier or in its store epilogue the other two keep the matrix pipe busy
@@ -736,7 +737,7 @@ __device__ __forceinline__ void epi8_bf16(const float4& x0, const float4& x1, co
 //   The 128 x 128 tiles of v4 pull 1/64 byte of operand per flop out of L2: 68 GB per bs=512 B/32 forward,
 //   ~15 TB/s sustained at v4's speed -- the L2 -> LDS path, not the matrix pipe, is what v4 saturates
 //   (profiles/r01_notes.md).  Here the byte/flop ratio is 1/128 (MB = 4) or 1/142 (MB = 5):
-//     * 8 waves as 2 (M) x 4 (N); a wave owns (32*MB) x 64 outputs (v6's wave tile: 14 ds_read_b128 per 20 MFMAs)
+//     * 8 waves as 2 (M) x 4 (N); a wave owns (32*MB) x 64 outputs (14 ds_read_b128 per 20 MFMAs at MB = 5)
 //     * slot = (64*MB + 256) rows x 64 B (36 KB at MB = 5); FOUR slots (144 KB of the 160 KB) -> slab k+3 is
 //       issued while slab k is multiplied, three slabs (108 KB per CU) in flight
 //     * per slab a wave issues NA = ceil(4*MB / 8) A-instructions + 2 B-instructions; at MB = 5 waves 4..7 have
