@@ -21,6 +21,8 @@
 #include <stdlib.h>
 
 #include "gemm.hpp"
+
+#include <hip/hip_ext.h>
 #include "prof.hpp"
 
 namespace {
@@ -982,9 +984,16 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         double outs = 1.0;
         if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        ProfScope prof(PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
         const dim3 grid(ntm * ntn), block(512);
-#define PV_V7_LAUNCH(EPI, ACT) hipLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, p)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool timed = !getenv("PV_PROF_MARKERS") &&
+                           pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
+        ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+#define PV_V7_LAUNCH(EPI, ACT)                                                                                      \
+    do {                                                                                                            \
+        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, p);                      \
+    } while (0)
         if (p.epi == PV_EPI_BIAS) PV_V7_LAUNCH(PV_EPI_BIAS, 0);
         else if (p.epi == PV_EPI_QKV) PV_V7_LAUNCH(PV_EPI_QKV, 0);
         else if (p.epi == PV_EPI_RESID) PV_V7_LAUNCH(PV_EPI_RESID, 0);

@@ -33,6 +33,24 @@ int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes) {
     return tok;
 }
 
+bool pv_prof_events(int kind, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop) {
+    if (!pv_prof_on(kind)) return false;
+    Pool& p = g_pool[kind];
+    if (p.used >= kMaxEvents) return false;
+    if (p.used >= p.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+        p.start.push_back(a);
+        p.stop.push_back(b);
+    }
+    const size_t tok = p.used++;
+    p.flops += flops;
+    p.bytes += bytes;
+    *start = p.start[tok];
+    *stop = p.stop[tok];
+    return true;
+}
+
 void pv_prof_end(int kind, int token, hipStream_t stream) { (void)hipEventRecord(g_pool[kind].stop[token], stream); }
 
 extern "C" int pv_prof_enable(int32_t on) {

@@ -20,11 +20,16 @@ bool pv_prof_on(int kind);      // enabled AND this kernel family selected (pv_p
 int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes);
 void pv_prof_end(int kind, int token, hipStream_t stream);
 
+// Event pair for a launch that carries its own timestamps (hipExtLaunchKernelGGL attaches the start / stop events to
+// the kernel's dispatch packet: no separate marker packets on the stream, so timing a launch costs no stream time).
+// Returns false when this kernel family is not being timed.
+bool pv_prof_events(int kind, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
+
 struct ProfScope {
     int kind, token;
     hipStream_t stream;
     ProfScope(int k, hipStream_t s, double flops, double bytes) : kind(k), token(-1), stream(s) {
-        if (pv_prof_on(k)) token = pv_prof_begin(k, s, flops, bytes);
+        if (k < PV_PROF__COUNT && pv_prof_on(k)) token = pv_prof_begin(k, s, flops, bytes);     // (k == PV_PROF__COUNT: inert scope)
     }
     ~ProfScope() {
         if (token >= 0) pv_prof_end(kind, token, stream);
