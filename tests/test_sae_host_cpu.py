@@ -159,3 +159,56 @@ def test_on_disk_activation_cache_format_matches_the_reference(tmp_path):
     assert seen > 0
     with pytest.raises(ValueError):
         CacheVisionActivationStore(make_cfg(use_cached_activations=False))
+
+
+class _LoggedImages(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.x = torch.randn(n, 3, 32, 32, generator=torch.Generator().manual_seed(3))
+        self.seen = []
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        self.seen.append(int(i))
+        return self.x[i], 0
+
+
+def _harvest_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vit_prisma_amd import HookedViT, HookedViTConfig
+    from vit_prisma_amd.sae import VisionActivationsStore
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    arch = ARCHS["tiny"]
+    model = HookedViT(HookedViTConfig(**arch, device="cpu"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    data = _LoggedImages(16)
+    cfg = make_cfg(hook_point_layer=1, context_size=17, store_batch_size=2, n_batches_in_buffer=4, train_batch_size=32)
+    store = VisionActivationsStore(cfg, model.eval(), data)         # fills one buffer: 4 store batches = 8 images = one epoch share
+    first_epoch = list(data.seen[:8])
+    batch = store.next_batch()
+    q.put((rank, first_epoch, tuple(batch.shape), tuple(store.storage_buffer.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_harvest_shards_images_across_ranks_gloo_world2():
+    """with torch.distributed initialised every rank's VisionActivationsStore draws a disjoint shard of
+    each epoch's images (no collective in harvesting) and serves train_batch_size / world tokens per step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harvest_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, seen0, b0, buf0), (r1, seen1, b1, buf1) = got
+    assert (r0, r1) == (0, 1)
+    assert len(seen0) == len(seen1) == 8 and not set(seen0) & set(seen1) and set(seen0) | set(seen1) == set(range(16))
+    assert b0 == b1 == (16, 1, 64)                      # 32 tokens per global step -> 16 per rank
+    assert buf0[1:] == buf1[1:] == (1, 64)
