@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 6
+#define PV_ABI_VERSION 7
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -213,6 +213,14 @@ int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flop
 int pv_debug_gemm_trace_arm(int32_t launch_idx);
 int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6);
 
+/* Debug only (tests, A/B measurements): kernel-choice overrides.  The launch path never reads the environment;
+ * these process-global switches are the only way to force a kernel.  Keys: "gemm_tile" (-1 auto, 0 = 128 x 128,
+ * 4 / 5 = one-workgroup-per-CU 256 / 320 x 256), "gemm_v1", "gemm_v1patch", "attn_wg", "prof_markers", "sae_exact",
+ * "gemm_dbg" (ablations, -DPV_TUNING builds only); key "reset" restores every default.
+ * pv_debug_get_tuning("any") = 1 when anything is overridden: bench.py records it and refuses to measure then. */
+int pv_debug_set_tuning(const char* key, int32_t value);
+int pv_debug_get_tuning(const char* key, int32_t* value);
+
 /* ------------------------------------------------------------------------------------------ */
 /* SAE training step (sae/sae.py:557-645 forward; sae/train_sae.py:278-411 step)                */
 /* ------------------------------------------------------------------------------------------ */
@@ -233,10 +241,17 @@ typedef struct pv_sae_state {
                                                    /* Adam kernel transposes it back tile-wise).    */
                                                    /* ONE contiguous flat buffer is recommended so  */
                                                    /* a single all-reduce + one norm pass cover it  */
-    float *mW_enc, *mW_dec, *mb_enc, *mb_dec;      /* Adam exp_avg                               */
-    float *vW_enc, *vW_dec, *vb_enc, *vb_dec;      /* Adam exp_avg_sq                            */
+    float *mW_enc, *mW_dec, *mb_enc, *mb_dec;      /* Adam exp_avg; mW_enc / vW_enc are kept in the */
+    float *vW_enc, *vW_dec, *vb_enc, *vb_dec;      /* gradient's TRANSPOSED [d_sae, d_in] layout    */
     float *act_freq_scores;                        /* [d_sae]  train_sae.py:360                  */
     float *n_fwd_since_fired;                      /* [d_sae]  train_sae.py:357-358              */
+    /* Encoder shadows (caller-owned memory, contents owned by the library: pv_sae_apply keeps them in step with W_enc,
+     * pv_sae_sync_shadows rebuilds them).  NULL disables the filtered encoder (exact fp32 GEMM + top-k instead);
+     * pv_sae_apply requires them. */
+    float *W_encT;                                 /* [d_sae, d_in] fp32 transpose of W_enc: the layout Adam runs in and
+                                                      the exact re-scoring gathers rows from                          */
+    uint16_t *W_enc16T;                            /* [d_sae, d_in] fp16 (B operand of the filter GEMM)               */
+    float *enc_colsq;                              /* [d_sae] ||W_enc[:, j]||^2 (error bound of the filter)           */
 } pv_sae_state;
 
 /* Per-step outputs, caller-owned. */
@@ -269,12 +284,28 @@ int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_t
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.
  * partial_1024: 1024 floats of scratch.  Deterministic two-stage reduction. */
 int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* partial_1024, float* scalars, void* stream);
+/* The same over the gradient rows of features [j_lo, j_hi) only (+ gb_dec when include_b_dec): one rank's term of the
+ * clip norm when the optimizer is sharded by feature (new functionality; j_lo % 4 == 0). */
+int pv_sae_grad_sqnorm_rows(pv_sae_plan* plan, const pv_sae_state* st, int32_t j_lo, int32_t j_hi, int32_t include_b_dec,
+                            float* partial_1024, float* scalars, void* stream);
 
 /* clip (coef from scalars[3] on device, max_norm <= 0 disables) -> remove gradient parallel to
  * decoder rows (sae.py:279-297) -> Adam(betas .9/.999, eps 1e-8, wd 0; train_sae.py:229) with
- * learning rate lr at 1-based step `step` -- one fused pass over parameters + moments. */
+ * learning rate lr at 1-based step `step` -- one fused pass over parameters + moments, for the features
+ * [j_lo, j_hi) (0, d_sae = everything; a sub-range = this rank's shard of the optimizer) and always b_dec.
+ * Keeps W_enc, W_encT, W_enc16T and enc_colsq of those features in step. */
 int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* scalars, float max_grad_norm,
-                 float lr, int32_t step, void* stream);
+                 float lr, int32_t step, int32_t j_lo, int32_t j_hi, void* stream);
+
+/* Rebuild the encoder shadows of features [j_lo, j_hi): from_transposed = 0 takes W_enc as the truth (parameters loaded
+ * or edited by the caller), 1 takes W_encT (e.g. after an all-gather of optimizer shards) and rewrites W_enc. */
+int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t from_transposed, int32_t j_lo, int32_t j_hi, void* stream);
+/* 1 when this plan's shapes take the filtered encoder (fp16 MFMA filter + exact fp32 re-scoring, sae_enc.hip), 0 when
+ * they take the exact fp32 GEMM + streaming top-k. */
+int pv_sae_encoder_is_filtered(const pv_sae_plan* plan);
+/* Debug / tests: byte offset of a named workspace region ("fb_count": uint32, tokens of the last encode that took the
+ * exact fallback; "fb_list", "cand_cnt", "thr"), (size_t)-1 if unknown. */
+size_t pv_debug_sae_ws_offset(const pv_sae_plan* plan, const char* name);
 
 /* Inference-side pieces for the module API (StandardSparseAutoencoder.encode/decode). */
 int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t n_tokens,

@@ -26,3 +26,11 @@ def rel_fro(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.sqrt((b * b).sum())
     return float(np.sqrt(((a - b) ** 2).sum()) / max(den, 1e-30))
+
+
+@pytest.fixture
+def tuning():
+    """Kernel-choice overrides (pv_debug_set_tuning) that are reset after the test."""
+    from vit_prisma_amd import _native
+    yield _native.set_tuning
+    _native.set_tuning("reset")

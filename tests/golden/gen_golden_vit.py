@@ -153,3 +153,69 @@ if __name__ == "__main__":
         dump_l14()
     if "bf16" in what:
         dump_bf16_budget()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: budgets at the configurations bench.py reports (VERDICT r1 "next" item 1)
+# ---------------------------------------------------------------------------------------------
+SUB512 = list(range(0, 8)) + list(range(504, 512))      # images of the bs=512 batch the parity test checks
+L14_SUB = [0, 127]                                      # images of the bs=128 L/14@336 batch
+
+
+def _budget(c32, c16, keys=None):
+    out = {}
+    for k in (keys or c32.keys()):
+        a, b = c32[k].double(), c16[k].double()
+        out[k] = {"rel_fro": float((a - b).norm() / a.norm().clamp_min(1e-30)), "max_abs": float((a - b).abs().max()),
+                  "ref_absmax": float(a.abs().max()), "dtype_bf16_run": str(c16[k].dtype)}
+    return out
+
+
+def dump_bf16_budget_sub512():
+    """The reference's bf16-vs-fp32 error on images SUB512 of synth_images(b32, 512, seed=1) (images do not interact, so
+    the 16-image reference run stands for the reference's bs=512 run): all 214 keys, and the harvest form
+    (stop_at_layer=7, names_filter=[blocks.6.hook_resid_post])."""
+    arch = ARCHS["clip-vit-b32"]
+    imgs = synth_images(arch, 512, seed=1)[SUB512]
+    m32, _ = build_reference_model("clip-vit-b32", dtype=torch.float32)
+    m16, _ = build_reference_model("clip-vit-b32", dtype=torch.bfloat16)
+    o32, c32 = run_ref(m32, imgs)
+    o16, c16 = run_ref(m16, imgs)
+    budget = _budget(c32.cache_dict, c16.cache_dict)
+    budget["__out__"] = _budget({"o": o32}, {"o": o16})["o"]
+    h32, hc32 = run_ref(m32, imgs, names_filter=["blocks.6.hook_resid_post"], stop_at_layer=7)
+    h16, hc16 = run_ref(m16, imgs, names_filter=["blocks.6.hook_resid_post"], stop_at_layer=7)
+    harvest = _budget(hc32.cache_dict, hc16.cache_dict)
+    harvest["__out__"] = _budget({"o": h32}, {"o": h16})["o"]
+    with open(os.path.join(HERE, "vit_b32_bf16_budget_sub512.json"), "w") as f:
+        json.dump({"arch": "clip-vit-b32", "batch": 512, "images": SUB512, "seed": 1, "budget": budget, "harvest": harvest}, f)
+    rel = sorted(v["rel_fro"] for v in budget.values())
+    print("sub512 bf16 budget rel_fro min/median/max", rel[0], rel[len(rel) // 2], rel[-1])
+
+
+def dump_l14_bf16_budget():
+    """L/14@336: the reference's bf16-vs-fp32 error of blocks.{0,23}.attn.hook_pattern on images L14_SUB of
+    synth_images(l14, 128, seed=1) (attention.py:135-152 is what the bf16 kernel is matched against)."""
+    arch = ARCHS["clip-vit-l14-336"]
+    imgs = synth_images(arch, 128, seed=1)[L14_SUB]
+    want = [f"blocks.{l}.attn.hook_pattern" for l in (0, 23)]
+    m32, _ = build_reference_model("clip-vit-l14-336", dtype=torch.float32)
+    o32, c32 = run_ref(m32, imgs, names_filter=want)
+    del m32
+    m16, _ = build_reference_model("clip-vit-l14-336", dtype=torch.bfloat16)
+    t0 = time.time()
+    o16, c16 = run_ref(m16, imgs, names_filter=want)
+    print("l14 bf16 reference forward", time.time() - t0, "s")
+    budget = _budget(c32.cache_dict, c16.cache_dict)
+    budget["__out__"] = _budget({"o": o32}, {"o": o16})["o"]
+    with open(os.path.join(HERE, "vit_l14_bf16_budget_sub128.json"), "w") as f:
+        json.dump({"arch": "clip-vit-l14-336", "batch": 128, "images": L14_SUB, "seed": 1, "budget": budget}, f)
+    print({k: v["rel_fro"] for k, v in budget.items()})
+
+
+if __name__ == "__main__":
+    what2 = sys.argv[1:]
+    if "sub512" in what2:
+        dump_bf16_budget_sub512()
+    if "l14bf16" in what2:
+        dump_l14_bf16_budget()

@@ -240,3 +240,74 @@ def test_native_data_parallel_world2_equals_single_process_oracle():
         assert rel_fro(params[n], P[n]) < 1e-4, n
     assert np.array_equal(act, stats["act_freq_scores"])
     assert leg_tps > 0 and e2e_tps > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the filtered encoder (sae_enc.hip): fp16 MFMA filter + exact fp32 re-scoring must be indistinguishable from the
+# exact fp32 GEMM + streaming top-k it replaces
+# ---------------------------------------------------------------------------------------------------
+def _both_paths(eng, x, tuning):
+    tuning("reset")
+    idx_f, val_f, mu_f, sd_f = (t.clone() for t in eng.encode_topk(x))
+    n_fb = eng.fallback_rows()
+    tuning("sae_exact", 1)
+    idx_e, val_e, mu_e, sd_e = (t.clone() for t in eng.encode_topk(x))
+    tuning("reset")
+    torch.cuda.synchronize()
+    return (idx_f, val_f), (idx_e, val_e), n_fb
+
+
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257)])
+def test_filtered_encoder_equals_exact_path(d_in, d_sae, k, n, tuning):
+    _, _, _, T = fresh(d_in, d_sae)
+    T["b_enc"].mul_(20.0)                                                  # biases that matter
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+    assert eng.filtered_encoder
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=5)).cuda()
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
+    assert n_fb == 0                                                       # ordinary data: the filter decides every token
+    assert torch.equal(idx_f.sort(dim=1).values, idx_e.sort(dim=1).values)  # exact index sets
+    # values: both are fp32 dot products of the same operands in different summation orders
+    o_f, o_e = idx_f.sort(dim=1).indices, idx_e.sort(dim=1).indices
+    assert float((val_f.gather(1, o_f) - val_e.gather(1, o_e)).abs().max()) <= 2e-6 * float(val_e.abs().max())
+    # and against the oracle
+    P = {kk: v.cpu().numpy() for kk, v in T.items()}
+    fw = O.sae_forward(P, x.cpu().numpy(), k)
+    assert np.array_equal(np.sort(idx_f.cpu().numpy(), axis=1), np.sort(fw["idx"], axis=1))
+
+
+def test_filtered_encoder_exact_fallback_on_ties_range_and_outside_edits(tuning):
+    d_in, d_sae, k, n = 64, 4096, 8, 40
+    _, _, _, T = fresh(d_in, d_sae)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, False, n)      # no input LayerNorm: raw magnitudes reach the GEMM
+    assert eng.filtered_encoder
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=2)).cuda()
+    x[3, 5] = 3.0e5                                                        # outside the fp16 range: that token must take the exact path
+    x[7] *= 1e-7                                                           # fp16-subnormal inputs: covered by the bound's absolute term
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
+    assert 1 <= n_fb <= 3
+    assert torch.equal(idx_f.sort(dim=1).values, idx_e.sort(dim=1).values)
+    # duplicated encoder columns: every value comes as an exactly tied pair -> the band around the k-th value holds both
+    # members, the exact re-scoring ties, the index order decides (which member survives is arbitrary, values are not)
+    with torch.no_grad():
+        T["W_enc"][:, 1::2] = T["W_enc"][:, 0::2]
+        T["b_enc"][1::2] = T["b_enc"][0::2]
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=3)).cuda()
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)     # (the in-place edits above re-sync the shadows)
+    assert torch.equal(val_f.sort(dim=1).values, val_e.sort(dim=1).values)
+    for r in range(n):
+        assert len(set(idx_f[r].cpu().tolist())) == k
+    # 2048 identical columns on top of every row: a 2048-way tie at the k-th value -> candidate-list overflow -> every
+    # token is recomputed exactly (radix top-k)
+    with torch.no_grad():
+        T["W_enc"][:, :2048] = T["W_enc"][:, :1].clone()
+        T["b_enc"][:2048] = 5.0
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
+    assert n_fb == n
+    assert torch.equal(val_f.sort(dim=1).values, val_e.sort(dim=1).values)
+    assert bool((idx_f < 2048).all()) and all(len(set(idx_f[r].cpu().tolist())) == k for r in range(n))
+    # a weight outside the fp16 range poisons the bound: every token takes the exact path, results stay right
+    with torch.no_grad():
+        T["W_enc"][3, 77] = 1.0e6
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
+    assert n_fb == n and torch.equal(val_f.sort(dim=1).values, val_e.sort(dim=1).values)

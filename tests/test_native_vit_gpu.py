@@ -3,9 +3,9 @@ and the reference-generated golden fixtures.  Run with ``-m gpu`` on an MI355X.
 
 Tolerances (stated per north_star / SURVEY.md section 7 hard part 1):
   * fp32 mode: rel-Frobenius <= 1e-4 per cache tensor vs the fp32 oracle (measured ~2e-6)
-  * bf16 mode: error vs the fp32 oracle <= 2 x the reference's OWN bf16-vs-fp32 error for the same key
-    (tests/golden/vit_b32_bf16_budget.json, produced by running the reference with cfg.dtype=bf16);
-    a 1e-4 bound is unattainable for any bf16 pipeline, the reference's included
+  * bf16 mode: error vs the fp32 oracle <= 1.0 x the reference's OWN bf16-vs-fp32 error for the same key on the same
+    images (tests/golden/vit_*_bf16_budget*.json, produced by running the reference with cfg.dtype=bf16; one documented
+    exception class, see bf16_limit); a 1e-4 bound is unattainable for any bf16 pipeline, the reference's included
   * hook names / order / shapes / dtypes: exact
 """
 import json
@@ -24,6 +24,21 @@ from conftest import GOLDEN, rel_fro
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4
+
+# bf16 bar (hard part 1(ii)): error vs the fp32 oracle <= 1.0 x the error the REFERENCE's own bf16 run
+# has for the same key on the same images.  Measured at bs = 512 (profiles/r02_parity_ratios.json): 211 of 214 keys at
+# 0.94-1.000 (the embedding / ln_pre / block-0 keys are BIT-identical to the reference's bf16 tensors, ratio 1.000000).
+# One documented exception class: ``*.hook_scale`` -- fp32 per-token scalars sqrt(mean(x^2) + eps) of a bf16 residual
+# stream (budget 2e-4 .. 5e-4).  Their error is the rounding noise of that stream, which is independent of (and as large
+# as) the reference's, so the per-key ratio scatters around 1 (measured 0.93 .. 1.13): held to 1.25 x.
+# BF16_SLACK: the budget was computed with torch's norm, the test with numpy's -- identical tensors differ by 1e-13.
+BF16_SLACK = 1.0 + 1e-6
+
+
+def bf16_limit(key: str, budget_rel_fro: float) -> float:
+    return budget_rel_fro * (1.25 if key.endswith(".hook_scale") else 1.0) * BF16_SLACK
+
+
 
 
 def build(arch_name, dtype, outliers=False):
@@ -101,12 +116,12 @@ def test_fp32_b32_bs16_all_hooks_vs_oracle_and_golden():
 
 
 @pytest.mark.parametrize("tile", [None, "5", "4", "0"])
-def test_bf16_b32_within_reference_bf16_budget(tile, monkeypatch):
+def test_bf16_b32_within_reference_bf16_budget(tile, tuning):
     """tile: the GEMM kernel the library would pick by itself at this size (128 x 128, 3 workgroups per CU), then the
-    large-batch kernels forced onto the same small problem (PV_GEMM_TILE: 320 x 256 / 256 x 256 tile, one 8-wave
+    large-batch kernels forced onto the same small problem (pv_debug_set_tuning gemm_tile: 320 x 256 / 256 x 256 tile, one 8-wave
     workgroup per CU, compile-time epilogues) -- every variant has to meet the same budget."""
     if tile is not None:
-        monkeypatch.setenv("PV_GEMM_TILE", tile)
+        tuning("gemm_tile", int(tile))
     with open(os.path.join(GOLDEN, "vit_b32_bf16_budget.json")) as f:
         budget = json.load(f)["budget"]
     model, arch, sd = build("clip-vit-b32", torch.bfloat16)
@@ -120,9 +135,9 @@ def test_bf16_b32_within_reference_bf16_budget(tile, monkeypatch):
         assert str(cache[k].dtype) == budget[k]["dtype_bf16_run"], k
         n32 += cache[k].dtype == torch.float32
         err = rel_fro(cache[k].float().cpu().numpy(), ref)
-        assert err <= max(2.0 * budget[k]["rel_fro"], 1e-3), (k, err, budget[k]["rel_fro"])
+        assert err <= bf16_limit(k, budget[k]["rel_fro"]), (k, err, budget[k]["rel_fro"])
     assert n32 == 52
-    assert rel_fro(out.float().cpu().numpy(), o_ref) <= max(2.0 * budget["__out__"]["rel_fro"], 1e-3)
+    assert rel_fro(out.float().cpu().numpy(), o_ref) <= budget["__out__"]["rel_fro"] * BF16_SLACK
 
 
 def test_filters_stop_remove_batch_and_cpu_device():
@@ -365,11 +380,11 @@ def test_sae_substitution_style_eval_on_b32_bf16():
 
 @pytest.mark.parametrize("tile", ["5", "4", "0"])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40)])
-def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, monkeypatch):
+def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, tuning):
     """pv_gemm_bias against an fp32 torch reference on shapes that are multiples of nothing: partial row / column
     tiles, K that ends inside a 64-byte slab (K = 200, 72, 40), N = 8 (one 16-byte chunk)."""
     import ctypes as C
-    monkeypatch.setenv("PV_GEMM_TILE", tile)
+    tuning("gemm_tile", int(tile))
     L = _native.lib()
     g = torch.Generator(device="cuda").manual_seed(M * 31 + N)
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -383,3 +398,108 @@ def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, monkeypatch):
     err = float((out[:M].float() - ref).abs().max()) / float(ref.abs().max())
     assert err <= 2 ** -7, err                                                         # one bf16 rounding of the result
     assert float(out[M].float().min()) == 7.0 and float(out[M].float().max()) == 7.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# parity at the configurations bench.py reports (no kernel overrides: the library picks what the bench runs)
+# ---------------------------------------------------------------------------------------------------
+def _held_to_budget(cache, c_ref, budget, sub, tag):
+    bad = []
+    for k, ref in c_ref.items():
+        got = cache[k][sub].float().cpu().numpy()
+        assert got.shape == ref.shape, (tag, k)
+        err = rel_fro(got, ref)
+        if err > bf16_limit(k, budget[k]["rel_fro"]):
+            bad.append((k, err, budget[k]["rel_fro"]))
+    assert not bad, (tag, bad[:8], len(bad))
+
+
+def test_bf16_bs512_all_hooks_and_harvest_vs_oracle_at_reference_budget():
+    """BASELINE config 2 exactly as bench.py runs it (bs = 512, bf16, all 214 hooks, the kernels the library picks at
+    this size): images 0-7 and 504-511 of the batch against the fp32 oracle run on those 16 images (images do not
+    interact), every key held to the error the REFERENCE's bf16 path has on the same images
+    (tests/golden/vit_b32_bf16_budget_sub512.json, generated by executing the reference).  Then the harvest form of
+    VisionActivationsStore.get_activations (stop_at_layer = 7, names_filter = [blocks.6.hook_resid_post])."""
+    with open(os.path.join(GOLDEN, "vit_b32_bf16_budget_sub512.json")) as f:
+        G = json.load(f)
+    sub = G["images"]
+    model, arch, sd = build("clip-vit-b32", torch.bfloat16)
+    assert _native.get_tuning("any") == 0
+    imgs = synth_images(arch, 512, G["seed"])
+    o_ref, c_ref = vit_forward(sd, arch, imgs[sub])
+    x = torch.from_numpy(imgs).cuda().bfloat16()
+    with torch.no_grad():
+        out, cache = model.run_with_cache(x)
+        torch.cuda.synchronize()
+        assert model.last_run_native and list(cache.keys()) == list(c_ref.keys()) and len(cache) == 214
+        _held_to_budget(cache, c_ref, G["budget"], sub, "all hooks")
+        assert rel_fro(out[sub].float().cpu().numpy(), o_ref) <= G["budget"]["__out__"]["rel_fro"] * BF16_SLACK
+        del cache
+        h_ref, hc_ref = vit_forward(sd, arch, imgs[sub], stop_at_layer=7, names_filter=["blocks.6.hook_resid_post"])
+        hout, hcache = model.run_with_cache(x, stop_at_layer=7, names_filter=["blocks.6.hook_resid_post"])
+        torch.cuda.synchronize()
+        assert model.last_run_native and list(hcache.keys()) == ["blocks.6.hook_resid_post"]
+        _held_to_budget(hcache, hc_ref, G["harvest"], sub, "harvest")
+        assert torch.equal(hout, hcache["blocks.6.hook_resid_post"])
+
+
+def test_bf16_l14_bs128_pattern_vs_oracle_at_reference_budget():
+    """BASELINE config 5 as bench.py runs it (L/14@336, bs = 128, bf16, the 24 pattern taps): blocks.{0,23}.attn.hook_pattern
+    of images 0 and 127 against the fp32 oracle, held to the reference's own bf16 error on the same images
+    (tests/golden/vit_l14_bf16_budget_sub128.json; attention.py:135-152 is what the kernel matches)."""
+    with open(os.path.join(GOLDEN, "vit_l14_bf16_budget_sub128.json")) as f:
+        G = json.load(f)
+    sub = G["images"]
+    model, arch, sd = build("clip-vit-l14-336", torch.bfloat16)
+    imgs = synth_images(arch, 128, G["seed"])
+    want = [f"blocks.{l}.attn.hook_pattern" for l in (0, 23)]
+    o_ref, c_ref = vit_forward(sd, arch, imgs[sub], names_filter=want)
+    x = torch.from_numpy(imgs).cuda().bfloat16()
+    with torch.no_grad():
+        out, cache = model.run_with_cache(x, names_filter=lambda n: n.endswith("attn.hook_pattern"))
+    torch.cuda.synchronize()
+    assert model.last_run_native and len(cache) == 24
+    _held_to_budget({k: cache[k] for k in want}, c_ref, G["budget"], sub, "l14 pattern")
+    assert rel_fro(out[sub].float().cpu().numpy(), o_ref) <= G["budget"]["__out__"]["rel_fro"] * BF16_SLACK
+    s = cache["blocks.23.attn.hook_pattern"][sub].float().sum(-1)
+    assert float((s - 1).abs().max()) < 2e-2
+
+
+def _digests(model, bs_list):
+    import hashlib
+    out = []
+    for bs in bs_list:
+        x = torch.randn(bs, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(bs)).bfloat16()
+        with torch.no_grad():
+            o, cache = model.run_with_cache(x)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for k in cache.keys():
+            h.update(cache[k].contiguous().view(torch.uint8).cpu().numpy().tobytes())
+        h.update(o.contiguous().view(torch.uint8).cpu().numpy().tobytes())
+        out.append(h.hexdigest())
+        del o, cache
+    return out
+
+
+def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning):
+    """At 77 and 300 images (partial row tiles in every GEMM) the three bf16 GEMM kernels -- 128 x 128 (v4), 256 x 256 and
+    320 x 256 (v7) -- must give BIT-identical digests over all 214 cache tensors: they accumulate every output element
+    in the same K order and share one activation / rounding sequence (act_any in gemm.hip).  Consequence, checked last:
+    an image's cache rows are the same bits at bs = 1 (v4 picked) and inside a 300-image batch (v7 picked)."""
+    model, arch, _ = build("clip-vit-b32", torch.bfloat16)
+    ref = None
+    for tile in (None, 0, 4, 5):
+        tuning("reset")
+        if tile is not None:
+            tuning("gemm_tile", tile)
+        d = _digests(model, (77, 300))
+        ref = ref or d
+        assert d == ref, tile
+    tuning("reset")
+    x = torch.randn(300, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(300)).bfloat16()
+    with torch.no_grad():
+        _, big = model.run_with_cache(x)
+        _, one = model.run_with_cache(x[123:124])
+    for k in big.keys():
+        assert torch.equal(big[k][123], one[k][0]), k

@@ -1,6 +1,5 @@
-"""rocprofv3 target: a few SAE train steps at BASELINE config 3."""
-import os, sys
+"""7 full SAE train steps (768 -> 24576, k = 32, N = 4096) for rocprofv3 --kernel-trace --stats / --pmc."""
+import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 from vit_prisma_amd.sae.bench_leg import sae_bench_leg
-print(sae_bench_leg(torch.device("cuda:0"), steps=5, warmup=2))
+print(sae_bench_leg(torch.device("cuda", 0), steps=5, warmup=2))

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -62,7 +62,7 @@ class SaeState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "W_enc", "W_dec", "b_enc", "b_dec", "gW_enc", "gW_dec", "gb_enc", "gb_dec",
         "mW_enc", "mW_dec", "mb_enc", "mb_dec", "vW_enc", "vW_dec", "vb_enc", "vb_dec",
-        "act_freq_scores", "n_fwd_since_fired")]
+        "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq")]
 
 
 class SaeOut(C.Structure):
@@ -79,8 +79,9 @@ EXPORTS = [
     "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_gemm_bias", "pv_transpose_batched",
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
-    "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_apply", "pv_sae_encode_topk",
-    "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read",
+    "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
+    "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset",
+    "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
 ]
 
 
@@ -119,6 +120,8 @@ def lib() -> C.CDLL:
     L.pv_prof_enable.argtypes = [i32]
     L.pv_prof_read.argtypes = [i32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]
+    L.pv_debug_set_tuning.argtypes = [C.c_char_p, i32]
+    L.pv_debug_get_tuning.argtypes = [C.c_char_p, C.POINTER(i32)]
     if hasattr(L, "pv_sae_plan_create"):
         L.pv_sae_plan_create.argtypes = [C.POINTER(SaeDesc), C.POINTER(vp)]
         L.pv_sae_plan_destroy.argtypes = [vp]
@@ -128,7 +131,12 @@ def lib() -> C.CDLL:
         L.pv_sae_renorm_decoder.argtypes = [vp, C.POINTER(SaeState), vp]
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
-        L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, vp]
+        L.pv_sae_grad_sqnorm_rows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp, vp, vp]
+        L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, i32, i32, vp]
+        L.pv_sae_sync_shadows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp]
+        L.pv_sae_encoder_is_filtered.argtypes = [vp]
+        L.pv_debug_sae_ws_offset.argtypes = [vp, C.c_char_p]
+        L.pv_debug_sae_ws_offset.restype = sz
         L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]
     _lib = L
     return L
@@ -166,3 +174,15 @@ def prof_read(kind: str) -> dict:
     n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
     check(lib().pv_prof_read(PROF_KINDS[kind], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "pv_prof_read")
     return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+
+
+def set_tuning(key: str, value: int = 0) -> None:
+    """Kernel-choice override for tests / A-B measurements (``key="reset"`` restores every default).  The library
+    never reads the environment on the launch path; this is the only switch."""
+    check(lib().pv_debug_set_tuning(key.encode(), int(value)), "pv_debug_set_tuning")
+
+
+def get_tuning(key: str = "any") -> int:
+    v = C.c_int32()
+    check(lib().pv_debug_get_tuning(key.encode(), C.byref(v)), "pv_debug_get_tuning")
+    return v.value

@@ -778,14 +778,14 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         // one head per wave: needs whole bf16 pairs per row and 4-byte aligned head blocks in the taps
         const bool taps_ok = (reinterpret_cast<uintptr_t>(p.scores) % 4 == 0) && (reinterpret_cast<uintptr_t>(p.pattern) % 4 == 0);
-        if (p.T <= 64 && p.T % 2 == 0 && taps_ok && pv_aligned16(p.z) && !getenv("PV_ATTN_WG") &&
+        if (p.T <= 64 && p.T % 2 == 0 && taps_ok && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
             (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31)) {
             if (p.dh == 64) return launch_attn_wave<64>(p, stream);
             if (p.dh == 32) return launch_attn_wave<32>(p, stream);
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !getenv("PV_ATTN_WG") &&
+        if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
             (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31))
             return launch_attn_stream(p, stream);
     }

@@ -18,8 +18,6 @@
 //   costs one HBM store, nothing is re-read).
 //   blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (which share the A rows)
 //   are placed on the same XCD so the A slab is served from that XCD's L2.
-#include <stdlib.h>
-
 #include "gemm.hpp"
 
 #include <hip/hip_ext.h>
@@ -115,6 +113,54 @@ struct Loader {
     }
 };
 
+__device__ __forceinline__ pv_f32x2 unpack2(uint32_t w) {
+    return pv_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint32_t pack2(pv_f32x2 v) { return pack_bf16x2(v.x, v.y); }
+
+template <int ACT>
+__device__ __forceinline__ pv_f32x2 act2(pv_f32x2 x) {
+    if constexpr (ACT == PV_ACT_QUICK_GELU) {                // x * sigmoid(1.702 x), models/activation_fns.py:19
+        const pv_f32x2 t = x * (-1.702f * 1.4426950408889634f);
+        pv_f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        d = d + 1.0f;
+        const pv_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        return x * r;
+    } else if constexpr (ACT == PV_ACT_GELU) {               // 0.5 x (1 + erf(x / sqrt 2)); erf: Abramowitz-Stegun 7.1.26
+        const pv_f32x2 z = x * 0.70710678118654752440f;
+        const pv_f32x2 az = __builtin_elementwise_abs(z);
+        const pv_f32x2 den = __builtin_elementwise_fma(az, pv_f32x2{0.3275911f, 0.3275911f}, pv_f32x2{1.0f, 1.0f});
+        const pv_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        pv_f32x2 q = __builtin_elementwise_fma(t, pv_f32x2{1.061405429f, 1.061405429f}, pv_f32x2{-1.453152027f, -1.453152027f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{1.421413741f, 1.421413741f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{-0.284496736f, -0.284496736f});
+        q = __builtin_elementwise_fma(t, q, pv_f32x2{0.254829592f, 0.254829592f});
+        q = q * t;
+        const pv_f32x2 a2 = az * az * (-1.4426950408889634f);
+        const pv_f32x2 e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+        pv_f32x2 r = __builtin_elementwise_fma(-q, e, pv_f32x2{1.0f, 1.0f});
+        r = __builtin_elementwise_copysign(r, z);
+        const pv_f32x2 hx = x * 0.5f;
+        return __builtin_elementwise_fma(hx, r, hx);
+    } else {
+        return __builtin_elementwise_max(x, pv_f32x2{0.0f, 0.0f});
+    }
+}
+
+// The activation every bf16 epilogue applies (v4's run-time epilogues included): ONE instruction sequence for all
+// kernels, so mlp.hook_post of an image has the same bits whatever GEMM kernel its batch size selects.
+template <typename T>
+__device__ __forceinline__ float act_any(float x, int act) {
+    if constexpr (sizeof(T) == 2) {
+        const pv_f32x2 v = {x, x};
+        if (act == PV_ACT_GELU) return act2<PV_ACT_GELU>(v).x;
+        if (act == PV_ACT_QUICK_GELU) return act2<PV_ACT_QUICK_GELU>(v).x;
+        return act2<PV_ACT_RELU>(v).x;
+    } else {
+        return pv_act<false>(x, act);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], int gm, int gn) {
     T* out0 = reinterpret_cast<T*>(p.out0);
@@ -153,7 +199,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
             for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
             if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = pv_act<sizeof(T) == 2>(v[i], p.act);
+            for (int i = 0; i < 8; ++i) v[i] = act_any<T>(v[i], p.act);
             store8(out1 + (int64_t)gm * p.ldo + gn, v);
         }
     } else {
@@ -179,7 +225,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, float (&v)[8], in
             } else {
                 x = DT<T>::round(x);
                 if (o0) DT<T>::store(o0 + (int64_t)gm * p.ldo + g, x);
-                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, pv_act<sizeof(T) == 2>(x, p.act));
+                DT<T>::store(out1 + (int64_t)gm * p.ldo + g, act_any<T>(x, p.act));
             }
         }
     }
@@ -217,7 +263,7 @@ __device__ __forceinline__ void epilogue8_pre(const GemmParams& p, float (&v)[8]
         for (int i = 0; i < 8; ++i) v[i] = DT<T>::round(v[i]);
         if (out0) store8(out0 + (int64_t)gm * p.ldo + gn, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = pv_act<sizeof(T) == 2>(v[i], p.act);
+        for (int i = 0; i < 8; ++i) v[i] = act_any<T>(v[i], p.act);
         store8(out1 + (int64_t)gm * p.ldo + gn, v);
     }
 }
@@ -464,11 +510,16 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
             // NOTE: no branch may surround these DMA instructions -- hipcc's waitcnt pass answers a
             // conditionally executed LDS-DMA with s_waitcnt vmcnt(0) before the next ds_read (ring drained)
             // (bitwise, not short-circuit: it has to compile to selects)
-            const bool oob = (kt >= nk) | (ktail & (kbase + kcb[j] >= Kb)) | (((p.dbg & 1) != 0) & (kt >= 2));
+            bool oob = (kt >= nk) | (ktail & (kbase + kcb[j] >= Kb));
+#ifdef PV_TUNING
+            oob |= (((p.dbg & 1) != 0) & (kt >= 2));
+#endif
             oa = oob ? 0xffffff00u : oa;
             ob = oob ? 0xffffff00u : ob;
+#ifdef PV_TUNING
             oa = (p.dbg & 4) ? lane * 16u : oa;                     // ablation: every DMA hits the same cached 1 KiB
             ob = (p.dbg & 4) ? lane * 16u : ob;
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(Ab + j * 1024), 16, oa, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(Bb + j * 1024), 16, ob, 0, 0, 0);
         }
@@ -532,7 +583,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
     // residual epilogues, its 8 x 16 B of residual-stream rows.  They are older than every DMA in the vmcnt
     // queue, so the counted waits of the loop retire them for free and the store epilogue never waits on HBM.
     const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
-    const bool e_fast = EB == 2 && p.vec_out && e_gn + 8 <= p.N && !(p.dbg & 8);
+    const bool e_fast = EB == 2 && p.vec_out && e_gn + 8 <= p.N;
     uint4 e_bias = make_uint4(0, 0, 0, 0);        // 8 raw bf16 (converted in the epilogue: no wait up here)
     uint4 e_res[2][4];
     int e_col = e_gn;
@@ -579,10 +630,12 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel_v4(const GemmParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
     __syncthreads();
     trace_stamp(p.trace, bid, 1);
+#ifdef PV_TUNING
     if (p.dbg & 2) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
         return;
     }
+#endif
 
     // ---- epilogue in two 32-row halves per wave; staging 32 x 64 floats per wave (waves 0,1 in ring0,
     //      waves 2,3 in ring1)
@@ -668,42 +721,6 @@ int launch(const GemmParams& p, hipStream_t stream) {
 // for 8 waves per CU).  Here: packed fp32 math (v_pk_*), v_exp / v_rcp instead of expf / division (the value
 // is rounded to bf16 two instructions later), no run-time switches.
 // ---------------------------------------------------------------------------------------------------
-typedef float pv_f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ pv_f32x2 unpack2(uint32_t w) {
-    return pv_f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
-}
-__device__ __forceinline__ uint32_t pack2(pv_f32x2 v) { return pack_bf16x2(v.x, v.y); }
-
-template <int ACT>
-__device__ __forceinline__ pv_f32x2 act2(pv_f32x2 x) {
-    if constexpr (ACT == PV_ACT_QUICK_GELU) {                // x * sigmoid(1.702 x), models/activation_fns.py:19
-        const pv_f32x2 t = x * (-1.702f * 1.4426950408889634f);
-        pv_f32x2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-        d = d + 1.0f;
-        const pv_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-        return x * r;
-    } else if constexpr (ACT == PV_ACT_GELU) {               // 0.5 x (1 + erf(x / sqrt 2)); erf: Abramowitz-Stegun 7.1.26
-        const pv_f32x2 z = x * 0.70710678118654752440f;
-        const pv_f32x2 az = __builtin_elementwise_abs(z);
-        const pv_f32x2 den = __builtin_elementwise_fma(az, pv_f32x2{0.3275911f, 0.3275911f}, pv_f32x2{1.0f, 1.0f});
-        const pv_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        pv_f32x2 q = __builtin_elementwise_fma(t, pv_f32x2{1.061405429f, 1.061405429f}, pv_f32x2{-1.453152027f, -1.453152027f});
-        q = __builtin_elementwise_fma(t, q, pv_f32x2{1.421413741f, 1.421413741f});
-        q = __builtin_elementwise_fma(t, q, pv_f32x2{-0.284496736f, -0.284496736f});
-        q = __builtin_elementwise_fma(t, q, pv_f32x2{0.254829592f, 0.254829592f});
-        q = q * t;
-        const pv_f32x2 a2 = az * az * (-1.4426950408889634f);
-        const pv_f32x2 e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-        pv_f32x2 r = __builtin_elementwise_fma(-q, e, pv_f32x2{1.0f, 1.0f});
-        r = __builtin_elementwise_copysign(r, z);
-        const pv_f32x2 hx = x * 0.5f;
-        return __builtin_elementwise_fma(hx, r, hx);
-    } else {
-        return __builtin_elementwise_max(x, pv_f32x2{0.0f, 0.0f});
-    }
-}
-
 // one 8-element chunk: acc + bias -> (rounded) outputs.  o0 / o1 point at the chunk; b = unpacked bias.
 template <int EPI, int ACT>
 __device__ __forceinline__ void epi8_bf16(const float4& x0, const float4& x1, const pv_f32x2 (&b)[4], bf16_t* o0, bf16_t* o1,
@@ -822,7 +839,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     }
     auto issue = [&](int kt, unsigned char* slot) {
         const unsigned kbase = (unsigned)kt * 64;
-        const bool dead = (kt >= nk) | (((p.dbg & 1) != 0) & (kt >= 3));
+        bool dead = (kt >= nk);
+#ifdef PV_TUNING
+        dead |= (((p.dbg & 1) != 0) & (kt >= 3));
+#endif
         // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
         const unsigned kbaseA = patch ? (unsigned)((kt >> 5) * p.pS * p.pS + (kt & 31) * p.pS) * EB : kbase;
 #pragma unroll
@@ -932,10 +952,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
     __syncthreads();
     trace_stamp(p.trace, bid, 1);
+#ifdef PV_TUNING
     if (p.dbg & 2) {
         if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.out0)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
         return;
     }
+#endif
 
     constexpr int CLD = 64;
     float* Cs = reinterpret_cast<float*>((wave < 4 ? ring0 : ring1) + (wave & 3) * (32 * CLD * 4));
@@ -986,7 +1008,7 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
         const dim3 grid(ntm * ntn), block(512);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = !getenv("PV_PROF_MARKERS") &&
+        const bool timed = !g_pv_tuning.prof_markers &&
                            pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
         ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
 #define PV_V7_LAUNCH(EPI, ACT)                                                                                      \
@@ -1010,7 +1032,7 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
 // measured per-tile K-loop + epilogue of the two kernels at K = 768 on the B/32 shapes (tools/gemm_trace.py):
 // v4 25 us for 3 x (128 x 128) per CU, v7 26.5 us (MB = 4) / 32 us (MB = 5) for one (64*MB) x 256 per CU.
 inline int pick_v7(const GemmParams& p) {
-    if (const char* e = getenv("PV_GEMM_TILE")) return atoi(e);          // 0 = v4, 4 / 5 = v7<MB>
+    if (g_pv_tuning.gemm_tile >= 0) return g_pv_tuning.gemm_tile;           // 0 = v4, 4 / 5 = v7<MB>
     auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
     const int64_t M = p.M, N = p.N;
     const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 768) * 25.0;
@@ -1040,7 +1062,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
     p.vec_out = vo ? 1 : 0;
     if (p.a_mode == PV_A_PLAIN && vec) {
         const uint64_t spanA = ((uint64_t)p.M + BM) * (uint64_t)p.lda * EB, spanB = ((uint64_t)p.N + BN) * (uint64_t)p.ldb * EB;
-        if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !getenv("PV_GEMM_V1")) {
+        if (spanA < 0xffffff00ull && spanB < 0xffffff00ull && !g_pv_tuning.gemm_v1) {
             // 128 x 128 tiles, 3 workgroups / CU (v4) or one 8-wave workgroup with a (64*MB) x 256 tile (v7);
             // history and measurements of the variants in between: profiles/r01_notes.md
             if constexpr (EB == 2) {
@@ -1058,7 +1080,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
         const uint64_t img_bytes = (uint64_t)(p.pG ? p.M / (p.pG * p.pG) : 0) * p.pC * p.pS * p.pS * EB;
         if (p.a_mode == PV_A_PATCH && vec && p.vec_out && p.N % 8 == 0 && p.pP == 32 && p.K == p.pC * 1024 && p.pG > 0 &&
             p.M % (p.pG * p.pG) == 0 && img_bytes < 0xffffff00ull && (uint64_t)(p.N + 256) * p.ldb * EB < 0xffffff00ull &&
-            !getenv("PV_GEMM_V1") && !getenv("PV_GEMM_V1PATCH")) {
+            !g_pv_tuning.gemm_v1 && !g_pv_tuning.gemm_v1patch) {
             const int pick = pick_v7(p);
             if (pick == 5) return launch_v7<T, 5>(p, stream);
             if (pick == 4) return launch_v7<T, 4>(p, stream);
@@ -1098,7 +1120,7 @@ extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int3
 }
 
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
-    if (const char* e = getenv("PV_GEMM_DBG")) p.dbg = atoi(e);
+    p.dbg = g_pv_tuning.gemm_dbg;
     p.trace = nullptr;
     if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {
         if (g_trace_countdown-- == 0) {

@@ -86,3 +86,54 @@ extern "C" int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, d
     if (bytes) *bytes = p.bytes;
     return PV_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// kernel-choice overrides (tests, A/B measurements).  Process-global, never read from the environment.
+// ---------------------------------------------------------------------------------------------------
+#include <string.h>
+
+PvTuning g_pv_tuning;
+
+namespace {
+int* tuning_field(const char* key) {
+    if (!key) return nullptr;
+    if (!strcmp(key, "gemm_tile")) return &g_pv_tuning.gemm_tile;
+    if (!strcmp(key, "gemm_v1")) return &g_pv_tuning.gemm_v1;
+    if (!strcmp(key, "gemm_v1patch")) return &g_pv_tuning.gemm_v1patch;
+    if (!strcmp(key, "attn_wg")) return &g_pv_tuning.attn_wg;
+    if (!strcmp(key, "prof_markers")) return &g_pv_tuning.prof_markers;
+    if (!strcmp(key, "sae_exact")) return &g_pv_tuning.sae_exact;
+    if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int pv_debug_set_tuning(const char* key, int32_t value) {
+    if (key && !strcmp(key, "reset")) {
+        g_pv_tuning = PvTuning();
+        return PV_OK;
+    }
+    int* f = tuning_field(key);
+    PV_REQUIRE(f != nullptr, "unknown tuning key");
+#ifndef PV_TUNING
+    PV_REQUIRE(f != &g_pv_tuning.gemm_dbg || value == 0, "gemm_dbg ablations exist only in -DPV_TUNING builds");
+#endif
+    *f = value;
+    return PV_OK;
+}
+
+// value of one key; key "any" = 1 when any field differs from its default (what bench.py asserts to be 0)
+extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
+    PV_REQUIRE(key && value, "null argument");
+    if (!strcmp(key, "any")) {
+        const PvTuning d;
+        const PvTuning& t = g_pv_tuning;
+        *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg ||
+                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg) ? 1 : 0;
+        return PV_OK;
+    }
+    const int* f = tuning_field(key);
+    PV_REQUIRE(f != nullptr, "unknown tuning key");
+    *value = *f;
+    return PV_OK;
+}

@@ -136,5 +136,21 @@ __device__ __forceinline__ float pv_act(float x, int act) {
     return fmaxf(x, 0.0f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// kernel-choice overrides for tests / A-B measurements (pv_debug_set_tuning in pv_native.h).  The launch path reads
+// these process-global ints -- never the environment; every field's default is "let the library decide", and
+// bench.py records pv_debug_get_tuning("any") in its JSON line and refuses to run when it is non-zero.
+// ---------------------------------------------------------------------------------------------
+struct PvTuning {
+    int gemm_tile = -1;      // -1 auto; 0 = 128 x 128 kernel (v4); 4 / 5 = one-workgroup-per-CU kernel with a 256 / 320 x 256 tile
+    int gemm_v1 = 0;         // 1: register-staged 128 x 128 kernel for everything
+    int gemm_v1patch = 0;    // 1: register-staged kernel for the patch embedding only
+    int attn_wg = 0;         // 1: workgroup-per-(image, head, query block) attention kernel for every shape
+    int prof_markers = 0;    // 1: time v7 launches with hipEventRecord markers instead of dispatch-packet events
+    int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
+    int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds
+};
+extern PvTuning g_pv_tuning;
+
 static inline int64_t pv_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static inline bool pv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -19,13 +19,13 @@
 //   bias grads  gb_dec = colsum(dY) - W_enc @ gb_enc   (the encoder-input path of b_dec, folded into a GEMV)
 //   apply       clip coefficient -> remove component parallel to decoder rows -> Adam, fused per tensor
 #include <math.h>
+#include <string.h>
 
-#include "gemm.hpp"
-#include "prof.hpp"
+#include "sae.hpp"
 
 namespace {
 
-constexpr int MAXK = 64;
+constexpr int MAXK = PV_SAE_MAXK;
 
 // ------------------------------------------------------------------------------------------------
 // generic helpers
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
                                                        const float* __restrict__ batch_mean, float* __restrict__ sae_in,
+                                                       _Float16* __restrict__ x16, float* __restrict__ xnorm_out,
                                                        float* __restrict__ mu_out, float* __restrict__ std_out,
                                                        float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps) {
     const int lane = threadIdx.x & 63;
@@ -97,14 +98,23 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
     }
     // torch.std: unbiased (divide by d - 1)
     const float sd = use_ln ? sqrtf(wave_sum(sq) / (float)(d - 1)) : 1.f;
+    float s2 = 0.f, amax = 0.f;
     for (int i = lane; i < d; i += 64) {
         const float xh = use_ln ? (xr[i] - mu) / (sd + eps) : xr[i];
-        sae_in[(int64_t)n * d + i] = xh - b_dec[i];
+        const float si = xh - b_dec[i];
+        sae_in[(int64_t)n * d + i] = si;
+        if (x16) x16[(int64_t)n * d + i] = (_Float16)si;       // operand of the filter GEMM (sae_enc.hip)
+        s2 += si * si;
+        amax = fmaxf(amax, fabsf(si));
     }
+    s2 = wave_sum(s2);
+    amax = wave_max(amax);
     if (lane == 0) {
         mu_out[n] = mu;
         std_out[n] = sd;
         norm_out[n] = sqrtf(cn);
+        // ||sae_in||_2 for the filter's error bound; a row outside the fp16 range (or NaN) is sent to the exact path
+        if (xnorm_out) xnorm_out[n] = (amax <= 6.0e4f) ? sqrtf(s2) : INFINITY;
     }
 }
 
@@ -129,14 +139,32 @@ constexpr int TOPK_CAP = 1024;   // candidate list capacity of the fast path
 //           the result is sorted by value like torch.topk and run-to-run deterministic
 // Fallback (more than TOPK_CAP candidates: massive ties at the top, e.g. constant rows): MSB-first radix
 // select that re-streams the row once per digit.
+// `row_list` != nullptr: the workgroups walk rows row_list[blockIdx.x], row_list[blockIdx.x + gridDim.x], ... (the tokens
+// the filtered encoder of sae_enc.hip could not decide); otherwise row = blockIdx.x.
+__device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                             int d_sae, int k, int64_t row);
+
 __global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__ hidden, int32_t* __restrict__ idx_out,
-                                                       float* __restrict__ val_out, int d_sae, int k) {
+                                                       float* __restrict__ val_out, int d_sae, int k,
+                                                       const int32_t* __restrict__ row_list, const uint32_t* __restrict__ n_list) {
+    if (!row_list) {
+        sae_topk_row(hidden, idx_out, val_out, d_sae, k, blockIdx.x);
+        return;
+    }
+    const uint32_t n = *n_list;
+    for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
+        __syncthreads();
+        sae_topk_row(hidden, idx_out, val_out, d_sae, k, row_list[s]);
+    }
+}
+
+__device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                             int d_sae, int k, int64_t row) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_T0, sh_ncand, sh_prefix, sh_k, sh_wcnt[4];
     __shared__ uint32_t cand_key[TOPK_CAP];
     __shared__ int32_t cand_idx[TOPK_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row = blockIdx.x;
     const float* h = hidden + row * d_sae;
     const int nvec = d_sae >> 2;                     // d_sae % 4 == 0 (checked at plan creation)
 
@@ -517,13 +545,13 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
     return w - (c.lr / c.bc1) * (m / denom);
 }
 
-template <int DPL>   // W_dec rows: one wave per row, with the parallel-gradient projection
+template <int DPL>   // W_dec rows [j_lo, j_hi): one wave per row, with the parallel-gradient projection
 __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                         float* __restrict__ M, float* __restrict__ V,
-                                                        const float* __restrict__ scalars, AdamC c, int rows, int d) {
+                                                        const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= rows) return;
+    const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= j_hi) return;
     const float coef = clip_coef(scalars, c.max_norm);
     float w[DPL], g[DPL];
     float dot = 0.f;
@@ -552,38 +580,87 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
     }
 }
 
-// W_enc [d_in][d_sae] with its gradient stored transposed [d_sae][d_in]: 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void adam_wenc_kernel(float* __restrict__ W, const float* __restrict__ GT,
-                                                        float* __restrict__ M, float* __restrict__ V,
-                                                        const float* __restrict__ scalars, AdamC c, int d_in, int d_sae) {
+// ------------------------------------------------------------------------------------------------
+// W_enc lives three times: the module's parameter W [d_in][d_sae]; WT = its transpose [d_sae][d_in] in fp32 -- the
+// layout the sparse backward writes gradients in and the exact re-scoring of sae_enc.hip gathers rows from, hence
+// the layout Adam runs in (gradient, both moments and WT are read and written coalesced, feature rows [j_lo, j_hi) are
+// contiguous: the data-parallel trainer shards the optimizer by feature); and W16T = WT rounded to fp16, the B operand of
+// the filter GEMM.  One workgroup owns 32 features x all d_in: tile-wise it updates WT / moments / W16T in place,
+// transposes the new values through LDS into W, and leaves ||W_enc[:, j]||^2 (the filter's error bound) in colsq.
+// MODE 0: Adam step.  MODE 1: rebuild W, W16T, colsq from WT (after an all-gather of WT).  MODE 2: rebuild WT, W16T,
+// colsq from W (parameters edited from outside).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, float* __restrict__ WT, _Float16* __restrict__ W16T,
+                                                        float* __restrict__ colsq, const float* __restrict__ GT,
+                                                        float* __restrict__ MT, float* __restrict__ VT,
+                                                        const float* __restrict__ scalars, AdamC c, int d_in, int d_sae,
+                                                        int j_lo, int j_hi) {
     __shared__ float tile[32][33];
-    const float coef = clip_coef(scalars, c.max_norm);
-    const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int j0 = j_lo + blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float coef = 1.f;
+    if constexpr (MODE == 0) coef = clip_coef(scalars, c.max_norm);
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    bool big = false;
+    for (int i0 = 0; i0 < d_in; i0 += 32) {
+        if constexpr (MODE == 2) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = j0 + ty + 8 * r, i = i0 + tx;
-        tile[ty + 8 * r][tx] = (j < d_sae && i < d_in) ? GT[(int64_t)j * d_in + i] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ty + 8 * r, j = j0 + tx;
-        if (i < d_in && j < d_sae) {
-            const int64_t o = (int64_t)i * d_sae + j;
-            float m = M[o], v = V[o];
-            W[o] = adam_update(W[o], tile[tx][ty + 8 * r] * coef, m, v, c);
-            M[o] = m;
-            V[o] = v;
+            for (int r = 0; r < 4; ++r) {                       // read W[i][j0 + tx] coalesced along j
+                const int i = i0 + ty + 8 * r, j = j0 + tx;
+                tile[tx][ty + 8 * r] = (i < d_in && j < j_hi) ? W[(int64_t)i * d_sae + j] : 0.f;
+            }
+            __syncthreads();
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + ty + 8 * r, i = i0 + tx;
+            if (j < j_hi && i < d_in) {
+                const int64_t o = (int64_t)j * d_in + i;
+                float wn;
+                if constexpr (MODE == 0) {
+                    float m = MT[o], v = VT[o];
+                    wn = adam_update(WT[o], GT[o] * coef, m, v, c);
+                    MT[o] = m;
+                    VT[o] = v;
+                    WT[o] = wn;
+                } else if constexpr (MODE == 1) {
+                    wn = WT[o];
+                } else {
+                    wn = tile[ty + 8 * r][tx];
+                    WT[o] = wn;
+                }
+                W16T[o] = (_Float16)wn;
+                sq[r] += wn * wn;
+                big = big || !(fabsf(wn) <= 6.0e4f);            // outside the fp16 range (or NaN): the filter must not be trusted
+                if constexpr (MODE != 2) tile[ty + 8 * r][tx] = wn;
+            }
+        }
+        if constexpr (MODE != 2) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + ty + 8 * r, j = j0 + tx;
+                if (i < d_in && j < j_hi) W[(int64_t)i * d_sae + j] = tile[tx][ty + 8 * r];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = big ? INFINITY : sq[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);           // the 32 lanes that share ty
+        const int j = j0 + ty + 8 * r;
+        if (tx == 0 && j < j_hi) colsq[j] = s;
     }
 }
 
 __global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                        float* __restrict__ M, float* __restrict__ V,
-                                                       const float* __restrict__ scalars, AdamC c, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                       const float* __restrict__ scalars, AdamC c, int lo, int hi) {
+    const int i = lo + blockIdx.x * 256 + threadIdx.x;
+    if (i >= hi) return;
     const float coef = clip_coef(scalars, c.max_norm);
     float m = M[i], v = V[i];
     W[i] = adam_update(W[i], G[i] * coef, m, v, c);
@@ -615,27 +692,22 @@ __global__ __launch_bounds__(256) void renorm_rows_kernel(float* __restrict__ W,
 
 }  // namespace
 
+void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
+                   const uint32_t* n_list, int slots, hipStream_t stream) {
+    hipLaunchKernelGGL(sae_topk_kernel, dim3(row_list ? slots : n_rows), dim3(256), 0, stream, hidden, idx_out, val_out, d_sae, k,
+                       row_list, n_list);
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan + C ABI
 // ------------------------------------------------------------------------------------------------
-struct pv_sae_plan {
-    pv_sae_desc d;
-};
-
-namespace {
-struct SaeWs {
-    size_t total;
-    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, pairs, colpart, colsum, batch_mean, sqpart;
-    int nblk64, sq_blocks;
-};
 SaeWs sae_carve(const pv_sae_desc& d) {
     SaeWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
     const size_t N = d.max_tokens;
-    w.nblk64 = (int)((N + 63) / 64);
     w.sq_blocks = 1024;
-    w.hidden = take(N * (size_t)d.d_sae * 4);
+    w.hidden = take(N * (size_t)d.d_sae * 4);        // exact path: hidden_pre; filtered path: rows of undecided tokens only
     w.sae_in = take(N * (size_t)d.d_in * 4);
     w.dY = take(N * (size_t)d.d_in * 4);
     w.mu = take(N * 4);
@@ -651,10 +723,20 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.colsum = take((size_t)d.d_in * 4);
     w.batch_mean = take((size_t)d.d_in * 4);
     w.sqpart = take((size_t)w.sq_blocks * 4);
+    w.x16 = take(N * (size_t)d.d_in * 2);
+    w.xnorm = take(N * 4);
+    w.sample = take(N * (size_t)(d.d_sae / PV_SAE_SAMPLE_STRIDE + 1) * 4);
+    w.thr = take(N * 4);
+    w.sq = take(N * 4);
+    w.band = take(N * 4);
+    w.cand_cnt = take(N * 4);
+    w.cand = take(N * (size_t)PV_SAE_CAND_CAP * 8);
+    w.fb_list = take(N * 4);
+    w.fb_count = take(256);
+    w.wmax = take(256);
     w.total = off + 256;
     return w;
 }
-}  // namespace
 
 extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan) {
     PV_REQUIRE(desc && out_plan, "null argument");
@@ -669,6 +751,18 @@ extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_pla
 }
 extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) { delete plan; }
 extern "C" size_t pv_sae_workspace_bytes(const pv_sae_plan* plan) { return plan ? sae_carve(plan->d).total : 0; }
+extern "C" int pv_sae_encoder_is_filtered(const pv_sae_plan* plan) { return plan && pv_sae_fast_ok(plan->d) ? 1 : 0; }
+// debug / tests: byte offset of a named region of the workspace ("fb_count": uint32 number of tokens of the last encode that
+// took the exact fallback; "cand_cnt": uint32 [N] candidates per token), or (size_t)-1
+extern "C" size_t pv_debug_sae_ws_offset(const pv_sae_plan* plan, const char* name) {
+    if (!plan || !name) return (size_t)-1;
+    const SaeWs w = sae_carve(plan->d);
+    if (!strcmp(name, "fb_count")) return w.fb_count;
+    if (!strcmp(name, "fb_list")) return w.fb_list;
+    if (!strcmp(name, "cand_cnt")) return w.cand_cnt;
+    if (!strcmp(name, "thr")) return w.thr;
+    return (size_t)-1;
+}
 
 #define DPL_DISPATCH(d_in, CALL)            \
     do {                                    \
@@ -689,9 +783,32 @@ extern "C" int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* 
     return PV_OK;
 }
 
+// Rebuild the encoder shadows for features [j_lo, j_hi).  from_transposed = 0: W_enc is the truth (parameters were edited
+// outside: load_state_dict, a fresh engine) -> W_encT, W_enc16T, enc_colsq; 1: W_encT is the truth (an all-gather of the
+// sharded optimizer's slices just landed) -> W_enc, W_enc16T, enc_colsq.
+extern "C" int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t from_transposed, int32_t j_lo, int32_t j_hi,
+                                   void* stream_) {
+    PV_REQUIRE(plan && st && st->W_enc && st->W_encT && st->W_enc16T && st->enc_colsq, "null argument");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(j_lo >= 0 && j_lo <= j_hi && j_hi <= d.d_sae, "feature range");
+    if (j_lo == j_hi) return PV_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((j_hi - j_lo + 31) / 32), block(256);
+    AdamC c = {};
+    if (from_transposed)
+        hipLaunchKernelGGL((wenc_rows_kernel<1>), grid, block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T, st->enc_colsq,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, c, d.d_in, d.d_sae, j_lo, j_hi);
+    else
+        hipLaunchKernelGGL((wenc_rows_kernel<2>), grid, block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T, st->enc_colsq,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, c, d.d_in, d.d_sae, j_lo, j_hi);
+    PV_LAUNCH_CHECK("wenc_rows_kernel");
+    return PV_OK;
+}
+
 static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
                            int32_t* topk_idx, float* topk_val, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
     const pv_sae_desc& d = plan->d;
+    const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     float* bmean = (float*)(wsb + ws.batch_mean);
     if (batch_mean) {
         PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
@@ -702,20 +819,23 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
     hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, st->b_dec, bmean,
-                       (float*)(wsb + ws.sae_in), (float*)(wsb + ws.mu), (float*)(wsb + ws.sd), (float*)(wsb + ws.norm), N,
-                       d.d_in, d.normalize_layer_norm, d.ln_eps);
+                       (float*)(wsb + ws.sae_in), fast ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
+                       fast ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
+                       (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps);
     PV_LAUNCH_CHECK("sae_prep_kernel");
+    // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
+    ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
+                   ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
+                       (fast ? 0.0 : (double)N * d.d_sae * 8.0));
+    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, wsb, ws, stream);
     {
-        // hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574); W_enc consumed in its own [d_in][d_sae] layout
-        ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
-                       ((double)N * d.d_in + (double)d.d_in * d.d_sae + (double)N * d.d_sae) * 4.0);
+        // exact path: hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574) on the fp32 MFMA, W_enc in its own [d_in][d_sae] layout
         GemmParams g = {};
         g.A = wsb + ws.sae_in; g.lda = d.d_in; g.a_mode = PV_A_PLAIN; g.Bt = st->W_enc; g.ldb = d.d_sae; g.b_kn = 1;
         g.M = N; g.N = d.d_sae; g.K = d.d_in; g.epi = PV_EPI_BIAS; g.bias0 = st->b_enc; g.out0 = wsb + ws.hidden; g.ldo = d.d_sae;
         int rc = pv_launch_gemm(PV_DTYPE_F32, g, stream);
         if (rc) return rc;
-        const float* hid = (const float*)(wsb + ws.hidden);
-        hipLaunchKernelGGL(sae_topk_kernel, dim3(N), dim3(256), 0, stream, hid, topk_idx, topk_val, d.d_sae, d.k);
+        sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, nullptr, nullptr, 0, stream);
     }
     PV_LAUNCH_CHECK("sae_topk_kernel");
     return PV_OK;
@@ -829,27 +949,56 @@ extern "C" int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* par
     return PV_OK;
 }
 
+// The same over the gradient rows of features [j_lo, j_hi) only (gW_enc^T, gW_dec, gb_enc slices; + gb_dec when
+// include_b_dec): the local term of the sharded optimizer's clip norm (the ranks' terms are summed by one scalar all-reduce).
+extern "C" int pv_sae_grad_sqnorm_rows(pv_sae_plan* plan, const pv_sae_state* st, int32_t j_lo, int32_t j_hi, int32_t include_b_dec,
+                                       float* partial, float* scalars, void* stream_) {
+    PV_REQUIRE(plan && st && partial && scalars && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "null argument");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(j_lo >= 0 && j_lo <= j_hi && j_hi <= d.d_sae, "feature range");
+    hipStream_t stream = (hipStream_t)stream_;
+    PV_HIP_CHECK(hipMemsetAsync(partial, 0, 1024 * 4, stream));
+    const int64_t nrow = (int64_t)(j_hi - j_lo) * d.d_in;
+    if (nrow > 0) {
+        PV_REQUIRE(((int64_t)j_lo * d.d_in) % 4 == 0, "slice must start on a 16-byte boundary");
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(384), dim3(256), 0, stream, (const float*)st->gW_enc + (int64_t)j_lo * d.d_in, nrow, partial);
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(384), dim3(256), 0, stream, (const float*)st->gW_dec + (int64_t)j_lo * d.d_in, nrow, partial + 384);
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(8), dim3(256), 0, stream, (const float*)st->gb_enc + j_lo, (int64_t)(j_hi - j_lo), partial + 768);
+    }
+    if (include_b_dec)
+        hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(8), dim3(256), 0, stream, (const float*)st->gb_dec, (int64_t)d.d_in, partial + 776);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3);
+    PV_LAUNCH_CHECK("sqnorm kernels");
+    return PV_OK;
+}
+
 extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* scalars, float max_grad_norm, float lr,
-                            int32_t step, void* stream_) {
+                            int32_t step, int32_t j_lo, int32_t j_hi, void* stream_) {
     PV_REQUIRE(plan && st && scalars && step >= 1, "null argument / step must be >= 1");
     PV_REQUIRE(st->mW_enc && st->mW_dec && st->mb_enc && st->mb_dec && st->vW_enc && st->vW_dec && st->vb_enc && st->vb_dec, "Adam state");
+    PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows");
     hipStream_t stream = (hipStream_t)stream_;
     const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(j_lo >= 0 && j_lo <= j_hi && j_hi <= d.d_sae, "feature range");
     AdamC c;
     c.lr = lr; c.b1 = 0.9f; c.b2 = 0.999f; c.eps = 1e-8f; c.max_norm = max_grad_norm;
     c.bc1 = (float)(1.0 - pow(0.9, (double)step));
     c.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, (double)step));
-    ProfScope prof(PV_PROF_SAE_APPLY, stream, 0.0, 7.0 * 4.0 * (2.0 * d.d_in * (double)d.d_sae + d.d_sae + d.d_in));
+    const int nj = j_hi - j_lo;
+    // algorithmic bytes: 7 x 4 per parameter (w, g, m, v read; w, m, v written) + the two extra copies of W_enc (fp32 + fp16)
+    ProfScope prof(PV_PROF_SAE_APPLY, stream, 0.0, 7.0 * 4.0 * (2.0 * d.d_in * (double)nj + nj + d.d_in) + 6.0 * d.d_in * (double)nj);
     const dim3 block(256);
-#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, d.d_sae, d.d_in)
-    DPL_DISPATCH(d.d_in, CALL);
+    if (nj > 0) {
+#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in)
+        DPL_DISPATCH(d.d_in, CALL);
 #undef CALL
-    hipLaunchKernelGGL(adam_wenc_kernel, dim3((d.d_sae + 31) / 32, (d.d_in + 31) / 32), block, 0, stream, st->W_enc,
-                       (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae);
-    hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
-                       st->mb_enc, st->vb_enc, scalars, c, d.d_sae);
+        hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
+                           st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi);
+        hipLaunchKernelGGL(adam_vec_kernel, dim3((nj + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
+                           st->mb_enc, st->vb_enc, scalars, c, j_lo, j_hi);
+    }
     hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, st->b_dec, (const float*)st->gb_dec,
-                       st->mb_dec, st->vb_dec, scalars, c, d.d_in);
+                       st->mb_dec, st->vb_dec, scalars, c, 0, d.d_in);
     PV_LAUNCH_CHECK("adam kernels");
     return PV_OK;
 }

@@ -1,0 +1,43 @@
+// Shared definitions of the SAE step (sae.hip: prep / decode / backward / Adam; sae_enc.hip: the encoder + top-k).
+#pragma once
+#include "gemm.hpp"
+#include "prof.hpp"
+
+constexpr int PV_SAE_MAXK = 64;
+constexpr int PV_SAE_SAMPLE_STRIDE = 16;     // pass 0 looks at every 16th feature
+constexpr int PV_SAE_CAND_CAP = 1024;        // candidate slots per token of the filter GEMM
+constexpr int PV_SAE_RESCORE_MAX = 192;      // candidates re-scored exactly per token (more -> exact fallback row)
+constexpr int PV_SAE_FB_SLOTS = 32;          // workgroup columns of the fallback kernels
+
+struct pv_sae_plan {
+    pv_sae_desc d;
+};
+
+struct SaeWs {
+    size_t total;
+    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, pairs, colpart, colsum, batch_mean, sqpart;
+    // fast encoder (sae_enc.hip)
+    size_t x16, xnorm, sample, thr, sq, band, cand_cnt, cand, fb_list, fb_count, wmax;
+    int sq_blocks;
+};
+SaeWs sae_carve(const pv_sae_desc& d);
+
+// number of sampled values per token that bound the k-th largest from below (order statistic taken in pass 0)
+static inline int pv_sae_sample_q(int k) { return k * 3 / 8 > 8 ? k * 3 / 8 : 8; }
+
+// Is the filtered (fp16 MFMA) encoder applicable to this plan?  Otherwise the exact-fp32 GEMM + streaming top-k runs.
+static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
+    return d.d_sae % 256 == 0 && d.d_sae >= 4096 && d.d_in % 8 == 0 && d.d_in >= 32 && d.k <= PV_SAE_MAXK &&
+           pv_sae_sample_q(d.k) * PV_SAE_SAMPLE_STRIDE * 2 <= PV_SAE_CAND_CAP && !g_pv_tuning.sae_exact;
+}
+
+// sae_enc.hip: hidden_pre top-k of N tokens through the fp16 filter GEMM + exact re-scoring (see the file header).
+// Requires the shadows (W_encT, W_enc16T, enc_colsq) of `st` to be current.  prep (sae.hip) has already filled sae_in,
+// x16, xnorm.  Rows the filter cannot decide are recomputed exactly (hidden scratch + sae_topk_rows).
+int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
+                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+
+// sae.hip: exact streaming / radix top-k of rows of `hidden`; row_list == nullptr: rows 0..n_rows-1 (one workgroup each),
+// else the rows row_list[0 .. *n_list) are walked by `slots` workgroups.
+void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
+                   const uint32_t* n_list, int slots, hipStream_t stream);

@@ -1,0 +1,525 @@
+// SAE encoder + TopK without materialising hidden_pre (gfx950).
+//
+// Reference semantics: hidden_pre = sae_in @ W_enc + b_enc (sae/sae.py:567-574), TopK keeps the k largest per token
+// (sae/sae.py:795-810).  Only k = 32 of the d_sae = 24 576 pre-activations of a token survive, so the [N, d_sae] fp32
+// matrix (403 MB at N = 4096) is never written.  Instead:
+//
+//   pass 0   filter GEMM on every 16th feature (fp16 MFMA, 1/16 of the work) -> sample [N, d_sae/16]
+//   thr      per token: s_q = q-th largest sampled value (q = 12 for k = 32).  Any q values bound the k-th largest of
+//            the full row from below unless q of the true top-k happen to sit in the sample (2e-7 per token), so
+//            T_n = s_q - 2 B_n is a threshold that ~16 q = 190 of the 24 576 values pass
+//   filter   the full encoder product on v_mfma_f32_32x32x16_f16 (operands rounded to fp16: a_j = approx hidden_pre,
+//            |a_j - exact| <= B_n, see below); the epilogue keeps no tile -- it appends (j, a_j) for a_j >= T_n to the
+//            token's candidate list (one atomic per hit, ~0.8 % of the elements)
+//   select   per token: t = k-th largest a; if t >= s_q every feature with a_j >= t - 2 B_n is in the list, and that set
+//            contains the exact top-k.  Those (~k + 7) candidates are re-scored EXACTLY in fp32 against a transposed
+//            fp32 copy of W_enc (coalesced 3 KB rows) and ranked by (value desc, index asc): index sets and values are
+//            those of the exact-fp32 path
+//   fallback tokens the filter cannot decide (t < s_q, list overflow = massive ties, > 192 candidates in the band,
+//            fp16 overflow) are recomputed exactly (fp32 row into the hidden scratch + the streaming / radix top-k of
+//            sae.hip).  Expected: none on ordinary data; everything on adversarial data; never a wrong answer.
+//
+// Error bound of the filter (x = sae_in row, w = W_enc column, K = d_in; fp16 has an 11-bit significand, u = 2^-11):
+//   |x.w - fl16(x).fl16(w)| <= (2u + u^2) sum|x_i w_i| + 2^-25 (sum|x_i| + sum|w_i|)      (operand rounding, subnormals)
+//   fp32 accumulation of exact products on the matrix core, and the fp32 re-scoring it is compared with:
+//                           <= 4 K 2^-24 sum|x_i w_i| + K 2^-24 sum|x_i w_i|
+//   => B_n = ||x_n||_2 (C1 Wmax + C2) + C2 Wmax,  C1 = 1.25e-3 >= 2^-10 (1 + 2^-12) + 5 K 2^-24 (K <= 1024),
+//      C2 = 2^-25 sqrt(K),  Wmax = max_j ||W_enc[:, j]||_2 (maintained by the Adam kernel as enc_colsq).
+// Rows with |x| beyond the fp16 range get B = inf (-> fallback); a weight beyond it makes its column norm inf (-> every
+// row falls back): slow, never wrong.
+#include "sae.hpp"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct EncParams {
+    const void* A;            // [M][lda] fp16
+    const void* B;            // fp16 rows; row of output column c starts at B + c * ldb_bytes
+    const float* bias;        // bias of column c = bias[c * bias_stride]
+    int32_t M, N, K, lda;
+    uint32_t ldb_bytes, b_span;
+    int32_t bias_stride;
+    float* out;               // MODE 0: [M][ldo] fp32 (sample)
+    int32_t ldo;
+    const float* thr;         // MODE 1: [M] thresholds
+    uint32_t* cnt;            //         [M] candidate counters
+    int2* cand;               //         [M][cap] (feature, bits of a)
+    int32_t cap;
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter GEMM: the v7 mainloop of gemm.hip (one 8-wave workgroup per CU, 256 x 256 tile, 64-byte K slabs DMA'd into a
+// 4-slot LDS ring three slabs ahead, counted vmcnt across a raw s_barrier) on fp16 operands, with an epilogue that
+// stores nothing but the hits.  MODE 0: plain fp32 store of acc + bias (the sample of pass 0).
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p) {
+    constexpr int MB = 4, TM = 64 * MB, TN = 256;
+    constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring3[SLOT];
+    __shared__ __attribute__((aligned(16))) float trow[512];
+    __shared__ uint32_t hit_n;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // tile order as in gemm_kernel_v7: column blocks of <= 8 N-tiles, M-major inside (a block's weight panel -- 8 x 256 rows
+    // x K fp16 = 3 MB at K = 768 -- stays in the XCD's L2 while the token rows stream past)
+    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    const int blk = swz / (ntm * wblk);
+    const int rem = swz - blk * (ntm * wblk);
+    const int wcur = min(wblk, ntn - blk * wblk);
+    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    const unsigned Kb = (unsigned)p.K * 2u;
+    const int nk = (int)((Kb + 63) / 64);
+    const bool ktail = (Kb % 64) != 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_span, 0x00020000);
+
+    unsigned offA[2], kcA[2], offB[2], kcB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 16 + (lane >> 2);
+        const int kc = (lane & 3) ^ ((row >> 2) & 3);
+        kcA[j] = kcB[j] = kc * 16;
+        offA[j] = (unsigned)(m0 + row) * (unsigned)p.lda * 2u + kc * 16;       // rows >= M land past the descriptor: zero fill
+        offB[j] = (n0 + row < p.N) ? (unsigned)(n0 + row) * p.ldb_bytes + kc * 16 : 0xffffff00u;
+    }
+    auto issue = [&](int kt, unsigned char* slot) {
+        const unsigned kbase = (unsigned)kt * 64;
+        const bool dead = kt >= nk;
+        // (selects only: a branch around an LDS-DMA makes hipcc drain the queue before the next ds_read)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = offA[j] + kbase;
+            o = (dead | (ktail & (kbase + kcA[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned o = offB[j] + kbase;
+            o = (dead | (offB[j] == 0xffffff00u) | (ktail & (kbase + kcB[j] >= Kb))) ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
+    const int a_row = (wm * 32 * MB + l31) * 64;
+    const int b_row = A_BYTES + (wn * 64 + l31) * 64;
+    auto compute = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = j == 0 ? co0 : co1;
+            uint4 a[MB], b[2];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) a[mi] = *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + co);
+            b[0] = *reinterpret_cast<const uint4*>(slot + b_row + co);
+            b[1] = *reinterpret_cast<const uint4*>(slot + b_row + 2048 + co);
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8, a[mi]), __builtin_bit_cast(f16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    // epilogue operands in flight before the K loop: this lane's two bias values and (MODE 1) the tile's 256 thresholds,
+    // DMA'd into LDS (they are the oldest entries of the vmcnt queue, so the first counted wait retires them)
+    const int colb = n0 + wn * 64 + l31;
+    float bias[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bias[ni] = (colb + ni * 32 < p.N) ? p.bias[(int64_t)(colb + ni * 32) * p.bias_stride] : 0.0f;
+    if constexpr (MODE == 1) {
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.thr), 0, p.M * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)(trow + wave * 64), 4, (unsigned)(m0 + wave * 64 + lane) * 4u, 0, 0, 0);
+    }
+
+    // step kt: slab kt must have landed -- the 8 DMA instructions of slabs kt+1, kt+2 may stay in flight
+#define PV_ENC_STEP(KT, CUR, NXT3)                 \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);        \
+    __builtin_amdgcn_s_barrier();                  \
+    issue((KT) + 3, NXT3);                         \
+    compute(CUR);
+
+    issue(0, ring0);
+    issue(1, ring1);
+    issue(2, ring2);
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+        PV_ENC_STEP(kt, ring0, ring3)
+        PV_ENC_STEP(kt + 1, ring1, ring0)
+        PV_ENC_STEP(kt + 2, ring2, ring1)
+        PV_ENC_STEP(kt + 3, ring3, ring2)
+    }
+    if (kt < nk) { PV_ENC_STEP(kt, ring0, ring3) }
+    if (kt + 1 < nk) { PV_ENC_STEP(kt + 1, ring1, ring0) }
+    if (kt + 2 < nk) { PV_ENC_STEP(kt + 2, ring2, ring1) }
+#undef PV_ENC_STEP
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches (and the threshold DMA)
+    __syncthreads();
+
+    const int rows_left = p.M - (m0 + wm * 32 * MB);       // local row r of this wave's block is real iff r < rows_left
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (row < rows_left) {
+                    float* o = p.out + (int64_t)(m0 + wm * 32 * MB + row) * p.ldo + colb;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        if (colb + ni * 32 < p.N) o[ni * 32] = acc[mi][ni][e] + bias[ni];
+                }
+            }
+    } else {
+        // Hits are ~0.8 % of the tile.  A returning global atomic per hit would serialise a ~1 us round trip behind every
+        // register that has one, so the hits are first compacted into LDS (the ring is free now) with no global round trip:
+        // per 32-row block a lane builds the bitmap of its 32 accumulators, a wave scan + ONE LDS atomic per wave hands out
+        // list positions, the set bits are written as (row, column, value).  Then the list is flushed: one global atomic
+        // per hit, all of them in flight at once.  A tile with more than HCAP hits (massive ties) marks the rows of the
+        // surplus as overflowed (bit 31 of their counter): those tokens take the exact path.
+        constexpr int HCAP = SLOT / 8;
+        uint2* hlist = reinterpret_cast<uint2*>(ring0);
+        if (tid == 0) hit_n = 0u;
+        __syncthreads();
+        const float* trw = trow + wm * 32 * MB;
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            uint32_t m = 0;                                        // bit (g * 8 + s * 2 + ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = mi * 32 + 8 * g + 4 * half;
+                const float4 t4 = *reinterpret_cast<const float4*>(trw + r0);
+                const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const bool hit = (r0 + s < rows_left) && (acc[mi][ni][4 * g + s] + bias[ni] >= tt[s]);
+                        m |= (hit ? 1u : 0u) << (g * 8 + s * 2 + ni);
+                    }
+            }
+            if (__ballot(m != 0u) == 0ull) continue;               // (wave-uniform)
+            const int nh = __popc(m);
+            int incl = nh;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            uint32_t base = 0;
+            if (lane == 63) base = atomicAdd(&hit_n, (uint32_t)incl);
+            base = __shfl(base, 63, 64);
+            uint32_t pos = base + (uint32_t)(incl - nh);
+            if (m != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            if (m & (1u << (g * 8 + s * 2 + ni))) {
+                                const int lrow = wm * 32 * MB + mi * 32 + 8 * g + 4 * half + s;
+                                if (pos < (uint32_t)HCAP)
+                                    hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
+                                                            __float_as_uint(acc[mi][ni][4 * g + s] + bias[ni]));
+                                else
+                                    atomicOr(&p.cnt[m0 + lrow], 0x80000000u);
+                                ++pos;
+                            }
+                        }
+            }
+        }
+        __syncthreads();
+        const uint32_t nhit = min(hit_n, (uint32_t)HCAP);
+        for (uint32_t e = tid; e < nhit; e += 512) {
+            const uint2 h = hlist[e];
+            const int grow = m0 + (int)(h.x >> 8), gcol = n0 + (int)(h.x & 255u);
+            const uint32_t gp = atomicAdd(&p.cnt[grow], 1u);
+            if (gp < (uint32_t)p.cap) p.cand[(int64_t)grow * p.cap + gp] = make_int2(gcol, (int)h.y);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// thr: q-th largest of a token's sampled values, band and threshold.  One wave per token.
+// ---------------------------------------------------------------------------------------------------
+constexpr float ENC_C1 = 1.25e-3f;
+
+__global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
+                                                      const float* __restrict__ wmax_sq, int qsel, int d_in, float* __restrict__ thr,
+                                                      float* __restrict__ sq_out, float* __restrict__ band, uint32_t* __restrict__ cand_cnt,
+                                                      int n_tok) {
+    constexpr int VPL = 32;                                   // ns <= 2048
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    const float* s = sample + (int64_t)n * ns;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < ns ? s[c] : -INFINITY;
+        v[i] = (v[i] == v[i]) ? v[i] : -INFINITY;             // NaN never bounds anything
+    }
+    float m = -INFINITY;
+    for (int rnd = 0; rnd < qsel; ++rnd) {
+        float lm = v[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i) lm = fmaxf(lm, v[i]);
+        m = wave_max(lm);
+        const unsigned long long owners = __ballot(lm == m);
+        const int owner = __ffsll((long long)owners) - 1;
+        if (lane == owner) {                                  // remove ONE instance (multiplicity counts)
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const bool hit = !done && v[i] == m;
+                v[i] = hit ? -INFINITY : v[i];
+                done = done || hit;
+            }
+        }
+    }
+    if (lane == 0) {
+        const float wmx = sqrtf(*wmax_sq);
+        const float c2 = 2.98023224e-8f * sqrtf((float)d_in);
+        const float B = xnorm[n] * (ENC_C1 * wmx + c2) + c2 * wmx + 4.8e-7f * fabsf(m);
+        sq_out[n] = m;
+        band[n] = 2.0f * B;
+        thr[n] = m - 2.0f * B;
+        cand_cnt[n] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict__ colsq, int d_sae, float* __restrict__ out,
+                                                        uint32_t* __restrict__ fb_count) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int j = threadIdx.x; j < d_sae; j += 1024) {
+        const float c = colsq[j];
+        m = (c == c) ? fmaxf(m, c) : INFINITY;                // a NaN column norm poisons the bound (-> exact fallback)
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        for (int w = 1; w < 16; ++w) r = fmaxf(r, red[w]);
+        *out = r;
+        *fb_count = 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// select: candidates -> exact top-k.  One workgroup per token.
+// ---------------------------------------------------------------------------------------------------
+template <int DPL>
+__global__ __launch_bounds__(256) void sae_select_kernel(
+    const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
+    const uint32_t* __restrict__ cand_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
+    const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
+    uint32_t* __restrict__ fb_count, int d, int k, int cap) {
+    __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
+    __shared__ int32_t cidx[PV_SAE_CAND_CAP];
+    __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
+    __shared__ float rval[PV_SAE_RESCORE_MAX];
+    __shared__ uint32_t sh_t, sh_nr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const uint32_t n = cand_cnt[row];
+    bool bad = n > (uint32_t)cap || n < (uint32_t)k;
+    const uint32_t nc = min(n, (uint32_t)cap);
+    for (uint32_t c = tid; c < nc; c += 256) {
+        const int2 e = cand[row * cap + c];
+        ckey[c] = f2ord(__int_as_float(e.y));
+        cidx[c] = e.x;
+    }
+    if (tid == 0) { sh_t = 0u; sh_nr = 0u; }
+    __syncthreads();
+    if (!bad) {
+        for (uint32_t c = tid; c < nc; c += 256) {
+            const uint32_t kc = ckey[c];
+            const int32_t ic = cidx[c];
+            uint32_t rank = 0;
+            for (uint32_t o = 0; o < nc; ++o) {
+                const uint32_t ko = ckey[o];
+                rank += (ko > kc) || (ko == kc && cidx[o] < ic);
+            }
+            if (rank == (uint32_t)(k - 1)) sh_t = kc;
+        }
+    }
+    __syncthreads();
+    const float t = ord2f(sh_t);
+    bad = bad || !(t >= sq[row]);                              // band below t not guaranteed to be in the list (or NaN)
+    const float lo = t - band[row];
+    if (!bad) {
+        for (uint32_t c = tid; c < nc; c += 256) {
+            if (ord2f(ckey[c]) >= lo) {
+                const uint32_t pos = atomicAdd(&sh_nr, 1u);
+                if (pos < (uint32_t)PV_SAE_RESCORE_MAX) ridx[pos] = cidx[c];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nr = sh_nr;
+    bad = bad || nr > (uint32_t)PV_SAE_RESCORE_MAX;
+    if (bad) {                                                 // (uniform over the workgroup)
+        if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
+        return;
+    }
+    // exact fp32 re-scoring: a wave per candidate, two candidates in flight
+    float xr[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int c = lane + 64 * i;
+        xr[i] = c < d ? sae_in[row * d + c] : 0.f;
+    }
+    for (uint32_t c = wave; c < nr; c += 8) {
+        const uint32_t c2 = c + 4;
+        const int j0 = ridx[c], j1 = c2 < nr ? ridx[c2] : ridx[c];
+        const float* w0 = W_encT + (int64_t)j0 * d;
+        const float* w1 = W_encT + (int64_t)j1 * d;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int col = lane + 64 * i;
+            if (col < d) {
+                a0 = fmaf(xr[i], w0[col], a0);
+                a1 = fmaf(xr[i], w1[col], a1);
+            }
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+            rval[c] = a0 + b_enc[j0];
+            if (c2 < nr) rval[c2] = a1 + b_enc[j1];
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < nr; c += 256) {
+        const float vc = rval[c];
+        const int32_t ic = ridx[c];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < nr; ++o) {
+            const float vo = rval[o];
+            rank += (vo > vc) || (vo == vc && ridx[o] < ic);
+        }
+        if (rank < (uint32_t)k) {
+            idx_out[row * k + rank] = ic;
+            val_out[row * k + rank] = fmaxf(vc, 0.f);          // postact_fn = ReLU (sae.py:806)
+        }
+    }
+}
+
+// exact fp32 hidden_pre rows of the tokens the filter could not decide -> hidden scratch
+__global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restrict__ sae_in, const float* __restrict__ W_enc,
+                                                            const float* __restrict__ b_enc, const int32_t* __restrict__ fb_list,
+                                                            const uint32_t* __restrict__ fb_count, float* __restrict__ hidden,
+                                                            int d, int d_sae) {
+    __shared__ float xs[1024];
+    const uint32_t nfb = *fb_count;
+    const int j = (blockIdx.y * 256 + threadIdx.x) * 4;
+    for (uint32_t s = blockIdx.x; s < nfb; s += gridDim.x) {
+        const int64_t row = fb_list[s];
+        __syncthreads();
+        for (int i = threadIdx.x; i < d; i += 256) xs[i] = sae_in[row * d + i];
+        __syncthreads();
+        if (j < d_sae) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < d; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(W_enc + (int64_t)i * d_sae + j);
+                const float x = xs[i];
+                a.x = fmaf(x, w.x, a.x); a.y = fmaf(x, w.y, a.y); a.z = fmaf(x, w.z, a.z); a.w = fmaf(x, w.w, a.w);
+            }
+            const float4 b = *reinterpret_cast<const float4*>(b_enc + j);
+            *reinterpret_cast<float4*>(hidden + row * d_sae + j) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+    }
+}
+
+int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
+    const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+    const dim3 grid(ntm * ntn), block(512);
+    if (mode == 0) hipLaunchKernelGGL((sae_enc_gemm_kernel<0>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((sae_enc_gemm_kernel<1>), grid, block, 0, stream, p);
+    PV_LAUNCH_CHECK("sae_enc_gemm_kernel");
+    return PV_OK;
+}
+
+}  // namespace
+
+int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
+                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+    PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
+    const int S = PV_SAE_SAMPLE_STRIDE, ns = d.d_sae / S, q = pv_sae_sample_q(d.k);
+    float* wmax = (float*)(wsb + ws.wmax);
+    uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
+    int32_t* fb_list = (int32_t*)(wsb + ws.fb_list);
+    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count);
+    EncParams p = {};
+    p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
+    // pass 0: every S-th feature
+    p.B = st->W_enc16T; p.N = ns; p.ldb_bytes = (uint32_t)S * d.d_in * 2u; p.b_span = (uint32_t)ns * p.ldb_bytes;
+    p.bias = st->b_enc; p.bias_stride = S; p.out = (float*)(wsb + ws.sample); p.ldo = ns;
+    int rc = launch_enc_gemm(0, p, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sae_thr_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,
+                       (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq),
+                       (float*)(wsb + ws.band), (uint32_t*)(wsb + ws.cand_cnt), N);
+    PV_LAUNCH_CHECK("sae_thr_kernel");
+    // filter: all features
+    p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes; p.bias_stride = 1;
+    p.out = nullptr; p.thr = (const float*)(wsb + ws.thr); p.cnt = (uint32_t*)(wsb + ws.cand_cnt); p.cand = (int2*)(wsb + ws.cand);
+    p.cap = PV_SAE_CAND_CAP;
+    rc = launch_enc_gemm(1, p, stream);
+    if (rc) return rc;
+#define CALL(D)                                                                                                             \
+    hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
+                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
+                       (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
+                       topk_val, fb_list, fb_count, d.d_in, d.k, PV_SAE_CAND_CAP)
+    if (d.d_in <= 64 * 4) { CALL(4); } else if (d.d_in <= 64 * 12) { CALL(12); } else { CALL(16); }
+#undef CALL
+    PV_LAUNCH_CHECK("sae_select_kernel");
+    // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)
+    hipLaunchKernelGGL(sae_fb_hidden_kernel, dim3(PV_SAE_FB_SLOTS, (d.d_sae + 1023) / 1024), dim3(256), 0, stream,
+                       (const float*)(wsb + ws.sae_in), (const float*)st->W_enc, (const float*)st->b_enc, (const int32_t*)fb_list,
+                       (const uint32_t*)fb_count, (float*)(wsb + ws.hidden), d.d_in, d.d_sae);
+    PV_LAUNCH_CHECK("sae_fb_hidden_kernel");
+    sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, fb_list, fb_count, PV_SAE_FB_SLOTS, stream);
+    return PV_OK;
+}

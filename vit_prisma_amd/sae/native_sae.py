@@ -1,13 +1,20 @@
 """Host driver of the native SAE train step (pv_sae_* in include/pv_native.h).
 
 All state lives in caller-owned torch tensors (plumbing): fp32 master parameters are the SAE
-module's own ``nn.Parameter`` storage, gradients sit in ONE flat buffer (so the data-parallel
-all-reduce and the clip-norm pass are one call each), Adam moments in two flat buffers.
+module's own ``nn.Parameter`` storage, gradients sit in ONE flat buffer
+``[gW_enc^T | gW_dec | gb_enc | gb_dec]`` (feature-indexed rows first: a rank's optimizer shard is a
+contiguous row range of each segment), Adam moments in two flat buffers of the same layout.
+
+``W_enc`` additionally lives as ``W_encT`` (its fp32 transpose -- the layout the sparse backward
+writes gradients in, Adam runs in and the exact re-scoring gathers rows from) and ``W_enc16T``
+(fp16, the B operand of the filter GEMM); ``pv_sae_apply`` keeps all of them in step, and an edit of
+the parameter from outside (``load_state_dict``, ``sae.W_enc.data.copy_``) is detected through the
+tensor version counter and answered with ``pv_sae_sync_shadows``.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -26,11 +33,14 @@ class NativeSAE:
         assert tuple(W_dec.shape) == (self.d_sae, self.d_in)
         self.k = int(k)
         self.max_tokens = int(max_tokens)
-        self.params = dict(W_enc=W_enc, W_dec=W_dec, b_enc=b_enc, b_dec=b_dec)
+        # the tensors whose version counters tell about outside edits (nn.Parameters when the trainer passes them)
+        self._src = dict(W_enc=W_enc, W_dec=W_dec, b_enc=b_enc, b_dec=b_dec)
+        self.params = {n: t.detach() for n, t in self._src.items()}
         desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
                          max_tokens=self.max_tokens, ln_eps=ln_eps)
         self._plan = C.c_void_p()
         N.check(self.lib.pv_sae_plan_create(C.byref(desc), C.byref(self._plan)), "pv_sae_plan_create")
+        self.filtered_encoder = bool(self.lib.pv_sae_encoder_is_filtered(self._plan))
         dev = self.device
         nW = self.d_in * self.d_sae
         self.n_flat = 2 * nW + self.d_sae + self.d_in
@@ -39,18 +49,26 @@ class NativeSAE:
         self.flat_m = torch.zeros(self.n_flat, **f32)
         self.flat_v = torch.zeros(self.n_flat, **f32)
 
-        def views(flat: torch.Tensor, enc_transposed: bool) -> Dict[str, torch.Tensor]:
+        def views(flat: torch.Tensor) -> Dict[str, torch.Tensor]:
             o = 0
             out = {}
-            out["W_enc"] = flat[o:o + nW].view((self.d_sae, self.d_in) if enc_transposed else (self.d_in, self.d_sae)); o += nW
+            out["W_encT"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["W_dec"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["b_enc"] = flat[o:o + self.d_sae]; o += self.d_sae
             out["b_dec"] = flat[o:o + self.d_in]
             return out
 
-        self.g = views(self.flat_g, True)        # NB: g["W_enc"] is the TRANSPOSED gradient [d_sae, d_in]
-        self.m = views(self.flat_m, False)
-        self.v = views(self.flat_v, False)
+        def param_layout(v: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+            return dict(W_enc=v["W_encT"].t(), W_dec=v["W_dec"], b_enc=v["b_enc"], b_dec=v["b_dec"])
+
+        self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
+        # views in the parameters' own layouts (W_enc: a transposed, non-contiguous view)
+        self.g = dict(W_enc=self._g["W_encT"], W_dec=self._g["W_dec"], b_enc=self._g["b_enc"], b_dec=self._g["b_dec"])   # NB: g["W_enc"] is TRANSPOSED
+        self.m, self.v = param_layout(self._m), param_layout(self._v)
+        # encoder shadows
+        self.W_encT = torch.empty(self.d_sae, self.d_in, **f32)
+        self.W_enc16T = torch.empty(self.d_sae, self.d_in, dtype=torch.float16, device=dev)
+        self.enc_colsq = torch.zeros(self.d_sae, **f32)
         self.act_freq_scores = torch.zeros(self.d_sae, **f32)
         self.n_fwd_since_fired = torch.zeros(self.d_sae, **f32)
         self.fire_count = torch.zeros(self.d_sae, **f32)
@@ -61,6 +79,8 @@ class NativeSAE:
         self.sae_out = torch.zeros(self.max_tokens, self.d_in, **f32)
         self.workspace = torch.empty(self.lib.pv_sae_workspace_bytes(self._plan), dtype=torch.uint8, device=dev)
         self.adam_step = 0
+        self._shadow_key: Optional[Tuple[int, int]] = None
+        self.sync_shadows()
 
     def __del__(self):
         try:
@@ -72,13 +92,14 @@ class NativeSAE:
 
     # ------------------------------------------------------------------------------------------
     def _state(self) -> N.SaeState:
-        P, g, m, v = self.params, self.g, self.m, self.v
+        P, g, m, v = self.params, self._g, self._m, self._v
         return N.SaeState(
             W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(), b_dec=P["b_dec"].data_ptr(),
-            gW_enc=g["W_enc"].data_ptr(), gW_dec=g["W_dec"].data_ptr(), gb_enc=g["b_enc"].data_ptr(), gb_dec=g["b_dec"].data_ptr(),
-            mW_enc=m["W_enc"].data_ptr(), mW_dec=m["W_dec"].data_ptr(), mb_enc=m["b_enc"].data_ptr(), mb_dec=m["b_dec"].data_ptr(),
-            vW_enc=v["W_enc"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
-            act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr())
+            gW_enc=g["W_encT"].data_ptr(), gW_dec=g["W_dec"].data_ptr(), gb_enc=g["b_enc"].data_ptr(), gb_dec=g["b_dec"].data_ptr(),
+            mW_enc=m["W_encT"].data_ptr(), mW_dec=m["W_dec"].data_ptr(), mb_enc=m["b_enc"].data_ptr(), mb_dec=m["b_dec"].data_ptr(),
+            vW_enc=v["W_encT"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
+            act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr(),
+            W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(), enc_colsq=self.enc_colsq.data_ptr())
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -91,6 +112,25 @@ class NativeSAE:
             raise ValueError(f"expected [N<={self.max_tokens}, {self.d_in}] on {self.device}, got {tuple(x.shape)} on {x.device}")
         return x
 
+    # ---- encoder shadows -------------------------------------------------------------------------
+    def _w_enc_key(self) -> Tuple[int, int]:
+        t = self._src["W_enc"]
+        return (t.data_ptr(), t._version)
+
+    def sync_shadows(self, from_transposed: bool = False, j_lo: int = 0, j_hi: Optional[int] = None) -> None:
+        """Rebuild W_encT / W_enc16T / enc_colsq from W_enc (default), or W_enc / W_enc16T / enc_colsq from W_encT."""
+        st = self._state()
+        N.check(self.lib.pv_sae_sync_shadows(self._plan, C.byref(st), int(from_transposed), int(j_lo),
+                                             int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_sync_shadows")
+        self._shadow_key = self._w_enc_key()
+
+    def _ensure_shadows(self) -> None:
+        """An in-place edit of W_enc from outside (optimizer.step() of another trainer, load_state_dict, .copy_) bumps
+        the tensor's version counter; the library's own updates go through raw pointers and do not."""
+        if self._shadow_key != self._w_enc_key():
+            self.sync_shadows()
+
+    # ---- the step ----------------------------------------------------------------------------------
     def renorm_decoder(self) -> None:
         st = self._state()
         N.check(self.lib.pv_sae_renorm_decoder(self._plan, C.byref(st), self._stream()), "pv_sae_renorm_decoder")
@@ -100,6 +140,7 @@ class NativeSAE:
         """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
         loss, mse_loss, l0 (device)."""
         x = self._check_x(x)
+        self._ensure_shadows()
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=self.topk_idx.data_ptr(),
@@ -116,16 +157,25 @@ class NativeSAE:
         N.check(self.lib.pv_sae_grad_sqnorm(self.flat_g.data_ptr(), self.n_flat, self.sq_partial.data_ptr(),
                                             self.scalars.data_ptr(), self._stream()), "pv_sae_grad_sqnorm")
 
-    def apply(self, lr: float, max_grad_norm: Optional[float]) -> None:
+    def grad_sqnorm_rows(self, j_lo: int, j_hi: int, include_b_dec: bool) -> None:
+        """scalars[3] = sum of squares of the gradient rows of features [j_lo, j_hi) (+ gb_dec): one rank's term."""
+        st = self._state()
+        N.check(self.lib.pv_sae_grad_sqnorm_rows(self._plan, C.byref(st), int(j_lo), int(j_hi), int(include_b_dec),
+                                                 self.sq_partial.data_ptr(), self.scalars.data_ptr(), self._stream()),
+                "pv_sae_grad_sqnorm_rows")
+
+    def apply(self, lr: float, max_grad_norm: Optional[float], j_lo: int = 0, j_hi: Optional[int] = None) -> None:
+        """clip -> project -> Adam for the features [j_lo, j_hi) (default: all) and b_dec."""
         self.adam_step += 1
         st = self._state()
         N.check(self.lib.pv_sae_apply(self._plan, C.byref(st), self.scalars.data_ptr(),
                                       float(max_grad_norm) if max_grad_norm else -1.0, float(lr), self.adam_step,
-                                      self._stream()), "pv_sae_apply")
+                                      int(j_lo), int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_apply")
 
     def encode_topk(self, x: torch.Tensor):
         """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts."""
         x = self._check_x(x)
+        self._ensure_shadows()
         n = x.shape[0]
         st = self._state()
         mu = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -145,4 +195,11 @@ class NativeSAE:
 
     def grad_W_enc(self) -> torch.Tensor:
         """Gradient of W_enc in the parameter's own [d_in, d_sae] layout (a transposed view)."""
-        return self.g["W_enc"].t()
+        return self._g["W_encT"].t()
+
+    def fallback_rows(self) -> int:
+        """Tokens of the last encode the filter could not decide (recomputed exactly); a device read-back, for tests."""
+        if not self.filtered_encoder:
+            return 0
+        off = self.lib.pv_debug_sae_ws_offset(self._plan, b"fb_count")
+        return int(self.workspace[off:off + 4].view(torch.int32).item())

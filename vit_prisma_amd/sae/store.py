@@ -40,8 +40,7 @@ class VisionActivationsStore:
         self.cfg = cfg
         self.model = model.to(cfg.device)
         self.dataset = dataset
-        if hasattr(self.model, "freeze_native_weights"):
-            self.model.freeze_native_weights(True)          # the ViT is constant while harvesting
+        self.n_tokens_harvested = 0                          # rows written into buffers so far (bench: harvested / trained)
         rank, world = _dist_info()
         sampler = None
         if world > 1:
@@ -111,11 +110,24 @@ class VisionActivationsStore:
         n_layers = len(self._layers())
         ctx = cfg.context_size
         buf = torch.zeros((total, ctx, n_layers, cfg.d_in), dtype=cfg.dtype, device=cfg.device)
-        for start in range(0, total, bs):
-            acts = self.get_activations(next(self.image_dataloader_iter))
-            if cfg.use_patches_only:
-                acts = acts[:, 1:, :, :]
-            buf[start:start + bs, : acts.shape[1]] = acts
+        # the ViT is constant while one buffer is harvested: skip the per-call weight-version compare inside this loop
+        # only (an edit of the model between buffers is picked up by the next one)
+        freeze = getattr(self.model, "freeze_native_weights", None)
+        was_frozen = bool(getattr(self.model, "_native_frozen", False))
+        if freeze is not None:
+            freeze(True)
+        try:
+            for start in range(0, total, bs):
+                acts = self.get_activations(next(self.image_dataloader_iter))
+                if cfg.use_patches_only:
+                    acts = acts[:, 1:, :, :]
+                # the reference's assignment (activations_store.py:345): a [bs, 1, L, d] CLS-only harvest broadcasts over
+                # context_size, any other token-count mismatch raises
+                buf[start:start + bs, ...] = acts
+                self.n_tokens_harvested += bs * ctx
+        finally:
+            if freeze is not None:
+                freeze(was_frozen)
         buf = buf.reshape(-1, n_layers, cfg.d_in)
         return buf[torch.randperm(buf.shape[0], device=buf.device)]
 

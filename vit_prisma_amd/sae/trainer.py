@@ -12,9 +12,20 @@ in the engine.  Everything else (ReLU+L1, gated, ghost grads, CPU) takes the PyT
 is the reference algorithm verbatim.
 
 Data parallel (new functionality, SURVEY.md section 8e -- the reference is single-process): one process
-per GPU; per step ONE 768-float all-reduce (global batch mean for the loss normaliser) and ONE RCCL
-all-reduce of the flat 37.77 M-float gradient buffer, issued before the clip norm, which is therefore
-the GLOBAL gradient norm exactly as in a single process at the global batch size.
+per GPU, each with its share of the global token batch and a 1/W shard of the OPTIMIZER, by feature
+(rows j in [r d_sae/W, (r+1) d_sae/W) of W_enc^T, W_dec, b_enc -- contiguous slices of the flat buffers):
+
+    all-reduce     768 floats            global batch mean for the loss normaliser (sae.py:145), before the forward
+    reduce-scatter gW_enc^T, gW_dec, gb_enc   every rank receives the summed gradient rows of ITS features
+    all-reduce     gb_dec | fire counts | loss, mse, l0     one small bucket (768 + d_sae + 3 floats)
+    all-reduce     1 float               sum of the ranks' squared-norm terms: the clip norm is the GLOBAL gradient
+                                         norm exactly as in a single process (train_sae.py:394-397)
+    (local)        clip -> project -> Adam on the rank's rows only: the 1.06 GB / step optimizer pass shrinks by W
+    all-gather     W_enc^T, W_dec, b_enc rows    asynchronous: they ride RCCL's stream while this rank already harvests
+                                         the next batch; waited for at the start of the next step
+
+b_dec (768 floats) is updated redundantly and identically on every rank.  When d_sae is not divisible by 4 W the
+trainer falls back to one all-reduce of the flat gradient buffer and a replicated optimizer.
 """
 from __future__ import annotations
 
@@ -58,7 +69,15 @@ class VisionSAETrainer:
                                                             num_workers=0)
         self.checkpoint_thresholds = self.get_checkpoint_thresholds()
         self._engine = None
+        self._native_pref: Optional[bool] = None            # None = auto, True = native or raise, False = PyTorch path
+        self._pending = []                                  # in-flight parameter all-gathers of the sharded optimizer
+        self._small = None
         self.rank, self.world = _dist_info()
+
+    def use_native(self, flag: Optional[bool]) -> "VisionSAETrainer":
+        """True: the fused HIP step or an error; False: always the PyTorch path; None (default): native when supported."""
+        self._native_pref = flag
+        return self
 
     # ---- bookkeeping ------------------------------------------------------------------------------
     def get_checkpoint_thresholds(self) -> List[int]:
@@ -87,6 +106,12 @@ class VisionSAETrainer:
             from .geometric_median import compute_geometric_median
             acts = self.activations_store.storage_buffer.detach()[:, lid, :]
             medians[lid] = compute_geometric_median(acts, maxiter=200).median
+            if self.world > 1:
+                # every rank harvested different images: rank 0's median is THE initial b_dec (replicas must start equal)
+                import torch.distributed as dist
+                med = medians[lid].to(cfg.device).contiguous()
+                dist.broadcast(med, src=0)
+                medians[lid] = med
             self.sparse_coder.initialize_b_dec_with_precalculated(medians[lid])
         elif cfg.b_dec_init_method == "mean":
             acts = self.activations_store.storage_buffer.detach()[:, lid, :]
@@ -109,17 +134,61 @@ class VisionSAETrainer:
                 and all(p.is_cuda and p.dtype == torch.float32 for p in sae.parameters())
                 and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 32768
                 and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
-                and os.environ.get("PV_SAE_NATIVE", "1") != "0")
+                and self._native_pref is not False)
 
     def _get_engine(self, sae, n_tokens: int):
         from .native_sae import NativeSAE
         eng = self._engine
-        if eng is None or eng.max_tokens < n_tokens or eng.params["W_enc"].data_ptr() != sae.W_enc.data_ptr():
-            eng = NativeSAE(sae.W_enc.data, sae.W_dec.data, sae.b_enc.data, sae.b_dec.data,
+        stale = eng is not None and any(eng.params[n].data_ptr() != getattr(sae, n).data_ptr()
+                                        for n in ("W_enc", "W_dec", "b_enc", "b_dec"))     # e.g. b_dec.data re-bound by an init
+        if eng is None or eng.max_tokens < n_tokens or stale:
+            if self.world > 1:
+                # replicas must start from identical parameters (a per-rank b_dec initialisation, a different seed or a
+                # caller-supplied module would otherwise never converge: every rank applies the same summed gradient)
+                import torch.distributed as dist
+                for p in sae.parameters():
+                    dist.broadcast(p.data, src=0)
+            old = eng
+            eng = NativeSAE(sae.W_enc, sae.W_dec, sae.b_enc, sae.b_dec,
                             k=sae.cfg.activation_fn_kwargs["k"], layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world))
+            if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
+                eng.flat_m.copy_(old.flat_m)
+                eng.flat_v.copy_(old.flat_v)
+                eng.adam_step = old.adam_step
             self._engine = eng
         return eng
+
+    # ---- data-parallel plumbing ----------------------------------------------------------------------
+    def _shard(self, d_sae: int):
+        """This rank's feature rows, or None when the optimizer cannot be sharded evenly on 16-byte boundaries."""
+        if self.world == 1 or d_sae % (4 * self.world) != 0:
+            return None
+        n = d_sae // self.world
+        return self.rank * n, (self.rank + 1) * n
+
+    def _dp_flush(self) -> None:
+        """Wait for the parameter all-gathers of the previous step and rebuild the other ranks' rows of W_enc / W_enc16T."""
+        if not self._pending:
+            return
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        eng = self._engine
+        j_lo, j_hi = self._shard(eng.d_sae)
+        eng.sync_shadows(from_transposed=True, j_lo=0, j_hi=j_lo)
+        eng.sync_shadows(from_transposed=True, j_lo=j_hi, j_hi=eng.d_sae)
+
+    @staticmethod
+    def _reduce_scatter_rows(dist, seg: torch.Tensor, j_lo: int, j_hi: int) -> None:
+        """seg[j_lo:j_hi] <- sum over ranks; the other rows are left undefined."""
+        mine = seg[j_lo:j_hi]
+        if dist.get_backend() == "nccl":
+            dist.reduce_scatter_tensor(mine, seg)                   # in place: output = this rank's chunk of the input
+        else:
+            out = torch.empty_like(mine)                            # gloo (tests): no aliasing guarantees
+            dist.reduce_scatter_tensor(out, seg)
+            mine.copy_(out)
 
     # ---- one step ---------------------------------------------------------------------------------
     def train_step(self, sparse_autoencoder, optimizer, scheduler, act_freq_scores, n_forward_passes_since_fired,
@@ -136,17 +205,24 @@ class VisionSAETrainer:
             act_freq_scores = torch.zeros(hp.d_sae, device=hp.device)
             n_frac_active_tokens = 0
 
-        if self._native_ok(sparse_autoencoder, sae_in):
+        native = self._native_ok(sparse_autoencoder, sae_in)
+        if self._native_pref is True and not native:
+            from .._native import NativeError
+            raise NativeError("use_native(True): this SAE configuration / input is not served by the fused HIP step "
+                              f"(activation {hp.activation_fn_str!r}, architecture {getattr(hp, 'architecture', 'standard')!r}, "
+                              f"device {sae_in.device})")
+        if native:
             loss, mse_loss, l1_loss, l0 = self._native_step(sparse_autoencoder, optimizer, scheduler, sae_in,
                                                             act_freq_scores, n_forward_passes_since_fired)
         else:
             loss, mse_loss, l1_loss, l0 = self._torch_step(sparse_autoencoder, optimizer, scheduler, sae_in,
                                                            act_freq_scores, n_forward_passes_since_fired)
         n_frac_active_tokens += sae_in.shape[0] * self.world
-        self.last_step_native = self._native_ok(sparse_autoencoder, sae_in)
+        self.last_step_native = native
         return loss, mse_loss, l1_loss, l0, act_freq_scores, n_forward_passes_since_fired, n_frac_active_tokens
 
     def _native_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
+        self._dp_flush()                                        # parameters of the previous step must have landed
         eng = self._get_engine(sae, x.shape[0])
         lr = optimizer.param_groups[0]["lr"]
         # statistics tensors are the caller's: the kernels update them in place
@@ -155,26 +231,53 @@ class VisionSAETrainer:
         eng.renorm_decoder()                                    # set_decoder_norm_to_unit_norm
         if self.world == 1:
             eng.step(x, update_stats=True)
+            eng.grad_sqnorm()                                   # clip_grad_norm_
+            eng.apply(lr, self.cfg.max_grad_norm)
         else:
-            import torch.distributed as dist
-            n_global = x.shape[0] * self.world
-            bm = x.float().sum(dim=0)
-            dist.all_reduce(bm)                                 # global batch mean (sae.py:145)
-            eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False)
-            dist.all_reduce(eng.flat_g)                         # one RCCL all-reduce of all four gradients
-            dist.all_reduce(eng.fire_count)
-            dist.all_reduce(eng.scalars[:3])
-            eng.scalars[2] /= self.world                        # l0 is a mean over tokens
-            fired = eng.fire_count > 0                          # train_sae.py:356-361 on the global batch
-            n_since_fired += 1
-            n_since_fired[fired] = 0
-            act_freq_scores += eng.fire_count
-        eng.grad_sqnorm()                                       # clip_grad_norm_ over the (global) gradient
-        eng.apply(lr, self.cfg.max_grad_norm)
+            self._native_dp_step(eng, sae, x, lr, act_freq_scores, n_since_fired)
         optimizer._opt_called = True                            # the native apply IS the optimizer step
         scheduler.step()
         sc = eng.scalars.clone()
         return sc[0], sc[1], None, sc[2]
+
+    def _native_dp_step(self, eng, sae, x, lr, act_freq_scores, n_since_fired):
+        import torch.distributed as dist
+        W = self.world
+        n_global = x.shape[0] * W
+        bm = x.float().sum(dim=0)
+        dist.all_reduce(bm)                                     # global batch mean (sae.py:145)
+        eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False)
+        shard = self._shard(eng.d_sae)
+        d_in, d_sae = eng.d_in, eng.d_sae
+        if self._small is None or self._small.numel() != d_in + d_sae + 3:
+            self._small = torch.empty(d_in + d_sae + 3, dtype=torch.float32, device=x.device)
+        small = self._small
+        small[:d_in].copy_(eng._g["b_dec"])
+        small[d_in:d_in + d_sae].copy_(eng.fire_count)
+        small[d_in + d_sae:].copy_(eng.scalars[:3])
+        if shard is None:
+            dist.all_reduce(eng.flat_g[:eng.n_flat - d_in])      # replicated optimizer: every rank needs every row
+        else:
+            for name in ("W_encT", "W_dec", "b_enc"):
+                self._reduce_scatter_rows(dist, eng._g[name], *shard)
+        dist.all_reduce(small)                                  # gb_dec | fire counts | loss, mse, l0 in one bucket
+        eng._g["b_dec"].copy_(small[:d_in])
+        fire = small[d_in:d_in + d_sae]
+        eng.scalars[:3].copy_(small[d_in + d_sae:])
+        eng.scalars[2] /= W                                     # l0 is a mean over tokens
+        n_since_fired += 1                                      # train_sae.py:356-361 on the global batch
+        n_since_fired[fire > 0] = 0
+        act_freq_scores += fire
+        if shard is None:
+            eng.grad_sqnorm()
+            eng.apply(lr, self.cfg.max_grad_norm)
+            return
+        j_lo, j_hi = shard
+        eng.grad_sqnorm_rows(j_lo, j_hi, include_b_dec=self.rank == 0)
+        dist.all_reduce(eng.scalars[3:4])                       # the clip norm is over the GLOBAL gradient
+        eng.apply(lr, self.cfg.max_grad_norm, j_lo, j_hi)       # this rank's rows (+ b_dec, identically everywhere)
+        self._pending = [dist.all_gather_into_tensor(full, full[j_lo:j_hi], async_op=True)
+                         for full in (eng.W_encT, eng.params["W_dec"], eng.params["b_enc"])]
 
     def _torch_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
         """The reference algorithm on PyTorch autograd (CPU, ReLU/L1, ghost grads, ...)."""
@@ -183,11 +286,18 @@ class VisionSAETrainer:
         dead = (n_since_fired > sae.cfg.dead_feature_window).bool()
         sae_out, feature_acts, loss, mse_loss, l1_loss, ghost, aux = sae(x, dead)
         with torch.no_grad():
-            did_fire = (feature_acts > 0).float().sum(-2) > 0
-            n_since_fired += 1
-            n_since_fired[did_fire] = 0
-            act_freq_scores += (feature_acts.abs() > 0).float().sum(0)
+            fire = (feature_acts.abs() > 0).float().sum(0)
+            pos = (feature_acts > 0).float().sum(-2)
             l0 = (feature_acts > 0).float().sum(-1).mean()
+            if self.world > 1:                                   # statistics are over the GLOBAL batch, like the native path
+                import torch.distributed as dist
+                dist.all_reduce(fire)
+                dist.all_reduce(pos)
+                dist.all_reduce(l0)
+                l0 = l0 / self.world
+            n_since_fired += 1
+            n_since_fired[pos > 0] = 0
+            act_freq_scores += fire
         loss.backward()
         if self.world > 1:
             import torch.distributed as dist
@@ -211,6 +321,7 @@ class VisionSAETrainer:
                     "sparsity/below_1e-6": (feature_sparsity < 1e-6).float().mean().item()}, step=n_training_steps)
 
     def checkpoint(self, sae, n_training_tokens, act_freq_scores, n_frac_active_tokens):
+        self._dp_flush()
         if self.rank != 0:
             return
         folder = self.cfg.checkpoint_path
@@ -254,6 +365,7 @@ class VisionSAETrainer:
                 if n_training_steps % 50 == 0:        # .item() syncs the stream: keep it off the hot loop
                     pbar.set_description(f"Training SAE: Loss: {float(loss):.4f}, MSE Loss: {float(mse_loss):.4f}, "
                                          f"L0: {float(l0):.4f}", refresh=False)
+        self._dp_flush()
         if cfg.n_checkpoints:
             self.checkpoint(self.sparse_coder, n_training_tokens, act_freq_scores, n_frac_active_tokens)
         if pbar is not None:
