@@ -200,6 +200,7 @@ def _dp_gpu_worker(rank, world, port, q):
             n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
         losses.append(float(loss))
     assert tr._engine is not None, "the native engine did not run"
+    tr.sync_parameters()                                          # the last step's all-gather lands here
     # the bench legs a rank of the scaling run executes (tiny step counts: this is a does-it-complete check)
     from vit_prisma_amd.sae.bench_leg import sae_bench_leg, sae_end_to_end_leg
     leg = sae_bench_leg(dev, dist=dist, steps=2, warmup=1)
@@ -214,9 +215,10 @@ def _dp_gpu_worker(rank, world, port, q):
 @pytest.mark.timeout(900)
 def test_native_data_parallel_world2_equals_single_process_oracle():
     """The multi-GPU path on real kernels: two ranks (sharing the one GPU of the test box, gloo collectives) each take
-    half of every 256-token batch through VisionSAETrainer's native step -- global batch mean pre-reduction, ONE
-    all-reduce of the flat gradient buffer, global clip, replicated Adam -- and must land on the oracle's
-    single-process parameters after three steps.  The bench's DP legs must complete too."""
+    half of every 256-token batch through VisionSAETrainer's native step -- global batch mean pre-reduction,
+    reduce-scatter of the gradient rows, global clip norm from the ranks' terms, Adam on each rank's half of the
+    features, asynchronous all-gather of the parameters -- and must land on the oracle's single-process parameters
+    after three steps.  The bench's DP legs must complete too."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

@@ -1,5 +1,5 @@
-# round-2 GPU call 2: the rebuilt SAE step -- parity tests, step-only bench, kernel stats
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c2; rm -rf $O; mkdir -p $O
+# round-2 GPU call 3: the rebuilt SAE step -- parity tests, step-only bench, kernel stats
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c3; rm -rf $O; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests/test_native_sae_gpu.py -m gpu -x -q > $O/tests_sae.log 2>&1; echo "tests rc=$?" >> $O/tests_sae.log
 timeout 300 python -c "

@@ -9,11 +9,12 @@ from .activation_cache import ActivationCache
 from .configs import HookedViTConfig
 from .hook_points import HookPoint, LensHandle
 from .hooked_root_module import HookedRootModule
+from .compat import install_as
 from .vit import (Attention, Head, HookedViT, LayerNorm, LayerNormPre, MLP, PatchEmbedding, PosEmbedding,
                   TransformerBlock)
 
 __all__ = [
     "ActivationCache", "HookedViTConfig", "HookPoint", "LensHandle", "HookedRootModule", "HookedViT",
     "Attention", "Head", "LayerNorm", "LayerNormPre", "MLP", "PatchEmbedding", "PosEmbedding",
-    "TransformerBlock",
+    "TransformerBlock", "install_as",
 ]

@@ -56,18 +56,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         partial[(int64_t)blockIdx.x * d + c] = s;
     }
 }
-// stage 2: out[c] = scale * sum_blk partial[blk][c]; one wave per column group of 64, 4 partial streams per lane
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                           int nblk, int d, float scale) {
-    __shared__ float red[4][64];
+// stage 2: out[c] = scale * sum_blk partial[blk][c]; 64 columns per workgroup, 16 partial streams per column (the
+// 256 partial rows of a 4096-token batch are 16 loads per thread instead of a 64-deep serial chain)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int nblk, int d, float scale) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < d)
-        for (int b = part; b < nblk; b += 4) s += partial[(int64_t)b * d + c];
+        for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
     red[part][lane] = s;
     __syncthreads();
-    if (part == 0 && c < d) out[c] = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) * scale;
+    if (part == 0 && c < d) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][lane];        // fixed order
+        out[c] = t * scale;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,7 +291,14 @@ __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restri
 // ------------------------------------------------------------------------------------------------
 // decode + LN-out + loss partial + dY + dh    (one wave per token)
 // ------------------------------------------------------------------------------------------------
-template <int DPL>   // dims per lane: d_in <= 64 * DPL
+// A wave owns a token; lane l owns the 16-byte column groups 4 l + 256 i (i < V4: d_in <= 256 V4), so every gathered
+// W_dec row is fetched as V4 16-byte loads per lane (1 KiB per wave-instruction), four rows in flight.
+__device__ __forceinline__ float4 ld4(const float* p, bool ok) {
+    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+template <int V4>
 __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ x, const float* __restrict__ W_dec, const float* __restrict__ b_dec,
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ mu,
@@ -295,54 +308,79 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
-    float acc[DPL];
+    bool ok[V4];
+    int col[V4];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int c = lane + 64 * i;
-        acc[i] = 0.f;
-        (void)c;
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
     }
+    float4 acc[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* ir = idx + (int64_t)n * k;
     const float* vr = val + (int64_t)n * k;
-    for (int s = 0; s < k; ++s) {
-        const float a = vr[s];
-        const float* w = W_dec + (int64_t)ir[s] * d;
+    for (int s = 0; s < k; s += 4) {
+        float a[4];
+        float4 w[4][V4];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d) acc[i] += a * w[c];
+        for (int u = 0; u < 4; ++u) {
+            const int su = min(s + u, k - 1);
+            a[u] = s + u < k ? vr[su] : 0.f;
+            const float* wr = W_dec + (int64_t)ir[su] * d;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i]);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                       // (slot order, as torch's dense matmul would not care; fixed here)
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                acc[i].x += a[u] * w[u][i].x; acc[i].y += a[u] * w[u][i].y;
+                acc[i].z += a[u] * w[u][i].z; acc[i].w += a[u] * w[u][i].w;
+            }
     }
     const float m = mu[n], sdv = sd[n], nf = norm[n];
     float lsum = 0.f;
-    float g[DPL];
+    float4 g[V4];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int c = lane + 64 * i;
-        g[i] = 0.f;
-        if (c < d) {
-            const float o = (acc[i] + b_dec[c]) * sdv + m;        // decode (sae.py:583-595) + LN-out (:89-90)
-            const float e = o - x[(int64_t)n * d + c];
-            if (sae_out) sae_out[(int64_t)n * d + c] = o;
-            lsum += (e * e) / nf;                                 // sae.py:146-148
-            g[i] = grad_scale * e / nf * sdv;                     // dL/d(pre-LN-out reconstruction)
-            if (want_grad) dY[(int64_t)n * d + c] = g[i];
+    for (int i = 0; i < V4; ++i) {
+        g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[i]) {
+            const float4 bd = *reinterpret_cast<const float4*>(b_dec + col[i]);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + col[i]);
+            float4 o, e;
+            o.x = (acc[i].x + bd.x) * sdv + m; o.y = (acc[i].y + bd.y) * sdv + m;      // decode (sae.py:583-595) + LN-out (:89-90)
+            o.z = (acc[i].z + bd.z) * sdv + m; o.w = (acc[i].w + bd.w) * sdv + m;
+            e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
+            if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + col[i]) = o;
+            lsum += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;      // sae.py:146-148
+            g[i].x = grad_scale * e.x / nf * sdv; g[i].y = grad_scale * e.y / nf * sdv;            // dL/d(pre-LN-out reconstruction)
+            g[i].z = grad_scale * e.z / nf * sdv; g[i].w = grad_scale * e.w / nf * sdv;
+            if (want_grad) *reinterpret_cast<float4*>(dY + (int64_t)n * d + col[i]) = g[i];
         }
     }
     lsum = wave_sum(lsum);
     if (lane == 0) loss_partial[n] = lsum;
     if (!want_grad) return;
-    for (int s = 0; s < k; ++s) {
-        const float* w = W_dec + (int64_t)ir[s] * d;
-        float dot = 0.f;
+    for (int s = 0; s < k; s += 4) {
+        float dot[4];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d) dot += g[i] * w[c];
+        for (int u = 0; u < 4; ++u) {
+            const float* wr = W_dec + (int64_t)ir[min(s + u, k - 1)] * d;
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) t += dot4(g[i], ld4(wr + col[i], ok[i]));
+            dot[u] = t;
         }
-        dot = wave_sum(dot);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
         // TopK backward: gradient reaches only selected entries; ReLU gate on the kept value
-        if (lane == 0) dh[(int64_t)n * k + s] = vr[s] > 0.f ? dot : 0.f;
+        if (lane < 4 && s + lane < k) {
+            const float dsel = lane == 0 ? dot[0] : (lane == 1 ? dot[1] : (lane == 2 ? dot[2] : dot[3]));
+            dh[(int64_t)n * k + s + lane] = vr[s + lane] > 0.f ? dsel : 0.f;
+        }
     }
 }
 
@@ -364,18 +402,20 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restric
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < n_pairs && val[p] > 0.f) atomicAdd(&cnt[idx[p]], 1u);
 }
-// single-workgroup exclusive scan over d_sae counts (d_sae ~ 25k: 96 per thread)
+// single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
+// contiguous runs scanned out of LDS, shuffles across threads, coalesced store of offs / cursor
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ cursor, int d_sae, float* __restrict__ scalars,
                                                         float inv_tokens) {
+    __shared__ uint32_t buf[32768];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < d_sae; i += 1024) buf[i] = cnt[i];
+    __syncthreads();
     const int per = (d_sae + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, d_sae);
     uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += cnt[i];
-    // inclusive scan of the 1024 per-thread sums: shuffles inside a wave, 16 wave totals through LDS (one barrier
-    // instead of the 20 of a Hillis-Steele scan over LDS)
+    for (int i = lo; i < hi; ++i) s += buf[i];
     uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -388,12 +428,17 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
     for (int w = 0; w < wv; ++w) base += wsum[w];
     uint32_t total = 0;
     for (int w = 0; w < 16; ++w) total += wsum[w];
-    uint32_t part_tid = base + inc;                 // inclusive prefix of this thread
-    uint32_t run = part_tid - s;
+    uint32_t run = base + inc - s;                  // exclusive prefix of this thread's run
     for (int i = lo; i < hi; ++i) {
-        offs[i] = run;
-        cursor[i] = run;
-        run += cnt[i];
+        const uint32_t c = buf[i];
+        buf[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < d_sae; i += 1024) {
+        const uint32_t o = buf[i];
+        offs[i] = o;
+        cursor[i] = o;
     }
     if (tid == 1023) {
         offs[d_sae] = total;
@@ -415,7 +460,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int BWD_CH = 16;
 
-template <int DPL>
+template <int V4>
 __global__ __launch_bounds__(256) void sae_backward_kernel(
     const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
     const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
@@ -426,27 +471,35 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     const uint32_t q0 = (uint32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * BWD_CH;
     if (q0 >= n_active) return;
     const uint32_t q1 = min(q0 + BWD_CH, n_active);
-    float gd[DPL], ge[DPL];
+    bool ok[V4];
+    int col[V4];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) { gd[i] = 0.f; ge[i] = 0.f; }
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+    }
+    float4 gd[V4], ge[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) { gd[i] = make_float4(0.f, 0.f, 0.f, 0.f); ge[i] = gd[i]; }
     float gb = 0.f;
     int cur = idx[pairs[q0]];
     auto flush = [&](int j) {
         const bool whole = offs[j] >= q0 && offs[j + 1] <= q1;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d) {
+        for (int i = 0; i < V4; ++i) {
+            if (ok[i]) {
+                float* pd = gW_dec + (int64_t)j * d + col[i];
+                float* pe = gW_encT + (int64_t)j * d + col[i];
                 if (whole) {
-                    gW_dec[(int64_t)j * d + c] = gd[i];
-                    gW_encT[(int64_t)j * d + c] = ge[i];
+                    *reinterpret_cast<float4*>(pd) = gd[i];
+                    *reinterpret_cast<float4*>(pe) = ge[i];
                 } else {
-                    unsafeAtomicAdd(&gW_dec[(int64_t)j * d + c], gd[i]);
-                    unsafeAtomicAdd(&gW_encT[(int64_t)j * d + c], ge[i]);
+                    unsafeAtomicAdd(pd, gd[i].x); unsafeAtomicAdd(pd + 1, gd[i].y); unsafeAtomicAdd(pd + 2, gd[i].z); unsafeAtomicAdd(pd + 3, gd[i].w);
+                    unsafeAtomicAdd(pe, ge[i].x); unsafeAtomicAdd(pe + 1, ge[i].y); unsafeAtomicAdd(pe + 2, ge[i].z); unsafeAtomicAdd(pe + 3, ge[i].w);
                 }
             }
-            gd[i] = 0.f;
-            ge[i] = 0.f;
+            gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ge[i] = gd[i];
         }
         if (lane == 0) {
             if (whole) gb_enc[j] = gb;
@@ -454,26 +507,43 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
         }
         gb = 0.f;
     };
+    // two pairs in flight: the rows of pair q+1 are requested before pair q is accumulated
+    int32_t p = pairs[q0];
+    float4 dy[V4], si[V4];
+    {
+        const int n0 = p / k;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            dy[i] = ld4(dY + (int64_t)n0 * d + col[i], ok[i]);
+            si[i] = ld4(sae_in + (int64_t)n0 * d + col[i], ok[i]);
+        }
+    }
     for (uint32_t q = q0; q < q1; ++q) {
-        const int32_t p = pairs[q];
+        const int32_t pn = q + 1 < q1 ? pairs[q + 1] : p;
+        float4 dyn[V4], sin_[V4];
+        {
+            const int nn = pn / k;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                dyn[i] = ld4(dY + (int64_t)nn * d + col[i], ok[i]);
+                sin_[i] = ld4(sae_in + (int64_t)nn * d + col[i], ok[i]);
+            }
+        }
         const int j = idx[p];
         if (j != cur) {
             flush(cur);
             cur = j;
         }
-        const int n = p / k;
         const float a = val[p], g = dh[p];
-        const float* dy = dY + (int64_t)n * d;
-        const float* si = sae_in + (int64_t)n * d;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < d) {
-                gd[i] += a * dy[c];       // d loss / d W_dec[j, c]
-                ge[i] += g * si[c];       // d loss / d W_enc[c, j]
-            }
+        for (int i = 0; i < V4; ++i) {
+            gd[i].x += a * dy[i].x; gd[i].y += a * dy[i].y; gd[i].z += a * dy[i].z; gd[i].w += a * dy[i].w;      // d loss / d W_dec[j, :]
+            ge[i].x += g * si[i].x; ge[i].y += g * si[i].y; ge[i].z += g * si[i].z; ge[i].w += g * si[i].w;      // d loss / d W_enc[:, j]
         }
         gb += g;
+        p = pn;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) { dy[i] = dyn[i]; si[i] = sin_[i]; }
     }
     flush(cur);
 }
@@ -729,8 +799,9 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.thr = take(N * 4);
     w.sq = take(N * 4);
     w.band = take(N * 4);
-    w.cand_cnt = take(N * 4);
-    w.cand = take(N * (size_t)PV_SAE_CAND_CAP * 8);
+    const size_t ntn = (size_t)(d.d_sae + 255) / 256;
+    w.cand_cnt = take(N * ntn * 4);
+    w.cand = take(N * ntn * (size_t)PV_SAE_TILE_SLOTS * 8);
     w.fb_list = take(N * 4);
     w.fb_count = take(256);
     w.wmax = take(256);
@@ -769,6 +840,13 @@ extern "C" size_t pv_debug_sae_ws_offset(const pv_sae_plan* plan, const char* na
         if ((d_in) <= 64 * 4) { CALL(4); }  \
         else if ((d_in) <= 64 * 12) { CALL(12); } \
         else { CALL(16); }                  \
+    } while (0)
+// kernels whose lanes own 16-byte column groups: d_in <= 256 * V4
+#define V4_DISPATCH(d_in, CALL)             \
+    do {                                    \
+        if ((d_in) <= 256) { CALL(1); }     \
+        else if ((d_in) <= 768) { CALL(3); } \
+        else { CALL(4); }                   \
     } while (0)
 
 extern "C" int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream_) {
@@ -815,7 +893,7 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     } else {
         const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(256), 0, stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
     hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, st->b_dec, bmean,
@@ -889,7 +967,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                        (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)(wsb + ws.mu),      \
                        (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, dh,             \
                        (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1)
-        DPL_DISPATCH(d.d_in, CALL);
+        V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
         // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
@@ -919,7 +997,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const int32_t*)pairs, \
                        (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, (const float*)dY, \
                        (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae, d.d_in, k)
-        DPL_DISPATCH(d.d_in, CALL);
+        V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
         hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
@@ -927,7 +1005,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         // gb_dec = colsum(dY) - W_enc @ gb_enc
         const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(256), 0, stream,
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
                            (const float*)(wsb + ws.colpart), (float*)(wsb + ws.colsum), nblk, d.d_in, 1.0f);
         hipLaunchKernelGGL(sae_gbdec_kernel, dim3(d.d_in), dim3(256), 0, stream, (const float*)st->W_enc, (const float*)st->gb_enc,
                            (const float*)(wsb + ws.colsum), st->gb_dec, d.d_sae);

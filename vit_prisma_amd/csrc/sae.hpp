@@ -5,7 +5,8 @@
 
 constexpr int PV_SAE_MAXK = 64;
 constexpr int PV_SAE_SAMPLE_STRIDE = 16;     // pass 0 looks at every 16th feature
-constexpr int PV_SAE_CAND_CAP = 1024;        // candidate slots per token of the filter GEMM
+constexpr int PV_SAE_CAND_CAP = 1024;        // candidates of a token the select kernel can rank (more -> exact fallback row)
+constexpr int PV_SAE_TILE_SLOTS = 16;        // candidate slots per (token, 256-feature tile) of the filter GEMM
 constexpr int PV_SAE_RESCORE_MAX = 192;      // candidates re-scored exactly per token (more -> exact fallback row)
 constexpr int PV_SAE_FB_SLOTS = 32;          // workgroup columns of the fallback kernels
 

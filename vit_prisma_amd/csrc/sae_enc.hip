@@ -44,9 +44,8 @@ struct EncParams {
     float* out;               // MODE 0: [M][ldo] fp32 (sample)
     int32_t ldo;
     const float* thr;         // MODE 1: [M] thresholds
-    uint32_t* cnt;            //         [M] candidate counters
-    int2* cand;               //         [M][cap] (feature, bits of a)
-    int32_t cap;
+    uint32_t* cnt;            //         [M][ntn] hits of (token, N-tile); 0xffffffff = more than PV_SAE_TILE_SLOTS
+    int2* cand;               //         [M][ntn][PV_SAE_TILE_SLOTS] (feature, bits of a)
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -71,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
     __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
     __shared__ __attribute__((aligned(16))) unsigned char ring3[SLOT];
     __shared__ __attribute__((aligned(16))) float trow[512];
+    __shared__ uint32_t rowcnt[256];
     __shared__ uint32_t hit_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -206,15 +206,17 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                 }
             }
     } else {
-        // Hits are ~0.8 % of the tile.  A returning global atomic per hit would serialise a ~1 us round trip behind every
-        // register that has one, so the hits are first compacted into LDS (the ring is free now) with no global round trip:
-        // per 32-row block a lane builds the bitmap of its 32 accumulators, a wave scan + ONE LDS atomic per wave hands out
-        // list positions, the set bits are written as (row, column, value).  Then the list is flushed: one global atomic
-        // per hit, all of them in flight at once.  A tile with more than HCAP hits (massive ties) marks the rows of the
-        // surplus as overflowed (bit 31 of their counter): those tokens take the exact path.
+        // Hits are ~0.8 % of the tile (~2 per token row).  Nothing global is contended for them: every (token, N-tile) pair
+        // owns PV_SAE_TILE_SLOTS candidate slots and a count word that only this workgroup writes (a device-scope atomic
+        // per hit on per-token counters cost more than the whole K loop: ~0.8 M atomics per step queue up behind a few dozen
+        // memory channels).  The hits are compacted into LDS with no round trip -- per 32-row block a lane builds the
+        // bitmap of its 32 accumulators, a wave scan + ONE LDS atomic per wave hands out list positions -- then every
+        // list entry draws its slot from an LDS per-row counter and is stored.  Rows with more hits than slots (or a tile
+        // with more than HCAP hits: massive ties) are marked overflowed: those tokens take the exact path.
         constexpr int HCAP = SLOT / 8;
         uint2* hlist = reinterpret_cast<uint2*>(ring0);
         if (tid == 0) hit_n = 0u;
+        if (tid < 256) rowcnt[tid] = 0u;
         __syncthreads();
         const float* trw = trow + wm * 32 * MB;
 #pragma unroll
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                                     hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
                                                             __float_as_uint(acc[mi][ni][4 * g + s] + bias[ni]));
                                 else
-                                    atomicOr(&p.cnt[m0 + lrow], 0x80000000u);
+                                    atomicOr(&rowcnt[lrow], 0x80000000u);
                                 ++pos;
                             }
                         }
@@ -268,9 +270,15 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         const uint32_t nhit = min(hit_n, (uint32_t)HCAP);
         for (uint32_t e = tid; e < nhit; e += 512) {
             const uint2 h = hlist[e];
-            const int grow = m0 + (int)(h.x >> 8), gcol = n0 + (int)(h.x & 255u);
-            const uint32_t gp = atomicAdd(&p.cnt[grow], 1u);
-            if (gp < (uint32_t)p.cap) p.cand[(int64_t)grow * p.cap + gp] = make_int2(gcol, (int)h.y);
+            const int lrow = (int)(h.x >> 8);
+            const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
+            if (li < (uint32_t)PV_SAE_TILE_SLOTS)
+                p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * PV_SAE_TILE_SLOTS + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
+        }
+        __syncthreads();
+        if (tid < 256 && m0 + tid < p.M) {
+            const uint32_t c = rowcnt[tid];
+            p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)PV_SAE_TILE_SLOTS ? 0xffffffffu : c;
         }
     }
 }
@@ -282,8 +290,7 @@ constexpr float ENC_C1 = 1.25e-3f;
 
 __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
                                                       const float* __restrict__ wmax_sq, int qsel, int d_in, float* __restrict__ thr,
-                                                      float* __restrict__ sq_out, float* __restrict__ band, uint32_t* __restrict__ cand_cnt,
-                                                      int n_tok) {
+                                                      float* __restrict__ sq_out, float* __restrict__ band, int n_tok) {
     constexpr int VPL = 32;                                   // ns <= 2048
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -321,7 +328,6 @@ __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ 
         sq_out[n] = m;
         band[n] = 2.0f * B;
         thr[n] = m - 2.0f * B;
-        cand_cnt[n] = 0u;
     }
 }
 
@@ -347,28 +353,47 @@ __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // select: candidates -> exact top-k.  One workgroup per token.
 // ---------------------------------------------------------------------------------------------------
-template <int DPL>
+template <int V4>
 __global__ __launch_bounds__(256) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
-    const uint32_t* __restrict__ cand_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
+    const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
-    uint32_t* __restrict__ fb_count, int d, int k, int cap) {
+    uint32_t* __restrict__ fb_count, int d, int k, int ntn) {
     __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
     __shared__ float rval[PV_SAE_RESCORE_MAX];
-    __shared__ uint32_t sh_t, sh_nr;
+    __shared__ uint32_t tcnt[128];
+    __shared__ uint32_t sh_t, sh_nr, sh_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
-    const uint32_t n = cand_cnt[row];
-    bool bad = n > (uint32_t)cap || n < (uint32_t)k;
-    const uint32_t nc = min(n, (uint32_t)cap);
-    for (uint32_t c = tid; c < nc; c += 256) {
-        const int2 e = cand[row * cap + c];
-        ckey[c] = f2ord(__int_as_float(e.y));
-        cidx[c] = e.x;
+    // gather the token's candidates: ntn (<= 128) per-tile lists of <= PV_SAE_TILE_SLOTS entries
+    uint32_t myc = 0;
+    if (tid < ntn) myc = tile_cnt[row * ntn + tid];
+    if (tid < 128) tcnt[tid] = tid < ntn ? myc : 0u;
+    if (tid == 0) { sh_t = 0u; sh_nr = 0u; sh_bad = 0u; }
+    __syncthreads();
+    if (tid < ntn && myc == 0xffffffffu) sh_bad = 1u;
+    __syncthreads();
+    bool bad = sh_bad != 0u;
+    uint32_t n = 0, off = 0;
+    if (!bad) {
+        for (int t = 0; t < ntn; ++t) {
+            const uint32_t c = tcnt[t];
+            off += t < tid ? c : 0u;
+            n += c;
+        }
+        bad = n > (uint32_t)PV_SAE_CAND_CAP || n < (uint32_t)k;
     }
-    if (tid == 0) { sh_t = 0u; sh_nr = 0u; }
+    if (!bad && tid < ntn) {
+        const int2* src = cand + (row * ntn + tid) * PV_SAE_TILE_SLOTS;
+        for (uint32_t e = 0; e < myc; ++e) {
+            const int2 c = src[e];
+            ckey[off + e] = f2ord(__int_as_float(c.y));
+            cidx[off + e] = c.x;
+        }
+    }
+    const uint32_t nc = bad ? 0u : n;
     __syncthreads();
     if (!bad) {
         for (uint32_t c = tid; c < nc; c += 256) {
@@ -401,32 +426,43 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
         if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
         return;
     }
-    // exact fp32 re-scoring: a wave per candidate, two candidates in flight
-    float xr[DPL];
+    // exact fp32 re-scoring: a wave per candidate, four candidates (4 x V4 16-byte loads per lane) in flight
+    bool ok[V4];
+    int col[V4];
+    float4 xr[V4];
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int c = lane + 64 * i;
-        xr[i] = c < d ? sae_in[row * d + c] : 0.f;
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+        xr[i] = ok[i] ? *reinterpret_cast<const float4*>(sae_in + row * d + col[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (uint32_t c = wave; c < nr; c += 8) {
-        const uint32_t c2 = c + 4;
-        const int j0 = ridx[c], j1 = c2 < nr ? ridx[c2] : ridx[c];
-        const float* w0 = W_encT + (int64_t)j0 * d;
-        const float* w1 = W_encT + (int64_t)j1 * d;
-        float a0 = 0.f, a1 = 0.f;
+    for (uint32_t c0 = wave; c0 < nr; c0 += 16) {
+        int jj[4];
+        float acc[4];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int col = lane + 64 * i;
-            if (col < d) {
-                a0 = fmaf(xr[i], w0[col], a0);
-                a1 = fmaf(xr[i], w1[col], a1);
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + 4 * u;
+            jj[u] = ridx[c < nr ? c : c0];
+            const float* w = W_encT + (int64_t)jj[u] * d;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                if (ok[i]) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + col[i]);
+                    a = fmaf(xr[i].x, wv.x, a); a = fmaf(xr[i].y, wv.y, a); a = fmaf(xr[i].z, wv.z, a); a = fmaf(xr[i].w, wv.w, a);
+                }
             }
+            acc[u] = a;
         }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) {
-            rval[c] = a0 + b_enc[j0];
-            if (c2 < nr) rval[c2] = a1 + b_enc[j1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
+        if (lane < 4) {
+            const uint32_t c = c0 + 4 * lane;
+            const float av = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+            const int jv = lane == 0 ? jj[0] : (lane == 1 ? jj[1] : (lane == 2 ? jj[2] : jj[3]));
+            if (c < nr) rval[c] = av + b_enc[jv];
         }
     }
     __syncthreads();
@@ -499,20 +535,20 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     if (rc) return rc;
     hipLaunchKernelGGL(sae_thr_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,
                        (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq),
-                       (float*)(wsb + ws.band), (uint32_t*)(wsb + ws.cand_cnt), N);
+                       (float*)(wsb + ws.band), N);
     PV_LAUNCH_CHECK("sae_thr_kernel");
     // filter: all features
     p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes; p.bias_stride = 1;
     p.out = nullptr; p.thr = (const float*)(wsb + ws.thr); p.cnt = (uint32_t*)(wsb + ws.cand_cnt); p.cand = (int2*)(wsb + ws.cand);
-    p.cap = PV_SAE_CAND_CAP;
+    const int ntn = d.d_sae / 256;
     rc = launch_enc_gemm(1, p, stream);
     if (rc) return rc;
 #define CALL(D)                                                                                                             \
     hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
                        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
                        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
-                       topk_val, fb_list, fb_count, d.d_in, d.k, PV_SAE_CAND_CAP)
-    if (d.d_in <= 64 * 4) { CALL(4); } else if (d.d_in <= 64 * 12) { CALL(12); } else { CALL(16); }
+                       topk_val, fb_list, fb_count, d.d_in, d.k, ntn)
+    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
 #undef CALL
     PV_LAUNCH_CHECK("sae_select_kernel");
     // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)

@@ -56,8 +56,9 @@ class VisionActivationsStore:
         self.image_dataloader_iter = self._batch_stream(self.image_dataloader, cfg.device)
         if create_dataloader:
             if cfg.is_transcoder:
-                raise NotImplementedError("transcoder buffers are outside the MI355X hot path")
-            self.storage_buffer = self.get_buffer(cfg.n_batches_in_buffer)
+                self.storage_buffer, self.storage_buffer_out = self.get_buffer(cfg.n_batches_in_buffer)
+            else:
+                self.storage_buffer = self.get_buffer(cfg.n_batches_in_buffer)
             self.dataloader = self.get_data_loader()
 
     # ---- image streams ----------------------------------------------------------------------------
@@ -82,25 +83,38 @@ class VisionActivationsStore:
         return list(hl) if isinstance(hl, list) else [hl]
 
     @torch.no_grad()
-    def get_activations(self, batch_tokens: torch.Tensor) -> torch.Tensor:
-        """[B, ctx, n_layers, d_in] activations of the configured hook point(s)
-        (activations_store.py:251-296)."""
+    def get_activations(self, batch_tokens: torch.Tensor):
+        """[B, ctx, n_layers, d_in] activations of the configured hook point(s); for a transcoder the pair
+        (input hook point(s), output hook point(s)) harvested by ONE forward (activations_store.py:251-296)."""
         cfg = self.cfg
         layers = self._layers()
         if isinstance(cfg.hook_point_layer, list):
             names = [cfg.hook_point.format(layer=layer) for layer in layers]
         else:
             names = [cfg.hook_point]
-        _, cache = self.model.run_with_cache(batch_tokens, names_filter=names, stop_at_layer=max(layers) + 1)
-        acts = []
-        for name in names:
-            a = cache[name]
-            if cfg.hook_point_head_index is not None:
-                a = a[:, :, cfg.hook_point_head_index]
-            if cfg.cls_token_only:
-                a = a[:, 0:1]
-            acts.append(a)
-        return torch.stack(acts, dim=2)
+        out_names, stop = [], max(layers) + 1
+        if cfg.is_transcoder:
+            ol = cfg.out_hook_point_layer
+            out_layers = list(ol) if isinstance(ol, list) else [ol]
+            out_names = [cfg.out_hook_point] if not isinstance(ol, list) else [
+                f"blocks.{layer}.{cfg.layer_out_subtype}" for layer in out_layers]
+            stop = max(max(layers), max(out_layers)) + 1
+        _, cache = self.model.run_with_cache(batch_tokens, names_filter=names + out_names, stop_at_layer=stop)
+
+        def pick(which):
+            acts = []
+            for name in which:
+                a = cache[name]
+                if cfg.hook_point_head_index is not None:
+                    a = a[:, :, cfg.hook_point_head_index]
+                if cfg.cls_token_only:
+                    a = a[:, 0:1]
+                acts.append(a)
+            return torch.stack(acts, dim=2)
+
+        if cfg.is_transcoder:
+            return pick(names), pick(out_names)
+        return pick(names)
 
     def get_buffer(self, n_batches_in_buffer: int) -> torch.Tensor:
         """[bs * n_batches * ctx, n_layers, d_in], rows shuffled (activations_store.py:298-362)."""
@@ -110,6 +124,10 @@ class VisionActivationsStore:
         n_layers = len(self._layers())
         ctx = cfg.context_size
         buf = torch.zeros((total, ctx, n_layers, cfg.d_in), dtype=cfg.dtype, device=cfg.device)
+        buf_out = None
+        if cfg.is_transcoder:
+            ol = cfg.out_hook_point_layer
+            buf_out = torch.zeros((total, ctx, len(ol) if isinstance(ol, list) else 1, cfg.d_out), dtype=cfg.dtype, device=cfg.device)
         # the ViT is constant while one buffer is harvested: skip the per-call weight-version compare inside this loop
         # only (an edit of the model between buffers is picked up by the next one)
         freeze = getattr(self.model, "freeze_native_weights", None)
@@ -119,8 +137,14 @@ class VisionActivationsStore:
         try:
             for start in range(0, total, bs):
                 acts = self.get_activations(next(self.image_dataloader_iter))
+                acts_out = None
+                if cfg.is_transcoder:
+                    acts, acts_out = acts
                 if cfg.use_patches_only:
                     acts = acts[:, 1:, :, :]
+                    acts_out = acts_out[:, 1:, :, :] if acts_out is not None else None
+                if acts_out is not None:
+                    buf_out[start:start + bs, ...] = acts_out
                 # the reference's assignment (activations_store.py:345): a [bs, 1, L, d] CLS-only harvest broadcasts over
                 # context_size, any other token-count mismatch raises
                 buf[start:start + bs, ...] = acts
@@ -129,17 +153,31 @@ class VisionActivationsStore:
             if freeze is not None:
                 freeze(was_frozen)
         buf = buf.reshape(-1, n_layers, cfg.d_in)
-        return buf[torch.randperm(buf.shape[0], device=buf.device)]
+        perm = torch.randperm(buf.shape[0], device=buf.device)
+        if buf_out is not None:
+            return buf[perm], buf_out.reshape(-1, buf_out.shape[2], cfg.d_out)[perm]
+        return buf[perm]
 
     def get_data_loader(self) -> Iterator[Any]:
         """Mix a fresh half buffer into the stored one, keep half, serve the other half
-        (activations_store.py:445-492)."""
+        (activations_store.py:445-492).  Transcoder: input and target rows are shuffled together and served side by
+        side along dim 1 (``batch[:, 0]`` input, ``batch[:, 1]`` target; requires d_out == d_in like the reference's cat)."""
         cfg = self.cfg
-        mix = torch.cat([self.get_buffer(cfg.n_batches_in_buffer // 2), self.storage_buffer], dim=0)
-        mix = mix[torch.randperm(mix.shape[0], device=mix.device)]
-        half = mix.shape[0] // 2
-        self.storage_buffer = mix[:half]
-        serve = mix[half:]
+        if cfg.is_transcoder:
+            new, new_out = self.get_buffer(cfg.n_batches_in_buffer // 2)
+            mix = torch.cat([new, self.storage_buffer], dim=0)
+            mix_out = torch.cat([new_out, self.storage_buffer_out], dim=0)
+            perm = torch.randperm(mix.shape[0], device=mix.device)
+            mix, mix_out = mix[perm], mix_out[perm]
+            half = mix.shape[0] // 2
+            self.storage_buffer, self.storage_buffer_out = mix[:half], mix_out[:half]
+            serve = torch.cat([mix[half:], mix_out[half:]], dim=1)
+        else:
+            mix = torch.cat([self.get_buffer(cfg.n_batches_in_buffer // 2), self.storage_buffer], dim=0)
+            mix = mix[torch.randperm(mix.shape[0], device=mix.device)]
+            half = mix.shape[0] // 2
+            self.storage_buffer = mix[:half]
+            serve = mix[half:]
         _, world = _dist_info()
         local_bs = max(cfg.train_batch_size // world, 1)
         return iter(_TensorBatches(serve, local_bs))

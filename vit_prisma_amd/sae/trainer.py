@@ -54,16 +54,28 @@ class VisionSAETrainer:
                  activations_store=None):
         self.cfg = cfg
         self.is_transcoder = bool(getattr(cfg, "is_transcoder", False))
-        if self.is_transcoder or cfg.architecture != "standard":
-            raise NotImplementedError("only the standard SAE architecture is on the MI355X hot path")
         self.model = model
         self.dataset = dataset
         self.eval_dataset = eval_dataset
         self.bad_run_check = cfg.min_l0 is not None and cfg.min_explained_variance is not None
         torch.manual_seed(cfg.seed)
-        self.sparse_coder = sparse_coder if sparse_coder is not None else StandardSparseAutoencoder(cfg)
+        if sparse_coder is None:                          # train_sae.py:72-81
+            if self.is_transcoder:
+                from .variants import Transcoder
+                sparse_coder = Transcoder(cfg)
+            elif cfg.architecture == "gated":
+                from .variants import GatedSparseAutoencoder
+                sparse_coder = GatedSparseAutoencoder(cfg)
+            elif cfg.architecture in ("standard", "vanilla"):
+                sparse_coder = StandardSparseAutoencoder(cfg)
+            else:
+                raise ValueError(f"Loading of {cfg.architecture} not supported")
+        self.sparse_coder = sparse_coder
         self.sae = self.sparse_coder                      # legacy alias
         self.activations_store = activations_store
+        if self.activations_store is None and cfg.use_cached_activations and not self.is_transcoder:
+            from .store import CacheVisionActivationStore
+            self.activations_store = CacheVisionActivationStore(cfg)             # train_sae.py:138-139
         if self.activations_store is None and dataset is not None:
             self.activations_store = VisionActivationsStore(cfg, model, dataset, eval_dataset=eval_dataset,
                                                             num_workers=0)
@@ -106,13 +118,20 @@ class VisionSAETrainer:
             from .geometric_median import compute_geometric_median
             acts = self.activations_store.storage_buffer.detach()[:, lid, :]
             medians[lid] = compute_geometric_median(acts, maxiter=200).median
+            out_median = None
+            if self.is_transcoder:
+                acts_out = self.activations_store.storage_buffer_out.detach()[:, lid, :]
+                out_median = compute_geometric_median(acts_out, maxiter=200).median
             if self.world > 1:
                 # every rank harvested different images: rank 0's median is THE initial b_dec (replicas must start equal)
                 import torch.distributed as dist
                 med = medians[lid].to(cfg.device).contiguous()
                 dist.broadcast(med, src=0)
                 medians[lid] = med
-            self.sparse_coder.initialize_b_dec_with_precalculated(medians[lid])
+                if out_median is not None:
+                    out_median = out_median.to(cfg.device).contiguous()
+                    dist.broadcast(out_median, src=0)
+            self.sparse_coder.initialize_b_dec_with_precalculated(medians[lid], out_median)
         elif cfg.b_dec_init_method == "mean":
             acts = self.activations_store.storage_buffer.detach()[:, lid, :]
             if self.world > 1:
@@ -167,6 +186,13 @@ class VisionSAETrainer:
         n = d_sae // self.world
         return self.rank * n, (self.rank + 1) * n
 
+    def sync_parameters(self) -> None:
+        """Data parallel only: make the module's parameters complete on this rank.  ``train_step`` returns while the
+        all-gather of the other ranks' updated rows is still in flight (it overlaps the next harvest); the next
+        ``train_step``, ``checkpoint`` and the end of ``run`` wait for it themselves -- call this before reading
+        ``sae.W_enc`` / ``W_dec`` / ``b_enc`` in between."""
+        self._dp_flush()
+
     def _dp_flush(self) -> None:
         """Wait for the parameter all-gathers of the previous step and rebuild the other ranks' rows of W_enc / W_enc16T."""
         if not self._pending:
@@ -196,7 +222,11 @@ class VisionSAETrainer:
         hp = sparse_autoencoder.cfg
         layers = hp.hook_point_layer if isinstance(hp.hook_point_layer, list) else [hp.hook_point_layer]
         layer_id = 0 if isinstance(hp.hook_point_layer, list) else layers.index(hp.hook_point_layer)
-        sae_in = layer_acts[:, layer_id, :]
+        self._target = None
+        if self.is_transcoder:                                                   # train_sae.py:299-301
+            sae_in, self._target = layer_acts[:, 0, :], layer_acts[:, 1, :]
+        else:
+            sae_in = layer_acts[:, layer_id, :]
         sparse_autoencoder.train()
 
         if (n_training_steps + 1) % self.cfg.feature_sampling_window == 0:     # train_sae.py:310-326
@@ -284,7 +314,10 @@ class VisionSAETrainer:
         sae.set_decoder_norm_to_unit_norm()
         optimizer.zero_grad()
         dead = (n_since_fired > sae.cfg.dead_feature_window).bool()
-        sae_out, feature_acts, loss, mse_loss, l1_loss, ghost, aux = sae(x, dead)
+        if self.is_transcoder:
+            sae_out, feature_acts, loss, mse_loss, l1_loss, ghost, aux = sae(x, self._target, dead)
+        else:
+            sae_out, feature_acts, loss, mse_loss, l1_loss, ghost, aux = sae(x, dead)
         with torch.no_grad():
             fire = (feature_acts.abs() > 0).float().sum(0)
             pos = (feature_acts > 0).float().sum(-2)
