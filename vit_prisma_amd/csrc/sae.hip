@@ -147,25 +147,29 @@ constexpr int TOPK_CAP = 1024;   // candidate list capacity of the fast path
 // select that re-streams the row once per digit.
 // `row_list` != nullptr: the workgroups walk rows row_list[blockIdx.x], row_list[blockIdx.x + gridDim.x], ... (the tokens
 // the filtered encoder of sae_enc.hip could not decide); otherwise row = blockIdx.x.
+// `feat_cnt` / `wpos` (both or neither): every kept (token, slot) with a positive value draws its position inside its
+// feature's pair list from feat_cnt[feature] (zeroed by the caller) -- the CSR-by-feature of the backward then needs only
+// a scan and an atomic-free scatter.
 __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
-                             int d_sae, int k, int64_t row);
+                             int d_sae, int k, int64_t row, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos);
 
 __global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__ hidden, int32_t* __restrict__ idx_out,
                                                        float* __restrict__ val_out, int d_sae, int k,
-                                                       const int32_t* __restrict__ row_list, const uint32_t* __restrict__ n_list) {
+                                                       const int32_t* __restrict__ row_list, const uint32_t* __restrict__ n_list,
+                                                       uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos) {
     if (!row_list) {
-        sae_topk_row(hidden, idx_out, val_out, d_sae, k, blockIdx.x);
+        sae_topk_row(hidden, idx_out, val_out, d_sae, k, blockIdx.x, feat_cnt, wpos);
         return;
     }
     const uint32_t n = *n_list;
     for (uint32_t s = blockIdx.x; s < n; s += gridDim.x) {
         __syncthreads();
-        sae_topk_row(hidden, idx_out, val_out, d_sae, k, row_list[s]);
+        sae_topk_row(hidden, idx_out, val_out, d_sae, k, row_list[s], feat_cnt, wpos);
     }
 }
 
 __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
-                             int d_sae, int k, int64_t row) {
+                             int d_sae, int k, int64_t row, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_T0, sh_ncand, sh_prefix, sh_k, sh_wcnt[4];
     __shared__ uint32_t cand_key[TOPK_CAP];
@@ -215,8 +219,10 @@ __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restri
                 rank += (ko > kc) || (ko == kc && cand_idx[o] < ic);
             }
             if (rank < (uint32_t)k) {
+                const float v = fmaxf(h[ic], 0.f);                // postact_fn = ReLU (sae.py:806)
                 idx_out[row * k + rank] = ic;
-                val_out[row * k + rank] = fmaxf(h[ic], 0.f);      // postact_fn = ReLU (sae.py:806)
+                val_out[row * k + rank] = v;
+                if (feat_cnt) wpos[row * k + rank] = v > 0.f ? atomicAdd(&feat_cnt[ic], 1u) : 0xffffffffu;
             }
         }
         return;
@@ -282,8 +288,10 @@ __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restri
         if (key > prefix) slot = (int)pos_gt++;
         else if (key == prefix) { if (pos_eq < kk) slot = (int)(tot_gt + pos_eq); pos_eq++; }
         if (slot >= 0 && slot < k) {
+            const float v = fmaxf(h[c], 0.f);
             idx_out[row * k + slot] = c;
-            val_out[row * k + slot] = fmaxf(h[c], 0.f);
+            val_out[row * k + slot] = v;
+            if (feat_cnt) wpos[row * k + slot] = v > 0.f ? atomicAdd(&feat_cnt[c], 1u) : 0xffffffffu;
         }
     }
 }
@@ -397,16 +405,18 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // CSR by feature of the active (token, slot) pairs
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
-                                                        uint32_t* __restrict__ cnt, int n_pairs) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < n_pairs && val[p] > 0.f) atomicAdd(&cnt[idx[p]], 1u);
-}
 // single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
 // contiguous runs scanned out of LDS, shuffles across threads, coalesced store of offs / cursor
+// Also cuts the CSR-ordered pair sequence into the chunks the backward's waves own: nominally BWD_CH pairs each, but a cut
+// that would fall inside a SHORT list (<= BWD_LMAX pairs) moves forward to that list's end, so that only long lists are
+// ever shared between waves (those accumulate through atomics on rows zeroed by sae_rows_prep_kernel; every other
+// gradient row is written exactly once, by plain stores, by one wave).
+constexpr int BWD_CH = 16;
+constexpr int BWD_LMAX = 64;
+
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ cursor, int d_sae, float* __restrict__ scalars,
-                                                        float inv_tokens) {
+                                                        uint32_t* __restrict__ chunk_start, int max_chunks, int d_sae,
+                                                        float* __restrict__ scalars, float inv_tokens) {
     __shared__ uint32_t buf[32768];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -435,20 +445,32 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         run += c;
     }
     __syncthreads();
-    for (int i = tid; i < d_sae; i += 1024) {
-        const uint32_t o = buf[i];
-        offs[i] = o;
-        cursor[i] = o;
-    }
+    for (int i = tid; i < d_sae; i += 1024) offs[i] = buf[i];
     if (tid == 1023) {
         offs[d_sae] = total;
         if (scalars) scalars[2] = (float)total * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
     }
+    for (int w = tid; w <= max_chunks; w += 1024) {
+        const uint32_t g = (uint32_t)w * BWD_CH;
+        uint32_t sres = total;
+        if (g < total) {
+            int lo_j = 0, hi_j = d_sae;                                  // j = last feature with buf[j] <= g (the one holding pair g)
+            while (hi_j - lo_j > 1) {
+                const int mid = (lo_j + hi_j) >> 1;
+                if (buf[mid] <= g) lo_j = mid; else hi_j = mid;
+            }
+            const uint32_t beg = buf[lo_j], end = lo_j + 1 < d_sae ? buf[lo_j + 1] : total;
+            sres = (g == beg || end - beg > (uint32_t)BWD_LMAX) ? g : end;
+        }
+        chunk_start[w] = sres;
+    }
 }
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
-                                                       uint32_t* __restrict__ cursor, int32_t* __restrict__ pairs, int n_pairs) {
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
+                                                       const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int n_pairs) {
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < n_pairs && val[p] > 0.f) pairs[atomicAdd(&cursor[idx[p]], 1u)] = p;
+    if (p >= n_pairs) return;
+    const uint32_t w = wpos[p];
+    if (w != 0xffffffffu) pairs[offs[idx[p]] + w] = p;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,19 +480,17 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 // feature and flushes a row when the feature changes: plain stores when the feature's whole list lies
 // inside this wave's range, hardware float atomics otherwise (rows are zeroed beforehand).
 // ------------------------------------------------------------------------------------------------
-constexpr int BWD_CH = 16;
-
 template <int V4>
 __global__ __launch_bounds__(256) void sae_backward_kernel(
-    const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
-    const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
+    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
+    const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
     const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    int d_sae, int d, int k) {
+    int d_sae, int d, int k, int n_chunks) {
     const int lane = threadIdx.x & 63;
-    const uint32_t n_active = offs[d_sae];
-    const uint32_t q0 = (uint32_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * BWD_CH;
-    if (q0 >= n_active) return;
-    const uint32_t q1 = min(q0 + BWD_CH, n_active);
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_chunks) return;
+    const uint32_t q0 = chunk_start[wv], q1 = chunk_start[wv + 1];
+    if (q0 >= q1) return;
     bool ok[V4];
     int col[V4];
 #pragma unroll
@@ -548,17 +568,31 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     flush(cur);
 }
 
-// firing statistics per feature (train_sae.py:356-361) from the CSR offsets
-__global__ __launch_bounds__(256) void sae_stats_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
-                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
-                                                        int d_sae, int update_stats) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+// Per feature (one wave each): firing statistics (train_sae.py:356-361) from the CSR offsets, and zero gradient rows for
+// the features no backward wave will write -- the ones that did not fire (this IS their zero_grad) and the long-list ones
+// that several waves accumulate into with atomics.
+__global__ __launch_bounds__(256) void sae_rows_prep_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
+                                                            float* __restrict__ n_since_fired, float* __restrict__ fire_count,
+                                                            float* __restrict__ gW_dec, float* __restrict__ gW_encT,
+                                                            float* __restrict__ gb_enc, int d_sae, int d, int update_stats) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= d_sae) return;
-    const float cnt = (float)(offs[j + 1] - offs[j]);
-    if (fire_count) fire_count[j] = cnt;
-    if (update_stats) {
-        act_freq[j] += cnt;
-        n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
+    const uint32_t c = offs[j + 1] - offs[j];
+    if (lane == 0) {
+        const float cnt = (float)c;
+        if (fire_count) fire_count[j] = cnt;
+        if (update_stats) {
+            act_freq[j] += cnt;
+            n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
+        }
+    }
+    if (c == 0u || c > (uint32_t)BWD_LMAX) {
+        for (int col = 4 * lane; col < d; col += 256) {
+            *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (lane == 0) gb_enc[j] = 0.f;
     }
 }
 
@@ -763,9 +797,9 @@ __global__ __launch_bounds__(256) void renorm_rows_kernel(float* __restrict__ W,
 }  // namespace
 
 void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
-                   const uint32_t* n_list, int slots, hipStream_t stream) {
+                   const uint32_t* n_list, int slots, uint32_t* feat_cnt, uint32_t* wpos, hipStream_t stream) {
     hipLaunchKernelGGL(sae_topk_kernel, dim3(row_list ? slots : n_rows), dim3(256), 0, stream, hidden, idx_out, val_out, d_sae, k,
-                       row_list, n_list);
+                       row_list, n_list, feat_cnt, wpos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -787,7 +821,8 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.loss_part = take(N * 4);
     w.cnt = take((size_t)d.d_sae * 4);
     w.offs = take(((size_t)d.d_sae + 1) * 4);
-    w.cursor = take((size_t)d.d_sae * 4);
+    w.cursor = take((N * (size_t)d.k / BWD_CH + 8) * 4);      // chunk starts of the backward's waves
+    w.wpos = take(N * (size_t)d.k * 4);
     w.pairs = take(N * (size_t)d.k * 4);
     w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS) * d.d_in * 4);
     w.colsum = take((size_t)d.d_in * 4);
@@ -883,9 +918,13 @@ extern "C" int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t 
     return PV_OK;
 }
 
+// want_csr: also count the kept pairs per feature (ws.cnt) and record their positions (ws.wpos) for the backward
 static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
-                           int32_t* topk_idx, float* topk_val, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                           int32_t* topk_idx, float* topk_val, bool want_csr, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
     const pv_sae_desc& d = plan->d;
+    uint32_t* feat_cnt = want_csr ? (uint32_t*)(wsb + ws.cnt) : nullptr;
+    uint32_t* wpos = want_csr ? (uint32_t*)(wsb + ws.wpos) : nullptr;
+    if (want_csr) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     float* bmean = (float*)(wsb + ws.batch_mean);
     if (batch_mean) {
@@ -905,7 +944,7 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
                    ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
                        (fast ? 0.0 : (double)N * d.d_sae * 8.0));
-    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, wsb, ws, stream);
+    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, feat_cnt, wpos, wsb, ws, stream);
     {
         // exact path: hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574) on the fp32 MFMA, W_enc in its own [d_in][d_sae] layout
         GemmParams g = {};
@@ -913,7 +952,7 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
         g.M = N; g.N = d.d_sae; g.K = d.d_in; g.epi = PV_EPI_BIAS; g.bias0 = st->b_enc; g.out0 = wsb + ws.hidden; g.ldo = d.d_sae;
         int rc = pv_launch_gemm(PV_DTYPE_F32, g, stream);
         if (rc) return rc;
-        sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, nullptr, nullptr, 0, stream);
+        sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, nullptr, nullptr, 0, feat_cnt, wpos, stream);
     }
     PV_LAUNCH_CHECK("sae_topk_kernel");
     return PV_OK;
@@ -928,7 +967,7 @@ extern "C" int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, con
     PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* wsb = (unsigned char*)workspace;
-    int rc = sae_encode_topk(plan, st, x, N, nullptr, topk_idx, topk_val, wsb, ws, stream);
+    int rc = sae_encode_topk(plan, st, x, N, nullptr, topk_idx, topk_val, false, wsb, ws, stream);
     if (rc) return rc;
     if (ln_mu) PV_HIP_CHECK(hipMemcpyAsync(ln_mu, wsb + ws.mu, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
     if (ln_std) PV_HIP_CHECK(hipMemcpyAsync(ln_std, wsb + ws.sd, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
@@ -952,7 +991,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     unsigned char* wsb = (unsigned char*)workspace;
     const int k = d.k, n_pairs = N * k;
 
-    int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, wsb, ws, stream);
+    int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, true, wsb, ws, stream);
     if (rc) return rc;
 
     float* dY = (float*)(wsb + ws.dY);
@@ -973,35 +1012,29 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
                            1.0f / ((float)n_global * (float)d.d_in), 1);
-        // CSR by feature
+        // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
         uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
-        uint32_t* cursor = (uint32_t*)(wsb + ws.cursor);
+        uint32_t* chunk_start = (uint32_t*)(wsb + ws.cursor);
         int32_t* pairs = (int32_t*)(wsb + ws.pairs);
-        PV_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)d.d_sae * 4, stream));
-        hipLaunchKernelGGL(csr_count_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
-                           (const float*)out->topk_val, cnt, n_pairs);
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, cursor, d.d_sae,
-                           out->scalars, 1.0f / (float)N);
+        const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, chunk_start, max_chunks,
+                           d.d_sae, out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
-                           (const float*)out->topk_val, cursor, pairs, n_pairs);
+                           (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
+        // statistics + zero rows of the features no wave will store (did not fire / long lists that accumulate atomically)
+        hipLaunchKernelGGL(sae_rows_prep_kernel, dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs,
+                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae,
+                           d.d_in, update_stats);
         PV_LAUNCH_CHECK("csr kernels");
-        // rows are zeroed first: features with no active pair keep a zero gradient (this IS zero_grad), and
-        // features whose pair list spans several waves accumulate through atomics
-        PV_HIP_CHECK(hipMemsetAsync(st->gW_dec, 0, (size_t)d.d_sae * d.d_in * 4, stream));
-        PV_HIP_CHECK(hipMemsetAsync(st->gW_enc, 0, (size_t)d.d_sae * d.d_in * 4, stream));
-        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)d.d_sae * 4, stream));
-        const int n_waves = (n_pairs + BWD_CH - 1) / BWD_CH;
-        const dim3 gridf((n_waves + 3) / 4);
+        const dim3 gridf((max_chunks + 3) / 4);
 #define CALL(D)                                                                                                        \
-    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const int32_t*)pairs, \
-                       (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, (const float*)dY, \
-                       (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae, d.d_in, k)
+    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
+                       (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
+                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae, d.d_in, k, max_chunks)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
-        hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
-                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, update_stats);
         // gb_dec = colsum(dY) - W_enc @ gb_enc
         const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);

@@ -16,7 +16,7 @@ struct pv_sae_plan {
 
 struct SaeWs {
     size_t total;
-    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, pairs, colpart, colsum, batch_mean, sqpart;
+    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, wpos, pairs, colpart, colsum, batch_mean, sqpart;
     // fast encoder (sae_enc.hip)
     size_t x16, xnorm, sample, thr, sq, band, cand_cnt, cand, fb_list, fb_count, wmax;
     int sq_blocks;
@@ -35,10 +35,12 @@ static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
 // sae_enc.hip: hidden_pre top-k of N tokens through the fp16 filter GEMM + exact re-scoring (see the file header).
 // Requires the shadows (W_encT, W_enc16T, enc_colsq) of `st` to be current.  prep (sae.hip) has already filled sae_in,
 // x16, xnorm.  Rows the filter cannot decide are recomputed exactly (hidden scratch + sae_topk_rows).
+// feat_cnt / wpos (both or neither; feat_cnt zeroed by the caller): per-feature pair counts and each kept pair's position in
+// its feature's list, for the backward's CSR.
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
-                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
 
 // sae.hip: exact streaming / radix top-k of rows of `hidden`; row_list == nullptr: rows 0..n_rows-1 (one workgroup each),
 // else the rows row_list[0 .. *n_list) are walked by `slots` workgroups.
 void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
-                   const uint32_t* n_list, int slots, hipStream_t stream);
+                   const uint32_t* n_list, int slots, uint32_t* feat_cnt, uint32_t* wpos, hipStream_t stream);

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
-    uint32_t* __restrict__ fb_count, int d, int k, int ntn) {
+    uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn) {
     __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
@@ -385,9 +385,18 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
         }
         bad = n > (uint32_t)PV_SAE_CAND_CAP || n < (uint32_t)k;
     }
-    if (!bad && tid < ntn) {
+    if (!bad && tid < ntn && myc > 0u) {
         const int2* src = cand + (row * ntn + tid) * PV_SAE_TILE_SLOTS;
-        for (uint32_t e = 0; e < myc; ++e) {
+        // (the usual list is 1-4 entries: two independent 16-byte loads instead of a dependent chain)
+        const int4 e01 = *reinterpret_cast<const int4*>(src), e23 = *reinterpret_cast<const int4*>(src + 2);
+        const int2 first[4] = {{e01.x, e01.y}, {e01.z, e01.w}, {e23.x, e23.y}, {e23.z, e23.w}};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if ((uint32_t)e < myc) {
+                ckey[off + e] = f2ord(__int_as_float(first[e].y));
+                cidx[off + e] = first[e].x;
+            }
+        for (uint32_t e = 4; e < myc; ++e) {
             const int2 c = src[e];
             ckey[off + e] = f2ord(__int_as_float(c.y));
             cidx[off + e] = c.x;
@@ -475,8 +484,11 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
             rank += (vo > vc) || (vo == vc && ridx[o] < ic);
         }
         if (rank < (uint32_t)k) {
+            const float v = fmaxf(vc, 0.f);                    // postact_fn = ReLU (sae.py:806)
             idx_out[row * k + rank] = ic;
-            val_out[row * k + rank] = fmaxf(vc, 0.f);          // postact_fn = ReLU (sae.py:806)
+            val_out[row * k + rank] = v;
+            // position of this pair in its feature's list (CSR of the backward), drawn while the result is written
+            if (feat_cnt) wpos[row * k + rank] = v > 0.f ? atomicAdd(&feat_cnt[ic], 1u) : 0xffffffffu;
         }
     }
 }
@@ -519,7 +531,7 @@ int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
 }  // namespace
 
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
-                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
     PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
     const int S = PV_SAE_SAMPLE_STRIDE, ns = d.d_sae / S, q = pv_sae_sample_q(d.k);
     float* wmax = (float*)(wsb + ws.wmax);
@@ -547,7 +559,7 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
                        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
                        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
-                       topk_val, fb_list, fb_count, d.d_in, d.k, ntn)
+                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
 #undef CALL
     PV_LAUNCH_CHECK("sae_select_kernel");
@@ -556,6 +568,6 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
                        (const float*)(wsb + ws.sae_in), (const float*)st->W_enc, (const float*)st->b_enc, (const int32_t*)fb_list,
                        (const uint32_t*)fb_count, (float*)(wsb + ws.hidden), d.d_in, d.d_sae);
     PV_LAUNCH_CHECK("sae_fb_hidden_kernel");
-    sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, fb_list, fb_count, PV_SAE_FB_SLOTS, stream);
+    sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, fb_list, fb_count, PV_SAE_FB_SLOTS, feat_cnt, wpos, stream);
     return PV_OK;
 }
