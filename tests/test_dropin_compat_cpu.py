@@ -1,0 +1,121 @@
+"""Drop-in loose ends (north_star: "existing Prisma notebooks and SAE configs drop in unchanged"):
+  * ``vit_prisma_amd.install_as("vit_prisma")``: the reference's import paths resolve to this build, and the REFERENCE'S OWN
+    offline tests (tests/test_hooks.py, test_cache_hook_names.py, test_weight_properties.py,
+    tests/sae/test_load_VisionModelSAERunnerConfig.py) pass against it unmodified (build container only: they are run
+    from /root/reference, never copied)
+  * checkpoints written by the reference (pickled vit_prisma.sae.config.VisionModelSAERunnerConfig) load, in the
+    reference's argument order, and reproduce the reference module's output bit for bit
+  * VisionSAETrainer.run() end to end on the tiny model, geometric-median b_dec initialisation against the reference's
+    own result
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vit_prisma_amd import HookedViT, HookedViTConfig
+from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
+from vit_prisma_amd.sae.geometric_median import compute_geometric_median
+from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state
+
+from conftest import GOLDEN, ROOT
+
+REF_TESTS = "/root/reference/tests"
+
+
+def test_import_aliases_cover_the_reference_paths():
+    code = (
+        "import vit_prisma_amd as A; A.install_as('vit_prisma')\n"
+        "from vit_prisma.models.base_vit import HookedViT\n"
+        "from vit_prisma.configs.HookedViTConfig import HookedViTConfig\n"
+        "from vit_prisma.prisma_tools.hook_point import HookPoint\n"
+        "from vit_prisma.prisma_tools.hooked_root_module import HookedRootModule\n"
+        "from vit_prisma.prisma_tools.activation_cache import ActivationCache\n"
+        "from vit_prisma.sae.config import VisionModelSAERunnerConfig\n"
+        "from vit_prisma.sae.sae import StandardSparseAutoencoder, GatedSparseAutoencoder, SparseAutoencoder\n"
+        "from vit_prisma.sae.transcoder import Transcoder\n"
+        "from vit_prisma.sae.train_sae import VisionSAETrainer\n"
+        "from vit_prisma.sae.training.activations_store import VisionActivationsStore, CacheVisionActivationStore\n"
+        "from vit_prisma.sae.training.geometric_median import compute_geometric_median\n"
+        "from vit_prisma.sae import VisionSAETrainer as T2\n"
+        "assert HookedViT is A.HookedViT and T2 is VisionSAETrainer\n"
+        "import vit_prisma.sae.sae as m; assert m.StandardSparseAutoencoder.__module__ == 'vit_prisma_amd.sae.sae'\n"
+        "print('aliases ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and "aliases ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="the reference tree only exists in the build container")
+def test_the_references_own_offline_tests_pass_against_this_build(tmp_path):
+    files = [os.path.join(REF_TESTS, f) for f in ("test_hooks.py", "test_cache_hook_names.py", "test_weight_properties.py",
+                                                   "sae/test_load_VisionModelSAERunnerConfig.py")]
+    code = ("import sys, pytest, vit_prisma_amd\n"
+            "vit_prisma_amd.install_as('vit_prisma')\n"
+            f"sys.exit(pytest.main({files!r} + ['-q', '-p', 'no:cacheprovider']))\n")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "17 passed" in r.stdout, r.stdout[-500:]
+
+
+def test_checkpoints_written_by_the_reference_load_and_reproduce_its_output():
+    d = os.path.join(GOLDEN, "sae_ref_ckpt")
+    io = torch.load(os.path.join(d, "io.pt"))
+    m = StandardSparseAutoencoder.load_from_pretrained(os.path.join(d, "ref_legacy.pt"))
+    assert type(m.cfg) is VisionModelSAERunnerConfig and m.cfg.d_sae == 512 and m.cfg.activation_fn_kwargs == {"k": 8}
+    assert torch.equal(m(io["x"])[0], io["out"])
+    # split form: bare state dict + config.json beside it; the reference's positional order (weights_path, current_cfg)
+    m2 = StandardSparseAutoencoder.load_from_pretrained(os.path.join(d, "weights.pt"), {"lr": 0.5, "not_a_field": 1})
+    assert m2.cfg.lr == 0.5 and not hasattr(m2.cfg, "not_a_field") and torch.equal(m2(io["x"])[0], io["out"])
+    m3 = StandardSparseAutoencoder.load_from_pretrained(os.path.join(d, "weights.pt"), config_path=os.path.join(d, "config.json"))
+    assert torch.equal(m3(io["x"])[0], io["out"])
+    with pytest.raises(FileNotFoundError):
+        StandardSparseAutoencoder.load_from_pretrained(os.path.join(d, "nope.pt"))
+
+
+def test_geometric_median_equals_the_references():
+    g = np.load(os.path.join(GOLDEN, "geometric_median.npz"))
+    res = compute_geometric_median(torch.from_numpy(g["points"]), maxiter=100)
+    assert float((res.median - torch.from_numpy(g["median"])).abs().max()) < 1e-5
+    assert float((res.median - torch.from_numpy(g["points"]).mean(0)).norm()) > 1.0       # it is not the mean
+
+
+@pytest.mark.parametrize("b_dec_init", ["geometric_median", "mean"])
+def test_trainer_run_end_to_end_on_the_tiny_model(tmp_path, b_dec_init):
+    """VisionSAETrainer.run() (train_sae.py:772-861): store harvest -> b_dec initialisation -> ~20 train steps ->
+    checkpoint, on CPU with the tiny ViT; the loss must fall and the checkpoint must load back."""
+    arch = ARCHS["tiny"]
+    vit = HookedViT(HookedViTConfig(**arch, device="cpu"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()})
+    vit.eval()
+    images = torch.from_numpy(synth_images(arch, 64, 3))
+    ds = [(images[i], 0) for i in range(64)]
+    n_steps, bs = 20, 128
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=4, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", b_dec_init_method=b_dec_init, train_batch_size=bs,
+        lr=2e-3, max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=1,
+        context_size=17, store_batch_size=8, n_batches_in_buffer=4, checkpoint_path=str(tmp_path), verbose=False)
+    cfg.total_training_images = n_steps * bs // 17 + 1
+    tr = VisionSAETrainer(cfg, vit, ds, eval_dataset=ds)
+    before = tr.sparse_coder.b_dec.detach().clone()
+    losses = []
+    orig = tr.train_step
+
+    def spy(**kw):
+        out = orig(**kw)
+        losses.append(float(out[0]))
+        return out
+
+    tr.train_step = spy
+    sae = tr.run()
+    assert sae is tr.sparse_coder and len(losses) >= n_steps and tr.final_stats["n_training_steps"] == len(losses)
+    assert not torch.equal(sae.b_dec.detach(), before)                         # b_dec was initialised from the buffer
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
+    ck = [f for f in os.listdir(cfg.checkpoint_path) if f.endswith(".pt") and "sparsity" not in f]
+    assert ck and os.path.exists(os.path.join(cfg.checkpoint_path, "config.json"))
+    back = StandardSparseAutoencoder.load_from_pretrained(os.path.join(cfg.checkpoint_path, ck[0]))
+    assert torch.allclose(back.W_dec, sae.W_dec) and float((back.W_dec.norm(dim=1) - 1).abs().max()) < 1e-5

@@ -527,72 +527,82 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
         }
         gb = 0.f;
     };
-    // two pairs in flight: the rows of pair q+1 are requested before pair q is accumulated
-    int32_t p = pairs[q0];
-    float4 dy[V4], si[V4];
-    {
-        const int n0 = p / k;
-#pragma unroll
-        for (int i = 0; i < V4; ++i) {
-            dy[i] = ld4(dY + (int64_t)n0 * d + col[i], ok[i]);
-            si[i] = ld4(sae_in + (int64_t)n0 * d + col[i], ok[i]);
+    // The chunk's pair metadata is fetched up front, one pair per lane (<= BWD_CH + BWD_LMAX pairs: at most two rounds of
+    // 64), and broadcast with readlane: the only memory operations left in the loop are the row gathers, issued two
+    // pairs ahead of the accumulation (vmcnt retires loads in order, so nothing younger may sit between a gather and its
+    // use).
+    for (uint32_t base = q0; base < q1; base += 64) {
+        const int cnt = (int)min(64u, q1 - base);
+        int my_n = 0, my_j = 0;
+        float my_a = 0.f, my_g = 0.f;
+        if (lane < cnt) {
+            const int32_t p = pairs[base + lane];
+            my_n = p / k;
+            my_j = idx[p];
+            my_a = val[p];
+            my_g = dh[p];
         }
-    }
-    for (uint32_t q = q0; q < q1; ++q) {
-        const int32_t pn = q + 1 < q1 ? pairs[q + 1] : p;
-        float4 dyn[V4], sin_[V4];
-        {
-            const int nn = pn / k;
+        float4 dy0[V4], si0[V4], dy1[V4], si1[V4];
+        auto gather = [&](float4 (&dy)[V4], float4 (&si)[V4], int t) {
+            const int n = __shfl(my_n, t, 64);
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
-                dyn[i] = ld4(dY + (int64_t)nn * d + col[i], ok[i]);
-                sin_[i] = ld4(sae_in + (int64_t)nn * d + col[i], ok[i]);
+                dy[i] = ld4(dY + (int64_t)n * d + col[i], ok[i]);
+                si[i] = ld4(sae_in + (int64_t)n * d + col[i], ok[i]);
+            }
+        };
+        auto accumulate = [&](const float4 (&dy)[V4], const float4 (&si)[V4], int t) {
+            const int j = __shfl(my_j, t, 64);
+            const float a = __shfl(my_a, t, 64), g = __shfl(my_g, t, 64);
+            if (j != cur) {
+                flush(cur);
+                cur = j;
+            }
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                gd[i].x += a * dy[i].x; gd[i].y += a * dy[i].y; gd[i].z += a * dy[i].z; gd[i].w += a * dy[i].w;      // d loss / d W_dec[j, :]
+                ge[i].x += g * si[i].x; ge[i].y += g * si[i].y; ge[i].z += g * si[i].z; ge[i].w += g * si[i].w;      // d loss / d W_enc[:, j]
+            }
+            gb += g;
+        };
+        gather(dy0, si0, 0);
+        if (cnt > 1) gather(dy1, si1, 1);
+        for (int t = 0; t < cnt; t += 2) {
+            accumulate(dy0, si0, t);
+            if (t + 2 < cnt) gather(dy0, si0, t + 2);
+            if (t + 1 < cnt) {
+                accumulate(dy1, si1, t + 1);
+                if (t + 3 < cnt) gather(dy1, si1, t + 3);
             }
         }
-        const int j = idx[p];
-        if (j != cur) {
-            flush(cur);
-            cur = j;
-        }
-        const float a = val[p], g = dh[p];
-#pragma unroll
-        for (int i = 0; i < V4; ++i) {
-            gd[i].x += a * dy[i].x; gd[i].y += a * dy[i].y; gd[i].z += a * dy[i].z; gd[i].w += a * dy[i].w;      // d loss / d W_dec[j, :]
-            ge[i].x += g * si[i].x; ge[i].y += g * si[i].y; ge[i].z += g * si[i].z; ge[i].w += g * si[i].w;      // d loss / d W_enc[:, j]
-        }
-        gb += g;
-        p = pn;
-#pragma unroll
-        for (int i = 0; i < V4; ++i) { dy[i] = dyn[i]; si[i] = sin_[i]; }
     }
     flush(cur);
 }
 
-// Per feature (one wave each): firing statistics (train_sae.py:356-361) from the CSR offsets, and zero gradient rows for
-// the features no backward wave will write -- the ones that did not fire (this IS their zero_grad) and the long-list ones
-// that several waves accumulate into with atomics.
+// Per feature (one thread each): firing statistics (train_sae.py:356-361) from the CSR offsets, and zero gradient rows
+// for the features no backward wave will store -- the ones that did not fire (this IS their zero_grad) and the long-list
+// ones that several waves accumulate into with atomics.  Both are rare (a fraction of a percent of the features), so a
+// thread zeroes its two rows by itself.
 __global__ __launch_bounds__(256) void sae_rows_prep_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
                                                             float* __restrict__ n_since_fired, float* __restrict__ fire_count,
                                                             float* __restrict__ gW_dec, float* __restrict__ gW_encT,
                                                             float* __restrict__ gb_enc, int d_sae, int d, int update_stats) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d_sae) return;
     const uint32_t c = offs[j + 1] - offs[j];
-    if (lane == 0) {
-        const float cnt = (float)c;
-        if (fire_count) fire_count[j] = cnt;
-        if (update_stats) {
-            act_freq[j] += cnt;
-            n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
-        }
+    const float cnt = (float)c;
+    if (fire_count) fire_count[j] = cnt;
+    if (update_stats) {
+        act_freq[j] += cnt;
+        n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
     }
     if (c == 0u || c > (uint32_t)BWD_LMAX) {
-        for (int col = 4 * lane; col < d; col += 256) {
-            *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int col = 0; col < d; col += 4) {
+            *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col) = z;
+            *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col) = z;
         }
-        if (lane == 0) gb_enc[j] = 0.f;
+        gb_enc[j] = 0.f;
     }
 }
 
@@ -836,7 +846,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.band = take(N * 4);
     const size_t ntn = (size_t)(d.d_sae + 255) / 256;
     w.cand_cnt = take(N * ntn * 4);
-    w.cand = take(N * ntn * (size_t)PV_SAE_TILE_SLOTS * 8);
+    w.cand = take(N * ntn * (size_t)pv_sae_tile_slots(d) * 8);
     w.fb_list = take(N * 4);
     w.fb_count = take(256);
     w.wmax = take(256);
@@ -1023,7 +1033,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
         // statistics + zero rows of the features no wave will store (did not fire / long lists that accumulate atomically)
-        hipLaunchKernelGGL(sae_rows_prep_kernel, dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs,
+        hipLaunchKernelGGL(sae_rows_prep_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
                            st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae,
                            d.d_in, update_stats);
         PV_LAUNCH_CHECK("csr kernels");

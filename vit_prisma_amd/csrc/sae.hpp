@@ -6,7 +6,7 @@
 constexpr int PV_SAE_MAXK = 64;
 constexpr int PV_SAE_SAMPLE_STRIDE = 16;     // pass 0 looks at every 16th feature
 constexpr int PV_SAE_CAND_CAP = 1024;        // candidates of a token the select kernel can rank (more -> exact fallback row)
-constexpr int PV_SAE_TILE_SLOTS = 16;        // candidate slots per (token, 256-feature tile) of the filter GEMM
+constexpr int PV_SAE_TILE_SLOTS_MIN = 16;    // candidate slots per (token, 256-feature tile) of the filter GEMM, at least
 constexpr int PV_SAE_RESCORE_MAX = 192;      // candidates re-scored exactly per token (more -> exact fallback row)
 constexpr int PV_SAE_FB_SLOTS = 32;          // workgroup columns of the fallback kernels
 
@@ -26,10 +26,20 @@ SaeWs sae_carve(const pv_sae_desc& d);
 // number of sampled values per token that bound the k-th largest from below (order statistic taken in pass 0)
 static inline int pv_sae_sample_q(int k) { return k * 3 / 8 > 8 ? k * 3 / 8 : 8; }
 
+// Slots per (token, tile): the threshold lets ~16 q candidates per token through, spread over d_sae / 256 tiles; 4 x the
+// mean + 6, rounded up to a power of two in [16, 256] (beyond that the plan takes the exact path).
+static inline int pv_sae_tile_slots(const pv_sae_desc& d) {
+    const int ntn = (d.d_sae + 255) / 256;
+    const int want = 4 * PV_SAE_SAMPLE_STRIDE * pv_sae_sample_q(d.k) / ntn + 6;
+    int s = PV_SAE_TILE_SLOTS_MIN;
+    while (s < want) s *= 2;
+    return s;
+}
+
 // Is the filtered (fp16 MFMA) encoder applicable to this plan?  Otherwise the exact-fp32 GEMM + streaming top-k runs.
 static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
     return d.d_sae % 256 == 0 && d.d_sae >= 4096 && d.d_in % 8 == 0 && d.d_in >= 32 && d.k <= PV_SAE_MAXK &&
-           pv_sae_sample_q(d.k) * PV_SAE_SAMPLE_STRIDE * 2 <= PV_SAE_CAND_CAP && !g_pv_tuning.sae_exact;
+           pv_sae_sample_q(d.k) * PV_SAE_SAMPLE_STRIDE * 2 <= PV_SAE_CAND_CAP && pv_sae_tile_slots(d) <= 256 && !g_pv_tuning.sae_exact;
 }
 
 // sae_enc.hip: hidden_pre top-k of N tokens through the fp16 filter GEMM + exact re-scoring (see the file header).

@@ -44,8 +44,9 @@ struct EncParams {
     float* out;               // MODE 0: [M][ldo] fp32 (sample)
     int32_t ldo;
     const float* thr;         // MODE 1: [M] thresholds
-    uint32_t* cnt;            //         [M][ntn] hits of (token, N-tile); 0xffffffff = more than PV_SAE_TILE_SLOTS
-    int2* cand;               //         [M][ntn][PV_SAE_TILE_SLOTS] (feature, bits of a)
+    uint32_t* cnt;            //         [M][ntn] hits of (token, N-tile); 0xffffffff = more than `slots`
+    int2* cand;               //         [M][ntn][slots] (feature, bits of a)
+    int32_t slots;            //         pv_sae_tile_slots(plan)
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
             }
     } else {
         // Hits are ~0.8 % of the tile (~2 per token row).  Nothing global is contended for them: every (token, N-tile) pair
-        // owns PV_SAE_TILE_SLOTS candidate slots and a count word that only this workgroup writes (a device-scope atomic
+        // owns pv_sae_tile_slots() candidate slots and a count word that only this workgroup writes (a device-scope atomic
         // per hit on per-token counters cost more than the whole K loop: ~0.8 M atomics per step queue up behind a few dozen
         // memory channels).  The hits are compacted into LDS with no round trip -- per 32-row block a lane builds the
         // bitmap of its 32 accumulators, a wave scan + ONE LDS atomic per wave hands out list positions -- then every
@@ -272,13 +273,13 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
             const uint2 h = hlist[e];
             const int lrow = (int)(h.x >> 8);
             const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
-            if (li < (uint32_t)PV_SAE_TILE_SLOTS)
-                p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * PV_SAE_TILE_SLOTS + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
+            if (li < (uint32_t)p.slots)
+                p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * p.slots + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
         }
         __syncthreads();
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
-            p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)PV_SAE_TILE_SLOTS ? 0xffffffffu : c;
+            p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)p.slots ? 0xffffffffu : c;
         }
     }
 }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
-    uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn) {
+    uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn, int slots) {
     __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     __shared__ uint32_t sh_t, sh_nr, sh_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
-    // gather the token's candidates: ntn (<= 128) per-tile lists of <= PV_SAE_TILE_SLOTS entries
+    // gather the token's candidates: ntn (<= 128) per-tile lists of <= slots entries
     uint32_t myc = 0;
     if (tid < ntn) myc = tile_cnt[row * ntn + tid];
     if (tid < 128) tcnt[tid] = tid < ntn ? myc : 0u;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
         bad = n > (uint32_t)PV_SAE_CAND_CAP || n < (uint32_t)k;
     }
     if (!bad && tid < ntn && myc > 0u) {
-        const int2* src = cand + (row * ntn + tid) * PV_SAE_TILE_SLOTS;
+        const int2* src = cand + (row * ntn + tid) * slots;
         // (the usual list is 1-4 entries: two independent 16-byte loads instead of a dependent chain)
         const int4 e01 = *reinterpret_cast<const int4*>(src), e23 = *reinterpret_cast<const int4*>(src + 2);
         const int2 first[4] = {{e01.x, e01.y}, {e01.z, e01.w}, {e23.x, e23.y}, {e23.z, e23.w}};
@@ -553,13 +554,14 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes; p.bias_stride = 1;
     p.out = nullptr; p.thr = (const float*)(wsb + ws.thr); p.cnt = (uint32_t*)(wsb + ws.cand_cnt); p.cand = (int2*)(wsb + ws.cand);
     const int ntn = d.d_sae / 256;
+    p.slots = pv_sae_tile_slots(d);
     rc = launch_enc_gemm(1, p, stream);
     if (rc) return rc;
 #define CALL(D)                                                                                                             \
     hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
                        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
                        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
-                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn)
+                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
 #undef CALL
     PV_LAUNCH_CHECK("sae_select_kernel");

@@ -142,7 +142,16 @@ class VisionModelSAERunnerConfig:
 
     @property
     def total_training_images(self) -> int:
+        over = self.__dict__.get("_total_training_images")
+        if over is not None:
+            return int(over)
         return int(1_300_000 * self.num_epochs)            # config.py:472-481 hard-codes ImageNet-1k
+
+    @total_training_images.setter
+    def total_training_images(self, n: int) -> None:
+        """Deliberate extension: the reference's property is read-only (so its own tests/sae/test_sae_training.py, which
+        assigns it, cannot run); here the assignment sets the length of the run."""
+        self.__dict__["_total_training_images"] = None if n is None else int(n)
 
     @property
     def total_training_tokens(self) -> int:

@@ -26,6 +26,36 @@ from ..hooked_root_module import HookedRootModule
 from .config import VisionModelSAERunnerConfig
 
 
+def _compat_pickle():
+    """A ``pickle``-shaped module whose Unpickler resolves the reference's module paths (``vit_prisma.sae.config`` ...)
+    to this package's classes -- what ``vit_prisma_amd.install_as("vit_prisma")`` does process-wide, scoped to one load."""
+    import types
+    remap = {"vit_prisma.sae.config": "vit_prisma_amd.sae.config", "vit_prisma.sae.sae": "vit_prisma_amd.sae.sae",
+             "vit_prisma.sae.transcoder": "vit_prisma_amd.sae.variants",
+             "vit_prisma.configs.HookedViTConfig": "vit_prisma_amd.configs"}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module in remap and (module not in __import__("sys").modules or module.startswith("vit_prisma.")):
+                import importlib
+                tgt = importlib.import_module(remap[module])
+                if hasattr(tgt, name):
+                    return getattr(tgt, name)
+                if module == "vit_prisma.sae.sae":                     # GatedSparseAutoencoder lives in variants here
+                    from . import variants
+                    if hasattr(variants, name):
+                        return getattr(variants, name)
+            return super().find_class(module, name)
+
+    mod = types.ModuleType("pv_compat_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.__name__ = "pickle"
+    for n in ("Pickler", "dump", "dumps", "loads", "HIGHEST_PROTOCOL", "DEFAULT_PROTOCOL", "PickleError", "UnpicklingError"):
+        setattr(mod, n, getattr(pickle, n))
+    return mod
+
+
 class TopK(nn.Module):
     """Keep the k largest pre-activations per row, apply ``postact_fn`` (ReLU), zero the rest."""
 
@@ -187,28 +217,65 @@ class SparseAutoencoder(HookedRootModule, ABC):
         logging.info(f"Saved model to {path}")
 
     @classmethod
-    def load_from_pretrained(cls, weights_path: str, config_path: Optional[str] = None, current_cfg=None):
+    def load_from_pretrained(cls, weights_path, current_cfg=None, config_path=None):
+        """Same signature and resolution order as the reference (sae.py:410-528): ``weights_path`` is a ``.pt`` /
+        ``.pkl`` / ``.pkl.gz`` file holding either the legacy ``{"cfg", "state_dict"}`` blob (its pickled config is
+        used when ``config_path`` is None) or a bare state dict (the config is then ``config.json`` next to the weights,
+        as in the reference -- an explicit ``config_path`` is honoured first); ``current_cfg`` (a mapping or a config
+        object) overrides every matching attribute; the class is picked from the config (transcoder / standard / gated).
+        Checkpoints written by the reference pickle ``vit_prisma.sae.config.VisionModelSAERunnerConfig``: the unpickler
+        maps ``vit_prisma.*`` onto this package, so they load without the reference installed."""
         if not os.path.isfile(weights_path):
-            raise FileNotFoundError(f"No file found at specified path: {weights_path}")
-        if weights_path.endswith(".pkl.gz"):
-            import gzip
-            with gzip.open(weights_path, "rb") as f:
-                blob = pickle.load(f)
+            raise FileNotFoundError(f"No weights file found at: {weights_path}")
+        try:
+            if weights_path.endswith(".pt"):
+                blob = torch.load(weights_path, map_location="cpu", weights_only=False, pickle_module=_compat_pickle())
+            elif weights_path.endswith(".pkl.gz"):
+                import gzip
+                with gzip.open(weights_path, "rb") as f:
+                    blob = _compat_pickle().Unpickler(f).load()
+            elif weights_path.endswith(".pkl"):
+                with open(weights_path, "rb") as f:
+                    blob = _compat_pickle().Unpickler(f).load()
+            else:
+                raise ValueError(f"Unexpected file extension: {weights_path}")
+        except (ValueError, FileNotFoundError):
+            raise
+        except Exception as e:
+            raise IOError(f"Error loading the state dictionary from {weights_path}: {e}")
+        is_legacy = isinstance(blob, dict) and "cfg" in blob and "state_dict" in blob
+        if is_legacy and config_path is None:
+            loaded_cfg, weights = blob["cfg"], blob["state_dict"]
         else:
-            blob = torch.load(weights_path, map_location="cpu", weights_only=False)
-        if isinstance(blob, dict) and "state_dict" in blob:
-            state_dict = blob["state_dict"]
-            cfg = blob.get("cfg") or blob.get("config")
-        else:
-            state_dict, cfg = blob, None
-        if config_path is not None:
-            cfg = VisionModelSAERunnerConfig.load_config(config_path)
-        if cfg is None:
-            raise ValueError("no config found: pass config_path for split weights/config checkpoints")
+            if config_path is None or not os.path.isfile(config_path):
+                config_path = os.path.join(os.path.dirname(weights_path), "config.json")
+            if not os.path.isfile(config_path):
+                raise FileNotFoundError(f"No config file found at {config_path} and no legacy format detected")
+            loaded_cfg = VisionModelSAERunnerConfig.load_config(config_path)
+            weights = blob["state_dict"] if is_legacy else blob
+        if not hasattr(loaded_cfg, "activation_fn_kwargs"):             # very old pickles (sae.py:486-497)
+            slope = {"negative_slope": 0.01} if getattr(loaded_cfg, "activation_fn_str", "relu") == "leaky_relu" else {}
+            loaded_cfg.activation_fn_kwargs = slope
         if current_cfg is not None:
-            cfg.device = current_cfg.device
-        inst = cls(cfg)
-        inst.load_state_dict(state_dict)
+            items = current_cfg.items() if hasattr(current_cfg, "items") else vars(current_cfg).items()
+            for key, value in items:
+                if hasattr(loaded_cfg, key):
+                    try:
+                        setattr(loaded_cfg, key, value)
+                    except AttributeError:                              # read-only property of the config
+                        pass
+        if getattr(loaded_cfg, "is_transcoder", False):
+            from .variants import Transcoder
+            model_cls = Transcoder
+        elif getattr(loaded_cfg, "architecture", "standard") in ("standard", "vanilla"):
+            model_cls = StandardSparseAutoencoder
+        elif loaded_cfg.architecture == "gated":
+            from .variants import GatedSparseAutoencoder
+            model_cls = GatedSparseAutoencoder
+        else:
+            raise ValueError(f"Unsupported architecture type: {loaded_cfg.architecture}")
+        inst = model_cls(loaded_cfg)
+        inst.load_state_dict(weights)
         return inst
 
     def get_name(self) -> str:
