@@ -312,6 +312,14 @@ int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x
                        int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Inference forward for the module API (StandardSparseAutoencoder.forward, sae.py:597-645, in eval / no-grad use such
+ * as the SAE-substitution evals, sae/evals/evals.py:321-392): top-k encode + sparse decode + LN-out -> sae_out [N, d_in]
+ * plus the sparse feature activations (topk_idx / topk_val [N, k]).  scalars (optional, >= 2 floats): [1] = mse loss of
+ * these N tokens as one batch.  ln_mu / ln_std optional. */
+int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t n_tokens, float* sae_out,
+                   int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, float* scalars, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

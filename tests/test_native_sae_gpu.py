@@ -313,3 +313,81 @@ def test_filtered_encoder_exact_fallback_on_ties_range_and_outside_edits(tuning)
         T["W_enc"][3, 77] = 1.0e6
     (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
     assert n_fb == n and torch.equal(val_f.sort(dim=1).values, val_e.sort(dim=1).values)
+
+
+# ---------------------------------------------------------------------------------------------------
+# module-level inference on the HIP kernels (the SAE inside a ViT hook)
+# ---------------------------------------------------------------------------------------------------
+def _module(d_in, d_sae, k, return_out_only=False):
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in, activation_fn_str="topk",
+        activation_fn_kwargs={"k": k}, normalize_activations="layer_norm", _device="cuda", log_to_wandb=False)
+    cfg.return_out_only = return_out_only
+    sae = StandardSparseAutoencoder(cfg)
+    with torch.no_grad():
+        for n, v in synth_sae_state(d_in, d_sae, 0).items():
+            getattr(sae, n).copy_(torch.from_numpy(v))
+    return sae.eval()
+
+
+def test_module_forward_and_encode_run_natively_and_equal_the_torch_path():
+    sae = _module(768, 24576, 32)
+    x = torch.from_numpy(synth_sae_batch(300, 768, seed=4)).cuda().view(6, 50, 768)      # [batch, tokens, d_in] like a hook sees it
+    with torch.no_grad():
+        got = sae(x)
+        assert sae.last_run_native, sae.native_fallback_reason
+        sae_in_n, acts_n = sae.encode(x)
+        assert sae.last_run_native
+        sae.use_native(False)
+        want = sae(x)
+        sae_in_t, acts_t = sae.encode(x)
+        assert not sae.last_run_native
+        sae.use_native(None)
+    assert len(got) == 7 and got[0].shape == x.shape and got[1].shape == (6, 50, 24576) and got[4] is None
+    assert rel_fro(got[0].cpu().numpy(), want[0].cpu().numpy()) < 1e-5
+    assert torch.equal(got[1] > 0, want[1] > 0)                                          # same active sets
+    assert rel_fro(got[1].cpu().numpy(), want[1].cpu().numpy()) < 1e-5
+    assert abs(float(got[2]) - float(want[2])) <= 1e-5 * float(want[2])                  # loss over dim 0 of the 3-D input, like the reference
+    assert torch.equal(acts_n > 0, acts_t > 0) and rel_fro(sae_in_n.cpu().numpy(), sae_in_t.cpu().numpy()) < 1e-6
+    # autograd recording -> PyTorch path (auto), error when forced
+    out = sae(x)
+    assert not sae.last_run_native and "autograd" in sae.native_fallback_reason and out[2].requires_grad
+    with pytest.raises(Exception):
+        sae.use_native(True)(x)
+    sae.use_native(None)
+    # a hook on the SAE's own hook points -> PyTorch path
+    with torch.no_grad():
+        seen = []
+        sae.hook_hidden_post.add_hook(lambda t, hook: seen.append(t.shape))
+        sae(x)
+        assert not sae.last_run_native and seen
+        sae.reset_hooks()
+
+
+def test_sae_substitution_inside_a_vit_hook_is_native_end_to_end():
+    """sae/evals/evals.py:321-392: the ViT forward with blocks.6.hook_resid_post replaced by the SAE's reconstruction.
+    ViT split plan (HIP) -> Python hook -> SAE forward (HIP) -> rest of the ViT (HIP); against the all-PyTorch run."""
+    from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state
+    arch = ARCHS["clip-vit-b32"]
+    vit = HookedViT(HookedViTConfig(**arch, device="cuda"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()})
+    vit = vit.cuda().eval()
+    sae = _module(768, 24576, 32, return_out_only=True)
+    x = torch.from_numpy(synth_images(arch, 4, 2)).cuda()
+    name = "blocks.6.hook_resid_post"
+    calls = []
+
+    def substitute(t, hook):
+        out = sae(t)
+        calls.append(sae.last_run_native)
+        return out
+
+    with torch.no_grad():
+        vit.use_native(True)
+        got = vit.run_with_hooks(x, fwd_hooks=[(name, substitute)])
+        assert vit.last_run_native and calls == [True]
+        vit.use_native(False)
+        sae.use_native(False)
+        want = vit.run_with_hooks(x, fwd_hooks=[(name, substitute)])
+        assert not vit.last_run_native and calls == [True, False]
+    assert rel_fro(got.cpu().numpy(), want.cpu().numpy()) < 1e-4

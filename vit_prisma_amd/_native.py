@@ -80,7 +80,7 @@ EXPORTS = [
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
-    "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset",
+    "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
 ]
 
@@ -135,6 +135,7 @@ def lib() -> C.CDLL:
         L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, i32, i32, vp]
         L.pv_sae_sync_shadows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp]
         L.pv_sae_encoder_is_filtered.argtypes = [vp]
+        L.pv_sae_forward.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.pv_debug_sae_ws_offset.argtypes = [vp, C.c_char_p]
         L.pv_debug_sae_ws_offset.restype = sz
         L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]

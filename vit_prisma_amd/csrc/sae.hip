@@ -407,18 +407,22 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
 // contiguous runs scanned out of LDS, shuffles across threads, coalesced store of offs / cursor
-// Also cuts the CSR-ordered pair sequence into the chunks the backward's waves own: nominally BWD_CH pairs each, but a cut
-// that would fall inside a SHORT list (<= BWD_LMAX pairs) moves forward to that list's end, so that only long lists are
-// ever shared between waves (those accumulate through atomics on rows zeroed by sae_rows_prep_kernel; every other
-// gradient row is written exactly once, by plain stores, by one wave).
+// Also (a) cuts the CSR-ordered pair sequence into the chunks the short-list backward's waves own -- nominally BWD_CH pairs
+// each, but a cut that would fall inside a list moves forward to that list's end, so a chunk is a run of WHOLE lists of
+// which only the last can be long -- and (b) collects the features with more than BWD_LMAX pairs (dense features: on the
+// bench batch 1.5 % of the features hold 36 % of the pairs) for the long-list kernel.  No gradient row is ever shared
+// between waves of the short-list kernel, none needs atomics, every row is written exactly once.
 constexpr int BWD_CH = 16;
 constexpr int BWD_LMAX = 64;
 
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ chunk_start, int max_chunks, int d_sae,
+                                                        uint32_t* __restrict__ chunk_start, int max_chunks,
+                                                        int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long, int d_sae,
                                                         float* __restrict__ scalars, float inv_tokens) {
     __shared__ uint32_t buf[32768];
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t sh_nlong;
+    if (threadIdx.x == 0) sh_nlong = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < d_sae; i += 1024) buf[i] = cnt[i];
     __syncthreads();
@@ -443,8 +447,10 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         const uint32_t c = buf[i];
         buf[i] = run;
         run += c;
+        if (c > (uint32_t)BWD_LMAX) long_list[atomicAdd(&sh_nlong, 1u)] = i;
     }
     __syncthreads();
+    if (tid == 0) *n_long = sh_nlong;
     for (int i = tid; i < d_sae; i += 1024) offs[i] = buf[i];
     if (tid == 1023) {
         offs[d_sae] = total;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
                 if (buf[mid] <= g) lo_j = mid; else hi_j = mid;
             }
             const uint32_t beg = buf[lo_j], end = lo_j + 1 < d_sae ? buf[lo_j + 1] : total;
-            sres = (g == beg || end - beg > (uint32_t)BWD_LMAX) ? g : end;
+            sres = g == beg ? g : end;
         }
         chunk_start[w] = sres;
     }
@@ -474,64 +480,50 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse backward.  Work is split by PAIRS, not by feature: wave w owns the CSR-ordered pair range
-// [w*BWD_CH, (w+1)*BWD_CH) -- perfectly balanced even when a few dense features fire on most tokens
-// (one-wave-per-feature measured 8.6 ms/step on such data).  A wave walks its range, accumulates per
-// feature and flushes a row when the feature changes: plain stores when the feature's whole list lies
-// inside this wave's range, hardware float atomics otherwise (rows are zeroed beforehand).
+// sparse backward:  gW_dec[j, :] = sum_p a_p dY[n_p, :],  gW_enc^T[j, :] = sum_p g_p sae_in[n_p, :],  gb_enc[j] = sum_p g_p
+// over the pairs p = (token n_p, feature j) of feature j's list (a = kept activation, g = dh).  One-wave-per-feature
+// collapses on skewed data (8.6 ms / step measured), so the work is split by PAIRS:
+//   short lists (<= BWD_LMAX pairs)  sae_backward_kernel: wave w owns the chunk [chunk_start[w], chunk_start[w+1]) of whole
+//                                    lists (~BWD_CH pairs), accumulates per feature and stores each finished row once
+//   long lists                       sae_backward_long_kernel: a 16-wave workgroup per dense feature, 1/16 of the list
+//                                    per wave, partial rows summed through LDS in a fixed order, one store
+// Rows of features that did not fire are zeroed by the caller (this IS their zero_grad).  No atomics.
+// Shared inner loop: the pair metadata of a run is fetched up front, one pair per lane, and broadcast with readlane, so the
+// only memory operations inside the loop are the row gathers (16 bytes per lane), issued two pairs ahead of their use
+// (vmcnt retires loads in order: nothing younger may sit between a gather and its use).
 // ------------------------------------------------------------------------------------------------
 template <int V4>
-__global__ __launch_bounds__(256) void sae_backward_kernel(
-    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
-    const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
-    const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    int d_sae, int d, int k, int n_chunks) {
-    const int lane = threadIdx.x & 63;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= n_chunks) return;
-    const uint32_t q0 = chunk_start[wv], q1 = chunk_start[wv + 1];
-    if (q0 >= q1) return;
-    bool ok[V4];
-    int col[V4];
-#pragma unroll
-    for (int i = 0; i < V4; ++i) {
-        col[i] = 4 * lane + 256 * i;
-        ok[i] = col[i] < d;
-    }
+struct BwdAcc {
     float4 gd[V4], ge[V4];
+    float gb;
+    __device__ __forceinline__ void clear() {
 #pragma unroll
-    for (int i = 0; i < V4; ++i) { gd[i] = make_float4(0.f, 0.f, 0.f, 0.f); ge[i] = gd[i]; }
-    float gb = 0.f;
-    int cur = idx[pairs[q0]];
-    auto flush = [&](int j) {
-        const bool whole = offs[j] >= q0 && offs[j + 1] <= q1;
-#pragma unroll
-        for (int i = 0; i < V4; ++i) {
-            if (ok[i]) {
-                float* pd = gW_dec + (int64_t)j * d + col[i];
-                float* pe = gW_encT + (int64_t)j * d + col[i];
-                if (whole) {
-                    *reinterpret_cast<float4*>(pd) = gd[i];
-                    *reinterpret_cast<float4*>(pe) = ge[i];
-                } else {
-                    unsafeAtomicAdd(pd, gd[i].x); unsafeAtomicAdd(pd + 1, gd[i].y); unsafeAtomicAdd(pd + 2, gd[i].z); unsafeAtomicAdd(pd + 3, gd[i].w);
-                    unsafeAtomicAdd(pe, ge[i].x); unsafeAtomicAdd(pe + 1, ge[i].y); unsafeAtomicAdd(pe + 2, ge[i].z); unsafeAtomicAdd(pe + 3, ge[i].w);
-                }
-            }
-            gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            ge[i] = gd[i];
-        }
-        if (lane == 0) {
-            if (whole) gb_enc[j] = gb;
-            else unsafeAtomicAdd(&gb_enc[j], gb);
-        }
+        for (int i = 0; i < V4; ++i) { gd[i] = make_float4(0.f, 0.f, 0.f, 0.f); ge[i] = gd[i]; }
         gb = 0.f;
+    }
+};
+
+// accumulate the pairs [q0, q1) (all of ONE feature when STOP_AT_LONG is false).  With STOP_AT_LONG the run is a chunk of
+// whole lists: a finished feature's rows are stored, and the walk ends at the first long list (the last list of a chunk).
+template <int V4, bool STOP_AT_LONG>
+__device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t q1, const uint32_t* __restrict__ offs,
+                                         const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
+                                         const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
+                                         const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT,
+                                         float* __restrict__ gb_enc, int d, int k, int lane, const int (&col)[V4], const bool (&ok)[V4]) {
+    int cur = -1;
+    auto store_rows = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i)
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col[i]) = acc.gd[i];
+                *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = acc.ge[i];
+            }
+        if (lane == 0) gb_enc[j] = acc.gb;
+        acc.clear();
     };
-    // The chunk's pair metadata is fetched up front, one pair per lane (<= BWD_CH + BWD_LMAX pairs: at most two rounds of
-    // 64), and broadcast with readlane: the only memory operations left in the loop are the row gathers, issued two
-    // pairs ahead of the accumulation (vmcnt retires loads in order, so nothing younger may sit between a gather and its
-    // use).
-    for (uint32_t base = q0; base < q1; base += 64) {
+    bool stop = false;
+    for (uint32_t base = q0; base < q1 && !stop; base += 64) {
         const int cnt = (int)min(64u, q1 - base);
         int my_n = 0, my_j = 0;
         float my_a = 0.f, my_g = 0.f;
@@ -552,57 +544,126 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
             }
         };
         auto accumulate = [&](const float4 (&dy)[V4], const float4 (&si)[V4], int t) {
-            const int j = __shfl(my_j, t, 64);
             const float a = __shfl(my_a, t, 64), g = __shfl(my_g, t, 64);
-            if (j != cur) {
-                flush(cur);
-                cur = j;
+            if constexpr (STOP_AT_LONG) {
+                const int j = __shfl(my_j, t, 64);
+                if (j != cur) {
+                    if (cur >= 0) store_rows(cur);
+                    cur = j;
+                    stop = offs[j + 1] - offs[j] > (uint32_t)BWD_LMAX;       // (uniform) the long-list kernel owns it
+                }
+                if (stop) return;
             }
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
-                gd[i].x += a * dy[i].x; gd[i].y += a * dy[i].y; gd[i].z += a * dy[i].z; gd[i].w += a * dy[i].w;      // d loss / d W_dec[j, :]
-                ge[i].x += g * si[i].x; ge[i].y += g * si[i].y; ge[i].z += g * si[i].z; ge[i].w += g * si[i].w;      // d loss / d W_enc[:, j]
+                acc.gd[i].x += a * dy[i].x; acc.gd[i].y += a * dy[i].y; acc.gd[i].z += a * dy[i].z; acc.gd[i].w += a * dy[i].w;
+                acc.ge[i].x += g * si[i].x; acc.ge[i].y += g * si[i].y; acc.ge[i].z += g * si[i].z; acc.ge[i].w += g * si[i].w;
             }
-            gb += g;
+            acc.gb += g;
         };
         gather(dy0, si0, 0);
         if (cnt > 1) gather(dy1, si1, 1);
-        for (int t = 0; t < cnt; t += 2) {
+        for (int t = 0; t < cnt && !stop; t += 2) {
             accumulate(dy0, si0, t);
             if (t + 2 < cnt) gather(dy0, si0, t + 2);
-            if (t + 1 < cnt) {
+            if (t + 1 < cnt && !stop) {
                 accumulate(dy1, si1, t + 1);
                 if (t + 3 < cnt) gather(dy1, si1, t + 3);
             }
         }
     }
-    flush(cur);
+    if constexpr (STOP_AT_LONG) {
+        if (!stop && cur >= 0) store_rows(cur);
+    }
 }
 
-// Per feature (one thread each): firing statistics (train_sae.py:356-361) from the CSR offsets, and zero gradient rows
-// for the features no backward wave will store -- the ones that did not fire (this IS their zero_grad) and the long-list
-// ones that several waves accumulate into with atomics.  Both are rare (a fraction of a percent of the features), so a
-// thread zeroes its two rows by itself.
-__global__ __launch_bounds__(256) void sae_rows_prep_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
-                                                            float* __restrict__ n_since_fired, float* __restrict__ fire_count,
-                                                            float* __restrict__ gW_dec, float* __restrict__ gW_encT,
-                                                            float* __restrict__ gb_enc, int d_sae, int d, int update_stats) {
+template <int V4>
+__global__ __launch_bounds__(256) void sae_backward_kernel(
+    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
+    const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
+    const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+    int d, int k, int n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_chunks) return;
+    const uint32_t q0 = chunk_start[wv], q1 = chunk_start[wv + 1];
+    if (q0 >= q1) return;
+    bool ok[V4];
+    int col[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+    }
+    BwdAcc<V4> acc;
+    acc.clear();
+    bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, d, k, lane, col, ok);
+}
+
+constexpr int BWD_LONG_WAVES = 16;
+
+template <int V4>
+__global__ __launch_bounds__(64 * BWD_LONG_WAVES) void sae_backward_long_kernel(
+    const uint32_t* __restrict__ offs, const int32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long,
+    const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
+    const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ gW_dec,
+    float* __restrict__ gW_encT, float* __restrict__ gb_enc, int d, int k) {
+    __shared__ float4 part[BWD_LONG_WAVES][2 * V4][64];
+    __shared__ float part_b[BWD_LONG_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool ok[V4];
+    int col[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+    }
+    const uint32_t nl = *n_long;
+    for (uint32_t f = blockIdx.x; f < nl; f += gridDim.x) {
+        const int j = long_list[f];
+        const uint32_t beg = offs[j], end = offs[j + 1];
+        const uint32_t per = (end - beg + BWD_LONG_WAVES - 1) / BWD_LONG_WAVES;
+        const uint32_t q0 = min(beg + wave * per, end), q1 = min(q0 + per, end);
+        BwdAcc<V4> acc;
+        acc.clear();
+        bwd_walk<V4, false>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, d, k, lane, col, ok);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            part[wave][2 * i][lane] = acc.gd[i];
+            part[wave][2 * i + 1][lane] = acc.ge[i];
+        }
+        if (lane == 0) part_b[wave] = acc.gb;
+        __syncthreads();
+        // waves 0 .. 2 V4 - 1 each sum one 16-byte column group over the 16 partials, in wave order
+        if (wave < 2 * V4) {
+            float4 t = part[0][wave][lane];
+            for (int w = 1; w < BWD_LONG_WAVES; ++w) {
+                const float4 u = part[w][wave][lane];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            const int i = wave >> 1;
+            if (ok[i]) *reinterpret_cast<float4*>(((wave & 1) ? gW_encT : gW_dec) + (int64_t)j * d + col[i]) = t;
+        }
+        if (threadIdx.x == 64 * BWD_LONG_WAVES - 1) {
+            float t = part_b[0];
+            for (int w = 1; w < BWD_LONG_WAVES; ++w) t += part_b[w];
+            gb_enc[j] = t;
+        }
+    }
+}
+
+// firing statistics per feature (train_sae.py:356-361) from the CSR offsets
+__global__ __launch_bounds__(256) void sae_stats_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
+                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
+                                                        int d_sae, int update_stats) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d_sae) return;
-    const uint32_t c = offs[j + 1] - offs[j];
-    const float cnt = (float)c;
+    const float cnt = (float)(offs[j + 1] - offs[j]);
     if (fire_count) fire_count[j] = cnt;
     if (update_stats) {
         act_freq[j] += cnt;
         n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
-    }
-    if (c == 0u || c > (uint32_t)BWD_LMAX) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int col = 0; col < d; col += 4) {
-            *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col) = z;
-            *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col) = z;
-        }
-        gb_enc[j] = 0.f;
     }
 }
 
@@ -833,6 +894,8 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.offs = take(((size_t)d.d_sae + 1) * 4);
     w.cursor = take((N * (size_t)d.k / BWD_CH + 8) * 4);      // chunk starts of the backward's waves
     w.wpos = take(N * (size_t)d.k * 4);
+    w.long_list = take((size_t)d.d_sae * 4);
+    w.n_long = take(256);
     w.pairs = take(N * (size_t)d.k * 4);
     w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS) * d.d_in * 4);
     w.colsum = take((size_t)d.d_in * 4);
@@ -984,6 +1047,38 @@ extern "C" int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, con
     return PV_OK;
 }
 
+// Inference forward of the module API (StandardSparseAutoencoder.forward / encode + decode, sae.py:557-645): top-k
+// encode + sparse decode + LN-out -> sae_out [N, d_in]; no gradients, no statistics.  scalars[1] (optional) receives the
+// mse loss over these N tokens taken as ONE batch (sae.py:144-149).
+extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t N, float* sae_out,
+                              int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, float* scalars, void* workspace,
+                              size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(plan && st && x && sae_out && topk_idx && topk_val && workspace, "null argument");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    int rc = sae_encode_topk(plan, st, x, N, nullptr, topk_idx, topk_val, false, wsb, ws, stream);
+    if (rc) return rc;
+    const dim3 grid((N + 3) / 4), block(256);
+#define CALL(D)                                                                                                      \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
+                       (const int32_t*)topk_idx, (const float*)topk_val, (const float*)(wsb + ws.mu),                \
+                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, (float*)nullptr, (float*)nullptr, \
+                       (float*)(wsb + ws.loss_part), N, d.d_in, d.k, 0.0f, 0)
+    V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+    PV_LAUNCH_CHECK("sae_decode_kernel");
+    if (scalars)
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), scalars, N,
+                           1.0f / ((float)N * (float)d.d_in), 1);
+    if (ln_mu) PV_HIP_CHECK(hipMemcpyAsync(ln_mu, wsb + ws.mu, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
+    if (ln_std) PV_HIP_CHECK(hipMemcpyAsync(ln_std, wsb + ws.sd, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
+    return PV_OK;
+}
+
 extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
                            int32_t n_global, int32_t update_stats, pv_sae_out* out, void* workspace,
                            size_t workspace_bytes, void* stream_) {
@@ -1027,21 +1122,29 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
         uint32_t* chunk_start = (uint32_t*)(wsb + ws.cursor);
         int32_t* pairs = (int32_t*)(wsb + ws.pairs);
+        int32_t* long_list = (int32_t*)(wsb + ws.long_list);
+        uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
         const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
+        // rows of the features that did not fire stay zero (this IS their zero_grad); every other row is stored exactly once
+        PV_HIP_CHECK(hipMemsetAsync(st->gW_dec, 0, (size_t)d.d_sae * d.d_in * 4, stream));
+        PV_HIP_CHECK(hipMemsetAsync(st->gW_enc, 0, (size_t)d.d_sae * d.d_in * 4, stream));
+        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)d.d_sae * 4, stream));
         hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, chunk_start, max_chunks,
-                           d.d_sae, out->scalars, 1.0f / (float)N);
+                           long_list, n_long, d.d_sae, out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
-        // statistics + zero rows of the features no wave will store (did not fire / long lists that accumulate atomically)
-        hipLaunchKernelGGL(sae_rows_prep_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
-                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae,
-                           d.d_in, update_stats);
+        hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
+                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, update_stats);
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
 #define CALL(D)                                                                                                        \
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
-                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_sae, d.d_in, k, max_chunks)
+                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_in, k, max_chunks);      \
+    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(512), dim3(64 * BWD_LONG_WAVES), 0, stream, (const uint32_t*)offs, \
+                       (const int32_t*)long_list, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
+                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, st->gW_dec,   \
+                       st->gW_enc, st->gb_enc, d.d_in, k)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");

@@ -23,7 +23,8 @@ from .. import _native as N
 
 class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
-                 layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5):
+                 layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False):
+        """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``."""
         for t in (W_enc, W_dec, b_enc, b_dec):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
                 raise N.NativeError("native SAE needs contiguous fp32 CUDA parameters")
@@ -45,13 +46,18 @@ class NativeSAE:
         nW = self.d_in * self.d_sae
         self.n_flat = 2 * nW + self.d_sae + self.d_in
         f32 = dict(dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(self.n_flat, **f32)
-        self.flat_m = torch.zeros(self.n_flat, **f32)
-        self.flat_v = torch.zeros(self.n_flat, **f32)
+        self.inference = bool(inference)
+        n_alloc = 0 if inference else self.n_flat
+        self.flat_g = torch.zeros(n_alloc, **f32)
+        self.flat_m = torch.zeros(n_alloc, **f32)
+        self.flat_v = torch.zeros(n_alloc, **f32)
 
         def views(flat: torch.Tensor) -> Dict[str, torch.Tensor]:
             o = 0
             out = {}
+            if flat.numel() == 0:                                  # inference engine: null pointers
+                z = flat.view(0, self.d_in)
+                return dict(W_encT=z, W_dec=z, b_enc=flat, b_dec=flat)
             out["W_encT"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["W_dec"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["b_enc"] = flat[o:o + self.d_sae]; o += self.d_sae
@@ -93,6 +99,10 @@ class NativeSAE:
     # ------------------------------------------------------------------------------------------
     def _state(self) -> N.SaeState:
         P, g, m, v = self.params, self._g, self._m, self._v
+        if self.inference:
+            return N.SaeState(W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(),
+                              b_dec=P["b_dec"].data_ptr(), W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(),
+                              enc_colsq=self.enc_colsq.data_ptr())
         return N.SaeState(
             W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(), b_dec=P["b_dec"].data_ptr(),
             gW_enc=g["W_encT"].data_ptr(), gW_dec=g["W_dec"].data_ptr(), gb_enc=g["b_enc"].data_ptr(), gb_dec=g["b_dec"].data_ptr(),
@@ -185,6 +195,17 @@ class NativeSAE:
                                             self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
                 "pv_sae_encode_topk")
         return self.topk_idx[:n], self.topk_val[:n], mu, sd
+
+    def forward(self, x: torch.Tensor):
+        """Inference: (sae_out [N, d_in], idx [N, k] int32, val [N, k]); the views are overwritten by the next call."""
+        x = self._check_x(x)
+        self._ensure_shadows()
+        n = x.shape[0]
+        st = self._state()
+        N.check(self.lib.pv_sae_forward(self._plan, C.byref(st), x.data_ptr(), n, self.sae_out.data_ptr(), self.topk_idx.data_ptr(),
+                                        self.topk_val.data_ptr(), None, None, self.scalars.data_ptr(), self.workspace.data_ptr(),
+                                        self.workspace.numel(), self._stream()), "pv_sae_forward")
+        return self.sae_out[:n], self.topk_idx[:n], self.topk_val[:n]
 
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:

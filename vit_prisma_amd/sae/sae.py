@@ -294,7 +294,67 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         self.b_enc = nn.Parameter(torch.zeros(self.d_sae, dtype=self.dtype, device=self.device))
         self.b_dec = nn.Parameter(torch.zeros(self.d_in, dtype=self.dtype, device=self.device))
 
+    # ---- native inference path (SAE substitution / evals run the SAE inside a ViT hook) ----------
+    def use_native(self, flag: Optional[bool]) -> "StandardSparseAutoencoder":
+        """None (default): ``forward`` / ``encode`` run on the HIP kernels whenever that is observationally identical
+        (see ``native_fallback_reason``); True: or raise; False: always PyTorch."""
+        self._native_pref = flag
+        return self
+
+    def _native_reason(self, x: torch.Tensor, need_hidden_pre: bool = False) -> Optional[str]:
+        cfg = self.cfg
+        if getattr(self, "_native_pref", None) is False:
+            return "disabled by use_native(False)"
+        if not x.is_cuda:
+            return "input is not on a GPU"
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return "autograd is recording (the native forward has no backward; wrap the call in torch.no_grad())"
+        if need_hidden_pre:
+            return "hidden_pre [N, d_sae] is never materialised by the native encoder"
+        if cfg.activation_fn_str != "topk" or not isinstance(self.activation_fn, TopK) or not isinstance(self.activation_fn.postact_fn, nn.ReLU):
+            return f"activation {cfg.activation_fn_str!r} (the native encoder is the top-k one)"
+        if cfg.normalize_activations not in ("layer_norm", "none", None):
+            return f"normalize_activations={cfg.normalize_activations!r}"
+        if self.dtype != torch.float32 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.parameters()):
+            return "parameters are not contiguous fp32 CUDA tensors"
+        k = cfg.activation_fn_kwargs.get("k", 0)
+        if not (cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 32768 and 1 <= k <= 64):
+            return "shape outside the native plan's limits"
+        if self.is_caching or any(hp.fwd_hooks or hp.bwd_hooks for hp in (self.hook_sae_in, self.hook_hidden_pre, self.hook_hidden_post, self.hook_sae_out)):
+            return "hooks on the SAE's own hook points"
+        return None
+
+    def _native_engine(self, n_tokens: int):
+        from .native_sae import NativeSAE
+        eng = getattr(self, "_engine", None)
+        stale = eng is not None and any(eng.params[n].data_ptr() != getattr(self, n).data_ptr() for n in ("W_enc", "W_dec", "b_enc", "b_dec"))
+        if eng is None or stale or eng.max_tokens < n_tokens:
+            eng = NativeSAE(self.W_enc, self.W_dec, self.b_enc, self.b_dec, k=self.cfg.activation_fn_kwargs["k"],
+                            layer_norm=self.cfg.normalize_activations == "layer_norm", max_tokens=max(n_tokens, 4096), inference=True)
+            object.__setattr__(self, "_engine", eng)          # (not a submodule / parameter)
+        return eng
+
+    def _native_dispatch(self, x: torch.Tensor, need_hidden_pre: bool = False) -> bool:
+        why = self._native_reason(x, need_hidden_pre)
+        self.native_fallback_reason = why
+        self.last_run_native = why is None
+        if why is not None and getattr(self, "_native_pref", None) is True:
+            from .._native import NativeError
+            raise NativeError(f"use_native(True): {why}")
+        return why is None
+
+    def _dense_acts(self, idx: torch.Tensor, val: torch.Tensor, lead_shape) -> torch.Tensor:
+        acts = torch.zeros(idx.shape[0], self.d_sae, dtype=self.dtype, device=idx.device)
+        acts.scatter_(1, idx.long(), val)                     # TopK.forward's dense output (sae.py:808-809)
+        return acts.view(*lead_shape, self.d_sae)
+
     def encode(self, x: torch.Tensor, return_hidden_pre: bool = False):
+        if self._native_dispatch(x, need_hidden_pre=return_hidden_pre):
+            xf = x.to(self.dtype)
+            sae_in = self.run_time_activation_norm_fn_in(xf) - self.b_dec          # (cheap elementwise; also sets ln_mu / ln_std for decode)
+            flat = xf.reshape(-1, self.d_in)
+            idx, val, _, _ = self._native_engine(flat.shape[0]).encode_topk(flat)
+            return sae_in, self._dense_acts(idx, val, x.shape[:-1])
         x = x.to(self.dtype)
         sae_in = self.hook_sae_in(self.run_time_activation_norm_fn_in(x) - self.b_dec)
         hidden_pre = self.hook_hidden_pre(sae_in @ self.W_enc + self.b_enc)
@@ -308,6 +368,19 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         return self.run_time_activation_norm_fn_out(sae_out)
 
     def forward(self, x: torch.Tensor, dead_neuron_mask: torch.Tensor = None, *args, **kwargs):
+        ghost_wanted = self.cfg.use_ghost_grads and self.training and dead_neuron_mask is not None
+        if not ghost_wanted and self._native_dispatch(x):
+            # top-k encode (filtered fp16 MFMA + exact re-scoring) + sparse decode + LN-out on the HIP kernels: the
+            # [N, d_sae] pre-activations are never formed; the dense feature_acts the API returns is scattered on demand
+            xf = x.to(self.dtype)
+            flat = xf.reshape(-1, self.d_in)
+            out, idx, val = self._native_engine(flat.shape[0]).forward(flat)
+            sae_out = out.clone().view(xf.shape)
+            if getattr(self.cfg, "return_out_only", False):
+                return sae_out
+            feature_acts = self._dense_acts(idx, val, x.shape[:-1])
+            mse_loss = self._compute_mse_loss(xf, sae_out)
+            return sae_out, feature_acts, mse_loss, mse_loss, None, self.zero_loss, torch.tensor(0.0)
         _, feature_acts, hidden_pre = self.encode(x, return_hidden_pre=True)
         sae_out = self.decode(feature_acts)
         mse_loss = self._compute_mse_loss(x, sae_out)
