@@ -366,8 +366,10 @@ def test_sae_substitution_style_eval_on_b32_bf16():
     x = torch.from_numpy(synth_images(arch, 8, 2)).cuda().bfloat16()
     name = "blocks.6.hook_resid_post"
     with torch.no_grad():
-        clean, _ = model.run_with_cache(x, names_filter=[])            # (an un-hooked forward() stays on PyTorch)
+        clean, _ = model.run_with_cache(x, names_filter=[])
         assert model.last_run_native
+        plain = model(x)                                               # an un-hooked no-grad forward is the same plan without taps
+        assert model.last_run_native and torch.equal(plain, clean)
         same = model.run_with_hooks(x, fwd_hooks=[(name, lambda t, hook: t.clone())])
         assert model.last_run_native and torch.equal(same, clean)
         zero = model.run_with_hooks(x, fwd_hooks=[(name, lambda t, hook: torch.zeros_like(t))])
@@ -503,3 +505,23 @@ def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning)
         _, one = model.run_with_cache(x[123:124])
     for k in big.keys():
         assert torch.equal(big[k][123], one[k][0]), k
+
+
+def test_plain_forward_is_native_and_the_autograd_fallback_warns_once():
+    model, arch, sd = build("tiny", torch.float32)
+    model.use_native(None)                                             # auto mode
+    x = torch.from_numpy(synth_images(arch, 2, 1)).cuda()
+    with torch.no_grad():
+        out = model(x)
+        assert model.last_run_native
+        o_ref, _ = vit_forward(sd, arch, synth_images(arch, 2, 1))
+        assert rel_fro(out.cpu().numpy(), o_ref) < FP32_TOL
+        mid = model(x, stop_at_layer=1)
+        assert model.last_run_native and mid.shape == (2, 17, 64)
+    import warnings
+    with warnings.catch_warnings(record=True) as w:                    # parameters require grad, no no_grad(): PyTorch path + ONE warning
+        warnings.simplefilter("always")
+        out2 = model(x)
+        model.run_with_cache(x)
+        assert not model.last_run_native and "autograd" in model.native_fallback_reason and out2.requires_grad
+    assert sum("PyTorch path" in str(m.message) for m in w) == 1

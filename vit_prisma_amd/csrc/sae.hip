@@ -414,15 +414,17 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 // between waves of the short-list kernel, none needs atomics, every row is written exactly once.
 constexpr int BWD_CH = 16;
 constexpr int BWD_LMAX = 64;
+constexpr int BWD_SEG = 32;
 
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ chunk_start, int max_chunks,
-                                                        int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long, int d_sae,
+                                                        int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                        uint32_t* __restrict__ seg_range, int max_segs, int d_sae,
                                                         float* __restrict__ scalars, float inv_tokens) {
     __shared__ uint32_t buf[32768];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t sh_nlong;
-    if (threadIdx.x == 0) sh_nlong = 0u;
+    __shared__ uint32_t sh_nlong, sh_nseg;
+    if (threadIdx.x == 0) { sh_nlong = 0u; sh_nseg = 0u; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < d_sae; i += 1024) buf[i] = cnt[i];
     __syncthreads();
@@ -447,10 +449,23 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         const uint32_t c = buf[i];
         buf[i] = run;
         run += c;
-        if (c > (uint32_t)BWD_LMAX) long_list[atomicAdd(&sh_nlong, 1u)] = i;
+        if (c > (uint32_t)BWD_LMAX) {
+            // a long list is cut into segments of BWD_SEG pairs, one wave each; long_list: {feature, first segment, #segments}
+            const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
+            const uint32_t sb = atomicAdd(&sh_nseg, nseg);
+            const uint32_t e = atomicAdd(&sh_nlong, 1u);
+            long_list[3 * e] = i;
+            long_list[3 * e + 1] = (int32_t)sb;
+            long_list[3 * e + 2] = (int32_t)nseg;
+            const uint32_t beg = run - c;
+            for (uint32_t sg = 0; sg < nseg && sb + sg < (uint32_t)max_segs; ++sg) {
+                seg_range[2 * (sb + sg)] = beg + sg * BWD_SEG;
+                seg_range[2 * (sb + sg) + 1] = min(beg + (sg + 1) * BWD_SEG, beg + c);
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0) *n_long = sh_nlong;
+    if (tid == 0) { n_long[0] = sh_nlong; n_long[1] = min(sh_nseg, (uint32_t)max_segs); }
     for (int i = tid; i < d_sae; i += 1024) offs[i] = buf[i];
     if (tid == 1023) {
         offs[d_sae] = total;
@@ -485,8 +500,10 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 // collapses on skewed data (8.6 ms / step measured), so the work is split by PAIRS:
 //   short lists (<= BWD_LMAX pairs)  sae_backward_kernel: wave w owns the chunk [chunk_start[w], chunk_start[w+1]) of whole
 //                                    lists (~BWD_CH pairs), accumulates per feature and stores each finished row once
-//   long lists                       sae_backward_long_kernel: a 16-wave workgroup per dense feature, 1/16 of the list
-//                                    per wave, partial rows summed through LDS in a fixed order, one store
+//   long lists                       cut into BWD_SEG-pair segments: sae_backward_seg_kernel (a wave per segment -> partial
+//                                    rows in scratch), then sae_backward_long_kernel (a wave per dense feature sums its
+//                                    segments in order, one store).  A feature that fires on all 4096 tokens is 128
+//                                    independent waves, not one long chain
 // Rows of features that did not fire are zeroed by the caller (this IS their zero_grad).  No atomics.
 // Shared inner loop: the pair metadata of a run is fetched up front, one pair per lane, and broadcast with readlane, so the
 // only memory operations inside the loop are the row gathers (16 bytes per lane), issued two pairs ahead of their use
@@ -600,17 +617,15 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, d, k, lane, col, ok);
 }
 
-constexpr int BWD_LONG_WAVES = 16;
-
+// long lists, stage 1: one wave per BWD_SEG-pair segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb)
 template <int V4>
-__global__ __launch_bounds__(64 * BWD_LONG_WAVES) void sae_backward_long_kernel(
-    const uint32_t* __restrict__ offs, const int32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long,
+__global__ __launch_bounds__(256) void sae_backward_seg_kernel(
+    const uint32_t* __restrict__ offs, const uint32_t* __restrict__ seg_range, const uint32_t* __restrict__ n_long,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
-    const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ gW_dec,
-    float* __restrict__ gW_encT, float* __restrict__ gb_enc, int d, int k) {
-    __shared__ float4 part[BWD_LONG_WAVES][2 * V4][64];
-    __shared__ float part_b[BWD_LONG_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ seg_rows,
+    float* __restrict__ seg_b, int d, int k) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nseg = n_long[1];
     bool ok[V4];
     int col[V4];
 #pragma unroll
@@ -618,38 +633,59 @@ __global__ __launch_bounds__(64 * BWD_LONG_WAVES) void sae_backward_long_kernel(
         col[i] = 4 * lane + 256 * i;
         ok[i] = col[i] < d;
     }
-    const uint32_t nl = *n_long;
-    for (uint32_t f = blockIdx.x; f < nl; f += gridDim.x) {
-        const int j = long_list[f];
-        const uint32_t beg = offs[j], end = offs[j + 1];
-        const uint32_t per = (end - beg + BWD_LONG_WAVES - 1) / BWD_LONG_WAVES;
-        const uint32_t q0 = min(beg + wave * per, end), q1 = min(q0 + per, end);
+    for (uint32_t sg = blockIdx.x * 4 + (threadIdx.x >> 6); sg < nseg; sg += gridDim.x * 4) {
         BwdAcc<V4> acc;
         acc.clear();
-        bwd_walk<V4, false>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, d, k, lane, col, ok);
-        __syncthreads();
+        bwd_walk<V4, false>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
+                            nullptr, d, k, lane, col, ok);
+        float* o = seg_rows + (int64_t)sg * 2 * d;
 #pragma unroll
-        for (int i = 0; i < V4; ++i) {
-            part[wave][2 * i][lane] = acc.gd[i];
-            part[wave][2 * i + 1][lane] = acc.ge[i];
-        }
-        if (lane == 0) part_b[wave] = acc.gb;
-        __syncthreads();
-        // waves 0 .. 2 V4 - 1 each sum one 16-byte column group over the 16 partials, in wave order
-        if (wave < 2 * V4) {
-            float4 t = part[0][wave][lane];
-            for (int w = 1; w < BWD_LONG_WAVES; ++w) {
-                const float4 u = part[w][wave][lane];
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        for (int i = 0; i < V4; ++i)
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(o + col[i]) = acc.gd[i];
+                *reinterpret_cast<float4*>(o + d + col[i]) = acc.ge[i];
             }
-            const int i = wave >> 1;
-            if (ok[i]) *reinterpret_cast<float4*>(((wave & 1) ? gW_encT : gW_dec) + (int64_t)j * d + col[i]) = t;
+        if (lane == 0) seg_b[sg] = acc.gb;
+    }
+}
+
+// long lists, stage 2: one wave per dense feature sums its segments' partial rows in segment order and stores
+template <int V4>
+__global__ __launch_bounds__(256) void sae_backward_long_kernel(
+    const int32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long, const float* __restrict__ seg_rows,
+    const float* __restrict__ seg_b, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+    int d, int max_segs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nl = n_long[0];
+    bool ok[V4];
+    int col[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+    }
+    for (uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6); f < nl; f += gridDim.x * 4) {
+        const int j = long_list[3 * f];
+        const uint32_t sb = (uint32_t)long_list[3 * f + 1], ns = (uint32_t)long_list[3 * f + 2];
+        BwdAcc<V4> acc;
+        acc.clear();
+        for (uint32_t sg = sb; sg < sb + ns && sg < (uint32_t)max_segs; ++sg) {
+            const float* o = seg_rows + (int64_t)sg * 2 * d;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                const float4 a = ld4(o + col[i], ok[i]), b = ld4(o + d + col[i], ok[i]);
+                acc.gd[i].x += a.x; acc.gd[i].y += a.y; acc.gd[i].z += a.z; acc.gd[i].w += a.w;
+                acc.ge[i].x += b.x; acc.ge[i].y += b.y; acc.ge[i].z += b.z; acc.ge[i].w += b.w;
+            }
+            acc.gb += seg_b[sg];
         }
-        if (threadIdx.x == 64 * BWD_LONG_WAVES - 1) {
-            float t = part_b[0];
-            for (int w = 1; w < BWD_LONG_WAVES; ++w) t += part_b[w];
-            gb_enc[j] = t;
-        }
+#pragma unroll
+        for (int i = 0; i < V4; ++i)
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col[i]) = acc.gd[i];
+                *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = acc.ge[i];
+            }
+        if (lane == 0) gb_enc[j] = acc.gb;
     }
 }
 
@@ -894,8 +930,14 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.offs = take(((size_t)d.d_sae + 1) * 4);
     w.cursor = take((N * (size_t)d.k / BWD_CH + 8) * 4);      // chunk starts of the backward's waves
     w.wpos = take(N * (size_t)d.k * 4);
-    w.long_list = take((size_t)d.d_sae * 4);
+    w.long_list = take((size_t)d.d_sae * 12);
     w.n_long = take(256);
+    {
+        const size_t max_segs = N * (size_t)d.k / BWD_SEG + N * (size_t)d.k / BWD_LMAX + 1;
+        w.seg_range = take(max_segs * 8);
+        w.seg_rows = take(max_segs * 2 * (size_t)d.d_in * 4);
+        w.seg_b = take(max_segs * 4);
+    }
     w.pairs = take(N * (size_t)d.k * 4);
     w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS) * d.d_in * 4);
     w.colsum = take((size_t)d.d_in * 4);
@@ -1129,8 +1171,12 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         PV_HIP_CHECK(hipMemsetAsync(st->gW_dec, 0, (size_t)d.d_sae * d.d_in * 4, stream));
         PV_HIP_CHECK(hipMemsetAsync(st->gW_enc, 0, (size_t)d.d_sae * d.d_in * 4, stream));
         PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)d.d_sae * 4, stream));
+        const int max_segs = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1;        // sum ceil(c / SEG) over lists with c > LMAX
+        uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
+        float* seg_rows = (float*)(wsb + ws.seg_rows);
+        float* seg_b = (float*)(wsb + ws.seg_b);
         hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, chunk_start, max_chunks,
-                           long_list, n_long, d.d_sae, out->scalars, 1.0f / (float)N);
+                           long_list, n_long, seg_range, max_segs, d.d_sae, out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
         hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
@@ -1141,10 +1187,13 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
                        (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_in, k, max_chunks);      \
-    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(512), dim3(64 * BWD_LONG_WAVES), 0, stream, (const uint32_t*)offs, \
-                       (const int32_t*)long_list, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
-                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, st->gW_dec,   \
-                       st->gW_enc, st->gb_enc, d.d_in, k)
+    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
+                       (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
+                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
+                       d.d_in, k);                                                                                     \
+    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
+                       (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
+                       st->gb_enc, d.d_in, max_segs)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");

@@ -220,8 +220,9 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         if (tid < 256) rowcnt[tid] = 0u;
         __syncthreads();
         const float* trw = trow + wm * 32 * MB;
+        uint32_t flushed = 0;                                      // list positions below this were flushed by earlier blocks
 #pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {
+        for (int mi = 0; mi < MB; ++mi) {                          // one 32-row block (64 rows of the tile) per round
             uint32_t m = 0;                                        // bit (g * 8 + s * 2 + ni)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -236,47 +237,52 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                         m |= (hit ? 1u : 0u) << (g * 8 + s * 2 + ni);
                     }
             }
-            if (__ballot(m != 0u) == 0ull) continue;               // (wave-uniform)
-            const int nh = __popc(m);
-            int incl = nh;
+            if (__ballot(m != 0u) != 0ull) {                       // (wave-uniform)
+                const int nh = __popc(m);
+                int incl = nh;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-            uint32_t base = 0;
-            if (lane == 63) base = atomicAdd(&hit_n, (uint32_t)incl);
-            base = __shfl(base, 63, 64);
-            uint32_t pos = base + (uint32_t)(incl - nh);
-            if (m != 0u) {
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&hit_n, (uint32_t)incl);
+                base = __shfl(base, 63, 64);
+                uint32_t pos = base + (uint32_t)(incl - nh) - flushed;
+                if (m != 0u) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            if (m & (1u << (g * 8 + s * 2 + ni))) {
-                                const int lrow = wm * 32 * MB + mi * 32 + 8 * g + 4 * half + s;
-                                if (pos < (uint32_t)HCAP)
-                                    hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
-                                                            __float_as_uint(acc[mi][ni][4 * g + s] + bias[ni]));
-                                else
-                                    atomicOr(&rowcnt[lrow], 0x80000000u);
-                                ++pos;
+                            for (int ni = 0; ni < 2; ++ni) {
+                                if (m & (1u << (g * 8 + s * 2 + ni))) {
+                                    const int lrow = wm * 32 * MB + mi * 32 + 8 * g + 4 * half + s;
+                                    if (pos < (uint32_t)HCAP)
+                                        hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
+                                                                __float_as_uint(acc[mi][ni][4 * g + s] + bias[ni]));
+                                    else
+                                        atomicOr(&rowcnt[lrow], 0x80000000u);
+                                    ++pos;
+                                }
                             }
-                        }
+                }
             }
+            // flush this block's hits (the list holds HCAP = 4096 of the block's 64 x 256 elements: beyond that the rows
+            // are marked overflowed above).  hit_n keeps counting; `flushed` rebases the positions of the next block.
+            __syncthreads();
+            const uint32_t total = hit_n;
+            const uint32_t nhit = min(total - flushed, (uint32_t)HCAP);
+            for (uint32_t e = tid; e < nhit; e += 512) {
+                const uint2 h = hlist[e];
+                const int lrow = (int)(h.x >> 8);
+                const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
+                if (li < (uint32_t)p.slots)
+                    p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * p.slots + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
+            }
+            flushed = total;
+            __syncthreads();
         }
-        __syncthreads();
-        const uint32_t nhit = min(hit_n, (uint32_t)HCAP);
-        for (uint32_t e = tid; e < nhit; e += 512) {
-            const uint2 h = hlist[e];
-            const int lrow = (int)(h.x >> 8);
-            const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
-            if (li < (uint32_t)p.slots)
-                p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * p.slots + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
-        }
-        __syncthreads();
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
             p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)p.slots ? 0xffffffffu : c;

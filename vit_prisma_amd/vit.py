@@ -316,18 +316,19 @@ class HookedViT(HookedRootModule):
         if self.native_mode != "off" and isinstance(input, torch.Tensor) and input.is_cuda:
             # run_with_hooks / `with model.hooks(...)` whose hooks all sit on block boundaries (SAE substitution,
             # zero-ablation: sae/evals/evals.py:321-392): the HIP plan runs in segments, Python only at the hooks
-            bh = self._boundary_hooks()
-            if bh != {} and not getattr(self, "_in_cache_fallback", False):
+            # ... and a plain, un-hooked model(x) outside autograd is the same plan with no taps at all
+            if not getattr(self, "_in_cache_fallback", False):
                 reason = self._native_reason((input,), {"stop_at_layer": stop_at_layer})
                 if reason is None:
                     out, _ = self._run_with_cache_native(input, False, names_filter=[], stop_at_layer=stop_at_layer)
                     self.last_run_native = True
                     self.native_fallback_reason = None
                     return out
-                if self.native_mode == "force":
+                if self.native_mode == "force" and self._boundary_hooks() != {}:
                     raise _native.NativeError(f"native forward with hooks impossible: {reason}")
                 self.last_run_native = False
                 self.native_fallback_reason = reason
+                self._warn_fallback_once(reason)
         embed = self.hook_embed(self.embed(input))
         if cfg.use_cls_token:
             embed = torch.cat((self.cls_token.expand(input.shape[0], -1, -1), embed), dim=1)
@@ -398,6 +399,17 @@ class HookedViT(HookedRootModule):
         after edits through ``param.data`` which do not bump the version counter)."""
         if self._native is not None:
             self._native._weights_key = None
+
+    def _warn_fallback_once(self, reason: Optional[str]) -> None:
+        """The commonest silent slow path: an eval-mode model whose parameters still require grad (the default after
+        load_state_dict) called outside torch.no_grad().  Say so once per model."""
+        if (reason and reason.startswith("autograd is recording") and not self.training
+                and not getattr(self, "_warned_autograd_fallback", False)):
+            self._warned_autograd_fallback = True
+            import warnings
+            warnings.warn("vit_prisma_amd: this call ran on the PyTorch path, not on the MI355X kernels, because autograd is "
+                          "recording (parameters require grad). Wrap inference in torch.no_grad() or call "
+                          "model.requires_grad_(False) to take the native path.", stacklevel=3)
 
     def freeze_native_weights(self, frozen: bool = True) -> None:
         """Promise that parameters do not change (skips the per-call change detection)."""
@@ -508,6 +520,7 @@ class HookedViT(HookedRootModule):
                 raise _native.NativeError(f"native run_with_cache impossible: {reason}")
             self.last_run_native = False
             self.native_fallback_reason = reason
+            self._warn_fallback_once(reason)
             self._in_cache_fallback = True
             try:
                 out, cache_dict = super().run_with_cache(*model_args, remove_batch_dim=remove_batch_dim, **kwargs)
