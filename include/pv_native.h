@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 7
+#define PV_ABI_VERSION 8
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -252,6 +252,7 @@ typedef struct pv_sae_state {
                                                       the exact re-scoring gathers rows from                          */
     uint16_t *W_enc16T;                            /* [d_sae, d_in] fp16 (B operand of the filter GEMM)               */
     float *enc_colsq;                              /* [d_sae] ||W_enc[:, j]||^2 (error bound of the filter)           */
+    float *dec_inv_norm;                           /* [d_sae] scratch of PV_SAE_RENORM_DECODER (1 / ||W_dec[j]||), or NULL */
 } pv_sae_state;
 
 /* Per-step outputs, caller-owned. */
@@ -275,9 +276,14 @@ int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
  * (train_sae.py:328-392 between zero_grad and clip).  Gradients are WRITTEN (not accumulated)
  * into st->g*.  `batch_mean` [d_in] is mean_n(x) over the GLOBAL batch (sae.py:145) -- pass NULL to
  * have it computed from x (single process); `n_global` scales the loss mean (N for 1 process).
- * update_stats: apply did_fire / act_freq updates (train_sae.py:356-361). */
+ * flags: PV_SAE_UPDATE_STATS    apply did_fire / act_freq updates (train_sae.py:356-361);
+ *        PV_SAE_RENORM_DECODER  set_decoder_norm_to_unit_norm (train_sae.py:307) as part of this step: the forward and
+ *                               backward use the unit-norm rows, the physical rewrite of W_dec is deferred to (and fused
+ *                               into) the following pv_sae_apply (needs st->dec_inv_norm). */
+#define PV_SAE_UPDATE_STATS 1
+#define PV_SAE_RENORM_DECODER 2
 int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
-                const float* batch_mean, int32_t n_global, int32_t update_stats, pv_sae_out* out,
+                const float* batch_mean, int32_t n_global, int32_t flags, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for

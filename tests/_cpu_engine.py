@@ -1,0 +1,96 @@
+"""A CPU stand-in with NativeSAE's interface, built from the oracle (test infrastructure only).
+
+The data-parallel orchestration of ``VisionSAETrainer._native_dp_step`` -- which collective moves what, which rows a rank
+clips / projects / updates, when the parameter all-gathers are waited for -- is plain host code around the engine's
+methods.  This twin lets that code run under gloo on CPU (world 2 and 4) where the HIP engine cannot."""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from oracle import sae_oracle as O
+
+
+class OracleEngine:
+    def __init__(self, sae, k: int, max_tokens: int):
+        self.params = {n: getattr(sae, n).data for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+        self.d_in, self.d_sae = self.params["W_enc"].shape
+        self.k, self.max_tokens = k, max_tokens
+        nW = self.d_in * self.d_sae
+        self.n_flat = 2 * nW + self.d_sae + self.d_in
+        z = lambda: torch.zeros(self.n_flat)                  # noqa: E731
+
+        def views(flat):
+            return dict(W_encT=flat[:nW].view(self.d_sae, self.d_in), W_dec=flat[nW:2 * nW].view(self.d_sae, self.d_in),
+                        b_enc=flat[2 * nW:2 * nW + self.d_sae], b_dec=flat[2 * nW + self.d_sae:])
+
+        self.flat_g, self.flat_m, self.flat_v = z(), z(), z()
+        self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
+        self.W_encT = self.params["W_enc"].t().contiguous()
+        self.fire_count = torch.zeros(self.d_sae)
+        self.scalars = torch.zeros(8)
+        self.act_freq_scores = torch.zeros(self.d_sae)
+        self.n_fwd_since_fired = torch.zeros(self.d_sae)
+        self.adam_step = 0
+        self.filtered_encoder = False
+
+    def _P(self):
+        return {n: t.numpy() for n, t in self.params.items()}          # (numpy views of the parameter storage)
+
+    def renorm_decoder(self):
+        O.renorm_decoder(self._P())
+
+    def step(self, x, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=False):
+        if renorm_decoder:
+            self.renorm_decoder()
+        P, xn = self._P(), x.numpy()
+        bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
+        fw = O.sae_forward(P, xn, self.k, batch_mean=bm, n_global=n_global)
+        g = O.sae_backward(P, xn, fw, n_global=n_global)
+        self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
+        for n in ("W_dec", "b_enc", "b_dec"):
+            self._g[n].copy_(torch.from_numpy(g[n]))
+        fire = (fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)
+        self.fire_count.copy_(torch.from_numpy(fire))
+        self.scalars[0], self.scalars[1], self.scalars[2] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"])
+        if update_stats:
+            self.act_freq_scores += self.fire_count
+            self.n_fwd_since_fired += 1
+            self.n_fwd_since_fired[self.fire_count > 0] = 0
+
+    def grad_sqnorm(self):
+        self.scalars[3] = float((self.flat_g.double() ** 2).sum())
+
+    def grad_sqnorm_rows(self, j_lo, j_hi, include_b_dec):
+        s = sum(float((self._g[n][j_lo:j_hi].double() ** 2).sum()) for n in ("W_encT", "W_dec", "b_enc"))
+        if include_b_dec:
+            s += float((self._g["b_dec"].double() ** 2).sum())
+        self.scalars[3] = s
+
+    def apply(self, lr, max_grad_norm, j_lo=0, j_hi=None):
+        j_hi = self.d_sae if j_hi is None else j_hi
+        self.adam_step += 1
+        total = float(self.scalars[3]) ** 0.5
+        coef = min(max_grad_norm / (total + 1e-6), 1.0) if max_grad_norm else 1.0
+        sl = slice(j_lo, j_hi)
+        rows = {"W_encT": (self.W_encT, sl), "W_dec": (self.params["W_dec"], sl), "b_enc": (self.params["b_enc"], sl),
+                "b_dec": (self.params["b_dec"], slice(None))}
+        P, g, m, v = {}, {}, {}, {}
+        for n, (w, s_) in rows.items():
+            P[n] = w[s_].numpy()
+            g[n] = (self._g[n][s_] * coef).numpy().copy()
+            m[n], v[n] = self._m[n][s_].numpy(), self._v[n][s_].numpy()
+        par = (g["W_dec"] * P["W_dec"]).sum(axis=1, keepdims=True)      # remove_gradient_parallel_to_decoder_directions
+        g["W_dec"] -= par * P["W_dec"]
+        O.adam_step(P, g, m, v, lr, self.adam_step)
+        self.params["W_enc"][:, sl] = self.W_encT[sl].t()               # the engine keeps W_enc in step with W_encT
+
+    def sync_shadows(self, from_transposed=False, j_lo=0, j_hi=None):
+        j_hi = self.d_sae if j_hi is None else j_hi
+        if from_transposed:
+            self.params["W_enc"][:, j_lo:j_hi] = self.W_encT[j_lo:j_hi].t()
+        else:
+            self.W_encT[j_lo:j_hi] = self.params["W_enc"][:, j_lo:j_hi].t()
+
+    def fallback_rows(self):
+        return 0

@@ -1,0 +1,106 @@
+"""The data-parallel SAE step with a feature-sharded optimizer on CPU: the trainer's own
+``_native_dp_step`` -- global batch mean all-reduce, reduce-scatter of the gradient rows, one small bucket (gb_dec | fire
+counts | loss, mse, l0), scalar all-reduce of the ranks' clip-norm terms, clip / project / Adam on the rank's rows only,
+asynchronous all-gather of the parameter rows -- runs under gloo with world 2 and world 4 around a CPU engine built from
+the oracle (tests/_cpu_engine.py), and must land on the single-process oracle's parameters, losses and statistics."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import sae_oracle as O
+from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state
+
+from conftest import rel_fro
+
+D_IN, D_SAE, K, N, STEPS = 32, 256, 4, 128, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, b_dec_init):
+    import torch.distributed as dist
+    from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
+    from _cpu_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                                    # ranks START with different parameters on purpose
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN, activation_fn_str="topk",
+        activation_fn_kwargs={"k": K}, normalize_activations="layer_norm", b_dec_init_method=b_dec_init, train_batch_size=N,
+        lr=1e-3, max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0, seed=7 + rank)
+    sae = StandardSparseAutoencoder(cfg)
+    if rank == 0:
+        with torch.no_grad():
+            for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae)
+    assert tr.world == world and tr._shard(D_SAE) == (rank * D_SAE // world, (rank + 1) * D_SAE // world)
+    # run the trainer's native branch on the CPU twin of the engine
+    tr._native_ok = lambda *a, **k: True
+    real_get = VisionSAETrainer._get_engine
+
+    def get_engine(s, n_tokens):
+        if tr._engine is None:
+            for p in s.parameters():                                  # what _get_engine does first under DP
+                dist.broadcast(p.data, src=0)
+            tr._engine = OracleEngine(s, K, n_tokens)
+        return tr._engine
+
+    tr._get_engine = get_engine
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    losses = []
+    for t in range(STEPS):
+        x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
+        xs = x[rank * (N // world):(rank + 1) * (N // world)][:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
+        losses.append((float(loss), float(l0)))
+        assert tr.last_step_native
+    assert len(tr._pending) == 3                                     # W_enc^T, W_dec, b_enc rows still in flight
+    tr.sync_parameters()
+    assert not tr._pending
+    out = {n: getattr(sae, n).detach().numpy().copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy(), frac))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_step_equals_single_process_oracle(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "mean")) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    P = {kk: v.copy() for kk, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    ref_losses = []
+    for t in range(STEPS):
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), K, lr=1e-3, step=t + 1)
+        ref_losses.append((ref["loss"], ref["l0"]))
+    for rank, params, losses, act, since, frac in got:
+        for n in P:                                                   # every rank holds the complete, identical parameters
+            assert rel_fro(params[n], P[n]) < 1e-5, (rank, n)
+            assert np.array_equal(params[n], got[0][1][n]), (rank, n)
+        for (l, l0), (rl, rl0) in zip(losses, ref_losses):
+            assert abs(l - rl) <= 1e-5 * abs(rl) and abs(l0 - rl0) < 1e-6
+        assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
+        assert frac == STEPS * N

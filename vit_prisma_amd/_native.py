@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -62,7 +62,7 @@ class SaeState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "W_enc", "W_dec", "b_enc", "b_dec", "gW_enc", "gW_dec", "gb_enc", "gb_dec",
         "mW_enc", "mW_dec", "mb_enc", "mb_dec", "vW_enc", "vW_dec", "vb_enc", "vb_dec",
-        "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq")]
+        "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq", "dec_inv_norm")]
 
 
 class SaeOut(C.Structure):

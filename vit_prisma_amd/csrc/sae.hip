@@ -312,7 +312,9 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ mu,
     const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out,
     float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
-    float grad_scale /* 2 / (N_global * d_in) */, int want_grad) {
+    float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm) {
+    // inv_norm != nullptr: set_decoder_norm_to_unit_norm is pending -- W_dec still holds the un-normalised rows and row j
+    // stands for W_dec[j] * inv_norm[j] (the Adam kernel writes the normalised + updated row; see pv_sae_step)
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -334,8 +336,10 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int su = min(s + u, k - 1);
+            const int ju = ir[su];
             a[u] = s + u < k ? vr[su] : 0.f;
-            const float* wr = W_dec + (int64_t)ir[su] * d;
+            if (inv_norm) a[u] *= inv_norm[ju];
+            const float* wr = W_dec + (int64_t)ju * d;
 #pragma unroll
             for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i]);
         }
@@ -374,11 +378,12 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
         float dot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* wr = W_dec + (int64_t)ir[min(s + u, k - 1)] * d;
+            const int ju = ir[min(s + u, k - 1)];
+            const float* wr = W_dec + (int64_t)ju * d;
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < V4; ++i) t += dot4(g[i], ld4(wr + col[i], ok[i]));
-            dot[u] = t;
+            dot[u] = inv_norm ? t * inv_norm[ju] : t;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -405,26 +410,24 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // CSR by feature of the active (token, slot) pairs
 // ------------------------------------------------------------------------------------------------
-// single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
-// contiguous runs scanned out of LDS, shuffles across threads, coalesced store of offs / cursor
-// Also (a) cuts the CSR-ordered pair sequence into the chunks the short-list backward's waves own -- nominally BWD_CH pairs
-// each, but a cut that would fall inside a list moves forward to that list's end, so a chunk is a run of WHOLE lists of
-// which only the last can be long -- and (b) collects the features with more than BWD_LMAX pairs (dense features: on the
-// bench batch 1.5 % of the features hold 36 % of the pairs) for the long-list kernel.  No gradient row is ever shared
-// between waves of the short-list kernel, none needs atomics, every row is written exactly once.
+// The pair counts per feature come out of the top-k selection (feat_cnt); csr_scan_kernel turns them into offsets,
+// csr_fill_kernel scatters the pairs (no atomics), csr_post_kernel (a) cuts the CSR-ordered pair sequence into the chunks
+// the short-list backward's waves own -- nominally BWD_CH pairs each, but a cut that would fall inside a list moves
+// forward to that list's end, so a chunk is a run of WHOLE lists of which only the last can be long -- and (b) registers
+// the features with more than BWD_LMAX pairs (dense features: on the bench batch 1.5 % of the features hold 36 % of the
+// pairs) with their BWD_SEG-pair segments.  No gradient row is ever shared between waves, none needs atomics, every row is
+// written exactly once.
 constexpr int BWD_CH = 16;
 constexpr int BWD_LMAX = 64;
 constexpr int BWD_SEG = 32;
 
+// single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
+// contiguous runs scanned out of LDS, shuffles across threads, coalesced store
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ chunk_start, int max_chunks,
-                                                        int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
-                                                        uint32_t* __restrict__ seg_range, int max_segs, int d_sae,
+                                                        uint32_t* __restrict__ n_long, int d_sae,
                                                         float* __restrict__ scalars, float inv_tokens) {
     __shared__ uint32_t buf[32768];
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t sh_nlong, sh_nseg;
-    if (threadIdx.x == 0) { sh_nlong = 0u; sh_nseg = 0u; }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < d_sae; i += 1024) buf[i] = cnt[i];
     __syncthreads();
@@ -449,43 +452,56 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         const uint32_t c = buf[i];
         buf[i] = run;
         run += c;
-        if (c > (uint32_t)BWD_LMAX) {
-            // a long list is cut into segments of BWD_SEG pairs, one wave each; long_list: {feature, first segment, #segments}
-            const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
-            const uint32_t sb = atomicAdd(&sh_nseg, nseg);
-            const uint32_t e = atomicAdd(&sh_nlong, 1u);
-            long_list[3 * e] = i;
-            long_list[3 * e + 1] = (int32_t)sb;
-            long_list[3 * e + 2] = (int32_t)nseg;
-            const uint32_t beg = run - c;
-            for (uint32_t sg = 0; sg < nseg && sb + sg < (uint32_t)max_segs; ++sg) {
-                seg_range[2 * (sb + sg)] = beg + sg * BWD_SEG;
-                seg_range[2 * (sb + sg) + 1] = min(beg + (sg + 1) * BWD_SEG, beg + c);
-            }
-        }
     }
     __syncthreads();
-    if (tid == 0) { n_long[0] = sh_nlong; n_long[1] = min(sh_nseg, (uint32_t)max_segs); }
     for (int i = tid; i < d_sae; i += 1024) offs[i] = buf[i];
     if (tid == 1023) {
         offs[d_sae] = total;
         if (scalars) scalars[2] = (float)total * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
     }
-    for (int w = tid; w <= max_chunks; w += 1024) {
-        const uint32_t g = (uint32_t)w * BWD_CH;
-        uint32_t sres = total;
-        if (g < total) {
-            int lo_j = 0, hi_j = d_sae;                                  // j = last feature with buf[j] <= g (the one holding pair g)
-            while (hi_j - lo_j > 1) {
-                const int mid = (lo_j + hi_j) >> 1;
-                if (buf[mid] <= g) lo_j = mid; else hi_j = mid;
-            }
-            const uint32_t beg = buf[lo_j], end = lo_j + 1 < d_sae ? buf[lo_j + 1] : total;
-            sres = g == beg ? g : end;
+    if (tid == 0) { n_long[0] = 0u; n_long[1] = 0u; }                 // counters of csr_post_kernel
+}
+
+// Per feature (one thread each), after the scan:
+//   * firing statistics (train_sae.py:356-361);
+//   * the chunk cuts of the short-list backward: the grid point g = w * BWD_CH that falls inside this feature's list
+//     [beg, end) becomes chunk_start[w] = end (beg itself when g == beg) -- every grid point below the total lies in
+//     exactly one list, so the scatter is disjoint; thread 0 fills the cuts at and beyond the total;
+//   * long lists (> BWD_LMAX pairs): registered in long_list {feature, first segment, #segments} with their
+//     BWD_SEG-pair segments in seg_range (two device counters, zeroed by the scan kernel).
+__global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restrict__ offs, uint32_t* __restrict__ chunk_start,
+                                                       int max_chunks, int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                       uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
+                                                       float* __restrict__ n_since_fired, float* __restrict__ fire_count,
+                                                       int d_sae, int update_stats) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d_sae) return;
+    const uint32_t beg = offs[j], end = offs[j + 1], c = end - beg;
+    const float cnt = (float)c;
+    if (fire_count) fire_count[j] = cnt;
+    if (update_stats) {
+        act_freq[j] += cnt;
+        n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
+    }
+    for (uint32_t w = (beg + BWD_CH - 1) / BWD_CH; w * BWD_CH < end; ++w) chunk_start[w] = w * BWD_CH == beg ? beg : end;
+    if (j == 0) {
+        const uint32_t total = offs[d_sae];
+        for (uint32_t w = (total + BWD_CH - 1) / BWD_CH; w <= (uint32_t)max_chunks; ++w) chunk_start[w] = total;
+    }
+    if (c > (uint32_t)BWD_LMAX) {
+        const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
+        const uint32_t sb = atomicAdd(&n_long[1], nseg);
+        const uint32_t e = atomicAdd(&n_long[0], 1u);
+        long_list[3 * e] = j;
+        long_list[3 * e + 1] = (int32_t)sb;
+        long_list[3 * e + 2] = (int32_t)nseg;
+        for (uint32_t sg = 0; sg < nseg && sb + sg < (uint32_t)max_segs; ++sg) {
+            seg_range[2 * (sb + sg)] = beg + sg * BWD_SEG;
+            seg_range[2 * (sb + sg) + 1] = min(beg + (sg + 1) * BWD_SEG, end);
         }
-        chunk_start[w] = sres;
     }
 }
+
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
                                                        const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int n_pairs) {
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -623,9 +639,9 @@ __global__ __launch_bounds__(256) void sae_backward_seg_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ seg_range, const uint32_t* __restrict__ n_long,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ seg_rows,
-    float* __restrict__ seg_b, int d, int k) {
+    float* __restrict__ seg_b, int d, int k, int max_segs) {
     const int lane = threadIdx.x & 63;
-    const uint32_t nseg = n_long[1];
+    const uint32_t nseg = min(n_long[1], (uint32_t)max_segs);
     bool ok[V4];
     int col[V4];
 #pragma unroll
@@ -669,15 +685,30 @@ __global__ __launch_bounds__(256) void sae_backward_long_kernel(
         const uint32_t sb = (uint32_t)long_list[3 * f + 1], ns = (uint32_t)long_list[3 * f + 2];
         BwdAcc<V4> acc;
         acc.clear();
-        for (uint32_t sg = sb; sg < sb + ns && sg < (uint32_t)max_segs; ++sg) {
-            const float* o = seg_rows + (int64_t)sg * 2 * d;
+        const uint32_t s_end = min(sb + ns, (uint32_t)max_segs);
+        for (uint32_t sg = sb; sg < s_end; sg += 4) {                 // four partial rows in flight, summed in segment order
+            float4 a[4][V4], b[4][V4];
+            float gb4[4];
 #pragma unroll
-            for (int i = 0; i < V4; ++i) {
-                const float4 a = ld4(o + col[i], ok[i]), b = ld4(o + d + col[i], ok[i]);
-                acc.gd[i].x += a.x; acc.gd[i].y += a.y; acc.gd[i].z += a.z; acc.gd[i].w += a.w;
-                acc.ge[i].x += b.x; acc.ge[i].y += b.y; acc.ge[i].z += b.z; acc.ge[i].w += b.w;
+            for (int u = 0; u < 4; ++u) {
+                const bool live = sg + u < s_end;
+                const float* o = seg_rows + (int64_t)(live ? sg + u : sg) * 2 * d;
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    a[u][i] = ld4(o + col[i], ok[i] && live);
+                    b[u][i] = ld4(o + d + col[i], ok[i] && live);
+                }
+                gb4[u] = live ? seg_b[sg + u] : 0.f;
             }
-            acc.gb += seg_b[sg];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    acc.gd[i].x += a[u][i].x; acc.gd[i].y += a[u][i].y; acc.gd[i].z += a[u][i].z; acc.gd[i].w += a[u][i].w;
+                    acc.ge[i].x += b[u][i].x; acc.ge[i].y += b[u][i].y; acc.ge[i].z += b[u][i].z; acc.ge[i].w += b[u][i].w;
+                }
+                acc.gb += gb4[u];
+            }
         }
 #pragma unroll
         for (int i = 0; i < V4; ++i)
@@ -686,20 +717,6 @@ __global__ __launch_bounds__(256) void sae_backward_long_kernel(
                 *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = acc.ge[i];
             }
         if (lane == 0) gb_enc[j] = acc.gb;
-    }
-}
-
-// firing statistics per feature (train_sae.py:356-361) from the CSR offsets
-__global__ __launch_bounds__(256) void sae_stats_kernel(const uint32_t* __restrict__ offs, float* __restrict__ act_freq,
-                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
-                                                        int d_sae, int update_stats) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= d_sae) return;
-    const float cnt = (float)(offs[j + 1] - offs[j]);
-    if (fire_count) fire_count[j] = cnt;
-    if (update_stats) {
-        act_freq[j] += cnt;
-        n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
     }
 }
 
@@ -759,11 +776,13 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
 template <int DPL>   // W_dec rows [j_lo, j_hi): one wave per row, with the parallel-gradient projection
 __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                         float* __restrict__ M, float* __restrict__ V,
-                                                        const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d) {
+                                                        const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d,
+                                                        const float* __restrict__ inv_norm) {
     const int lane = threadIdx.x & 63;
     const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= j_hi) return;
     const float coef = clip_coef(scalars, c.max_norm);
+    const float rn = inv_norm ? inv_norm[j] : 1.f;            // pending set_decoder_norm_to_unit_norm (see pv_sae_step)
     float w[DPL], g[DPL];
     float dot = 0.f;
 #pragma unroll
@@ -771,7 +790,7 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
         const int col = lane + 64 * i;
         w[i] = g[i] = 0.f;
         if (col < d) {
-            w[i] = W[(int64_t)j * d + col];
+            w[i] = W[(int64_t)j * d + col] * rn;
             g[i] = G[(int64_t)j * d + col] * coef;
             dot += g[i] * w[i];
         }
@@ -807,53 +826,75 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                                                         float* __restrict__ MT, float* __restrict__ VT,
                                                         const float* __restrict__ scalars, AdamC c, int d_in, int d_sae,
                                                         int j_lo, int j_hi) {
-    __shared__ float tile[32][33];
+    constexpr int NC = 2;                                     // 32-column chunks per iteration (16 independent loads per array)
+    __shared__ float tile[NC][32][33];
     const int j0 = j_lo + blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     float coef = 1.f;
     if constexpr (MODE == 0) coef = clip_coef(scalars, c.max_norm);
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
     bool big = false;
-    for (int i0 = 0; i0 < d_in; i0 += 32) {
+    for (int i0 = 0; i0 < d_in; i0 += 32 * NC) {
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                       // read W[i][j0 + tx] coalesced along j
-                const int i = i0 + ty + 8 * r, j = j0 + tx;
-                tile[tx][ty + 8 * r] = (i < d_in && j < j_hi) ? W[(int64_t)i * d_sae + j] : 0.f;
-            }
+            for (int u = 0; u < NC; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                   // read W[i][j0 + tx] coalesced along j
+                    const int i = i0 + 32 * u + ty + 8 * r, j = j0 + tx;
+                    tile[u][tx][ty + 8 * r] = (i < d_in && j < j_hi) ? W[(int64_t)i * d_sae + j] : 0.f;
+                }
             __syncthreads();
         }
+        float wv[NC][4], gv[NC][4], mv[NC][4], vv[NC][4];
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + ty + 8 * r, i = i0 + tx;
-            if (j < j_hi && i < d_in) {
-                const int64_t o = (int64_t)j * d_in + i;
-                float wn;
-                if constexpr (MODE == 0) {
-                    float m = MT[o], v = VT[o];
-                    wn = adam_update(WT[o], GT[o] * coef, m, v, c);
-                    MT[o] = m;
-                    VT[o] = v;
-                    WT[o] = wn;
-                } else if constexpr (MODE == 1) {
-                    wn = WT[o];
-                } else {
-                    wn = tile[ty + 8 * r][tx];
-                    WT[o] = wn;
+            for (int u = 0; u < NC; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + ty + 8 * r, i = i0 + 32 * u + tx;
+                    const bool in = j < j_hi && i < d_in;
+                    const int64_t o = (int64_t)j * d_in + i;
+                    wv[u][r] = in ? WT[o] : 0.f;
+                    gv[u][r] = in ? GT[o] : 0.f;
+                    mv[u][r] = in ? MT[o] : 0.f;
+                    vv[u][r] = in ? VT[o] : 0.f;
                 }
-                W16T[o] = (_Float16)wn;
-                sq[r] += wn * wn;
-                big = big || !(fabsf(wn) <= 6.0e4f);            // outside the fp16 range (or NaN): the filter must not be trusted
-                if constexpr (MODE != 2) tile[ty + 8 * r][tx] = wn;
-            }
         }
+#pragma unroll
+        for (int u = 0; u < NC; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + ty + 8 * r, i = i0 + 32 * u + tx;
+                if (j < j_hi && i < d_in) {
+                    const int64_t o = (int64_t)j * d_in + i;
+                    float wn;
+                    if constexpr (MODE == 0) {
+                        float m = mv[u][r], v = vv[u][r];
+                        wn = adam_update(wv[u][r], gv[u][r] * coef, m, v, c);
+                        MT[o] = m;
+                        VT[o] = v;
+                        WT[o] = wn;
+                    } else if constexpr (MODE == 1) {
+                        wn = WT[o];
+                    } else {
+                        wn = tile[u][ty + 8 * r][tx];
+                        WT[o] = wn;
+                    }
+                    W16T[o] = (_Float16)wn;
+                    sq[r] += wn * wn;
+                    big = big || !(fabsf(wn) <= 6.0e4f);        // outside the fp16 range (or NaN): the filter must not be trusted
+                    if constexpr (MODE != 2) tile[u][ty + 8 * r][tx] = wn;
+                }
+            }
         if constexpr (MODE != 2) {
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + ty + 8 * r, j = j0 + tx;
-                if (i < d_in && j < j_hi) W[(int64_t)i * d_sae + j] = tile[tx][ty + 8 * r];
-            }
+            for (int u = 0; u < NC; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 32 * u + ty + 8 * r, j = j0 + tx;
+                    if (i < d_in && j < j_hi) W[(int64_t)i * d_sae + j] = tile[u][tx][ty + 8 * r];
+                }
         }
         __syncthreads();
     }
@@ -877,6 +918,20 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, co
     W[i] = adam_update(W[i], G[i] * coef, m, v, c);
     M[i] = m;
     V[i] = v;
+}
+
+// 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm)
+__global__ __launch_bounds__(256) void dec_inv_norm_kernel(const float* __restrict__ W, float* __restrict__ inv, int rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    float sq = 0.f;
+    for (int c = 4 * lane; c < d; c += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)j * d + c);
+        sq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) inv[j] = 1.0f / sqrtf(sq);
 }
 
 // set_decoder_norm_to_unit_norm (sae.py:275-277)
@@ -1008,6 +1063,7 @@ extern "C" int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* 
     DPL_DISPATCH(d.d_in, CALL);
 #undef CALL
     PV_LAUNCH_CHECK("renorm_rows_kernel");
+    plan->renorm_pending = false;
     return PV_OK;
 }
 
@@ -1109,7 +1165,7 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
     hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
                        (const int32_t*)topk_idx, (const float*)topk_val, (const float*)(wsb + ws.mu),                \
                        (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, (float*)nullptr, (float*)nullptr, \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, d.k, 0.0f, 0)
+                       (float*)(wsb + ws.loss_part), N, d.d_in, d.k, 0.0f, 0, (const float*)nullptr)
     V4_DISPATCH(d.d_in, CALL);
 #undef CALL
     PV_LAUNCH_CHECK("sae_decode_kernel");
@@ -1122,8 +1178,10 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 }
 
 extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
-                           int32_t n_global, int32_t update_stats, pv_sae_out* out, void* workspace,
+                           int32_t n_global, int32_t flags, pv_sae_out* out, void* workspace,
                            size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    const bool renorm = (flags & PV_SAE_RENORM_DECODER) != 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
     PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
@@ -1138,6 +1196,18 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     unsigned char* wsb = (unsigned char*)workspace;
     const int k = d.k, n_pairs = N * k;
 
+    // set_decoder_norm_to_unit_norm (train_sae.py:307) as part of the step: instead of a read-modify-write pass over
+    // W_dec (151 MB), only the inverse row norms are computed (75 MB read); decode / dh use W_dec[j] * inv_norm[j] on the
+    // fly and pv_sae_apply writes the normalised + updated rows -- W_dec holds exactly what the reference's holds at every
+    // step boundary (un-normalised after the optimizer step, as there).
+    PV_REQUIRE(!renorm || st->dec_inv_norm, "PV_SAE_RENORM_DECODER needs pv_sae_state.dec_inv_norm");
+    const float* inv_norm = nullptr;
+    plan->renorm_pending = renorm;
+    if (renorm) {
+        hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const float*)st->W_dec,
+                           st->dec_inv_norm, d.d_sae, d.d_in);
+        inv_norm = st->dec_inv_norm;
+    }
     int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, true, wsb, ws, stream);
     if (rc) return rc;
 
@@ -1152,7 +1222,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
                        (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)(wsb + ws.mu),      \
                        (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, dh,             \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1)
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
@@ -1175,12 +1245,13 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
         float* seg_rows = (float*)(wsb + ws.seg_rows);
         float* seg_b = (float*)(wsb + ws.seg_b);
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, chunk_start, max_chunks,
-                           long_list, n_long, seg_range, max_segs, d.d_sae, out->scalars, 1.0f / (float)N);
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
+                           out->scalars, 1.0f / (float)N);
+        hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
+                           max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
+                           out->fire_count, d.d_sae, update_stats);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
-        hipLaunchKernelGGL(sae_stats_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs,
-                           st->act_freq_scores, st->n_fwd_since_fired, out->fire_count, d.d_sae, update_stats);
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
 #define CALL(D)                                                                                                        \
@@ -1190,7 +1261,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
                        (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
                        (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
-                       d.d_in, k);                                                                                     \
+                       d.d_in, k, max_segs);                                                                                     \
     hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
                        (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
                        st->gb_enc, d.d_in, max_segs)
@@ -1262,7 +1333,8 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     ProfScope prof(PV_PROF_SAE_APPLY, stream, 0.0, 7.0 * 4.0 * (2.0 * d.d_in * (double)nj + nj + d.d_in) + 6.0 * d.d_in * (double)nj);
     const dim3 block(256);
     if (nj > 0) {
-#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in)
+        const float* inv_norm = plan->renorm_pending ? (const float*)st->dec_inv_norm : nullptr;
+#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm)
         DPL_DISPATCH(d.d_in, CALL);
 #undef CALL
         hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
@@ -1273,5 +1345,6 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, st->b_dec, (const float*)st->gb_dec,
                        st->mb_dec, st->vb_dec, scalars, c, 0, d.d_in);
     PV_LAUNCH_CHECK("adam kernels");
+    if (j_lo == 0 && j_hi == d.d_sae) plan->renorm_pending = false;      // (a sharded apply leaves the other ranks' rows to the all-gather)
     return PV_OK;
 }

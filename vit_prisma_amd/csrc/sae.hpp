@@ -12,6 +12,7 @@ constexpr int PV_SAE_FB_SLOTS = 32;          // workgroup columns of the fallbac
 
 struct pv_sae_plan {
     pv_sae_desc d;
+    bool renorm_pending = false;     // the last pv_sae_step deferred set_decoder_norm_to_unit_norm to pv_sae_apply
 };
 
 struct SaeWs {

@@ -342,9 +342,12 @@ __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict_
                                                         uint32_t* __restrict__ fb_count) {
     __shared__ float red[16];
     float m = 0.f;
-    for (int j = threadIdx.x; j < d_sae; j += 1024) {
-        const float c = colsq[j];
-        m = (c == c) ? fmaxf(m, c) : INFINITY;                // a NaN column norm poisons the bound (-> exact fallback)
+    for (int j0 = threadIdx.x; j0 < d_sae; j0 += 8 * 1024) {  // 8 independent loads in flight per thread
+        float c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = j0 + u * 1024 < d_sae ? colsq[j0 + u * 1024] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = (c[u] == c[u]) ? fmaxf(m, c[u]) : INFINITY;      // a NaN column norm poisons the bound (-> exact fallback)
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

@@ -75,6 +75,7 @@ class NativeSAE:
         self.W_encT = torch.empty(self.d_sae, self.d_in, **f32)
         self.W_enc16T = torch.empty(self.d_sae, self.d_in, dtype=torch.float16, device=dev)
         self.enc_colsq = torch.zeros(self.d_sae, **f32)
+        self.dec_inv_norm = torch.ones(self.d_sae, **f32)
         self.act_freq_scores = torch.zeros(self.d_sae, **f32)
         self.n_fwd_since_fired = torch.zeros(self.d_sae, **f32)
         self.fire_count = torch.zeros(self.d_sae, **f32)
@@ -109,7 +110,8 @@ class NativeSAE:
             mW_enc=m["W_encT"].data_ptr(), mW_dec=m["W_dec"].data_ptr(), mb_enc=m["b_enc"].data_ptr(), mb_dec=m["b_dec"].data_ptr(),
             vW_enc=v["W_encT"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
             act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr(),
-            W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(), enc_colsq=self.enc_colsq.data_ptr())
+            W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(), enc_colsq=self.enc_colsq.data_ptr(),
+            dec_inv_norm=self.dec_inv_norm.data_ptr())
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -146,9 +148,10 @@ class NativeSAE:
         N.check(self.lib.pv_sae_renorm_decoder(self._plan, C.byref(st), self._stream()), "pv_sae_renorm_decoder")
 
     def step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
-             update_stats: bool = True, want_out: bool = False) -> None:
+             update_stats: bool = True, want_out: bool = False, renorm_decoder: bool = False) -> None:
         """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
-        loss, mse_loss, l0 (device)."""
+        loss, mse_loss, l0 (device).  renorm_decoder: set_decoder_norm_to_unit_norm as part of the step (the rewrite of
+        W_dec is fused into the following ``apply``) instead of a separate ``renorm_decoder()`` pass."""
         x = self._check_x(x)
         self._ensure_shadows()
         n = x.shape[0]
@@ -160,7 +163,8 @@ class NativeSAE:
         if batch_mean is not None:
             bm = batch_mean.to(torch.float32).contiguous()
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
-                                     int(n_global if n_global is not None else n), int(update_stats), C.byref(out),
+                                     int(n_global if n_global is not None else n),
+                                     int(bool(update_stats)) | (2 if renorm_decoder else 0), C.byref(out),
                                      self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_step")
 
     def grad_sqnorm(self) -> None:
@@ -209,8 +213,7 @@ class NativeSAE:
 
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:
-        self.renorm_decoder()
-        self.step(x)
+        self.step(x, renorm_decoder=True)
         self.grad_sqnorm()
         self.apply(lr, max_grad_norm)
 

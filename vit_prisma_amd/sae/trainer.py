@@ -258,9 +258,8 @@ class VisionSAETrainer:
         # statistics tensors are the caller's: the kernels update them in place
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
-        eng.renorm_decoder()                                    # set_decoder_norm_to_unit_norm
         if self.world == 1:
-            eng.step(x, update_stats=True)
+            eng.step(x, update_stats=True, renorm_decoder=True)  # set_decoder_norm_to_unit_norm is part of the step
             eng.grad_sqnorm()                                   # clip_grad_norm_
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
@@ -276,7 +275,7 @@ class VisionSAETrainer:
         n_global = x.shape[0] * W
         bm = x.float().sum(dim=0)
         dist.all_reduce(bm)                                     # global batch mean (sae.py:145)
-        eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False)
+        eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
         shard = self._shard(eng.d_sae)
         d_in, d_sae = eng.d_in, eng.d_sae
         if self._small is None or self._small.numel() != d_in + d_sae + 3:
