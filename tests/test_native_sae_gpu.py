@@ -415,3 +415,34 @@ def test_deferred_decoder_renorm_equals_the_explicit_pass():
         for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
             assert rel_fro(b.params[name].cpu().numpy(), a.params[name].cpu().numpy()) < 1e-6, (t, name)
     assert float((b.params["W_dec"].norm(dim=1) - 1).abs().max()) > 1e-5               # un-normalised after the optimizer step
+
+
+def test_activation_cache_shards_written_from_the_native_harvest_match_the_references():
+    """SURVEY.md 8f row 2 on the GPU: generate_cached_activations_from_dataset driven by the native run_with_cache writes the
+    {idx}.pt fp16 shards the REFERENCE's writer produced for the same images (tests/golden/act_cache_tiny/)."""
+    import tempfile
+    from vit_prisma_amd.sae import CacheVisionActivationStore
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    gold = os.path.join(GOLDEN, "act_cache_tiny")
+    ref = np.load(os.path.join(gold, "reference_reader.npz"))
+    arch = ARCHS["tiny"]
+    vit = HookedViT(HookedViTConfig(**arch, device="cuda"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    vit = vit.cuda().eval().use_native(True)
+    imgs = torch.from_numpy(ref["images"])
+    ds = torch.utils.data.TensorDataset(imgs, torch.zeros(len(imgs), dtype=torch.long))
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = VisionModelSAERunnerConfig(
+            hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=8, activation_fn_str="topk",
+            activation_fn_kwargs={"k": 8}, context_size=17, store_batch_size=2, n_batches_in_buffer=4, train_batch_size=16,
+            cached_activations_path=os.path.join(tmp, "cache"), use_cached_activations=True, _device="cuda", log_to_wandb=False)
+        store = VisionActivationsStore(cfg, vit, ds, create_dataloader=False)
+        assert store.generate_cached_activations_from_dataset(tokens_per_file=50) == 3 and vit.last_run_native
+        for i, rows in enumerate((50, 50, 19)):
+            ours, theirs = torch.load(os.path.join(tmp, "cache", f"{i}.pt")), torch.load(os.path.join(gold, f"{i}.pt"))
+            assert ours.dtype == torch.float16 and tuple(ours.shape) == (rows, 1, 64) == tuple(theirs.shape)
+            assert torch.allclose(ours.float(), theirs.float(), atol=4e-3, rtol=2e-3), i       # one fp16 ulp at |x| ~ 4
+        # and the reader serves training batches from them on the GPU
+        reader = CacheVisionActivationStore(cfg)
+        b = reader.next_batch()
+        assert b.is_cuda and b.shape == (16, 1, 64)

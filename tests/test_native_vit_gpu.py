@@ -31,8 +31,10 @@ FP32_TOL = 1e-4
 # One documented exception class: ``*.hook_scale`` -- fp32 per-token scalars sqrt(mean(x^2) + eps) of a bf16 residual
 # stream (budget 2e-4 .. 5e-4).  Their error is the rounding noise of that stream, which is independent of (and as large
 # as) the reference's, so the per-key ratio scatters around 1 (measured 0.93 .. 1.13): held to 1.25 x.
-# BF16_SLACK: the budget was computed with torch's norm, the test with numpy's -- identical tensors differ by 1e-13.
-BF16_SLACK = 1.0 + 1e-6
+# BF16_SLACK: "1.0 x" is asserted up to 1e-4 relative: the early keys reproduce the reference's bf16 tensors up to a
+# handful of differently rounded elements (measured ratios 1.000000 .. 1.000004), and the budget itself was computed with
+# torch's norm, the test with numpy's.
+BF16_SLACK = 1.0 + 1e-4
 
 
 def bf16_limit(key: str, budget_rel_fro: float) -> float:
@@ -525,3 +527,49 @@ def test_plain_forward_is_native_and_the_autograd_fallback_warns_once():
         model.run_with_cache(x)
         assert not model.last_run_native and "autograd" in model.native_fallback_reason and out2.requires_grad
     assert sum("PyTorch path" in str(m.message) for m in w) == 1
+
+
+def _hook_cases():
+    def scale_shift(t, hook):
+        return t * 0.5 + 1.0
+
+    def zero(t, hook):
+        return torch.zeros_like(t)
+
+    def edit_cls(t, hook):
+        t[:, 0] = 0.25
+
+    return {"A": [("blocks.6.hook_resid_post", scale_shift)],
+            "B": [("blocks.3.hook_attn_out", zero), ("blocks.9.hook_resid_mid", edit_cls)]}
+
+
+def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
+    """SURVEY.md 8f row 1 at the real size: run_with_cache(fwd_hooks=[replacing / ablating / in-place hooks]) on the split
+    native plan against what the REFERENCE produced for the same hooks (tests/golden/vit_b32_hooks_bs4.json, generated by
+    executing it): fp32 fingerprints at 1e-4, bf16 held to the reference's own bf16 error under the same hooks."""
+    with open(os.path.join(GOLDEN, "vit_b32_hooks_bs4.json")) as f:
+        G = json.load(f)
+    keys = G["keys"]
+    m32, arch, _ = build("clip-vit-b32", torch.float32)
+    m16, _, _ = build("clip-vit-b32", torch.bfloat16)
+    imgs = synth_images(arch, G["batch"], G["seed"])
+    for name, hooks in _hook_cases().items():
+        want = G["cases"][name]
+        out, cache = run(m32, imgs, torch.float32, fwd_hooks=hooks, names_filter=keys)
+        assert list(cache.keys()) == keys
+        for k in keys + ["__out__"]:
+            got = (out if k == "__out__" else cache[k]).cpu().numpy()
+            fp, gw = fingerprint(got), (want["out"] if k == "__out__" else want["cache"][k])
+            assert fp["shape"] == gw["shape"], (name, k)
+            assert abs(fp["l2"] - gw["l2"]) <= FP32_TOL * max(gw["l2"], 1e-6), (name, k)
+            vw = np.array(gw["vals"])
+            assert np.max(np.abs(np.array(fp["vals"]) - vw)) <= 1e-3 * max(np.max(np.abs(vw)), gw["l2"] / np.sqrt(got.size), 1e-6), (name, k)
+        out16, cache16 = run(m16, imgs, torch.bfloat16, fwd_hooks=hooks, names_filter=keys)
+        for k in keys + ["__out__"]:
+            ref = (out if k == "__out__" else cache[k]).cpu().numpy()
+            got = (out16 if k == "__out__" else cache16[k]).float().cpu().numpy()
+            budget = want["bf16_budget"][k]
+            if budget == 0.0:
+                assert np.abs(got).max() == 0.0, (name, k)               # the zero-ablated tensor itself
+            else:
+                assert rel_fro(got, ref) <= bf16_limit(k, budget), (name, k, rel_fro(got, ref), budget)

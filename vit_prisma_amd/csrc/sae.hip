@@ -920,18 +920,27 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, co
     V[i] = v;
 }
 
-// 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm)
+// 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm): a wave takes four rows, all loads in flight
 __global__ __launch_bounds__(256) void dec_inv_norm_kernel(const float* __restrict__ W, float* __restrict__ inv, int rows, int d) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= rows) return;
-    float sq = 0.f;
+    const int j0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (j0 >= rows) return;
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 4 * lane; c < d; c += 256) {
-        const float4 w = *reinterpret_cast<const float4*>(W + (int64_t)j * d + c);
-        sq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+        float4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = ld4(W + (int64_t)min(j0 + u, rows - 1) * d + c, true);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq[u] += w[u].x * w[u].x + w[u].y * w[u].y + w[u].z * w[u].z + w[u].w * w[u].w;
     }
-    sq = wave_sum(sq);
-    if (lane == 0) inv[j] = 1.0f / sqrtf(sq);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq[u] += __shfl_xor(sq[u], o, 64);
+    if (lane < 4 && j0 + lane < rows) {
+        const float s = lane == 0 ? sq[0] : (lane == 1 ? sq[1] : (lane == 2 ? sq[2] : sq[3]));
+        inv[j0 + lane] = 1.0f / sqrtf(s);
+    }
 }
 
 // set_decoder_norm_to_unit_norm (sae.py:275-277)
@@ -1204,7 +1213,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     const float* inv_norm = nullptr;
     plan->renorm_pending = renorm;
     if (renorm) {
-        hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const float*)st->W_dec,
+        hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 15) / 16), dim3(256), 0, stream, (const float*)st->W_dec,
                            st->dec_inv_norm, d.d_sae, d.d_in);
         inv_norm = st->dec_inv_norm;
     }

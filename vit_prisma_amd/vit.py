@@ -329,6 +329,9 @@ class HookedViT(HookedRootModule):
                 self.last_run_native = False
                 self.native_fallback_reason = reason
                 self._warn_fallback_once(reason)
+        elif not getattr(self, "_in_cache_fallback", False):
+            self.last_run_native = False
+            self.native_fallback_reason = "native_mode == 'off'" if self.native_mode == "off" else "input is not on a GPU"
         embed = self.hook_embed(self.embed(input))
         if cfg.use_cls_token:
             embed = torch.cat((self.cls_token.expand(input.shape[0], -1, -1), embed), dim=1)
