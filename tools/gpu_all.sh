@@ -1,5 +1,5 @@
 # full GPU regression: every -m gpu test, SAE step bench + kernel stats
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c7; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c9; rm -rf $O; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests/ -m gpu -q > $O/tests_gpu.log 2>&1; echo "tests rc=$?" >> $O/tests_gpu.log
 timeout 300 python -c "

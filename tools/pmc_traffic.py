@@ -26,5 +26,5 @@ for k in sorted(set(F) | set(W)):
                          "WRITE_SIZE_KB_per_launch": round(w, 1), "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024)}
 json.dump(res, open(out, "w"), indent=1)
 for k, v in res["kernels"].items():
-    if any(s in k for s in ("gemm", "attn", "ln_kernel", "sae", "adam", "topk")):
+    if any(s in k for s in ("gemm", "attn", "ln_kernel", "sae", "adam", "topk", "wenc", "csr", "inv_norm")):
         print(k[:60], v)
