@@ -573,3 +573,33 @@ def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
                 assert np.abs(got).max() == 0.0, (name, k)               # the zero-ablated tensor itself
             else:
                 assert rel_fro(got, ref) <= bf16_limit(k, budget), (name, k, rel_fro(got, ref), budget)
+
+
+@pytest.mark.parametrize("image_size,patch,kernel", [(224, 16, "strip"), (224, 16, "stream"), (208, 13, "strip"), (400, 16, "stream")])
+def test_bf16_long_sequence_attention_kernels(image_size, patch, kernel, tuning):
+    """The two T > 64 bf16 attention kernels on token counts other than L/14's 577: T = 197 (odd: head blocks of the
+    taps only 2-byte aligned), 257 (one key past a tile edge), 626 (> 600: beyond the strip kernel's LDS budget, the
+    two-pass kernel takes it).  scores / pattern / z against an fp32 recompute from the q, k, v the same run cached."""
+    cfg = dict(n_layers=1, d_model=128, n_heads=2, d_head=64, d_mlp=256, patch_size=patch, image_size=image_size, n_channels=3,
+               n_classes=16, eps=1e-5, layer_norm_pre=True, normalize_output=True, return_type="class_logits",
+               activation_name="gelu", use_cls_token=True, normalization_type="LN", classification_type="cls")
+    if kernel == "stream":
+        tuning("attn_stream", 1)
+    model = HookedViT(HookedViTConfig(**cfg, dtype=torch.bfloat16, device="cuda")).to(torch.bfloat16).cuda().eval().use_native(True)
+    T = (image_size // patch) ** 2 + 1
+    x = torch.randn(3, 3, image_size, image_size, device="cuda", generator=torch.Generator(device="cuda").manual_seed(T)).bfloat16()
+    with torch.no_grad():
+        _, cache = model.run_with_cache(x)
+        _, only_z = model.run_with_cache(x, names_filter="blocks.0.attn.hook_z")           # no taps at all
+    assert model.last_run_native
+    q, k, v = (cache["blocks.0.attn." + n].float() for n in ("hook_q", "hook_k", "hook_v"))
+    s_ref = torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0
+    s_got = cache["blocks.0.attn.hook_attn_scores"].float()
+    assert s_got.shape == (3, 2, T, T)
+    assert float((s_got - s_ref).abs().max()) <= 2 ** -8 * float(s_ref.abs().max()) + 1e-6
+    p_got = cache["blocks.0.attn.hook_pattern"].float()
+    assert float((p_got - torch.softmax(s_got, dim=-1)).abs().max()) <= 2 ** -8
+    z_ref = torch.einsum("bhqk,bkhd->bqhd", p_got, v)
+    z_got = cache["blocks.0.attn.hook_z"].float()
+    assert float((z_got - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6
+    assert torch.equal(only_z["blocks.0.attn.hook_z"], cache["blocks.0.attn.hook_z"])

@@ -772,6 +772,261 @@ int launch_attn_stream(const AttnParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Long-sequence variant, single pass over the keys (bf16, 64 < T <= 600, d_head 64): the wave's 32-query x T score strip
+// lives in LDS (32 x roundup16(2 T) bytes = 36.5 KB at T = 577; four strips per workgroup = one workgroup per CU), so
+//   pass A  K streamed ONCE: S^T = K Q^T tile on MFMA, scaled + rounded to bf16 like the reference's score tensor,
+//           online (max, sum) per lane, the tile parked in the strip (8-byte pieces in the MFMA C layout)
+//   [tap]   hook_attn_scores = the strip, flushed row by row (below)
+//   pass B  V streamed once: the tile comes back out of the strip, p = exp(s - max) / sum rounded to bf16, moves to the
+//           A-operand layout (one cross-half exchange per k16 step), goes back into the strip as 16-byte pieces and
+//           feeds z += P V on MFMA; V is staged TRANSPOSED ([d][key]) so a B fragment is one ds_read_b128
+//   [tap]   hook_pattern = the strip, flushed
+// Flush: a query row is 2 T contiguous bytes of the head's [T][T] block, but the block is only 2-byte aligned when T is
+// odd -- the row is written as 16-byte-aligned global chunks whose LDS source is realigned ONCE per chunk with
+// v_alignbyte (the strip rows are 16-byte aligned), plus <= 7 two-byte stores at each end.  QK^T is computed once
+// (attn_stream_kernel: twice), the taps leave as full 16-byte stores (there: 32-byte pieces with funnel shifts per piece).
+// ---------------------------------------------------------------------------------------------------
+constexpr int ST_KROW = 144;                // K tile row: 128 B + 16 pad
+constexpr int ST_VROW = 80;                 // V^T tile row: 32 keys x 2 B + 16 pad
+
+__device__ __forceinline__ int st_strip_bytes(int T) { return 32 * ((2 * T + 15) / 16 * 16) + 32; }
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_strip_kernel(const AttnParams p) {
+    static_assert(DH == 64, "d_head 64");
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
+    constexpr int NKS = DH / 16;
+    constexpr int NTN = DH / 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T_ = p.T, H = p.H;
+    const int RS = (2 * T_ + 15) / 16 * 16;
+    unsigned char* Kst = st_smem;                               // [32][ST_KROW]
+    unsigned char* Vt = st_smem + 32 * ST_KROW;                 // [DH][ST_VROW]
+    unsigned char* S = Vt + DH * ST_VROW + wave * st_strip_bytes(T_);          // this wave's strip [32][RS]
+    const int qblocks = (T_ + 127) / 128;
+    const int g = blockIdx.x / qblocks;                         // (image, head)
+    const int q0 = (blockIdx.x - g * qblocks) * 128 + wave * 32;
+    const bool active = q0 < T_;                                // idle waves of a head's last block still load tiles and meet the barriers
+    const int b = g / H, h = g - b * H;
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned tokb = (unsigned)H * DH * 2u;
+    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;
+    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
+    const int ntile = (T_ + 31) / 32;
+    const float inv_scale = 1.0f / p.attn_scale;
+
+    u32x4_t qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+    // cooperative tile fetch: thread t moves 16 B (8 d-values) of key row t / 8
+    const int t_key = threadIdx.x >> 3, t_dc = threadIdx.x & 7;
+    const unsigned tile_off = (unsigned)t_key * tokb + t_dc * 16;
+    unsigned char* my_row = S + l31 * RS;
+
+    // flush the strip's rows (queries q0 .. ) into the head's [T][T] block `dst`
+    auto flush = [&](bf16_t* dst) {
+        __builtin_amdgcn_wave_barrier();
+        const int rows = min(32, T_ - q0);
+        for (int r = 0; r < rows; ++r) {
+            unsigned char* d = reinterpret_cast<unsigned char*>(dst) + ((int64_t)(q0 + r) * T_) * 2;
+            const unsigned char* src = S + r * RS;
+            const int n_head = (int)((16u - (unsigned)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u);       // bytes up to the first aligned chunk
+            const int body = (2 * T_ - n_head) / 16;                                                   // full 16-byte chunks
+            const int tail0 = n_head + 16 * body;                                                      // first byte of the tail
+            const int sh = n_head & 3;                                                                 // 0 or 2
+            for (int c = lane; c < body; c += 64) {
+                const unsigned char* s4 = src + ((n_head + 16 * c) & ~3);
+                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(s4), w1 = *reinterpret_cast<const uint32_t*>(s4 + 4),
+                               w2 = *reinterpret_cast<const uint32_t*>(s4 + 8), w3 = *reinterpret_cast<const uint32_t*>(s4 + 12),
+                               w4 = *reinterpret_cast<const uint32_t*>(s4 + 16);
+                uint4 o;
+                if (sh == 0) o = make_uint4(w0, w1, w2, w3);
+                else o = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, 2), __builtin_amdgcn_alignbyte(w2, w1, 2),
+                                    __builtin_amdgcn_alignbyte(w3, w2, 2), __builtin_amdgcn_alignbyte(w4, w3, 2));
+                *reinterpret_cast<uint4*>(d + n_head + 16 * c) = o;
+            }
+            // head and tail: two-byte stores (at most 7 each)
+            if (lane < 8) {
+                if (2 * lane < n_head) *reinterpret_cast<unsigned short*>(d + 2 * lane) = *reinterpret_cast<const unsigned short*>(src + 2 * lane);
+            } else if (lane < 16) {
+                const int o2 = tail0 + 2 * (lane - 8);
+                if (o2 < 2 * T_) *reinterpret_cast<unsigned short*>(d + o2) = *reinterpret_cast<const unsigned short*>(src + o2);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- pass A: scores -> strip, online max / sum
+    float m = -INFINITY, l = 0.f;
+    {
+        u32x4_t kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
+        *reinterpret_cast<u32x4_t*>(Kst + t_key * ST_KROW + t_dc * 16) = kn;
+    }
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        u32x4_t kn = {0, 0, 0, 0};
+        if (kt + 1 < ntile) kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+        if (active) {
+            uint4 kf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(Kst + l31 * ST_KROW + (2 * ks + half) * 16);
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
+            // acc[e] = score(query q0 + l31, key kt*32 + (e & 3) + 8 * (e >> 2) + 4 * half)
+            float sc[16];
+            float tm = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                sc[e] = bf16_to_f32(f32_to_bf16(acc[e] * inv_scale));
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (key < T_) tm = fmaxf(tm, sc[e]);
+            }
+            const float mn = fmaxf(m, tm);
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (key < T_) add += __expf(sc[e] - mn);
+            }
+            l = (mn == -INFINITY) ? 0.f : l * __expf(m - mn) + add;
+            m = mn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                       // keys 8 j + 4 half + 0..3: 8 bytes
+                const int kb = (kt * 32 + 8 * j + 4 * half) * 2;
+                if (kb + 8 <= RS)
+                    *reinterpret_cast<uint2*>(my_row + kb) = make_uint2(pack_bf16x2(sc[4 * j], sc[4 * j + 1]), pack_bf16x2(sc[4 * j + 2], sc[4 * j + 3]));
+            }
+        }
+        __syncthreads();
+        *reinterpret_cast<u32x4_t*>(Kst + t_key * ST_KROW + t_dc * 16) = kn;
+        __syncthreads();
+    }
+    {   // merge the two lanes of a query
+        const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
+        const float M = fmaxf(m, mo);
+        l = (M == -INFINITY) ? 0.f : l * __expf(m - M) + lo * __expf(mo - M);
+        m = M;
+    }
+    const float rl = active ? 1.0f / l : 0.f;
+    if (active && p.scores) flush(reinterpret_cast<bf16_t*>(p.scores) + (int64_t)g * T_ * T_);
+
+    // ---- pass B: pattern -> strip, z
+    f32x16 zacc[NTN];
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zacc[tn][e] = 0.f;
+    auto stage_v = [&](const u32x4_t& v) {                      // 8 d-values of key t_key -> V^T[d][key]
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<unsigned short*>(Vt + (t_dc * 8 + 2 * i) * ST_VROW + t_key * 2) = (unsigned short)(w[i] & 0xffffu);
+            *reinterpret_cast<unsigned short*>(Vt + (t_dc * 8 + 2 * i + 1) * ST_VROW + t_key * 2) = (unsigned short)(w[i] >> 16);
+        }
+    };
+    stage_v(__builtin_amdgcn_raw_buffer_load_b128(rsV, tile_off, 0, 0));
+    __syncthreads();
+    for (int kt = 0; kt < ntile; ++kt) {
+        u32x4_t vn = {0, 0, 0, 0};
+        if (kt + 1 < ntile) vn = __builtin_amdgcn_raw_buffer_load_b128(rsV, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+        if (active) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kb = (kt * 32 + 8 * j + 4 * half) * 2;
+                uint2 w = make_uint2(0u, 0u);
+                if (kb + 8 <= RS) w = *reinterpret_cast<const uint2*>(my_row + kb);
+                const uint32_t ww[2] = {w.x, w.y};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int key = kt * 32 + 8 * j + 4 * half + 2 * u;
+                    float x0 = key < T_ ? __expf(__uint_as_float(ww[u] << 16) - m) * rl : 0.f;
+                    float x1 = key + 1 < T_ ? __expf(__uint_as_float(ww[u] & 0xffff0000u) - m) * rl : 0.f;
+                    if (x0 != x0) x0 = 0.f;                                 // attention.py:149
+                    if (x1 != x1) x1 = 0.f;
+                    pk[2 * j + u] = pack_bf16x2(x0, x1);
+                }
+            }
+            // C layout (keys 8 j + 4 half + 0..3 as pk[2j], pk[2j+1]) -> A operand (keys 16 ks + 8 half + 0..7): per k16 step
+            // the halves swap one group of four keys
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t s0 = half ? pk[4 * ks + 0] : pk[4 * ks + 2];
+                const uint32_t s1 = half ? pk[4 * ks + 1] : pk[4 * ks + 3];
+                const uint32_t r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+                u32x4_t pa;
+                if (half) pa = u32x4_t{r0, r1, pk[4 * ks + 2], pk[4 * ks + 3]};
+                else pa = u32x4_t{pk[4 * ks + 0], pk[4 * ks + 1], r0, r1};
+                const int kb = (kt * 32 + 16 * ks + 8 * half) * 2;
+                if (kb + 16 <= RS) *reinterpret_cast<u32x4_t*>(my_row + kb) = pa;
+#pragma unroll
+                for (int tn = 0; tn < NTN; ++tn) {
+                    const uint4 vf = *reinterpret_cast<const uint4*>(Vt + (tn * 32 + l31) * ST_VROW + (16 * ks + 8 * half) * 2);
+                    zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, vf), zacc[tn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        stage_v(vn);
+        __syncthreads();
+    }
+    if (!active) return;
+    if (p.pattern) flush(reinterpret_cast<bf16_t*>(p.pattern) + (int64_t)g * T_ * T_);
+
+    // ---- z: C layout (col = d, rows = queries) -> strip rows [32][DH] -> 16-byte row stores
+#pragma unroll
+    for (int tn = 0; tn < NTN; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
+            *reinterpret_cast<bf16_t*>(S + row * 144 + (tn * 32 + l31) * 2) = f32_to_bf16(zacc[tn][e]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    {
+        constexpr int CPR = DH / 8;
+        bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
+        for (int c = lane; c < 32 * CPR; c += 64) {
+            const int row = c / CPR, ch = c - row * CPR;
+            if (q0 + row < T_)
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(zb) + (int64_t)(q0 + row) * tokb + ch * 16) =
+                    *reinterpret_cast<const uint4*>(S + row * 144 + ch * 16);
+        }
+    }
+}
+
+int launch_attn_strip(const AttnParams& p, hipStream_t stream) {
+    const int heads = p.B * p.H, qblocks = (p.T + 127) / 128;
+    const int RS = (2 * p.T + 15) / 16 * 16;
+    const size_t lds = 32 * ST_KROW + 64 * ST_VROW + 4 * (size_t)(32 * RS + 32);
+    static size_t attr_done = 0;
+    if (lds > attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_kernel<64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = lds;
+    }
+    {
+        const double bh = (double)heads, tt = (double)p.T * p.T;
+        const double bytes = (4.0 * bh * p.T * p.dh + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
+        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
+        hipLaunchKernelGGL((attn_strip_kernel<64>), dim3(heads * qblocks), dim3(256), lds, stream, p);
+    }
+    PV_LAUNCH_CHECK("attn_strip_kernel");
+    return PV_OK;
+}
+
 template <typename T>
 int dispatch_attn(AttnParams& p, hipStream_t stream) {
     p.Tpad = (p.T + 31) / 32 * 32;
@@ -786,8 +1041,12 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     }
     if constexpr (sizeof(T) == 2) {
         if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
-            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31))
+            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31)) {
+            // single pass with the score strip in LDS while four strips fit beside the K / V tiles; two passes beyond
+            const bool taps_ok = (reinterpret_cast<uintptr_t>(p.scores) % 2 == 0) && (reinterpret_cast<uintptr_t>(p.pattern) % 2 == 0);
+            if (p.T <= 600 && taps_ok && g_pv_tuning.attn_stream != 1) return launch_attn_strip(p, stream);
             return launch_attn_stream(p, stream);
+        }
     }
     if (p.T <= 64) {
         if (p.dh == 64) return launch_attn<T, 64, 64, 1>(p, stream);
