@@ -575,16 +575,15 @@ def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
                 assert rel_fro(got, ref) <= bf16_limit(k, budget), (name, k, rel_fro(got, ref), budget)
 
 
-@pytest.mark.parametrize("image_size,patch,kernel", [(224, 16, "strip"), (224, 16, "stream"), (208, 13, "strip"), (400, 16, "stream")])
-def test_bf16_long_sequence_attention_kernels(image_size, patch, kernel, tuning):
-    """The two T > 64 bf16 attention kernels on token counts other than L/14's 577: T = 197 (odd: head blocks of the
-    taps only 2-byte aligned), 257 (one key past a tile edge), 626 (> 600: beyond the strip kernel's LDS budget, the
-    two-pass kernel takes it).  scores / pattern / z against an fp32 recompute from the q, k, v the same run cached."""
+@pytest.mark.parametrize("image_size,patch", [(224, 16), (208, 13), (400, 16), (176, 16), (256, 16)])
+def test_bf16_long_sequence_attention_kernel(image_size, patch):
+    """The T > 64 bf16 attention kernel on token counts other than L/14's 577: T = 197 (odd: head blocks of the taps only
+    2-byte aligned, one full tap window + a ragged one), 257 (one key past a tile edge), 626 (> 4 windows, last one ragged),
+    122 (even, < one window), 257 again at another patch size.  scores / pattern / z against an fp32 recompute from the q, k,
+    v the same run cached."""
     cfg = dict(n_layers=1, d_model=128, n_heads=2, d_head=64, d_mlp=256, patch_size=patch, image_size=image_size, n_channels=3,
                n_classes=16, eps=1e-5, layer_norm_pre=True, normalize_output=True, return_type="class_logits",
                activation_name="gelu", use_cls_token=True, normalization_type="LN", classification_type="cls")
-    if kernel == "stream":
-        tuning("attn_stream", 1)
     model = HookedViT(HookedViTConfig(**cfg, dtype=torch.bfloat16, device="cuda")).to(torch.bfloat16).cuda().eval().use_native(True)
     T = (image_size // patch) ** 2 + 1
     x = torch.randn(3, 3, image_size, image_size, device="cuda", generator=torch.Generator(device="cuda").manual_seed(T)).bfloat16()

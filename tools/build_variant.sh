@@ -1,13 +1,15 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [-DFLAG ...]: gemm.hip rebuilt with extra defines into tools/variants/libpvnative_NAME.so
-# (the other objects come from the regular in-tree build); select it with PV_NATIVE_LIB=tools/variants/libpvnative_NAME.so
+# tools/build_variant.sh NAME [-DFLAG ...]: one source of csrc/ (SRC=gemm by default) rebuilt with extra defines into
+# tools/variants/libpvnative_NAME.so (the other objects come from the regular in-tree build); select it with
+# PV_NATIVE_LIB=tools/variants/libpvnative_NAME.so
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
+src=${SRC:-gemm}
 mkdir -p tools/variants
 python -m vit_prisma_amd.build >/dev/null
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off "$@" -c vit_prisma_amd/csrc/gemm.hip -o tools/variants/gemm_$name.o
-objs=$(ls vit_prisma_amd/csrc/_obj/*.o | grep -v "/gemm.o")
-hipcc -shared -fPIC --offload-arch=gfx950 -o tools/variants/libpvnative_$name.so $objs tools/variants/gemm_$name.o
-rm tools/variants/gemm_$name.o
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off -Iinclude "$@" -c vit_prisma_amd/csrc/$src.hip -o tools/variants/${src}_$name.o
+objs=$(ls vit_prisma_amd/csrc/_obj/*.o | grep -v "/$src.o")
+hipcc -shared -fPIC --offload-arch=gfx950 -o tools/variants/libpvnative_$name.so $objs tools/variants/${src}_$name.o
+rm tools/variants/${src}_$name.o
 echo built tools/variants/libpvnative_$name.so

@@ -16,6 +16,7 @@
 //            fp32: V rows read directly (the f32 MFMA takes one float per lane)
 #include "attention.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include "prof.hpp"
@@ -508,38 +509,61 @@ int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Long-sequence variant (bf16, T > 64: L/14@336 has T = 577): a WAVE owns 32 query rows of one (image, head) and
-// streams the keys twice, with the product SWAPPED (S^T = K Q^T) so that a lane holds 16 keys of ONE query:
-//   pass 1  per 32-key tile: S^T tile on MFMA (K rows and the wave's Q rows straight from global, pad rows read 0),
-//           scaled + rounded to bf16 like the reference's score tensor, online (max, sum) per lane; the two lanes of
-//           a query (halves of the wave) are merged at the end
-//   pass 2  the same tiles again: p = exp(s - max) / sum, rounded; (a) hook_pattern: the 32 x 32 tile goes through
-//           2.5 KB of LDS to become 32-byte row pieces -> dword stores (the [T][T] block of a head is only 2-byte
-//           aligned when T is odd: odd-address rows are shifted one element with funnel shifts);
-//           (b) z += P V on MFMA -- P moves from the C layout to the A-operand layout with one cross-half
-//           exchange per k16 step, V fragments are 2-byte buffer loads (32 lanes = 64 contiguous bytes of a key row)
-//   The four waves of a workgroup (128 consecutive queries of one head) share each 32-key K (and V) tile: fetched
-//   cooperatively as full 128-byte rows into registers one tile ahead, parked in 4.5 KB of LDS between two barriers.
-//   No [QB][T] score block in LDS (the workgroup kernel above needs 41 KB of it and runs 8 waves per CU);
-//   hook_attn_scores, when tapped, is written from pass 1 the same way as the pattern.
+// Long-sequence variant (bf16, T > 64, d_head 64: L/14@336 has T = 577): a WAVE owns 32 query rows of one (image, head)
+// and streams the keys twice, with the product SWAPPED (S^T = K Q^T) so that a lane holds 16 keys of ONE query:
+//   pass 1  per 32-key tile: S^T tile on MFMA, scaled + rounded to bf16 like the reference's score tensor, online
+//           (max, sum) per lane; the two lanes of a query (halves of the wave) are merged at the end
+//           (+ hook_attn_scores, when tapped, leaves through the same window as the pattern)
+//   pass 2  the same tiles again: p = exp(s - max) / sum, rounded -> hook_pattern, and z += P V on MFMA
+// The four waves of a workgroup (128 consecutive queries of one head) share each K / V tile: fetched cooperatively one
+// tile ahead into registers, parked in double-buffered LDS (one barrier per tile).  No [QB][T] score block in LDS.
+// The kernel is bound by VALU issue and by the tap's HBM write stream, not by MFMA (profiles/r02_notes.md): round 1's
+// form spent about 640 wave instructions per 32 x 32 tile over the two passes; this one about 300:
+//   * 1 / attn_scale folded into the Q fragments when it is a power of two (exact in bf16; d_head 64 -> 1/8)
+//   * score rounding = v_cvt_pk_bf16_f32 + shift / mask; max as v_max3; exp(s - m) = v_exp(fma(s, log2 e, -m log2 e)) on
+//     packed f32 pairs; pass 2 folds 1 / sum into the exponent (p = exp2(s log2 e - (m log2 e + log2 sum)))
+//   * NaN rows (attention.py:149): a softmax row is NaN entirely or not at all, so the where() is one AND with a row mask,
+//     taken only by waves that hold such a row
+//   * P: C layout -> A operand with v_permlane32_swap (4 per tile); V staged TRANSPOSED once per workgroup ([d][key]) so a
+//     B fragment is one ds_read_b128 (round 1: 32 two-byte reads per tile)
+//   * taps: four 32 x 32 tiles collect in a per-wave LDS window and leave as 4 rows x 256 contiguous bytes per store
+//     instruction, 16-byte global stores at the row's own 2-byte alignment (the [T][T] block of a head is only 2-byte
+//     aligned when T is odd; gfx950 global memory takes unaligned dwordx4 stores) -- no funnel shifts, no parity branch
+//   * workgroups dealt to the XCDs by whole heads (the query blocks of a head share one L2's copy of its K / V)
+// A single-pass variant (the wave's 32 x T score strip kept in LDS, QK^T computed once) was built and measured: 37 KB per
+// wave = one workgroup per CU = one wave per SIMD, 1.9 ms per layer against 0.66 ms here without taps -- removed.
 // ---------------------------------------------------------------------------------------------------
-constexpr int AS_PROW = 80;                 // bytes per LDS row of a 32 x 32 bf16 tile (64 + 16 pad)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(2))) U4a2 { uint32_t x, y, z, w; };      // a 16-byte store at 2-byte alignment
+constexpr int L2_VROW = 80;                 // V^T tile row: 32 keys x 2 B + 16 pad
+constexpr float PV_LOG2E = 1.4426950408889634f;
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
+template <int DH, bool PRESCALE>
+__global__ __launch_bounds__(256) void attn_lean_kernel(const AttnParams p) {
     static_assert(DH == 64, "d_head 64");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * 144];      // per wave: P tile (2.5 KB) / z staging (4.5 KB)
-    __shared__ __attribute__((aligned(16))) unsigned char Kst[32 * 144];          // the workgroup's current key tile   [32][d_head] (+16 B pad)
-    __shared__ __attribute__((aligned(16))) unsigned char Vst[32 * 144];          // ... and value tile (pass 2)
+    __shared__ __attribute__((aligned(16))) unsigned char Kst[2][32 * 144];          // key tile [32][d_head] (+16 B pad), double-buffered
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[2][DH * L2_VROW];       // value tile transposed [d][32 keys]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * 256];         // per wave: tap window of 4 tiles (8 KB) / z staging (4.5 KB)
     constexpr int NKS = DH / 16;
     constexpr int NTN = DH / 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int T_ = p.T, H = p.H;
     const int qblocks = (T_ + 127) / 128;
-    const int g = blockIdx.x / qblocks;                     // (image, head)
-    const int q0 = (blockIdx.x - g * qblocks) * 128 + wave * 32;
-    const bool active = q0 < T_;                            // idle waves of a head's last block still load tiles and meet the barriers
+    // workgroups are dealt to the 8 XCDs round-robin: give every XCD whole heads, so the query blocks of a head share one
+    // L2's copy of its K / V (plain order: each of the 5 blocks at T = 577 pulls them through a different L2 -- PMC: 1.2 GB
+    // fetched per launch for 0.45 GB of q, k, v)
+    int bid = blockIdx.x;
+    {
+        const int heads = p.B * H, per_xcd = heads / 8;
+        if (bid < per_xcd * 8 * qblocks) {
+            const int xcd = bid & 7, i = bid >> 3;
+            bid = ((i / qblocks) * 8 + xcd) * qblocks + i % qblocks;
+        }
+    }
+    const int g = bid / qblocks;                            // (image, head)
+    const int q0 = (bid - g * qblocks) * 128 + wave * 32;
+    const bool active = q0 < T_;                            // idle waves of a head's last block still stage tiles and meet the barriers
     const int b = g / H, h = g - b * H;
     const int half = lane >> 5, l31 = lane & 31;
     unsigned char* L = smem[wave];
@@ -553,22 +577,49 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
     const int ntile = (T_ + 31) / 32;
-    const float inv_scale = 1.0f / p.attn_scale;     // (a power of two for every d_head in use; the product is rounded to bf16 next)
+    const float inv_scale = 1.0f / p.attn_scale;
+    const f32x2_t inv_scale2 = {inv_scale, inv_scale};
+    const f32x2_t log2e2 = {PV_LOG2E, PV_LOG2E};
 
     // Q as the B operand (columns = this wave's queries): lane (query l31, half) holds d-chunk (2 ks + half)
     u32x4_t qf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
+    for (int ks = 0; ks < NKS; ++ks) {
         qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+        if (PRESCALE) {
+            uint32_t w[4] = {qf[ks].x, qf[ks].y, qf[ks].z, qf[ks].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                w[i] = pack_bf16x2(__uint_as_float(w[i] << 16) * inv_scale, __uint_as_float(w[i] & 0xffff0000u) * inv_scale);
+            qf[ks] = u32x4_t{w[0], w[1], w[2], w[3]};
+        }
+    }
 
-    // S^T tile kt: acc[e] = score(query q0 + l31, key kt*32 + (e & 3) + 8 * (e >> 2) + 4 * half), bf16-rounded
-    // cooperative tile fetch: thread t moves 16 B of key row t / 8 (one full 128-byte row per 8 lanes; rows >= T read 0)
-    const unsigned tile_off = (unsigned)(threadIdx.x >> 3) * tokb + (threadIdx.x & 7) * 16;
-    const int tile_lds = (threadIdx.x >> 3) * 144 + (threadIdx.x & 7) * 16;
-    auto score_tile = [&](int kt, float (&sc)[16]) {
+    // cooperative tile fetch: thread t moves 16 B (8 d-values, chunk t / 32) of key row t % 32; rows >= T read 0.  A half-wave
+    // = the 32 keys of one chunk: its transposed two-byte V^T writes fall into 64 contiguous bytes per d row (key-major
+    // lanes would put eight d rows -- 8 x 80 B apart, the same banks -- into every write: measured 8-way conflicts)
+    const int t_key = threadIdx.x & 31, t_dc = threadIdx.x >> 5;
+    const unsigned tile_off = (unsigned)t_key * tokb + t_dc * 16;
+    const int k_lds = t_key * 144 + t_dc * 16;
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t& rs, int kt) -> u32x4_t {
+        if (kt < ntile) return __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)kt * 32u * tokb + tile_off, 0, 0);
+        return u32x4_t{0, 0, 0, 0};
+    };
+    auto stage_v = [&](unsigned char* dst, const u32x4_t& v) {          // 8 d-values of key t_key -> V^T[d][key]
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<unsigned short*>(dst + (t_dc * 8 + 2 * i) * L2_VROW + t_key * 2) = (unsigned short)(w[i] & 0xffffu);
+            *reinterpret_cast<unsigned short*>(dst + (t_dc * 8 + 2 * i + 1) * L2_VROW + t_key * 2) = (unsigned short)(w[i] >> 16);
+        }
+    };
+
+    // S^T tile out of Kst[buf]: pk[i] = bf16 scores of keys kt*32 + key_of(2 i), key_of(2 i + 1); s[e] the same as floats;
+    // key_of(e) = (e & 3) + 8 * (e >> 2) + 4 * half
+    auto score_tile = [&](const unsigned char* kb, uint32_t (&pk)[8], float (&sc)[16]) {
         uint4 kf[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(Kst + l31 * 144 + (2 * ks + half) * 16);
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kb + l31 * 144 + (2 * ks + half) * 16);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -576,98 +627,127 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
         for (int ks = 0; ks < NKS; ++ks)
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sc[e] = bf16_to_f32(f32_to_bf16(acc[e] * inv_scale));
-    };
-    // a 32 x 32 bf16 tile held as 8 packed dwords per lane (pk[i] = keys (4 i' .. ) see above) -> LDS -> row-piece stores
-    // into the head's [T][T] block `dst` (element (q, key)); lane handles row lane >> 1, 16 elements from key (lane & 1) * 16
-    auto store_tile = [&](bf16_t* dst, int kt, const uint32_t (&pk)[8]) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)          // keys 8 gq + 4 half + 0..3 of query l31: 8 contiguous bytes
-            *reinterpret_cast<uint2*>(L + l31 * AS_PROW + (8 * gq + 4 * half) * 2) = make_uint2(pk[2 * gq], pk[2 * gq + 1]);
-        __builtin_amdgcn_wave_barrier();
-        const int row = lane >> 1, k0 = kt * 32 + (lane & 1) * 16;
-        const uint4 r0 = *reinterpret_cast<const uint4*>(L + row * AS_PROW + (lane & 1) * 32);
-        const uint4 r1 = *reinterpret_cast<const uint4*>(L + row * AS_PROW + (lane & 1) * 32 + 16);
-        __builtin_amdgcn_wave_barrier();
-        const int q = q0 + row;
-        const int nv = min(16, T_ - k0);
-        if (q < T_ && nv > 0) {
-            const int64_t gidx = (int64_t)q * T_ + k0;                 // element index inside the head's block
-            unsigned char* d = reinterpret_cast<unsigned char*>(dst) + gidx * 2;
-            const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-            const bool odd = (reinterpret_cast<uintptr_t>(d) & 2) != 0;
-            if (nv == 16 && !odd) {
-                *reinterpret_cast<uint4*>(d) = r0;                     // dword-aligned 16-byte stores
-                *reinterpret_cast<uint4*>(d + 16) = r1;
-            } else if (nv == 16) {
-                *reinterpret_cast<unsigned short*>(d) = (unsigned short)(w[0] & 0xffffu);
-                uint32_t o[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) o[i] = (w[i] >> 16) | (w[i + 1] << 16);
-                *reinterpret_cast<uint4*>(d + 2) = make_uint4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<uint2*>(d + 18) = make_uint2(o[4], o[5]);
-                *reinterpret_cast<uint32_t*>(d + 26) = o[6];
-                *reinterpret_cast<unsigned short*>(d + 30) = (unsigned short)(w[7] >> 16);
-            } else {
-                for (int i = 0; i < nv; ++i)
-                    *reinterpret_cast<unsigned short*>(d + 2 * i) = (unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
-            }
+        for (int i = 0; i < 8; ++i) {
+            f32x2_t t = {acc[2 * i], acc[2 * i + 1]};
+            if (!PRESCALE) t = t * inv_scale2;
+            pk[i] = pack_bf16x2(t.x, t.y);
+            sc[2 * i] = __uint_as_float(pk[i] << 16);
+            sc[2 * i + 1] = __uint_as_float(pk[i] & 0xffff0000u);
         }
     };
 
+    // P / S tile from the C layout (this lane: keys 4 half + 8 j + 0..3, j = 0..3, as pk[2j], pk[2j+1]) to the A-operand layout
+    // (keys ks*16 + half*8 + 0..7 = 16 contiguous bytes of the query's row): the upper half-wave's group 2 ks trades places
+    // with the lower half-wave's group 2 ks + 1
+    auto to_rows = [&](const uint32_t (&pk)[8], u32x4_t (&pa)[2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 0], pk[4 * ks + 2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+            pa[ks] = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+        }
+    };
+    // Taps: the tile goes into the wave's LDS window [32 rows][4 tiles x 64 B] (16-byte chunk c of row r at position
+    // c ^ (r & 15): the rows of one ds_write_b128 cover every bank); every fourth tile (and after the last) the window leaves
+    // as 16-byte stores, 4 rows x 256 contiguous bytes per instruction, at the row's own 2-byte alignment.  (One tile per
+    // flush = 64-byte pieces: every piece straddles two 64-byte blocks of HBM and the L2 writes most of them out twice --
+    // PMC: 2.2 GB written for 1.36 GB of pattern.)
+    const int st_row = lane >> 4, st_ch = lane & 15;
+    auto tap_put = [&](int kt, const u32x4_t (&pa)[2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            *reinterpret_cast<u32x4_t*>(L + l31 * 256 + ((((kt & 3) * 4 + 2 * ks + half) ^ (l31 & 15)) * 16)) = pa[ks];
+    };
+    auto tap_flush = [&](unsigned char* dst, int kt) {
+        if ((kt & 3) != 3 && kt + 1 < ntile) return;
+        __builtin_amdgcn_wave_barrier();
+        const int k0 = (kt & ~3) * 32;                                       // first key of the window
+        const int nb = min(256, (T_ - k0) * 2);                              // valid bytes per row
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int row = st_row + 4 * it;
+            if (q0 + row < T_ && st_ch * 16 < nb) {
+                const unsigned char* src = L + row * 256 + ((st_ch ^ (row & 15)) * 16);
+                unsigned char* d = dst + ((size_t)(uint32_t)((q0 + row) * T_ + k0 + st_ch * 8)) * 2;
+                if (st_ch * 16 + 16 <= nb) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(src);
+                    *reinterpret_cast<U4a2*>(d) = U4a2{r.x, r.y, r.z, r.w};
+                } else {
+                    for (int e = 0; e < (nb - st_ch * 16) / 2; ++e)
+                        *reinterpret_cast<unsigned short*>(d + 2 * e) = *reinterpret_cast<const unsigned short*>(src + 2 * e);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
     // ---- pass 1: online max / sum (and the score tap)
-    bf16_t* sc_dst = p.scores ? reinterpret_cast<bf16_t*>(p.scores) + (int64_t)g * T_ * T_ : nullptr;
+    unsigned char* sc_dst = p.scores ? reinterpret_cast<unsigned char*>(p.scores) + (int64_t)g * T_ * T_ * 2 : nullptr;
     float m = -INFINITY, l = 0.f;
     auto pass1_tile = [&](int kt, auto masked) {
         constexpr bool MASK = decltype(masked)::value;
+        uint32_t pk[8];
         float sc[16];
-        score_tile(kt, sc);
-        float tm = -INFINITY;
+        score_tile(Kst[kt & 1], pk, sc);
+        if (MASK) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            if (!MASK || key < T_) tm = fmaxf(tm, sc[e]);
+            for (int e = 0; e < 16; ++e)
+                if (kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half >= T_) sc[e] = -INFINITY;
         }
+        float tm = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) tm = fmaxf(fmaxf(tm, sc[e]), sc[e + 1]);
+        tm = fmaxf(tm, sc[15]);
         const float mn = fmaxf(m, tm);
-        float add = 0.f;
+        const float nb = -(mn * PV_LOG2E);
+        const f32x2_t nb2 = {nb, nb};
+        f32x2_t sum2 = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            if (!MASK || key < T_) add += __expf(sc[e] - mn);
+        for (int i = 0; i < 8; ++i) {
+            const f32x2_t a = __builtin_elementwise_fma(f32x2_t{sc[2 * i], sc[2 * i + 1]}, log2e2, nb2);
+            sum2 += f32x2_t{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};      // exp2(-inf) = 0 for masked keys
         }
-        l = (mn == -INFINITY) ? 0.f : l * __expf(m - mn) + add;
+        l = l * __builtin_amdgcn_exp2f((m - mn) * PV_LOG2E) + (sum2.x + sum2.y);
         m = mn;
         if (sc_dst) {
-            uint32_t pk[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pk[i] = pack_bf16x2(sc[2 * i], sc[2 * i + 1]);
-            store_tile(sc_dst, kt, pk);
+            u32x4_t sa[2];
+            to_rows(pk, sa);
+            tap_put(kt, sa);
         }
     };
-    // tile kt+1 is fetched into registers while tile kt is consumed out of LDS (only the last tile can hold keys >= T)
-    *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
+    {
+        const u32x4_t k0 = fetch(rsK, 0);
+        *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;
+    }
+    // per tile: issue the fetch of tile kt + 1 -> multiply tile kt out of LDS -> park the fetched tile in the other buffer
+    // -> flush the tap window when it is due -> barrier.  The flush comes LAST: its stores share vmcnt with the fetch, and
+    // a wave that waits for its tile behind freshly issued stores waits for HBM write latency at every flush.
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
-        u32x4_t kn = {0, 0, 0, 0};
-        if (kt + 1 < ntile) kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
+        const u32x4_t kn = fetch(rsK, kt + 1);
         if (active) {
             if (kt + 1 < ntile) pass1_tile(kt, std::false_type{});
             else pass1_tile(kt, std::true_type{});
         }
-        __syncthreads();
-        *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = kn;
+        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn;        // free since the barrier that ended tile kt - 1
+        if (active && sc_dst) tap_flush(sc_dst, kt);
         __syncthreads();
     }
     {   // merge the two lanes of a query
         const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
         const float M = fmaxf(m, mo);
-        l = (M == -INFINITY) ? 0.f : l * __expf(m - M) + lo * __expf(mo - M);
+        l = l * __builtin_amdgcn_exp2f((m - M) * PV_LOG2E) + lo * __builtin_amdgcn_exp2f((mo - M) * PV_LOG2E);
         m = M;
     }
-    const float rl = active ? 1.0f / l : 0.f;
+    // a row with an infinite / NaN score (or none at all) is NaN throughout in the reference -> zeros (attention.py:149)
+    const bool row_ok = active && l > 0.f && l < INFINITY && m > -INFINITY && m < INFINITY;
+    const uint32_t row_mask = row_ok ? 0xffffffffu : 0u;
+    const bool any_bad = active && __builtin_amdgcn_ballot_w64(!row_ok) != 0;
+    const float nbias = row_ok ? -(m * PV_LOG2E + __builtin_amdgcn_logf(l)) : 0.f;
+    const f32x2_t nbias2 = {nbias, nbias};
 
     // ---- pass 2: pattern tap + z
-    bf16_t* pt_dst = p.pattern ? reinterpret_cast<bf16_t*>(p.pattern) + (int64_t)g * T_ * T_ : nullptr;
+    unsigned char* pt_dst = p.pattern ? reinterpret_cast<unsigned char*>(p.pattern) + (int64_t)g * T_ * T_ * 2 : nullptr;
     f32x16 zacc[NTN];
 #pragma unroll
     for (int tn = 0; tn < NTN; ++tn)
@@ -675,65 +755,50 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
         for (int e = 0; e < 16; ++e) zacc[tn][e] = 0.f;
     auto pass2_tile = [&](int kt, auto masked) {
         constexpr bool MASK = decltype(masked)::value;
-        float sc[16];
-        score_tile(kt, sc);
         uint32_t pk[8];
+        float sc[16];
+        score_tile(Kst[kt & 1], pk, sc);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float pv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = 2 * i + u;
-                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                float x = (!MASK || key < T_) ? __expf(sc[e] - m) * rl : 0.f;
-                if (x != x) x = 0.f;                                     // attention.py:149
-                pv[u] = x;
+            const f32x2_t a = __builtin_elementwise_fma(f32x2_t{sc[2 * i], sc[2 * i + 1]}, log2e2, nbias2);
+            float x0 = __builtin_amdgcn_exp2f(a.x), x1 = __builtin_amdgcn_exp2f(a.y);
+            if (MASK) {
+                if (kt * 32 + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * half >= T_) x0 = 0.f;
+                if (kt * 32 + ((2 * i + 1) & 3) + 8 * ((2 * i + 1) >> 2) + 4 * half >= T_) x1 = 0.f;
             }
-            pk[i] = pack_bf16x2(pv[0], pv[1]);
+            pk[i] = pack_bf16x2(x0, x1);
         }
-        if (pt_dst) store_tile(pt_dst, kt, pk);
-        // P from the C layout (this lane: keys 4 half + 8 j + 0..3, j = 0..3, as pk[2j], pk[2j+1]) to the A operand
-        // (lane needs keys ks*16 + half*8 + 0..7): per k16 step the halves swap one group of four keys
+        if (any_bad) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            // half 0 keeps group 2ks, sends group 2ks+1, receives the partner's group 2ks; half 1 the mirror image
-            const uint32_t s0 = half ? pk[4 * ks + 0] : pk[4 * ks + 2];
-            const uint32_t s1 = half ? pk[4 * ks + 1] : pk[4 * ks + 3];
-            const uint32_t r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-            u32x4_t pa;
-            if (half) pa = u32x4_t{r0, r1, pk[4 * ks + 2], pk[4 * ks + 3]};
-            else pa = u32x4_t{pk[4 * ks + 0], pk[4 * ks + 1], r0, r1};
+            for (int i = 0; i < 8; ++i) pk[i] &= row_mask;
+        }
+        u32x4_t pa[2];
+        to_rows(pk, pa);
+        if (pt_dst) tap_put(kt, pa);
+        const unsigned char* vb = Vt[kt & 1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int tn = 0; tn < NTN; ++tn) {
-                uint32_t w[4];
-#pragma unroll
-                for (int q2 = 0; q2 < 4; ++q2) {
-                    const unsigned char* vp = Vst + (ks * 16 + half * 8 + q2 * 2) * 144 + (tn * 32 + l31) * 2;
-                    const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(vp);
-                    const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(vp + 144);
-                    w[q2] = lo16 | (hi16 << 16);
-                }
-                zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa),
-                                                                   __builtin_bit_cast(bf16x8, u32x4_t{w[0], w[1], w[2], w[3]}), zacc[tn], 0, 0, 0);
+                const uint4 vf = *reinterpret_cast<const uint4*>(vb + (tn * 32 + l31) * L2_VROW + (16 * ks + 8 * half) * 2);
+                zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ks]), __builtin_bit_cast(bf16x8, vf), zacc[tn], 0, 0, 0);
             }
-        }
     };
-    *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
-    *reinterpret_cast<u32x4_t*>(Vst + tile_lds) = __builtin_amdgcn_raw_buffer_load_b128(rsV, tile_off, 0, 0);
+    {
+        const u32x4_t k0 = fetch(rsK, 0), v0 = fetch(rsV, 0);
+        *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;      // (everyone left pass 1's last tile, in Kst[(ntile - 1) & 1], through its closing barrier;
+        stage_v(Vt[0], v0);                                      //  Kst[0] was last read one barrier earlier still when ntile is even)
+    }
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
-        u32x4_t kn = {0, 0, 0, 0}, vn = {0, 0, 0, 0};
-        if (kt + 1 < ntile) {
-            kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
-            vn = __builtin_amdgcn_raw_buffer_load_b128(rsV, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
-        }
+        const u32x4_t kn = fetch(rsK, kt + 1), vn = fetch(rsV, kt + 1);
         if (active) {
             if (kt + 1 < ntile) pass2_tile(kt, std::false_type{});
             else pass2_tile(kt, std::true_type{});
         }
-        __syncthreads();
-        *reinterpret_cast<u32x4_t*>(Kst + tile_lds) = kn;
-        *reinterpret_cast<u32x4_t*>(Vst + tile_lds) = vn;
+        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn;
+        stage_v(Vt[(kt + 1) & 1], vn);
+        if (active && pt_dst) tap_flush(pt_dst, kt);
         __syncthreads();
     }
     if (!active) return;
@@ -760,270 +825,18 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnParams p) {
     }
 }
 
-int launch_attn_stream(const AttnParams& p, hipStream_t stream) {
+int launch_attn_lean(const AttnParams& p, hipStream_t stream) {
     const int heads = p.B * p.H, qblocks = (p.T + 127) / 128;
+    int ex = 0;
+    const bool pow2 = p.attn_scale > 0.f && std::frexp(p.attn_scale, &ex) == 0.5f;
     {
         const double bh = (double)heads, tt = (double)p.T * p.T;
         const double bytes = (4.0 * bh * p.T * p.dh + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
         ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
-        hipLaunchKernelGGL((attn_stream_kernel<64>), dim3(heads * qblocks), dim3(256), 0, stream, p);
+        if (pow2) hipLaunchKernelGGL((attn_lean_kernel<64, true>), dim3(heads * qblocks), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attn_lean_kernel<64, false>), dim3(heads * qblocks), dim3(256), 0, stream, p);
     }
-    PV_LAUNCH_CHECK("attn_stream_kernel");
-    return PV_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Long-sequence variant, single pass over the keys (bf16, 64 < T <= 600, d_head 64): the wave's 32-query x T score strip
-// lives in LDS (32 x roundup16(2 T) bytes = 36.5 KB at T = 577; four strips per workgroup = one workgroup per CU), so
-//   pass A  K streamed ONCE: S^T = K Q^T tile on MFMA, scaled + rounded to bf16 like the reference's score tensor,
-//           online (max, sum) per lane, the tile parked in the strip (8-byte pieces in the MFMA C layout)
-//   [tap]   hook_attn_scores = the strip, flushed row by row (below)
-//   pass B  V streamed once: the tile comes back out of the strip, p = exp(s - max) / sum rounded to bf16, moves to the
-//           A-operand layout (one cross-half exchange per k16 step), goes back into the strip as 16-byte pieces and
-//           feeds z += P V on MFMA; V is staged TRANSPOSED ([d][key]) so a B fragment is one ds_read_b128
-//   [tap]   hook_pattern = the strip, flushed
-// Flush: a query row is 2 T contiguous bytes of the head's [T][T] block, but the block is only 2-byte aligned when T is
-// odd -- the row is written as 16-byte-aligned global chunks whose LDS source is realigned ONCE per chunk with
-// v_alignbyte (the strip rows are 16-byte aligned), plus <= 7 two-byte stores at each end.  QK^T is computed once
-// (attn_stream_kernel: twice), the taps leave as full 16-byte stores (there: 32-byte pieces with funnel shifts per piece).
-// ---------------------------------------------------------------------------------------------------
-constexpr int ST_KROW = 144;                // K tile row: 128 B + 16 pad
-constexpr int ST_VROW = 80;                 // V^T tile row: 32 keys x 2 B + 16 pad
-
-__device__ __forceinline__ int st_strip_bytes(int T) { return 32 * ((2 * T + 15) / 16 * 16) + 32; }
-
-template <int DH>
-__global__ __launch_bounds__(256) void attn_strip_kernel(const AttnParams p) {
-    static_assert(DH == 64, "d_head 64");
-    extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
-    constexpr int NKS = DH / 16;
-    constexpr int NTN = DH / 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int T_ = p.T, H = p.H;
-    const int RS = (2 * T_ + 15) / 16 * 16;
-    unsigned char* Kst = st_smem;                               // [32][ST_KROW]
-    unsigned char* Vt = st_smem + 32 * ST_KROW;                 // [DH][ST_VROW]
-    unsigned char* S = Vt + DH * ST_VROW + wave * st_strip_bytes(T_);          // this wave's strip [32][RS]
-    const int qblocks = (T_ + 127) / 128;
-    const int g = blockIdx.x / qblocks;                         // (image, head)
-    const int q0 = (blockIdx.x - g * qblocks) * 128 + wave * 32;
-    const bool active = q0 < T_;                                // idle waves of a head's last block still load tiles and meet the barriers
-    const int b = g / H, h = g - b * H;
-    const int half = lane >> 5, l31 = lane & 31;
-    const unsigned tokb = (unsigned)H * DH * 2u;
-    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;
-    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
-    const int ntile = (T_ + 31) / 32;
-    const float inv_scale = 1.0f / p.attn_scale;
-
-    u32x4_t qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-        qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
-    // cooperative tile fetch: thread t moves 16 B (8 d-values) of key row t / 8
-    const int t_key = threadIdx.x >> 3, t_dc = threadIdx.x & 7;
-    const unsigned tile_off = (unsigned)t_key * tokb + t_dc * 16;
-    unsigned char* my_row = S + l31 * RS;
-
-    // flush the strip's rows (queries q0 .. ) into the head's [T][T] block `dst`
-    auto flush = [&](bf16_t* dst) {
-        __builtin_amdgcn_wave_barrier();
-        const int rows = min(32, T_ - q0);
-        for (int r = 0; r < rows; ++r) {
-            unsigned char* d = reinterpret_cast<unsigned char*>(dst) + ((int64_t)(q0 + r) * T_) * 2;
-            const unsigned char* src = S + r * RS;
-            const int n_head = (int)((16u - (unsigned)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u);       // bytes up to the first aligned chunk
-            const int body = (2 * T_ - n_head) / 16;                                                   // full 16-byte chunks
-            const int tail0 = n_head + 16 * body;                                                      // first byte of the tail
-            const int sh = n_head & 3;                                                                 // 0 or 2
-            for (int c = lane; c < body; c += 64) {
-                const unsigned char* s4 = src + ((n_head + 16 * c) & ~3);
-                const uint32_t w0 = *reinterpret_cast<const uint32_t*>(s4), w1 = *reinterpret_cast<const uint32_t*>(s4 + 4),
-                               w2 = *reinterpret_cast<const uint32_t*>(s4 + 8), w3 = *reinterpret_cast<const uint32_t*>(s4 + 12),
-                               w4 = *reinterpret_cast<const uint32_t*>(s4 + 16);
-                uint4 o;
-                if (sh == 0) o = make_uint4(w0, w1, w2, w3);
-                else o = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, 2), __builtin_amdgcn_alignbyte(w2, w1, 2),
-                                    __builtin_amdgcn_alignbyte(w3, w2, 2), __builtin_amdgcn_alignbyte(w4, w3, 2));
-                *reinterpret_cast<uint4*>(d + n_head + 16 * c) = o;
-            }
-            // head and tail: two-byte stores (at most 7 each)
-            if (lane < 8) {
-                if (2 * lane < n_head) *reinterpret_cast<unsigned short*>(d + 2 * lane) = *reinterpret_cast<const unsigned short*>(src + 2 * lane);
-            } else if (lane < 16) {
-                const int o2 = tail0 + 2 * (lane - 8);
-                if (o2 < 2 * T_) *reinterpret_cast<unsigned short*>(d + o2) = *reinterpret_cast<const unsigned short*>(src + o2);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // ---- pass A: scores -> strip, online max / sum
-    float m = -INFINITY, l = 0.f;
-    {
-        u32x4_t kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, tile_off, 0, 0);
-        *reinterpret_cast<u32x4_t*>(Kst + t_key * ST_KROW + t_dc * 16) = kn;
-    }
-    __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) {
-        u32x4_t kn = {0, 0, 0, 0};
-        if (kt + 1 < ntile) kn = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
-        if (active) {
-            uint4 kf[NKS];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(Kst + l31 * ST_KROW + (2 * ks + half) * 16);
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
-            // acc[e] = score(query q0 + l31, key kt*32 + (e & 3) + 8 * (e >> 2) + 4 * half)
-            float sc[16];
-            float tm = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                sc[e] = bf16_to_f32(f32_to_bf16(acc[e] * inv_scale));
-                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (key < T_) tm = fmaxf(tm, sc[e]);
-            }
-            const float mn = fmaxf(m, tm);
-            float add = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (key < T_) add += __expf(sc[e] - mn);
-            }
-            l = (mn == -INFINITY) ? 0.f : l * __expf(m - mn) + add;
-            m = mn;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                       // keys 8 j + 4 half + 0..3: 8 bytes
-                const int kb = (kt * 32 + 8 * j + 4 * half) * 2;
-                if (kb + 8 <= RS)
-                    *reinterpret_cast<uint2*>(my_row + kb) = make_uint2(pack_bf16x2(sc[4 * j], sc[4 * j + 1]), pack_bf16x2(sc[4 * j + 2], sc[4 * j + 3]));
-            }
-        }
-        __syncthreads();
-        *reinterpret_cast<u32x4_t*>(Kst + t_key * ST_KROW + t_dc * 16) = kn;
-        __syncthreads();
-    }
-    {   // merge the two lanes of a query
-        const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
-        const float M = fmaxf(m, mo);
-        l = (M == -INFINITY) ? 0.f : l * __expf(m - M) + lo * __expf(mo - M);
-        m = M;
-    }
-    const float rl = active ? 1.0f / l : 0.f;
-    if (active && p.scores) flush(reinterpret_cast<bf16_t*>(p.scores) + (int64_t)g * T_ * T_);
-
-    // ---- pass B: pattern -> strip, z
-    f32x16 zacc[NTN];
-#pragma unroll
-    for (int tn = 0; tn < NTN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) zacc[tn][e] = 0.f;
-    auto stage_v = [&](const u32x4_t& v) {                      // 8 d-values of key t_key -> V^T[d][key]
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<unsigned short*>(Vt + (t_dc * 8 + 2 * i) * ST_VROW + t_key * 2) = (unsigned short)(w[i] & 0xffffu);
-            *reinterpret_cast<unsigned short*>(Vt + (t_dc * 8 + 2 * i + 1) * ST_VROW + t_key * 2) = (unsigned short)(w[i] >> 16);
-        }
-    };
-    stage_v(__builtin_amdgcn_raw_buffer_load_b128(rsV, tile_off, 0, 0));
-    __syncthreads();
-    for (int kt = 0; kt < ntile; ++kt) {
-        u32x4_t vn = {0, 0, 0, 0};
-        if (kt + 1 < ntile) vn = __builtin_amdgcn_raw_buffer_load_b128(rsV, (unsigned)(kt + 1) * 32u * tokb + tile_off, 0, 0);
-        if (active) {
-            uint32_t pk[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kb = (kt * 32 + 8 * j + 4 * half) * 2;
-                uint2 w = make_uint2(0u, 0u);
-                if (kb + 8 <= RS) w = *reinterpret_cast<const uint2*>(my_row + kb);
-                const uint32_t ww[2] = {w.x, w.y};
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int key = kt * 32 + 8 * j + 4 * half + 2 * u;
-                    float x0 = key < T_ ? __expf(__uint_as_float(ww[u] << 16) - m) * rl : 0.f;
-                    float x1 = key + 1 < T_ ? __expf(__uint_as_float(ww[u] & 0xffff0000u) - m) * rl : 0.f;
-                    if (x0 != x0) x0 = 0.f;                                 // attention.py:149
-                    if (x1 != x1) x1 = 0.f;
-                    pk[2 * j + u] = pack_bf16x2(x0, x1);
-                }
-            }
-            // C layout (keys 8 j + 4 half + 0..3 as pk[2j], pk[2j+1]) -> A operand (keys 16 ks + 8 half + 0..7): per k16 step
-            // the halves swap one group of four keys
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint32_t s0 = half ? pk[4 * ks + 0] : pk[4 * ks + 2];
-                const uint32_t s1 = half ? pk[4 * ks + 1] : pk[4 * ks + 3];
-                const uint32_t r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
-                u32x4_t pa;
-                if (half) pa = u32x4_t{r0, r1, pk[4 * ks + 2], pk[4 * ks + 3]};
-                else pa = u32x4_t{pk[4 * ks + 0], pk[4 * ks + 1], r0, r1};
-                const int kb = (kt * 32 + 16 * ks + 8 * half) * 2;
-                if (kb + 16 <= RS) *reinterpret_cast<u32x4_t*>(my_row + kb) = pa;
-#pragma unroll
-                for (int tn = 0; tn < NTN; ++tn) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(Vt + (tn * 32 + l31) * ST_VROW + (16 * ks + 8 * half) * 2);
-                    zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, vf), zacc[tn], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-        stage_v(vn);
-        __syncthreads();
-    }
-    if (!active) return;
-    if (p.pattern) flush(reinterpret_cast<bf16_t*>(p.pattern) + (int64_t)g * T_ * T_);
-
-    // ---- z: C layout (col = d, rows = queries) -> strip rows [32][DH] -> 16-byte row stores
-#pragma unroll
-    for (int tn = 0; tn < NTN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-            *reinterpret_cast<bf16_t*>(S + row * 144 + (tn * 32 + l31) * 2) = f32_to_bf16(zacc[tn][e]);
-        }
-    __builtin_amdgcn_wave_barrier();
-    {
-        constexpr int CPR = DH / 8;
-        bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
-        for (int c = lane; c < 32 * CPR; c += 64) {
-            const int row = c / CPR, ch = c - row * CPR;
-            if (q0 + row < T_)
-                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(zb) + (int64_t)(q0 + row) * tokb + ch * 16) =
-                    *reinterpret_cast<const uint4*>(S + row * 144 + ch * 16);
-        }
-    }
-}
-
-int launch_attn_strip(const AttnParams& p, hipStream_t stream) {
-    const int heads = p.B * p.H, qblocks = (p.T + 127) / 128;
-    const int RS = (2 * p.T + 15) / 16 * 16;
-    const size_t lds = 32 * ST_KROW + 64 * ST_VROW + 4 * (size_t)(32 * RS + 32);
-    static size_t attr_done = 0;
-    if (lds > attr_done) {
-        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_kernel<64>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = lds;
-    }
-    {
-        const double bh = (double)heads, tt = (double)p.T * p.T;
-        const double bytes = (4.0 * bh * p.T * p.dh + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
-        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
-        hipLaunchKernelGGL((attn_strip_kernel<64>), dim3(heads * qblocks), dim3(256), lds, stream, p);
-    }
-    PV_LAUNCH_CHECK("attn_strip_kernel");
+    PV_LAUNCH_CHECK("attn_lean_kernel");
     return PV_OK;
 }
 
@@ -1042,10 +855,7 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     if constexpr (sizeof(T) == 2) {
         if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
             (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31)) {
-            // single pass with the score strip in LDS while four strips fit beside the K / V tiles; two passes beyond
-            const bool taps_ok = (reinterpret_cast<uintptr_t>(p.scores) % 2 == 0) && (reinterpret_cast<uintptr_t>(p.pattern) % 2 == 0);
-            if (p.T <= 600 && taps_ok && g_pv_tuning.attn_stream != 1) return launch_attn_strip(p, stream);
-            return launch_attn_stream(p, stream);
+            return launch_attn_lean(p, stream);
         }
     }
     if (p.T <= 64) {
