@@ -312,6 +312,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    # BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives go through the host) -- never a measurement, the line carries the backend
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -321,7 +326,10 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from vit_prisma_amd import HookedViT, HookedViTConfig, _native as N
@@ -425,6 +433,8 @@ def main():
         "roofline": roofline, "kernels": kernels, "whole_forward": whole,
         "overrides": {"env": pv_env, "tuning": N.get_tuning("any")},
     }
+    if backend != "nccl":
+        line["rehearsal_backend"] = backend
 
     if not a.no_sae:
         from vit_prisma_amd.sae.bench_leg import sae_bench_leg

@@ -41,7 +41,7 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 8
+#define PV_ABI_VERSION 9
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -279,9 +279,13 @@ int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
  * flags: PV_SAE_UPDATE_STATS    apply did_fire / act_freq updates (train_sae.py:356-361);
  *        PV_SAE_RENORM_DECODER  set_decoder_norm_to_unit_norm (train_sae.py:307) as part of this step: the forward and
  *                               backward use the unit-norm rows, the physical rewrite of W_dec is deferred to (and fused
- *                               into) the following pv_sae_apply (needs st->dec_inv_norm). */
+ *                               into) the following pv_sae_apply (needs st->dec_inv_norm);
+ *        PV_SAE_INV_NORM_VALID  (with PV_SAE_RENORM_DECODER) st->dec_inv_norm already holds 1 / ||W_dec[j]|| of the current
+ *                               rows: a pv_sae_apply over ALL features leaves them there, and the caller vouches that W_dec
+ *                               has not been touched since -- saves re-reading W_dec for the norms. */
 #define PV_SAE_UPDATE_STATS 1
 #define PV_SAE_RENORM_DECODER 2
+#define PV_SAE_INV_NORM_VALID 4
 int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
                 const float* batch_mean, int32_t n_global, int32_t flags, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);
@@ -290,6 +294,10 @@ int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_t
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.
  * partial_1024: 1024 floats of scratch.  Deterministic two-stage reduction. */
 int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* partial_1024, float* scalars, void* stream);
+/* The same number (up to summation order) from the per-feature sums of squares the backward kernels of the last pv_sae_step
+ * left in `workspace`, without re-reading the gradient: valid only while the gradient buffers are as that step wrote them
+ * (single process: no all-reduce in between). */
+int pv_sae_grad_sqnorm_step(pv_sae_plan* plan, const pv_sae_state* st, const void* workspace, float* scalars, void* stream);
 /* The same over the gradient rows of features [j_lo, j_hi) only (+ gb_dec when include_b_dec): one rank's term of the
  * clip norm when the optimizer is sharded by feature (new functionality; j_lo % 4 == 0). */
 int pv_sae_grad_sqnorm_rows(pv_sae_plan* plan, const pv_sae_state* st, int32_t j_lo, int32_t j_hi, int32_t include_b_dec,

@@ -417,6 +417,31 @@ def test_deferred_decoder_renorm_equals_the_explicit_pass():
     assert float((b.params["W_dec"].norm(dim=1) - 1).abs().max()) > 1e-5               # un-normalised after the optimizer step
 
 
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(768, 24576, 32, 1024), (128, 8192, 16, 512), (100, 4096, 8, 96)])
+def test_every_gradient_row_is_written_and_the_clip_norm_comes_from_the_backward(d_in, d_sae, k, n):
+    """The step has no zero_grad pass: rows of features no token kept are zeroed by their own kernel, every other row is
+    stored once -- poison the buffer first.  The clip norm assembled from the backward kernels' per-feature terms
+    (pv_sae_grad_sqnorm_step) equals the two-stage reduction over the whole buffer (pv_sae_grad_sqnorm)."""
+    _, _, _, T = fresh(d_in, d_sae)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+    for t in range(2):
+        x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+        eng.flat_g.fill_(float("nan"))
+        eng.step(x, renorm_decoder=True)
+        assert bool(torch.isfinite(eng.flat_g[:eng.n_flat]).all())
+        empty = eng.fire_count == 0
+        assert int(empty.sum()) > 0 and float(eng.g["W_dec"][empty].abs().max()) == 0.0
+        eng.grad_sqnorm(from_step=True)
+        fused = float(eng.scalars[3])
+        eng.grad_sqnorm()
+        full = float(eng.scalars[3])
+        ref = float((eng.flat_g[:eng.n_flat].double() ** 2).sum())
+        assert abs(fused - ref) <= 1e-5 * ref and abs(full - ref) <= 1e-5 * ref, (fused, full, ref)
+        eng.apply(1e-3, 1.0)
+        eng.grad_sqnorm(from_step=True)                      # stale after apply: must fall back to the full pass
+        assert abs(float(eng.scalars[3]) - ref) <= 1e-5 * ref
+
+
 def test_activation_cache_shards_written_from_the_native_harvest_match_the_references():
     """SURVEY.md 8f row 2 on the GPU: generate_cached_activations_from_dataset driven by the native run_with_cache writes the
     {idx}.pt fp16 shards the REFERENCE's writer produced for the same images (tests/golden/act_cache_tiny/)."""

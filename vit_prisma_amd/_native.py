@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -79,7 +79,7 @@ EXPORTS = [
     "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_gemm_bias", "pv_transpose_batched",
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
-    "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
+    "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
 ]
@@ -131,6 +131,7 @@ def lib() -> C.CDLL:
         L.pv_sae_renorm_decoder.argtypes = [vp, C.POINTER(SaeState), vp]
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
+        L.pv_sae_grad_sqnorm_step.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp]
         L.pv_sae_grad_sqnorm_rows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp, vp, vp]
         L.pv_sae_apply.argtypes = [vp, C.POINTER(SaeState), vp, C.c_float, C.c_float, i32, i32, i32, vp]
         L.pv_sae_sync_shadows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp]

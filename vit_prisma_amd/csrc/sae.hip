@@ -534,6 +534,25 @@ struct BwdAcc {
         for (int i = 0; i < V4; ++i) { gd[i] = make_float4(0.f, 0.f, 0.f, 0.f); ge[i] = gd[i]; }
         gb = 0.f;
     }
+    // the finished rows of feature j -> gW_dec[j], gW_encT[j], gb_enc[j]; rowsq[j] = their sum of squares (this feature's
+    // term of the clip norm, so that the norm does not have to re-read the 151 MB it was just written to)
+    __device__ __forceinline__ void store(int j, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+                                          float* __restrict__ rowsq, int d, int lane, const int (&col)[V4], const bool (&ok)[V4]) const {
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i)
+            if (ok[i]) {
+                *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col[i]) = gd[i];
+                *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = ge[i];
+                sq += gd[i].x * gd[i].x + gd[i].y * gd[i].y + gd[i].z * gd[i].z + gd[i].w * gd[i].w;
+                sq += ge[i].x * ge[i].x + ge[i].y * ge[i].y + ge[i].z * ge[i].z + ge[i].w * ge[i].w;
+            }
+        sq = wave_sum(sq);
+        if (lane == 0) {
+            gb_enc[j] = gb;
+            rowsq[j] = sq + gb * gb;
+        }
+    }
 };
 
 // accumulate the pairs [q0, q1) (all of ONE feature when STOP_AT_LONG is false).  With STOP_AT_LONG the run is a chunk of
@@ -543,16 +562,11 @@ __device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t 
                                          const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
                                          const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
                                          const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT,
-                                         float* __restrict__ gb_enc, int d, int k, int lane, const int (&col)[V4], const bool (&ok)[V4]) {
+                                         float* __restrict__ gb_enc, float* __restrict__ rowsq, int d, int k, int lane,
+                                         const int (&col)[V4], const bool (&ok)[V4]) {
     int cur = -1;
     auto store_rows = [&](int j) {
-#pragma unroll
-        for (int i = 0; i < V4; ++i)
-            if (ok[i]) {
-                *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col[i]) = acc.gd[i];
-                *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = acc.ge[i];
-            }
-        if (lane == 0) gb_enc[j] = acc.gb;
+        acc.store(j, gW_dec, gW_encT, gb_enc, rowsq, d, lane, col, ok);
         acc.clear();
     };
     bool stop = false;
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
     const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    int d, int k, int n_chunks) {
+    float* __restrict__ rowsq, int d, int k, int n_chunks) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= n_chunks) return;
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     }
     BwdAcc<V4> acc;
     acc.clear();
-    bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, d, k, lane, col, ok);
+    bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, rowsq, d, k, lane, col, ok);
 }
 
 // long lists, stage 1: one wave per BWD_SEG-pair segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb)
@@ -653,7 +667,7 @@ __global__ __launch_bounds__(256) void sae_backward_seg_kernel(
         BwdAcc<V4> acc;
         acc.clear();
         bwd_walk<V4, false>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
-                            nullptr, d, k, lane, col, ok);
+                            nullptr, nullptr, d, k, lane, col, ok);
         float* o = seg_rows + (int64_t)sg * 2 * d;
 #pragma unroll
         for (int i = 0; i < V4; ++i)
@@ -670,7 +684,7 @@ template <int V4>
 __global__ __launch_bounds__(256) void sae_backward_long_kernel(
     const int32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long, const float* __restrict__ seg_rows,
     const float* __restrict__ seg_b, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    int d, int max_segs) {
+    float* __restrict__ rowsq, int d, int max_segs) {
     const int lane = threadIdx.x & 63;
     const uint32_t nl = n_long[0];
     bool ok[V4];
@@ -710,13 +724,48 @@ __global__ __launch_bounds__(256) void sae_backward_long_kernel(
                 acc.gb += gb4[u];
             }
         }
+        acc.store(j, gW_dec, gW_encT, gb_enc, rowsq, d, lane, col, ok);
+    }
+}
+
+// The features no token kept: their gradient rows are zero (this IS their zero_grad).  One wave per feature; the others
+// leave at once (their rows are stored, exactly once, by the backward kernels).
+template <int V4>
+__global__ __launch_bounds__(256) void sae_zero_empty_kernel(const uint32_t* __restrict__ offs, float* __restrict__ gW_dec,
+                                                             float* __restrict__ gW_encT, float* __restrict__ gb_enc,
+                                                             float* __restrict__ rowsq, int d_sae, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= d_sae || offs[j + 1] != offs[j]) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < V4; ++i)
-            if (ok[i]) {
-                *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + col[i]) = acc.gd[i];
-                *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + col[i]) = acc.ge[i];
-            }
-        if (lane == 0) gb_enc[j] = acc.gb;
+    for (int i = 0; i < V4; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < d) {
+            *reinterpret_cast<float4*>(gW_dec + (int64_t)j * d + c) = z;
+            *reinterpret_cast<float4*>(gW_encT + (int64_t)j * d + c) = z;
+        }
+    }
+    if (lane == 0) {
+        gb_enc[j] = 0.f;
+        rowsq[j] = 0.f;
+    }
+}
+
+// clip norm from the per-feature terms of the backward (+ gb_dec): one workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restrict__ rowsq, int d_sae, const float* __restrict__ gb_dec,
+                                                            int d_in, float* __restrict__ scalars) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < d_sae; j += 1024) s += rowsq[j];
+    for (int i = threadIdx.x; i < d_in; i += 1024) s += gb_dec[i] * gb_dec[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        scalars[3] = t;
     }
 }
 
@@ -773,40 +822,56 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
     return w - (c.lr / c.bc1) * (m / denom);
 }
 
-template <int DPL>   // W_dec rows [j_lo, j_hi): one wave per row, with the parallel-gradient projection
+template <int V4>   // W_dec rows [j_lo, j_hi): one wave per row (16 bytes per lane and load), with the parallel-gradient projection
 __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                         float* __restrict__ M, float* __restrict__ V,
                                                         const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d,
-                                                        const float* __restrict__ inv_norm) {
+                                                        const float* inv_norm, float* inv_next /* may be the same array */) {
     const int lane = threadIdx.x & 63;
     const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= j_hi) return;
     const float coef = clip_coef(scalars, c.max_norm);
     const float rn = inv_norm ? inv_norm[j] : 1.f;            // pending set_decoder_norm_to_unit_norm (see pv_sae_step)
-    float w[DPL], g[DPL];
+    float4 w[V4], g[V4], m[V4], v[V4];
+    bool ok[V4];
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int col = lane + 64 * i;
-        w[i] = g[i] = 0.f;
-        if (col < d) {
-            w[i] = W[(int64_t)j * d + col] * rn;
-            g[i] = G[(int64_t)j * d + col] * coef;
-            dot += g[i] * w[i];
-        }
+    for (int i = 0; i < V4; ++i) {
+        const int col = 4 * lane + 256 * i;
+        ok[i] = col < d;
+        const int64_t o = (int64_t)j * d + col;
+        w[i] = ld4(W + o, ok[i]);
+        g[i] = ld4(G + o, ok[i]);
+        m[i] = ld4(M + o, ok[i]);
+        v[i] = ld4(V + o, ok[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        w[i].x *= rn; w[i].y *= rn; w[i].z *= rn; w[i].w *= rn;
+        g[i].x *= coef; g[i].y *= coef; g[i].z *= coef; g[i].w *= coef;
+        dot += g[i].x * w[i].x + g[i].y * w[i].y + g[i].z * w[i].z + g[i].w * w[i].w;
     }
     dot = wave_sum(dot);
+    float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-        const int col = lane + 64 * i;
-        if (col < d) {
-            const int64_t o = (int64_t)j * d + col;
-            const float gp = g[i] - dot * w[i];             // remove_gradient_parallel_to_decoder_directions
-            float m = M[o], v = V[o];
-            W[o] = adam_update(w[i], gp, m, v, c);
-            M[o] = m;
-            V[o] = v;
-        }
+    for (int i = 0; i < V4; ++i) {
+        if (!ok[i]) continue;
+        const int64_t o = (int64_t)j * d + 4 * lane + 256 * i;
+        float4 wn;                                          // g - dot * w: remove_gradient_parallel_to_decoder_directions
+        wn.x = adam_update(w[i].x, g[i].x - dot * w[i].x, m[i].x, v[i].x, c);
+        wn.y = adam_update(w[i].y, g[i].y - dot * w[i].y, m[i].y, v[i].y, c);
+        wn.z = adam_update(w[i].z, g[i].z - dot * w[i].z, m[i].z, v[i].z, c);
+        wn.w = adam_update(w[i].w, g[i].w - dot * w[i].w, m[i].w, v[i].w, c);
+        *reinterpret_cast<float4*>(W + o) = wn;
+        *reinterpret_cast<float4*>(M + o) = m[i];
+        *reinterpret_cast<float4*>(V + o) = v[i];
+        sq += wn.x * wn.x + wn.y * wn.y + wn.z * wn.z + wn.w * wn.w;
+    }
+    // the next step's set_decoder_norm_to_unit_norm needs 1 / ||row|| of what was just written: leave it behind
+    // (PV_SAE_INV_NORM_VALID) instead of re-reading W_dec for it
+    if (inv_next) {
+        sq = wave_sum(sq);
+        if (lane == 0) inv_next[j] = 1.0f / sqrtf(sq);
     }
 }
 
@@ -1007,6 +1072,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.colsum = take((size_t)d.d_in * 4);
     w.batch_mean = take((size_t)d.d_in * 4);
     w.sqpart = take((size_t)w.sq_blocks * 4);
+    w.rowsq = take((size_t)d.d_sae * 4);              // per-feature terms of the clip norm (backward kernels)
     w.x16 = take(N * (size_t)d.d_in * 2);
     w.xnorm = take(N * 4);
     w.sample = take(N * (size_t)(d.d_sae / PV_SAE_SAMPLE_STRIDE + 1) * 4);
@@ -1212,11 +1278,11 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     PV_REQUIRE(!renorm || st->dec_inv_norm, "PV_SAE_RENORM_DECODER needs pv_sae_state.dec_inv_norm");
     const float* inv_norm = nullptr;
     plan->renorm_pending = renorm;
-    if (renorm) {
+    if (renorm && !(flags & PV_SAE_INV_NORM_VALID)) {
         hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 15) / 16), dim3(256), 0, stream, (const float*)st->W_dec,
                            st->dec_inv_norm, d.d_sae, d.d_in);
-        inv_norm = st->dec_inv_norm;
     }
+    if (renorm) inv_norm = st->dec_inv_norm;
     int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, true, wsb, ws, stream);
     if (rc) return rc;
 
@@ -1246,10 +1312,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         int32_t* long_list = (int32_t*)(wsb + ws.long_list);
         uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
         const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
-        // rows of the features that did not fire stay zero (this IS their zero_grad); every other row is stored exactly once
-        PV_HIP_CHECK(hipMemsetAsync(st->gW_dec, 0, (size_t)d.d_sae * d.d_in * 4, stream));
-        PV_HIP_CHECK(hipMemsetAsync(st->gW_enc, 0, (size_t)d.d_sae * d.d_in * 4, stream));
-        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)d.d_sae * 4, stream));
+        float* rowsq = (float*)(wsb + ws.rowsq);
         const int max_segs = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1;        // sum ceil(c / SEG) over lists with c > LMAX
         uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
         float* seg_rows = (float*)(wsb + ws.seg_rows);
@@ -1263,17 +1326,21 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
+        // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
+        // the long-list combine
 #define CALL(D)                                                                                                        \
+    hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
+                       st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in);                                                   \
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
-                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, d.d_in, k, max_chunks);      \
+                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
     hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
                        (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
                        (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
                        d.d_in, k, max_segs);                                                                                     \
     hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
                        (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
-                       st->gb_enc, d.d_in, max_segs)
+                       st->gb_enc, rowsq, d.d_in, max_segs)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
@@ -1288,6 +1355,17 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     }
     // scalars[0] = loss (== mse for topk)
     PV_HIP_CHECK(hipMemcpyAsync(out->scalars, out->scalars + 1, 4, hipMemcpyDeviceToDevice, stream));
+    return PV_OK;
+}
+
+// the same number from the per-feature terms the last pv_sae_step left in its workspace
+extern "C" int pv_sae_grad_sqnorm_step(pv_sae_plan* plan, const pv_sae_state* st, const void* workspace, float* scalars, void* stream_) {
+    PV_REQUIRE(plan && st && workspace && scalars && st->gb_dec, "null argument");
+    const pv_sae_desc& d = plan->d;
+    const SaeWs ws = sae_carve(d);
+    hipLaunchKernelGGL(sqnorm_rowsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_,
+                       (const float*)((const unsigned char*)workspace + ws.rowsq), d.d_sae, (const float*)st->gb_dec, d.d_in, scalars);
+    PV_LAUNCH_CHECK("sqnorm_rowsq_kernel");
     return PV_OK;
 }
 
@@ -1343,8 +1421,8 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     const dim3 block(256);
     if (nj > 0) {
         const float* inv_norm = plan->renorm_pending ? (const float*)st->dec_inv_norm : nullptr;
-#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm)
-        DPL_DISPATCH(d.d_in, CALL);
+#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm, st->dec_inv_norm)
+        V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
                            st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi);

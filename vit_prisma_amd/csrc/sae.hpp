@@ -17,7 +17,7 @@ struct pv_sae_plan {
 
 struct SaeWs {
     size_t total;
-    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, wpos, long_list, n_long, seg_range, seg_rows, seg_b, pairs, colpart, colsum, batch_mean, sqpart;
+    size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, wpos, long_list, n_long, seg_range, seg_rows, seg_b, pairs, colpart, colsum, batch_mean, sqpart, rowsq;
     // fast encoder (sae_enc.hip)
     size_t x16, xnorm, sample, thr, sq, band, cand_cnt, cand, fb_list, fb_count, wmax;
     int sq_blocks;

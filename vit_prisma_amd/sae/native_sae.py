@@ -87,6 +87,8 @@ class NativeSAE:
         self.workspace = torch.empty(self.lib.pv_sae_workspace_bytes(self._plan), dtype=torch.uint8, device=dev)
         self.adam_step = 0
         self._shadow_key: Optional[Tuple[int, int]] = None
+        self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
+        self._grad_fresh = False                                   # gradient buffers exactly as the last step wrote them
         self.sync_shadows()
 
     def __del__(self):
@@ -143,7 +145,12 @@ class NativeSAE:
             self.sync_shadows()
 
     # ---- the step ----------------------------------------------------------------------------------
+    def _w_dec_key(self) -> Tuple[int, int]:
+        t = self._src["W_dec"]
+        return (t.data_ptr(), t._version)
+
     def renorm_decoder(self) -> None:
+        self._inv_norm_key = None
         st = self._state()
         N.check(self.lib.pv_sae_renorm_decoder(self._plan, C.byref(st), self._stream()), "pv_sae_renorm_decoder")
 
@@ -156,6 +163,8 @@ class NativeSAE:
         self._ensure_shadows()
         n = x.shape[0]
         st = self._state()
+        # the last full-range apply left 1 / ||W_dec[j]|| of the rows it wrote; good as long as nobody touched W_dec since
+        inv_valid = renorm_decoder and self._inv_norm_key is not None and self._inv_norm_key == self._w_dec_key()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=self.topk_idx.data_ptr(),
                        topk_val=self.topk_val.data_ptr(), scalars=self.scalars.data_ptr(),
                        fire_count=self.fire_count.data_ptr())
@@ -164,10 +173,19 @@ class NativeSAE:
             bm = batch_mean.to(torch.float32).contiguous()
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                      int(n_global if n_global is not None else n),
-                                     int(bool(update_stats)) | (2 if renorm_decoder else 0), C.byref(out),
+                                     int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0), C.byref(out),
                                      self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_step")
+        self._grad_fresh = True
 
-    def grad_sqnorm(self) -> None:
+    def grad_sqnorm(self, from_step: bool = False) -> None:
+        """scalars[3] = sum of squares of the whole gradient.  from_step: take it from the per-feature terms the backward
+        kernels of the last ``step`` left behind instead of re-reading the 151 MB -- only while the gradient buffers are
+        exactly what that step wrote (no all-reduce, no edit through ``g``); otherwise the full pass runs."""
+        if from_step and self._grad_fresh:
+            st = self._state()
+            N.check(self.lib.pv_sae_grad_sqnorm_step(self._plan, C.byref(st), self.workspace.data_ptr(), self.scalars.data_ptr(),
+                                                     self._stream()), "pv_sae_grad_sqnorm_step")
+            return
         N.check(self.lib.pv_sae_grad_sqnorm(self.flat_g.data_ptr(), self.n_flat, self.sq_partial.data_ptr(),
                                             self.scalars.data_ptr(), self._stream()), "pv_sae_grad_sqnorm")
 
@@ -185,6 +203,9 @@ class NativeSAE:
         N.check(self.lib.pv_sae_apply(self._plan, C.byref(st), self.scalars.data_ptr(),
                                       float(max_grad_norm) if max_grad_norm else -1.0, float(lr), self.adam_step,
                                       int(j_lo), int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_apply")
+        self._grad_fresh = False
+        full = j_lo == 0 and (j_hi is None or j_hi == self.d_sae)
+        self._inv_norm_key = self._w_dec_key() if full else None
 
     def encode_topk(self, x: torch.Tensor):
         """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts."""
@@ -214,7 +235,7 @@ class NativeSAE:
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:
         self.step(x, renorm_decoder=True)
-        self.grad_sqnorm()
+        self.grad_sqnorm(from_step=True)
         self.apply(lr, max_grad_norm)
 
     def grad_W_enc(self) -> torch.Tensor:

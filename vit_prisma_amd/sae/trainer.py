@@ -260,7 +260,7 @@ class VisionSAETrainer:
         eng.n_fwd_since_fired = n_since_fired
         if self.world == 1:
             eng.step(x, update_stats=True, renorm_decoder=True)  # set_decoder_norm_to_unit_norm is part of the step
-            eng.grad_sqnorm()                                   # clip_grad_norm_
+            eng.grad_sqnorm(from_step=True)                     # clip_grad_norm_ (the gradient is as the step wrote it)
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
             self._native_dp_step(eng, sae, x, lr, act_freq_scores, n_since_fired)
