@@ -149,6 +149,64 @@ int pv_launch_l2norm(int dtype, const void* x, void* out, int rows, int n, hipSt
     return PV_OK;
 }
 
+namespace {
+// bf16 patches as GEMM rows (patch size other than 32, even): image row (b, c, y) is S contiguous pixels = G runs of p; run
+// px goes to row b*P + (y/p)*G + px of the [B*P][Kp] matrix at column c*p*p + (y%p)*p.  One thread per pixel PAIR (a dword:
+// p and every column offset are even), so the reads of a wave are one contiguous stretch of the image row.
+// Columns [K, Kp) (Kp = K rounded up to 8: whole 16-byte chunks for the DMA of the tiled GEMM) are zeroed.
+__global__ __launch_bounds__(256) void patch_pack_kernel(const uint32_t* __restrict__ img, uint32_t* __restrict__ out, int B, int C,
+                                                         int S, int p, int G, int Kp) {
+    const int half_row = S / 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_rows = (int64_t)B * C * S;
+    if (t >= n_rows * half_row) return;
+    const int w = (int)(t % half_row);
+    const int64_t r = t / half_row;                    // (b, c, y)
+    const int y = (int)(r % S);
+    const int c = (int)((r / S) % C);
+    const int b = (int)(r / ((int64_t)S * C));
+    const int px = 2 * w / p, j = 2 * w - px * p, py = y / p, i = y - py * p;
+    if (px >= G || py >= G) return;                    // pixels beyond the last whole patch
+    const int64_t m = ((int64_t)b * G + py) * G + px;
+    out[(m * Kp + (c * p + i) * p + j) >> 1] = img[t];
+}
+__global__ __launch_bounds__(256) void patch_pad_kernel(uint32_t* __restrict__ out, int64_t rows, int K, int Kp) {
+    const int padw = (Kp - K) / 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * padw) return;
+    out[((t / padw) * Kp + K) / 2 + t % padw] = 0u;
+}
+// rows of [R][K] -> [R][Kp], zero-padded (the patch-embedding weights beside patch_pack_kernel's rows)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int K, int Kp) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)R * Kp) return;
+    const int col = (int)(t % Kp);
+    out[t] = col < K ? in[(t / Kp) * K + col] : (uint16_t)0;
+}
+}  // namespace
+
+int pv_launch_patch_pack_bf16(const void* images, void* out, int B, int C, int S, int p, int G, int Kp, hipStream_t stream) {
+    PV_REQUIRE(p % 2 == 0 && S % 2 == 0 && Kp % 2 == 0, "patch_pack needs an even patch and image size");
+    PV_REQUIRE(((uintptr_t)images & 3) == 0 && ((uintptr_t)out & 3) == 0, "patch_pack alignment");
+    const int K = C * p * p;
+    const int64_t n = (int64_t)B * C * S * (S / 2);
+    hipLaunchKernelGGL(patch_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)images,
+                       (uint32_t*)out, B, C, S, p, G, Kp);
+    if (Kp > K) {
+        const int64_t rows = (int64_t)B * G * G, m = rows * ((Kp - K) / 2);
+        hipLaunchKernelGGL(patch_pad_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, (uint32_t*)out, rows, K, Kp);
+    }
+    PV_LAUNCH_CHECK("patch_pack_kernel");
+    return PV_OK;
+}
+
+int pv_launch_pad_rows_bf16(const void* in, void* out, int R, int K, int Kp, hipStream_t stream) {
+    const int64_t n = (int64_t)R * Kp;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, R, K, Kp);
+    PV_LAUNCH_CHECK("pad_rows_kernel");
+    return PV_OK;
+}
+
 int pv_launch_transpose(int elem_bytes, const void* in, void* out, int batch, int R, int C, hipStream_t stream) {
     PV_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "transpose element size must be 2 or 4");
     PV_REQUIRE(batch > 0 && R > 0 && C > 0 && batch < 65536, "transpose dims");

@@ -24,3 +24,7 @@ struct LnParams {
 int pv_launch_ln(int dtype, const LnParams& p, hipStream_t stream);
 int pv_launch_l2norm(int dtype, const void* x, void* out, int rows, int n, hipStream_t stream);
 int pv_launch_transpose(int elem_bytes, const void* in, void* out, int batch, int R, int C, hipStream_t stream);
+// bf16 NCHW images -> [B*G*G][Kp] patch rows (im2col once per batch, zero-padded to Kp columns), and the matching row padding
+// of the [d][K] patch-embedding weights: the operands of the tiled GEMM for patch sizes its in-kernel gather does not cover
+int pv_launch_patch_pack_bf16(const void* images, void* out, int B, int C, int S, int p, int G, int Kp, hipStream_t stream);
+int pv_launch_pad_rows_bf16(const void* in, void* out, int R, int K, int Kp, hipStream_t stream);

@@ -238,10 +238,13 @@ class CacheVisionActivationStore:
     (activations_store.py:21-152): same constructor (``cfg`` only, ``cfg.use_cached_activations`` must be set), same
     ``storage_buffer`` / ``get_buffer`` / ``get_data_loader`` / ``next_batch`` and the same half-buffer shuffle-mix.
     Like the reference, every refill starts reading at shard 0 (its ``next_cache_idx`` is a local of
-    ``_load_cached_activations``): the cache is meant to be at least one buffer long."""
+    ``_load_cached_activations``): the cache is meant to be at least one buffer long.
+    Data parallel (no reference counterpart): rank r of ``world`` reads the shards r, r + world, ... and serves
+    ``train_batch_size // world`` tokens per step, like the live store's DistributedSampler split."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, rank: int = 0, world: int = 1):
         self.cfg = cfg
+        self.rank, self.world = int(rank), max(int(world), 1)
         if not cfg.use_cached_activations:
             raise ValueError("CacheVisionActivationStore cannot be initialized with cfg.use_cached_activations = False ")
         self._files = {}
@@ -262,7 +265,7 @@ class CacheVisionActivationStore:
         buffer_size = total_size * context_size
         buf = torch.zeros((buffer_size, num_layers, d_in), dtype=cfg.dtype, device=cfg.device)
         filled = 0
-        idx = 0
+        idx = self.rank
         while filled < buffer_size:
             path = f"{cfg.cached_activations_path}/{idx}.pt"
             if not os.path.exists(path):
@@ -276,7 +279,7 @@ class CacheVisionActivationStore:
             if partial:
                 self.next_idx_within_buffer = acts.shape[0]
             else:
-                idx += 1
+                idx += self.world
                 self.next_idx_within_buffer = 0
         return buf
 
@@ -291,7 +294,7 @@ class CacheVisionActivationStore:
         mix = mix[torch.randperm(mix.shape[0], device=mix.device)]
         half = mix.shape[0] // 2
         self.storage_buffer = mix[:half]
-        return iter(_TensorBatches(mix[half:], cfg.train_batch_size))
+        return iter(_TensorBatches(mix[half:], max(cfg.train_batch_size // self.world, 1)))
 
     def next_batch(self) -> torch.Tensor:
         try:

@@ -75,7 +75,7 @@ class VisionSAETrainer:
         self.activations_store = activations_store
         if self.activations_store is None and cfg.use_cached_activations and not self.is_transcoder:
             from .store import CacheVisionActivationStore
-            self.activations_store = CacheVisionActivationStore(cfg)             # train_sae.py:138-139
+            self.activations_store = CacheVisionActivationStore(cfg, *_dist_info())     # train_sae.py:138-139
         if self.activations_store is None and dataset is not None:
             self.activations_store = VisionActivationsStore(cfg, model, dataset, eval_dataset=eval_dataset,
                                                             num_workers=0)
