@@ -334,6 +334,20 @@ int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const float* x, in
                    int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, float* scalars, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline: get_clip_val_transforms (transforms/model_transforms.py:9-20) for a batch of decoded
+ * uint8 RGB images [B][H][W][3] (device) -> [B][3][S][S] fp32 / bf16 in one kernel:
+ *   Resize(S, BICUBIC, antialias) -- Pillow's two-pass fixed-point resampler, which is what torchvision's Resize runs on the
+ *   PIL images the reference feeds it: bounds [n][2] = (first input index, tap count) and taps [n][ksize] (int32, 22
+ *   fractional bits) per output column / row, built on the host the way Resample.c precompute_coeffs + normalize_coeffs_8bpc
+ *   do (vit_prisma_amd/transforms.py:_pil_coeffs); horizontal pass, uint8 rounding, vertical pass, uint8 rounding --
+ *   CenterCrop (`left`, `top` inside the new_w x new_h resized image) -- ToTensor (/ 255) -- Normalize ((x - mean) / std).
+ * Bit-identical to the reference's CPU pipeline for RGB uint8 input. */
+int pv_clip_preprocess(const uint8_t* images, int32_t B, int32_t H, int32_t W, const int32_t* xbounds, const int32_t* xtaps,
+                       int32_t ksize_x, const int32_t* ybounds, const int32_t* ytaps, int32_t ksize_y, int32_t new_w,
+                       int32_t new_h, int32_t left, int32_t top, int32_t S, const float* mean3_host, const float* std3_host,
+                       int32_t out_dtype, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

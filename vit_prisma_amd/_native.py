@@ -82,6 +82,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
+    "pv_clip_preprocess",
 ]
 
 
@@ -138,6 +139,8 @@ def lib() -> C.CDLL:
         L.pv_sae_encoder_is_filtered.argtypes = [vp]
         L.pv_sae_forward.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.pv_debug_sae_ws_offset.argtypes = [vp, C.c_char_p]
+        L.pv_clip_preprocess.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32,
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp]
         L.pv_debug_sae_ws_offset.restype = sz
         L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]
     _lib = L
