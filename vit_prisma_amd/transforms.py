@@ -75,8 +75,11 @@ def get_clip_val_transforms(image_size: int = 224, mean: Sequence[float] = CLIP_
 
 class GpuClipTransform:
     def __init__(self, image_size: int = 224, mean: Sequence[float] = CLIP_MEAN, std: Sequence[float] = CLIP_STD,
-                 device: Union[str, torch.device] = "cuda", dtype: torch.dtype = torch.float32):
+                 device: Union[str, torch.device] = "cuda", dtype: torch.dtype = torch.float32, native: Union[bool, None] = None):
+        """native: None = the HIP kernel on a GPU (an error if libpvnative.so is missing there), PyTorch on the CPU;
+        False = always the PyTorch path."""
         self.size, self.device, self.dtype = image_size, torch.device(device), dtype
+        self.native = native
         self.mean = torch.tensor(mean, dtype=torch.float32, device=self.device)[None, :, None, None]
         self.std = torch.tensor(std, dtype=torch.float32, device=self.device)[None, :, None, None]
         self._mean3, self._std3 = tuple(float(v) for v in mean), tuple(float(v) for v in std)
@@ -85,7 +88,12 @@ class GpuClipTransform:
 
     def _native_ok(self) -> bool:
         from . import _native as N
-        return self.device.type == "cuda" and self.dtype in (torch.float32, torch.bfloat16) and N.available()
+        if self.native is False or self.device.type != "cuda" or self.dtype not in (torch.float32, torch.bfloat16):
+            return False
+        if not N.available():
+            raise RuntimeError("GpuClipTransform on a GPU needs libpvnative.so (python -m vit_prisma_amd.build); "
+                               "pass native=False for the PyTorch path")
+        return True
 
     def _native_batch(self, x_u8: torch.Tensor) -> torch.Tensor:
         """``[B, H, W, 3]`` uint8 on the device -> ``[B, 3, S, S]`` through pv_clip_preprocess."""
