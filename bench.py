@@ -233,12 +233,15 @@ def sae_cpu_baseline(seconds: float) -> dict:
 
 
 def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary
-    (profiles/*pmc_traffic*.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x FETCH correction), as the
+    """HBM bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary of the B/32 bs=512 forward
+    (profiles/r*_pmc_traffic_vit.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x FETCH correction), as the
     launch-weighted mean over every kernel of the family (the GEMM family = all its template instances: what the
     HIP events of the timed region bracket).  None when no PMC summary is committed."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), key=os.path.getmtime)
+    # the B/32 bs=512 passes only (r02_pmc_traffic_vit.json, round 1: r01_pmc_traffic_v7.json), newest round first by NAME:
+    # modification times mean nothing in a fresh copy of the tree, and the SAE / L/14 summaries hold other workloads
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))
+                   if os.path.basename(p).endswith(("_vit.json", "_v7.json")))
     for path in reversed(paths):
         try:
             with open(path) as f:

@@ -31,7 +31,7 @@ def _pmc_step_traffic() -> dict:
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    paths = sorted(glob.glob(os.path.join(root, "profiles", "*pmc_traffic_sae*.json")), key=os.path.getmtime)
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic_sae*.json")))      # newest round last, by name
     for path in reversed(paths):
         try:
             with open(path) as f:
