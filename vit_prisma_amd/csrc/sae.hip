@@ -399,12 +399,15 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
 
 // deterministic scalar reduction: out[slot] = scale * sum(v[0..n))
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ v, float* __restrict__ out, int n,
-                                                         float scale, int slot) {
+                                                         float scale, int slot, int slot2) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += v[i];
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) out[slot] = s * scale;
+    if (threadIdx.x == 0) {
+        out[slot] = s * scale;
+        if (slot2 >= 0) out[slot2] = s * scale;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,21 +772,50 @@ __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restr
     }
 }
 
-// gb_dec[i] = colsum(dY)[i] - sum_j W_enc[i][j] gb_enc[j]     (one workgroup per input dim i)
-__global__ __launch_bounds__(256) void sae_gbdec_kernel(const float* __restrict__ W_enc, const float* __restrict__ gb_enc,
-                                                        const float* __restrict__ dy_colsum, float* __restrict__ gb_dec,
-                                                        int d_sae) {
-    __shared__ float red[4];
-    const int i = blockIdx.x;
-    const float* w = W_enc + (int64_t)i * d_sae;
-    float s = 0.f;
-    for (int j = threadIdx.x * 4; j < d_sae; j += 1024) {
-        const float4 a = *reinterpret_cast<const float4*>(w + j);
-        const float4 b = *reinterpret_cast<const float4*>(gb_enc + j);
-        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+// gb_dec = colsum(dY) - W_enc gb_enc (the encoder-input path of b_dec: sae_in = x - b_dec).  The second term as partial rows
+// for colsum_final_kernel, stacked under the dY partials with the sign folded in: workgroup c sums -gb_enc[j] * W_encT[j][:]
+// over its GBD_ROWS features, skipping the features no token kept (gb_enc = 0: half of them on the bench batch), so the
+// pass reads the fired rows of W_encT once, coalesced, instead of all of W_enc.
+constexpr int GBD_ROWS = 96;
+__global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
+                                                                float* __restrict__ partial, int d_sae, int d) {
+    __shared__ float red[3][1024];                       // waves 1..3 -> wave 0, up to 1024 columns
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * GBD_ROWS, j1 = min(j0 + GBD_ROWS, d_sae);
+    float4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0 + wv; j < j1; j += 4) {
+        const float g = gb_enc[j];
+        if (g == 0.f) continue;                          // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < d) {
+                const float4 w = *reinterpret_cast<const float4*>(W_encT + (int64_t)j * d + c);
+                acc[i].x -= g * w.x; acc[i].y -= g * w.y; acc[i].z -= g * w.z; acc[i].w -= g * w.w;
+            }
+        }
     }
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) gb_dec[i] = dy_colsum[i] - s;
+    if (wv > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&red[wv - 1][4 * lane + 256 * i]) = acc[i];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < d) {
+                float4 t = acc[i];
+                for (int w = 0; w < 3; ++w) {            // fixed order
+                    const float4 o = *reinterpret_cast<const float4*>(&red[w][c]);
+                    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+                }
+                *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * d + c) = t;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1068,7 +1100,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
         w.seg_b = take(max_segs * 4);
     }
     w.pairs = take(N * (size_t)d.k * 4);
-    w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS) * d.d_in * 4);
+    w.colpart = take((size_t)((d.max_tokens + CS_ROWS - 1) / CS_ROWS + (d.d_sae + GBD_ROWS - 1) / GBD_ROWS) * d.d_in * 4);
     w.colsum = take((size_t)d.d_in * 4);
     w.batch_mean = take((size_t)d.d_in * 4);
     w.sqpart = take((size_t)w.sq_blocks * 4);
@@ -1170,8 +1202,8 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     const pv_sae_desc& d = plan->d;
     uint32_t* feat_cnt = want_csr ? (uint32_t*)(wsb + ws.cnt) : nullptr;
     uint32_t* wpos = want_csr ? (uint32_t*)(wsb + ws.wpos) : nullptr;
-    if (want_csr) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
+    if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
     float* bmean = (float*)(wsb + ws.batch_mean);
     if (batch_mean) {
         PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
@@ -1246,7 +1278,7 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
     PV_LAUNCH_CHECK("sae_decode_kernel");
     if (scalars)
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), scalars, N,
-                           1.0f / ((float)N * (float)d.d_in), 1);
+                           1.0f / ((float)N * (float)d.d_in), 1, -1);
     if (ln_mu) PV_HIP_CHECK(hipMemcpyAsync(ln_mu, wsb + ws.mu, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
     if (ln_std) PV_HIP_CHECK(hipMemcpyAsync(ln_std, wsb + ws.sd, (size_t)N * 4, hipMemcpyDeviceToDevice, stream));
     return PV_OK;
@@ -1260,6 +1292,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
     PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_encT, "pv_sae_step needs the transposed encoder copy (pv_sae_state.W_encT, see pv_sae_sync_shadows)");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
     const pv_sae_desc& d = plan->d;
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
@@ -1303,7 +1336,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         PV_LAUNCH_CHECK("sae_decode_kernel");
         // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
-                           1.0f / ((float)n_global * (float)d.d_in), 1);
+                           1.0f / ((float)n_global * (float)d.d_in), 1, 0);                  // scalars[0] = loss == scalars[1] = mse
         // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
         uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
@@ -1344,17 +1377,16 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
-        // gb_dec = colsum(dY) - W_enc @ gb_enc
-        const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
-                           (const float*)(wsb + ws.colpart), (float*)(wsb + ws.colsum), nblk, d.d_in, 1.0f);
-        hipLaunchKernelGGL(sae_gbdec_kernel, dim3(d.d_in), dim3(256), 0, stream, (const float*)st->W_enc, (const float*)st->gb_enc,
-                           (const float*)(wsb + ws.colsum), st->gb_dec, d.d_sae);
+        // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+        float* colpart = (float*)(wsb + ws.colpart);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, colpart, N, d.d_in);
+        hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                           colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                           nblk + ngb, d.d_in, 1.0f);
         PV_LAUNCH_CHECK("sae bias-grad kernels");
     }
-    // scalars[0] = loss (== mse for topk)
-    PV_HIP_CHECK(hipMemcpyAsync(out->scalars, out->scalars + 1, 4, hipMemcpyDeviceToDevice, stream));
     return PV_OK;
 }
 
@@ -1375,7 +1407,7 @@ extern "C" int pv_sae_grad_sqnorm(const float* flat_grads, int64_t n, float* par
     PV_REQUIRE(pv_aligned16(flat_grads), "gradient buffer must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, stream, flat_grads, n, partial);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3, -1);
     PV_LAUNCH_CHECK("sqnorm kernels");
     return PV_OK;
 }
@@ -1398,7 +1430,7 @@ extern "C" int pv_sae_grad_sqnorm_rows(pv_sae_plan* plan, const pv_sae_state* st
     }
     if (include_b_dec)
         hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(8), dim3(256), 0, stream, (const float*)st->gb_dec, (int64_t)d.d_in, partial + 776);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)partial, scalars, 1024, 1.0f, 3, -1);
     PV_LAUNCH_CHECK("sqnorm kernels");
     return PV_OK;
 }

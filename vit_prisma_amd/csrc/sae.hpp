@@ -46,7 +46,7 @@ static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
 // sae_enc.hip: hidden_pre top-k of N tokens through the fp16 filter GEMM + exact re-scoring (see the file header).
 // Requires the shadows (W_encT, W_enc16T, enc_colsq) of `st` to be current.  prep (sae.hip) has already filled sae_in,
 // x16, xnorm.  Rows the filter cannot decide are recomputed exactly (hidden scratch + sae_topk_rows).
-// feat_cnt / wpos (both or neither; feat_cnt zeroed by the caller): per-feature pair counts and each kept pair's position in
+// feat_cnt / wpos (both or neither; feat_cnt is zeroed here): per-feature pair counts and each kept pair's position in
 // its feature's list, for the backward's CSR.
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
                     uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream);

@@ -339,8 +339,11 @@ __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict__ colsq, int d_sae, float* __restrict__ out,
-                                                        uint32_t* __restrict__ fb_count) {
+                                                        uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt) {
     __shared__ float red[16];
+    // (also the zeroing of the per-feature pair counters the select kernel draws list positions from)
+    if (feat_cnt)
+        for (int j = threadIdx.x; j < d_sae; j += 1024) feat_cnt[j] = 0u;
     float m = 0.f;
     for (int j0 = threadIdx.x; j0 < d_sae; j0 += 8 * 1024) {  // 8 independent loads in flight per thread
         float c[8];
@@ -547,7 +550,7 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     float* wmax = (float*)(wsb + ws.wmax);
     uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
     int32_t* fb_list = (int32_t*)(wsb + ws.fb_list);
-    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count);
+    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count, feat_cnt);
     EncParams p = {};
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
     // pass 0: every S-th feature
