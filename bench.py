@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allow-overrides", action="store_true", help="A/B runs only: measure with PV_* env / tuning overrides (recorded)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B runs only (needs --allow-overrides): pv_debug_set_tuning(KEY, VALUE) before measuring")
     return ap.parse_args()
 
 
@@ -341,6 +343,10 @@ def main():
     # a measurement is only valid on the kernels the library picks by itself: no PV_* environment variable, no
     # pv_debug_set_tuning override (the launch path reads neither the environment nor anything else that could skip work)
     pv_env = sorted(k for k in os.environ if k.startswith("PV_"))
+    for kv in a.tune:
+        assert a.allow_overrides, "--tune is for A/B runs: pass --allow-overrides"
+        key, val = kv.split("=")
+        N.set_tuning(key, int(val))
     if (pv_env or N.get_tuning("any")) and not a.allow_overrides:
         raise SystemExit(f"bench.py refuses to measure with kernel overrides active: env {pv_env}, tuning {N.get_tuning('any')}")
 
@@ -434,7 +440,7 @@ def main():
                                f"bs={a.batch}/GPU, {a.dtype}", "images_per_gpu_per_step": a.batch,
                    "cache_keys": n_keys, "parallelism": f"image-batch sharding x{world}, no data-path collective"},
         "roofline": roofline, "kernels": kernels, "whole_forward": whole,
-        "overrides": {"env": pv_env, "tuning": N.get_tuning("any")},
+        "overrides": {"env": pv_env, "tuning": N.get_tuning("any"), "tune": list(a.tune)},
     }
     if backend != "nccl":
         line["rehearsal_backend"] = backend

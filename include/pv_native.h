@@ -282,10 +282,17 @@ int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
  *                               into) the following pv_sae_apply (needs st->dec_inv_norm);
  *        PV_SAE_INV_NORM_VALID  (with PV_SAE_RENORM_DECODER) st->dec_inv_norm already holds 1 / ||W_dec[j]|| of the current
  *                               rows: a pv_sae_apply over ALL features leaves them there, and the caller vouches that W_dec
- *                               has not been touched since -- saves re-reading W_dec for the norms. */
+ *                               has not been touched since -- saves re-reading W_dec for the norms;
+ *        PV_SAE_SPARSE_GRADS    single-process training only: the gradient rows (gW_enc^T, gW_dec) of features that kept no
+ *                               token this step are NOT written (they are zero by definition; on a trained-like batch that is
+ *                               half of the 151 MB).  The following pv_sae_apply takes them as zero from the per-feature
+ *                               offsets this step leaves in `workspace`, so the workspace must stay untouched until then;
+ *                               pv_sae_grad_sqnorm_step stays valid, every reader of the raw gradient buffers (pv_sae_grad_sqnorm,
+ *                               pv_sae_grad_sqnorm_rows, a gradient all-reduce) must not be used with this flag. */
 #define PV_SAE_UPDATE_STATS 1
 #define PV_SAE_RENORM_DECODER 2
 #define PV_SAE_INV_NORM_VALID 4
+#define PV_SAE_SPARSE_GRADS 8
 int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
                 const float* batch_mean, int32_t n_global, int32_t flags, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);

@@ -40,7 +40,7 @@ class OracleEngine:
     def renorm_decoder(self):
         O.renorm_decoder(self._P())
 
-    def step(self, x, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=False):
+    def step(self, x, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=False, sparse_grads=False):
         if renorm_decoder:
             self.renorm_decoder()
         P, xn = self._P(), x.numpy()
@@ -58,7 +58,7 @@ class OracleEngine:
             self.n_fwd_since_fired += 1
             self.n_fwd_since_fired[self.fire_count > 0] = 0
 
-    def grad_sqnorm(self):
+    def grad_sqnorm(self, from_step=False):
         self.scalars[3] = float((self.flat_g.double() ** 2).sum())
 
     def grad_sqnorm_rows(self, j_lo, j_hi, include_b_dec):

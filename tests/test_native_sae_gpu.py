@@ -248,8 +248,9 @@ def test_native_data_parallel_world2_equals_single_process_oracle():
 # the filtered encoder (sae_enc.hip): fp16 MFMA filter + exact fp32 re-scoring must be indistinguishable from the
 # exact fp32 GEMM + streaming top-k it replaces
 # ---------------------------------------------------------------------------------------------------
-def _both_paths(eng, x, tuning):
+def _both_paths(eng, x, tuning, loop=-1):
     tuning("reset")
+    tuning("gemm_loop", loop)                      # K loop of the filter GEMM: -1 software-pipelined (default), 0 barrier-then-fetch
     idx_f, val_f, mu_f, sd_f = (t.clone() for t in eng.encode_topk(x))
     n_fb = eng.fallback_rows()
     tuning("sae_exact", 1)
@@ -259,14 +260,15 @@ def _both_paths(eng, x, tuning):
     return (idx_f, val_f), (idx_e, val_e), n_fb
 
 
-@pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257)])
-def test_filtered_encoder_equals_exact_path(d_in, d_sae, k, n, tuning):
+@pytest.mark.parametrize("loop", [-1, 0])
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257), (104, 4096, 16, 300)])
+def test_filtered_encoder_equals_exact_path(d_in, d_sae, k, n, loop, tuning):
     _, _, _, T = fresh(d_in, d_sae)
     T["b_enc"].mul_(20.0)                                                  # biases that matter
     eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
     assert eng.filtered_encoder
     x = torch.from_numpy(synth_sae_batch(n, d_in, seed=5)).cuda()
-    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning)
+    (idx_f, val_f), (idx_e, val_e), n_fb = _both_paths(eng, x, tuning, loop)
     assert n_fb == 0                                                       # ordinary data: the filter decides every token
     assert torch.equal(idx_f.sort(dim=1).values, idx_e.sort(dim=1).values)  # exact index sets
     # values: both are fp32 dot products of the same operands in different summation orders
@@ -440,6 +442,40 @@ def test_every_gradient_row_is_written_and_the_clip_norm_comes_from_the_backward
         eng.apply(1e-3, 1.0)
         eng.grad_sqnorm(from_step=True)                      # stale after apply: must fall back to the full pass
         assert abs(float(eng.scalars[3]) - ref) <= 1e-5 * ref
+
+
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(768, 24576, 32, 1024), (100, 4096, 8, 96)])
+def test_sparse_gradient_step_lands_on_the_same_parameters_as_the_dense_one(d_in, d_sae, k, n):
+    """PV_SAE_SPARSE_GRADS (what the single-process trainer passes): rows of features that kept no token are neither zeroed
+    by the step nor read by apply.  Poisoned gradient buffers stay poisoned exactly there, the clip norm from the step's
+    per-feature terms is unchanged, and parameters + Adam moments after apply are BIT-identical to the dense-gradient step
+    (g = 0 either way).  Readers of the raw buffers refuse to run while such a step is pending."""
+    engs = []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        engs.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n))
+    dense, sparse = engs
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+        dense.step(x, renorm_decoder=True); dense.grad_sqnorm(from_step=True); dense.apply(1e-3, 1.0)
+        sparse.flat_g.fill_(float("nan"))
+        sparse.step(x, renorm_decoder=True, sparse_grads=True)
+        empty = sparse.fire_count == 0
+        assert int(empty.sum()) > 0
+        assert bool(torch.isnan(sparse.g["W_dec"][empty]).all()) and bool(torch.isnan(sparse.g["W_enc"][empty]).all())
+        assert bool(torch.isfinite(sparse.g["W_dec"][~empty]).all()) and bool(torch.isfinite(sparse.g["b_enc"]).all())
+        with pytest.raises(RuntimeError):
+            sparse.grad_sqnorm()
+        with pytest.raises(RuntimeError):
+            sparse.forward(x)
+        sparse.grad_sqnorm(from_step=True)
+        sparse.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        assert float(sparse.scalars[3]) == float(dense.scalars[3]) and float(sparse.scalars[0]) == float(dense.scalars[0])
+        for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            assert torch.equal(sparse.params[name], dense.params[name]), (t, name)
+        assert torch.equal(sparse.flat_m, dense.flat_m) and torch.equal(sparse.flat_v, dense.flat_v), t
+    sparse.forward(x)                                        # nothing pending any more
 
 
 def test_activation_cache_shards_written_from_the_native_harvest_match_the_references():

@@ -383,12 +383,16 @@ def test_sae_substitution_style_eval_on_b32_bf16():
 
 
 @pytest.mark.parametrize("tile", ["5", "4", "0"])
-@pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40)])
-def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, tuning):
+@pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40), (645, 264, 96), (1931, 1032, 1056)])
+@pytest.mark.parametrize("loop", [-1, 0])
+def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, loop, tuning):
     """pv_gemm_bias against an fp32 torch reference on shapes that are multiples of nothing: partial row / column
-    tiles, K that ends inside a 64-byte slab (K = 200, 72, 40), N = 8 (one 16-byte chunk)."""
+    tiles, K that ends inside a 64-byte slab (K = 200, 72, 40: the barrier-then-fetch loop) or is a whole number of
+    slabs not divisible by the 4-step unrolling (K = 96, 1056: the software-pipelined loop unless gemm_loop = 0),
+    N = 8 (one 16-byte chunk)."""
     import ctypes as C
     tuning("gemm_tile", int(tile))
+    tuning("gemm_loop", loop)
     L = _native.lib()
     g = torch.Generator(device="cuda").manual_seed(M * 31 + N)
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -493,13 +497,14 @@ def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning)
     an image's cache rows are the same bits at bs = 1 (v4 picked) and inside a 300-image batch (v7 picked)."""
     model, arch, _ = build("clip-vit-b32", torch.bfloat16)
     ref = None
-    for tile in (None, 0, 4, 5):
+    for tile, loop in ((None, -1), (0, -1), (4, -1), (5, -1), (4, 0), (5, 0)):       # loop 0: barrier-then-fetch K loop, -1: pipelined
         tuning("reset")
         if tile is not None:
             tuning("gemm_tile", tile)
+        tuning("gemm_loop", loop)
         d = _digests(model, (77, 300))
         ref = ref or d
-        assert d == ref, tile
+        assert d == ref, (tile, loop)
     tuning("reset")
     x = torch.randn(300, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(300)).bfloat16()
     with torch.no_grad():

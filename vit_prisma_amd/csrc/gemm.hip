@@ -765,7 +765,7 @@ __device__ __forceinline__ void epi8_bf16(const float4& x0, const float4& x1, co
 //     * MB = 5 makes M = 25600 (512 images x 50 tokens) exactly 80 row tiles: the N = 768 GEMMs (O-projection,
 //       MLP-2) are 240 tiles = ONE round of the 256 CUs, the QKV GEMM 720 = three
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MB, int EPI, int ACT>
+template <typename T, int MB, int EPI, int ACT, int LP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     static_assert(sizeof(T) == 2, "v7 is the bf16 kernel");
     constexpr int TM = 64 * MB;
@@ -934,19 +934,115 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     issue((KT) + 3, NXT3);                                      \
     compute(CUR);
 
-    issue(0, ring0);
-    issue(1, ring1);
-    issue(2, ring2);
-    int kt = 0;
-    for (; kt + 4 <= nk; kt += 4) {
-        PV_V7_STEP(kt, ring0, ring3)
-        PV_V7_STEP(kt + 1, ring1, ring0)
-        PV_V7_STEP(kt + 2, ring2, ring1)
-        PV_V7_STEP(kt + 3, ring3, ring2)
+    if constexpr (LP == 0) {
+        issue(0, ring0);
+        issue(1, ring1);
+        issue(2, ring2);
+        int kt = 0;
+        for (; kt + 4 <= nk; kt += 4) {
+            PV_V7_STEP(kt, ring0, ring3)
+            PV_V7_STEP(kt + 1, ring1, ring0)
+            PV_V7_STEP(kt + 2, ring2, ring1)
+            PV_V7_STEP(kt + 3, ring3, ring2)
+        }
+        if (kt < nk) { PV_V7_STEP(kt, ring0, ring3) }
+        if (kt + 1 < nk) { PV_V7_STEP(kt + 1, ring1, ring0) }
+        if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
+    } else {
+        // Software-pipelined form.  The loop above has every wave arrive at the slab's barrier with empty fragment
+        // registers: both waves of a SIMD then issue their DMA pieces and their first ds_reads and sit out the LDS
+        // latency with the matrix pipe idle.  Here the fragments of a half-slab are fetched while the previous
+        // half-slab is multiplied (each A fragment is refilled right behind the two MFMAs that consumed it), the
+        // barrier of slab s+1 sits in the MIDDLE of step s (between its two halves: by then every read of slab s has
+        // been issued, and the second half's operands are already in registers), and the DMA pieces of slab s+4 go
+        // out one per MFMA pair during the second half, into the slot the barrier has just freed.
+        //   ring depth as before: at the barrier of slab s+1 the pieces of slabs s+2 and s+3 stay in flight.
+        // (plain A operand, whole 64-byte slabs only -- the launcher keeps the loop above for the patch gather and
+        // for a K tail: a piece's source offset is then one per-lane base + a uniform term, two VALU per piece)
+        const unsigned pA0 = (unsigned)(m0 + wave * 16 + (lane >> 2)) * (unsigned)p.lda * EB + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+        const unsigned pB0 = (unsigned)(n0 + wave * 16 + (lane >> 2)) * (unsigned)p.ldb * EB + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+        const unsigned strideA = 128u * (unsigned)p.lda * EB, strideB = 128u * (unsigned)p.ldb * EB;
+        auto issue_piece = [&](int kt, unsigned char* slot, int j) {
+            const unsigned kbase = (unsigned)kt * 64;
+            const bool dead = (kt >= nk);
+            if (j < NA) {
+                const bool off = dead | ((j * 8 + wave) >= 4 * MB);                  // uniform
+                const unsigned o = off ? 0xffffff00u : pA0 + ((unsigned)j * strideA + kbase);
+                unsigned char* dst = slot + (j * 8 + wave) * 1024;
+                if constexpr (PAD) { if (j == NA - 1) dst = (j * 8 + wave) < 4 * MB ? dst : pad + wave * 1024; }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, o, 0, 0, 0);
+            } else {
+                const int jb = j - NA;
+                const unsigned o = dead ? 0xffffff00u : pB0 + ((unsigned)jb * strideB + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (jb * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            }
+        };
+        auto issue_all = [&](int kt, unsigned char* slot) {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) issue_piece(kt, slot, j);
+        };
+        auto rdA = [&](const unsigned char* slot, int h, int mi) {
+            return *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + (h == 0 ? co0 : co1));
+        };
+        auto rdB = [&](const unsigned char* slot, int h, int ni) {
+            return *reinterpret_cast<const uint4*>(slot + b_row + ni * 2048 + (h == 0 ? co0 : co1));
+        };
+        static_assert(3 * NPIECE <= 15 && NPIECE <= MB, "prologue vmcnt immediate; one DMA piece per MFMA pair");
+        constexpr int BPOS = MB >= 4 ? 1 : 0;           // which MFMA pair the next half's B fragments are fetched behind
+        uint4 fa[MB], fb0[2], fb1[2];
+        // the issue order below is the schedule: MFMA pair | DMA piece + fragment refill | MFMA pair | ... (left to itself
+        // hipcc sinks the refills to the end of the half-slab and waits for them right behind the barrier)
+#define PV_V7_PIN() __builtin_amdgcn_sched_barrier(0)
+#define PV_V7_PIN2() __builtin_amdgcn_sched_barrier(0)
+#define PV_V7_PAIR(MI, FB)                                                                                   \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                     \
+            acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                           \
+                __builtin_bit_cast(bf16x8, fa[MI]), __builtin_bit_cast(bf16x8, FB[ni]), acc[MI][ni], 0, 0, 0);
+        // step KT: slab KT in CUR (visible), slab KT+1 in NXT; fa / fb0 hold the first half of slab KT
+#define PV_V7_PSTEP(KT, CUR, NXT)                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
+            PV_V7_PAIR(mi, fb0)                                                                              \
+            PV_V7_PIN2();                                                                                    \
+            fa[mi] = rdA(CUR, 1, mi);                                                                        \
+            if (mi == BPOS) { fb1[0] = rdB(CUR, 1, 0); fb1[1] = rdB(CUR, 1, 1); }                            \
+            PV_V7_PIN();                                                                                     \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPIECE));                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
+            PV_V7_PAIR(mi, fb1)                                                                              \
+            PV_V7_PIN2();                                                                                    \
+            fa[mi] = rdA(NXT, 0, mi);                                                                        \
+            if (mi == BPOS) { fb0[0] = rdB(NXT, 0, 0); fb0[1] = rdB(NXT, 0, 1); }                            \
+            if (mi < NPIECE) issue_piece((KT) + 4, CUR, mi);                                                 \
+            PV_V7_PIN();                                                                                     \
+        }
+        issue_all(0, ring0);
+        issue_all(1, ring1);
+        issue_all(2, ring2);
+        issue_all(3, ring3);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * NPIECE));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA(ring0, 0, mi);
+        fb0[0] = rdB(ring0, 0, 0); fb0[1] = rdB(ring0, 0, 1);
+        int kt = 0;
+        for (; kt + 4 <= nk; kt += 4) {
+            PV_V7_PSTEP(kt, ring0, ring1)
+            PV_V7_PSTEP(kt + 1, ring1, ring2)
+            PV_V7_PSTEP(kt + 2, ring2, ring3)
+            PV_V7_PSTEP(kt + 3, ring3, ring0)
+        }
+        if (kt < nk) { PV_V7_PSTEP(kt, ring0, ring1) }
+        if (kt + 1 < nk) { PV_V7_PSTEP(kt + 1, ring1, ring2) }
+        if (kt + 2 < nk) { PV_V7_PSTEP(kt + 2, ring2, ring3) }
+#undef PV_V7_PSTEP
+#undef PV_V7_PAIR
+#undef PV_V7_PIN
+#undef PV_V7_PIN2
     }
-    if (kt < nk) { PV_V7_STEP(kt, ring0, ring3) }
-    if (kt + 1 < nk) { PV_V7_STEP(kt + 1, ring1, ring0) }
-    if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
 #undef PV_V7_STEP
 #undef PV_V7_SYNC
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
@@ -1007,14 +1103,21 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
         const dim3 grid(ntm * ntn), block(512);
+        // the software-pipelined K loop covers plain A operands and whole 64-byte slabs
+        const int loop_sel = (p.a_mode == PV_A_PLAIN && ((int64_t)p.K * DT<T>::kBytes) % 64 == 0) ? (g_pv_tuning.gemm_loop != 0) : 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = !g_pv_tuning.prof_markers &&
                            pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
         ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-#define PV_V7_LAUNCH(EPI, ACT)                                                                                      \
-    do {                                                                                                            \
-        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, ev0, ev1, 0, p); \
-        else hipLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT>), grid, block, 0, stream, p);                      \
+#define PV_V7_LAUNCH_LP(EPI, ACT, LP)                                                                                   \
+    do {                                                                                                                \
+        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT, LP>), grid, block, 0, stream, ev0, ev1, 0, p); \
+        else hipLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT, LP>), grid, block, 0, stream, p);                      \
+    } while (0)
+#define PV_V7_LAUNCH(EPI, ACT)                                                   \
+    do {                                                                         \
+        if (loop_sel) PV_V7_LAUNCH_LP(EPI, ACT, 1);                              \
+        else PV_V7_LAUNCH_LP(EPI, ACT, 0);                                       \
     } while (0)
         if (p.epi == PV_EPI_BIAS) PV_V7_LAUNCH(PV_EPI_BIAS, 0);
         else if (p.epi == PV_EPI_QKV) PV_V7_LAUNCH(PV_EPI_QKV, 0);
@@ -1023,6 +1126,7 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         else if (p.act == PV_ACT_QUICK_GELU) PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_QUICK_GELU);
         else PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_RELU);
 #undef PV_V7_LAUNCH
+#undef PV_V7_LAUNCH_LP
     }
     PV_LAUNCH_CHECK("gemm_kernel_v7");
     return PV_OK;

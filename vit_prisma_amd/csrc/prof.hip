@@ -104,6 +104,7 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "prof_markers")) return &g_pv_tuning.prof_markers;
     if (!strcmp(key, "sae_exact")) return &g_pv_tuning.sae_exact;
     if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
+    if (!strcmp(key, "gemm_loop")) return &g_pv_tuning.gemm_loop;
     return nullptr;
 }
 }  // namespace
@@ -129,7 +130,7 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
         const PvTuning d;
         const PvTuning& t = g_pv_tuning;
         *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg ||
-                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg) ? 1 : 0;
+                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg || t.gemm_loop != d.gemm_loop) ? 1 : 0;
         return PV_OK;
     }
     const int* f = tuning_field(key);

@@ -149,6 +149,8 @@ struct PvTuning {
     int prof_markers = 0;    // 1: time v7 launches with hipEventRecord markers instead of dispatch-packet events
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
     int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds
+    int gemm_loop = -1;      // K loop of the one-workgroup-per-CU kernels (ViT GEMMs, SAE filter GEMM): -1 auto (software-pipelined where it
+                             // applies: plain A operand, whole 64-byte slabs); 0 = the barrier-then-fetch loop everywhere; 1 = as auto
 };
 extern PvTuning g_pv_tuning;
 

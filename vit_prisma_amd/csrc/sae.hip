@@ -476,12 +476,17 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
                                                        int max_chunks, int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
                                                        uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
-                                                       int d_sae, int update_stats) {
+                                                       int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
+                                                       float* __restrict__ rowsq_sparse) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d_sae) return;
     const uint32_t beg = offs[j], end = offs[j + 1], c = end - beg;
     const float cnt = (float)c;
     if (fire_count) fire_count[j] = cnt;
+    if (gb_enc_sparse && c == 0) {                    // PV_SAE_SPARSE_GRADS: the rows stay as they are, the scalars are zeroed here
+        gb_enc_sparse[j] = 0.f;
+        rowsq_sparse[j] = 0.f;
+    }
     if (update_stats) {
         act_freq[j] += cnt;
         n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
@@ -858,10 +863,12 @@ template <int V4>   // W_dec rows [j_lo, j_hi): one wave per row (16 bytes per l
 __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, const float* __restrict__ G,
                                                         float* __restrict__ M, float* __restrict__ V,
                                                         const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d,
-                                                        const float* inv_norm, float* inv_next /* may be the same array */) {
+                                                        const float* inv_norm, float* inv_next /* may be the same array */,
+                                                        const uint32_t* __restrict__ live_offs) {
     const int lane = threadIdx.x & 63;
     const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= j_hi) return;
+    const bool live = !live_offs || live_offs[j + 1] != live_offs[j];        // (wave-uniform) PV_SAE_SPARSE_GRADS: no pair, g = 0
     const float coef = clip_coef(scalars, c.max_norm);
     const float rn = inv_norm ? inv_norm[j] : 1.f;            // pending set_decoder_norm_to_unit_norm (see pv_sae_step)
     float4 w[V4], g[V4], m[V4], v[V4];
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
         ok[i] = col < d;
         const int64_t o = (int64_t)j * d + col;
         w[i] = ld4(W + o, ok[i]);
-        g[i] = ld4(G + o, ok[i]);
+        g[i] = ld4(G + o, ok[i] && live);
         m[i] = ld4(M + o, ok[i]);
         v[i] = ld4(V + o, ok[i]);
     }
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                                                         float* __restrict__ colsq, const float* __restrict__ GT,
                                                         float* __restrict__ MT, float* __restrict__ VT,
                                                         const float* __restrict__ scalars, AdamC c, int d_in, int d_sae,
-                                                        int j_lo, int j_hi) {
+                                                        int j_lo, int j_hi, const uint32_t* __restrict__ live_offs = nullptr) {
     constexpr int NC = 2;                                     // 32-column chunks per iteration (16 independent loads per array)
     __shared__ float tile[NC][32][33];
     const int j0 = j_lo + blockIdx.x * 32;
@@ -931,6 +938,16 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
     if constexpr (MODE == 0) coef = clip_coef(scalars, c.max_norm);
     float sq[4] = {0.f, 0.f, 0.f, 0.f};
     bool big = false;
+    bool live[4] = {true, true, true, true};                  // PV_SAE_SPARSE_GRADS: rows of features without a pair are not read
+    if constexpr (MODE == 0) {
+        if (live_offs) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + ty + 8 * r;
+                live[r] = j < j_hi && live_offs[j + 1] != live_offs[j];
+            }
+        }
+    }
     for (int i0 = 0; i0 < d_in; i0 += 32 * NC) {
         if constexpr (MODE == 2) {
 #pragma unroll
@@ -952,7 +969,7 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                     const bool in = j < j_hi && i < d_in;
                     const int64_t o = (int64_t)j * d_in + i;
                     wv[u][r] = in ? WT[o] : 0.f;
-                    gv[u][r] = in ? GT[o] : 0.f;
+                    gv[u][r] = (in && live[r]) ? GT[o] : 0.f;
                     mv[u][r] = in ? MT[o] : 0.f;
                     vv[u][r] = in ? VT[o] : 0.f;
                 }
@@ -1289,6 +1306,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            size_t workspace_bytes, void* stream_) {
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     const bool renorm = (flags & PV_SAE_RENORM_DECODER) != 0;
+    const bool sparse = (flags & PV_SAE_SPARSE_GRADS) != 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
     PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
@@ -1354,16 +1372,20 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
                            max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
-                           out->fire_count, d.d_sae, update_stats);
+                           out->fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
         // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
-        // the long-list combine
+        // the long-list combine.  PV_SAE_SPARSE_GRADS: the rows of features no token kept are not touched at all -- pv_sae_apply
+        // takes their gradient as zero from the feature offsets this step leaves in the workspace (about half of the features
+        // on a trained-like batch: 2 x 39 MB not written here and not read there)
+        plan->live_offs = sparse ? offs : nullptr;
 #define CALL(D)                                                                                                        \
-    hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
-                       st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in);                                                   \
+    if (!sparse)                                                                                                       \
+        hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
+                           st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in);                                               \
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
                        (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
@@ -1453,11 +1475,12 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     const dim3 block(256);
     if (nj > 0) {
         const float* inv_norm = plan->renorm_pending ? (const float*)st->dec_inv_norm : nullptr;
-#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm, st->dec_inv_norm)
+#define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm, st->dec_inv_norm, plan->live_offs)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
-                           st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi);
+                           st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi,
+                           plan->live_offs);
         hipLaunchKernelGGL(adam_vec_kernel, dim3((nj + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
                            st->mb_enc, st->vb_enc, scalars, c, j_lo, j_hi);
     }

@@ -13,6 +13,7 @@ constexpr int PV_SAE_FB_SLOTS = 32;          // workgroup columns of the fallbac
 struct pv_sae_plan {
     pv_sae_desc d;
     bool renorm_pending = false;     // the last pv_sae_step deferred set_decoder_norm_to_unit_norm to pv_sae_apply
+    const uint32_t* live_offs = nullptr;   // PV_SAE_SPARSE_GRADS: feature offsets of the last pv_sae_step (in ITS workspace), else null
 };
 
 struct SaeWs {

@@ -62,7 +62,7 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 // 4-slot LDS ring three slabs ahead, counted vmcnt across a raw s_barrier) on fp16 operands, with an epilogue that
 // stores nothing but the hits.  MODE 0: plain fp32 store of acc + bias (the sample of pass 0).
 // ---------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int LP = 0>
 __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p) {
     constexpr int MB = 4, TM = 64 * MB, TN = 256;
     constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (lds_ptr_t)(trow + wave * 64), 4, (unsigned)(m0 + wave * 64 + lane) * 4u, 0, 0, 0);
     }
 
+    if constexpr (LP == 0) {
     // step kt: slab kt must have landed -- the 8 DMA instructions of slabs kt+1, kt+2 may stay in flight
 #define PV_ENC_STEP(KT, CUR, NXT3)                 \
     __builtin_amdgcn_s_waitcnt(0x0F70 | 8);        \
@@ -189,6 +190,80 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
     if (kt + 1 < nk) { PV_ENC_STEP(kt + 1, ring1, ring0) }
     if (kt + 2 < nk) { PV_ENC_STEP(kt + 2, ring2, ring1) }
 #undef PV_ENC_STEP
+    } else {
+        // software-pipelined form of the loop (gemm.hip, gemm_kernel_v7<..., LP = 1>): fragments of a half-slab refilled
+        // right behind the MFMA pair that consumed them, the slab's barrier between its two halves, the DMA pieces of
+        // slab s+4 one per MFMA pair in the second half.  Whole 64-byte slabs only (the launcher checks K % 32 == 0).
+        constexpr int NPIECE = 4;
+        const unsigned pA0 = (unsigned)(m0 + wave * 16 + (lane >> 2)) * (unsigned)p.lda * 2u + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+        const unsigned strideA = 128u * (unsigned)p.lda * 2u;
+        auto issue_piece = [&](int kt, unsigned char* slot, int j) {
+            const unsigned kbase = (unsigned)kt * 64;
+            const bool dead = kt >= nk;
+            if (j < 2) {
+                const unsigned o = dead ? 0xffffff00u : pA0 + ((unsigned)j * strideA + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            } else {
+                const int jb = j - 2;
+                const unsigned o = (dead | (offB[jb] == 0xffffff00u)) ? 0xffffff00u : offB[jb] + kbase;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A_BYTES + (jb * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            }
+        };
+        auto issue_all = [&](int kt, unsigned char* slot) {
+#pragma unroll
+            for (int j = 0; j < NPIECE; ++j) issue_piece(kt, slot, j);
+        };
+        auto rdA = [&](const unsigned char* slot, int h, int mi) {
+            return *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + (h == 0 ? co0 : co1));
+        };
+        auto rdB = [&](const unsigned char* slot, int h, int ni) {
+            return *reinterpret_cast<const uint4*>(slot + b_row + ni * 2048 + (h == 0 ? co0 : co1));
+        };
+        uint4 fa[MB], fb0[2], fb1[2];
+#define PV_ENC_PAIR(MI, FB)                                                                                  \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                     \
+            acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                            \
+                __builtin_bit_cast(f16x8, fa[MI]), __builtin_bit_cast(f16x8, FB[ni]), acc[MI][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);
+#define PV_ENC_PSTEP(KT, CUR, NXT)                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
+            PV_ENC_PAIR(mi, fb0)                                                                             \
+            fa[mi] = rdA(CUR, 1, mi);                                                                        \
+            if (mi == 1) { fb1[0] = rdB(CUR, 1, 0); fb1[1] = rdB(CUR, 1, 1); }                               \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NPIECE));                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
+            PV_ENC_PAIR(mi, fb1)                                                                             \
+            fa[mi] = rdA(NXT, 0, mi);                                                                        \
+            if (mi == 1) { fb0[0] = rdB(NXT, 0, 0); fb0[1] = rdB(NXT, 0, 1); }                               \
+            issue_piece((KT) + 4, CUR, mi);                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }
+        issue_all(0, ring0);
+        issue_all(1, ring1);
+        issue_all(2, ring2);
+        issue_all(3, ring3);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * NPIECE));
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA(ring0, 0, mi);
+        fb0[0] = rdB(ring0, 0, 0); fb0[1] = rdB(ring0, 0, 1);
+        int kt = 0;
+        for (; kt + 4 <= nk; kt += 4) {
+            PV_ENC_PSTEP(kt, ring0, ring1)
+            PV_ENC_PSTEP(kt + 1, ring1, ring2)
+            PV_ENC_PSTEP(kt + 2, ring2, ring3)
+            PV_ENC_PSTEP(kt + 3, ring3, ring0)
+        }
+        if (kt < nk) { PV_ENC_PSTEP(kt, ring0, ring1) }
+        if (kt + 1 < nk) { PV_ENC_PSTEP(kt + 1, ring1, ring2) }
+        if (kt + 2 < nk) { PV_ENC_PSTEP(kt + 2, ring2, ring3) }
+#undef PV_ENC_PSTEP
+#undef PV_ENC_PAIR
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches (and the threshold DMA)
     __syncthreads();
 
@@ -535,8 +610,14 @@ __global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restr
 int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
     const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
     const dim3 grid(ntm * ntn), block(512);
-    if (mode == 0) hipLaunchKernelGGL((sae_enc_gemm_kernel<0>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((sae_enc_gemm_kernel<1>), grid, block, 0, stream, p);
+    const bool piped = g_pv_tuning.gemm_loop != 0 && p.K % 32 == 0;      // whole 64-byte slabs of fp16
+    if (mode == 0) {
+        if (piped) hipLaunchKernelGGL((sae_enc_gemm_kernel<0, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((sae_enc_gemm_kernel<0, 0>), grid, block, 0, stream, p);
+    } else {
+        if (piped) hipLaunchKernelGGL((sae_enc_gemm_kernel<1, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((sae_enc_gemm_kernel<1, 0>), grid, block, 0, stream, p);
+    }
     PV_LAUNCH_CHECK("sae_enc_gemm_kernel");
     return PV_OK;
 }

@@ -155,10 +155,14 @@ class NativeSAE:
         N.check(self.lib.pv_sae_renorm_decoder(self._plan, C.byref(st), self._stream()), "pv_sae_renorm_decoder")
 
     def step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
-             update_stats: bool = True, want_out: bool = False, renorm_decoder: bool = False) -> None:
+             update_stats: bool = True, want_out: bool = False, renorm_decoder: bool = False,
+             sparse_grads: bool = False) -> None:
         """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
         loss, mse_loss, l0 (device).  renorm_decoder: set_decoder_norm_to_unit_norm as part of the step (the rewrite of
-        W_dec is fused into the following ``apply``) instead of a separate ``renorm_decoder()`` pass."""
+        W_dec is fused into the following ``apply``) instead of a separate ``renorm_decoder()`` pass.  sparse_grads
+        (PV_SAE_SPARSE_GRADS, single process): the gradient rows of features that kept no token are left unwritten and
+        ``apply`` takes them as zero -- ``flat_g`` is then NOT a complete gradient and only ``grad_sqnorm(from_step=True)``
+        and ``apply`` may follow."""
         x = self._check_x(x)
         self._ensure_shadows()
         n = x.shape[0]
@@ -173,9 +177,16 @@ class NativeSAE:
             bm = batch_mean.to(torch.float32).contiguous()
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                      int(n_global if n_global is not None else n),
-                                     int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0), C.byref(out),
+                                     int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0) |
+                                     (8 if sparse_grads else 0), C.byref(out),
                                      self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_step")
         self._grad_fresh = True
+        self._grad_sparse = bool(sparse_grads)
+
+    def _no_pending_sparse(self, what: str) -> None:
+        if getattr(self, "_grad_sparse", False) and self._grad_fresh:
+            raise RuntimeError(f"{what} between a sparse_grads step and its apply(): the step's workspace (the list of live "
+                               "features) and its partial gradient buffers are only good for grad_sqnorm(from_step=True) / apply()")
 
     def grad_sqnorm(self, from_step: bool = False) -> None:
         """scalars[3] = sum of squares of the whole gradient.  from_step: take it from the per-feature terms the backward
@@ -186,11 +197,13 @@ class NativeSAE:
             N.check(self.lib.pv_sae_grad_sqnorm_step(self._plan, C.byref(st), self.workspace.data_ptr(), self.scalars.data_ptr(),
                                                      self._stream()), "pv_sae_grad_sqnorm_step")
             return
+        self._no_pending_sparse("a full pass over the gradient buffers")
         N.check(self.lib.pv_sae_grad_sqnorm(self.flat_g.data_ptr(), self.n_flat, self.sq_partial.data_ptr(),
                                             self.scalars.data_ptr(), self._stream()), "pv_sae_grad_sqnorm")
 
     def grad_sqnorm_rows(self, j_lo: int, j_hi: int, include_b_dec: bool) -> None:
         """scalars[3] = sum of squares of the gradient rows of features [j_lo, j_hi) (+ gb_dec): one rank's term."""
+        self._no_pending_sparse("grad_sqnorm_rows")
         st = self._state()
         N.check(self.lib.pv_sae_grad_sqnorm_rows(self._plan, C.byref(st), int(j_lo), int(j_hi), int(include_b_dec),
                                                  self.sq_partial.data_ptr(), self.scalars.data_ptr(), self._stream()),
@@ -209,6 +222,7 @@ class NativeSAE:
 
     def encode_topk(self, x: torch.Tensor):
         """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts."""
+        self._no_pending_sparse("encode_topk")
         x = self._check_x(x)
         self._ensure_shadows()
         n = x.shape[0]
@@ -223,6 +237,7 @@ class NativeSAE:
 
     def forward(self, x: torch.Tensor):
         """Inference: (sae_out [N, d_in], idx [N, k] int32, val [N, k]); the views are overwritten by the next call."""
+        self._no_pending_sparse("forward")
         x = self._check_x(x)
         self._ensure_shadows()
         n = x.shape[0]
@@ -234,7 +249,7 @@ class NativeSAE:
 
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:
-        self.step(x, renorm_decoder=True)
+        self.step(x, renorm_decoder=True, sparse_grads=True)
         self.grad_sqnorm(from_step=True)
         self.apply(lr, max_grad_norm)
 

@@ -259,7 +259,9 @@ class VisionSAETrainer:
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
         if self.world == 1:
-            eng.step(x, update_stats=True, renorm_decoder=True)  # set_decoder_norm_to_unit_norm is part of the step
+            # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
+            # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
+            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True)
             eng.grad_sqnorm(from_step=True)                     # clip_grad_norm_ (the gradient is as the step wrote it)
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
