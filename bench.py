@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allow-overrides", action="store_true", help="A/B runs only: measure with PV_* env / tuning overrides (recorded)")
+    ap.add_argument("--leg-timeout", type=float, default=420.0,
+                    help="under torchrun: seconds the secondary legs (SAE, L/14) may take before the main line is printed without them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B runs only (needs --allow-overrides): pv_debug_set_tuning(KEY, VALUE) before measuring")
     return ap.parse_args()
@@ -445,14 +447,46 @@ def main():
     if backend != "nccl":
         line["rehearsal_backend"] = backend
 
+    # The secondary legs come after the main line is complete.  Under torchrun (world > 1) they contain collectives; a rank
+    # that fails or stalls there must not take the main line with it: a watchdog prints what is there and leaves.
+    import threading
+    done = threading.Event()
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+
+    def emergency():
+        if not done.is_set():
+            line["secondary_legs"] = f"abandoned after {a.leg_timeout:.0f} s (see stderr)"
+            sys.stderr.write(f"[bench rank {rank}] secondary legs did not finish in {a.leg_timeout:.0f} s: printing the main line only\n")
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+    wd = None
+    if world > 1:
+        wd = threading.Timer(a.leg_timeout, emergency)
+        wd.daemon = True
+        wd.start()
+
+    def leg(name, fn):
+        """Single process: errors propagate (a broken leg must be seen).  Under torchrun: recorded in the line."""
+        if world == 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as e:                                   # noqa: BLE001
+            sys.stderr.write(f"[bench rank {rank}] leg {name} failed: {type(e).__name__}: {e}\n")
+            return {"error": f"{type(e).__name__}: {e}"}
+
     if not a.no_sae:
-        from vit_prisma_amd.sae.bench_leg import sae_bench_leg
+        from vit_prisma_amd.sae.bench_leg import sae_bench_leg, sae_end_to_end_leg
         del model, images
         torch.cuda.empty_cache()
-        sae = sae_bench_leg(dev, dist=dist)
+        sae = leg("sae", lambda: sae_bench_leg(dev, dist=dist))
         torch.cuda.empty_cache()
-        from vit_prisma_amd.sae.bench_leg import sae_end_to_end_leg
-        e2e = sae_end_to_end_leg(dev, dist=dist)
+        e2e = leg("sae_end_to_end", lambda: sae_end_to_end_leg(dev, dist=dist))
         if rank == 0:
             line["sae"] = sae
             sae["end_to_end"] = e2e
@@ -461,18 +495,23 @@ def main():
                 sae["cpu_baseline"]["numpy_oracle"] = sae_cpu_baseline(6.0)
     if not a.no_l14:
         torch.cuda.empty_cache()
-        l14 = l14_pattern_leg(dev, dist)
+        l14 = leg("l14_336_pattern", lambda: l14_pattern_leg(dev, dist))
         if rank == 0:
             line["l14_336_pattern"] = l14
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_torch(a.cpu_seconds)
         line["cpu_baseline"]["numpy_oracle"] = cpu_baseline(min(a.cpu_seconds, 8.0))
         line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+    done.set()
+    if wd is not None:
+        wd.cancel()
+    emit()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        # (the line is out: a rank that died in a secondary leg must not hold the others in a barrier)
+        try:
+            dist.destroy_process_group()
+        except Exception:                                        # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

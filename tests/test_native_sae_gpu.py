@@ -448,8 +448,8 @@ def test_every_gradient_row_is_written_and_the_clip_norm_comes_from_the_backward
 def test_sparse_gradient_step_lands_on_the_same_parameters_as_the_dense_one(d_in, d_sae, k, n):
     """PV_SAE_SPARSE_GRADS (what the single-process trainer passes): rows of features that kept no token are neither zeroed
     by the step nor read by apply.  Poisoned gradient buffers stay poisoned exactly there, the clip norm from the step's
-    per-feature terms is unchanged, and parameters + Adam moments after apply are BIT-identical to the dense-gradient step
-    (g = 0 either way).  Readers of the raw buffers refuse to run while such a step is pending."""
+    per-feature terms is unchanged, and parameters + Adam moments after apply equal the dense-gradient step's (to summation
+    noise everywhere, to the bit on the rows in question: g = 0 either way).  Readers of the raw buffers refuse to run while such a step is pending."""
     engs = []
     for _ in range(2):
         _, _, _, T = fresh(d_in, d_sae)
@@ -471,10 +471,20 @@ def test_sparse_gradient_step_lands_on_the_same_parameters_as_the_dense_one(d_in
         sparse.grad_sqnorm(from_step=True)
         sparse.apply(1e-3, 1.0)
         torch.cuda.synchronize()
-        assert float(sparse.scalars[3]) == float(dense.scalars[3]) and float(sparse.scalars[0]) == float(dense.scalars[0])
+        for i in (0, 3):                                     # loss, clip norm
+            assert abs(float(sparse.scalars[i]) - float(dense.scalars[i])) <= 1e-6 * abs(float(dense.scalars[i])), (t, i)
+        # two runs of the step agree to summation-order noise (the order pairs enter a feature's list is scheduling-dependent,
+        # DESIGN 3.1) -- except on the rows this flag is about, which see g = 0 in both and must be the same bits
         for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
-            assert torch.equal(sparse.params[name], dense.params[name]), (t, name)
-        assert torch.equal(sparse.flat_m, dense.flat_m) and torch.equal(sparse.flat_v, dense.flat_v), t
+            assert rel_fro(sparse.params[name].cpu().numpy(), dense.params[name].cpu().numpy()) < 1e-6, (t, name)
+        assert rel_fro(sparse.flat_m.cpu().numpy(), dense.flat_m.cpu().numpy()) < 1e-5, t
+        assert rel_fro(sparse.flat_v.cpu().numpy(), dense.flat_v.cpu().numpy()) < 1e-5, t
+        never = empty if t == 0 else (never & empty)        # features without a pair in every step so far: no noise to inherit
+        assert int(never.sum()) > 0
+        assert torch.equal(sparse.params["W_dec"][never], dense.params["W_dec"][never]), t
+        assert torch.equal(sparse.params["W_enc"][:, never], dense.params["W_enc"][:, never]), t
+        assert torch.equal(sparse._m["W_dec"][never], dense._m["W_dec"][never]) and torch.equal(sparse._v["W_encT"][never], dense._v["W_encT"][never]), t
+        assert bool(torch.isfinite(sparse.flat_m).all()) and bool(torch.isfinite(sparse.flat_v).all())
     sparse.forward(x)                                        # nothing pending any more
 
 
