@@ -384,7 +384,7 @@ def test_sae_substitution_style_eval_on_b32_bf16():
 
 @pytest.mark.parametrize("tile", ["5", "4", "0"])
 @pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40), (645, 264, 96), (1931, 1032, 1056)])
-@pytest.mark.parametrize("loop", [-1, 0])
+@pytest.mark.parametrize("loop", [-1, 0, 2])
 def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, loop, tuning):
     """pv_gemm_bias against an fp32 torch reference on shapes that are multiples of nothing: partial row / column
     tiles, K that ends inside a 64-byte slab (K = 200, 72, 40: the barrier-then-fetch loop) or is a whole number of
@@ -497,7 +497,7 @@ def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning)
     an image's cache rows are the same bits at bs = 1 (v4 picked) and inside a 300-image batch (v7 picked)."""
     model, arch, _ = build("clip-vit-b32", torch.bfloat16)
     ref = None
-    for tile, loop in ((None, -1), (0, -1), (4, -1), (5, -1), (4, 0), (5, 0)):       # loop 0: barrier-then-fetch K loop, -1: pipelined
+    for tile, loop in ((None, -1), (0, -1), (4, -1), (5, -1), (4, 0), (5, 0), (4, 2), (5, 2)):   # loop 0: barrier-then-fetch K loop, -1: pipelined, 2: full-line slabs
         tuning("reset")
         if tile is not None:
             tuning("gemm_tile", tile)

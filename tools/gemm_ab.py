@@ -1,6 +1,6 @@
 """A/B of the K-loop forms of the one-workgroup-per-CU bf16 GEMM (tuning key gemm_loop): bit-equality against
 form 0 on the B/32 bs=512 shapes (+ a ragged M) and time per launch for every epilogue the forward uses.
-    python tools/gemm_ab.py [loops, default 0,1,2,3]"""
+    python tools/gemm_ab.py [loops, default 0,1,2]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from vit_prisma_amd import _native as N
 
 L = N.lib()
 dev = torch.device("cuda:0")
-loops = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3".split(","))]
+loops = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2".split(","))]
 reps = int(os.environ.get("REPS", "30"))
 shapes = [("qkv", 25600, 2304, 768), ("oproj", 25600, 768, 768), ("mlp1", 25600, 3072, 768), ("mlp2", 25600, 768, 3072),
           ("ragged", 25600 - 37, 1024, 1024), ("sq4096", 4096, 4096, 4096)]

@@ -774,11 +774,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     constexpr int NA = (4 * MB + 7) / 8;                  // A wave-instructions per wave per slab
     constexpr bool PAD = (4 * MB) % 8 != 0;
     static_assert(4 * SLOT + (PAD ? 8192 : 16) <= 160 * 1024, "one workgroup per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring3[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char pad[PAD ? 8192 : 16];
+    // LP == 2 (full-line form below): two slots of 128-byte rows in ring0 / ring1, the other objects shrink to stubs
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[LP == 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[LP == 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[LP == 2 ? 16 : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring3[LP == 2 ? 16 : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char pad[(PAD && LP != 2) ? 8192 : 16];
     constexpr int EB = DT<T>::kBytes;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
         if (kt < nk) { PV_V7_STEP(kt, ring0, ring3) }
         if (kt + 1 < nk) { PV_V7_STEP(kt + 1, ring1, ring0) }
         if (kt + 2 < nk) { PV_V7_STEP(kt + 2, ring2, ring1) }
-    } else {
+    } else if constexpr (LP == 1) {
         // Software-pipelined form.  The loop above has every wave arrive at the slab's barrier with empty fragment
         // registers: both waves of a SIMD then issue their DMA pieces and their first ds_reads and sit out the LDS
         // latency with the matrix pipe idle.  Here the fragments of a half-slab are fetched while the previous
@@ -1042,6 +1043,92 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
 #undef PV_V7_PAIR
 #undef PV_V7_PIN
 #undef PV_V7_PIN2
+    } else {
+        // Full-line form (LP == 2): K slabs of 128 BYTES per row, i.e. whole cache lines -- a DMA piece (1 KiB) is 8 rows x 128 B
+        // = 8 lines instead of 16 half lines (the 64-byte slabs above pull every operand line through the L1 twice, 1 us
+        // apart, and the texture addresser is busy 55-79 % of the launch: profiles/r02_notes.md).  Two 72 KB slots; the
+        // software pipeline of LP == 1 on four 16-element k-steps per slab: the barrier of slab s+1 sits before the LAST k-step
+        // of slab s (every read of slab s has been issued by then), the pieces of slab s+2 go out behind the MFMA pairs of
+        // that last k-step (into the slot the barrier freed) and of the next slab's first k-step.  One slab of prefetch
+        // distance (the slot it lands in is read until the barrier), so the wait before the barrier is vmcnt(0).
+        //   LDS row = 128 B = 8 chunks; chunk c of row r at position c ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group
+        //   (8 even, 8 odd) then cover all 64 banks.
+        constexpr int A2 = TM * 128;                                   // bytes of the A part of a slot
+        constexpr int NP2 = MB + 4;                                    // pieces per wave per slab: MB of A, 4 of B
+        static_assert(MB >= 4, "four B pieces ride on the first k-step's MFMA pairs");
+        const int prow = lane >> 3;                                    // row of the piece this lane fetches
+        const int psw = ((lane >> 4) + 4 * (wave & 1)) & 7;            // (row >> 1) & 7 of that row (row = (j*8 + wave)*8 + prow)
+        const unsigned pcol = (unsigned)(((lane & 7) ^ psw) * 16);
+        const unsigned pA0 = (unsigned)(m0 + wave * 8 + prow) * (unsigned)p.lda * EB + pcol;
+        const unsigned pB0 = (unsigned)(n0 + wave * 8 + prow) * (unsigned)p.ldb * EB + pcol;
+        const unsigned strideA = 64u * (unsigned)p.lda * EB, strideB = 64u * (unsigned)p.ldb * EB;
+        const int nk2 = (int)(Kb / 128);
+        auto issue_piece2 = [&](int kt, unsigned char* slot, int j) {
+            const unsigned kbase = (unsigned)kt * 128;
+            const bool dead = (kt >= nk2);
+            if (j < MB) {
+                const unsigned o = dead ? 0xffffff00u : pA0 + ((unsigned)j * strideA + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            } else {
+                const int jb = j - MB;
+                const unsigned o = dead ? 0xffffff00u : pB0 + ((unsigned)jb * strideB + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A2 + (jb * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            }
+        };
+        const int fsw = (l31 >> 1) & 7;
+        const int a_row2 = (wm * 32 * MB + l31) * 128, b_row2 = A2 + (wn * 64 + l31) * 128;
+        int fco[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) fco[h] = ((2 * h + half) ^ fsw) * 16;
+        auto rdA2 = [&](const unsigned char* slot, int h, int mi) {
+            return *reinterpret_cast<const uint4*>(slot + a_row2 + mi * 4096 + fco[h]);
+        };
+        auto rdB2 = [&](const unsigned char* slot, int h, int ni) {
+            return *reinterpret_cast<const uint4*>(slot + b_row2 + ni * 4096 + fco[h]);
+        };
+        uint4 fa[MB], fb[2][2];
+#define PV_V7_PAIR2(MI, H)                                                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                      \
+            acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                            \
+                __builtin_bit_cast(bf16x8, fa[MI]), __builtin_bit_cast(bf16x8, fb[(H) & 1][ni]), acc[MI][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);
+        // slab KT in CUR (visible), slab KT+1 arriving in NXT; fa / fb[0] hold k-step 0 of slab KT
+#define PV_V7_FSTEP(KT, CUR, NXT)                                                                             \
+        _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                                       \
+            if (h == 3) {                                                                                     \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                           \
+                __builtin_amdgcn_s_barrier();                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                               \
+                PV_V7_PAIR2(mi, h)                                                                            \
+                fa[mi] = h < 3 ? rdA2(CUR, h < 3 ? h + 1 : 0, mi) : rdA2(NXT, 0, mi);                         \
+                if (mi == 1) {                                                                                \
+                    fb[(h + 1) & 1][0] = h < 3 ? rdB2(CUR, h < 3 ? h + 1 : 0, 0) : rdB2(NXT, 0, 0);           \
+                    fb[(h + 1) & 1][1] = h < 3 ? rdB2(CUR, h < 3 ? h + 1 : 0, 1) : rdB2(NXT, 0, 1);           \
+                }                                                                                             \
+                if (h == 3) issue_piece2((KT) + 2, CUR, mi);                                                  \
+                if (h == 0 && mi < 4) issue_piece2((KT) + 1, NXT, MB + mi);                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+        }
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) issue_piece2(0, ring0, j);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < MB; ++j) issue_piece2(1, ring1, j);      // (the B pieces of slab 1 ride on step 0's first k-step)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA2(ring0, 0, mi);
+        fb[0][0] = rdB2(ring0, 0, 0); fb[0][1] = rdB2(ring0, 0, 1);
+        int kt = 0;
+        for (; kt + 2 <= nk2; kt += 2) {
+            PV_V7_FSTEP(kt, ring0, ring1)
+            PV_V7_FSTEP(kt + 1, ring1, ring0)
+        }
+        if (kt < nk2) { PV_V7_FSTEP(kt, ring0, ring1) }
+#undef PV_V7_FSTEP
+#undef PV_V7_PAIR2
     }
 #undef PV_V7_STEP
 #undef PV_V7_SYNC
@@ -1104,7 +1191,12 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
         const dim3 grid(ntm * ntn), block(512);
         // the software-pipelined K loop covers plain A operands and whole 64-byte slabs
-        const int loop_sel = (p.a_mode == PV_A_PLAIN && ((int64_t)p.K * DT<T>::kBytes) % 64 == 0) ? (g_pv_tuning.gemm_loop != 0) : 0;
+        // K loop: 2 = full-line form (whole 128-byte slabs: every B/32, L/14 shape), 1 = pipelined 64-byte slabs, 0 = the
+        // barrier-then-fetch loop (patch gather, K tails).  gemm_loop: -1 auto, 0 / 1 force the simpler forms where legal.
+        const int64_t kbytes = (int64_t)p.K * DT<T>::kBytes;
+        int loop_sel = 0;
+        if (p.a_mode == PV_A_PLAIN && kbytes % 64 == 0 && g_pv_tuning.gemm_loop != 0)
+            loop_sel = (kbytes % 128 == 0 && g_pv_tuning.gemm_loop != 1) ? 2 : 1;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = !g_pv_tuning.prof_markers &&
                            pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
@@ -1116,7 +1208,8 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
     } while (0)
 #define PV_V7_LAUNCH(EPI, ACT)                                                   \
     do {                                                                         \
-        if (loop_sel) PV_V7_LAUNCH_LP(EPI, ACT, 1);                              \
+        if (loop_sel == 2) PV_V7_LAUNCH_LP(EPI, ACT, 2);                         \
+        else if (loop_sel) PV_V7_LAUNCH_LP(EPI, ACT, 1);                         \
         else PV_V7_LAUNCH_LP(EPI, ACT, 0);                                       \
     } while (0)
         if (p.epi == PV_EPI_BIAS) PV_V7_LAUNCH(PV_EPI_BIAS, 0);
@@ -1139,9 +1232,11 @@ inline int pick_v7(const GemmParams& p) {
     if (g_pv_tuning.gemm_tile >= 0) return g_pv_tuning.gemm_tile;           // 0 = v4, 4 / 5 = v7<MB>
     auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
     const int64_t M = p.M, N = p.N;
+    // (v7 on whole 128-byte K slabs runs the full-line loop: its tiles are about 12 % faster -- profiles/r02_notes.md)
+    const double fl = ((int64_t)p.K * 2) % 128 == 0 && p.a_mode == PV_A_PLAIN ? 0.89 : 1.0;
     const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 768) * 25.0;
-    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5;
-    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0;
+    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5 * fl;
+    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0 * fl;
     if (c4 <= c74 && c4 <= c75) return 0;
     return c75 <= c74 ? 5 : 4;
 }

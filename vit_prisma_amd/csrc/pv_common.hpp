@@ -149,8 +149,10 @@ struct PvTuning {
     int prof_markers = 0;    // 1: time v7 launches with hipEventRecord markers instead of dispatch-packet events
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
     int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds
-    int gemm_loop = -1;      // K loop of the one-workgroup-per-CU kernels (ViT GEMMs, SAE filter GEMM): -1 auto (software-pipelined where it
-                             // applies: plain A operand, whole 64-byte slabs); 0 = the barrier-then-fetch loop everywhere; 1 = as auto
+    int gemm_loop = -1;      // K loop of the one-workgroup-per-CU kernels (ViT GEMMs, SAE filter GEMM): -1 auto = the full-line form (128-byte
+                             // slabs, two slots) where K is a whole number of 128-byte slabs, else the pipelined 64-byte-slab form,
+                             // else (patch gather, K tails) the barrier-then-fetch loop; 0 = barrier-then-fetch everywhere;
+                             // 1 = pipelined 64-byte slabs where legal; 2 = as auto
 };
 extern PvTuning g_pv_tuning;
 

@@ -66,10 +66,11 @@ template <int MODE, int LP = 0>
 __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p) {
     constexpr int MB = 4, TM = 64 * MB, TN = 256;
     constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring3[SLOT];
+    // LP == 2 (full-line K slabs): two slots of 128-byte rows in ring0 / ring1, ring2 / ring3 shrink to stubs
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[LP == 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[LP == 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[LP == 2 ? 16 : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring3[LP == 2 ? 16 : SLOT];
     __shared__ __attribute__((aligned(16))) float trow[512];
     __shared__ uint32_t rowcnt[256];
     __shared__ uint32_t hit_n;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
     if (kt + 1 < nk) { PV_ENC_STEP(kt + 1, ring1, ring0) }
     if (kt + 2 < nk) { PV_ENC_STEP(kt + 2, ring2, ring1) }
 #undef PV_ENC_STEP
-    } else {
+    } else if constexpr (LP == 1) {
         // software-pipelined form of the loop (gemm.hip, gemm_kernel_v7<..., LP = 1>): fragments of a half-slab refilled
         // right behind the MFMA pair that consumed them, the slab's barrier between its two halves, the DMA pieces of
         // slab s+4 one per MFMA pair in the second half.  Whole 64-byte slabs only (the launcher checks K % 32 == 0).
@@ -263,6 +264,84 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         if (kt + 2 < nk) { PV_ENC_PSTEP(kt + 2, ring2, ring3) }
 #undef PV_ENC_PSTEP
 #undef PV_ENC_PAIR
+    } else {
+        // full-line form (gemm.hip, gemm_kernel_v7<..., LP = 2>): 128-byte K slabs = whole cache lines per DMA piece (8 rows x
+        // 128 B), two 64 KB slots, four 16-element k-steps per slab, the next slab's barrier before the last k-step, vmcnt(0)
+        // there (one slab of prefetch distance).  Whole 128-byte slabs only (the launcher checks K % 64 == 0).
+        constexpr int A2 = TM * 128, NP2 = MB + 4;
+        const int prow = lane >> 3;
+        const int psw = ((lane >> 4) + 4 * (wave & 1)) & 7;
+        const unsigned pcol = (unsigned)(((lane & 7) ^ psw) * 16);
+        const unsigned pA0 = (unsigned)(m0 + wave * 8 + prow) * (unsigned)p.lda * 2u + pcol;
+        const int brow0 = n0 + wave * 8 + prow;
+        const unsigned pB0 = (unsigned)brow0 * p.ldb_bytes + pcol;
+        const unsigned strideA = 64u * (unsigned)p.lda * 2u, strideB = 64u * p.ldb_bytes;
+        const int nk2 = (int)(Kb / 128);
+        auto issue_piece2 = [&](int kt, unsigned char* slot, int j) {
+            const unsigned kbase = (unsigned)kt * 128;
+            const bool dead = kt >= nk2;
+            if (j < MB) {
+                const unsigned o = dead ? 0xffffff00u : pA0 + ((unsigned)j * strideA + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            } else {
+                const int jb = j - MB;
+                const unsigned o = (dead | (brow0 + jb * 64 >= p.N)) ? 0xffffff00u : pB0 + ((unsigned)jb * strideB + kbase);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A2 + (jb * 8 + wave) * 1024), 16, o, 0, 0, 0);
+            }
+        };
+        const int fsw = (l31 >> 1) & 7;
+        const int a_row2 = (wm * 32 * MB + l31) * 128, b_row2 = A2 + (wn * 64 + l31) * 128;
+        int fco[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) fco[h] = ((2 * h + half) ^ fsw) * 16;
+        auto rdA2 = [&](const unsigned char* slot, int h, int mi) {
+            return *reinterpret_cast<const uint4*>(slot + a_row2 + mi * 4096 + fco[h]);
+        };
+        auto rdB2 = [&](const unsigned char* slot, int h, int ni) {
+            return *reinterpret_cast<const uint4*>(slot + b_row2 + ni * 4096 + fco[h]);
+        };
+        uint4 fa[MB], fb[2][2];
+#define PV_ENC_PAIR2(MI, H)                                                                                   \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                      \
+            acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                             \
+                __builtin_bit_cast(f16x8, fa[MI]), __builtin_bit_cast(f16x8, fb[(H) & 1][ni]), acc[MI][ni], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);
+#define PV_ENC_FSTEP(KT, CUR, NXT)                                                                            \
+        _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                                       \
+            if (h == 3) {                                                                                     \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                           \
+                __builtin_amdgcn_s_barrier();                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                               \
+                PV_ENC_PAIR2(mi, h)                                                                           \
+                fa[mi] = h < 3 ? rdA2(CUR, h < 3 ? h + 1 : 0, mi) : rdA2(NXT, 0, mi);                         \
+                if (mi == 1) {                                                                                \
+                    fb[(h + 1) & 1][0] = h < 3 ? rdB2(CUR, h < 3 ? h + 1 : 0, 0) : rdB2(NXT, 0, 0);           \
+                    fb[(h + 1) & 1][1] = h < 3 ? rdB2(CUR, h < 3 ? h + 1 : 0, 1) : rdB2(NXT, 0, 1);           \
+                }                                                                                             \
+                if (h == 3) issue_piece2((KT) + 2, CUR, mi);                                                  \
+                if (h == 0) issue_piece2((KT) + 1, NXT, MB + mi);                                             \
+                __builtin_amdgcn_sched_barrier(0);                                                            \
+            }                                                                                                 \
+        }
+#pragma unroll
+        for (int j = 0; j < NP2; ++j) issue_piece2(0, ring0, j);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < MB; ++j) issue_piece2(1, ring1, j);
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA2(ring0, 0, mi);
+        fb[0][0] = rdB2(ring0, 0, 0); fb[0][1] = rdB2(ring0, 0, 1);
+        int kt = 0;
+        for (; kt + 2 <= nk2; kt += 2) {
+            PV_ENC_FSTEP(kt, ring0, ring1)
+            PV_ENC_FSTEP(kt + 1, ring1, ring0)
+        }
+        if (kt < nk2) { PV_ENC_FSTEP(kt, ring0, ring1) }
+#undef PV_ENC_FSTEP
+#undef PV_ENC_PAIR2
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches (and the threshold DMA)
     __syncthreads();
@@ -610,14 +689,19 @@ __global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restr
 int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
     const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
     const dim3 grid(ntm * ntn), block(512);
-    const bool piped = g_pv_tuning.gemm_loop != 0 && p.K % 32 == 0;      // whole 64-byte slabs of fp16
-    if (mode == 0) {
-        if (piped) hipLaunchKernelGGL((sae_enc_gemm_kernel<0, 1>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((sae_enc_gemm_kernel<0, 0>), grid, block, 0, stream, p);
-    } else {
-        if (piped) hipLaunchKernelGGL((sae_enc_gemm_kernel<1, 1>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((sae_enc_gemm_kernel<1, 0>), grid, block, 0, stream, p);
-    }
+    // K loop as in gemm.hip's launcher: 2 = full-line form (whole 128-byte slabs of fp16: K % 64 == 0), 1 = pipelined 64-byte
+    // slabs (K % 32 == 0), 0 = barrier-then-fetch
+    int lp = 0;
+    if (g_pv_tuning.gemm_loop != 0 && p.K % 32 == 0) lp = (p.K % 64 == 0 && g_pv_tuning.gemm_loop != 1) ? 2 : 1;
+#define PV_ENC_LAUNCH(MODE)                                                                              \
+    do {                                                                                                 \
+        if (lp == 2) hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 2>), grid, block, 0, stream, p);      \
+        else if (lp == 1) hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 1>), grid, block, 0, stream, p); \
+        else hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 0>), grid, block, 0, stream, p);              \
+    } while (0)
+    if (mode == 0) PV_ENC_LAUNCH(0);
+    else PV_ENC_LAUNCH(1);
+#undef PV_ENC_LAUNCH
     PV_LAUNCH_CHECK("sae_enc_gemm_kernel");
     return PV_OK;
 }
