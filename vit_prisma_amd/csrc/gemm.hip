@@ -774,12 +774,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     constexpr int NA = (4 * MB + 7) / 8;                  // A wave-instructions per wave per slab
     constexpr bool PAD = (4 * MB) % 8 != 0;
     static_assert(4 * SLOT + (PAD ? 8192 : 16) <= 160 * 1024, "one workgroup per CU");
-    // LP == 2 (full-line form below): two slots of 128-byte rows in ring0 / ring1, the other objects shrink to stubs
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[LP == 2 ? 2 * SLOT : SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[LP == 2 ? 2 * SLOT : SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring2[LP == 2 ? 16 : SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring3[LP == 2 ? 16 : SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char pad[(PAD && LP != 2) ? 8192 : 16];
+    // LP >= 2 (full-line form below): two slots of 128-byte rows in ring0 / ring1, the other objects shrink to stubs
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[LP >= 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[LP >= 2 ? 2 * SLOT : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring2[LP >= 2 ? 16 : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char ring3[LP >= 2 ? 16 : SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned char pad[(PAD && LP < 2) ? 8192 : 16];
     constexpr int EB = DT<T>::kBytes;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
