@@ -1232,11 +1232,11 @@ inline int pick_v7(const GemmParams& p) {
     if (g_pv_tuning.gemm_tile >= 0) return g_pv_tuning.gemm_tile;           // 0 = v4, 4 / 5 = v7<MB>
     auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
     const int64_t M = p.M, N = p.N;
-    // (v7 on whole 128-byte K slabs runs the full-line loop: its tiles are about 12 % faster -- profiles/r02_notes.md)
-    const double fl = ((int64_t)p.K * 2) % 128 == 0 && p.a_mode == PV_A_PLAIN ? 0.89 : 1.0;
+    // (the round times predate the full-line loop, which makes the v7 tiles about 10 % faster; scaling them moved only the
+    // 512 x 512 head GEMM from 16 small tiles to 4 large ones -- slower -- so the measured constants stay)
     const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 768) * 25.0;
-    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5 * fl;
-    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0 * fl;
+    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5;
+    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0;
     if (c4 <= c74 && c4 <= c75) return 0;
     return c75 <= c74 ? 5 : 4;
 }
