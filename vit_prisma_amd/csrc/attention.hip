@@ -306,7 +306,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int AW_ROW = 144;                 // bytes per LDS row: 64 bf16 + 16 pad (conflict-free b128 rows)
 
-template <int DH>
+template <int DH, bool STAGE = true>
 __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4][64 * AW_ROW];
     constexpr int NKS = DH / 16;            // k16 steps of Q K^T
@@ -330,20 +330,51 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
         const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
 
     // ---- 1, 2: scores
+    // STAGE: K and Q arrive as WHOLE rows (a lane takes one 16-byte chunk of a row; 64 / CPR rows = whole cache lines per
+    // instruction), are parked in the wave's LDS rows and read back as MFMA fragments.  The direct form asks for the
+    // fragment layout straight from global: 32 rows x 32 bytes per instruction, i.e. every 128-byte head row is looked
+    // up by four instructions -- the texture addresser's line lookups, not the bytes, are what that costs.
+    constexpr int CPR = DH / 8, RPI = 64 / CPR, NLD = 64 / RPI;       // chunks per row, rows per instruction, instructions
+    const int s_row = lane / CPR, s_ch = lane % CPR;
     u32x4_t kf[2][NKS];
+    u32x4_t qrow[STAGE ? NLD : 1];
+    if constexpr (STAGE) {
+        u32x4_t krow[NLD];
 #pragma unroll
-    for (int ki = 0; ki < 2; ++ki)
+        for (int i = 0; i < NLD; ++i) krow[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(i * RPI + s_row) * tokb + s_ch * 16, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            kf[ki][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(ki * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+        for (int i = 0; i < NLD; ++i) qrow[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(i * RPI + s_row) * tokb + s_ch * 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4_t*>(SP + (i * RPI + s_row) * AW_ROW + s_ch * 16) = krow[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                kf[ki][ks] = *reinterpret_cast<const u32x4_t*>(SP + (ki * 32 + l31) * AW_ROW + (2 * ks + half) * 16);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4_t*>(SP + (i * RPI + s_row) * AW_ROW + s_ch * 16) = qrow[i];
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                kf[ki][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(ki * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+    }
     const float inv_scale = 1.0f / p.attn_scale;
     (void)inv_scale;
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq) {
+        // (STAGE: the score rows tq * 32 .. + 31 written below land on the Q rows this iteration has just read; the Q rows of
+        // the other iteration sit in the other half of the LDS block)
         u32x4_t qf[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(tq * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) {
+            if constexpr (STAGE) qf[ks] = *reinterpret_cast<const u32x4_t*>(SP + (tq * 32 + l31) * AW_ROW + (2 * ks + half) * 16);
+            else qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(tq * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int ki = 0; ki < 2; ++ki)
@@ -502,7 +533,8 @@ int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
         const double bh = (double)heads, tt = (double)p.T * p.T;
         const double bytes = (4.0 * bh * p.T * DH + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
         ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * DH, bytes);
-        hipLaunchKernelGGL((attn_wave_kernel<DH>), dim3((heads + 3) / 4), dim3(256), 0, stream, p);
+        if (g_pv_tuning.attn_direct) hipLaunchKernelGGL((attn_wave_kernel<DH, false>), dim3((heads + 3) / 4), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attn_wave_kernel<DH, true>), dim3((heads + 3) / 4), dim3(256), 0, stream, p);
     }
     PV_LAUNCH_CHECK("attn_wave_kernel");
     return PV_OK;
