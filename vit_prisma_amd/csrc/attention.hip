@@ -363,8 +363,9 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
             for (int ks = 0; ks < NKS; ++ks)
                 kf[ki][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(ki * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
     }
+    // attn_scale = sqrt(d_head) is a power of two for d_head 64 (and 16, 256): x * (1 / scale) is then x / scale exactly
     const float inv_scale = 1.0f / p.attn_scale;
-    (void)inv_scale;
+    const bool scale_pow2 = (__float_as_uint(p.attn_scale) & 0x007fffffu) == 0u && p.attn_scale > 0.f;
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq) {
         // (STAGE: the score rows tq * 32 .. + 31 written below land on the Q rows this iteration has just read; the Q rows of
@@ -383,17 +384,28 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
+            for (int ki = 0; ki < 2; ++ki)        // S^T = K Q^T: a lane ends up with 4 x 4 consecutive keys of ONE query
+                acc[ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ki][ks]),
+                                                                  __builtin_bit_cast(bf16x8, qf[ks]), acc[ki], 0, 0, 0);
+        // C layout: col = lane & 31 (query), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (key): four consecutive keys ->
+        // one 8-byte LDS write into the query's row (64 two-byte writes per lane in the Q K^T orientation)
+        unsigned char* srow = SP + (tq * 32 + l31) * AW_ROW;
+        auto put_scores = [&](auto exact_recip) {
+#pragma unroll
             for (int ki = 0; ki < 2; ++ki)
-                acc[ki] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf[ks]),
-                                                                  __builtin_bit_cast(bf16x8, kf[ki][ks]), acc[ki], 0, 0, 0);
-        // C layout: col = lane & 31 (key), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (query)
 #pragma unroll
-        for (int ki = 0; ki < 2; ++ki)
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                *reinterpret_cast<bf16_t*>(SP + row * AW_ROW + (ki * 32 + l31) * 2) = f32_to_bf16(acc[ki][e] / p.attn_scale);
-            }
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (decltype(exact_recip)::value) v[i] = acc[ki][4 * j + i] * inv_scale;
+                        else v[i] = acc[ki][4 * j + i] / p.attn_scale;
+                    }
+                    *reinterpret_cast<uint2*>(srow + (ki * 32 + 8 * j + 4 * half) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+        };
+        if (scale_pow2) put_scores(std::true_type{});       // (wave-uniform branch: the divisions are not executed)
+        else put_scores(std::false_type{});
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -452,15 +464,16 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
             sum += e_[j];
         }
         const float rs = 1.0f / sum;
+        // NaN -> 0 (attention.py:149): a softmax row is NaN throughout or nowhere (exp(s - max) <= 1; a NaN / +inf score or an
+        // all -inf row makes the SUM NaN), so the where() is one test per row
+        const bool keep = lane < T_ && rs == rs;                          // pad rows: finite zeros for the MFMA
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) {
             uint32_t w[4];
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {
-                float p0 = e_[c8 * 8 + q2 * 2] * rs, p1 = e_[c8 * 8 + q2 * 2 + 1] * rs;
-                if (p0 != p0) p0 = 0.f;
-                if (p1 != p1) p1 = 0.f;
-                w[q2] = (lane < T_) ? pack_bf16x2(p0, p1) : 0u;          // pad rows: finite zeros for the MFMA
+                const float p0 = e_[c8 * 8 + q2 * 2] * rs, p1 = e_[c8 * 8 + q2 * 2 + 1] * rs;
+                w[q2] = keep ? pack_bf16x2(p0, p1) : 0u;
             }
             *reinterpret_cast<uint4*>(rowp + c8 * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -498,25 +511,25 @@ __global__ __launch_bounds__(256) void attn_wave_kernel(const AttnParams p) {
             const uint4 pa = *reinterpret_cast<const uint4*>(SP + (tq * 32 + l31) * AW_ROW + ks * 32 + half * 16);
 #pragma unroll
             for (int tn = 0; tn < NTN; ++tn)
-                zacc[tq][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa),
-                                                                       __builtin_bit_cast(bf16x8, vf[tn]), zacc[tq][tn], 0, 0, 0);
+                zacc[tq][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[tn]),      // z^T = V^T P^T
+                                                                       __builtin_bit_cast(bf16x8, pa), zacc[tq][tn], 0, 0, 0);
         }
     }
     __builtin_amdgcn_wave_barrier();
 
     // ---- 7: z -> LDS rows [64][DH] -> 16-byte row stores into [B, T, H, dh]
+    // (C layout of z^T: col = lane & 31 = query, rows = four consecutive d per group -> 8-byte writes into the query's row)
 #pragma unroll
     for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
         for (int tn = 0; tn < NTN; ++tn)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = tq * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                *reinterpret_cast<bf16_t*>(SP + row * AW_ROW + (tn * 32 + l31) * 2) = f32_to_bf16(zacc[tq][tn][e]);
-            }
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<uint2*>(SP + (tq * 32 + l31) * AW_ROW + (tn * 32 + 8 * j + 4 * half) * 2) =
+                    make_uint2(pack_bf16x2(zacc[tq][tn][4 * j], zacc[tq][tn][4 * j + 1]),
+                               pack_bf16x2(zacc[tq][tn][4 * j + 2], zacc[tq][tn][4 * j + 3]));
     __builtin_amdgcn_wave_barrier();
     {
-        constexpr int CPR = DH / 8;                                      // 16-byte chunks per row
         bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
         for (int c = lane; c < T_ * CPR; c += 64) {
             const int row = c / CPR, ch = c - row * CPR;
