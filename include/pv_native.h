@@ -40,8 +40,8 @@ extern "C" {
 #define PV_ACT_QUICK_GELU 1   /* models/activation_fns.py:19                       */
 #define PV_ACT_RELU 2
 
-/* ABI version; bumped on any struct/signature change. */
-#define PV_ABI_VERSION 9
+/* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS). */
+#define PV_ABI_VERSION 10
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
