@@ -40,7 +40,7 @@ extern "C" {
 #define PV_ACT_QUICK_GELU 1   /* models/activation_fns.py:19                       */
 #define PV_ACT_RELU 2
 
-/* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS). */
+/* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish). */
 #define PV_ABI_VERSION 10
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
@@ -293,9 +293,33 @@ int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
 #define PV_SAE_RENORM_DECODER 2
 #define PV_SAE_INV_NORM_VALID 4
 #define PV_SAE_SPARSE_GRADS 8
+#define PV_SAE_TP_ENC_TERM_ONLY 16   /* pv_sae_tp_finish: st->gb_dec = -W_enc[:, shard] gb_enc[shard] only (without colsum(dY)) */
 int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
                 const float* batch_mean, int32_t n_global, int32_t flags, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- feature-parallel training step (new functionality) ------------------------------------
+ * This rank's plan / state cover a SHARD of the features (all tokens of the batch on every rank).  pv_sae_step cut at the
+ * reconstruction, with the global top-k taken by the caller in between:
+ *   pv_sae_encode_topk   this rank's k candidates per token (the workspace keeps LN statistics, normaliser, sae_in)
+ *   [caller: all-gather of the candidate values, global top-k per token; local candidates that lose get value 0 -- a pair
+ *    with value <= 0 is a hole in every kernel, exactly like the reference's ReLU behind its top-k (sae.py:795-810)]
+ *   pv_sae_tp_partial    partial [N, d_in] = sum_s val_s W_dec[idx_s] over this rank's kept pairs (no b_dec, no LN-out);
+ *                        flags: PV_SAE_RENORM_DECODER / PV_SAE_INV_NORM_VALID as in pv_sae_step
+ *   [caller: all-reduce of the partials]
+ *   pv_sae_tp_finish     pre_sum [N, d_in] = the summed reconstruction: LN-out, loss, dY, dh, CSR, sparse backward and
+ *                        (PV_SAE_UPDATE_STATS) firing statistics for the shard's features; SAME workspace and x as the
+ *                        encode; gradients written into st->g*; st->gb_dec = colsum(dY) - W_enc[:, shard] gb_enc[shard]
+ *                        (the caller sums the ranks' encoder terms: every rank but one passes PV_SAE_TP_ENC_TERM_ONLY, which
+ *                        leaves colsum(dY) out, and all-reduces gb_dec); scalars[0..1] = loss (replicated), scalars[2] = this
+ *                        rank's kept pairs per token (the ranks' values add up to l0); out->topk_idx / topk_val are unused
+ *   [caller: all-reduces of gb_dec's encoder term, of the clip-norm terms (pv_sae_grad_sqnorm_rows) and of l0]
+ *   pv_sae_apply(0, d_sae_shard)                                                                                         */
+int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int32_t* topk_idx, const float* topk_val, int32_t n_tokens,
+                      int32_t flags, float* partial, void* stream);
+int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float* x, const float* pre_sum, const int32_t* topk_idx,
+                     const float* topk_val, int32_t n_tokens, int32_t n_global, int32_t flags, pv_sae_out* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

@@ -94,3 +94,56 @@ class OracleEngine:
 
     def fallback_rows(self):
         return 0
+
+
+class OracleShardEngine(OracleEngine):
+    """The twin of a NativeSAE built over ONE RANK'S FEATURE SHARD, with the cut-at-the-reconstruction entry points of the
+    feature-parallel step (pv_sae_encode_topk / pv_sae_tp_partial / pv_sae_tp_finish; vit_prisma_amd/sae/feature_parallel.py)."""
+
+    def __init__(self, W_enc, W_dec, b_enc, b_dec, k: int, max_tokens: int):
+        import types
+        holder = types.SimpleNamespace(**{n: types.SimpleNamespace(data=t) for n, t in
+                                          dict(W_enc=W_enc, W_dec=W_dec, b_enc=b_enc, b_dec=b_dec).items()})
+        super().__init__(holder, k, max_tokens)
+        self.g = dict(W_enc=self._g["W_encT"], W_dec=self._g["W_dec"], b_enc=self._g["b_enc"], b_dec=self._g["b_dec"])
+        self._enc = None
+
+    def encode_topk(self, x):
+        P, xn = self._P(), x.numpy()
+        xh, mu, std = O.ln_in(xn)
+        sae_in = xh - P["b_dec"]
+        pre = sae_in @ P["W_enc"] + P["b_enc"]
+        idx, vals = O.topk_mask(pre, self.k)
+        nf = np.sqrt(((xn - xn.mean(axis=0, keepdims=True)) ** 2).sum(axis=-1, keepdims=True))
+        self._enc = dict(sae_in=sae_in, mu=mu, std=std, nf=nf)
+        return (torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(vals.astype(np.float32)),
+                torch.from_numpy(mu[:, 0].copy()), torch.from_numpy(std[:, 0].copy()))
+
+    def tp_partial(self, idx, val, renorm_decoder=True):
+        if renorm_decoder:
+            self.renorm_decoder()
+        W_dec = self._P()["W_dec"]
+        i, v = idx.numpy().astype(np.int64), val.numpy()
+        return torch.from_numpy(np.einsum("nk,nkd->nd", v, W_dec[i]).astype(np.float32))
+
+    def tp_finish(self, x, pre_sum, idx, val, n_global=None, enc_term_only=False, update_stats=False):
+        P, xn, e = self._P(), x.numpy(), self._enc
+        N, d = xn.shape
+        ng = N if n_global is None else n_global
+        dt = np.float32
+        sae_out = (pre_sum.numpy() + P["b_dec"]) * e["std"] + e["mu"]
+        mse = ((sae_out - xn) ** 2 / e["nf"]).sum() / dt(ng * d)
+        d_pre = dt(2.0) * (sae_out - xn) / e["nf"] / dt(ng * d) * e["std"]
+        feats = np.zeros((N, self.d_sae), dt)
+        np.put_along_axis(feats, idx.numpy().astype(np.int64), np.maximum(val.numpy(), 0), axis=-1)
+        d_hidden = np.where(feats > 0, d_pre @ P["W_dec"].T, dt(0))
+        self._g["W_dec"].copy_(torch.from_numpy(feats.T @ d_pre))
+        self._g["W_encT"].copy_(torch.from_numpy((e["sae_in"].T @ d_hidden).T.copy()))
+        self._g["b_enc"].copy_(torch.from_numpy(d_hidden.sum(axis=0)))
+        gb = -(d_hidden @ P["W_enc"].T).sum(axis=0)
+        if not enc_term_only:
+            gb = gb + d_pre.sum(axis=0)
+        self._g["b_dec"].copy_(torch.from_numpy(gb.astype(dt)))
+        self.fire_count.copy_(torch.from_numpy((feats > 0).sum(axis=0).astype(dt)))
+        self.scalars[0] = self.scalars[1] = float(mse)
+        self.scalars[2] = float((feats > 0).sum()) / N

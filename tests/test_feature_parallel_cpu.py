@@ -1,0 +1,104 @@
+"""The feature-parallel (tensor-parallel) top-k SAE step of vit_prisma_amd/sae/feature_parallel.py under gloo, world 2 and 4,
+around the CPU twin of the shard engine (tests/_cpu_engine.py): candidates all-gathered, global top-k, partial
+reconstructions all-reduced, shard-local backward / clip / project / Adam -- must land on the single-process oracle's
+parameters, losses, l0 and firing counts (to fp32 summation order: the reconstruction is a sum of per-rank partial sums)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import sae_oracle as O
+from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state
+
+from conftest import rel_fro
+
+D_IN, D_SAE, K, N, STEPS = 32, 256, 4, 128, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, harvest_per_rank):
+    import torch.distributed as dist
+    from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, shard_range
+    from _cpu_engine import OracleShardEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = {n: torch.from_numpy(v.copy()) for n, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    fp = FeatureParallelSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], K,
+                            lambda We, Wd, be, bd: OracleShardEngine(We, Wd, be, bd, K, N), dist=dist, rank=rank, world=world)
+    assert (fp.lo, fp.hi) == shard_range(D_SAE, rank, world) and fp.engine.d_sae == D_SAE // world
+    losses, fires = [], []
+    for t in range(STEPS):
+        x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
+        if harvest_per_rank:                                         # every rank brings its own tokens: all-gather first
+            per = N // world
+            x = fp.gather_tokens(x[rank * per:(rank + 1) * per].contiguous())
+            assert tuple(x.shape) == (N, D_IN)
+        loss, l0 = fp.step(x, lr=1e-3, max_grad_norm=1.0)
+        losses.append((float(loss), float(l0)))
+        fires.append(fp.fire_count.numpy().copy())
+    P = fp.gather_parameters()
+    q.put((rank, {n: v.numpy().copy() for n, v in P.items()}, losses, fires))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,harvest_per_rank", [(2, False), (4, True)])
+def test_feature_parallel_step_equals_single_process_oracle(world, harvest_per_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, harvest_per_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    P = {kk: v.copy() for kk, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    ref_losses, ref_fires = [], []
+    for t in range(STEPS):
+        before = stats["act_freq_scores"].copy()
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), K, lr=1e-3, step=t + 1)
+        ref_losses.append((ref["loss"], ref["l0"]))
+        ref_fires.append(stats["act_freq_scores"] - before)
+    for rank, params, losses, fires in got:
+        for n in P:
+            assert rel_fro(params[n], P[n]) < 1e-5, (rank, n)
+            assert np.array_equal(params[n], got[0][1][n]), (rank, n)        # every rank gathers the same parameters
+        for (l, l0), (rl, rl0) in zip(losses, ref_losses):
+            assert abs(l - rl) <= 1e-5 * abs(rl) and abs(l0 - rl0) < 1e-6, (rank, l, rl, l0, rl0)
+        for f, rf in zip(fires, ref_fires):
+            assert np.array_equal(f, rf), rank
+
+
+def test_global_topk_mask_breaks_ties_by_feature_index():
+    """Single process, two pretend ranks: equal candidate values across shards -- the lower GLOBAL feature index wins,
+    as torch.topk on the dense row (and the oracle) would have it."""
+    from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE
+    fp = FeatureParallelSAE.__new__(FeatureParallelSAE)
+    fp.k, fp.world, fp.rank, fp.lo = 2, 2, 0, 0
+    vals = {0: torch.tensor([[5.0, 1.0]]), 1: torch.tensor([[5.0, 3.0]])}
+    idxs = {0: torch.tensor([[7, 2]], dtype=torch.int32) + 0, 1: torch.tensor([[1, 0]], dtype=torch.int32) + 8}
+
+    def fake_gather(t):
+        src = vals if t.dtype == torch.float32 else idxs
+        return torch.stack([src[0], src[1]])
+    fp._all_gather = fake_gather
+    keep0 = fp.global_topk_mask(torch.tensor([[7, 2]], dtype=torch.int32), vals[0])
+    fp.rank, fp.lo = 1, 8
+    keep1 = fp.global_topk_mask(torch.tensor([[1, 0]], dtype=torch.int32), vals[1])
+    # candidates: (5.0, g7) (1.0, g2) | (5.0, g9) (3.0, g8): top-2 = the two 5.0s (g7 before g9)
+    assert keep0.tolist() == [[True, False]] and keep1.tolist() == [[True, False]]

@@ -81,6 +81,7 @@ EXPORTS = [
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
+    "pv_sae_tp_partial", "pv_sae_tp_finish",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -131,6 +132,8 @@ def lib() -> C.CDLL:
         L.pv_sae_workspace_bytes.restype = sz
         L.pv_sae_renorm_decoder.argtypes = [vp, C.POINTER(SaeState), vp]
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_tp_partial.argtypes = [vp, C.POINTER(SaeState), vp, vp, i32, i32, vp, vp]
+        L.pv_sae_tp_finish.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp, vp, i32, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
         L.pv_sae_grad_sqnorm_step.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp]
         L.pv_sae_grad_sqnorm_rows.argtypes = [vp, C.POINTER(SaeState), i32, i32, i32, vp, vp, vp]

@@ -306,13 +306,17 @@ __device__ __forceinline__ float4 ld4(const float* p, bool ok) {
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-template <int V4>
+// MODE 0: the whole thing.  The feature-parallel step cuts it at the reconstruction: MODE 1 = this rank's PARTIAL
+// reconstruction sum_s val_s W_dec[idx_s] only (written to sae_out, no b_dec, no LN-out); MODE 2 = everything behind it, the
+// reconstruction summed over the ranks coming in through pre_sum.
+template <int V4, int MODE = 0>
 __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ x, const float* __restrict__ W_dec, const float* __restrict__ b_dec,
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ mu,
     const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out,
     float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
-    float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm) {
+    float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm,
+    const float* __restrict__ pre_sum = nullptr) {
     // inv_norm != nullptr: set_decoder_norm_to_unit_norm is pending -- W_dec still holds the un-normalised rows and row j
     // stands for W_dec[j] * inv_norm[j] (the Adam kernel writes the normalised + updated row; see pv_sae_step)
     const int lane = threadIdx.x & 63;
@@ -330,7 +334,11 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     for (int i = 0; i < V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* ir = idx + (int64_t)n * k;
     const float* vr = val + (int64_t)n * k;
-    for (int s = 0; s < k; s += 4) {
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i) acc[i] = ld4(pre_sum + (int64_t)n * d + col[i], ok[i]);
+    }
+    for (int s = 0; MODE != 2 && s < k; s += 4) {
         float a[4];
         float4 w[4][V4];
 #pragma unroll
@@ -350,6 +358,12 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
                 acc[i].x += a[u] * w[u][i].x; acc[i].y += a[u] * w[u][i].y;
                 acc[i].z += a[u] * w[u][i].z; acc[i].w += a[u] * w[u][i].w;
             }
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i)
+            if (ok[i]) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + col[i]) = acc[i];
+        return;
     }
     const float m = mu[n], sdv = sd[n], nf = norm[n];
     float lsum = 0.f;
@@ -1407,6 +1421,148 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
         hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
                            nblk + ngb, d.d_in, 1.0f);
+        PV_LAUNCH_CHECK("sae bias-grad kernels");
+    }
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature-parallel step: this rank's engine covers a SHARD of the features; the top-k is taken over all ranks'
+// candidates by the caller, the local candidates that did not make it arrive here with value 0 -- and a pair with
+// value <= 0 is a hole everywhere (no decode contribution, no CSR entry, dh gated off), like the reference's ReLU behind
+// its top-k.  pv_sae_step cut at the reconstruction:
+//   pv_sae_encode_topk (this rank's k candidates per token)  ->  [all-gather of candidate values, global top-k: caller]
+//   pv_sae_tp_partial  (partial reconstruction of the kept pairs)  ->  [all-reduce of the partials: caller]
+//   pv_sae_tp_finish   (LN-out, loss, dY, dh, CSR, sparse backward, statistics for the shard's features)
+//   -> [gb_dec / clip norm / l0 all-reduces: caller] -> pv_sae_apply
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sae_recount_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val,
+                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ wpos, int n_pairs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    wpos[i] = val[i] > 0.f ? atomicAdd(&cnt[idx[i]], 1u) : 0xffffffffu;
+}
+
+extern "C" int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int32_t* topk_idx, const float* topk_val, int32_t N,
+                                 int32_t flags, float* partial, void* stream_) {
+    PV_REQUIRE(plan && st && topk_idx && topk_val && partial && st->W_dec, "null argument");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool renorm = (flags & PV_SAE_RENORM_DECODER) != 0;
+    PV_REQUIRE(!renorm || st->dec_inv_norm, "PV_SAE_RENORM_DECODER needs pv_sae_state.dec_inv_norm");
+    plan->renorm_pending = renorm;
+    plan->live_offs = nullptr;
+    if (renorm && !(flags & PV_SAE_INV_NORM_VALID))
+        hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 15) / 16), dim3(256), 0, stream, (const float*)st->W_dec,
+                           st->dec_inv_norm, d.d_sae, d.d_in);
+    const float* inv_norm = renorm ? (const float*)st->dec_inv_norm : nullptr;
+    const dim3 grid((N + 3) / 4), block(256);
+#define CALL(D)                                                                                                          \
+    hipLaunchKernelGGL((sae_decode_kernel<D, 1>), grid, block, 0, stream, (const float*)nullptr, (const float*)st->W_dec, \
+                       (const float*)nullptr, topk_idx, topk_val, (const float*)nullptr, (const float*)nullptr,          \
+                       (const float*)nullptr, partial, (float*)nullptr, (float*)nullptr, (float*)nullptr, N, d.d_in, d.k, \
+                       0.f, 0, inv_norm, (const float*)nullptr)
+    V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+    PV_LAUNCH_CHECK("sae_decode_kernel (partial)");
+    return PV_OK;
+}
+
+// `workspace` must be the one the preceding pv_sae_encode_topk ran in, on the same x (it holds the LN statistics, the
+// loss normaliser and sae_in); pre_sum [N, d_in] = the reconstruction summed over the ranks (without b_dec).  Gradients of
+// the shard's rows are WRITTEN into st->g*; st->gb_dec receives colsum(dY) - W_enc[:, shard] gb_enc[shard]: the caller
+// combines the ranks' encoder terms.  scalars[0..1] = loss (over the full batch, replicated), scalars[2] = this rank's
+// kept pairs per token (the ranks' values add up to l0).
+extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float* x, const float* pre_sum, const int32_t* topk_idx,
+                                const float* topk_val, int32_t N, int32_t n_global, int32_t flags, pv_sae_out* out,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    PV_REQUIRE(plan && st && x && pre_sum && topk_idx && topk_val && out && workspace, "null argument");
+    PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
+    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_encT, "the transposed encoder copy (pv_sae_state.W_encT) is required");
+    PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    const int k = d.k, n_pairs = N * k;
+    const float* inv_norm = plan->renorm_pending ? (const float*)st->dec_inv_norm : nullptr;       // as pv_sae_tp_partial left it
+    plan->live_offs = nullptr;
+    float* dY = (float*)(wsb + ws.dY);
+    float* dh = (float*)(wsb + ws.dh);
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
+    uint32_t* wposp = (uint32_t*)(wsb + ws.wpos);
+    const dim3 block(256);
+    // the pairs that survived the global top-k: counts and within-list positions afresh
+    PV_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)d.d_sae * 4, stream));
+    hipLaunchKernelGGL(sae_recount_kernel, dim3((n_pairs + 255) / 256), block, 0, stream, topk_idx, topk_val, cnt, wposp, n_pairs);
+    {
+        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        const dim3 grid((N + 3) / 4);
+#define CALL(D)                                                                                                        \
+    hipLaunchKernelGGL((sae_decode_kernel<D, 2>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
+                       topk_idx, topk_val, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),                    \
+                       (const float*)(wsb + ws.norm), out->sae_out, dY, dh, (float*)(wsb + ws.loss_part), N, d.d_in, k, \
+                       grad_scale, 1, inv_norm, pre_sum)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel (finish)");
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
+                           1.0f / ((float)n_global * (float)d.d_in), 1, 0);
+        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
+        uint32_t* chunk_start = (uint32_t*)(wsb + ws.cursor);
+        int32_t* pairs = (int32_t*)(wsb + ws.pairs);
+        int32_t* long_list = (int32_t*)(wsb + ws.long_list);
+        uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
+        const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
+        float* rowsq = (float*)(wsb + ws.rowsq);
+        const int max_segs = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1;
+        uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
+        float* seg_rows = (float*)(wsb + ws.seg_rows);
+        float* seg_b = (float*)(wsb + ws.seg_b);
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
+                           out->scalars, 1.0f / (float)N);
+        hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
+                           max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
+                           out->fire_count, d.d_sae, update_stats, (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, topk_idx,
+                           (const uint32_t*)wposp, (const uint32_t*)offs, pairs, n_pairs);
+        PV_LAUNCH_CHECK("csr kernels");
+        const dim3 gridf((max_chunks + 3) / 4);
+#define CALL(D)                                                                                                        \
+    hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
+                       st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in);                                                   \
+    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
+                       (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh,                                       \
+                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
+    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
+                       (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx,           \
+                       topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b,            \
+                       d.d_in, k, max_segs);                                                                           \
+    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
+                       (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
+                       st->gb_enc, rowsq, d.d_in, max_segs)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_backward_kernel");
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+        float* colpart = (float*)(wsb + ws.colpart);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, colpart, N, d.d_in);
+        hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                           colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+        // PV_SAE_TP_ENC_TERM_ONLY: every rank holds the same dY; only one of them contributes its column sum to the all-reduce
+        if (flags & PV_SAE_TP_ENC_TERM_ONLY)
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
+                               (const float*)(colpart + (size_t)nblk * d.d_in), st->gb_dec, ngb, d.d_in, 1.0f);
+        else
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                               nblk + ngb, d.d_in, 1.0f);
         PV_LAUNCH_CHECK("sae bias-grad kernels");
     }
     return PV_OK;

@@ -247,6 +247,39 @@ class NativeSAE:
                                         self.workspace.numel(), self._stream()), "pv_sae_forward")
         return self.sae_out[:n], self.topk_idx[:n], self.topk_val[:n]
 
+    # ---- feature-parallel step (this engine = one rank's feature shard; sae/feature_parallel.py drives it) -----------
+    def tp_partial(self, idx: torch.Tensor, val: torch.Tensor, renorm_decoder: bool = True) -> torch.Tensor:
+        """[N, d_in] partial reconstruction of this shard's kept pairs (value 0 = not kept); a view, overwritten by the
+        next call."""
+        self._no_pending_sparse("tp_partial")
+        n = idx.shape[0]
+        assert idx.dtype == torch.int32 and val.dtype == torch.float32 and idx.is_contiguous() and val.is_contiguous()
+        st = self._state()
+        inv_valid = renorm_decoder and self._inv_norm_key is not None and self._inv_norm_key == self._w_dec_key()
+        N.check(self.lib.pv_sae_tp_partial(self._plan, C.byref(st), idx.data_ptr(), val.data_ptr(), n,
+                                           (2 if renorm_decoder else 0) | (4 if inv_valid else 0), self.sae_out.data_ptr(),
+                                           self._stream()), "pv_sae_tp_partial")
+        return self.sae_out[:n]
+
+    def tp_finish(self, x: torch.Tensor, pre_sum: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, n_global: Optional[int] = None,
+                  enc_term_only: bool = False, update_stats: bool = False) -> None:
+        """Everything behind the summed reconstruction ``pre_sum`` (no b_dec): loss, gradients of this shard's rows (``g``),
+        ``g['b_dec']`` = colsum(dY) - this shard's encoder term (without colsum(dY) when enc_term_only), scalars[0..1] =
+        loss, scalars[2] = this shard's kept pairs per token.  Must follow ``encode_topk(x)`` on the same x."""
+        x = self._check_x(x)
+        n = x.shape[0]
+        pre_sum = pre_sum.contiguous()
+        assert pre_sum.dtype == torch.float32 and tuple(pre_sum.shape) == (n, self.d_in)
+        st = self._state()
+        out = N.SaeOut(sae_out=None, topk_idx=idx.data_ptr(), topk_val=val.data_ptr(), scalars=self.scalars.data_ptr(),
+                       fire_count=self.fire_count.data_ptr())
+        N.check(self.lib.pv_sae_tp_finish(self._plan, C.byref(st), x.data_ptr(), pre_sum.data_ptr(), idx.data_ptr(), val.data_ptr(),
+                                          n, int(n_global if n_global is not None else n),
+                                          int(bool(update_stats)) | (16 if enc_term_only else 0), C.byref(out),
+                                          self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_tp_finish")
+        self._grad_fresh = False            # (grad_sqnorm(from_step=True) is about pv_sae_step; use grad_sqnorm_rows here)
+        self._grad_sparse = False
+
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:
         self.step(x, renorm_decoder=True, sparse_grads=True)
