@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allow-overrides", action="store_true", help="A/B runs only: measure with PV_* env / tuning overrides (recorded)")
+    ap.add_argument("--sae-parallel", default="data", choices=["data", "feature"],
+                    help="under torchrun: the SAE step-only leg shards tokens + optimizer (data, default) or features (feature)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="under torchrun: seconds the secondary legs (SAE, L/14) may take before the main line is printed without them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -484,7 +486,7 @@ def main():
         from vit_prisma_amd.sae.bench_leg import sae_bench_leg, sae_end_to_end_leg
         del model, images
         torch.cuda.empty_cache()
-        sae = leg("sae", lambda: sae_bench_leg(dev, dist=dist))
+        sae = leg("sae", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=a.sae_parallel == "feature"))
         torch.cuda.empty_cache()
         e2e = leg("sae_end_to_end", lambda: sae_end_to_end_leg(dev, dist=dist))
         if rank == 0:

@@ -102,3 +102,70 @@ def test_global_topk_mask_breaks_ties_by_feature_index():
     keep1 = fp.global_topk_mask(torch.tensor([[1, 0]], dtype=torch.int32), vals[1])
     # candidates: (5.0, g7) (1.0, g2) | (5.0, g9) (3.0, g8): top-2 = the two 5.0s (g7 before g9)
     assert keep0.tolist() == [[True, False]] and keep1.tolist() == [[True, False]]
+
+
+def _trainer_worker(rank, world, port, q):
+    """The same step through VisionSAETrainer.train_step (use_feature_parallel): tokens harvested per rank, statistics,
+    sync_parameters() gathering the shards back into the module."""
+    import torch.distributed as dist
+    from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
+    from _cpu_engine import OracleShardEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN, activation_fn_str="topk",
+        activation_fn_kwargs={"k": K}, normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N,
+        lr=1e-3, max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0, seed=7 + rank)
+    sae = StandardSparseAutoencoder(cfg)
+    if rank == 0:
+        with torch.no_grad():
+            for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_feature_parallel(True)
+    tr._native_ok = lambda *a, **k: True
+    tr._make_shard_engine = lambda s, max_tokens: (lambda We, Wd, be, bd: OracleShardEngine(We, Wd, be, bd, K, max_tokens))
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    losses = []
+    for t in range(STEPS):
+        x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
+        xs = x[rank * (N // world):(rank + 1) * (N // world)][:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
+        losses.append((float(loss), float(l0)))
+        assert tr.last_step_native
+    tr.sync_parameters()
+    out = {n: getattr(sae, n).detach().numpy().copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy(), frac))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_feature_parallel_world2_equals_single_process_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    P = {kk: v.copy() for kk, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    ref_losses = []
+    for t in range(STEPS):
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), K, lr=1e-3, step=t + 1)
+        ref_losses.append((ref["loss"], ref["l0"]))
+    for rank, params, losses, act, since, frac in got:
+        for n in P:
+            assert rel_fro(params[n], P[n]) < 1e-5, (rank, n)
+        for (l, l0), (rl, rl0) in zip(losses, ref_losses):
+            assert abs(l - rl) <= 1e-5 * abs(rl) and abs(l0 - rl0) < 1e-6
+        assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
+        assert frac == STEPS * N

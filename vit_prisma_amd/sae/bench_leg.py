@@ -45,11 +45,12 @@ def _pmc_step_traffic() -> dict:
     return {"traffic": None}
 
 
-def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5) -> dict:
+def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, feature_parallel: bool = False) -> dict:
     """Step-only: ``VisionSAETrainer.train_step`` (the reference's call, train_sae.py:278-411) on batches resident in HBM.
     With a process group every rank takes 4096 / W tokens of the same global batch and the trainer's sharded-optimizer
     step runs (reduce-scatter of gradient rows, local clip / project / Adam on 1 / W of the features, asynchronous
-    all-gather of the parameters)."""
+    all-gather of the parameters); feature_parallel: the feature-sharded step of sae/feature_parallel.py instead (tokens
+    all-gathered, candidates all-gathered, partial reconstructions all-reduced; no gradient or parameter traffic)."""
     from .config import VisionModelSAERunnerConfig
     from .sae import StandardSparseAutoencoder
     from .trainer import VisionSAETrainer
@@ -66,6 +67,8 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
         for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
             getattr(sae, n).copy_(torch.from_numpy(v))
     tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True)
+    feature_parallel = bool(feature_parallel) and world > 1
+    tr.use_feature_parallel(feature_parallel)
     st = list(tr.initialize_training_variables())                 # act_freq, n_since_fired, n_frac, optimizer, scheduler
     batches = [torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=i)).to(dev)[rank * n_local:(rank + 1) * n_local][:, None, :].contiguous()
                for i in range(4)]
@@ -95,13 +98,13 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     elapsed = time.perf_counter() - t0
     N.prof_enable(False)
     tr._dp_flush()
-    eng = tr._engine
+    eng = tr._fp.engine if feature_parallel else tr._engine
     assert tr.last_step_native and eng is not None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(eng.scalars[0].item())
+    loss = float((tr._fp.loss if feature_parallel else eng.scalars[0]).item())
     enc = N.prof_read("sae_encode_topk")
     bwd = N.prof_read("sae_backward")
     app = N.prof_read("sae_apply")
@@ -116,7 +119,9 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
         "config": {"workload": f"top-k SAE 768 -> 24576 (32x), k=32, global batch {N_TOKENS} tokens, Adam, clip 1.0",
                    "tokens_per_gpu_per_step": n_local,
                    "parallelism": "single process" if world == 1 else
-                   f"dp{world}: tokens sharded, optimizer sharded by feature (reduce-scatter grads, all-gather params)",
+                   (f"tp{world}: features sharded for good, tokens / candidates all-gathered, partial reconstructions all-reduced"
+                    if feature_parallel else
+                    f"dp{world}: tokens sharded, optimizer sharded by feature (reduce-scatter grads, all-gather params)"),
                    "encoder": "fp16 MFMA filter + exact fp32 re-scoring" if eng.filtered_encoder else "exact fp32 MFMA"},
         "final_loss": loss,
         "roofline": {"kernel": "whole step (every kernel of one train step) vs the 1.4 GB of algorithmic HBM bytes per step of SURVEY.md 8(d)",

@@ -85,10 +85,20 @@ class VisionSAETrainer:
         self._pending = []                                  # in-flight parameter all-gathers of the sharded optimizer
         self._small = None
         self.rank, self.world = _dist_info()
+        self._feature_parallel = False                      # multi-rank native step: False = data parallel, True = feature parallel
+        self._fp = None                                     # FeatureParallelSAE (this rank's shard engine + choreography)
+        self._fp_dirty = False                              # the module's parameters lag behind the shards
 
     def use_native(self, flag: Optional[bool]) -> "VisionSAETrainer":
         """True: the fused HIP step or an error; False: always the PyTorch path; None (default): native when supported."""
         self._native_pref = flag
+        return self
+
+    def use_feature_parallel(self, flag: bool = True) -> "VisionSAETrainer":
+        """Multi-rank native steps shard the FEATURES (sae/feature_parallel.py: token-sized collectives, no gradient or
+        parameter traffic) instead of the tokens.  The module's own parameters are then refreshed only by
+        ``sync_parameters()`` (``checkpoint`` and the end of ``run`` call it).  New functionality; default off."""
+        self._feature_parallel = bool(flag)
         return self
 
     # ---- bookkeeping ------------------------------------------------------------------------------
@@ -195,6 +205,12 @@ class VisionSAETrainer:
 
     def _dp_flush(self) -> None:
         """Wait for the parameter all-gathers of the previous step and rebuild the other ranks' rows of W_enc / W_enc16T."""
+        if self._fp is not None and self._fp_dirty:         # feature parallel: gather the shards into the module
+            P = self._fp.gather_parameters()
+            with torch.no_grad():
+                for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
+                    getattr(self.sparse_coder, n).data.copy_(P[n])
+            self._fp_dirty = False
         if not self._pending:
             return
         for w in self._pending:
@@ -252,9 +268,11 @@ class VisionSAETrainer:
         return loss, mse_loss, l1_loss, l0, act_freq_scores, n_forward_passes_since_fired, n_frac_active_tokens
 
     def _native_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
+        lr = optimizer.param_groups[0]["lr"]
+        if self.world > 1 and self._feature_parallel:
+            return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         self._dp_flush()                                        # parameters of the previous step must have landed
         eng = self._get_engine(sae, x.shape[0])
-        lr = optimizer.param_groups[0]["lr"]
         # statistics tensors are the caller's: the kernels update them in place
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
@@ -270,6 +288,34 @@ class VisionSAETrainer:
         scheduler.step()
         sc = eng.scalars.clone()
         return sc[0], sc[1], None, sc[2]
+
+    def _make_shard_engine(self, sae, max_tokens: int):
+        """Engine over one rank's feature shard (tests substitute the CPU twin)."""
+        from .native_sae import NativeSAE
+        k, ln = sae.cfg.activation_fn_kwargs["k"], sae.cfg.normalize_activations == "layer_norm"
+        return lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k=k, layer_norm=ln, max_tokens=max_tokens)
+
+    def _native_tp_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired):
+        """Feature-parallel step (sae/feature_parallel.py): every rank brings its tokens, all ranks see the global batch,
+        each owns d_sae / world features for good."""
+        import torch.distributed as dist
+        from .feature_parallel import FeatureParallelSAE
+        n_global = x.shape[0] * self.world
+        if self._fp is None:
+            for p in sae.parameters():                          # shards are cut from identical replicas
+                dist.broadcast(p.data, src=0)
+            self._fp = FeatureParallelSAE(sae.W_enc.data, sae.W_dec.data, sae.b_enc.data, sae.b_dec.data,
+                                          sae.cfg.activation_fn_kwargs["k"], self._make_shard_engine(sae, n_global),
+                                          dist=dist, rank=self.rank, world=self.world)
+        fp = self._fp
+        loss, l0 = fp.step(fp.gather_tokens(x), lr, self.cfg.max_grad_norm)
+        self._fp_dirty = True
+        n_since_fired += 1                                      # train_sae.py:356-361 on the global batch
+        n_since_fired[fp.fire_count > 0] = 0
+        act_freq_scores += fp.fire_count
+        optimizer._opt_called = True
+        scheduler.step()
+        return loss, loss, None, l0
 
     def _native_dp_step(self, eng, sae, x, lr, act_freq_scores, n_since_fired):
         import torch.distributed as dist
