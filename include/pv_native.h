@@ -40,8 +40,9 @@ extern "C" {
 #define PV_ACT_QUICK_GELU 1   /* models/activation_fns.py:19                       */
 #define PV_ACT_RELU 2
 
-/* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish). */
-#define PV_ABI_VERSION 10
+/* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
+ * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
+#define PV_ABI_VERSION 11
 int pv_abi_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
@@ -320,6 +321,22 @@ int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int32_t* topk_i
 int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float* x, const float* pre_sum, const int32_t* topk_idx,
                      const float* topk_val, int32_t n_tokens, int32_t n_global, int32_t flags, pv_sae_out* out,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* Global top-k over the ranks' candidates (the step between pv_sae_encode_topk and pv_sae_tp_partial above).
+ * gathered [world][2][n_tokens][k] int32 = the all-gather of every rank's {candidate values (float bits), LOCAL feature
+ * indices}; a candidate's global feature index is rank * shard + local.  val_kept [n_tokens][k] = this rank's candidate
+ * values where they are among the k best of ALL ranks' candidates of their token in the order (value descending, global
+ * feature index ascending) -- torch.topk's order on the dense row (sae.py:795-810) -- and 0 elsewhere.  world <= 8. */
+int pv_sae_tp_merge(const int32_t* gathered, int32_t world, int32_t rank, int32_t n_tokens, int32_t k, int32_t shard,
+                    float* val_kept, void* stream);
+/* The one small all-reduce of the feature-parallel step.  bucket = [gb_dec (d_in) | clip-norm rows term | kept pairs per
+ * token | 2 floats of padding | firing counts of all d_sae_total features].  The caller points pv_sae_state.gb_dec at
+ * bucket and pv_sae_out.fire_count at bucket + d_in + 4 + j_lo for pv_sae_tp_finish; pack (after it, same workspace) adds
+ * the sum of squares of the shard's gradient rows and scalars[2], and zeroes the other ranks' firing counts; unpack
+ * (after the all-reduce) sets scalars[3] = sum of the ranks' row terms + ||gb_dec||^2 (the clip norm of the GLOBAL
+ * gradient, train_sae.py:394-397) and scalars[2] = l0. */
+int pv_sae_tp_bucket_pack(pv_sae_plan* plan, const void* workspace, const float* scalars, float* bucket, int32_t j_lo,
+                          int32_t d_sae_total, void* stream);
+int pv_sae_tp_bucket_unpack(pv_sae_plan* plan, const float* bucket, float* scalars, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

@@ -108,7 +108,50 @@ class OracleShardEngine(OracleEngine):
         self.g = dict(W_enc=self._g["W_encT"], W_dec=self._g["W_dec"], b_enc=self._g["b_enc"], b_dec=self._g["b_dec"])
         self._enc = None
 
+    # ---- the exchange buffers of the feature-parallel step (NativeSAE.tp_bind / tp_merge / tp_bucket_*) ----
+    def tp_bind(self, pack, bucket, lo, d_sae_total):
+        self._pack, self._tp = pack, (int(lo), int(d_sae_total))
+        self._g["b_dec"] = self.g["b_dec"] = bucket[:self.d_in]
+        self.fire_count = bucket[self.d_in + 4 + lo:self.d_in + 4 + lo + self.d_sae]
+
+    def tp_merge(self, gathered, world, rank, n):
+        """The host-side statement of pv_sae_tp_merge: rank all W k candidates of a token by (value desc, GLOBAL feature index
+        asc) with two stable sorts, keep the first k."""
+        k = self.k
+        v = gathered[:, 0].view(torch.float32).permute(1, 0, 2).reshape(n, world * k)
+        g = (gathered[:, 1] + torch.arange(world, dtype=torch.int32).view(world, 1, 1) * self.d_sae).permute(1, 0, 2).reshape(n, world * k).long()
+        o1 = torch.argsort(g, dim=1, stable=True)
+        o2 = torch.argsort(torch.gather(v, 1, o1), dim=1, descending=True, stable=True)
+        order = torch.gather(o1, 1, o2)
+        keep = torch.zeros(n, world * k, dtype=torch.bool)
+        keep.scatter_(1, order[:, :k], True)
+        mine = keep[:, rank * k:(rank + 1) * k]
+        return torch.where(mine, gathered[rank, 0].view(torch.float32), torch.zeros(()))
+
+    def tp_bucket_pack(self, bucket):
+        lo, total = self._tp
+        d = self.d_in
+        bucket[d] = sum(float((self._g[n].double() ** 2).sum()) for n in ("W_encT", "W_dec", "b_enc"))
+        bucket[d + 1] = self.scalars[2]
+        bucket[d + 2:d + 4] = 0
+        fire = bucket[d + 4:]
+        fire[:lo] = 0
+        fire[lo + self.d_sae:] = 0
+
+    def tp_bucket_unpack(self, bucket):
+        d = self.d_in
+        self.scalars[3] = float(bucket[d]) + float((bucket[:d].double() ** 2).sum())
+        self.scalars[2] = bucket[d + 1]
+
     def encode_topk(self, x):
+        out = self._encode_topk(x)
+        if getattr(self, "_pack", None) is not None:
+            n = x.shape[0]
+            self._pack[0, :n].view(torch.float32).copy_(out[1])
+            self._pack[1, :n].copy_(out[0])
+        return out
+
+    def _encode_topk(self, x):
         P, xn = self._P(), x.numpy()
         xh, mu, std = O.ln_in(xn)
         sae_in = xh - P["b_dec"]

@@ -84,24 +84,47 @@ def test_feature_parallel_step_equals_single_process_oracle(world, harvest_per_r
             assert np.array_equal(f, rf), rank
 
 
-def test_global_topk_mask_breaks_ties_by_feature_index():
-    """Single process, two pretend ranks: equal candidate values across shards -- the lower GLOBAL feature index wins,
-    as torch.topk on the dense row (and the oracle) would have it."""
-    from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE
-    fp = FeatureParallelSAE.__new__(FeatureParallelSAE)
-    fp.k, fp.world, fp.rank, fp.lo = 2, 2, 0, 0
-    vals = {0: torch.tensor([[5.0, 1.0]]), 1: torch.tensor([[5.0, 3.0]])}
-    idxs = {0: torch.tensor([[7, 2]], dtype=torch.int32) + 0, 1: torch.tensor([[1, 0]], dtype=torch.int32) + 8}
-
-    def fake_gather(t):
-        src = vals if t.dtype == torch.float32 else idxs
-        return torch.stack([src[0], src[1]])
-    fp._all_gather = fake_gather
-    keep0 = fp.global_topk_mask(torch.tensor([[7, 2]], dtype=torch.int32), vals[0])
-    fp.rank, fp.lo = 1, 8
-    keep1 = fp.global_topk_mask(torch.tensor([[1, 0]], dtype=torch.int32), vals[1])
+def test_global_topk_breaks_ties_by_feature_index():
+    """Two pretend ranks, equal candidate values across shards -- the lower GLOBAL feature index wins, as torch.topk on the
+    dense row (and the oracle) would have it.  (The host statement of pv_sae_tp_merge; the kernel itself is held to it in
+    tests/test_native_sae_gpu.py.)"""
+    from _cpu_engine import OracleShardEngine
+    eng = OracleShardEngine.__new__(OracleShardEngine)
+    eng.k, eng.d_sae = 2, 8
+    vals = torch.tensor([[[5.0, 1.0]], [[5.0, 3.0]]])                            # [W, n, k]
+    idxs = torch.tensor([[[7, 2]], [[1, 0]]], dtype=torch.int32)                 # local indices; rank 1's are global 9, 8
+    gathered = torch.stack([vals.view(torch.int32), idxs], dim=1).contiguous()   # [W, 2, n, k]
     # candidates: (5.0, g7) (1.0, g2) | (5.0, g9) (3.0, g8): top-2 = the two 5.0s (g7 before g9)
-    assert keep0.tolist() == [[True, False]] and keep1.tolist() == [[True, False]]
+    assert eng.tp_merge(gathered, 2, 0, 1).tolist() == [[5.0, 0.0]]
+    assert eng.tp_merge(gathered, 2, 1, 1).tolist() == [[5.0, 0.0]]
+    vals[1, 0, 1] = 5.0                                                          # now (5.0, g8) ties too: g7, g8 win, g9 loses
+    gathered = torch.stack([vals.view(torch.int32), idxs], dim=1).contiguous()
+    assert eng.tp_merge(gathered, 2, 0, 1).tolist() == [[5.0, 0.0]]
+    assert eng.tp_merge(gathered, 2, 1, 1).tolist() == [[0.0, 5.0]]
+
+
+def test_simulated_world_equals_the_process_group_step():
+    """simulate_step (all ranks of a world in one process, exchanges by hand) lands on the oracle like the gloo run does."""
+    from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, gather_parameters_local, simulate_step
+    from _cpu_engine import OracleShardEngine
+    world = 4
+    T = {n: torch.from_numpy(v.copy()) for n, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    ranks = [FeatureParallelSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], K,
+                                lambda We, Wd, be, bd: OracleShardEngine(We, Wd, be, bd, K, N), rank=r, world=world) for r in range(world)]
+    P = {kk: v.copy() for kk, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    for t in range(STEPS):
+        x = synth_sae_batch(N, D_IN, seed=t)
+        before = stats["act_freq_scores"].copy()
+        ref = O.train_step(P, opt, stats, x, K, lr=1e-3, step=t + 1)
+        loss, l0 = simulate_step(ranks, torch.from_numpy(x), lr=1e-3, max_grad_norm=1.0)
+        assert abs(float(loss) - ref["loss"]) <= 1e-5 * abs(ref["loss"]) and abs(float(l0) - ref["l0"]) < 1e-6
+        for fp in ranks:
+            assert np.array_equal(fp.fire_count.numpy(), stats["act_freq_scores"] - before)
+    got = gather_parameters_local(ranks)
+    for n in P:
+        assert rel_fro(got[n].numpy(), P[n]) < 1e-5, n
 
 
 def _trainer_worker(rank, world, port, q):

@@ -31,7 +31,10 @@ def fresh(d_in, d_sae):
     return P, opt, stats, T
 
 
-@pytest.mark.parametrize("d_in,d_sae,k,n", [(64, 512, 8, 256), (96, 1024, 16, 300), (768, 24576, 32, 4096)])
+# (768, 49152): the x64 CLIP-B/32 SAEs of the reference's docs/sae_table.md (d_sae > 32768: two blocks of the CSR scan, 192
+# candidate tiles, 3072 sampled values per token); (512, 65536): the plan's upper bound
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(64, 512, 8, 256), (96, 1024, 16, 300), (768, 24576, 32, 4096),
+                                            (768, 49152, 32, 1024), (768, 49152, 64, 512), (512, 65536, 32, 300)])
 def test_native_step_vs_oracle(d_in, d_sae, k, n):
     P, opt, stats, T = fresh(d_in, d_sae)
     eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
@@ -261,7 +264,8 @@ def _both_paths(eng, x, tuning, loop=-1):
 
 
 @pytest.mark.parametrize("loop", [-1, 0])
-@pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257), (104, 4096, 16, 300)])
+@pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257), (104, 4096, 16, 300),
+                                            (768, 49152, 32, 700), (768, 3072, 32, 900), (128, 2048, 8, 300)])
 def test_filtered_encoder_equals_exact_path(d_in, d_sae, k, n, loop, tuning):
     _, _, _, T = fresh(d_in, d_sae)
     T["b_enc"].mul_(20.0)                                                  # biases that matter
@@ -520,15 +524,17 @@ def test_activation_cache_shards_written_from_the_native_harvest_match_the_refer
 
 
 # ---------------------------------------------------------------------------------------------------
-# feature-parallel step on the real kernels (pv_sae_tp_partial / pv_sae_tp_finish), two ranks sharing the GPU over gloo.
-# The small shape (exact encoder, one 16-byte column group per lane) passed on an MI355X at the very end of round 2; the
-# large one (filtered encoder on a 4096-feature shard, d_in = 768) has not been run on hardware yet for lack of GPU time and
-# stays behind PV_EXPERIMENTAL=1 until it has.  The choreography itself is covered on CPU (tests/test_feature_parallel_cpu.py).
+# feature-parallel step on the real kernels (pv_sae_tp_merge / pv_sae_tp_partial / pv_sae_tp_finish / pv_sae_tp_bucket_*), two
+# ranks sharing the GPU over gloo: the small shape (exact encoder), a 4096-feature shard (filtered encoder) and the BENCH
+# shape (768 -> 24576, 4096 tokens).  The choreography itself is also covered on CPU (tests/test_feature_parallel_cpu.py).
+# Batches are synth_sae_batch(seed0 + t): the index-set comparison needs batches on which no token has its k-th and
+# (k+1)-th pre-activation closer than fp32 summation noise -- at 768 -> 8192 seed 0 has one (token 381, relative gap
+# 5.7e-8: the fp32 oracle and an fp64 evaluation disagree there; the kernels side with fp64, tools/tp_diag.py), seeds
+# 10..12 have none (smallest gap 3.4e-6).
 # ---------------------------------------------------------------------------------------------------
-_EXPERIMENTAL = os.environ.get("PV_EXPERIMENTAL") == "1"
 
 
-def _tp_gpu_worker(rank, world, port, q, d_in, d_sae, k, N, steps):
+def _tp_gpu_worker(rank, world, port, q, d_in, d_sae, k, N, steps, seed0):
     import torch.distributed as dist
     from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -540,7 +546,7 @@ def _tp_gpu_worker(rank, world, port, q, d_in, d_sae, k, N, steps):
                             lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k, True, N), dist=dist, rank=rank, world=world)
     losses, fires = [], []
     for t in range(steps):
-        x = torch.from_numpy(synth_sae_batch(N, d_in, seed=t)).to(dev)
+        x = torch.from_numpy(synth_sae_batch(N, d_in, seed=seed0 + t)).to(dev)
         loss, l0 = fp.step(x, lr=1e-3, max_grad_norm=1.0)
         losses.append((float(loss), float(l0)))
         fires.append(fp.fire_count.cpu().numpy().copy())
@@ -552,11 +558,8 @@ def _tp_gpu_worker(rank, world, port, q, d_in, d_sae, k, N, steps):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("d_in,d_sae,k,N", [
-    (64, 512, 8, 256),
-    pytest.param(768, 8192, 32, 512, marks=pytest.mark.skipif(not _EXPERIMENTAL, reason="not yet run on hardware: PV_EXPERIMENTAL=1 selects it")),
-])
-def test_feature_parallel_world2_equals_single_process_oracle(d_in, d_sae, k, N):
+@pytest.mark.parametrize("d_in,d_sae,k,N,seed0", [(64, 512, 8, 256, 0), (768, 8192, 32, 512, 10), (768, 24576, 32, 4096, 0)])
+def test_feature_parallel_world2_equals_single_process_oracle(d_in, d_sae, k, N, seed0):
     """Two ranks, each with a NativeSAE over its half of the features: candidates all-gathered, global top-k, partial
     reconstructions all-reduced, shard-local backward / clip / project / Adam (vit_prisma_amd/sae/feature_parallel.py) --
     losses, l0, firing counts and the gathered parameters against the single-process oracle."""
@@ -566,7 +569,7 @@ def test_feature_parallel_world2_equals_single_process_oracle(d_in, d_sae, k, N)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     steps = 3
-    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, q, d_in, d_sae, k, N, steps)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, q, d_in, d_sae, k, N, steps, seed0)) for r in range(2)]
     for p in procs:
         p.start()
     params, losses, fires = q.get(timeout=800)
@@ -578,8 +581,52 @@ def test_feature_parallel_world2_equals_single_process_oracle(d_in, d_sae, k, N)
     stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
     for t in range(steps):
         before = stats["act_freq_scores"].copy()
-        ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), k, lr=1e-3, step=t + 1)
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=seed0 + t), k, lr=1e-3, step=t + 1)
         assert abs(losses[t][0] - ref["loss"]) <= 1e-4 * abs(ref["loss"]) and abs(losses[t][1] - ref["l0"]) < 1e-4, (t, losses[t], ref)
         assert np.array_equal(fires[t], stats["act_freq_scores"] - before), t
     for n in P:
         assert rel_fro(params[n], P[n]) < 1e-4, n
+
+
+def test_tp_merge_kernel_equals_the_host_statement():
+    """pv_sae_tp_merge against the two-stable-sorts statement of the same rule (tests/_cpu_engine.py: value desc, global
+    feature index asc), on candidates with many exact ties across ranks, zeros and a world of 8."""
+    from _cpu_engine import OracleShardEngine
+    from vit_prisma_amd import _native as N
+    g = torch.Generator().manual_seed(3)
+    for W, n, k, shard in ((2, 300, 32, 4096), (8, 257, 64, 3072), (4, 64, 5, 16), (1, 10, 8, 64)):
+        vals = (torch.randint(0, 12, (W, n, k), generator=g).float() * 0.25)              # heavy ties, some zeros
+        vals, _ = vals.sort(dim=2, descending=True)
+        idx = torch.stack([torch.stack([torch.randperm(shard, generator=g)[:k] for _ in range(n)]) for _ in range(W)]).int()
+        gathered = torch.stack([vals.view(torch.int32), idx], dim=1).contiguous()         # [W, 2, n, k]
+        twin = OracleShardEngine.__new__(OracleShardEngine)
+        twin.k, twin.d_sae = k, shard
+        gd = gathered.cuda()
+        for rank in range(W):
+            out = torch.empty(n, k, dtype=torch.float32, device="cuda")
+            N.check(N.lib().pv_sae_tp_merge(gd.data_ptr(), W, rank, n, k, shard, out.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "pv_sae_tp_merge")
+            assert torch.equal(out.cpu(), twin.tp_merge(gathered, W, rank, n)), (W, rank)
+
+
+@pytest.mark.parametrize("world,d_in,d_sae,k,N", [(4, 64, 512, 8, 256), (4, 768, 24576, 32, 4096), (8, 768, 24576, 32, 4096)])
+def test_feature_parallel_simulated_world_equals_single_process_oracle(world, d_in, d_sae, k, N):
+    """All ranks of a world of 4 / 8 on ONE GPU in lockstep (feature_parallel.simulate_step: the phases of the real step, the
+    exchanges by hand) at the bench shape: losses, l0, firing counts and parameters against the single-process oracle.  At
+    world 8 a shard is 3072 features: the filtered encoder's smallest plans."""
+    from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, gather_parameters_local, simulate_step
+    P, opt, stats, T = fresh(d_in, d_sae)
+    ranks = [FeatureParallelSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k,
+                                lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k, True, N), rank=r, world=world) for r in range(world)]
+    for t in range(2):
+        x = synth_sae_batch(N, d_in, seed=t)
+        before = stats["act_freq_scores"].copy()
+        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1)
+        loss, l0 = simulate_step(ranks, torch.from_numpy(x).cuda(), lr=1e-3, max_grad_norm=1.0)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(float(l0) - ref["l0"]) < 1e-4, (t, float(loss), ref["loss"])
+        for fp in ranks:
+            assert np.array_equal(fp.fire_count.cpu().numpy(), stats["act_freq_scores"] - before), (t, fp.rank)
+    got = gather_parameters_local(ranks)
+    for n in P:
+        assert rel_fro(got[n].cpu().numpy(), P[n]) < TOL, n

@@ -1,0 +1,62 @@
+"""Diagnostic: which top-k index sets differ between the native encoder (single engine, and two feature shards merged) and the
+oracle at a given shape, and how close the oracle's k-th / (k+1)-th pre-activations of those tokens are (a near-tie at fp32
+summation-order distance is not an error of either side)."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oracle import sae_oracle as O                                    # noqa: E402
+from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, simulate_step   # noqa: E402
+from vit_prisma_amd.sae.native_sae import NativeSAE                   # noqa: E402
+from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state     # noqa: E402
+
+d_in, d_sae, k, n = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else (768, 8192, 32, 512)
+seed = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+sd = synth_sae_state(d_in, d_sae, 0)
+x = synth_sae_batch(n, d_in, seed=seed)
+P = {kk: v.copy() for kk, v in sd.items()}
+O.renorm_decoder(P)
+fw = O.sae_forward(P, x, k)
+xh, mu, std = O.ln_in(x)
+pre64 = (xh - P["b_dec"]).astype(np.float64) @ P["W_enc"].astype(np.float64) + P["b_enc"]
+srt = np.sort(pre64, axis=1)[:, ::-1]
+gap = (srt[:, k - 1] - srt[:, k]) / np.abs(srt[:, k - 1])
+print(f"shape {d_in}->{d_sae} k={k} n={n} seed={seed}: smallest relative gaps between the k-th and (k+1)-th value:", np.sort(gap)[:5])
+ref = np.sort(fw["idx"], axis=1)
+ref64 = np.sort(np.argsort(-pre64, axis=1, kind="stable")[:, :k], axis=1)
+print("oracle fp32 vs fp64 index sets differ on tokens:", np.nonzero((ref != ref64).any(axis=1))[0].tolist())
+
+T = {kk: torch.from_numpy(v.copy()).cuda() for kk, v in sd.items()}
+eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+eng.renorm_decoder()
+idx, val, _, _ = eng.encode_topk(torch.from_numpy(x).cuda())
+got = np.sort(idx.cpu().numpy(), axis=1)
+bad = np.nonzero((got != ref).any(axis=1))[0]
+print("single engine vs oracle(fp32): differing tokens", bad.tolist(), "gaps", gap[bad].tolist(), "fallback rows", eng.fallback_rows())
+print("single engine vs fp64        : differing tokens", np.nonzero((got != ref64).any(axis=1))[0].tolist())
+
+for W in (2, 4):
+    T = {kk: torch.from_numpy(v.copy()).cuda() for kk, v in sd.items()}
+    ranks = [FeatureParallelSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k,
+                                lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k, True, n), rank=r, world=W) for r in range(W)]
+    loss, l0 = simulate_step(ranks, torch.from_numpy(x).cuda(), 1e-3, 1.0)
+    torch.cuda.synchronize()
+    sets = []
+    for r, fp in enumerate(ranks):
+        i = fp.pack[1, :n].cpu().numpy() + fp.lo
+        v = fp._val_kept.cpu().numpy()
+        sets.append(np.where(v > 0, i, -1))
+    allk = np.concatenate(sets, axis=1)
+    fire = ranks[0].fire_count.cpu().numpy()
+    ref_fire = (fw["feature_acts"] > 0).sum(axis=0)
+    badf = np.nonzero(fire != ref_fire)[0]
+    print(f"W={W}: loss {float(loss):.8f} (oracle {fw['loss']:.8f}) l0 {float(l0)} fire-count mismatches at features {badf.tolist()}",
+          "filtered" if ranks[0].engine.filtered_encoder else "exact", "fallback rows", [fp.engine.fallback_rows() for fp in ranks])
+    for t in range(n):
+        s = set(allk[t][allk[t] >= 0].tolist())
+        r = set(fw["idx"][t][fw["feature_acts"][t, fw["idx"][t]] > 0].tolist())
+        if s != r:
+            print("   token", t, "extra", sorted(s - r), "missing", sorted(r - s), "gap", gap[t],
+                  "values", [float(pre64[t, j]) for j in sorted((s - r) | (r - s))])

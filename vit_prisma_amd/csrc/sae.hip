@@ -438,43 +438,51 @@ constexpr int BWD_CH = 16;
 constexpr int BWD_LMAX = 64;
 constexpr int BWD_SEG = 32;
 
-// single-workgroup exclusive scan over d_sae (<= 32768) counts, staged through LDS: coalesced load, per-thread
-// contiguous runs scanned out of LDS, shuffles across threads, coalesced store
+// single-workgroup exclusive scan over the d_sae counts, staged through LDS in blocks of 32768 features (one block for
+// the 24 576-feature bench shape, two for the x64 SAEs of docs/sae_table.md: 49 152): coalesced load, per-thread contiguous
+// runs scanned out of LDS, shuffles across threads, coalesced store, the running total carried into the next block
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ n_long, int d_sae,
                                                         float* __restrict__ scalars, float inv_tokens) {
-    __shared__ uint32_t buf[32768];
+    constexpr int BLK = 32768;
+    __shared__ uint32_t buf[BLK];
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < d_sae; i += 1024) buf[i] = cnt[i];
-    __syncthreads();
-    const int per = (d_sae + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, d_sae);
-    uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += buf[i];
-    uint32_t inc = s;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < d_sae; b0 += BLK) {
+        const int nb = min(BLK, d_sae - b0);
+        __syncthreads();                                 // (the previous block's stores out of buf, its reads of wsum)
+        for (int i = tid; i < nb; i += 1024) buf[i] = cnt[b0 + i];
+        __syncthreads();
+        const int per = (nb + 1023) / 1024;
+        const int lo = min(tid * per, nb), hi = min(lo + per, nb);
+        uint32_t s = 0;
+        for (int i = lo; i < hi; ++i) s += buf[i];
+        uint32_t inc = s;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t a = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += a;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += a;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t base = carry;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        uint32_t total = 0;
+        for (int w = 0; w < 16; ++w) total += wsum[w];
+        uint32_t run = base + inc - s;                  // exclusive prefix of this thread's run
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t c = buf[i];
+            buf[i] = run;
+            run += c;
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += 1024) offs[b0 + i] = buf[i];
+        carry += total;
     }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wv; ++w) base += wsum[w];
-    uint32_t total = 0;
-    for (int w = 0; w < 16; ++w) total += wsum[w];
-    uint32_t run = base + inc - s;                  // exclusive prefix of this thread's run
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t c = buf[i];
-        buf[i] = run;
-        run += c;
-    }
-    __syncthreads();
-    for (int i = tid; i < d_sae; i += 1024) offs[i] = buf[i];
     if (tid == 1023) {
-        offs[d_sae] = total;
-        if (scalars) scalars[2] = (float)total * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
+        offs[d_sae] = carry;
+        if (scalars) scalars[2] = (float)carry * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
     }
     if (tid == 0) { n_long[0] = 0u; n_long[1] = 0u; }                 // counters of csr_post_kernel
 }
@@ -1155,7 +1163,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
 extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan) {
     PV_REQUIRE(desc && out_plan, "null argument");
     PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 16 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1024");
-    PV_REQUIRE(desc->d_sae >= desc->k && desc->d_sae % 4 == 0 && desc->d_sae <= 256 * 128, "d_sae must be a multiple of 4, <= 32768");
+    PV_REQUIRE(desc->d_sae >= desc->k && desc->d_sae % 4 == 0 && desc->d_sae <= 256 * 256, "d_sae must be a multiple of 4, <= 65536");
     PV_REQUIRE(desc->k >= 1 && desc->k <= MAXK, "k must be in [1, 64]");
     PV_REQUIRE(desc->max_tokens >= 1, "max_tokens");
     pv_sae_plan* p = new pv_sae_plan();
@@ -1565,6 +1573,109 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
                                nblk + ngb, d.d_in, 1.0f);
         PV_LAUNCH_CHECK("sae bias-grad kernels");
     }
+    return PV_OK;
+}
+
+// ---- feature-parallel glue kernels: the global top-k over the ranks' candidates, and the ONE small all-reduce bucket ----
+// gathered [W][2][N][k]: rank r's piece = its k candidate values per token (float bits, sorted or not) followed by their
+// LOCAL feature indices (global index = r * shard + local).  A wave per token: lane s owns this rank's candidate s and
+// counts the candidates of all ranks that come before it in the order (value desc, global feature index asc) -- torch.topk's
+// order on the dense row, as the oracle -- out of an LDS copy of the token's W k candidates; rank < k = kept, otherwise
+// the value becomes 0 (a hole).  Replaces two argsorts over [N, W k] and a scatter on the host side.
+__global__ __launch_bounds__(256) void sae_tp_merge_kernel(const int32_t* __restrict__ gathered, int W, int rank, int n_tok, int k,
+                                                           int shard, float* __restrict__ val_kept) {
+    __shared__ float sv[4][8 * MAXK];
+    __shared__ int32_t sg[4][8 * MAXK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wv;
+    if (n >= n_tok) return;                                    // (whole waves leave; no workgroup barrier below)
+    const int64_t piece = 2 * (int64_t)n_tok * k;
+    const int total = W * k;
+    for (int c = lane; c < total; c += 64) {
+        const int r = c / k, t = c - r * k;
+        const int32_t* pr = gathered + r * piece + (int64_t)n * k + t;
+        sv[wv][c] = __int_as_float(pr[0]);
+        sg[wv][c] = r * shard + pr[(int64_t)n_tok * k];
+    }
+    __builtin_amdgcn_wave_barrier();                            // (a wave's LDS operations execute in order)
+    if (lane < k) {
+        const float v = sv[wv][rank * k + lane];
+        const int32_t g = sg[wv][rank * k + lane];
+        int before = 0;
+        for (int c = 0; c < total; ++c) {
+            const float vo = sv[wv][c];
+            before += (vo > v) || (vo == v && sg[wv][c] < g);
+        }
+        val_kept[(int64_t)n * k + lane] = before < k ? v : 0.f;
+    }
+}
+
+extern "C" int pv_sae_tp_merge(const int32_t* gathered, int32_t world, int32_t rank, int32_t N, int32_t k, int32_t shard,
+                               float* val_kept, void* stream_) {
+    PV_REQUIRE(gathered && val_kept, "null argument");
+    PV_REQUIRE(world >= 1 && world <= 8 && rank >= 0 && rank < world, "world size must be in [1, 8]");
+    PV_REQUIRE(k >= 1 && k <= MAXK && N >= 1 && shard >= k, "shape");
+    hipLaunchKernelGGL(sae_tp_merge_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream_, gathered, world, rank, N, k, shard,
+                       val_kept);
+    PV_LAUNCH_CHECK("sae_tp_merge_kernel");
+    return PV_OK;
+}
+
+// The bucket every rank all-reduces once per step: [gb_dec (d_in) | rows term of the clip norm | kept pairs per token | 2 pad |
+// firing counts of ALL features (d_sae_total)].  pv_sae_tp_finish has already written this rank's gb_dec term and its
+// shard's firing counts in place (the caller points st->gb_dec / out->fire_count into the bucket); pack adds the two
+// scalars and zeroes the other ranks' firing counts.  After the all-reduce, unpack forms the clip norm of the GLOBAL
+// gradient: the ranks' row terms + ||gb_dec||^2 of the summed gb_dec.
+__global__ __launch_bounds__(1024) void sae_tp_bucket_pack_kernel(const float* __restrict__ rowsq, int d_shard, const float* __restrict__ scalars,
+                                                                  float* __restrict__ bucket, int d_in, int j_lo, int d_total) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < d_shard; j += 1024) s += rowsq[j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    float* fire = bucket + d_in + 4;
+    for (int j = threadIdx.x; j < d_total; j += 1024)
+        if (j < j_lo || j >= j_lo + d_shard) fire[j] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        bucket[d_in] = t;
+        bucket[d_in + 1] = scalars[2];
+        bucket[d_in + 2] = 0.f;
+        bucket[d_in + 3] = 0.f;
+    }
+}
+__global__ __launch_bounds__(1024) void sae_tp_bucket_unpack_kernel(const float* __restrict__ bucket, int d_in, float* __restrict__ scalars) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < d_in; i += 1024) s += bucket[i] * bucket[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        scalars[3] = bucket[d_in] + t;
+        scalars[2] = bucket[d_in + 1];
+    }
+}
+
+extern "C" int pv_sae_tp_bucket_pack(pv_sae_plan* plan, const void* workspace, const float* scalars, float* bucket, int32_t j_lo,
+                                     int32_t d_sae_total, void* stream_) {
+    PV_REQUIRE(plan && workspace && scalars && bucket, "null argument");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(j_lo >= 0 && j_lo + d.d_sae <= d_sae_total, "shard range");
+    const SaeWs ws = sae_carve(d);
+    hipLaunchKernelGGL(sae_tp_bucket_pack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_,
+                       (const float*)((const unsigned char*)workspace + ws.rowsq), d.d_sae, scalars, bucket, d.d_in, j_lo, d_sae_total);
+    PV_LAUNCH_CHECK("sae_tp_bucket_pack_kernel");
+    return PV_OK;
+}
+extern "C" int pv_sae_tp_bucket_unpack(pv_sae_plan* plan, const float* bucket, float* scalars, void* stream_) {
+    PV_REQUIRE(plan && bucket && scalars, "null argument");
+    hipLaunchKernelGGL(sae_tp_bucket_unpack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, bucket, plan->d.d_in, scalars);
+    PV_LAUNCH_CHECK("sae_tp_bucket_unpack_kernel");
     return PV_OK;
 }
 

@@ -40,7 +40,7 @@ static inline int pv_sae_tile_slots(const pv_sae_desc& d) {
 
 // Is the filtered (fp16 MFMA) encoder applicable to this plan?  Otherwise the exact-fp32 GEMM + streaming top-k runs.
 static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
-    return d.d_sae % 256 == 0 && d.d_sae >= 4096 && d.d_in % 8 == 0 && d.d_in >= 32 && d.k <= PV_SAE_MAXK &&
+    return d.d_sae % 256 == 0 && d.d_sae >= 2048 && d.d_in % 8 == 0 && d.d_in >= 32 && d.k <= PV_SAE_MAXK &&
            pv_sae_sample_q(d.k) * PV_SAE_SAMPLE_STRIDE * 2 <= PV_SAE_CAND_CAP && pv_sae_tile_slots(d) <= 256 && !g_pv_tuning.sae_exact;
 }
 

@@ -449,10 +449,10 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
 // ---------------------------------------------------------------------------------------------------
 constexpr float ENC_C1 = 1.25e-3f;
 
+template <int VPL>                                            // sampled values per lane: ns <= 64 VPL
 __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
                                                       const float* __restrict__ wmax_sq, int qsel, int d_in, float* __restrict__ thr,
                                                       float* __restrict__ sq_out, float* __restrict__ band, int n_tok) {
-    constexpr int VPL = 32;                                   // ns <= 2048
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -530,14 +530,14 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
     __shared__ float rval[PV_SAE_RESCORE_MAX];
-    __shared__ uint32_t tcnt[128];
+    __shared__ uint32_t tcnt[256];
     __shared__ uint32_t sh_t, sh_nr, sh_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
-    // gather the token's candidates: ntn (<= 128) per-tile lists of <= slots entries
+    // gather the token's candidates: ntn (<= 256: d_sae <= 65536) per-tile lists of <= slots entries
     uint32_t myc = 0;
     if (tid < ntn) myc = tile_cnt[row * ntn + tid];
-    if (tid < 128) tcnt[tid] = tid < ntn ? myc : 0u;
+    tcnt[tid] = tid < ntn ? myc : 0u;
     if (tid == 0) { sh_t = 0u; sh_nr = 0u; sh_bad = 0u; }
     __syncthreads();
     if (tid < ntn && myc == 0xffffffffu) sh_bad = 1u;
@@ -723,9 +723,12 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     p.bias = st->b_enc; p.bias_stride = S; p.out = (float*)(wsb + ws.sample); p.ldo = ns;
     int rc = launch_enc_gemm(0, p, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(sae_thr_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,
-                       (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq),
-                       (float*)(wsb + ws.band), N);
+#define THR(V)                                                                                                                \
+    hipLaunchKernelGGL((sae_thr_kernel<V>), dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,         \
+                       (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq), \
+                       (float*)(wsb + ws.band), N)
+    if (ns <= 1024) { THR(16); } else if (ns <= 2048) { THR(32); } else { THR(64); }        // d_sae <= 65536: ns <= 4096
+#undef THR
     PV_LAUNCH_CHECK("sae_thr_kernel");
     // filter: all features
     p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes; p.bias_stride = 1;

@@ -7,9 +7,12 @@ contiguous row range of each segment), Adam moments in two flat buffers of the s
 
 ``W_enc`` additionally lives as ``W_encT`` (its fp32 transpose -- the layout the sparse backward
 writes gradients in, Adam runs in and the exact re-scoring gathers rows from) and ``W_enc16T``
-(fp16, the B operand of the filter GEMM); ``pv_sae_apply`` keeps all of them in step, and an edit of
-the parameter from outside (``load_state_dict``, ``sae.W_enc.data.copy_``) is detected through the
-tensor version counter and answered with ``pv_sae_sync_shadows``.
+(fp16, the B operand of the filter GEMM); ``pv_sae_apply`` keeps all of them in step.  An in-place edit
+of the parameter from outside (``load_state_dict``, ``optimizer.step()``, ``sae.W_enc.copy_(...)`` under
+``no_grad``) is detected through the tensor version counter and answered with ``pv_sae_sync_shadows``.
+Edits through ``param.data`` (``p.data.copy_``, ``p.data /= x``) do NOT move the version counter and are
+invisible: after one, call ``engine.invalidate()`` (the package's own writers -- ``set_decoder_norm_to_unit_norm``,
+the trainer's parameter gathers -- edit the Parameter itself, and ``VisionSAETrainer.checkpoint`` invalidates).
 """
 from __future__ import annotations
 
@@ -137,6 +140,12 @@ class NativeSAE:
         N.check(self.lib.pv_sae_sync_shadows(self._plan, C.byref(st), int(from_transposed), int(j_lo),
                                              int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_sync_shadows")
         self._shadow_key = self._w_enc_key()
+
+    def invalidate(self) -> None:
+        """Forget everything derived from the parameters (encoder shadows, the decoder's inverse row norms): the next
+        call rebuilds it.  For edits the version counters cannot show (``param.data`` writes, raw-pointer writers)."""
+        self._shadow_key = None
+        self._inv_norm_key = None
 
     def _ensure_shadows(self) -> None:
         """An in-place edit of W_enc from outside (optimizer.step() of another trainer, load_state_dict, .copy_) bumps
@@ -279,6 +288,39 @@ class NativeSAE:
                                           self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_tp_finish")
         self._grad_fresh = False            # (grad_sqnorm(from_step=True) is about pv_sae_step; use grad_sqnorm_rows here)
         self._grad_sparse = False
+
+    # the feature-parallel step's glue (sae/feature_parallel.py): exchange buffers the kernels write in place
+    def tp_bind(self, pack: torch.Tensor, bucket: torch.Tensor, lo: int, d_sae_total: int) -> None:
+        """Point this shard engine's outputs into the step's two exchange buffers: the candidates of ``encode_topk`` land
+        in ``pack`` [2, max_tokens, k] int32 (values as float bits | local indices: ONE all-gather), ``tp_finish`` writes its
+        ``gb_dec`` term into ``bucket[:d_in]`` and the shard's firing counts into ``bucket[d_in + 4 + lo:...]`` (ONE small
+        all-reduce, see ``tp_bucket_pack``)."""
+        assert pack.dtype == torch.int32 and tuple(pack.shape) == (2, self.max_tokens, self.k) and pack.is_contiguous()
+        assert bucket.dtype == torch.float32 and bucket.numel() == self.d_in + 4 + d_sae_total and bucket.is_contiguous()
+        self.topk_val = pack[0].view(torch.float32)
+        self.topk_idx = pack[1]
+        self._g["b_dec"] = self.g["b_dec"] = bucket[:self.d_in]
+        self.fire_count = bucket[self.d_in + 4 + lo:self.d_in + 4 + lo + self.d_sae]
+        self._tp = (int(lo), int(d_sae_total))
+        self._tp_val_kept = torch.zeros(self.max_tokens, self.k, dtype=torch.float32, device=self.device)
+
+    def tp_merge(self, gathered: torch.Tensor, world: int, rank: int, n: int) -> torch.Tensor:
+        """gathered [world, 2, n, k] int32 (the all-gather of the ranks' ``pack[:, :n]``) -> this rank's candidate values
+        where they are among the k best of all ranks' candidates of their token, 0 elsewhere (pv_sae_tp_merge)."""
+        assert gathered.dtype == torch.int32 and gathered.is_contiguous() and tuple(gathered.shape) == (world, 2, n, self.k)
+        out = self._tp_val_kept[:n]
+        N.check(self.lib.pv_sae_tp_merge(gathered.data_ptr(), int(world), int(rank), int(n), self.k, self.d_sae, out.data_ptr(),
+                                         self._stream()), "pv_sae_tp_merge")
+        return out
+
+    def tp_bucket_pack(self, bucket: torch.Tensor) -> None:
+        lo, total = self._tp
+        N.check(self.lib.pv_sae_tp_bucket_pack(self._plan, self.workspace.data_ptr(), self.scalars.data_ptr(), bucket.data_ptr(),
+                                               lo, total, self._stream()), "pv_sae_tp_bucket_pack")
+
+    def tp_bucket_unpack(self, bucket: torch.Tensor) -> None:
+        N.check(self.lib.pv_sae_tp_bucket_unpack(self._plan, bucket.data_ptr(), self.scalars.data_ptr(), self._stream()),
+                "pv_sae_tp_bucket_unpack")
 
     # convenience: one full reference train_step (train_sae.py:278-411) on a single GPU
     def train_step(self, x: torch.Tensor, lr: float, max_grad_norm: Optional[float] = 1.0) -> None:

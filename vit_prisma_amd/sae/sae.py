@@ -193,7 +193,9 @@ class SparseAutoencoder(HookedRootModule, ABC):
     # ---- decoder constraints (sae.py:275-297) ---------------------------------------------------
     @torch.no_grad()
     def set_decoder_norm_to_unit_norm(self):
-        self.W_dec.data /= torch.norm(self.W_dec.data, dim=1, keepdim=True)
+        # in place on the Parameter itself (not through ``.data``): the version counter moves, which is how the native
+        # engines notice an edit made behind their back (sae/native_sae.py: _ensure_shadows, the deferred-renorm key)
+        self.W_dec.div_(torch.norm(self.W_dec, dim=1, keepdim=True))
 
     @torch.no_grad()
     def remove_gradient_parallel_to_decoder_directions(self):
@@ -318,7 +320,7 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         if self.dtype != torch.float32 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.parameters()):
             return "parameters are not contiguous fp32 CUDA tensors"
         k = cfg.activation_fn_kwargs.get("k", 0)
-        if not (cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 32768 and 1 <= k <= 64):
+        if not (cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536 and 1 <= k <= 64):
             return "shape outside the native plan's limits"
         if self.is_caching or any(hp.fwd_hooks or hp.bwd_hooks for hp in (self.hook_sae_in, self.hook_hidden_pre, self.hook_hidden_post, self.hook_sae_out)):
             return "hooks on the SAE's own hook points"

@@ -161,7 +161,7 @@ class VisionSAETrainer:
                 and cfg.dtype == torch.float32 and not cfg.use_ghost_grads
                 and cfg.normalize_activations in ("layer_norm", "none", None)
                 and all(p.is_cuda and p.dtype == torch.float32 for p in sae.parameters())
-                and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 32768
+                and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                 and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
                 and self._native_pref is not False)
 
@@ -171,9 +171,11 @@ class VisionSAETrainer:
         stale = eng is not None and any(eng.params[n].data_ptr() != getattr(sae, n).data_ptr()
                                         for n in ("W_enc", "W_dec", "b_enc", "b_dec"))     # e.g. b_dec.data re-bound by an init
         if eng is None or eng.max_tokens < n_tokens or stale:
-            if self.world > 1:
+            if self.world > 1 and eng is None:
                 # replicas must start from identical parameters (a per-rank b_dec initialisation, a different seed or a
-                # caller-supplied module would otherwise never converge: every rank applies the same summed gradient)
+                # caller-supplied module would otherwise never converge: every rank applies the same summed gradient).
+                # Only at the FIRST creation, which every rank reaches in its first step: a later re-creation (a larger
+                # batch, a re-bound parameter) is a per-rank event and must not contain a collective.
                 import torch.distributed as dist
                 for p in sae.parameters():
                     dist.broadcast(p.data, src=0)
@@ -209,7 +211,10 @@ class VisionSAETrainer:
             P = self._fp.gather_parameters()
             with torch.no_grad():
                 for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
-                    getattr(self.sparse_coder, n).data.copy_(P[n])
+                    getattr(self.sparse_coder, n).copy_(P[n])       # (not through .data: the version counter must move)
+            eng = getattr(self.sparse_coder, "_engine", None)       # the module's own inference engine re-derives its shadows
+            if eng is not None:
+                eng.invalidate()
             self._fp_dirty = False
         if not self._pending:
             return
@@ -408,6 +413,8 @@ class VisionSAETrainer:
         os.makedirs(folder, exist_ok=True)
         self.cfg.save_config(os.path.join(folder, "config.json"))
         sae.set_decoder_norm_to_unit_norm()
+        if self._engine is not None:                             # W_dec was edited between steps: 1 / ||row|| of the last apply is stale
+            self._engine.invalidate()
         path = os.path.join(folder, f"n_images_{n_training_tokens // max(self.cfg.context_size, 1)}.pt")
         sae.save_model(path)
         sparsity = torch.log10(act_freq_scores / max(n_frac_active_tokens, 1) + 1e-10).detach().cpu()
