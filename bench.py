@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allow-overrides", action="store_true", help="A/B runs only: measure with PV_* env / tuning overrides (recorded)")
-    ap.add_argument("--sae-parallel", default="data", choices=["data", "feature"],
-                    help="under torchrun: the SAE step-only leg shards tokens + optimizer (data, default) or features (feature)")
+    ap.add_argument("--sae-parallel", default="feature", choices=["data", "feature"],
+                    help="under torchrun: the SAE legs shard the features (feature, default: token-sized collectives only) or "
+                         "tokens + optimizer (data: parameter-sized reduce-scatter / all-gather)")
     ap.add_argument("--leg-timeout", type=float, default=420.0,
                     help="under torchrun: seconds the secondary legs (SAE, L/14) may take before the main line is printed without them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -461,10 +462,11 @@ def main():
     def emergency():
         if not done.is_set():
             line["secondary_legs"] = f"abandoned after {a.leg_timeout:.0f} s (see stderr)"
+            line["ok"] = False
             sys.stderr.write(f"[bench rank {rank}] secondary legs did not finish in {a.leg_timeout:.0f} s: printing the main line only\n")
             emit()
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
 
     wd = None
     if world > 1:
@@ -486,12 +488,25 @@ def main():
         from vit_prisma_amd.sae.bench_leg import sae_bench_leg, sae_end_to_end_leg
         del model, images
         torch.cuda.empty_cache()
-        sae = leg("sae", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=a.sae_parallel == "feature"))
+        fp = a.sae_parallel == "feature"
+        sae = leg("sae", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=fp))
         torch.cuda.empty_cache()
-        e2e = leg("sae_end_to_end", lambda: sae_end_to_end_leg(dev, dist=dist))
+        e2e = leg("sae_end_to_end", lambda: sae_end_to_end_leg(dev, dist=dist, feature_parallel=fp))
+        torch.cuda.empty_cache()
+        if world > 1:
+            # SURVEY.md 8(d) config 4 asks for both: strong (global batch 4096, above) and weak (4096 tokens per GPU) scaling
+            weak = leg("sae_weak", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=False, weak=True))
+        else:
+            # the ReLU + L1 SAE (every published CLIP SAE of the reference) on the dense fused step
+            weak = None
+            relu = leg("sae_relu_l1", lambda: sae_bench_leg(dev, dist=None, steps=8, warmup=2, activation="relu"))
         if rank == 0:
             line["sae"] = sae
             sae["end_to_end"] = e2e
+            if weak is not None:
+                sae["weak_scaling_data_parallel"] = weak
+            else:
+                sae["relu_l1"] = relu
             if world == 1 and not a.no_cpu_baseline:
                 sae["cpu_baseline"] = sae_cpu_baseline_torch(10.0)
                 sae["cpu_baseline"]["numpy_oracle"] = sae_cpu_baseline(6.0)
@@ -507,6 +522,20 @@ def main():
     done.set()
     if wd is not None:
         wd.cancel()
+
+    def leg_errors(obj, path=""):
+        out = []
+        if isinstance(obj, dict):
+            if "error" in obj and isinstance(obj["error"], str):
+                out.append(f"{path or 'line'}: {obj['error']}")
+            for k, v in obj.items():
+                out.extend(leg_errors(v, f"{path}.{k}" if path else k))
+        return out
+
+    errs = leg_errors(line)
+    line["ok"] = not errs                          # a failed secondary leg is recorded, flagged here, and the exit code is 3
+    if errs:
+        line["leg_errors"] = errs
     emit()
     if dist is not None:
         # (the line is out: a rank that died in a secondary leg must not hold the others in a barrier)
@@ -514,6 +543,8 @@ def main():
             dist.destroy_process_group()
         except Exception:                                        # noqa: BLE001
             pass
+    if errs:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -44,6 +44,10 @@ extern "C" {
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
 #define PV_ABI_VERSION 11
 int pv_abi_version(void);
+/* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
+ * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
+ * a library whose id differs from the sources it finds (vit_prisma_amd/build.py:source_id). */
+const char* pv_build_id(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf. */
 void pv_last_error(char* buf, size_t len);
 
@@ -261,7 +265,7 @@ typedef struct pv_sae_out {
     float* sae_out;        /* [N, d_in] reconstruction (after LN-out), may be NULL                */
     int32_t* topk_idx;     /* [N, k]   selected feature indices                                  */
     float* topk_val;       /* [N, k]   relu(hidden_pre) at those indices (feature_acts, sparse)   */
-    float* scalars;        /* [8]: 0 loss, 1 mse_loss, 2 l0, 3 grad sum-of-squares (pre-clip)     */
+    float* scalars;        /* [8]: 0 loss, 1 mse_loss, 2 l0, 3 grad sum-of-squares (pre-clip), 4 l1_loss (dense step) */
     float* fire_count;     /* [d_sae] tokens of this call on which each feature fired, or NULL     */
 } pv_sae_out;
 
@@ -337,6 +341,19 @@ int pv_sae_tp_merge(const int32_t* gathered, int32_t world, int32_t rank, int32_
 int pv_sae_tp_bucket_pack(pv_sae_plan* plan, const void* workspace, const float* scalars, float* bucket, int32_t j_lo,
                           int32_t d_sae_total, void* stream);
 int pv_sae_tp_bucket_unpack(pv_sae_plan* plan, const float* bucket, float* scalars, void* stream);
+
+/* ---- dense step: ReLU + L1 SAEs (activation_fn_str = "relu": sae.py:557-645 with the L1 sparsity term :617-626; the kind
+ * every published CLIP SAE of the reference is, docs/sae_table.md) ---------------------------------------------------------
+ * Same contract as pv_sae_step (forward + backward + statistics of one train step on N tokens, gradients WRITTEN into
+ * st->g*, complete buffers), for feature activations that are not k-sparse: five dense GEMMs on the exact fp32 matrix
+ * instruction with the elementwise work in their epilogues (sae_dense.hip).  plan->d.k is ignored.  flags:
+ * PV_SAE_UPDATE_STATS, PV_SAE_RENORM_DECODER (set_decoder_norm_to_unit_norm is applied to W_dec in place, first).
+ * scalars: 0 loss = mse + l1, 1 mse_loss, 2 l0 (mean_n #(f > 0)), 4 l1_loss = l1_coefficient * mean_n ||f_n||_1.
+ * out->topk_idx / topk_val are unused; out->fire_count [d_sae] and out->sae_out [N, d_in] are optional.
+ * Follow with pv_sae_grad_sqnorm (the whole flat gradient buffer) and pv_sae_apply.  d_in % 8 == 0, d_sae % 8 == 0. */
+int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
+                      int32_t n_global, int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

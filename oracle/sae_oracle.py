@@ -1,5 +1,5 @@
-"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of ViT-Prisma's top-k SAE
-forward, loss, backward and optimiser step.
+"""ORACLE (test infrastructure, NOT product code) -- numpy restatement of ViT-Prisma's SAE forward, loss,
+backward and optimiser step: the top-k SAE (k given) and the ReLU + L1 SAE (k = None, l1_coefficient).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
 
@@ -8,7 +8,8 @@ section 4: "parity unpinned" by the reference), so this restatement is pinned ag
 reference itself executed in the build container -- ``tests/golden/gen_golden_sae.py`` drives the
 reference's real ``StandardSparseAutoencoder`` and ``VisionSAETrainer.train_step`` for three
 consecutive steps and dumps losses, gradients and post-step parameters
-(``tests/test_oracle_sae_vs_golden.py``).
+(``tests/test_oracle_sae_vs_golden.py``); the ReLU + L1 form against ``tests/golden/sae_variants_steps.npz``
+(``relu_l1``: the reference's own classes through its own train_step, ``tests/golden/gen_golden_sae_variants.py``).
 
 Citations are relative to /root/reference/src/vit_prisma/.
 """
@@ -41,10 +42,11 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
     return idx, vals
 
 
-def sae_forward(P: Dict[str, Array], x: Array, k: int, layer_norm: bool = True, batch_mean: Optional[Array] = None,
-                n_global: Optional[int] = None) -> Dict[str, Array]:
+def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
+                n_global: Optional[int] = None, l1_coefficient: float = 0.0) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
-    :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).
+    :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
+    (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
 
     batch_mean / n_global: the data-parallel form -- mean_n(x) over the GLOBAL
     batch and the global token count; default = this batch (single process, the reference)."""
@@ -56,9 +58,13 @@ def sae_forward(P: Dict[str, Array], x: Array, k: int, layer_norm: bool = True, 
         xh, mu, std = x, np.zeros((N, 1), x.dtype), np.ones((N, 1), x.dtype)
     sae_in = xh - P["b_dec"]                                           # :563-565
     hidden_pre = sae_in @ P["W_enc"] + P["b_enc"]                      # :567-574
-    idx, vals = topk_mask(hidden_pre, k)                               # :576
-    feats = np.zeros_like(hidden_pre)
-    np.put_along_axis(feats, idx, vals, axis=-1)
+    if k is None:
+        feats = np.maximum(hidden_pre, dt(0))                          # :576 with torch.nn.ReLU
+        idx = vals = None
+    else:
+        idx, vals = topk_mask(hidden_pre, k)                           # :576
+        feats = np.zeros_like(hidden_pre)
+        np.put_along_axis(feats, idx, vals, axis=-1)
     pre_out = feats @ P["W_dec"] + P["b_dec"]                          # :584-591
     sae_out = pre_out * std + mu if layer_norm else pre_out            # :89-90 (no eps on the way out)
     bm = x.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
@@ -66,13 +72,21 @@ def sae_forward(P: Dict[str, Array], x: Array, k: int, layer_norm: bool = True, 
     ng = N if n_global is None else n_global
     mse = ((sae_out - x) ** 2 / nf).sum() / dt(ng * d)                 # :146-148 (mean over N*d)
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()            # train_sae.py:364
+    l1 = None
+    loss = mse
+    if k is None:                                                      # :617-626: sparsity = ||f||_1 per token, mean over the batch
+        l1 = dt(l1_coefficient) * (np.abs(feats).sum(axis=-1).sum() / dt(ng))
+        loss = mse + l1
     return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
-                mu=mu, std=std, norm_factor=nf, loss=dt(mse), mse_loss=dt(mse), l0=l0)
+                mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0)
 
 
 def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True,
-                 n_global: Optional[int] = None) -> Dict[str, Array]:
-    """What ``loss.backward()`` (train_sae.py:392) deposits in the four ``.grad`` fields."""
+                 n_global: Optional[int] = None, l1_coefficient: float = 0.0, gate: Optional[Array] = None) -> Dict[str, Array]:
+    """What ``loss.backward()`` (train_sae.py:392) deposits in the four ``.grad`` fields.  l1_coefficient (ReLU + L1
+    forward only): d l1_loss / d f = l1_coefficient / N where f > 0 (the 1-norm's subgradient at 0 is 0, as torch's).
+    gate (tests of the dense step): the ReLU gate [N, d_sae] to use instead of ``feature_acts > 0`` -- the gradient is
+    discontinuous in the sign of hidden_pre, and an entry within fp32 summation noise of zero may fall on either side."""
     dt = x.dtype.type
     N, d = x.shape
     ng = N if n_global is None else n_global
@@ -82,7 +96,9 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     g = {}
     g["W_dec"] = feats.T @ d_pre
     d_feats = d_pre @ P["W_dec"].T
-    d_hidden = np.where(feats > 0, d_feats, dt(0))                    # topk scatter + ReLU gates
+    if fw.get("l1_loss") is not None:
+        d_feats = d_feats + dt(l1_coefficient) / dt(ng)
+    d_hidden = np.where(feats > 0 if gate is None else gate, d_feats, dt(0))     # topk scatter + ReLU gates
     g["W_enc"] = fw["sae_in"].T @ d_hidden
     g["b_enc"] = d_hidden.sum(axis=0)
     d_sae_in = d_hidden @ P["W_enc"].T
@@ -136,17 +152,18 @@ def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, 
     return lr_end + 0.5 * (1 - lr_end) * (1 + np.cos(np.pi * progress))
 
 
-def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: int, lr: float,
-               step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True) -> Dict[str, float]:
+def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: Optional[int], lr: float,
+               step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, float]:
     """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
     firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count)."""
     renorm_decoder(P)                                                   # :306-307
-    fw = sae_forward(P, x, k, layer_norm)
+    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient)
     fired = (fw["feature_acts"] > 0).sum(axis=0)                        # :356-361
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0
     stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
-    g = sae_backward(P, x, fw, layer_norm)
+    g = sae_backward(P, x, fw, layer_norm, l1_coefficient=l1_coefficient)
     total = clip_and_project(P, g, max_grad_norm)
     adam_step(P, g, opt["m"], opt["v"], lr, step)
-    return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total)
+    return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total,
+                l1_loss=None if fw["l1_loss"] is None else float(fw["l1_loss"]))

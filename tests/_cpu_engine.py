@@ -143,7 +143,7 @@ class OracleShardEngine(OracleEngine):
         self.scalars[3] = float(bucket[d]) + float((bucket[:d].double() ** 2).sum())
         self.scalars[2] = bucket[d + 1]
 
-    def encode_topk(self, x):
+    def encode_topk(self, x, want_ln_stats=True):
         out = self._encode_topk(x)
         if getattr(self, "_pack", None) is not None:
             n = x.shape[0]

@@ -44,7 +44,7 @@ def _worker(rank, world, port, q, b_dec_init):
         with torch.no_grad():
             for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
                 getattr(sae, n).copy_(torch.from_numpy(v))
-    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_feature_parallel(False)     # the data-parallel mode
     assert tr.world == world and tr._shard(D_SAE) == (rank * D_SAE // world, (rank + 1) * D_SAE // world)
     # run the trainer's native branch on the CPU twin of the engine
     tr._native_ok = lambda *a, **k: True

@@ -23,6 +23,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_native.EXPORTS) == syms       # the ctypes binding covers exactly the header
+    # the library is a prebuilt file next to the sources: it must have been built from exactly these sources
+    assert _native.build_id() == _native.source_id(), "libpvnative.so is stale: run python -m vit_prisma_amd.build"
 
 
 def test_plan_queries_and_error_reporting_without_gpu():

@@ -64,6 +64,8 @@ def test_native_library_is_loaded():
     assert lib.pv_abi_version() == _native.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libpvnative.so" in f.read()
+    # the prebuilt library travels next to the sources: it must have been built from exactly these files
+    assert _native.build_id() == _native.source_id(), "libpvnative.so is stale: run python -m vit_prisma_amd.build"
 
 
 @pytest.mark.parametrize("arch_name", ["tiny", "tiny-ragged"])

@@ -67,3 +67,23 @@ def test_b32_config3_step_fingerprints():
             assert abs(fp["l2"] - want["params"][n]["l2"]) <= 1e-6 * want["params"][n]["l2"], (t, n)
             assert np.max(np.abs(np.array(fp["vals"]) - np.array(want["params"][n]["vals"]))) < 2e-5, (t, n)
         assert abs(fingerprint(stats["act_freq_scores"])["sum"] - want["act_freq"]["sum"]) < 0.5
+
+
+def test_relu_l1_three_steps_vs_reference_fixture():
+    """The ReLU + L1 form of the oracle (k = None) against what the reference's own StandardSparseAutoencoder
+    (activation_fn_str = "relu", l1_coefficient = 2e-3) produced through its own train_step
+    (tests/golden/gen_golden_sae_variants.py): scalars, statistics, parameters after step 3."""
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, d_sae, N, l1c = 64, 512, 256, 2e-3
+    P = {n: g[f"relu_l1_init_{n}"].copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": g["relu_l1_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), None, lr=1e-3, step=t + 1, l1_coefficient=l1c)
+        loss, mse, l1, l0 = g[f"relu_l1_s{t}_scalars"][:4]
+        assert abs(out["loss"] - loss) <= 1e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        assert abs(out["l1_loss"] - l1) <= 1e-5 * abs(l1) and abs(out["l0"] - l0) <= 1e-6 * l0
+        assert np.array_equal(stats["act_freq_scores"], g[f"relu_l1_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"relu_l1_s{t}_n_since"])
+    for n in P:
+        assert rel_fro(P[n], g[f"relu_l1_s2_param_{n}"]) < 1e-5, n

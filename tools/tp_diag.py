@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import sae_oracle as O                                    # noqa: E402
 from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, simulate_step   # noqa: E402
 from vit_prisma_amd.sae.native_sae import NativeSAE                   # noqa: E402

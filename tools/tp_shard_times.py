@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vit_prisma_amd.sae.feature_parallel import FeatureParallelSAE, simulate_step     # noqa: E402
 from vit_prisma_amd.sae.native_sae import NativeSAE                                     # noqa: E402
 from vit_prisma_amd.synth import synth_sae_batch, synth_sae_state                       # noqa: E402
@@ -34,7 +34,8 @@ torch.cuda.synchronize()
 out["single_process_step_us"] = round(e0.elapsed_time(e1) * 1e3 / steps, 1)
 del eng, T
 
-for W in (1, 2, 4, 8):
+WORLDS = tuple(int(a) for a in sys.argv[1:]) or (1, 2, 4, 8)
+for W in WORLDS:
     T = {kk: torch.from_numpy(v.copy()).to(dev) for kk, v in sd.items()}
     ranks = [FeatureParallelSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k,
                                 lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k, True, n), rank=r, world=W) for r in range(W)]

@@ -74,7 +74,7 @@ _lib: Optional[C.CDLL] = None
 
 # every symbol include/pv_native.h declares
 EXPORTS = [
-    "pv_abi_version", "pv_last_error",
+    "pv_abi_version", "pv_build_id", "pv_last_error",
     "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
     "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_gemm_bias", "pv_transpose_batched",
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
@@ -82,6 +82,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_sae_tp_partial", "pv_sae_tp_finish", "pv_sae_tp_merge", "pv_sae_tp_bucket_pack", "pv_sae_tp_bucket_unpack",
+    "pv_sae_dense_step",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -103,6 +104,7 @@ def lib() -> C.CDLL:
     L.pv_abi_version.restype = C.c_int
     if L.pv_abi_version() != ABI_VERSION:
         raise NativeError(f"libpvnative ABI {L.pv_abi_version()} != binding {ABI_VERSION}; rebuild")
+    L.pv_build_id.restype = C.c_char_p
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     L.pv_last_error.argtypes = [C.c_char_p, sz]
     L.pv_last_error.restype = None
@@ -134,6 +136,7 @@ def lib() -> C.CDLL:
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_tp_partial.argtypes = [vp, C.POINTER(SaeState), vp, vp, i32, i32, vp, vp]
         L.pv_sae_tp_finish.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp, vp, i32, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_dense_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_tp_merge.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.pv_sae_tp_bucket_pack.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.pv_sae_tp_bucket_unpack.argtypes = [vp, vp, vp, vp]
@@ -151,6 +154,22 @@ def lib() -> C.CDLL:
         L.pv_sae_encode_topk.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, vp, vp, vp, vp, sz, vp]
     _lib = L
     return L
+
+
+def build_id() -> str:
+    """Source hash baked into the loaded library (pv_build_id)."""
+    return lib().pv_build_id().decode()
+
+
+def source_id() -> str:
+    """The same hash computed from the sources next to this file (vit_prisma_amd/build.py)."""
+    from .build import source_id as _sid
+    return _sid()
+
+
+def built_from_these_sources() -> bool:
+    """True when the loaded libpvnative.so was built from exactly the sources in this tree."""
+    return build_id() == source_id()
 
 
 def last_error() -> str:

@@ -35,17 +35,50 @@ def sources() -> List[str]:
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_id() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.hpp, include/pv_native.h: names and contents, sorted) -- what
+    ``pv_build_id()`` of a library built from exactly these files returns."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "pv_native.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:32]
+
+
+def _write_build_id() -> None:
+    inc = os.path.join(OBJ, "build_id.inc")
+    text = f'#define PV_BUILD_ID "{source_id()}"\n'
+    old = None
+    if os.path.exists(inc):
+        with open(inc) as f:
+            old = f.read()
+    if old != text:
+        with open(inc, "w") as f:
+            f.write(text)
+
+
 def _deps_mtime() -> float:
     paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     paths.append(os.path.join(os.path.dirname(HERE), "include", "pv_native.h"))
     return max(os.path.getmtime(p) for p in paths)
 
 
+def _extra_dep_mtime(src: str) -> float:
+    if src == "build_id.hip":
+        return os.path.getmtime(os.path.join(OBJ, "build_id.inc"))
+    return 0.0
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     spath = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
-            and os.path.getmtime(obj) > _deps_mtime()):
+            and os.path.getmtime(obj) > _deps_mtime() and os.path.getmtime(obj) > _extra_dep_mtime(src)):
         return obj
     cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,6 +91,7 @@ def _compile(src: str, force: bool) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    _write_build_id()
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))

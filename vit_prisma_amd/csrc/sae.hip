@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
 //   * firing statistics (train_sae.py:356-361);
 //   * the chunk cuts of the short-list backward: the grid point g = w * BWD_CH that falls inside this feature's list
 //     [beg, end) becomes chunk_start[w] = end (beg itself when g == beg) -- every grid point below the total lies in
-//     exactly one list, so the scatter is disjoint; thread 0 fills the cuts at and beyond the total;
+//     exactly one list, so the scatter is disjoint; the cuts at and beyond the total are filled by the whole grid;
 //   * long lists (> BWD_LMAX pairs): registered in long_list {feature, first segment, #segments} with their
 //     BWD_SEG-pair segments in seg_range (two device counters, zeroed by the scan kernel).
 __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restrict__ offs, uint32_t* __restrict__ chunk_start,
@@ -501,6 +501,11 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
                                                        int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
                                                        float* __restrict__ rowsq_sparse) {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    {   // the cuts at and beyond the total (all threads of the grid: a feature shard of the feature-parallel step keeps a
+        // fraction of the N k pairs the cut array is sized for -- 7 of 8 cuts lie beyond the total at world 8)
+        const uint32_t total = offs[d_sae];
+        for (uint32_t w = (total + BWD_CH - 1) / BWD_CH + (uint32_t)j; w <= (uint32_t)max_chunks; w += gridDim.x * 256u) chunk_start[w] = total;
+    }
     if (j >= d_sae) return;
     const uint32_t beg = offs[j], end = offs[j + 1], c = end - beg;
     const float cnt = (float)c;
@@ -514,10 +519,6 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
         n_since_fired[j] = cnt > 0.f ? 0.f : n_since_fired[j] + 1.f;
     }
     for (uint32_t w = (beg + BWD_CH - 1) / BWD_CH; w * BWD_CH < end; ++w) chunk_start[w] = w * BWD_CH == beg ? beg : end;
-    if (j == 0) {
-        const uint32_t total = offs[d_sae];
-        for (uint32_t w = (total + BWD_CH - 1) / BWD_CH; w <= (uint32_t)max_chunks; ++w) chunk_start[w] = total;
-    }
     if (c > (uint32_t)BWD_LMAX) {
         const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
         const uint32_t sb = atomicAdd(&n_long[1], nseg);
@@ -1156,6 +1157,12 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.fb_list = take(N * 4);
     w.fb_count = take(256);
     w.wmax = take(256);
+    {   // dense (ReLU + L1) step, sae_dense.hip
+        const size_t rblk = (N + 63) / 64, cblk = ((size_t)d.d_sae + 63) / 64;
+        w.dense_colpart = take(rblk * (size_t)d.d_sae * 4);
+        w.dense_rowpart = take(rblk * cblk * 4);
+        w.dense_kpart = take((size_t)PV_SAE_DENSE_SPLITK * N * (size_t)d.d_in * 4);
+    }
     w.total = off + 256;
     return w;
 }
@@ -1183,6 +1190,7 @@ extern "C" size_t pv_debug_sae_ws_offset(const pv_sae_plan* plan, const char* na
     if (!strcmp(name, "fb_list")) return w.fb_list;
     if (!strcmp(name, "cand_cnt")) return w.cand_cnt;
     if (!strcmp(name, "thr")) return w.thr;
+    if (!strcmp(name, "hidden")) return w.hidden;
     return (size_t)-1;
 }
 
@@ -1235,14 +1243,11 @@ extern "C" int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t 
     return PV_OK;
 }
 
-// want_csr: also count the kept pairs per feature (ws.cnt) and record their positions (ws.wpos) for the backward
-static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
-                           int32_t* topk_idx, float* topk_val, bool want_csr, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
-    const pv_sae_desc& d = plan->d;
-    uint32_t* feat_cnt = want_csr ? (uint32_t*)(wsb + ws.cnt) : nullptr;
-    uint32_t* wpos = want_csr ? (uint32_t*)(wsb + ws.wpos) : nullptr;
-    const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
-    if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
+// ---- pieces of the step shared with the dense (ReLU + L1) step of sae_dense.hip --------------------------------------------
+// batch mean (given, or computed from x) -> ws.batch_mean; LN-in, sae_in, loss normaliser (+ the fp16 copy / row norms the
+// filtered encoder wants) -> ws.sae_in, ws.mu, ws.sd, ws.norm (ws.x16, ws.xnorm)
+int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
     float* bmean = (float*)(wsb + ws.batch_mean);
     if (batch_mean) {
         PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
@@ -1252,11 +1257,43 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
         hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
-    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, st->b_dec, bmean,
-                       (float*)(wsb + ws.sae_in), fast ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
-                       fast ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
+    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, (const float*)bmean,
+                       (float*)(wsb + ws.sae_in), want_filter_inputs ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
+                       want_filter_inputs ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
                        (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps);
     PV_LAUNCH_CHECK("sae_prep_kernel");
+    return PV_OK;
+}
+
+// gb_dec = colsum(dY) - W_enc @ gb_enc (the encoder-input path of b_dec): both terms as partial rows of one column sum
+int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
+              hipStream_t stream) {
+    const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+    float* colpart = (float*)(wsb + ws.colpart);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
+    hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                       colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                       nblk + ngb, d.d_in, 1.0f);
+    PV_LAUNCH_CHECK("sae bias-grad kernels");
+    return PV_OK;
+}
+
+// out[slot] (and out[slot2] when >= 0) = scale * sum(v[0..n)), one workgroup, fixed order
+void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v, out, n, scale, slot, slot2);
+}
+
+// want_csr: also count the kept pairs per feature (ws.cnt) and record their positions (ws.wpos) for the backward
+static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
+                           int32_t* topk_idx, float* topk_val, bool want_csr, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+    const pv_sae_desc& d = plan->d;
+    uint32_t* feat_cnt = want_csr ? (uint32_t*)(wsb + ws.cnt) : nullptr;
+    uint32_t* wpos = want_csr ? (uint32_t*)(wsb + ws.wpos) : nullptr;
+    const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
+    if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
+    int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream);
+    if (rcp) return rcp;
     // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
     ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
                    ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
@@ -1422,14 +1459,8 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
-        const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
-        float* colpart = (float*)(wsb + ws.colpart);
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, (const float*)dY, colpart, N, d.d_in);
-        hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
-                           colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
-                           nblk + ngb, d.d_in, 1.0f);
-        PV_LAUNCH_CHECK("sae bias-grad kernels");
+        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        if (rc) return rc;
     }
     return PV_OK;
 }

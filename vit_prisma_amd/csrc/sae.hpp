@@ -18,6 +18,7 @@ struct pv_sae_plan {
 
 struct SaeWs {
     size_t total;
+    size_t dense_colpart, dense_rowpart, dense_kpart;     // sae_dense.hip: column partials [N/64][d_sae], per-wave sums, split-K partials
     size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, wpos, long_list, n_long, seg_range, seg_rows, seg_b, pairs, colpart, colsum, batch_mean, sqpart, rowsq;
     // fast encoder (sae_enc.hip)
     size_t x16, xnorm, sample, thr, sq, band, cand_cnt, cand, fb_list, fb_count, wmax;
@@ -56,3 +57,11 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
 // else the rows row_list[0 .. *n_list) are walked by `slots` workgroups.
 void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
                    const uint32_t* n_list, int slots, uint32_t* feat_cnt, uint32_t* wpos, hipStream_t stream);
+
+// sae.hip, shared with sae_dense.hip: see the definitions
+int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
+              hipStream_t stream);
+void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream);
+constexpr int PV_SAE_DENSE_SPLITK = 4;       // K splits of the dense decoder GEMM (M = tokens, N = d_in: too few tiles otherwise)

@@ -1,0 +1,423 @@
+// Dense SAE train step for the activations that are NOT k-sparse: ReLU + L1 (gfx950; C ABI: pv_sae_dense_step).
+//
+// Reference semantics: StandardSparseAutoencoder.forward with activation_fn_str = "relu" (/root/reference/src/vit_prisma/
+// sae/sae.py:557-645: encode :557-581, decode :583-595, mse :144-149, L1 sparsity :617-626 with lp_norm = 1) and the body of
+// VisionSAETrainer.train_step between zero_grad and clip (sae/train_sae.py:328-392).  Every published CLIP SAE of the
+// reference is of this kind (docs/sae_table.md:9-36).  A token keeps hundreds to thousands of its d_sae features, so the
+// k-sparse machinery of sae.hip does not apply: the step is five dense GEMMs of 2 N d_in d_sae FLOP each.  They run on the
+// EXACT fp32 matrix instruction (v_mfma_f32_32x32x2_f32 == an fmaf chain per output: no reduced-precision operand, results
+// equal to the reference's fp32 matmuls up to summation order, measured <= 2e-6 relative), and everything elementwise rides
+// in their epilogues -- no [N, d_sae] tensor is read or written except f itself (once) and dH over it (in place):
+//
+//   prep      (sae.hip)  LN-in, sae_in = x_hat - b_dec, loss normaliser
+//   G1  f  = relu(sae_in W_enc + b_enc)                 epilogue: bias, ReLU, store f; per-64-row column counts of f > 0
+//                                                        (firing statistics, l0) and per-wave sums of f (the L1 term)
+//   G2  pre = f W_dec  (split-K: [tokens x d_in] is only 192 tiles)   -> partial sums
+//   finish    sae_out = (pre + b_dec) std + mu, err, mse partials, dY                  (one wave per token)
+//   G4  gW_dec   = f^T dY                               straight into the flat gradient buffer
+//   G3  dH = (dY W_dec^T + l1 / N) [f > 0]              epilogue: gate by the stored f, written OVER f; per-64-row column sums
+//                                                        (gb_enc)
+//   G5  gW_enc^T = dH^T sae_in                          straight into the flat gradient buffer (transposed encoder layout)
+//   gb_dec = colsum(dY) - W_enc gb_enc   (sae.hip)
+// then pv_sae_grad_sqnorm / pv_sae_apply (clip -> project -> Adam) as for the top-k step.
+//
+// Operand layouts: the fp32 matrix instruction takes ONE float per lane and operand, so a matrix can be fed from either of
+// its two row-major layouts without a transposed copy -- K-contiguous rows ([rows][K]: one 16-byte LDS read = four k-steps) or
+// row-contiguous k-slices ([K][rows]: four 4-byte LDS reads, lanes on consecutive rows).  f^T, dH^T, dY and sae_in of G4 / G5
+// are therefore the buffers as they lie, read "the other way".
+#include "sae.hpp"
+
+namespace {
+
+constexpr int DG_BM = 128, DG_BN = 128;
+constexpr int DG_KSLAB = 32;                  // floats of K per stage
+constexpr int DG_ROWB = 144;                  // K-contiguous tile: 128 rows x (128 + 16 pad) bytes
+constexpr int DG_KROW = 528;                  // row-contiguous tile: 32 k-rows x (512 + 16 pad) bytes
+constexpr int DG_TILE = DG_BM * DG_ROWB;      // 18432 >= 32 * 528
+constexpr int DG_CS_LD = 68;                  // fp32 staging row of the epilogue (floats)
+constexpr int DG_LDS = 4 * DG_TILE;           // As[2] + Bs[2] = 73728 >= 4 waves x 64 x 68 x 4
+
+enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2 };
+
+struct DenseGemm {
+    const float* A; int64_t lda;              // A_KM ? [K][lda] (M contiguous) : [M][lda] (K contiguous)
+    const float* B; int64_t ldb;              // B_KN ? [K][ldb] (N contiguous) : [N][ldb] (K contiguous)
+    int M, N, K;
+    int k_chunk;                              // K range of one blockIdx.y (multiple of 32; K when not split)
+    float* out; int64_t ldo;                  // STORE: out + blockIdx.y * out_zstride
+    int64_t out_zstride;
+    const float* bias;                        // ENC: b_enc [N]
+    float* colpart;                           // ENC / DH: [ceil(M / 64)][N] column partials of the wave's 64-row block
+    float* rowpart;                           // ENC: [ceil(M / 64)][ceil(N / 64)] sums of f over the wave's 64 x 64 block
+    float add;                                // DH: l1_coefficient / N_global
+};
+
+// 16 bytes from global memory, or zeros (a plain branch: `ok ? *p : zero` makes hipcc select between two ADDRESSES and park the
+// staging registers in scratch)
+__device__ __forceinline__ uint4 ld16_or_zero(const float* ptr, bool ok) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = *reinterpret_cast<const uint4*>(ptr);
+    return v;
+}
+
+template <bool A_KM, bool B_KN, int EPI>
+__global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * DG_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware bijective remap (block b runs on XCD b % 8): each XCD gets a contiguous run of tiles, N fastest
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int ntn = (p.N + DG_BN - 1) / DG_BN;
+    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
+    const int m0 = tile_m * DG_BM, n0 = tile_n * DG_BN;
+    const int k_begin = blockIdx.y * p.k_chunk, k_end = min(p.K, k_begin + p.k_chunk);
+    const int nk = (k_end - k_begin + DG_KSLAB - 1) / DG_KSLAB;
+
+    uint4 ra[4], rb[4];
+    auto load_slab = [&](int kt) {
+        const int kb = k_begin + kt * DG_KSLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if constexpr (A_KM) {                      // chunk c -> k row c >> 5, 4-float group c & 31 of the 128 rows
+                const int k = kb + (c >> 5), mm = m0 + (c & 31) * 4;
+                ra[i] = ld16_or_zero(p.A + (int64_t)k * p.lda + mm, k < k_end && mm < p.M);
+            } else {                                   // chunk c -> row c >> 3, 4-float k group c & 7
+                const int mm = m0 + (c >> 3), k = kb + (c & 7) * 4;
+                ra[i] = ld16_or_zero(p.A + (int64_t)mm * p.lda + k, mm < p.M && k < k_end);
+            }
+            if constexpr (B_KN) {
+                const int k = kb + (c >> 5), nn = n0 + (c & 31) * 4;
+                rb[i] = ld16_or_zero(p.B + (int64_t)k * p.ldb + nn, k < k_end && nn < p.N);
+            } else {
+                const int nn = n0 + (c >> 3), k = kb + (c & 7) * 4;
+                rb[i] = ld16_or_zero(p.B + (int64_t)nn * p.ldb + k, nn < p.N && k < k_end);
+            }
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if constexpr (A_KM) *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = ra[i];
+            else *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = ra[i];
+            if constexpr (B_KN) *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = rb[i];
+            else *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int l31 = lane & 31, half = lane >> 5;
+    if (nk > 0) {
+        load_slab(0);
+        store_slab(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_slab(kt + 1);
+        const unsigned char* Ab = As + buf * DG_TILE;
+        const unsigned char* Bb = Bs + buf * DG_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // MFMA step (j, e) consumes k = 8 j + 4 half + e of the slab on BOTH operands
+            float af[2][4], bf[2][4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                if constexpr (A_KM) {
+                    const float* ak = reinterpret_cast<const float*>(Ab + (8 * j + 4 * half) * DG_KROW) + wm * 64 + mi * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[mi][e] = ak[e * (DG_KROW / 4)];
+                } else {
+                    const float4 a = *reinterpret_cast<const float4*>(Ab + (wm * 64 + mi * 32 + l31) * DG_ROWB + half * 16 + j * 32);
+                    af[mi][0] = a.x; af[mi][1] = a.y; af[mi][2] = a.z; af[mi][3] = a.w;
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if constexpr (B_KN) {
+                    const float* bk = reinterpret_cast<const float*>(Bb + (8 * j + 4 * half) * DG_KROW) + wn * 64 + ni * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bf[ni][e] = bk[e * (DG_KROW / 4)];
+                } else {
+                    const float4 b = *reinterpret_cast<const float4*>(Bb + (wn * 64 + ni * 32 + l31) * DG_ROWB + half * 16 + j * 32);
+                    bf[ni][0] = b.x; bf[ni][1] = b.y; bf[ni][2] = b.z; bf[ni][3] = b.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS block (the operand buffers are free: barrier above) -> a lane owns 8
+    // consecutive columns of a row, 8 rows of the wave's 64 x 64 block
+    float* Cs = reinterpret_cast<float*>(smem) + wave * (64 * DG_CS_LD);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                Cs[row * DG_CS_LD + ni * 32 + l31] = acc[mi][ni][e];
+            }
+    __builtin_amdgcn_wave_barrier();                      // (wave-private block; a wave's LDS operations execute in order)
+    const int cc = (lane & 7) * 8;
+    const int gn = n0 + wn * 64 + cc;
+    const bool col_ok = gn < p.N;                          // N % 8 == 0 is required by the launcher: a chunk is all or nothing
+    float csum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) csum[i] = 0.f;
+    float rsum = 0.f;
+    float b8[8];
+    if constexpr (EPI == DG_EPI_ENC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b8[i] = 0.f;
+        if (col_ok) load8(p.bias + gn, b8);
+    }
+    float* outz = p.out + (int64_t)blockIdx.y * p.out_zstride;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int gm = m0 + wm * 64 + row;
+        if (gm < p.M && col_ok) {
+            float v[8];
+            const float4 x0 = *reinterpret_cast<const float4*>(Cs + row * DG_CS_LD + cc);
+            const float4 x1 = *reinterpret_cast<const float4*>(Cs + row * DG_CS_LD + cc + 4);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            float* o = outz + (int64_t)gm * p.ldo + gn;
+            if constexpr (EPI == DG_EPI_ENC) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = fmaxf(v[i] + b8[i], 0.f);                   // hidden_pre + b_enc -> ReLU (sae.py:567-577)
+                    csum[i] += v[i] > 0.f ? 1.f : 0.f;                // firing counts (train_sae.py:356-364)
+                    rsum += v[i];                                     // ||f||_1 (sae.py:617)
+                }
+            } else if constexpr (EPI == DG_EPI_DH) {
+                float f8[8];
+                load8(o, f8);                                          // the stored activation: the ReLU gate of the backward
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = f8[i] > 0.f ? v[i] + p.add : 0.f;           // d loss / d hidden_pre = (dF + l1 / N) [f > 0]
+                    csum[i] += v[i];                                  // gb_enc
+                }
+            }
+            store8(o, v);
+        }
+    }
+    if constexpr (EPI != DG_EPI_STORE) {
+        // the wave's 64 rows of each column: lanes with equal (lane & 7) hold the same 8 columns
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            csum[i] += __shfl_xor(csum[i], 8, 64);
+            csum[i] += __shfl_xor(csum[i], 16, 64);
+            csum[i] += __shfl_xor(csum[i], 32, 64);
+        }
+        const int rblk = tile_m * 2 + wm;
+        if (lane < 8 && col_ok && m0 + wm * 64 < p.M) store8(p.colpart + (int64_t)rblk * p.N + gn, csum);
+        if constexpr (EPI == DG_EPI_ENC) {
+            rsum = wave_sum(rsum);
+            const int ncb = (p.N + 63) / 64;
+            if (lane == 0 && m0 + wm * 64 < p.M && n0 + wn * 64 < p.N) p.rowpart[(int64_t)rblk * ncb + tile_n * 2 + wn] = rsum;
+        }
+    }
+}
+
+template <bool A_KM, bool B_KN, int EPI>
+int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gemm_kernel<A_KM, B_KN, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
+        if (e != hipSuccess) {
+            pv_set_error(std::string("hipFuncSetAttribute(dense_gemm_kernel): ") + hipGetErrorString(e));
+            return PV_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    const int ntm = (p.M + DG_BM - 1) / DG_BM, ntn = (p.N + DG_BN - 1) / DG_BN;
+    hipLaunchKernelGGL((dense_gemm_kernel<A_KM, B_KN, EPI>), dim3(ntm * ntn, splits), dim3(256), DG_LDS, stream, p);
+    PV_LAUNCH_CHECK("dense_gemm_kernel");
+    return PV_OK;
+}
+
+// column partials [nblk][d] -> out[j] (+ firing statistics, + per-workgroup totals for l0)
+__global__ __launch_bounds__(256) void dense_colreduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ out,
+                                                              float* __restrict__ out2, float* __restrict__ act_freq,
+                                                              float* __restrict__ n_since_fired, int update_stats,
+                                                              float* __restrict__ block_tot) {
+    __shared__ float red[4];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (j < d) {
+        for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * d + j];        // fixed order; coalesced across the workgroup
+        out[j] = s;
+        if (out2) out2[j] = s;
+        if (update_stats) {                                                  // train_sae.py:356-361
+            act_freq[j] += s;
+            n_since_fired[j] = s > 0.f ? 0.f : n_since_fired[j] + 1.f;
+        }
+    }
+    if (block_tot) {
+        float t = wave_sum(s);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) red[wv] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) block_tot[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// decoder output from the split-K partial sums: LN-out (sae.py:89-90), mse partial (sae.py:144-149), dY.  One wave per token.
+__global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restrict__ x, const float* __restrict__ kpart, int splits,
+                                                           int64_t zstride, const float* __restrict__ b_dec, const float* __restrict__ mu,
+                                                           const float* __restrict__ sd, const float* __restrict__ norm,
+                                                           float* __restrict__ sae_out, float* __restrict__ dY,
+                                                           float* __restrict__ loss_partial, int n_tok, int d, float grad_scale) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    const float m = mu[n], sdv = sd[n], nf = norm[n];
+    float lsum = 0.f;
+    for (int c = 4 * lane; c < d; c += 256) {
+        float4 a = *reinterpret_cast<const float4*>(kpart + (int64_t)n * d + c);
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(kpart + z * zstride + (int64_t)n * d + c);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const float4 bd = *reinterpret_cast<const float4*>(b_dec + c);
+        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c);
+        float4 o, e, g;
+        o.x = (a.x + bd.x) * sdv + m; o.y = (a.y + bd.y) * sdv + m; o.z = (a.z + bd.z) * sdv + m; o.w = (a.w + bd.w) * sdv + m;
+        e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
+        if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + c) = o;
+        lsum += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;
+        g.x = grad_scale * e.x / nf * sdv; g.y = grad_scale * e.y / nf * sdv;
+        g.z = grad_scale * e.z / nf * sdv; g.w = grad_scale * e.w / nf * sdv;
+        *reinterpret_cast<float4*>(dY + (int64_t)n * d + c) = g;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) loss_partial[n] = lsum;
+}
+
+// scalars[0] = mse + l1 (sae.py:628), one thread
+__global__ void dense_loss_kernel(float* __restrict__ scalars) { scalars[0] = scalars[1] + scalars[4]; }
+
+}  // namespace
+
+// One train step of the ReLU + L1 SAE on N tokens: forward + backward + statistics; gradients are WRITTEN into st->g*
+// (complete buffers: pv_sae_grad_sqnorm and pv_sae_apply follow as usual).  scalars: 0 loss, 1 mse_loss, 2 l0, 4 l1_loss.
+extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                                 int32_t n_global, int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    PV_REQUIRE(plan && st && x && out && workspace, "null argument");
+    PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
+    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_encT, "the transposed encoder copy (pv_sae_state.W_encT) is required");
+    PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
+    PV_REQUIRE(d.d_in % 8 == 0 && d.d_sae % 8 == 0, "the dense step needs d_in and d_sae to be multiples of 8");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    plan->live_offs = nullptr;
+    plan->renorm_pending = false;
+    const int F = d.d_sae, D = d.d_in;
+
+    // set_decoder_norm_to_unit_norm (train_sae.py:307): the dense GEMMs read W_dec as it lies, so the rows are rewritten here
+    if (flags & PV_SAE_RENORM_DECODER) {
+        int rc = pv_sae_renorm_decoder(plan, st, stream_);
+        if (rc) return rc;
+    }
+    int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, false, wsb, ws, stream);
+    if (rc) return rc;
+    float* f = (float*)(wsb + ws.hidden);                  // [N][F]: f, later dH
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    float* dY = (float*)(wsb + ws.dY);
+    float* colpart = (float*)(wsb + ws.dense_colpart);
+    float* rowpart = (float*)(wsb + ws.dense_rowpart);
+    float* kpart = (float*)(wsb + ws.dense_kpart);
+    const int rblk = (N + 63) / 64, cblk = (F + 63) / 64;
+    const int nb_f = (F + 255) / 256;
+    float* blk_tot = (float*)(wsb + ws.sqpart);            // 1024 floats of scratch (nb_f <= 256)
+    {
+        ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + (double)N * F) * 4.0);
+        // G1: f = relu(sae_in @ W_enc + b_enc)
+        DenseGemm g = {};
+        g.A = sae_in; g.lda = D; g.B = st->W_enc; g.ldb = F; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
+        g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart;
+        rc = launch_dense_gemm<false, true, DG_EPI_ENC>(g, 1, stream);
+        if (rc) return rc;
+        // firing counts, statistics, l0, l1
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
+                           out->fire_count ? out->fire_count : (float*)(wsb + ws.rowsq), (float*)nullptr, st->act_freq_scores,
+                           st->n_fwd_since_fired, update_stats, blk_tot);
+        PV_LAUNCH_CHECK("dense_colreduce_kernel");
+        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream);                       // l0 (train_sae.py:364)
+        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)n_global, 4, -1, stream);  // l1_loss (sae.py:617-626)
+    }
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * N * (double)D * F, 0.0);
+        // G2: pre = f @ W_dec, split over K
+        const int S = PV_SAE_DENSE_SPLITK;
+        DenseGemm g = {};
+        g.A = f; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = N; g.N = D; g.K = F;
+        g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
+        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)N * D;
+        rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
+        if (rc) return rc;
+        const float grad_scale = 2.0f / ((float)n_global * (float)D);
+        hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, (const float*)kpart, S, (int64_t)N * D,
+                           (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
+                           (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D, grad_scale);
+        PV_LAUNCH_CHECK("dense_finish_kernel");
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream);
+        hipLaunchKernelGGL(dense_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
+        // G4: gW_dec = f^T @ dY
+        DenseGemm g4 = {};
+        g4.A = f; g4.lda = F; g4.B = dY; g4.ldb = D; g4.M = F; g4.N = D; g4.K = N; g4.k_chunk = N;
+        g4.out = st->gW_dec; g4.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
+        if (rc) return rc;
+        // G3: dH = (dY @ W_dec^T + l1 / N) [f > 0], over f
+        DenseGemm g3 = {};
+        g3.A = dY; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
+        g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global;
+        rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, st->gb_enc,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+        PV_LAUNCH_CHECK("dense_colreduce_kernel");
+        // G5: gW_enc^T = dH^T @ sae_in
+        DenseGemm g5 = {};
+        g5.A = f; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
+        g5.out = st->gW_enc; g5.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
+        if (rc) return rc;
+        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        if (rc) return rc;
+    }
+    return PV_OK;
+}

@@ -3,8 +3,10 @@
 Step-only measurement: batches are pre-staged in HBM (``randn(4096, 768) * 3 + per-dim offset``), a
 step is the full reference ``train_step`` (renorm decoder -> forward -> stats -> backward -> clip ->
 project -> Adam), fp32 master weights, d_in = 768, d_sae = 24576 (32x), top-k = 32.
-With a process group the GLOBAL batch stays 4096 tokens (strong scaling): each rank takes 4096 / W
-tokens and 1 / W of the optimizer (sae/trainer.py: reduce-scatter of gradient rows, all-gather of parameters).
+With a process group the GLOBAL batch stays 4096 tokens (strong scaling).  Default mode: feature parallel (each rank owns
+d_sae / W features for good and sees all 4096 tokens; token-sized collectives only -- sae/feature_parallel.py);
+``mode="data"``: each rank takes 4096 / W tokens and 1 / W of the optimizer (sae/trainer.py: reduce-scatter of gradient
+rows, all-gather of parameters).  ``weak=True``: 4096 tokens PER RANK (global batch 4096 W), the data-parallel mode.
 """
 from __future__ import annotations
 
@@ -45,39 +47,44 @@ def _pmc_step_traffic() -> dict:
     return {"traffic": None}
 
 
-def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, feature_parallel: bool = False) -> dict:
+def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, feature_parallel: bool = True,
+                  weak: bool = False, activation: str = "topk") -> dict:
     """Step-only: ``VisionSAETrainer.train_step`` (the reference's call, train_sae.py:278-411) on batches resident in HBM.
-    With a process group every rank takes 4096 / W tokens of the same global batch and the trainer's sharded-optimizer
-    step runs (reduce-scatter of gradient rows, local clip / project / Adam on 1 / W of the features, asynchronous
-    all-gather of the parameters); feature_parallel: the feature-sharded step of sae/feature_parallel.py instead (tokens
-    all-gathered, candidates all-gathered, partial reconstructions all-reduced; no gradient or parameter traffic)."""
+    With a process group: feature_parallel (default) = the feature-sharded step of sae/feature_parallel.py (tokens / candidates
+    all-gathered, partial reconstructions all-reduced; no gradient or parameter traffic); otherwise every rank takes 4096 / W
+    tokens of the same global batch and the trainer's sharded-optimizer step runs (reduce-scatter of gradient rows, local
+    clip / project / Adam on 1 / W of the features, asynchronous all-gather of the parameters).  weak: 4096 tokens per rank
+    (data parallel).  activation "relu": the ReLU + L1 SAE on the dense fused step (l1_coefficient 8e-5) instead of top-k."""
     from .config import VisionModelSAERunnerConfig
     from .sae import StandardSparseAutoencoder
     from .trainer import VisionSAETrainer
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    n_local = N_TOKENS // world
+    relu = activation == "relu"
+    feature_parallel = bool(feature_parallel) and world > 1 and not weak and not relu
+    n_global = N_TOKENS * world if weak else N_TOKENS
+    n_local = N_TOKENS if weak else N_TOKENS // world
     cfg = VisionModelSAERunnerConfig(
         hook_point_layer=6, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
-        activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, normalize_activations="layer_norm",
-        initialization_method="independent", b_dec_init_method="mean", train_batch_size=N_TOKENS, lr=1e-3,
+        activation_fn_str="relu" if relu else "topk", activation_fn_kwargs={} if relu else {"k": TOPK},
+        normalize_activations="layer_norm", l1_coefficient=8e-5,
+        initialization_method="independent", b_dec_init_method="mean", train_batch_size=n_global, lr=1e-3,
         max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0)
     sae = StandardSparseAutoencoder(cfg)
     with torch.no_grad():
         for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
             getattr(sae, n).copy_(torch.from_numpy(v))
     tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True)
-    feature_parallel = bool(feature_parallel) and world > 1
     tr.use_feature_parallel(feature_parallel)
     st = list(tr.initialize_training_variables())                 # act_freq, n_since_fired, n_frac, optimizer, scheduler
-    batches = [torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=i)).to(dev)[rank * n_local:(rank + 1) * n_local][:, None, :].contiguous()
+    batches = [torch.from_numpy(synth_sae_batch(n_global, D_IN, seed=i)).to(dev)[rank * n_local:(rank + 1) * n_local][:, None, :].contiguous()
                for i in range(4)]
     n_done = [0]
 
     def step(x: torch.Tensor) -> None:
         _, _, _, _, st[0], st[1], st[2] = tr.train_step(
             sparse_autoencoder=sae, optimizer=st[3], scheduler=st[4], act_freq_scores=st[0], n_forward_passes_since_fired=st[1],
-            n_frac_active_tokens=st[2], layer_acts=x, n_training_steps=n_done[0], n_training_tokens=n_done[0] * N_TOKENS)
+            n_frac_active_tokens=st[2], layer_acts=x, n_training_steps=n_done[0], n_training_tokens=n_done[0] * n_global)
         n_done[0] += 1
 
     for i in range(warmup):
@@ -109,14 +116,32 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     bwd = N.prof_read("sae_backward")
     app = N.prof_read("sae_apply")
     ms_step = elapsed / steps * 1e3
+    if relu:
+        # dense step: five fp32 MFMA GEMMs of 2 N d_in d_sae FLOP each (sae_dense.hip); bound by the fp32 matrix peak
+        flops = 10.0 * n_local * D_IN * D_SAE
+        tf = flops / (ms_step * 1e-3) / 1e12
+        return {
+            "metric": "SAE train-step tokens/sec, ReLU + L1 SAE (dense fused step, batches resident in HBM)",
+            "value": round(n_global * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_step, 3), "dtype": "f32",
+            "config": {"workload": f"ReLU + L1 SAE 768 -> 24576 (32x), l1_coefficient 8e-5, {n_global} tokens per step, Adam, clip 1.0",
+                       "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs with fused ReLU / L1 / loss / gate epilogues"},
+            "final_loss": loss, "l0": float(eng.scalars[2].item()),
+            "roofline": {"kernel": "whole step vs 10 N d_in d_sae FLOP (five dense fp32 GEMMs)", "bound": "mfma", "achieved": round(tf, 1),
+                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_TFLOPS, 4)},
+            "kernels": {"encoder_gemm": {"avg_us": round(enc["ms"] * 1e3 / max(enc["launches"], 1), 1)},
+                        "decoder_and_backward_gemms": {"avg_us": round(bwd["ms"] * 1e3 / max(bwd["launches"], 1), 1)},
+                        "clip_project_adam": {"avg_us": round(app["ms"] * 1e3 / max(app["launches"], 1), 1)}},
+        }
     # algorithmic HBM bytes of one step, SURVEY.md 8(d): Adam 7 x 151.1 MB = 1.06 GB + W_enc / W_dec reads for forward and
-    # backward 0.30 GB + x / out 25 MB ~ 1.4 GB (the figure the roofline fraction is quoted against)
+    # backward 0.30 GB + x / out 25 MB ~ 1.4 GB (the figure the roofline fraction is quoted against).  NOMINAL: the same
+    # single-process figure whatever the world size (a rank of W moves about 1 / W of it plus the collectives' bytes)
     alg_bytes = 1.4e9
     res = {
         "metric": "SAE train-step tokens/sec (step-only, batches resident in HBM)",
-        "value": round(N_TOKENS * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(ms_step, 3), "scaling": "strong" if world > 1 else "n/a", "dtype": "f32",
-        "config": {"workload": f"top-k SAE 768 -> 24576 (32x), k=32, global batch {N_TOKENS} tokens, Adam, clip 1.0",
+        "value": round(n_global * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_step, 3), "scaling": ("weak" if weak else "strong") if world > 1 else "n/a", "dtype": "f32",
+        "config": {"workload": f"top-k SAE 768 -> 24576 (32x), k=32, global batch {n_global} tokens, Adam, clip 1.0",
                    "tokens_per_gpu_per_step": n_local,
                    "parallelism": "single process" if world == 1 else
                    (f"tp{world}: features sharded for good, tokens / candidates all-gathered, partial reconstructions all-reduced"
@@ -126,7 +151,9 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
         "final_loss": loss,
         "roofline": {"kernel": "whole step (every kernel of one train step) vs the 1.4 GB of algorithmic HBM bytes per step of SURVEY.md 8(d)",
                      "bound": "hbm", "achieved": round(alg_bytes / (ms_step * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), **_pmc_step_traffic()},
+                     "frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                     "bytes_model": "nominal: the single-process 1.4 GB per 4096-token step at every world size",
+                     **(_pmc_step_traffic() if world == 1 else {"traffic": None})},
         "kernels": {
             "encode_topk": {"avg_us": round(enc["ms"] * 1e3 / max(enc["launches"], 1), 1),
                             "algorithmic_TFLOPs": round(enc["flops"] / max(enc["ms"], 1e-9) / 1e9, 1),
@@ -153,7 +180,7 @@ class _ResidentImages(torch.utils.data.Dataset):
         return self.x[i], 0
 
 
-def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: int = 64) -> dict:
+def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: int = 64, feature_parallel: bool = True) -> dict:
     """Config 3, second number: the training loop the reference runs -- VisionActivationsStore
     harvesting ``blocks.6.hook_resid_post`` from randn images through ViT blocks 0..6 (native run_with_cache,
     names_filter + stop_at_layer), half-buffer shuffle-mix, VisionSAETrainer.train_step on the fused native step.
@@ -184,7 +211,7 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
     # every rank holds the same index space; the store's DistributedSampler hands each rank 4 store batches per epoch
     data = _ResidentImages(4 * store_bs * world, dev, torch.bfloat16, seed=77)
     sae = StandardSparseAutoencoder(cfg)
-    tr = VisionSAETrainer(cfg, model=model, dataset=data, sparse_coder=sae)
+    tr = VisionSAETrainer(cfg, model=model, dataset=data, sparse_coder=sae).use_feature_parallel(bool(feature_parallel))
     act, since, frac, opt, sched = tr.initialize_training_variables()
     tr.initialize_geometric_medians()
     store = tr.activations_store
@@ -225,7 +252,10 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
         "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "bf16 ViT / f32 SAE",
         "config": {"workload": f"VisionSAETrainer loop: store_batch_size {store_bs} x n_batches_in_buffer {n_buf}, "
                                f"global train batch {N_TOKENS} tokens, hook blocks.6.hook_resid_post, images resident in HBM",
-                   "tokens_per_gpu_per_step": N_TOKENS // world},
+                   "tokens_per_gpu_per_step": N_TOKENS // world,
+                   "parallelism": "single process" if world == 1 else
+                   ("images sharded for the harvest, features sharded for the step (tokens all-gathered)" if feature_parallel
+                    else "images and tokens sharded, optimizer sharded by feature")},
         "flop_per_token": {"harvest": 104.8e6, "sae_step": 37.95e6}, "warmup": warmup,
         "harvested_tokens_per_trained_token": round((store.n_tokens_harvested - harvested0) / max(tokens, 1), 3),
     }

@@ -98,7 +98,7 @@ class FeatureParallelSAE:
         """-> this rank's candidates [2, n, k] int32 (values as float bits | local feature indices): what is all-gathered."""
         eng = self.engine
         n = self._n = x.shape[0]
-        eng.encode_topk(x)                                          # (lands in self.pack: tp_bind)
+        eng.encode_topk(x, want_ln_stats=False)                     # (lands in self.pack: tp_bind)
         return self.pack if n == eng.max_tokens else self.pack[:, :n].contiguous()
 
     def phase_partial(self, gathered: torch.Tensor) -> torch.Tensor:

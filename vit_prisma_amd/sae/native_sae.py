@@ -192,6 +192,27 @@ class NativeSAE:
         self._grad_fresh = True
         self._grad_sparse = bool(sparse_grads)
 
+    def dense_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
+                   n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
+                   renorm_decoder: bool = True) -> None:
+        """The ReLU + L1 step (pv_sae_dense_step): forward + backward + statistics on dense fp32 MFMA GEMMs with fused
+        epilogues; gradients are written into ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss.  The engine's
+        ``k`` plays no role."""
+        x = self._check_x(x)
+        n = x.shape[0]
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
+                       scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
+        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        N.check(self.lib.pv_sae_dense_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                           int(n_global if n_global is not None else n),
+                                           int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient),
+                                           C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
+                "pv_sae_dense_step")
+        self._inv_norm_key = None
+        self._grad_fresh = False
+        self._grad_sparse = False
+
     def _no_pending_sparse(self, what: str) -> None:
         if getattr(self, "_grad_sparse", False) and self._grad_fresh:
             raise RuntimeError(f"{what} between a sparse_grads step and its apply(): the step's workspace (the list of live "
@@ -229,17 +250,21 @@ class NativeSAE:
         full = j_lo == 0 and (j_hi is None or j_hi == self.d_sae)
         self._inv_norm_key = self._w_dec_key() if full else None
 
-    def encode_topk(self, x: torch.Tensor):
-        """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts."""
+    def encode_topk(self, x: torch.Tensor, want_ln_stats: bool = True):
+        """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts.  want_ln_stats=False: no copies
+        of the LayerNorm statistics out of the workspace (mu, std are None)."""
         self._no_pending_sparse("encode_topk")
         x = self._check_x(x)
         self._ensure_shadows()
         n = x.shape[0]
         st = self._state()
-        mu = torch.empty(n, dtype=torch.float32, device=self.device)
-        sd = torch.empty(n, dtype=torch.float32, device=self.device)
+        mu = sd = None
+        if want_ln_stats:
+            mu = torch.empty(n, dtype=torch.float32, device=self.device)
+            sd = torch.empty(n, dtype=torch.float32, device=self.device)
         N.check(self.lib.pv_sae_encode_topk(self._plan, C.byref(st), x.data_ptr(), n, self.topk_idx.data_ptr(),
-                                            self.topk_val.data_ptr(), mu.data_ptr(), sd.data_ptr(),
+                                            self.topk_val.data_ptr(), mu.data_ptr() if want_ln_stats else None,
+                                            sd.data_ptr() if want_ln_stats else None,
                                             self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
                 "pv_sae_encode_topk")
         return self.topk_idx[:n], self.topk_val[:n], mu, sd

@@ -6,10 +6,11 @@ eval_dataset=None)``, ``train_step`` argument names and 7-tuple, ``run() -> sae`
 operations inside a step is the reference's (:278-411): renorm decoder -> zero_grad -> forward ->
 firing statistics -> backward -> clip_grad_norm_ -> remove parallel gradient -> Adam -> scheduler.
 
-On an MI355X (fp32 top-k standard SAE with layer_norm / no input normalisation, no ghost grads) the
-step runs on ``NativeSAE`` (HIP kernels) directly on the module's parameter storage; Adam moments live
-in the engine.  Everything else (ReLU+L1, gated, ghost grads, CPU) takes the PyTorch path below, which
-is the reference algorithm verbatim.
+On an MI355X (fp32 standard SAE with layer_norm / no input normalisation, no ghost grads) the step runs on
+``NativeSAE`` (HIP kernels) directly on the module's parameter storage -- the k-sparse step for top-k, the
+dense fused step (exact fp32 MFMA GEMMs with ReLU / L1 / loss / gate epilogues) for ReLU + L1; Adam moments
+live in the engine.  Everything else (gated, transcoder, ghost grads, tanh-relu, CPU) takes the PyTorch path
+below, which is the reference algorithm verbatim.
 
 Data parallel (new functionality, SURVEY.md section 8e -- the reference is single-process): one process
 per GPU, each with its share of the global token batch and a 1/W shard of the OPTIMIZER, by feature
@@ -85,7 +86,8 @@ class VisionSAETrainer:
         self._pending = []                                  # in-flight parameter all-gathers of the sharded optimizer
         self._small = None
         self.rank, self.world = _dist_info()
-        self._feature_parallel = False                      # multi-rank native step: False = data parallel, True = feature parallel
+        self._feature_parallel: Optional[bool] = None       # multi-rank native top-k step: None = auto (feature parallel when d_sae
+                                                            # divides by the world size), True / False = forced
         self._fp = None                                     # FeatureParallelSAE (this rank's shard engine + choreography)
         self._fp_dirty = False                              # the module's parameters lag behind the shards
 
@@ -94,12 +96,24 @@ class VisionSAETrainer:
         self._native_pref = flag
         return self
 
-    def use_feature_parallel(self, flag: bool = True) -> "VisionSAETrainer":
-        """Multi-rank native steps shard the FEATURES (sae/feature_parallel.py: token-sized collectives, no gradient or
-        parameter traffic) instead of the tokens.  The module's own parameters are then refreshed only by
-        ``sync_parameters()`` (``checkpoint`` and the end of ``run`` call it).  New functionality; default off."""
-        self._feature_parallel = bool(flag)
+    def use_feature_parallel(self, flag: Optional[bool] = True) -> "VisionSAETrainer":
+        """How multi-rank native top-k steps are sharded.  True: by FEATURE (sae/feature_parallel.py: every rank keeps
+        d_sae / world features and their optimizer state for good, sees the whole token batch, and only token-sized
+        collectives cross the links); False: by token, with the optimizer sharded by feature (reduce-scatter of the gradient
+        rows, all-gather of the updated parameter rows: 302 MB per 4096-token step at 768 -> 24576); None (default): feature
+        parallel whenever d_sae is divisible by the world size -- by the measured per-rank phase times it is the faster of
+        the two at every world size for the reference's 4096-token batch.  In the feature-parallel mode
+        the module's own parameters are refreshed only by ``sync_parameters()`` (``checkpoint`` and the end of ``run`` call
+        it).  New functionality (the reference is single-process)."""
+        self._feature_parallel = None if flag is None else bool(flag)
         return self
+
+    def _use_tp(self, sae) -> bool:
+        if self.world <= 1 or self._feature_parallel is False:
+            return False
+        if self._feature_parallel is None:
+            return int(sae.cfg.d_sae) % self.world == 0
+        return True
 
     # ---- bookkeeping ------------------------------------------------------------------------------
     def get_checkpoint_thresholds(self) -> List[int]:
@@ -155,15 +169,25 @@ class VisionSAETrainer:
         return medians
 
     # ---- native engine ----------------------------------------------------------------------------
-    def _native_ok(self, sae, x: torch.Tensor) -> bool:
+    def _native_kind(self, sae, x: torch.Tensor) -> Optional[str]:
+        """Which fused HIP step serves this SAE: "topk" (k-sparse step, sae.hip), "relu" (dense ReLU + L1 step,
+        sae_dense.hip) or None (PyTorch path: gated / transcoder / ghost gradients / other activations / CPU)."""
         cfg = sae.cfg
-        return (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.activation_fn_str == "topk"
-                and cfg.dtype == torch.float32 and not cfg.use_ghost_grads
-                and cfg.normalize_activations in ("layer_norm", "none", None)
-                and all(p.is_cuda and p.dtype == torch.float32 for p in sae.parameters())
-                and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
-                and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
-                and self._native_pref is not False)
+        common = (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.dtype == torch.float32 and not cfg.use_ghost_grads
+                  and cfg.normalize_activations in ("layer_norm", "none", None)
+                  and all(p.is_cuda and p.dtype == torch.float32 for p in sae.parameters())
+                  and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
+                  and self._native_pref is not False)
+        if not common:
+            return None
+        if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64:
+            return "topk"
+        if cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0:
+            return "relu"
+        return None
+
+    def _native_ok(self, sae, x: torch.Tensor) -> bool:
+        return self._native_kind(sae, x) is not None
 
     def _get_engine(self, sae, n_tokens: int):
         from .native_sae import NativeSAE
@@ -181,7 +205,8 @@ class VisionSAETrainer:
                     dist.broadcast(p.data, src=0)
             old = eng
             eng = NativeSAE(sae.W_enc, sae.W_dec, sae.b_enc, sae.b_dec,
-                            k=sae.cfg.activation_fn_kwargs["k"], layer_norm=sae.cfg.normalize_activations == "layer_norm",
+                            k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
+                            layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world))
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
                 eng.flat_m.copy_(old.flat_m)
@@ -274,7 +299,9 @@ class VisionSAETrainer:
 
     def _native_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
         lr = optimizer.param_groups[0]["lr"]
-        if self.world > 1 and self._feature_parallel:
+        if self._native_kind(sae, x) == "relu":
+            return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
+        if self._use_tp(sae):
             return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         self._dp_flush()                                        # parameters of the previous step must have landed
         eng = self._get_engine(sae, x.shape[0])
@@ -293,6 +320,45 @@ class VisionSAETrainer:
         scheduler.step()
         sc = eng.scalars.clone()
         return sc[0], sc[1], None, sc[2]
+
+    def _native_dense_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired):
+        """ReLU + L1 (sae.py:617-626) on the dense fused step (pv_sae_dense_step).  Multi-rank: tokens sharded, ONE all-reduce
+        of the flat gradient buffer and a replicated optimizer (the step is ~6 ms of fp32 GEMMs: the 151 MB are not what
+        bounds it), statistics and losses over the global batch like every other path."""
+        self._dp_flush()
+        eng = self._get_engine(sae, x.shape[0])
+        eng.act_freq_scores = act_freq_scores
+        eng.n_fwd_since_fired = n_since_fired
+        l1 = float(sae.l1_coefficient)
+        if self.world == 1:
+            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True)
+        else:
+            import torch.distributed as dist
+            W = self.world
+            n_global = x.shape[0] * W
+            bm = x.float().sum(dim=0)
+            dist.all_reduce(bm)                                 # global batch mean (sae.py:145)
+            eng.dense_step(x, l1, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
+            d_sae = eng.d_sae
+            if self._small is None or self._small.numel() != d_sae + 5:
+                self._small = torch.empty(d_sae + 5, dtype=torch.float32, device=x.device)
+            small = self._small
+            small[:d_sae].copy_(eng.fire_count)
+            small[d_sae:].copy_(eng.scalars[:5])
+            dist.all_reduce(eng.flat_g)                         # every rank's share of the gradient (scaled by 1 / N_global already)
+            dist.all_reduce(small)                              # fire counts | loss, mse, l0, -, l1 in one bucket
+            fire = small[:d_sae]
+            eng.scalars[:5].copy_(small[d_sae:])
+            eng.scalars[2] /= W                                 # l0 is a mean over tokens
+            n_since_fired += 1                                  # train_sae.py:356-361 on the global batch
+            n_since_fired[fire > 0] = 0
+            act_freq_scores += fire
+        eng.grad_sqnorm()                                       # clip_grad_norm_ over the whole (summed) gradient
+        eng.apply(lr, self.cfg.max_grad_norm)
+        optimizer._opt_called = True
+        scheduler.step()
+        sc = eng.scalars.clone()
+        return sc[0], sc[1], sc[4], sc[2]
 
     def _make_shard_engine(self, sae, max_tokens: int):
         """Engine over one rank's feature shard (tests substitute the CPU twin)."""
