@@ -716,3 +716,42 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln):
             assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
         assert np.abs(eng.n_fwd_since_fired.cpu().numpy() - stats["n_fwd_since_fired"]).sum() <= 2
+
+
+def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():
+    """The store issues the NEXT refill's ViT forwards on a side stream while the current half buffer is served
+    (sae/store.py: overlap_harvest): same images, same order, the same permutations drawn at the same points -- every batch
+    it serves must be bit-identical to the synchronous store's, across several refills."""
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=8, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", b_dec_init_method="mean",
+        train_batch_size=64, lr=1e-3, max_grad_norm=1.0, _device="cuda", log_to_wandb=False,
+        lr_scheduler_name="constant", n_checkpoints=0, context_size=17, store_batch_size=4, n_batches_in_buffer=4)
+    arch = ARCHS["tiny"]
+    vit = HookedViT(HookedViTConfig(**arch, device="cuda"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()})
+    vit = vit.cuda().eval()
+    images = torch.from_numpy(synth_images(arch, 32, 3))
+    ds = [(images[i], 0) for i in range(32)]
+
+    def serve(overlap: bool):
+        torch.manual_seed(1234)
+        store = VisionActivationsStore(cfg, vit, ds, create_dataloader=False)
+        store.overlap_harvest = overlap                         # (set before the first refill is scheduled)
+        store.storage_buffer = store.get_buffer(cfg.n_batches_in_buffer)
+        store.dataloader = store.get_data_loader()
+        out = []
+        for _ in range(14):                                     # 16 * 17 / 64 = 4.25 batches per refill: three refills
+            b = store.next_batch()
+            out.append(b.clone())
+            if overlap:
+                torch.mm(torch.ones(512, 512, device="cuda"), torch.ones(512, 512, device="cuda"))   # main-stream work in between
+        torch.cuda.synchronize()
+        return out, store
+
+    sync_batches, _ = serve(False)
+    over_batches, st = serve(True)
+    assert st._side_stream is not None and vit.last_run_native
+    assert len(sync_batches) == len(over_batches)
+    for a, b in zip(sync_batches, over_batches):
+        assert a.shape == b.shape and torch.equal(a, b)

@@ -352,15 +352,71 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
         # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
         model.use_native(None)
-        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
+        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)])
         assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
-        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)]).cpu().numpy()) < FP32_TOL
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)]).cpu().numpy()) < FP32_TOL
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)])
         with pytest.raises(_native.NativeError):
-            model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_z", scale_shift)])
+            model.run_with_hooks(x, fwd_hooks=[("blocks.0.mlp.hook_pre", scale_shift)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+
+
+@pytest.mark.parametrize("arch_name,dtype", [("tiny", torch.float32), ("tiny-ragged", torch.float32), ("tiny", torch.bfloat16)])
+def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_plan(arch_name, dtype):
+    """Head ablation (attn.hook_z), edits of q / k / v and neuron ablation (mlp.hook_post) keep the HIP path: the plan is
+    split INSIDE the block (pv_vit_forward_stage) -- the hook sees the stage's activation, the rest of the block resumes from
+    what it returned, the residual stream it adds to is carried along.  Every result must equal the PyTorch hook path of the
+    same model (prisma_tools/hook_point.py:44-45; models/layers/attention.py:135-152, 186-281; mlp.py:65-80), cache
+    included; bf16: within the bf16 budget of the un-hooked comparison."""
+    model, arch, sd = build(arch_name, dtype)
+    ref = _pytorch_twin(model)
+    x = torch.from_numpy(synth_images(arch, 3, 5)).cuda().to(dtype)
+    nl = arch["n_layers"]
+    tol = FP32_TOL if dtype == torch.float32 else 3e-2
+
+    def half(t, hook):
+        return t * 0.5
+
+    def kill_head_1(t, hook):             # in place, returns None: [B, T, H, dh]
+        t[:, :, 1] = 0.0
+
+    def kill_neurons(t, hook):            # [B, T, d_mlp]
+        t[..., ::3] = 0.0
+
+    def swap_heads(t, hook):
+        return t.flip(2)
+
+    cases = [
+        [("blocks.0.attn.hook_z", kill_head_1)],
+        [(f"blocks.{nl - 1}.attn.hook_z", half)],
+        [("blocks.1.mlp.hook_post", kill_neurons)],
+        [("blocks.0.attn.hook_q", half), ("blocks.0.attn.hook_k", kill_head_1), ("blocks.0.attn.hook_v", swap_heads)],
+        [("blocks.1.attn.hook_v", swap_heads)],
+        [("blocks.0.attn.hook_z", kill_head_1), ("blocks.0.hook_resid_post", half)],
+        [("blocks.0.attn.hook_z", half), ("blocks.1.mlp.hook_post", kill_neurons), ("blocks.1.hook_attn_out", half)],
+        [(lambda n: n.endswith("attn.hook_z"), kill_head_1)],
+        [(lambda n: n.endswith(("attn.hook_q", "attn.hook_z", "hook_resid_mid", "mlp.hook_post", "hook_resid_post")), half)],
+        [(f"blocks.{nl - 1}.mlp.hook_post", half), (f"blocks.{nl - 1}.hook_mlp_out", kill_head_1 if False else half)],
+    ]
+    with torch.no_grad():
+        for hooks in cases:
+            want = ref.run_with_hooks(x.clone(), fwd_hooks=hooks)
+            got = model.run_with_hooks(x.clone(), fwd_hooks=hooks)
+            assert model.last_run_native, model.native_fallback_reason
+            assert rel_fro(got.float().cpu().numpy(), want.float().cpu().numpy()) < tol
+            assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+            for kw in ({}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post"))},
+                       {"stop_at_layer": nl - 1}):
+                w_out, w_cache = ref.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                assert model.last_run_native, model.native_fallback_reason
+                assert list(g_cache.keys()) == list(w_cache.keys())
+                assert rel_fro(g_out.float().cpu().numpy(), w_out.float().cpu().numpy()) < tol
+                for k in w_cache.keys():
+                    a, b = g_cache[k].float().cpu().numpy(), w_cache[k].float().cpu().numpy()
+                    assert a.shape == b.shape and rel_fro(a, b) < tol, (k, kw)
 
 
 def test_sae_substitution_style_eval_on_b32_bf16():

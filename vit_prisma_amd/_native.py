@@ -76,7 +76,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "pv_abi_version", "pv_build_id", "pv_last_error",
     "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
-    "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_gemm_bias", "pv_transpose_batched",
+    "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_vit_forward_stage", "pv_gemm_bias", "pv_transpose_batched",
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
     L.pv_vit_forward.argtypes = [vp, vp, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_vit_forward_from.argtypes = [vp, vp, i32, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_vit_forward_seg.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
+    L.pv_vit_forward_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_gemm_bias.argtypes = [i32, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp]
     L.pv_transpose_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     L.pv_prof_enable.argtypes = [i32]

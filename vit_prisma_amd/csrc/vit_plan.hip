@@ -183,16 +183,17 @@ extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
 }
 
 namespace {
-int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t entry_mid,
-                     int32_t n_blocks, int32_t exit_mid, int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
-                     size_t workspace_bytes, void* out, void* stream_);
+// entry_stage / exit_stage: PV_STAGE_* (positions inside a block: 0 entry, 1 q/k/v ready, 2 z ready, 3 resid_mid, 4 mlp post ready)
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, const void* const* act_in, int32_t B,
+                     int32_t first_block, int32_t entry_stage, int32_t n_blocks, int32_t exit_stage, int32_t run_head,
+                     const pv_tap* taps, int32_t n_taps, void* workspace, size_t workspace_bytes, void* out, void* stream_);
 }  // namespace
 
 extern "C" int pv_vit_forward(pv_vit_plan* p, const void* images, int32_t B, int32_t n_blocks,
                               int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                               size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(images, "null argument");
-    return vit_forward_impl(p, images, nullptr, B, 0, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+    return vit_forward_impl(p, images, nullptr, nullptr, B, 0, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
 }
 
 extern "C" int pv_vit_forward_seg(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block,
@@ -205,8 +206,29 @@ extern "C" int pv_vit_forward_seg(pv_vit_plan* p, const void* images, const void
     PV_REQUIRE(!entry_mid || first_block < p->d.n_layers, "entry_mid needs a block to resume");
     PV_REQUIRE(!exit_mid || (end_block < p->d.n_layers && !run_head), "exit_mid stops inside block end_block");
     PV_REQUIRE(!(entry_mid && first_block == end_block && !exit_mid), "a mid-block entry must finish its block");
-    return vit_forward_impl(p, images, resid_in, B, first_block, entry_mid, end_block, exit_mid, run_head, taps, n_taps, workspace,
-                            workspace_bytes, out, stream_);
+    return vit_forward_impl(p, images, resid_in, nullptr, B, first_block, entry_mid ? PV_STAGE_MID : 0, end_block,
+                            exit_mid ? PV_STAGE_MID : 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+}
+
+extern "C" int pv_vit_forward_stage(pv_vit_plan* p, const void* images, const void* resid_in, const void* act_in0, const void* act_in1,
+                                    const void* act_in2, int32_t B, int32_t first_block, int32_t entry_stage, int32_t end_block,
+                                    int32_t exit_stage, int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
+                                    size_t workspace_bytes, void* out, void* stream_) {
+    PV_REQUIRE(p && ((images != nullptr) != (resid_in != nullptr)), "exactly one of images / resid_in");
+    PV_REQUIRE(!resid_in || pv_aligned16(resid_in), "resid_in must be 16-byte aligned");
+    PV_REQUIRE(entry_stage >= 0 && entry_stage <= PV_STAGE_MLP_POST && exit_stage >= 0 && exit_stage <= PV_STAGE_MLP_POST, "stage");
+    PV_REQUIRE(images ? (first_block == 0 && !entry_stage) : (first_block >= 0 && first_block <= p->d.n_layers), "segment start");
+    PV_REQUIRE(first_block <= end_block && end_block <= p->d.n_layers, "segment end");
+    PV_REQUIRE(!entry_stage || first_block < p->d.n_layers, "a mid-block entry needs a block to resume");
+    PV_REQUIRE(!exit_stage || (end_block < p->d.n_layers && !run_head), "a mid-block exit stops inside block end_block");
+    PV_REQUIRE(first_block < end_block || entry_stage < exit_stage || (first_block == end_block && !exit_stage && !entry_stage),
+               "empty or backward segment");
+    if (entry_stage == PV_STAGE_QKV) PV_REQUIRE(act_in0 && act_in1 && act_in2, "entry at PV_STAGE_QKV needs q, k, v");
+    if (entry_stage == PV_STAGE_Z || entry_stage == PV_STAGE_MLP_POST) PV_REQUIRE(act_in0, "entry at PV_STAGE_Z / PV_STAGE_MLP_POST needs the activation");
+    const void* act[3] = {act_in0, act_in1, act_in2};
+    for (int i = 0; i < 3; ++i) PV_REQUIRE(!act[i] || pv_aligned16(act[i]), "activation inputs must be 16-byte aligned");
+    return vit_forward_impl(p, images, resid_in, act, B, first_block, entry_stage, end_block, exit_stage, run_head, taps, n_taps,
+                            workspace, workspace_bytes, out, stream_);
 }
 
 extern "C" int pv_vit_forward_from(pv_vit_plan* p, const void* resid_in, int32_t B, int32_t first_block, int32_t n_blocks,
@@ -214,13 +236,13 @@ extern "C" int pv_vit_forward_from(pv_vit_plan* p, const void* resid_in, int32_t
                                    size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(resid_in && pv_aligned16(resid_in), "resid_in must be a 16-byte aligned device pointer");
     PV_REQUIRE(p && first_block >= 0 && first_block <= p->d.n_layers && first_block <= n_blocks, "first_block out of range");
-    return vit_forward_impl(p, nullptr, resid_in, B, first_block, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
+    return vit_forward_impl(p, nullptr, resid_in, nullptr, B, first_block, 0, n_blocks, 0, run_head, taps, n_taps, workspace, workspace_bytes, out, stream_);
 }
 
 namespace {
-int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, int32_t B, int32_t first_block, int32_t entry_mid,
-                     int32_t n_blocks, int32_t exit_mid, int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
-                     size_t workspace_bytes, void* out, void* stream_) {
+int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, const void* const* act_in, int32_t B,
+                     int32_t first_block, int32_t entry_stage, int32_t n_blocks, int32_t exit_stage, int32_t run_head,
+                     const pv_tap* taps, int32_t n_taps, void* workspace, size_t workspace_bytes, void* out, void* stream_) {
     PV_REQUIRE(p && (images || resid_in) && workspace, "null argument");
     PV_REQUIRE(p->weights_set, "pv_vit_plan_set_weights has not been called");
     PV_REQUIRE(B > 0, "batch must be positive");
@@ -305,17 +327,23 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
     }
     bool resid_in_a = true;   // which workspace residual buffer may hold `resid`
 
-    // blocks [first_block, n_blocks) in full; with exit_mid also the attention half of block n_blocks (the segment
-    // then ends on its resid_mid); with entry_mid `resid` IS the resid_mid of first_block and its attention half is skipped
-    const int last_block = exit_mid ? n_blocks + 1 : n_blocks;
+    // blocks [first_block, n_blocks) in full; with exit_stage also block n_blocks up to that stage (the caller taps what it
+    // needs there); with entry_stage the first block resumes behind that stage: `resid` is then the residual stream the
+    // rest of the block adds to (resid_pre for PV_STAGE_QKV / PV_STAGE_Z, resid_mid for PV_STAGE_MID / PV_STAGE_MLP_POST) and
+    // act_in holds the (hook-edited) activations of the stage: q, k, v | z | mlp post
+    const int last_block = exit_stage ? n_blocks + 1 : n_blocks;
     for (int l = first_block; l < last_block; ++l) {
         const pv_vit_layer_weights& W = p->lw[l];
         const LayerShadow& S = p->sh[l];
+        const int es = l == first_block ? entry_stage : 0;
+        const int xs = (exit_stage && l == n_blocks) ? exit_stage : 99;
         void* resid_pre = resid;
-        void* resid_mid;
-        if (l == first_block && entry_mid) {
+        void* resid_mid = nullptr;
+        void *q = nullptr, *k = nullptr, *v = nullptr, *z = nullptr;
+        if (es >= PV_STAGE_MID) {
             resid_mid = resid;
         } else {
+        if (es < PV_STAGE_QKV) {
         // ln1 (transformer_block.py:106-109 ; layer_norm.py:75-93)
         void* ln1 = pick(PV_SLOT_LN1_OUT, l, ws.ln_out);
         {
@@ -328,9 +356,9 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             if ((rc = pv_launch_ln(dt, L, stream))) return rc;
         }
         // q, k, v (attention.py:186-244) as one GEMM against the packed [3*H*dh][d] shadow
-        void* q = pick(PV_SLOT_Q, l, ws.q);
-        void* k = pick(PV_SLOT_K, l, ws.k);
-        void* v = pick(PV_SLOT_V, l, ws.v);
+        q = pick(PV_SLOT_Q, l, ws.q);
+        k = pick(PV_SLOT_K, l, ws.k);
+        v = pick(PV_SLOT_V, l, ws.v);
         {
             GemmParams g = {};
             g.A = ln1; g.lda = dm; g.a_mode = PV_A_PLAIN; g.Bt = S.Wqkv; g.ldb = dm;
@@ -338,8 +366,13 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             g.bias0 = W.b_Q; g.bias1 = W.b_K; g.bias2 = W.b_V; g.out0 = q; g.out1 = k; g.out2 = v; g.ldo = HD;
             if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
         }
+        } else if (es == PV_STAGE_QKV) {
+            q = const_cast<void*>(act_in[0]); k = const_cast<void*>(act_in[1]); v = const_cast<void*>(act_in[2]);
+        }
+        if (xs == PV_STAGE_QKV) break;
+        if (es < PV_STAGE_Z) {
         // scores / pattern / z (attention.py:135-152, 246-281)
-        void* z = pick(PV_SLOT_Z, l, ws.z);
+        z = pick(PV_SLOT_Z, l, ws.z);
         {
             AttnParams a = {};
             a.q = q; a.k = k; a.v = v; a.z = z;
@@ -347,6 +380,10 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             a.B = B; a.T = T; a.H = d.n_heads; a.dh = d.d_head; a.attn_scale = d.attn_scale;
             if ((rc = pv_launch_attention(dt, a, stream))) return rc;
         }
+        } else {
+            z = const_cast<void*>(act_in[0]);
+        }
+        if (xs == PV_STAGE_Z) break;
         // attn_out = z W_O + b_O ; resid_mid = resid_pre + attn_out (attention.py:155-167 ; block :117-124)
         resid_mid = pick(PV_SLOT_RESID_MID, l, ws.resid_mid);
         {
@@ -357,10 +394,12 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
         }
         }
-        if (exit_mid && l == n_blocks) {
+        if (xs == PV_STAGE_MID) {
             resid = resid_mid;
             break;
         }
+        void* post;
+        if (es < PV_STAGE_MLP_POST) {
         // ln2 (block :130)
         void* ln2 = pick(PV_SLOT_LN2_OUT, l, ws.ln_out);
         {
@@ -373,7 +412,7 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             if ((rc = pv_launch_ln(dt, L, stream))) return rc;
         }
         // mlp (mlp.py:65-80): pre -> act -> post
-        void* post = pick(PV_SLOT_MLP_POST, l, ws.mlp_post);
+        post = pick(PV_SLOT_MLP_POST, l, ws.mlp_post);
         {
             GemmParams g = {};
             g.A = ln2; g.lda = dm; g.a_mode = PV_A_PLAIN; g.Bt = S.WinT; g.ldb = dm;
@@ -381,6 +420,10 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, i
             g.out0 = tap_at(PV_SLOT_MLP_PRE, l); g.out1 = post; g.ldo = dmlp;
             if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
         }
+        } else {
+            post = const_cast<void*>(act_in[0]);
+        }
+        if (xs == PV_STAGE_MLP_POST) break;
         // mlp_out ; resid_post = resid_mid + mlp_out (block :131-134)
         void* resid_post = tap_at(PV_SLOT_RESID_POST, l);
         if (!resid_post) {

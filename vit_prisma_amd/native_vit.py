@@ -221,13 +221,18 @@ class NativeViT:
     def forward(self, model, images: Optional[torch.Tensor], names: Sequence[str], n_blocks: int, run_head: bool,
                 cache_device=None, remove_batch_dim: bool = False, first_block: int = 0,
                 resid_in: Optional[torch.Tensor] = None, entry_mid: bool = False,
-                exit_mid: bool = False) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                exit_mid: bool = False, entry_stage: int = 0, exit_stage: int = 0,
+                act_in: Sequence[torch.Tensor] = ()) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
         With ``resid_in`` ([B, T, d_model]) the forward is RESUMED at block ``first_block`` from that residual
-        (``images`` is ignored, names of earlier stages must not be requested); ``entry_mid``: the residual is the
-        resid_mid of ``first_block`` (its attention half is skipped); ``exit_mid``: the segment also runs the
-        attention half of block ``n_blocks`` and returns its resid_mid (pv_vit_forward_seg).
-        Returns (model_out, {name: tensor})."""
+        (``images`` is ignored, names of earlier stages must not be requested).  Positions inside a block
+        (``entry_stage`` / ``exit_stage``, pv_vit_forward_stage): 0 block entry, 1 q / k / v ready, 2 z ready, 3 after the
+        attention half (``entry_mid`` / ``exit_mid`` = 3), 4 mlp post ready.  A segment that exits at a stage runs block
+        ``n_blocks`` up to it; one that enters at a stage gets the residual stream the rest of the block adds to in
+        ``resid_in`` and the (hook-edited) activations of the stage in ``act_in``: (q, k, v) | (z,) | (post,).
+        Returns (model_out, {name: tensor}); for an exit at stage 1 / 2 / 4 model_out is the stage's (first) activation."""
+        entry_stage = 3 if entry_mid else int(entry_stage)
+        exit_stage = 3 if exit_mid else int(exit_stage)
         cfg = self.cfg
         T = self.n_tokens
         if resid_in is not None:
@@ -252,9 +257,19 @@ class NativeViT:
         specs: Dict[str, TapSpec] = {n: tap_spec(n, cfg, B, T) for n in names}
         out_name = None
         if not run_head:
-            out_name = f"blocks.{n_blocks}.hook_resid_mid" if exit_mid else final_residual_name(cfg, n_blocks)
+            out_name = {0: None, 1: f"blocks.{n_blocks}.attn.hook_q", 2: f"blocks.{n_blocks}.attn.hook_z",
+                        3: f"blocks.{n_blocks}.hook_resid_mid", 4: f"blocks.{n_blocks}.mlp.hook_post"}[exit_stage] \
+                or final_residual_name(cfg, n_blocks)
             if out_name not in specs:
                 specs[out_name] = tap_spec(out_name, cfg, B, T)
+        acts = []
+        for t in act_in:
+            if t.device != self.device:
+                raise N.NativeError(f"activation on {t.device}, model on {self.device}")
+            acts.append(t.to(cfg.dtype).contiguous())
+        want_acts = {0: 0, 1: 3, 2: 1, 3: 0, 4: 1}[entry_stage]
+        if len(acts) != want_acts:
+            raise ValueError(f"entry_stage {entry_stage} takes {want_acts} activation tensors, got {len(acts)}")
         # unique buffers -> slab offsets
         offsets: Dict[Tuple[int, int], Tuple[int, TapSpec]] = {}
         total = 0
@@ -279,18 +294,29 @@ class NativeViT:
         for i, ((slot, layer), (off, _)) in enumerate(offsets.items()):
             taps[i] = N.Tap(slot=slot, layer=layer, dst=base + off)
         ws = self._get_workspace(B)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if resid_in is None and not exit_mid:
+        cur = torch.cuda.current_stream(self.device)
+        stream = cur.cuda_stream
+        # one plan = one workspace: a call on another stream than the previous one (the store's harvest prefetch runs on a
+        # side stream, sae/store.py) waits for that one to finish with it
+        last = getattr(self, "_last_use", None)
+        if last is not None and last[0] != stream:
+            cur.wait_event(last[1])
+        if resid_in is None and not exit_stage:
             N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
                                             ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
                     "pv_vit_forward")
         else:
-            N.check(self.lib.pv_vit_forward_seg(self._plan, images.data_ptr() if resid_in is None else None,
-                                                None if resid_in is None else resid_in.data_ptr(), B, first_block,
-                                                int(entry_mid), n_blocks, int(exit_mid), int(run_head), taps, len(offsets),
-                                                ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
-                    "pv_vit_forward_seg")
+            ap = [a.data_ptr() for a in acts] + [None] * (3 - len(acts))
+            N.check(self.lib.pv_vit_forward_stage(self._plan, images.data_ptr() if resid_in is None else None,
+                                                  None if resid_in is None else resid_in.data_ptr(), ap[0], ap[1], ap[2], B,
+                                                  first_block, entry_stage, n_blocks, exit_stage, int(run_head), taps,
+                                                  len(offsets), ws.data_ptr(), ws.numel(),
+                                                  (base + out_off) if run_head else None, stream),
+                    "pv_vit_forward_stage")
         self.n_forward += 1
+        ev = last[1] if last is not None else torch.cuda.Event()
+        ev.record(cur)
+        self._last_use = (stream, ev)
 
         def view(src: torch.Tensor, off: int, s_dtype: torch.dtype, shape: Tuple[int, ...]) -> torch.Tensor:
             n = 1

@@ -180,7 +180,8 @@ class _ResidentImages(torch.utils.data.Dataset):
         return self.x[i], 0
 
 
-def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: int = 64, feature_parallel: bool = True) -> dict:
+def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: int = 64, feature_parallel: bool = True,
+                       overlap_harvest: bool = True) -> dict:
     """Config 3, second number: the training loop the reference runs -- VisionActivationsStore
     harvesting ``blocks.6.hook_resid_post`` from randn images through ViT blocks 0..6 (native run_with_cache,
     names_filter + stop_at_layer), half-buffer shuffle-mix, VisionSAETrainer.train_step on the fused native step.
@@ -215,6 +216,7 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
     act, since, frac, opt, sched = tr.initialize_training_variables()
     tr.initialize_geometric_medians()
     store = tr.activations_store
+    store.overlap_harvest = bool(overlap_harvest)         # the next refill's ViT forwards on a side stream, behind the train steps
     n_steps = 0
 
     def one():
@@ -253,6 +255,7 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
         "config": {"workload": f"VisionSAETrainer loop: store_batch_size {store_bs} x n_batches_in_buffer {n_buf}, "
                                f"global train batch {N_TOKENS} tokens, hook blocks.6.hook_resid_post, images resident in HBM",
                    "tokens_per_gpu_per_step": N_TOKENS // world,
+                   "harvest": "next refill prefetched on a side stream (overlaps the train steps)" if overlap_harvest else "synchronous",
                    "parallelism": "single process" if world == 1 else
                    ("images sharded for the harvest, features sharded for the step (tokens all-gathered)" if feature_parallel
                     else "images and tokens sharded, optimizer sharded by feature")},

@@ -41,6 +41,14 @@ class VisionActivationsStore:
         self.model = model.to(cfg.device)
         self.dataset = dataset
         self.n_tokens_harvested = 0                          # rows written into buffers so far (bench: harvested / trained)
+        # The next refill's ViT forwards do not depend on the SAE being trained: on a GPU they are issued on a side stream as
+        # soon as the current half buffer is being served and overlap the train steps (whose many small kernels leave most of
+        # the chip idle); the refill then only waits for an event.  Same images, same order, same random permutations drawn
+        # at the same points -- the batches served are identical to the synchronous store's.  ``overlap_harvest = False``
+        # turns it off.
+        self.overlap_harvest = torch.device(cfg.device).type == "cuda"
+        self._prefetched = None                              # (n_batches, buf, buf_out, event) of the refill in flight
+        self._side_stream = None
         rank, world = _dist_info()
         sampler = None
         if world > 1:
@@ -116,8 +124,8 @@ class VisionActivationsStore:
             return pick(names), pick(out_names)
         return pick(names)
 
-    def get_buffer(self, n_batches_in_buffer: int) -> torch.Tensor:
-        """[bs * n_batches * ctx, n_layers, d_in], rows shuffled (activations_store.py:298-362)."""
+    def _harvest_raw(self, n_batches_in_buffer: int):
+        """The ViT part of ``get_buffer``: (buf [bs * n_batches, ctx, n_layers, d_in], buf_out or None), rows in harvest order."""
         cfg = self.cfg
         bs = cfg.store_batch_size
         total = bs * n_batches_in_buffer
@@ -152,6 +160,37 @@ class VisionActivationsStore:
         finally:
             if freeze is not None:
                 freeze(was_frozen)
+        return buf, buf_out
+
+    def _start_prefetch(self, n_batches: int) -> None:
+        """Issue the next refill's harvest on the side stream (returns at once; ``get_buffer`` picks it up)."""
+        dev = torch.device(self.cfg.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side, cur = self._side_stream, torch.cuda.current_stream(dev)
+        side.wait_stream(cur)                                 # (whatever the caller did to the model / images so far)
+        with torch.cuda.stream(side):
+            buf, buf_out = self._harvest_raw(n_batches)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._prefetched = (n_batches, buf, buf_out, ev)
+
+    def get_buffer(self, n_batches_in_buffer: int) -> torch.Tensor:
+        """[bs * n_batches * ctx, n_layers, d_in], rows shuffled (activations_store.py:298-362)."""
+        cfg = self.cfg
+        n_layers = len(self._layers())
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] == n_batches_in_buffer:
+            _, buf, buf_out, ev = pre
+            cur = torch.cuda.current_stream(buf.device)
+            cur.wait_event(ev)
+            buf.record_stream(cur)                            # (allocated on the side stream, consumed and freed on this one)
+            if buf_out is not None:
+                buf_out.record_stream(cur)
+        else:
+            if pre is not None:                               # a prefetch of another size: its images are spent, keep the order
+                torch.cuda.current_stream(pre[1].device).wait_event(pre[3])
+            buf, buf_out = self._harvest_raw(n_batches_in_buffer)
         buf = buf.reshape(-1, n_layers, cfg.d_in)
         perm = torch.randperm(buf.shape[0], device=buf.device)
         if buf_out is not None:
@@ -180,6 +219,8 @@ class VisionActivationsStore:
             serve = mix[half:]
         _, world = _dist_info()
         local_bs = max(cfg.train_batch_size // world, 1)
+        if self.overlap_harvest and cfg.n_batches_in_buffer // 2 > 0:
+            self._start_prefetch(cfg.n_batches_in_buffer // 2)    # the refill this iterator will end in, behind the train steps
         return iter(_TensorBatches(serve, local_bs))
 
     def next_batch(self) -> torch.Tensor:

@@ -452,22 +452,27 @@ class HookedViT(HookedRootModule):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
         if self._boundary_hooks() is None:
-            return "a hook is registered on a point the plan cannot be split at (supported: blocks.L.hook_resid_pre / hook_attn_out / hook_resid_mid / hook_mlp_out / hook_resid_post)"
+            return ("a hook is registered on a point the plan cannot be split at (supported: blocks.L.hook_resid_pre / hook_attn_out / "
+                    "hook_resid_mid / hook_mlp_out / hook_resid_post / attn.hook_q / attn.hook_k / attn.hook_v / attn.hook_z / mlp.hook_post)")
         for mod in self._plain_modules:                    # (valid: the tree is the one this list was built from)
             if mod._forward_hooks or mod._forward_pre_hooks:
                 return "nn.Module hooks registered"
         return None
 
-    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.hook_(resid_pre|attn_out|resid_mid|mlp_out|resid_post)$")
-    # firing order of the hookable residual-stream points at a split position
-    _KINDS_AT_ENTRY = ("mlp", "post", "pre")       # position 2b: hook_mlp_out / hook_resid_post of block b-1, hook_resid_pre of b
-    _KINDS_AT_MID = ("attn", "mid")                # position 2b+1: hook_attn_out, hook_resid_mid of block b
+    # HookPoints a forward hook may sit on while the call stays on the native plan: the plan is split there
+    _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.(hook_resid_pre|hook_attn_out|hook_resid_mid|hook_mlp_out|hook_resid_post|"
+                              r"attn\.hook_q|attn\.hook_k|attn\.hook_v|attn\.hook_z|mlp\.hook_post)$")
+    _NPOS = 5            # split positions per block: 0 entry | 1 q, k, v ready | 2 z ready | 3 after the attention half | 4 mlp post ready
+    _KIND_POS = {"hook_resid_pre": ("pre", 0), "attn.hook_q": ("q", 1), "attn.hook_k": ("k", 1), "attn.hook_v": ("v", 1),
+                 "attn.hook_z": ("z", 2), "hook_attn_out": ("attn", 3), "hook_resid_mid": ("mid", 3),
+                 "mlp.hook_post": ("mlppost", 4), "hook_mlp_out": ("mlp", 5), "hook_resid_post": ("post", 5)}
 
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
         """{position: {kind: HookPoint}} for every HookPoint that carries a forward hook, or None when some hook (a
         forward hook elsewhere, any backward hook) cannot be served by splitting the native plan.  Positions count
-        half blocks: 2b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
-        fire there, in that order), 2b+1 = after block b's attention half ("attn", then "mid")."""
+        _NPOS per block: 5b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
+        fire there, in that order), 5b+1 = its q, k, v ("q", "k", "v"), 5b+2 = its z, 5b+3 = after its attention half
+        ("attn", then "mid"), 5b+4 = its MLP activation ("mlppost")."""
         out: Dict[int, Dict[str, HookPoint]] = {}
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -477,9 +482,8 @@ class HookedViT(HookedRootModule):
             m = self._BOUNDARY_RE.fullmatch(name)
             if m is None:
                 return None
-            layer = int(m.group(1))
-            kind = {"resid_pre": "pre", "attn_out": "attn", "resid_mid": "mid", "mlp_out": "mlp", "resid_post": "post"}[m.group(2)]
-            pos = {"pre": 2 * layer, "attn": 2 * layer + 1, "mid": 2 * layer + 1, "mlp": 2 * layer + 2, "post": 2 * layer + 2}[kind]
+            kind, off = self._KIND_POS[m.group(2)]
+            pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
                 return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
             out.setdefault(pos, {})[kind] = hp
@@ -542,69 +546,109 @@ class HookedViT(HookedRootModule):
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
         nv = self._get_native(x.device)
         bh = self._boundary_hooks() or {}
-        end_pos = 2 * n_blocks
+        NP = self._NPOS
+        end_pos = NP * n_blocks
         # a hook at the very end fires only if its point is produced: "pre" of block n_blocks is not
         bounds = sorted(q for q in bh if q < end_pos or (q == end_pos and ("post" in bh[q] or "mlp" in bh[q])))
         if not bounds:
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
                               remove_batch_dim=remove_batch_dim)
-        # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count half blocks
+        # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
+        # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 + q, k, v | 1 attention core |
+        # 2 O-projection + residual | 3 ln2 + MLP up to the activation | 4 MLP output + residual.
         wanted = set(names)
         cache: Dict[str, torch.Tensor] = {}
-        first_half = ("hook_resid_pre", "ln1.", "attn.", "hook_attn_out", "hook_resid_mid")
 
         def pos_of(name: str) -> int:
-            """the half block that produces `name` (-1: embedding stage, 2 * n_layers: final stage)"""
+            """the stage that produces `name` (-1: embedding stage, NP * n_layers: final stage)"""
             if name.startswith("blocks."):
                 _, l, rest = name.split(".", 2)
-                return 2 * int(l) + (0 if rest.startswith(first_half) else 1)
+                if rest == "hook_resid_pre" or rest.startswith("ln1.") or rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
+                    st = 0
+                elif rest.startswith("attn."):
+                    st = 1
+                elif rest in ("hook_attn_out", "hook_resid_mid"):
+                    st = 2
+                elif rest.startswith(("ln2.", "mlp.")):
+                    st = 3
+                else:
+                    st = 4
+                return NP * int(l) + st
             return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
-                else 2 * cfg.n_layers
+                else NP * cfg.n_layers
 
-        p0, resid, out = 0, None, None
+        p0, resid, acts, out = 0, None, (), None
         for q in bounds + [None]:
             last = q is None
             p1 = end_pos if last else q
-            blk = (p1 - 1) // 2                                 # the block whose half ends at p1
-            seg = [n for n in names if (p0 == 0 or pos_of(n) >= p0) and pos_of(n) < (2 * cfg.n_layers + 1 if last else p1)
-                   and not (p0 > 0 and p0 % 2 == 0 and n == f"blocks.{p0 // 2}.hook_resid_pre")]     # (the resumed tensor: set by hand)
+            b1, s1 = divmod(p1, NP)                             # the segment ends at position s1 of block b1
+            blk = b1 if s1 else b1 - 1                          # the block its last stage lies in
+            seg = [n for n in names if (p0 == 0 or pos_of(n) >= p0) and pos_of(n) < (NP * cfg.n_layers + 1 if last else p1)
+                   and not (p0 > 0 and p0 % NP == 0 and n == f"blocks.{p0 // NP}.hook_resid_pre")]     # (the resumed tensor: set by hand)
             hooks = {} if last else bh[q]
             c: Dict[str, torch.Tensor] = {}
             seg_in = resid
+            pre_inside = p0 < NP * b1 or p0 == 0                # block b1's entry lies inside this segment
             if p0 == p1 and not (last and run_head):
                 out = resid                                   # nothing left to run: the hooked residual is the output
             else:
                 forced = []
                 if not last:
-                    if p1 % 2 == 0:
+                    pre_name, mid_name = f"blocks.{b1}.hook_resid_pre", f"blocks.{b1}.hook_resid_mid"
+                    if s1 == 0:
                         forced = [f"blocks.{blk}.hook_resid_post"]
                         if "mlp" in hooks:
-                            forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= 2 * blk else [])
-                    else:
-                        forced = [f"blocks.{blk}.hook_resid_mid"]
+                            forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= NP * blk + 2 else [])
+                    elif s1 == 1:
+                        forced = [f"blocks.{b1}.attn.hook_{t}" for t in "qkv"] + ([pre_name] if pre_inside else [])
+                    elif s1 == 2:
+                        forced = [f"blocks.{b1}.attn.hook_z"] + ([pre_name] if pre_inside else [])
+                    elif s1 == 3:
+                        forced = [mid_name]
                         if "attn" in hooks:
-                            forced += [f"blocks.{blk}.hook_attn_out"] + ([f"blocks.{blk}.hook_resid_pre"] if (p0 < 2 * blk or p0 == 0) else [])
+                            forced += [f"blocks.{b1}.hook_attn_out"] + ([pre_name] if pre_inside else [])
+                    else:
+                        forced = [f"blocks.{b1}.mlp.hook_post"] + ([mid_name] if p0 <= NP * b1 + 2 else [])
                 req = seg + [n for n in forced if n not in seg]
-                out, c = nv.forward(self, x if p0 == 0 else None, req, p1 // 2, last and run_head, first_block=p0 // 2,
-                                    resid_in=resid if p0 > 0 else None, entry_mid=bool(p0 % 2), exit_mid=bool(p1 % 2))
+                out, c = nv.forward(self, x if p0 == 0 else None, req, b1, last and run_head, first_block=p0 // NP,
+                                    resid_in=resid if p0 > 0 else None, entry_stage=p0 % NP, exit_stage=s1, act_in=acts)
                 cache.update({k: v for k, v in c.items() if k in wanted})
             if last:
                 break
-            if p1 % 2 == 1:
-                # after block blk's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
+            acts = ()
+            if s1 in (1, 2, 4):
+                # inside the attention half / the MLP: the hooks see the stage's activations (attention.py:135-152, 186-281;
+                # mlp.py:65-80), the rest of the block resumes from what they return; the residual stream the block adds to
+                # is carried along untouched
+                kinds = {1: ("q", "k", "v"), 2: ("z",), 4: ("mlppost",)}[s1]
+                vals = []
+                for kind in kinds:
+                    nm = f"blocks.{b1}." + {"q": "attn.hook_q", "k": "attn.hook_k", "v": "attn.hook_v", "z": "attn.hook_z",
+                                            "mlppost": "mlp.hook_post"}[kind]
+                    t = c[nm]
+                    if kind in hooks:
+                        t = hooks[kind](t)
+                    if nm in wanted:
+                        cache[nm] = t
+                    vals.append(t)
+                acts = tuple(vals)
+                carried = f"blocks.{b1}.hook_resid_mid" if s1 == 4 else f"blocks.{b1}.hook_resid_pre"
+                resid = c.get(carried, seg_in)
+            elif s1 == 3:
+                # after block b1's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
                 # kernel's rounding (transformer_block.py:117-124), then hook_resid_mid
-                resid = c[f"blocks.{blk}.hook_resid_mid"]
+                resid = c[f"blocks.{b1}.hook_resid_mid"]
                 if "attn" in hooks:
-                    a_name = f"blocks.{blk}.hook_attn_out"
+                    a_name = f"blocks.{b1}.hook_attn_out"
                     attn_out = hooks["attn"](c[a_name])
                     if a_name in wanted:
                         cache[a_name] = attn_out
-                    pre = c.get(f"blocks.{blk}.hook_resid_pre", seg_in)
+                    pre = c.get(f"blocks.{b1}.hook_resid_pre", seg_in)
                     resid = pre + attn_out.to(pre.dtype)
                 if "mid" in hooks:
                     resid = hooks["mid"](resid)
-                if f"blocks.{blk}.hook_resid_mid" in wanted:
-                    cache[f"blocks.{blk}.hook_resid_mid"] = resid
+                if f"blocks.{b1}.hook_resid_mid" in wanted:
+                    cache[f"blocks.{b1}.hook_resid_mid"] = resid
             else:
                 # entering block blk+1: hook_mlp_out rebuilds resid_post = resid_mid + mlp_out (block :131-134), then
                 # hook_resid_post, then the next block's hook_resid_pre
