@@ -261,6 +261,12 @@ typedef struct pv_sae_desc {
  * moments and training statistics -- all caller-owned (torch tensors), fp32 unless stated. */
 typedef struct pv_sae_state {
     float *W_enc, *W_dec, *b_enc, *b_dec;          /* [d_in,d_sae] [d_sae,d_in] [d_sae] [d_in]   */
+                                                   /* W_enc may be NULL in pv_sae_step / pv_sae_dense_step / pv_sae_tp_* /
+                                                      pv_sae_apply / pv_sae_encode_topk / pv_sae_forward: the kernels read the
+                                                      encoder through W_encT (below), and an apply without W_enc leaves the
+                                                      parameter's own layout stale (saves its 75 MB transposed write per step at
+                                                      768 -> 24576) until pv_sae_sync_shadows(from_transposed = 1) rewrites it --
+                                                      the host materialises it when somebody reads the parameter               */
     float *gW_enc, *gW_dec, *gb_enc, *gb_dec;      /* gradients; gW_enc is stored TRANSPOSED,      */
                                                    /* [d_sae, d_in] (coalesced sparse backward; the */
                                                    /* Adam kernel transposes it back tile-wise).    */

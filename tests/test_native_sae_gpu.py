@@ -755,3 +755,52 @@ def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():
     assert len(sync_batches) == len(over_batches)
     for a, b in zip(sync_batches, over_batches):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_checkpoint_mid_run_and_lazy_w_enc_match_the_torch_path(tmp_path):
+    """(a) trainer.checkpoint() between steps renormalises W_dec on the live parameters (sae.py:275-277): the engine must not
+    reuse the inverse row norms of its last apply afterwards -- the native run must keep tracking the PyTorch
+    path of the same trainer through a checkpoint.  (b) single process: the engine trains W_enc in its transposed master and
+    leaves the parameter's own layout stale until somebody reads it -- sae.W_enc, state_dict() and the saved checkpoint
+    must nevertheless hold the trained values."""
+    def make(native: bool, folder):
+        cfg = VisionModelSAERunnerConfig(
+            hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=8, activation_fn_str="topk",
+            activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=256,
+            lr=1e-3, max_grad_norm=1.0, _device="cuda", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
+            context_size=17, checkpoint_path=str(folder))
+        sae = StandardSparseAutoencoder(cfg)
+        with torch.no_grad():
+            for n, v in synth_sae_state(64, 512, 0).items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+        tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(native)
+        return cfg, sae, tr, list(tr.initialize_training_variables())
+
+    runs = {}
+    for native in (True, False):
+        cfg, sae, tr, st = make(native, tmp_path / ("native" if native else "torch"))
+        for t in range(5):
+            x = torch.from_numpy(synth_sae_batch(256, 64, seed=t)).cuda()[:, None, :]
+            _, _, _, _, st[0], st[1], st[2] = tr.train_step(
+                sparse_autoencoder=sae, optimizer=st[3], scheduler=st[4], act_freq_scores=st[0], n_forward_passes_since_fired=st[1],
+                n_frac_active_tokens=st[2], layer_acts=x, n_training_steps=t, n_training_tokens=t * 256)
+            assert tr.last_step_native == native
+            if native and t == 1:
+                eng = tr._engine
+                assert eng.lazy_w_enc and eng._w_enc_stale
+                stale = sae._parameters["W_enc"].detach().clone()               # the registry does not trigger the sync ...
+                fresh = sae.W_enc.detach().clone()                              # ... attribute access does
+                assert not eng._w_enc_stale and torch.equal(fresh, eng.W_encT.t()) and not torch.equal(stale, fresh)
+            if t == 2:
+                tr.checkpoint(sae, (t + 1) * 256, st[0], st[2])
+        runs[native] = {n: p.detach().cpu().numpy().copy() for n, p in sae.named_parameters()}
+        if native:
+            path = [f for f in os.listdir(tmp_path / "native") if f.endswith(".pt") and "sparsity" not in f][0]
+            blob = torch.load(tmp_path / "native" / path, weights_only=False)
+            ck = blob["state_dict"]["W_enc"].cpu().numpy()
+            # the checkpoint (after step 3) holds TRAINED values: two Adam steps of lr 1e-3 away from the final ones (each moves a
+            # 0.036-sized weight by up to 1e-3), three away from the initial ones
+            assert np.isfinite(ck).all() and 1e-3 < rel_fro(ck, runs[True]["W_enc"]) < 0.08
+            assert rel_fro(ck, synth_sae_state(64, 512, 0)["W_enc"]) > 2e-2
+    for n in runs[True]:
+        assert rel_fro(runs[True][n], runs[False][n]) < TOL, n

@@ -30,17 +30,18 @@ FP32_TOL = 1e-4
 # 0.94-1.000 (the embedding / ln_pre / block-0 keys are BIT-identical to the reference's bf16 tensors, ratio 1.000000).
 # One documented exception class: ``*.hook_scale`` -- fp32 per-token scalars sqrt(mean(x^2) + eps) of a bf16 residual
 # stream (budget 2e-4 .. 5e-4).  Their error is the rounding noise of that stream, which is independent of (and as large
-# as) the reference's, so the per-key ratio scatters around 1 (measured 0.93 .. 1.13): held to 1.25 x.
+# as) the reference's, so the per-key ratio scatters around 1 and the scatter shrinks with the number of rows averaged:
+# measured <= 1.022 over the 16 checked images of the bs = 512 bench batch (held to 1.05 x there), <= 1.13 on the 4-image
+# fixture (held to 1.15 x; profiles/r02_parity_ratios.json).
 # BF16_SLACK: "1.0 x" is asserted up to 1e-4 relative: the early keys reproduce the reference's bf16 tensors up to a
 # handful of differently rounded elements (measured ratios 1.000000 .. 1.000004), and the budget itself was computed with
 # torch's norm, the test with numpy's.
 BF16_SLACK = 1.0 + 1e-4
+SCALE_SLACK_SMALL, SCALE_SLACK_BENCH = 1.15, 1.05
 
 
-def bf16_limit(key: str, budget_rel_fro: float) -> float:
-    return budget_rel_fro * (1.25 if key.endswith(".hook_scale") else 1.0) * BF16_SLACK
-
-
+def bf16_limit(key: str, budget_rel_fro: float, scale_slack: float = SCALE_SLACK_SMALL) -> float:
+    return budget_rel_fro * (scale_slack if key.endswith(".hook_scale") else 1.0) * BF16_SLACK
 
 
 def build(arch_name, dtype, outliers=False):
@@ -469,13 +470,13 @@ def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, loop, tuning):
 # ---------------------------------------------------------------------------------------------------
 # parity at the configurations bench.py reports (no kernel overrides: the library picks what the bench runs)
 # ---------------------------------------------------------------------------------------------------
-def _held_to_budget(cache, c_ref, budget, sub, tag):
+def _held_to_budget(cache, c_ref, budget, sub, tag, scale_slack=SCALE_SLACK_BENCH):
     bad = []
     for k, ref in c_ref.items():
         got = cache[k][sub].float().cpu().numpy()
         assert got.shape == ref.shape, (tag, k)
         err = rel_fro(got, ref)
-        if err > bf16_limit(k, budget[k]["rel_fro"]):
+        if err > bf16_limit(k, budget[k]["rel_fro"], scale_slack):
             bad.append((k, err, budget[k]["rel_fro"]))
     assert not bad, (tag, bad[:8], len(bad))
 
@@ -635,7 +636,8 @@ def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
             if budget == 0.0:
                 assert np.abs(got).max() == 0.0, (name, k)               # the zero-ablated tensor itself
             else:
-                assert rel_fro(got, ref) <= bf16_limit(k, budget), (name, k, rel_fro(got, ref), budget)
+                # (4-image fixture with a rewritten residual stream: hook_scale held to the round-2 bar of 1.25 x here)
+                assert rel_fro(got, ref) <= bf16_limit(k, budget, 1.25), (name, k, rel_fro(got, ref), budget)
 
 
 @pytest.mark.parametrize("image_size,patch", [(224, 16), (208, 13), (400, 16), (176, 16), (256, 16)])

@@ -212,3 +212,29 @@ def test_harvest_shards_images_across_ranks_gloo_world2():
     assert len(seen0) == len(seen1) == 8 and not set(seen0) & set(seen1) and set(seen0) | set(seen1) == set(range(16))
     assert b0 == b1 == (16, 1, 64)                      # 32 tokens per global step -> 16 per rank
     assert buf0[1:] == buf1[1:] == (1, 64)
+
+
+def test_readers_of_w_enc_trigger_the_native_sync_hook():
+    """A native training engine may keep W_enc's own layout stale between steps (NativeSAE.lazy_w_enc); every way of reaching
+    the parameter through the module -- attribute access, state_dict(), parameters() / named_parameters() -- must call the
+    registered materialisation first; the raw registry (what the trainer's hot loop uses) must not."""
+    from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig
+    cfg = VisionModelSAERunnerConfig(hook_point_layer=1, layer_subtype="hook_resid_post", d_in=16, expansion_factor=2,
+                                     activation_fn_str="topk", activation_fn_kwargs={"k": 2}, _device="cpu", log_to_wandb=False)
+    sae = StandardSparseAutoencoder(cfg)
+    calls = []
+    object.__setattr__(sae, "_native_sync_fn", lambda: calls.append(1))
+    _ = sae._parameters["W_enc"]
+    _ = sae.W_dec
+    assert calls == []
+    _ = sae.W_enc
+    assert len(calls) == 1
+    sae.state_dict()
+    assert len(calls) >= 2
+    n = len(calls)
+    list(sae.parameters())
+    assert len(calls) > n
+    n = len(calls)
+    x = torch.randn(4, 16)
+    sae(x)                                               # the PyTorch forward reads self.W_enc
+    assert len(calls) > n

@@ -1020,20 +1020,24 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                     W16T[o] = (_Float16)wn;
                     sq[r] += wn * wn;
                     big = big || !(fabsf(wn) <= 6.0e4f);        // outside the fp16 range (or NaN): the filter must not be trusted
-                    if constexpr (MODE != 2) tile[u][ty + 8 * r][tx] = wn;
+                    if constexpr (MODE != 2) { if (W) tile[u][ty + 8 * r][tx] = wn; }
                 }
             }
         if constexpr (MODE != 2) {
+            if (W) {                                                   // (uniform) W == nullptr: the parameter layout is materialised lazily
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < NC; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + 32 * u + ty + 8 * r, j = j0 + tx;
+                        if (i < d_in && j < j_hi) W[(int64_t)i * d_sae + j] = tile[u][tx][ty + 8 * r];
+                    }
+                __syncthreads();
+            }
+        } else {
             __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NC; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + 32 * u + ty + 8 * r, j = j0 + tx;
-                    if (i < d_in && j < j_hi) W[(int64_t)i * d_sae + j] = tile[u][tx][ty + 8 * r];
-                }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1302,7 +1306,9 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     {
         // exact path: hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574) on the fp32 MFMA, W_enc in its own [d_in][d_sae] layout
         GemmParams g = {};
-        g.A = wsb + ws.sae_in; g.lda = d.d_in; g.a_mode = PV_A_PLAIN; g.Bt = st->W_enc; g.ldb = d.d_sae; g.b_kn = 1;
+        g.A = wsb + ws.sae_in; g.lda = d.d_in; g.a_mode = PV_A_PLAIN;
+        if (st->W_encT) { g.Bt = st->W_encT; g.ldb = d.d_in; g.b_kn = 0; }          // the transposed master (always current)
+        else { g.Bt = st->W_enc; g.ldb = d.d_sae; g.b_kn = 1; }                      // no shadows: the parameter's own [K][N] layout
         g.M = N; g.N = d.d_sae; g.K = d.d_in; g.epi = PV_EPI_BIAS; g.bias0 = st->b_enc; g.out0 = wsb + ws.hidden; g.ldo = d.d_sae;
         int rc = pv_launch_gemm(PV_DTYPE_F32, g, stream);
         if (rc) return rc;
@@ -1368,7 +1374,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     const bool sparse = (flags & PV_SAE_SPARSE_GRADS) != 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
-    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
     PV_REQUIRE(st->W_encT, "pv_sae_step needs the transposed encoder copy (pv_sae_state.W_encT, see pv_sae_sync_shadows)");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
     const pv_sae_desc& d = plan->d;
@@ -1519,7 +1525,7 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && pre_sum && topk_idx && topk_val && out && workspace, "null argument");
     PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
-    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
     PV_REQUIRE(st->W_encT, "the transposed encoder copy (pv_sae_state.W_encT) is required");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
     const pv_sae_desc& d = plan->d;

@@ -10,7 +10,7 @@
 // in their epilogues -- no [N, d_sae] tensor is read or written except f itself (once) and dH over it (in place):
 //
 //   prep      (sae.hip)  LN-in, sae_in = x_hat - b_dec, loss normaliser
-//   G1  f  = relu(sae_in W_enc + b_enc)                 epilogue: bias, ReLU, store f; per-64-row column counts of f > 0
+//   G1  f  = relu(sae_in W_enc + b_enc)  (W_enc^T read)  epilogue: bias, ReLU, store f; per-64-row column counts of f > 0
 //                                                        (firing statistics, l0) and per-wave sums of f (the L1 term)
 //   G2  pre = f W_dec  (split-K: [tokens x d_in] is only 192 tiles)   -> partial sums
 //   finish    sae_out = (pre + b_dec) std + mu, err, mse partials, dY                  (one wave per token)
@@ -330,7 +330,7 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
-    PV_REQUIRE(st->W_enc && st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
     PV_REQUIRE(st->W_encT, "the transposed encoder copy (pv_sae_state.W_encT) is required");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
     const pv_sae_desc& d = plan->d;
@@ -366,9 +366,11 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + (double)N * F) * 4.0);
         // G1: f = relu(sae_in @ W_enc + b_enc)
         DenseGemm g = {};
-        g.A = sae_in; g.lda = D; g.B = st->W_enc; g.ldb = F; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
+        // (W_enc is read as its transposed fp32 master W_encT [F][D] -- the copy Adam runs in, always current; the parameter's
+        // own layout may be materialised lazily)
+        g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart;
-        rc = launch_dense_gemm<false, true, DG_EPI_ENC>(g, 1, stream);
+        rc = launch_dense_gemm<false, false, DG_EPI_ENC>(g, 1, stream);
         if (rc) return rc;
         // firing counts, statistics, l0, l1
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,

@@ -660,28 +660,32 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     }
 }
 
-// exact fp32 hidden_pre rows of the tokens the filter could not decide -> hidden scratch
-__global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restrict__ sae_in, const float* __restrict__ W_enc,
+// exact fp32 hidden_pre rows of the tokens the filter could not decide -> hidden scratch.  Reads W_enc as W_encT (the fp32
+// master the Adam kernel keeps; the parameter's own layout may be stale): a wave per feature, the 3 KB row coalesced against
+// the token's row in LDS.
+__global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restrict__ sae_in, const float* __restrict__ W_encT,
                                                             const float* __restrict__ b_enc, const int32_t* __restrict__ fb_list,
                                                             const uint32_t* __restrict__ fb_count, float* __restrict__ hidden,
                                                             int d, int d_sae) {
     __shared__ float xs[1024];
     const uint32_t nfb = *fb_count;
-    const int j = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int jper = (d_sae + gridDim.y - 1) / gridDim.y;
+    const int j_lo = blockIdx.y * jper, j_hi = min(d_sae, j_lo + jper);
     for (uint32_t s = blockIdx.x; s < nfb; s += gridDim.x) {
         const int64_t row = fb_list[s];
         __syncthreads();
         for (int i = threadIdx.x; i < d; i += 256) xs[i] = sae_in[row * d + i];
         __syncthreads();
-        if (j < d_sae) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = 0; i < d; ++i) {
-                const float4 w = *reinterpret_cast<const float4*>(W_enc + (int64_t)i * d_sae + j);
-                const float x = xs[i];
-                a.x = fmaf(x, w.x, a.x); a.y = fmaf(x, w.y, a.y); a.z = fmaf(x, w.z, a.z); a.w = fmaf(x, w.w, a.w);
+        for (int j = j_lo + wv; j < j_hi; j += 4) {
+            const float* w = W_encT + (int64_t)j * d;
+            float a = 0.f;
+            for (int i = 4 * lane; i < d; i += 256) {
+                const float4 wv4 = *reinterpret_cast<const float4*>(w + i);
+                a = fmaf(xs[i], wv4.x, a); a = fmaf(xs[i + 1], wv4.y, a); a = fmaf(xs[i + 2], wv4.z, a); a = fmaf(xs[i + 3], wv4.w, a);
             }
-            const float4 b = *reinterpret_cast<const float4*>(b_enc + j);
-            *reinterpret_cast<float4*>(hidden + row * d_sae + j) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            a = wave_sum(a);
+            if (lane == 0) hidden[row * d_sae + j] = a + b_enc[j];
         }
     }
 }
@@ -747,7 +751,7 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     PV_LAUNCH_CHECK("sae_select_kernel");
     // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)
     hipLaunchKernelGGL(sae_fb_hidden_kernel, dim3(PV_SAE_FB_SLOTS, (d.d_sae + 1023) / 1024), dim3(256), 0, stream,
-                       (const float*)(wsb + ws.sae_in), (const float*)st->W_enc, (const float*)st->b_enc, (const int32_t*)fb_list,
+                       (const float*)(wsb + ws.sae_in), (const float*)st->W_encT, (const float*)st->b_enc, (const int32_t*)fb_list,
                        (const uint32_t*)fb_count, (float*)(wsb + ws.hidden), d.d_in, d.d_sae);
     PV_LAUNCH_CHECK("sae_fb_hidden_kernel");
     sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, fb_list, fb_count, PV_SAE_FB_SLOTS, feat_cnt, wpos, stream);

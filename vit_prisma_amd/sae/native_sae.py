@@ -92,6 +92,12 @@ class NativeSAE:
         self._shadow_key: Optional[Tuple[int, int]] = None
         self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
         self._grad_fresh = False                                   # gradient buffers exactly as the last step wrote them
+        # lazy_w_enc: ``apply`` keeps the encoder in W_encT (+ fp16 shadow) only and leaves the parameter's own [d_in, d_sae]
+        # layout stale (its transposed write is 75 MB per step at 768 -> 24576); ``materialize_w_enc()`` rewrites it.  The
+        # kernels never read that layout.  Off by default: whoever turns it on (VisionSAETrainer, single process) also makes
+        # sure readers of the parameter trigger the materialisation (StandardSparseAutoencoder._native_sync).
+        self.lazy_w_enc = False
+        self._w_enc_stale = False
         self.sync_shadows()
 
     def __del__(self):
@@ -103,14 +109,15 @@ class NativeSAE:
             pass
 
     # ------------------------------------------------------------------------------------------
-    def _state(self) -> N.SaeState:
+    def _state(self, with_w_enc: bool = False) -> N.SaeState:
         P, g, m, v = self.params, self._g, self._m, self._v
         if self.inference:
             return N.SaeState(W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(),
                               b_dec=P["b_dec"].data_ptr(), W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(),
                               enc_colsq=self.enc_colsq.data_ptr())
         return N.SaeState(
-            W_enc=P["W_enc"].data_ptr(), W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(), b_dec=P["b_dec"].data_ptr(),
+            W_enc=None if (self.lazy_w_enc and not with_w_enc) else P["W_enc"].data_ptr(),
+            W_dec=P["W_dec"].data_ptr(), b_enc=P["b_enc"].data_ptr(), b_dec=P["b_dec"].data_ptr(),
             gW_enc=g["W_encT"].data_ptr(), gW_dec=g["W_dec"].data_ptr(), gb_enc=g["b_enc"].data_ptr(), gb_dec=g["b_dec"].data_ptr(),
             mW_enc=m["W_encT"].data_ptr(), mW_dec=m["W_dec"].data_ptr(), mb_enc=m["b_enc"].data_ptr(), mb_dec=m["b_dec"].data_ptr(),
             vW_enc=v["W_encT"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
@@ -136,10 +143,18 @@ class NativeSAE:
 
     def sync_shadows(self, from_transposed: bool = False, j_lo: int = 0, j_hi: Optional[int] = None) -> None:
         """Rebuild W_encT / W_enc16T / enc_colsq from W_enc (default), or W_enc / W_enc16T / enc_colsq from W_encT."""
-        st = self._state()
+        st = self._state(with_w_enc=True)
         N.check(self.lib.pv_sae_sync_shadows(self._plan, C.byref(st), int(from_transposed), int(j_lo),
                                              int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_sync_shadows")
         self._shadow_key = self._w_enc_key()
+        if j_lo == 0 and (j_hi is None or j_hi == self.d_sae):
+            self._w_enc_stale = False                              # both layouts agree again
+
+    def materialize_w_enc(self) -> None:
+        """lazy_w_enc: bring the parameter's own layout up to date with the transposed master the kernels train (no-op when
+        it is)."""
+        if self._w_enc_stale:
+            self.sync_shadows(from_transposed=True)
 
     def invalidate(self) -> None:
         """Forget everything derived from the parameters (encoder shadows, the decoder's inverse row norms): the next
@@ -151,7 +166,7 @@ class NativeSAE:
         """An in-place edit of W_enc from outside (optimizer.step() of another trainer, load_state_dict, .copy_) bumps
         the tensor's version counter; the library's own updates go through raw pointers and do not."""
         if self._shadow_key != self._w_enc_key():
-            self.sync_shadows()
+            self.sync_shadows()                                    # (the outside edit is the truth now, stale or not)
 
     # ---- the step ----------------------------------------------------------------------------------
     def _w_dec_key(self) -> Tuple[int, int]:
@@ -249,6 +264,8 @@ class NativeSAE:
         self._grad_fresh = False
         full = j_lo == 0 and (j_hi is None or j_hi == self.d_sae)
         self._inv_norm_key = self._w_dec_key() if full else None
+        if self.lazy_w_enc:
+            self._w_enc_stale = True
 
     def encode_topk(self, x: torch.Tensor, want_ln_stats: bool = True):
         """(idx [N,k] int32, val [N,k], mu [N], std [N]) -- the sparse form of feature_acts.  want_ln_stats=False: no copies

@@ -303,6 +303,28 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         self._native_pref = flag
         return self
 
+    # ---- parameters a native training engine keeps in its own layout -------------------------------------------------
+    # VisionSAETrainer's single-process engine trains W_enc in its transposed fp32 master and rewrites the parameter's own
+    # [d_in, d_sae] layout only on demand (NativeSAE.lazy_w_enc).  Every way of reaching the parameter goes through one of
+    # these, so a reader always sees current values.
+    def _native_sync(self) -> None:
+        fn = self.__dict__.get("_native_sync_fn")
+        if fn is not None:
+            fn()
+
+    def __getattr__(self, name: str):
+        if name == "W_enc":
+            self._native_sync()
+        return super().__getattr__(name)
+
+    def state_dict(self, *args, **kwargs):
+        self._native_sync()
+        return super().state_dict(*args, **kwargs)
+
+    def named_parameters(self, *args, **kwargs):
+        self._native_sync()
+        return super().named_parameters(*args, **kwargs)
+
     def _native_reason(self, x: torch.Tensor, need_hidden_pre: bool = False) -> Optional[str]:
         cfg = self.cfg
         if getattr(self, "_native_pref", None) is False:

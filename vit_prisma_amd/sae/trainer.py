@@ -175,7 +175,7 @@ class VisionSAETrainer:
         cfg = sae.cfg
         common = (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.dtype == torch.float32 and not cfg.use_ghost_grads
                   and cfg.normalize_activations in ("layer_norm", "none", None)
-                  and all(p.is_cuda and p.dtype == torch.float32 for p in sae.parameters())
+                  and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
                   and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                   and self._native_pref is not False)
         if not common:
@@ -192,7 +192,7 @@ class VisionSAETrainer:
     def _get_engine(self, sae, n_tokens: int):
         from .native_sae import NativeSAE
         eng = self._engine
-        stale = eng is not None and any(eng.params[n].data_ptr() != getattr(sae, n).data_ptr()
+        stale = eng is not None and any(eng.params[n].data_ptr() != sae._parameters[n].data_ptr()
                                         for n in ("W_enc", "W_dec", "b_enc", "b_dec"))     # e.g. b_dec.data re-bound by an init
         if eng is None or eng.max_tokens < n_tokens or stale:
             if self.world > 1 and eng is None:
@@ -204,7 +204,10 @@ class VisionSAETrainer:
                 for p in sae.parameters():
                     dist.broadcast(p.data, src=0)
             old = eng
-            eng = NativeSAE(sae.W_enc, sae.W_dec, sae.b_enc, sae.b_dec,
+            if old is not None:
+                old.materialize_w_enc()                          # (the new engine derives its shadows from the parameter)
+            P_ = sae._parameters
+            eng = NativeSAE(P_["W_enc"], P_["W_dec"], P_["b_enc"], P_["b_dec"],
                             k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
                             layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world))
@@ -212,6 +215,11 @@ class VisionSAETrainer:
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
                 eng.adam_step = old.adam_step
+            if self.world == 1:
+                # one process: nobody but the kernels reads W_enc between steps -- they read its transposed master -- so the
+                # parameter's own layout is rewritten only when somebody asks for it (sae.W_enc, state_dict(), parameters())
+                eng.lazy_w_enc = True
+                object.__setattr__(sae, "_native_sync_fn", eng.materialize_w_enc)
             self._engine = eng
         return eng
 
@@ -241,6 +249,8 @@ class VisionSAETrainer:
             if eng is not None:
                 eng.invalidate()
             self._fp_dirty = False
+        if self._engine is not None:
+            self._engine.materialize_w_enc()                     # (single process: the lazily kept parameter layout of W_enc)
         if not self._pending:
             return
         for w in self._pending:
@@ -318,6 +328,7 @@ class VisionSAETrainer:
             self._native_dp_step(eng, sae, x, lr, act_freq_scores, n_since_fired)
         optimizer._opt_called = True                            # the native apply IS the optimizer step
         scheduler.step()
+        self._invalidate_inference_engine(sae)
         sc = eng.scalars.clone()
         return sc[0], sc[1], None, sc[2]
 
@@ -357,8 +368,17 @@ class VisionSAETrainer:
         eng.apply(lr, self.cfg.max_grad_norm)
         optimizer._opt_called = True
         scheduler.step()
+        self._invalidate_inference_engine(sae)
         sc = eng.scalars.clone()
         return sc[0], sc[1], sc[4], sc[2]
+
+    @staticmethod
+    def _invalidate_inference_engine(sae) -> None:
+        """The training kernels update the parameters through raw pointers (no version bump): the module's own inference
+        engine (StandardSparseAutoencoder.forward / encode on the HIP path) must re-derive its shadows before its next use."""
+        inf = sae.__dict__.get("_engine")
+        if inf is not None:
+            inf.invalidate()
 
     def _make_shard_engine(self, sae, max_tokens: int):
         """Engine over one rank's feature shard (tests substitute the CPU twin)."""
