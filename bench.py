@@ -493,6 +493,13 @@ def main():
         torch.cuda.empty_cache()
         e2e = leg("sae_end_to_end", lambda: sae_end_to_end_leg(dev, dist=dist, feature_parallel=fp))
         torch.cuda.empty_cache()
+        if world == 1:
+            # the same loop at the reference config's own store shape (store_batch_size 32 x n_batches_in_buffer 20, config.py:351-352):
+            # 16 000 tokens per refill = 3.9 train steps, the ViT harvests 32 images at a time
+            e2e_ref = leg("sae_end_to_end_ref_store", lambda: sae_end_to_end_leg(dev, dist=None, steps=40, warmup=24, store_bs=32, n_buf=20))
+            if isinstance(e2e, dict) and isinstance(e2e_ref, dict):
+                e2e["reference_store_shape"] = {k: e2e_ref.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "harvested_tokens_per_trained_token", "error") if k in e2e_ref}
+            torch.cuda.empty_cache()
         if world > 1:
             # SURVEY.md 8(d) config 4 asks for both: strong (global batch 4096, above) and weak (4096 tokens per GPU) scaling
             weak = leg("sae_weak", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=False, weak=True))

@@ -17,6 +17,8 @@
  *   - the library never allocates device memory: weights are borrowed from the caller's module
  *     parameters, MFMA-layout weight shadows, workspaces and every tap destination are caller-owned
  *     (sizes from the *_bytes queries).  Plans are not thread-safe; one plan per device.
+ *     Two debug / measurement facilities are the exceptions and say so where they are declared: pv_debug_gemm_trace_arm
+ *     (hipMalloc of a 256 KB stamp buffer on first use, never freed) and pv_prof_enable (a pool of HIP events).
  */
 #ifndef PV_NATIVE_H
 #define PV_NATIVE_H
@@ -234,7 +236,8 @@ int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flop
 
 /* Debug only (tools/gemm_trace.py): per-workgroup phase stamps {t_start, t_loop_end, t_end, hw_id} (100 MHz wall
  * clock) of the launch_idx-th plain GEMM launch from now; read blocks until the device is idle.
- * info6 = {M, N, K, epilogue, n_workgroups, kernel id}. */
+ * info6 = {M, N, K, epilogue, n_workgroups, kernel id}.  NOT part of the product path: the first arm hipMalloc's a
+ * 256 KB device buffer owned by the library (the one place it allocates device memory) and hipMemset's it. */
 int pv_debug_gemm_trace_arm(int32_t launch_idx);
 int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6);
 

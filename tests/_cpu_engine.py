@@ -33,6 +33,13 @@ class OracleEngine:
         self.n_fwd_since_fired = torch.zeros(self.d_sae)
         self.adam_step = 0
         self.filtered_encoder = False
+        self.lazy_w_enc = False
+
+    def materialize_w_enc(self):                                  # (NativeSAE.lazy_w_enc: this twin keeps W_enc current)
+        pass
+
+    def invalidate(self):
+        pass
 
     def _P(self):
         return {n: t.numpy() for n, t in self.params.items()}          # (numpy views of the parameter storage)

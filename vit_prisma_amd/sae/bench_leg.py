@@ -104,7 +104,7 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     N.prof_enable(False)
-    tr._dp_flush()
+    tr.sync_parameters()                                          # (outside the timed region: module parameters complete and current)
     eng = tr._fp.engine if feature_parallel else tr._engine
     assert tr.last_step_native and eng is not None
     if dist is not None:
@@ -181,7 +181,7 @@ class _ResidentImages(torch.utils.data.Dataset):
 
 
 def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: int = 64, feature_parallel: bool = True,
-                       overlap_harvest: bool = True) -> dict:
+                       overlap_harvest: bool = True, store_bs: int = 256, n_buf: int = 8) -> dict:
     """Config 3, second number: the training loop the reference runs -- VisionActivationsStore
     harvesting ``blocks.6.hook_resid_post`` from randn images through ViT blocks 0..6 (native run_with_cache,
     names_filter + stop_at_layer), half-buffer shuffle-mix, VisionSAETrainer.train_step on the fused native step.
@@ -202,7 +202,8 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
     model = HookedViT(HookedViTConfig(**arch, dtype=torch.bfloat16, device="cuda"))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
     model = model.to(torch.bfloat16).to(dev).eval().use_native(True)
-    store_bs, n_buf = 256, 8
+    # store shape: 256 x 8 by default (the GPU wants big harvest batches); (32, 20) = the reference config's own defaults
+    # (config.py:351-352), timed as bench.py's sae.end_to_end_reference_store_shape
     cfg = VisionModelSAERunnerConfig(
         hook_point_layer=6, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
         activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, normalize_activations="layer_norm",
@@ -210,7 +211,7 @@ def sae_end_to_end_leg(dev: torch.device, dist=None, steps: int = 52, warmup: in
         max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
         context_size=50, store_batch_size=store_bs, n_batches_in_buffer=n_buf)
     # every rank holds the same index space; the store's DistributedSampler hands each rank 4 store batches per epoch
-    data = _ResidentImages(4 * store_bs * world, dev, torch.bfloat16, seed=77)
+    data = _ResidentImages(max(4 * store_bs, 256) * world, dev, torch.bfloat16, seed=77)
     sae = StandardSparseAutoencoder(cfg)
     tr = VisionSAETrainer(cfg, model=model, dataset=data, sparse_coder=sae).use_feature_parallel(bool(feature_parallel))
     act, since, frac, opt, sched = tr.initialize_training_variables()

@@ -236,11 +236,15 @@ class VisionSAETrainer:
         all-gather of the other ranks' updated rows is still in flight (it overlaps the next harvest); the next
         ``train_step``, ``checkpoint`` and the end of ``run`` wait for it themselves -- call this before reading
         ``sae.W_enc`` / ``W_dec`` / ``b_enc`` in between."""
-        self._dp_flush()
+        self._dp_flush(materialize=True)
 
-    def _dp_flush(self) -> None:
-        """Wait for the parameter all-gathers of the previous step and rebuild the other ranks' rows of W_enc / W_enc16T."""
-        if self._fp is not None and self._fp_dirty:         # feature parallel: gather the shards into the module
+    def _dp_flush(self, materialize: bool = False) -> None:
+        """Wait for the parameter all-gathers of the previous step and rebuild the other ranks' rows of W_enc / W_enc16T.
+        materialize (sync_parameters / checkpoint / end of run; NOT the per-step call): also bring the module's parameters up to
+        date with what the engines train -- the feature-parallel shards, the lazily kept layout of W_enc."""
+        if materialize and self._engine is not None:
+            self._engine.materialize_w_enc()                     # (single process: the lazily kept parameter layout of W_enc)
+        if materialize and self._fp is not None and self._fp_dirty:         # feature parallel: gather the shards into the module
             P = self._fp.gather_parameters()
             with torch.no_grad():
                 for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
@@ -249,8 +253,6 @@ class VisionSAETrainer:
             if eng is not None:
                 eng.invalidate()
             self._fp_dirty = False
-        if self._engine is not None:
-            self._engine.materialize_w_enc()                     # (single process: the lazily kept parameter layout of W_enc)
         if not self._pending:
             return
         for w in self._pending:
@@ -492,7 +494,7 @@ class VisionSAETrainer:
                     "sparsity/below_1e-6": (feature_sparsity < 1e-6).float().mean().item()}, step=n_training_steps)
 
     def checkpoint(self, sae, n_training_tokens, act_freq_scores, n_frac_active_tokens):
-        self._dp_flush()
+        self._dp_flush(materialize=True)
         if self.rank != 0:
             return
         folder = self.cfg.checkpoint_path
@@ -538,7 +540,7 @@ class VisionSAETrainer:
                 if n_training_steps % 50 == 0:        # .item() syncs the stream: keep it off the hot loop
                     pbar.set_description(f"Training SAE: Loss: {float(loss):.4f}, MSE Loss: {float(mse_loss):.4f}, "
                                          f"L0: {float(l0):.4f}", refresh=False)
-        self._dp_flush()
+        self._dp_flush(materialize=True)
         if cfg.n_checkpoints:
             self.checkpoint(self.sparse_coder, n_training_tokens, act_freq_scores, n_frac_active_tokens)
         if pbar is not None:
