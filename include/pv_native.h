@@ -377,12 +377,28 @@ int pv_sae_tp_bucket_unpack(pv_sae_plan* plan, const float* bucket, float* scala
  * st->g*, complete buffers), for feature activations that are not k-sparse: five dense GEMMs on the exact fp32 matrix
  * instruction with the elementwise work in their epilogues (sae_dense.hip).  plan->d.k is ignored.  flags:
  * PV_SAE_UPDATE_STATS, PV_SAE_RENORM_DECODER (set_decoder_norm_to_unit_norm is applied to W_dec in place, first).
- * scalars: 0 loss = mse + l1, 1 mse_loss, 2 l0 (mean_n #(f > 0)), 4 l1_loss = l1_coefficient * mean_n ||f_n||_1.
+ * scalars: 0 loss = mse + l1 (+ ghost), 1 mse_loss, 2 l0 (mean_n #(f > 0)), 4 l1_loss = l1_coefficient * mean_n ||f_n||_1,
+ * 5 ghost residual loss (0 without pv_sae_ghost).
  * out->topk_idx / topk_val are unused; out->fire_count [d_sae] and out->sae_out [N, d_in] are optional.
  * Follow with pv_sae_grad_sqnorm (the whole flat gradient buffer) and pv_sae_apply.  d_in % 8 == 0, d_sae % 8 == 0. */
+/* Ghost gradients (use_ghost_grads: SparseAutoencoder._compute_ghost_residual_loss sae.py:151-179, train_sae.py:337-346): the
+ * caller lists the features that count as dead BEFORE this step (n_forward_passes_since_fired > dead_feature_window) --
+ * dead_idx [n_dead] ascending, dead_slot [d_sae] = position of feature j in that list or -1 -- and owns the extra workspace
+ * (pv_sae_ghost_workspace_bytes).  The step then adds the ghost residual loss (scalars[5]; the reference adds it even when
+ * no feature is dead) and its gradient: exp(hidden_pre) of the dead columns leaves the encoder GEMM's epilogue, three small
+ * GEMMs over the dead columns do the rest, the result joins dH in the G3 epilogue and gW_dec by a row scatter-add.
+ * Single process only (n_global == n_tokens).  NULL = no ghost gradients. */
+typedef struct pv_sae_ghost {
+    int32_t n_dead;
+    const int32_t* dead_idx;
+    const int32_t* dead_slot;
+    void* workspace;
+    size_t workspace_bytes;
+} pv_sae_ghost;
+size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t n_dead);
 int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
-                      int32_t n_global, int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

@@ -43,13 +43,15 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
 
 
 def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
-                n_global: Optional[int] = None, l1_coefficient: float = 0.0) -> Dict[str, Array]:
+                n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
     :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
     (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
 
     batch_mean / n_global: the data-parallel form -- mean_n(x) over the GLOBAL
-    batch and the global token count; default = this batch (single process, the reference)."""
+    batch and the global token count; default = this batch (single process, the reference).
+    dead_mask [d_sae] bool (use_ghost_grads, training): adds _compute_ghost_residual_loss (sae/sae.py:151-179) -- also when
+    no feature is dead (ghost_out is then zero and the term is a constant: the reference adds it all the same)."""
     dt = x.dtype.type
     N, d = x.shape
     if layer_norm:
@@ -77,8 +79,24 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     if k is None:                                                      # :617-626: sparsity = ||f||_1 per token, mean over the batch
         l1 = dt(l1_coefficient) * (np.abs(feats).sum(axis=-1).sum() / dt(ng))
         loss = mse + l1
+    gh = None
+    if dead_mask is not None:                                          # sae/sae.py:151-179
+        res = x - sae_out
+        rc = res - res.mean(axis=0, keepdims=True)
+        l2 = np.sqrt((res ** 2).sum(axis=-1))
+        E = np.exp(hidden_pre[:, dead_mask])
+        G0 = E @ P["W_dec"][dead_mask]
+        s = l2 / (dt(1e-6) + np.sqrt((G0 ** 2).sum(axis=-1)) * dt(2))         # (detached)
+        G = G0 * s[:, None]
+        den = np.sqrt((rc ** 2).sum(axis=-1, keepdims=True))                   # (detached)
+        mg = (G - res) ** 2 / den
+        r = dt(mse) / (mg + dt(1e-6))                                          # (detached)
+        ghost = (r * mg).mean(dtype=np.float64)
+        gh = dict(E=E, s=s, G=G, res=res, den=den, r=r, mask=dead_mask, loss=dt(ghost))
+        loss = loss + dt(ghost)
     return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
-                mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0)
+                mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0,
+                ghost=gh, ghost_loss=None if gh is None else gh["loss"])
 
 
 def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True,
@@ -99,6 +117,11 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     if fw.get("l1_loss") is not None:
         d_feats = d_feats + dt(l1_coefficient) / dt(ng)
     d_hidden = np.where(feats > 0 if gate is None else gate, d_feats, dt(0))     # topk scatter + ReLU gates
+    gh = fw.get("ghost")
+    if gh is not None and gh["mask"].any():                           # gradient of the ghost residual loss: through ghost_out only
+        dG0 = gh["r"] * dt(2) * (gh["G"] - gh["res"]) / gh["den"] / dt(N * d) * gh["s"][:, None]
+        g["W_dec"][gh["mask"]] += gh["E"].T @ dG0
+        d_hidden[:, gh["mask"]] += (dG0 @ P["W_dec"][gh["mask"]].T) * gh["E"]
     g["W_enc"] = fw["sae_in"].T @ d_hidden
     g["b_enc"] = d_hidden.sum(axis=0)
     d_sae_in = d_hidden @ P["W_enc"].T
@@ -153,11 +176,13 @@ def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, 
 
 
 def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: Optional[int], lr: float,
-               step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, float]:
+               step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
+               dead_feature_window: Optional[int] = None) -> Dict[str, float]:
     """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
     firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count)."""
     renorm_decoder(P)                                                   # :306-307
-    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient)
+    dead = None if dead_feature_window is None else stats["n_fwd_since_fired"] > dead_feature_window      # :330-332 (use_ghost_grads)
+    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead)
     fired = (fw["feature_acts"] > 0).sum(axis=0)                        # :356-361
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0
@@ -166,4 +191,5 @@ def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dic
     total = clip_and_project(P, g, max_grad_norm)
     adam_step(P, g, opt["m"], opt["v"], lr, step)
     return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total,
-                l1_loss=None if fw["l1_loss"] is None else float(fw["l1_loss"]))
+                l1_loss=None if fw["l1_loss"] is None else float(fw["l1_loss"]),
+                ghost_loss=None if fw["ghost_loss"] is None else float(fw["ghost_loss"]))

@@ -203,18 +203,20 @@ def test_native_equals_pytorch_hook_path_and_fallback_dispatch():
         for k in c_t.keys():
             assert c_n[k].shape == c_t[k].shape and c_n[k].dtype == c_t[k].dtype, k
             assert rel_fro(c_n[k].cpu().numpy(), c_t[k].cpu().numpy()) < FP32_TOL, k
-        # a mutating user hook on a residual-stream point splits the native plan; anywhere else it must run as a
-        # Python callback inside the PyTorch forward: auto mode falls back, force mode raises
+        # a mutating user hook on a residual-stream point (or on q / k / v / z / mlp post) splits the native plan; anywhere
+        # else it must run as a Python callback inside the PyTorch forward: auto mode falls back, force mode raises
         model.use_native(None)
         zero = lambda t, hook: torch.zeros_like(t)  # noqa: E731
         _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_attn_out", zero)])
         assert model.last_run_native and float(c_h["blocks.0.hook_attn_out"].abs().max()) == 0.0
         assert torch.equal(c_h["blocks.0.hook_resid_mid"], c_h["blocks.0.hook_resid_pre"])
-        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", zero)])
-        assert not model.last_run_native and float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", zero)])           # inside the block: split there too
+        assert model.last_run_native and float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])
+        assert not model.last_run_native and float(c_h["blocks.0.attn.hook_pattern"].abs().max()) == 0.0
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", zero)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])
     # weight edits are picked up (version counter) -> output changes
     model.use_native(True)
     with torch.no_grad():

@@ -87,3 +87,24 @@ def test_relu_l1_three_steps_vs_reference_fixture():
         assert np.array_equal(stats["n_fwd_since_fired"], g[f"relu_l1_s{t}_n_since"])
     for n in P:
         assert rel_fro(P[n], g[f"relu_l1_s2_param_{n}"]) < 1e-5, n
+
+
+def test_relu_ghost_three_steps_vs_reference_fixture():
+    """Ghost gradients (use_ghost_grads, a third of the features dead from the start): the oracle's ReLU + L1 + ghost form
+    against the reference's own run (relu_ghost of tests/golden/sae_variants_steps.npz)."""
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, d_sae, N, l1c = 64, 512, 256, 2e-3
+    P = {n: g[f"relu_ghost_init_{n}"].copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": g["relu_ghost_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    assert (stats["n_fwd_since_fired"] > 1).sum() > 100
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), None, lr=1e-3, step=t + 1, l1_coefficient=l1c,
+                           dead_feature_window=1)
+        loss, mse, l1, l0, ghost = g[f"relu_ghost_s{t}_scalars"][:5]
+        assert abs(out["loss"] - loss) <= 2e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        assert abs(out["ghost_loss"] - ghost) <= 2e-5 * abs(ghost) and abs(out["l1_loss"] - l1) <= 1e-5 * abs(l1), (t, out, ghost)
+        assert np.array_equal(stats["act_freq_scores"], g[f"relu_ghost_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"relu_ghost_s{t}_n_since"])
+    for n in P:
+        assert rel_fro(P[n], g[f"relu_ghost_s2_param_{n}"]) < 2e-5, n

@@ -65,6 +65,11 @@ class SaeState(C.Structure):
         "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq", "dec_inv_norm")]
 
 
+class SaeGhost(C.Structure):
+    _fields_ = [("n_dead", C.c_int32), ("dead_idx", C.c_void_p), ("dead_slot", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
 class SaeOut(C.Structure):
     _fields_ = [("sae_out", C.c_void_p), ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p),
                 ("scalars", C.c_void_p), ("fire_count", C.c_void_p)]
@@ -82,7 +87,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_sae_tp_partial", "pv_sae_tp_finish", "pv_sae_tp_merge", "pv_sae_tp_bucket_pack", "pv_sae_tp_bucket_unpack",
-    "pv_sae_dense_step",
+    "pv_sae_dense_step", "pv_sae_ghost_workspace_bytes",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -137,7 +142,10 @@ def lib() -> C.CDLL:
         L.pv_sae_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_tp_partial.argtypes = [vp, C.POINTER(SaeState), vp, vp, i32, i32, vp, vp]
         L.pv_sae_tp_finish.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp, vp, i32, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
-        L.pv_sae_dense_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_dense_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeGhost),
+                                        C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_ghost_workspace_bytes.argtypes = [vp, i32, i32]
+        L.pv_sae_ghost_workspace_bytes.restype = sz
         L.pv_sae_tp_merge.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.pv_sae_tp_bucket_pack.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.pv_sae_tp_bucket_unpack.argtypes = [vp, vp, vp, vp]

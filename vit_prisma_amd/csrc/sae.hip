@@ -1283,6 +1283,15 @@ int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int
     return PV_OK;
 }
 
+// out[c] = scale * sum_rows x[r][c] for a [rows][d] matrix; `partial` = (rows / 16 + 1) * d floats of scratch
+int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream) {
+    const int nblk = (rows + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, partial, rows, d);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(1024), 0, stream, (const float*)partial, out, nblk, d, scale);
+    PV_LAUNCH_CHECK("colsum kernels");
+    return PV_OK;
+}
+
 // out[slot] (and out[slot2] when >= 0) = scale * sum(v[0..n)), one workgroup, fixed order
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream) {
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v, out, n, scale, slot, slot2);

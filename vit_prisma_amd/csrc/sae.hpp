@@ -64,4 +64,5 @@ int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const flo
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
               hipStream_t stream);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream);
+int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);
 constexpr int PV_SAE_DENSE_SPLITK = 4;       // K splits of the dense decoder GEMM (M = tokens, N = d_in: too few tiles otherwise)

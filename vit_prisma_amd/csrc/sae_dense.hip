@@ -37,7 +37,7 @@ constexpr int DG_TILE = DG_BM * DG_ROWB;      // 18432 >= 32 * 528
 constexpr int DG_CS_LD = 68;                  // fp32 staging row of the epilogue (floats)
 constexpr int DG_LDS = 4 * DG_TILE;           // As[2] + Bs[2] = 73728 >= 4 waves x 64 x 68 x 4
 
-enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2 };
+enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3 };
 
 struct DenseGemm {
     const float* A; int64_t lda;              // A_KM ? [K][lda] (M contiguous) : [M][lda] (K contiguous)
@@ -50,6 +50,11 @@ struct DenseGemm {
     float* colpart;                           // ENC / DH: [ceil(M / 64)][N] column partials of the wave's 64-row block
     float* rowpart;                           // ENC: [ceil(M / 64)][ceil(N / 64)] sums of f over the wave's 64 x 64 block
     float add;                                // DH: l1_coefficient / N_global
+    // ghost gradients (sae.py:151-179): the dead features' columns, compacted
+    const int32_t* dead_slot;                 // ENC / DH: [N] column -> compact slot of a dead feature, -1 otherwise; or NULL
+    float* dead_act; int64_t ldd;             // ENC: exp(hidden_pre) of the dead columns -> dead_act[row][slot];  DH: the ghost term of
+                                              //      d loss / d hidden_pre, added to dH there
+    const float* mul;                         // MUL: out = acc * mul (same shape and leading dimension as out)
 };
 
 // 16 bytes from global memory, or zeros (a plain branch: `ok ? *p : zero` makes hipcc select between two ADDRESSES and park the
@@ -193,6 +198,15 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         for (int i = 0; i < 8; ++i) b8[i] = 0.f;
         if (col_ok) load8(p.bias + gn, b8);
     }
+    int dslot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dslot[i] = -1;
+    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_DH) {
+        if (p.dead_slot && col_ok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dslot[i] = p.dead_slot[gn + i];
+        }
+    }
     float* outz = p.out + (int64_t)blockIdx.y * p.out_zstride;
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
@@ -205,6 +219,13 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
             v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
             float* o = outz + (int64_t)gm * p.ldo + gn;
             if constexpr (EPI == DG_EPI_ENC) {
+                if (p.dead_slot) {                                     // ghost gradients: exp(hidden_pre) of the dead features (sae.py:163)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int sl = dslot[i];
+                        if (sl >= 0) p.dead_act[(int64_t)gm * p.ldd + sl] = __expf(v[i] + b8[i]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = fmaxf(v[i] + b8[i], 0.f);                   // hidden_pre + b_enc -> ReLU (sae.py:567-577)
@@ -217,13 +238,19 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = f8[i] > 0.f ? v[i] + p.add : 0.f;           // d loss / d hidden_pre = (dF + l1 / N) [f > 0]
+                    if (p.dead_slot && dslot[i] >= 0) v[i] += p.dead_act[(int64_t)gm * p.ldd + dslot[i]];    // + the ghost term (not gated)
                     csum[i] += v[i];                                  // gb_enc
                 }
+            } else if constexpr (EPI == DG_EPI_MUL) {
+                float m8[8];
+                load8(p.mul + (int64_t)gm * p.ldo + gn, m8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= m8[i];
             }
             store8(o, v);
         }
     }
-    if constexpr (EPI != DG_EPI_STORE) {
+    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_DH) {
         // the wave's 64 rows of each column: lanes with equal (lane & 7) hold the same 8 columns
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -290,7 +317,8 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            int64_t zstride, const float* __restrict__ b_dec, const float* __restrict__ mu,
                                                            const float* __restrict__ sd, const float* __restrict__ norm,
                                                            float* __restrict__ sae_out, float* __restrict__ dY,
-                                                           float* __restrict__ loss_partial, int n_tok, int d, float grad_scale) {
+                                                           float* __restrict__ loss_partial, int n_tok, int d, float grad_scale,
+                                                           float* __restrict__ err_out) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -308,6 +336,7 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
         o.x = (a.x + bd.x) * sdv + m; o.y = (a.y + bd.y) * sdv + m; o.z = (a.z + bd.z) * sdv + m; o.w = (a.w + bd.w) * sdv + m;
         e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
         if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + c) = o;
+        if (err_out) *reinterpret_cast<float4*>(err_out + (int64_t)n * d + c) = e;
         lsum += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;
         g.x = grad_scale * e.x / nf * sdv; g.y = grad_scale * e.y / nf * sdv;
         g.z = grad_scale * e.z / nf * sdv; g.w = grad_scale * e.w / nf * sdv;
@@ -317,16 +346,100 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
     if (lane == 0) loss_partial[n] = lsum;
 }
 
-// scalars[0] = mse + l1 (sae.py:628), one thread
-__global__ void dense_loss_kernel(float* __restrict__ scalars) { scalars[0] = scalars[1] + scalars[4]; }
+// scalars[0] = mse + l1 (+ ghost) (sae.py:628), one thread
+__global__ void dense_loss_kernel(float* __restrict__ scalars, int ghost) {
+    if (!ghost) scalars[5] = 0.f;
+    scalars[0] = scalars[1] + scalars[4] + scalars[5];
+}
+
+// ---- ghost gradients (SparseAutoencoder._compute_ghost_residual_loss, sae.py:151-179) ---------------------------------------
+// rows of W_dec of the dead features, compacted (zero rows up to the padded count)
+__global__ __launch_bounds__(256) void ghost_gather_rows_kernel(const float* __restrict__ W_dec, const int32_t* __restrict__ dead_idx,
+                                                                int n_dead, int n_pad, int d, float* __restrict__ out) {
+    const int s = blockIdx.x;
+    const float* src = s < n_dead ? W_dec + (int64_t)dead_idx[s] * d : nullptr;
+    for (int c = threadIdx.x; c < d; c += 256) out[(int64_t)s * d + c] = src ? src[c] : 0.f;
+}
+// gW_dec[dead_idx[s]] += add[s]
+__global__ __launch_bounds__(256) void ghost_scatter_add_rows_kernel(float* __restrict__ gW_dec, const int32_t* __restrict__ dead_idx,
+                                                                     int n_dead, int d, const float* __restrict__ add) {
+    const int s = blockIdx.x;
+    if (s >= n_dead) return;
+    float* dst = gW_dec + (int64_t)dead_idx[s] * d;
+    for (int c = threadIdx.x; c < d; c += 256) dst[c] += add[(int64_t)s * d + c];
+}
+// One wave per token.  res = x - sae_out = -err; G0 = exp(hidden_pre[:, dead]) @ W_dec[dead]:
+//   s = ||res|| / (1e-6 + 2 ||G0||)  (detached);  G = s G0;  den = || res - mean_batch(res) ||  (detached)
+//   mg = (G - res)^2 / den;  r = mse_loss / (mg + 1e-6)  (detached);  ghost loss = mean(r mg)
+//   d ghost / d G0 = s r 2 (G - res) / (den N d)
+__global__ __launch_bounds__(256) void ghost_rows_kernel(const float* __restrict__ err, const float* __restrict__ G0,
+                                                         const float* __restrict__ colmean_err, const float* __restrict__ scalars,
+                                                         float* __restrict__ dG0, float* __restrict__ part, int n_tok, int d,
+                                                         float inv_count) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    const float* e = err + (int64_t)n * d;
+    const float* g0 = G0 + (int64_t)n * d;
+    float r2 = 0.f, g2 = 0.f, c2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float res = -e[i], g = g0[i], rc = res + colmean_err[i];        // res - mean(res) = -(err - mean(err))
+        r2 += res * res; g2 += g * g; c2 += rc * rc;
+    }
+    r2 = wave_sum(r2); g2 = wave_sum(g2); c2 = wave_sum(c2);
+    const float s = sqrtf(r2) / (1e-6f + 2.0f * sqrtf(g2));
+    const float den = sqrtf(c2);
+    const float mse = scalars[1];
+    float acc = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float res = -e[i], diff = g0[i] * s - res;
+        const float mg = diff * diff / den;
+        const float r = mse / (mg + 1e-6f);
+        acc += r * mg;
+        dG0[(int64_t)n * d + i] = s * r * 2.0f * diff / den * inv_count;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[n] = acc;
+}
 
 }  // namespace
+
+namespace {
+struct GhostWs {
+    size_t total, dead_act, dhd, wdd, g0, dg0, err, tmpw, colmean, part, colpart;
+    int n_pad;
+};
+GhostWs ghost_carve(const pv_sae_desc& d, int N, int n_dead) {
+    GhostWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    w.n_pad = n_dead > 0 ? (n_dead + 7) / 8 * 8 : 0;
+    const size_t P = w.n_pad, D = d.d_in, n = N;
+    w.dead_act = take(n * P * 4);
+    w.dhd = take(n * P * 4);
+    w.wdd = take(P * D * 4);
+    w.tmpw = take(P * D * 4);
+    w.g0 = take(n * D * 4);
+    w.dg0 = take(n * D * 4);
+    w.err = take(n * D * 4);
+    w.colmean = take(D * 4);
+    w.part = take(n * 4);
+    w.colpart = take((n / 16 + 2) * D * 4);
+    w.total = off + 256;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t n_dead) {
+    if (!plan || n_tokens < 1 || n_dead < 0) return 0;
+    return ghost_carve(plan->d, n_tokens, n_dead).total;
+}
 
 // One train step of the ReLU + L1 SAE on N tokens: forward + backward + statistics; gradients are WRITTEN into st->g*
 // (complete buffers: pv_sae_grad_sqnorm and pv_sae_apply follow as usual).  scalars: 0 loss, 1 mse_loss, 2 l0, 4 l1_loss.
 extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
-                                 int32_t n_global, int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace,
-                                 size_t workspace_bytes, void* stream_) {
+                                 int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
@@ -337,6 +450,18 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
     PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
     PV_REQUIRE(d.d_in % 8 == 0 && d.d_sae % 8 == 0, "the dense step needs d_in and d_sae to be multiples of 8");
+    // ghost gradients (sae.py:151-179; train_sae.py:337-346): the caller lists the dead features (n_forward_passes_since_fired
+    // > dead_feature_window BEFORE this step's statistics) and owns the extra workspace
+    GhostWs gw = {};
+    unsigned char* gwb = nullptr;
+    const int nd = ghost ? ghost->n_dead : 0;
+    if (ghost) {
+        PV_REQUIRE(n_global == N, "ghost gradients: single process only");
+        PV_REQUIRE(nd >= 0 && nd <= d.d_sae && ghost->workspace && (nd == 0 || (ghost->dead_idx && ghost->dead_slot)), "pv_sae_ghost");
+        gw = ghost_carve(d, N, nd);
+        PV_REQUIRE(ghost->workspace_bytes >= gw.total && ((uintptr_t)ghost->workspace & 255) == 0, "ghost workspace too small / misaligned");
+        gwb = (unsigned char*)ghost->workspace;
+    }
     const SaeWs ws = sae_carve(d);
     PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
     PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
@@ -370,6 +495,10 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         // own layout may be materialised lazily)
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart;
+        if (nd > 0) {
+            PV_HIP_CHECK(hipMemsetAsync(gwb + gw.dead_act, 0, (size_t)N * gw.n_pad * 4, stream));       // (padding columns stay zero)
+            g.dead_slot = ghost->dead_slot; g.dead_act = (float*)(gwb + gw.dead_act); g.ldd = gw.n_pad;
+        }
         rc = launch_dense_gemm<false, false, DG_EPI_ENC>(g, 1, stream);
         if (rc) return rc;
         // firing counts, statistics, l0, l1
@@ -393,20 +522,66 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         const float grad_scale = 2.0f / ((float)n_global * (float)D);
         hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, (const float*)kpart, S, (int64_t)N * D,
                            (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
-                           (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D, grad_scale);
+                           (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D, grad_scale,
+                           ghost ? (float*)(gwb + gw.err) : (float*)nullptr);
         PV_LAUNCH_CHECK("dense_finish_kernel");
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream);
-        hipLaunchKernelGGL(dense_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
+        if (ghost) {
+            // ghost forward: G0 = exp(hidden_pre[:, dead]) @ W_dec[dead]; loss and d loss / d G0 per token; then the part of
+            // d loss / d hidden_pre that reaches the dead columns, dHd = (dG0 @ W_dec[dead]^T) * exp(hidden_pre[:, dead])
+            float* g0 = (float*)(gwb + gw.g0);
+            float* dg0 = (float*)(gwb + gw.dg0);
+            float* err = (float*)(gwb + gw.err);
+            float* act = (float*)(gwb + gw.dead_act);
+            float* wdd = (float*)(gwb + gw.wdd);
+            if (nd > 0) {
+                hipLaunchKernelGGL(ghost_gather_rows_kernel, dim3(gw.n_pad), dim3(256), 0, stream, (const float*)st->W_dec, ghost->dead_idx,
+                                   nd, gw.n_pad, D, wdd);
+                DenseGemm gg = {};
+                gg.A = act; gg.lda = gw.n_pad; gg.B = wdd; gg.ldb = D; gg.M = N; gg.N = D; gg.K = gw.n_pad; gg.k_chunk = gw.n_pad;
+                gg.out = g0; gg.ldo = D;
+                rc = launch_dense_gemm<false, true, DG_EPI_STORE>(gg, 1, stream);
+                if (rc) return rc;
+            } else {
+                PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
+            }
+            rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0,
+                               (const float*)(gwb + gw.colmean), (const float*)out->scalars, dg0, (float*)(gwb + gw.part), N, D,
+                               1.0f / ((float)N * (float)D));
+            PV_LAUNCH_CHECK("ghost_rows_kernel");
+            sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, 1.0f / ((float)N * (float)D), 5, -1, stream);
+            if (nd > 0) {
+                DenseGemm gb = {};
+                gb.A = dg0; gb.lda = D; gb.B = wdd; gb.ldb = D; gb.M = N; gb.N = gw.n_pad; gb.K = D; gb.k_chunk = D;
+                gb.out = (float*)(gwb + gw.dhd); gb.ldo = gw.n_pad; gb.mul = act;
+                rc = launch_dense_gemm<false, false, DG_EPI_MUL>(gb, 1, stream);
+                if (rc) return rc;
+            }
+        }
+        hipLaunchKernelGGL(dense_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, ghost ? 1 : 0);
         // G4: gW_dec = f^T @ dY
         DenseGemm g4 = {};
         g4.A = f; g4.lda = F; g4.B = dY; g4.ldb = D; g4.M = F; g4.N = D; g4.K = N; g4.k_chunk = N;
         g4.out = st->gW_dec; g4.ldo = D;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
+        if (nd > 0) {                                                 // gW_dec[dead] += exp(hidden_pre[:, dead])^T @ dG0
+            DenseGemm gt = {};
+            gt.A = (float*)(gwb + gw.dead_act); gt.lda = gw.n_pad; gt.B = (float*)(gwb + gw.dg0); gt.ldb = D;
+            gt.M = gw.n_pad; gt.N = D; gt.K = N; gt.k_chunk = N; gt.out = (float*)(gwb + gw.tmpw); gt.ldo = D;
+            rc = launch_dense_gemm<true, true, DG_EPI_STORE>(gt, 1, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ghost_scatter_add_rows_kernel, dim3(nd), dim3(256), 0, stream, st->gW_dec, ghost->dead_idx, nd, D,
+                               (const float*)(gwb + gw.tmpw));
+            PV_LAUNCH_CHECK("ghost_scatter_add_rows_kernel");
+        }
         // G3: dH = (dY @ W_dec^T + l1 / N) [f > 0], over f
         DenseGemm g3 = {};
         g3.A = dY; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
         g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global;
+        if (nd > 0) { g3.dead_slot = ghost->dead_slot; g3.dead_act = (float*)(gwb + gw.dhd); g3.ldd = gw.n_pad; }      // + the ghost term
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, st->gb_enc,

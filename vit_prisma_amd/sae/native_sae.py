@@ -209,19 +209,36 @@ class NativeSAE:
 
     def dense_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
-                   renorm_decoder: bool = True) -> None:
+                   renorm_decoder: bool = True, dead_mask: Optional[torch.Tensor] = None) -> None:
         """The ReLU + L1 step (pv_sae_dense_step): forward + backward + statistics on dense fp32 MFMA GEMMs with fused
-        epilogues; gradients are written into ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss.  The engine's
-        ``k`` plays no role."""
+        epilogues; gradients are written into ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, ghost loss.  The
+        engine's ``k`` plays no role.  dead_mask [d_sae] bool (use_ghost_grads: ``n_forward_passes_since_fired >
+        dead_feature_window`` BEFORE this step, train_sae.py:330-332): adds the ghost residual loss and its gradient
+        (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs)."""
         x = self._check_x(x)
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
         bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        ghost = None
+        if dead_mask is not None:
+            idx = torch.nonzero(dead_mask.to(self.device), as_tuple=False).flatten().to(torch.int32)     # (synchronises: n_dead is a launch size)
+            nd = int(idx.numel())
+            slot = torch.full((self.d_sae,), -1, dtype=torch.int32, device=self.device)
+            if nd:
+                slot[idx.long()] = torch.arange(nd, dtype=torch.int32, device=self.device)
+            need = self.lib.pv_sae_ghost_workspace_bytes(self._plan, n, nd)
+            gws = getattr(self, "_ghost_ws", None)
+            if gws is None or gws.numel() < need:
+                self._ghost_ws = gws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ghost_keep = (idx, slot)                        # (alive until the kernels have run)
+            ghost = N.SaeGhost(n_dead=nd, dead_idx=idx.data_ptr() if nd else None, dead_slot=slot.data_ptr(),
+                               workspace=gws.data_ptr(), workspace_bytes=gws.numel())
         N.check(self.lib.pv_sae_dense_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                            int(n_global if n_global is not None else n),
                                            int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient),
+                                           C.byref(ghost) if ghost is not None else None,
                                            C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
                 "pv_sae_dense_step")
         self._inv_norm_key = None

@@ -8,9 +8,9 @@ firing statistics -> backward -> clip_grad_norm_ -> remove parallel gradient -> 
 
 On an MI355X (fp32 standard SAE with layer_norm / no input normalisation, no ghost grads) the step runs on
 ``NativeSAE`` (HIP kernels) directly on the module's parameter storage -- the k-sparse step for top-k, the
-dense fused step (exact fp32 MFMA GEMMs with ReLU / L1 / loss / gate epilogues) for ReLU + L1; Adam moments
-live in the engine.  Everything else (gated, transcoder, ghost grads, tanh-relu, CPU) takes the PyTorch path
-below, which is the reference algorithm verbatim.
+dense fused step (exact fp32 MFMA GEMMs with ReLU / L1 / loss / gate epilogues) for ReLU + L1, ghost gradients
+included; Adam moments live in the engine.  Everything else (gated, transcoder, tanh-relu, top-k with ghost grads,
+CPU) takes the PyTorch path below, which is the reference algorithm verbatim.
 
 Data parallel (new functionality, SURVEY.md section 8e -- the reference is single-process): one process
 per GPU, each with its share of the global token batch and a 1/W shard of the OPTIMIZER, by feature
@@ -173,16 +173,17 @@ class VisionSAETrainer:
         """Which fused HIP step serves this SAE: "topk" (k-sparse step, sae.hip), "relu" (dense ReLU + L1 step,
         sae_dense.hip) or None (PyTorch path: gated / transcoder / ghost gradients / other activations / CPU)."""
         cfg = sae.cfg
-        common = (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.dtype == torch.float32 and not cfg.use_ghost_grads
+        common = (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
                   and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                   and self._native_pref is not False)
         if not common:
             return None
-        if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64:
+        if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64 and not cfg.use_ghost_grads:
             return "topk"
-        if cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0:
+        if (cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
+                and not (cfg.use_ghost_grads and self.world > 1)):           # (ghost gradients natively: single process)
             return "relu"
         return None
 
@@ -344,7 +345,10 @@ class VisionSAETrainer:
         eng.n_fwd_since_fired = n_since_fired
         l1 = float(sae.l1_coefficient)
         if self.world == 1:
-            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True)
+            dead = None
+            if sae.cfg.use_ghost_grads and sae.training:        # train_sae.py:330-332 (the mask is taken BEFORE this step's statistics)
+                dead = n_since_fired > sae.cfg.dead_feature_window
+            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True, dead_mask=dead)
         else:
             import torch.distributed as dist
             W = self.world
