@@ -437,6 +437,15 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 constexpr int BWD_CH = 16;
 constexpr int BWD_LMAX = 64;
 constexpr int BWD_SEG = 32;
+constexpr int BWD_RANGES = 8;               // token ranges of the long-list backward = XCDs (one L2 each)
+// segments of the long lists: ceil(c / SEG) per list with c > LMAX pairs (count-cut form), or BWD_RANGES per list (token-range
+// form; at most n_pairs / (LMAX + 1) long lists)
+static inline size_t sae_max_segs(size_t n_pairs) {
+    const size_t a = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1, b = (size_t)BWD_RANGES * (n_pairs / (BWD_LMAX + 1) + 1);
+    return a > b ? a : b;
+}
+// the token-range form sorts a list through a token-indexed LDS array: N tokens x 4 bytes (+ scratch) must fit the 160 KB
+static inline bool sae_long_ranged(int n_tokens) { return (size_t)n_tokens * 4 + 4096 <= 150 * 1024; }
 
 // single-workgroup exclusive scan over the d_sae counts, staged through LDS in blocks of 32768 features (one block for
 // the 24 576-feature bench shape, two for the x64 SAEs of docs/sae_table.md: 49 152): coalesced load, per-thread contiguous
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
                                                        int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
-                                                       float* __restrict__ rowsq_sparse) {
+                                                       float* __restrict__ rowsq_sparse, int ranged) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     {   // the cuts at and beyond the total (all threads of the grid: a feature shard of the feature-parallel step keeps a
         // fraction of the N k pairs the cut array is sized for -- 7 of 8 cuts lie beyond the total at world 8)
@@ -520,10 +529,11 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
     }
     for (uint32_t w = (beg + BWD_CH - 1) / BWD_CH; w * BWD_CH < end; ++w) chunk_start[w] = w * BWD_CH == beg ? beg : end;
     if (c > (uint32_t)BWD_LMAX) {
-        const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
-        const uint32_t sb = atomicAdd(&n_long[1], nseg);
         const uint32_t e = atomicAdd(&n_long[0], 1u);
         long_list[3 * e] = j;
+        if (ranged) return;                                       // (sae_long_sort_kernel cuts the list at the token ranges)
+        const uint32_t nseg = (c + BWD_SEG - 1) / BWD_SEG;
+        const uint32_t sb = atomicAdd(&n_long[1], nseg);
         long_list[3 * e + 1] = (int32_t)sb;
         long_list[3 * e + 2] = (int32_t)nseg;
         for (uint32_t sg = 0; sg < nseg && sb + sg < (uint32_t)max_segs; ++sg) {
@@ -678,14 +688,81 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, rowsq, d, k, lane, col, ok);
 }
 
-// long lists, stage 1: one wave per BWD_SEG-pair segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb)
+// long lists, stage 0 (token-range form): sort every long list by token and cut it at the BWD_RANGES token-range boundaries.
+// The 86 us / 608 MB of the count-cut segments were row gathers out of a 25 MB working set (dY + sae_in of 4096 tokens) that no
+// XCD's 4 MB L2 holds: with the lists in token order, segment (feature e, range r) only touches the N / 8 tokens of range r, and
+// the segment kernel gives range r to the workgroups of XCD r (3 MB of rows per L2).  A feature's pairs are DISTINCT tokens,
+// so the sort is a scatter into a token-indexed LDS array + a compaction -- which also makes the summation order of these
+// lists independent of the order the select kernel's atomics drew their positions in.  One workgroup per long feature.
+__global__ __launch_bounds__(256) void sae_long_sort_kernel(int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                            const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs,
+                                                            uint32_t* __restrict__ seg_range, int k, int n_tok, int max_segs) {
+    extern __shared__ int32_t slot[];                      // [n_tok] token -> pair (or -1)
+    __shared__ uint32_t wsum[4], bnd[BWD_RANGES + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nl = n_long[0];
+    if (blockIdx.x == 0 && tid == 0) n_long[1] = min(nl * BWD_RANGES, (uint32_t)max_segs);
+    const int chunk = (n_tok + 255) / 256;
+    const int rs = (n_tok + BWD_RANGES - 1) / BWD_RANGES;
+    for (uint32_t e = blockIdx.x; e < nl; e += gridDim.x) {
+        const int j = long_list[3 * e];
+        const uint32_t beg = offs[j], c = offs[j + 1] - beg;
+        __syncthreads();
+        for (int i = tid; i < n_tok; i += 256) slot[i] = -1;
+        if (tid <= BWD_RANGES) bnd[tid] = tid == 0 ? 0u : c;
+        __syncthreads();
+        for (uint32_t i = tid; i < c; i += 256) {
+            const int32_t p = pairs[beg + i];
+            slot[p / k] = p;
+        }
+        __syncthreads();
+        const int t0 = tid * chunk, t1 = min(t0 + chunk, n_tok);
+        uint32_t cnt = 0;
+        for (int t = t0; t < t1; ++t) cnt += slot[t] >= 0;
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += a;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t base = inc - cnt;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        uint32_t pos = base;
+        for (int t = t0; t < t1; ++t) {
+            if (t > 0 && t % rs == 0) bnd[t / rs] = pos;       // (first token of range t / rs: everything before it)
+            const int32_t p = slot[t];
+            if (p >= 0) pairs[beg + pos++] = p;
+        }
+        __syncthreads();
+        if (tid < BWD_RANGES) {
+            const uint32_t sg = e * BWD_RANGES + tid;
+            if (sg < (uint32_t)max_segs) {
+                seg_range[2 * sg] = beg + bnd[tid];
+                seg_range[2 * sg + 1] = beg + bnd[tid + 1];
+            }
+        }
+        if (tid == 0) {
+            long_list[3 * e + 1] = (int32_t)(e * BWD_RANGES);
+            long_list[3 * e + 2] = BWD_RANGES;
+        }
+    }
+}
+
+// long lists, stage 1: one wave per segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb).  Segments are BWD_SEG-pair
+// cuts (ranged == 0) or the BWD_RANGES token ranges of a sorted list (ranged == 1: segment 8 e + r goes to a workgroup with
+// blockIdx % 8 == r, i.e. to XCD r)
 template <int V4>
-__global__ __launch_bounds__(256) void sae_backward_seg_kernel(
+__global__ __launch_bounds__(512) void sae_backward_seg_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ seg_range, const uint32_t* __restrict__ n_long,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ seg_rows,
-    float* __restrict__ seg_b, int d, int k, int max_segs) {
-    const int lane = threadIdx.x & 63;
+    float* __restrict__ seg_b, int d, int k, int max_segs, int ranged) {
+    constexpr int NW = 8;                                          // waves per workgroup (token-range form: 512 threads)
+    __shared__ __attribute__((aligned(16))) float part[NW * 2 * 256 * V4];      // [wave][gd | ge][256 V4] (token-range form)
+    __shared__ float part_b[NW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nseg = min(n_long[1], (uint32_t)max_segs);
     bool ok[V4];
     int col[V4];
@@ -694,19 +771,65 @@ __global__ __launch_bounds__(256) void sae_backward_seg_kernel(
         col[i] = 4 * lane + 256 * i;
         ok[i] = col[i] < d;
     }
-    for (uint32_t sg = blockIdx.x * 4 + (threadIdx.x >> 6); sg < nseg; sg += gridDim.x * 4) {
+    if (!ranged) {
+        const uint32_t nw = blockDim.x >> 6;
+        for (uint32_t sg = blockIdx.x * nw + wv; sg < nseg; sg += gridDim.x * nw) {
+            BwdAcc<V4> acc;
+            acc.clear();
+            bwd_walk<V4, false>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
+                                nullptr, nullptr, d, k, lane, col, ok);
+            float* o = seg_rows + (int64_t)sg * 2 * d;
+#pragma unroll
+            for (int i = 0; i < V4; ++i)
+                if (ok[i]) {
+                    *reinterpret_cast<float4*>(o + col[i]) = acc.gd[i];
+                    *reinterpret_cast<float4*>(o + d + col[i]) = acc.ge[i];
+                }
+            if (lane == 0) seg_b[sg] = acc.gb;
+        }
+        return;
+    }
+    // token-range form: the WORKGROUP owns segment (long feature e, range r = blockIdx % 8 = its XCD); its eight waves take an
+    // eighth of the segment's (token-sorted) pairs each -- a dense feature has N / 8 pairs per range, one wave alone would be
+    // the kernel's tail -- and their partial rows are summed in wave order through LDS
+    constexpr int DP = 256 * V4;                                  // padded row length (floats)
+    float* pw = part;
+    for (uint32_t e = blockIdx.x >> 3; e * BWD_RANGES < nseg; e += gridDim.x >> 3) {
+        const uint32_t sg = e * BWD_RANGES + (blockIdx.x & 7);
+        const uint32_t q0 = seg_range[2 * sg], q1 = seg_range[2 * sg + 1];
+        const uint32_t per = (q1 - q0 + NW - 1) / NW;
+        const uint32_t w0 = min(q0 + wv * per, q1), w1 = min(w0 + per, q1);
         BwdAcc<V4> acc;
         acc.clear();
-        bwd_walk<V4, false>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
-                            nullptr, nullptr, d, k, lane, col, ok);
-        float* o = seg_rows + (int64_t)sg * 2 * d;
+        bwd_walk<V4, false>(acc, w0, w1, offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr, nullptr, nullptr, d, k, lane, col, ok);
+        __syncthreads();                                          // (the previous segment's reads of part)
 #pragma unroll
-        for (int i = 0; i < V4; ++i)
-            if (ok[i]) {
-                *reinterpret_cast<float4*>(o + col[i]) = acc.gd[i];
-                *reinterpret_cast<float4*>(o + d + col[i]) = acc.ge[i];
+        for (int i = 0; i < V4; ++i) {
+            *reinterpret_cast<float4*>(pw + (wv * 2 + 0) * DP + col[i]) = acc.gd[i];
+            *reinterpret_cast<float4*>(pw + (wv * 2 + 1) * DP + col[i]) = acc.ge[i];
+        }
+        if (lane == 0) part_b[wv] = acc.gb;
+        __syncthreads();
+        // 2 x d floats out: thread t sums column group t (gd for t < 64 V4 ... ) in wave order
+        float* o = seg_rows + (int64_t)sg * 2 * d;
+        for (int c4 = threadIdx.x; c4 < 2 * 64 * V4; c4 += NW * 64) {
+            const int which = c4 / (64 * V4), cc = (c4 - which * 64 * V4) * 4;
+            if (cc < d) {
+                float4 t = *reinterpret_cast<const float4*>(pw + (0 * 2 + which) * DP + cc);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const float4 u = *reinterpret_cast<const float4*>(pw + (w * 2 + which) * DP + cc);
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                *reinterpret_cast<float4*>(o + which * d + cc) = t;
             }
-        if (lane == 0) seg_b[sg] = acc.gb;
+        }
+        if (threadIdx.x == 0) {
+            float t = part_b[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) t += part_b[w];
+            seg_b[sg] = t;
+        }
     }
 }
 
@@ -1106,6 +1229,20 @@ __global__ __launch_bounds__(256) void renorm_rows_kernel(float* __restrict__ W,
     }
 }
 
+int launch_long_sort(int32_t* long_list, uint32_t* n_long, const uint32_t* offs, int32_t* pairs, uint32_t* seg_range, int k, int N,
+                     int max_segs, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&sae_long_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         150 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(sae_long_sort_kernel, dim3(512), dim3(256), (size_t)N * 4, stream, long_list, n_long, offs, pairs, seg_range, k, N,
+                       max_segs);
+    PV_LAUNCH_CHECK("sae_long_sort_kernel");
+    return PV_OK;
+}
+
 }  // namespace
 
 void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
@@ -1138,7 +1275,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     w.long_list = take((size_t)d.d_sae * 12);
     w.n_long = take(256);
     {
-        const size_t max_segs = N * (size_t)d.k / BWD_SEG + N * (size_t)d.k / BWD_LMAX + 1;
+        const size_t max_segs = sae_max_segs(N * (size_t)d.k);
         w.seg_range = take(max_segs * 8);
         w.seg_rows = take(max_segs * 2 * (size_t)d.d_in * 4);
         w.seg_b = take(max_segs * 4);
@@ -1438,7 +1575,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
         const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
         float* rowsq = (float*)(wsb + ws.rowsq);
-        const int max_segs = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1;        // sum ceil(c / SEG) over lists with c > LMAX
+        const int max_segs = (int)sae_max_segs((size_t)n_pairs);
         uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
         float* seg_rows = (float*)(wsb + ws.seg_rows);
         float* seg_b = (float*)(wsb + ws.seg_b);
@@ -1446,9 +1583,15 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
                            max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
-                           out->fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr);
+                           out->fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr,
+                           sae_long_ranged(N) ? 1 : 0);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
+        const int ranged = sae_long_ranged(N) ? 1 : 0;
+        if (ranged) {
+            rc = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
+            if (rc) return rc;
+        }
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
         // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
@@ -1463,10 +1606,10 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
                        (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
-    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
+    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
                        (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
                        (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
-                       d.d_in, k, max_segs);                                                                                     \
+                       d.d_in, k, max_segs, ranged);                                                                             \
     hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
                        (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
                        st->gb_enc, rowsq, d.d_in, max_segs)
@@ -1576,7 +1719,7 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
         uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
         const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
         float* rowsq = (float*)(wsb + ws.rowsq);
-        const int max_segs = n_pairs / BWD_SEG + n_pairs / BWD_LMAX + 1;
+        const int max_segs = (int)sae_max_segs((size_t)n_pairs);
         uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
         float* seg_rows = (float*)(wsb + ws.seg_rows);
         float* seg_b = (float*)(wsb + ws.seg_b);
@@ -1584,9 +1727,14 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
                            out->scalars, 1.0f / (float)N);
         hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
                            max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
-                           out->fire_count, d.d_sae, update_stats, (float*)nullptr, (float*)nullptr);
+                           out->fire_count, d.d_sae, update_stats, (float*)nullptr, (float*)nullptr, sae_long_ranged(N) ? 1 : 0);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, topk_idx,
                            (const uint32_t*)wposp, (const uint32_t*)offs, pairs, n_pairs);
+        const int ranged = sae_long_ranged(N) ? 1 : 0;
+        if (ranged) {
+            const int rcs = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
+            if (rcs) return rcs;
+        }
         PV_LAUNCH_CHECK("csr kernels");
         const dim3 gridf((max_chunks + 3) / 4);
 #define CALL(D)                                                                                                        \
@@ -1595,10 +1743,10 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
     hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
                        (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh,                                       \
                        (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
-    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(1024), block, 0, stream, (const uint32_t*)offs,            \
+    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
                        (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx,           \
                        topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b,            \
-                       d.d_in, k, max_segs);                                                                           \
+                       d.d_in, k, max_segs, ranged);                                                                   \
     hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
                        (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
                        st->gb_enc, rowsq, d.d_in, max_segs)
