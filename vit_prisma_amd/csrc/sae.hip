@@ -1060,6 +1060,57 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
     }
 }
 
+// W_enc's Adam step when the parameter's own [d_in][d_sae] layout is NOT rewritten (lazy materialisation, pv_sae_state.W_enc ==
+// NULL): everything lives in the transposed domain -- the fp32 master WT, gradient, moments, the fp16 shadow and the column
+// norms are all [d_sae][d_in] rows -- so this is the row-streaming form of adam_wdec_kernel (a wave per feature row, 16 bytes
+// per lane and load, no LDS transposes) instead of the 32 x 64 tile walk of wenc_rows_kernel.  Same arithmetic per element.
+template <int V4>
+__global__ __launch_bounds__(256) void adam_wenct_kernel(float* __restrict__ WT, _Float16* __restrict__ W16T, float* __restrict__ colsq,
+                                                         const float* __restrict__ GT, float* __restrict__ MT, float* __restrict__ VT,
+                                                         const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d,
+                                                         const uint32_t* __restrict__ live_offs) {
+    const int lane = threadIdx.x & 63;
+    const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= j_hi) return;
+    const bool live = !live_offs || live_offs[j + 1] != live_offs[j];        // (wave-uniform) PV_SAE_SPARSE_GRADS: no pair, g = 0
+    const float coef = clip_coef(scalars, c.max_norm);
+    float4 w[V4], g[V4], m[V4], v[V4];
+    bool ok[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int col = 4 * lane + 256 * i;
+        ok[i] = col < d;
+        const int64_t o = (int64_t)j * d + col;
+        w[i] = ld4(WT + o, ok[i]);
+        g[i] = ld4(GT + o, ok[i] && live);
+        m[i] = ld4(MT + o, ok[i]);
+        v[i] = ld4(VT + o, ok[i]);
+    }
+    float sq = 0.f;
+    bool big = false;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        if (!ok[i]) continue;
+        const int64_t o = (int64_t)j * d + 4 * lane + 256 * i;
+        float4 wn;
+        wn.x = adam_update(w[i].x, g[i].x * coef, m[i].x, v[i].x, c);
+        wn.y = adam_update(w[i].y, g[i].y * coef, m[i].y, v[i].y, c);
+        wn.z = adam_update(w[i].z, g[i].z * coef, m[i].z, v[i].z, c);
+        wn.w = adam_update(w[i].w, g[i].w * coef, m[i].w, v[i].w, c);
+        *reinterpret_cast<float4*>(WT + o) = wn;
+        *reinterpret_cast<float4*>(MT + o) = m[i];
+        *reinterpret_cast<float4*>(VT + o) = v[i];
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hv = {(_Float16)wn.x, (_Float16)wn.y, (_Float16)wn.z, (_Float16)wn.w};
+        *reinterpret_cast<h4*>(W16T + o) = hv;
+        sq += wn.x * wn.x + wn.y * wn.y + wn.z * wn.z + wn.w * wn.w;
+        big = big || !(fabsf(wn.x) <= 6.0e4f) || !(fabsf(wn.y) <= 6.0e4f) || !(fabsf(wn.z) <= 6.0e4f) || !(fabsf(wn.w) <= 6.0e4f);
+    }
+    sq = wave_sum(sq);
+    const bool any_big = __any(big);                        // outside the fp16 range (or NaN): the filter must not be trusted
+    if (lane == 0) colsq[j] = any_big ? INFINITY : sq;
+}
+
 // ------------------------------------------------------------------------------------------------
 // W_enc lives three times: the module's parameter W [d_in][d_sae]; WT = its transpose [d_sae][d_in] in fp32 -- the
 // layout the sparse backward writes gradients in and the exact re-scoring of sae_enc.hip gathers rows from, hence
@@ -1939,9 +1990,15 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
 #define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm, st->dec_inv_norm, plan->live_offs)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
-        hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
-                           st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi,
-                           plan->live_offs);
+        if (st->W_enc) {
+            hipLaunchKernelGGL((wenc_rows_kernel<0>), dim3((nj + 31) / 32), block, 0, stream, st->W_enc, st->W_encT, (_Float16*)st->W_enc16T,
+                               st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi,
+                               plan->live_offs);
+        } else {                                                  // lazy parameter layout: everything stays in the transposed domain
+#define CALL(D) hipLaunchKernelGGL((adam_wenct_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_encT, (_Float16*)st->W_enc16T, st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, j_lo, j_hi, d.d_in, plan->live_offs)
+            V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        }
         hipLaunchKernelGGL(adam_vec_kernel, dim3((nj + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
                            st->mb_enc, st->vb_enc, scalars, c, j_lo, j_hi);
     }
