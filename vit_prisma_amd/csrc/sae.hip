@@ -346,10 +346,12 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
             const int su = min(s + u, k - 1);
             const int ju = ir[su];
             a[u] = s + u < k ? vr[su] : 0.f;
+            const bool live = a[u] != 0.f;                        // (wave-uniform) a hole -- a candidate that lost the global top-k of the
+                                                                  // feature-parallel step, a clamped negative -- gathers nothing
             if (inv_norm) a[u] *= inv_norm[ju];
             const float* wr = W_dec + (int64_t)ju * d;
 #pragma unroll
-            for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i]);
+            for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i] && live);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)                       // (slot order, as torch's dense matmul would not care; fixed here)
@@ -392,11 +394,13 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
         float dot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int ju = ir[min(s + u, k - 1)];
+            const int su = min(s + u, k - 1);
+            const int ju = ir[su];
+            const bool live = vr[su] > 0.f;                       // (wave-uniform) dh of a hole is gated to 0 below: no gather
             const float* wr = W_dec + (int64_t)ju * d;
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < V4; ++i) t += dot4(g[i], ld4(wr + col[i], ok[i]));
+            for (int i = 0; i < V4; ++i) t += dot4(g[i], ld4(wr + col[i], ok[i] && live));
             dot[u] = inv_norm ? t * inv_norm[ju] : t;
         }
 #pragma unroll
