@@ -65,6 +65,9 @@ class FeatureParallelSAE:
         self.lo, self.hi = shard_range(self.d_sae, rank, world)
         self.shard = shard_tensors(W_enc, W_dec, b_enc, b_dec, rank, world)
         self.engine = eng = make_engine(self.shard["W_enc"], self.shard["W_dec"], self.shard["b_enc"], self.shard["b_dec"])
+        # the shard is this object's private copy and the kernels train its transposed master: the [d_in, shard] layout is
+        # rewritten only when the parameters are gathered (NativeSAE.lazy_w_enc)
+        eng.lazy_w_enc = True
         dev = W_enc.device
         # the two exchange buffers (the engine writes into them in place)
         self.pack = torch.zeros(2, eng.max_tokens, self.k, dtype=torch.int32, device=dev)       # candidate values (bits) | local indices
@@ -133,6 +136,7 @@ class FeatureParallelSAE:
     # ---- parameters back in the module's layout --------------------------------------------------------------------
     def gather_parameters(self) -> Dict[str, torch.Tensor]:
         """Full-size W_enc, W_dec, b_enc, b_dec (every rank gets all of them): checkpoints, evaluation."""
+        self.engine.materialize_w_enc()
         P = self.engine.params
         W_dec = self._all_gather(P["W_dec"]).reshape(self.d_sae, self.d_in)
         b_enc = self._all_gather(P["b_enc"]).reshape(self.d_sae)
@@ -174,6 +178,8 @@ def simulate_step(ranks: List[FeatureParallelSAE], x: torch.Tensor, lr: float, m
 
 def gather_parameters_local(ranks: List[FeatureParallelSAE]) -> Dict[str, torch.Tensor]:
     """The full-size parameters of a simulated world (see ``simulate_step``)."""
+    for fp in ranks:
+        fp.engine.materialize_w_enc()
     P = [fp.engine.params for fp in ranks]
     return dict(W_enc=torch.cat([p["W_enc"] for p in P], dim=1), W_dec=torch.cat([p["W_dec"] for p in P], dim=0),
                 b_enc=torch.cat([p["b_enc"] for p in P]), b_dec=P[0]["b_dec"].clone())
