@@ -100,6 +100,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        # a kernel template whose host-side instantiation failed silently leaves an undefined stub behind: load the library
+        # with immediate binding (in a child process: this one may hold an older copy) before calling it built
+        r = subprocess.run([sys.executable, "-c", f"import ctypes, os; ctypes.CDLL({LIB!r}, mode=os.RTLD_NOW)"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            os.remove(LIB)
+            raise RuntimeError(f"the linked library does not load:\n{r.stderr}")
     if verbose:
         print(f"[vit_prisma_amd.build] {LIB} ({os.path.getsize(LIB) // 1024} kB) from {len(srcs)} HIP sources")
     return LIB
