@@ -1225,269 +1225,6 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// v8: TWO independent 256-thread workgroups per CU, each with a (32*MB) x 256 tile (MB = 5: 160 x 256).
-//   v7's single workgroup leaves the matrix pipe idle for the whole store epilogue (11-15 us of a 37-41 us tile on the
-//   K = 768 GEMMs of B/32: the HBM burst of 240 synchronised tiles, or the GELU's VALU work) and at every slab barrier.
-//   Here the CU holds two workgroups that share nothing: while one stores its tile (or sits at its barrier) the other
-//   multiplies.  A wave's tile is v7's (32*MB x 64: the same fragment-read : MFMA ratio), the B rows are fetched once per
-//   workgroup instead of once per CU (1/98 byte per flop at MB = 5 against v7's 1/142).
-//     * 4 waves as 1 (M) x 4 (N); slot = (32*MB + 256) rows x 64 B = 26 KB at MB = 5; THREE slots per workgroup (78 KB;
-//       two workgroups = 156 of the 160 KB): slab k+2 in flight while slab k is multiplied
-//     * a slab is 2*MB + 16 DMA pieces of 16 rows x 64 B, piece q = j*4 + wave; at MB = 5 that is 26 pieces on 4 waves:
-//       the two missing ones are duplicates of the wave's own first piece (same bytes to the same place), so that every
-//       wave retires the same number and the counted wait is a compile-time vmcnt(NP)
-//     * the software pipeline of v7's LP == 1 form: fragments of a half-slab are fetched behind the MFMA pairs of the
-//       previous one, the barrier of slab s+1 sits between the halves of step s, the pieces of slab s+3 go out behind the
-//       second half's MFMA pairs into the slot the barrier freed
-//     * which of the two workgroups of a CU runs at raised wave priority (GemmParams::prio): both start together on the
-//       one-round GEMMs (480 tiles on 512 slots), and two equal-priority workgroups would march in step -- K loops
-//       together at half rate each, then both epilogues together.  The workgroup with the even slot id (HW_ID.TG_ID) takes
-//       the matrix pipe first and stores while the other multiplies.
-//   M = 25600 (512 images x 50 tokens): 160 row tiles; N = 768: 480 tiles = one round of the 512 slots.
-// ---------------------------------------------------------------------------------------------------
-template <typename T, int MB, int EPI, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_v8(const GemmParams p) {
-    static_assert(sizeof(T) == 2, "v8 is a bf16 kernel");
-    constexpr int TM = 32 * MB;
-    constexpr int TN = 256;
-    constexpr int A_PIECES = 2 * MB, PIECES = A_PIECES + 16;
-    constexpr int NP = (PIECES + 3) / 4;                     // pieces per wave per slab
-    constexpr int A_BYTES = A_PIECES * 1024, SLOT = PIECES * 1024;
-    static_assert(3 * SLOT <= 80 * 1024, "two workgroups per CU");
-    static_assert(2 * NP <= 15, "vmcnt immediates below use the low 4 bits only");
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring2[SLOT];
-    constexpr int EB = DT<T>::kBytes;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
-    const int nblk = (ntn + 7) / 8;
-    const int wblk = (ntn + nblk - 1) / nblk;
-    const int blk = swz / (ntm * wblk);
-    const int rem = swz - blk * (ntm * wblk);
-    const int wcur = min(wblk, ntn - blk * wblk);
-    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-    trace_stamp(p.trace, bid, 0);
-    if (p.prio) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        const unsigned bit = p.prio == 1 ? (hw >> 16) & 1u : (p.prio == 2 ? hw & 1u : (unsigned)((bid >> 3) / 32) & 1u);
-        if (bit == 0) __builtin_amdgcn_s_setprio(3);
-    }
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk = (int)(Kb / 64);                                       // (whole 64-byte slabs: the launcher checks)
-    const unsigned a_span = (unsigned)p.M * (unsigned)p.lda * EB, b_span = (unsigned)p.N * (unsigned)p.ldb * EB;
-    // piece q = j*4 + wave: 16 rows x 64 B; lane -> row (lane >> 2), chunk position (lane & 3) holding k-chunk pos ^ ((row >> 2) & 3)
-    const unsigned swz16 = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-    const unsigned pA0 = (unsigned)(m0 + (lane >> 2)) * (unsigned)p.lda * EB + swz16;
-    const unsigned pB0 = (unsigned)(n0 + (lane >> 2)) * (unsigned)p.ldb * EB + swz16;
-    const unsigned sA = 16u * (unsigned)p.lda * EB, sB = 16u * (unsigned)p.ldb * EB;
-    unsigned pbase[NP];
-    int pdst[NP];
-    bool pisA[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int q = j * 4 + wave;
-        const int qe = q < PIECES ? q : wave;                            // (the duplicates)
-        pisA[j] = qe < A_PIECES;
-        pbase[j] = pisA[j] ? pA0 + (unsigned)qe * sA : pB0 + (unsigned)(qe - A_PIECES) * sB;
-        pdst[j] = qe * 1024;
-    }
-    auto issue_piece = [&](int kt, unsigned char* slot, int j) {
-        const unsigned o = (kt >= nk) ? 0xffffff00u : pbase[j] + (unsigned)kt * 64u;
-        // (a wave-uniform choice of operand: the descriptor is four scalar selects)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pisA[j] ? p.A : p.Bt), 0,
-                                                                            (int)(pisA[j] ? a_span : b_span), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(slot + pdst[j]), 16, o, 0, 0, 0);
-    };
-    auto issue_all = [&](int kt, unsigned char* slot) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) issue_piece(kt, slot, j);
-    };
-
-    f32x16 acc[MB][2];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int sw = (l31 >> 2) & 3;
-    const int co0 = ((0 + half) ^ sw) * 16, co1 = ((2 + half) ^ sw) * 16;
-    const int a_row = l31 * 64;
-    const int b_row = A_BYTES + (wn * 64 + l31) * 64;
-
-    // epilogue operands in flight before the K loop (see v7)
-    const int e_gn = n0 + wn * 64 + (lane & 7) * 8;
-    const bool e_live = e_gn < p.N;
-    const int e_rows_left = e_live ? p.M - (m0 + (lane >> 3)) : 0;
-    uint4 e_bias = make_uint4(0, 0, 0, 0);
-    constexpr int NRES = EPI == PV_EPI_RESID ? MB : 1;
-    uint4 e_res[NRES][4];
-#pragma unroll
-    for (int mi = 0; mi < NRES; ++mi)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
-    int e_col = e_gn;
-    T* e_out0 = reinterpret_cast<T*>(p.out0);
-    const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + (lane >> 3)) * p.ldr + e_gn;
-#define PV_V8_FETCH_RES(MI)                                                                          \
-    if constexpr (EPI == PV_EPI_RESID) {                                                             \
-        _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
-            if ((MI) * 32 + it * 8 < e_rows_left)                                                    \
-                e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr); \
-    }
-    if (e_live) {
-        const T* bias = reinterpret_cast<const T*>(p.bias0);
-        if constexpr (EPI == PV_EPI_QKV) {
-            const int which = e_gn / p.nsplit;
-            e_col = e_gn - which * p.nsplit;
-            if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
-            if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
-        }
-        if (bias) e_bias = *reinterpret_cast<const uint4*>(bias + e_col);
-    }
-    // (the residual rows of block 0 are fetched behind the K loop: 16 more registers across it would spill)
-
-    auto rdA = [&](const unsigned char* slot, int h, int mi) {
-        return *reinterpret_cast<const uint4*>(slot + a_row + mi * 2048 + (h == 0 ? co0 : co1));
-    };
-    auto rdB = [&](const unsigned char* slot, int h, int ni) {
-        return *reinterpret_cast<const uint4*>(slot + b_row + ni * 2048 + (h == 0 ? co0 : co1));
-    };
-    constexpr int BPOS = MB >= 4 ? 1 : 0;
-    uint4 fa[MB], fb0[2], fb1[2];
-#define PV_V8_PIN() __builtin_amdgcn_sched_barrier(0)
-#define PV_V8_PAIR(MI, FB)                                                                                   \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                     \
-            acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                           \
-                __builtin_bit_cast(bf16x8, fa[MI]), __builtin_bit_cast(bf16x8, FB[ni]), acc[MI][ni], 0, 0, 0);
-    // step KT: slab KT in CUR (visible), slab KT+1 arriving in NXT, slab KT+2 in flight; fa / fb0 hold the first half of slab KT
-#define PV_V8_STEP(KT, CUR, NXT)                                                                             \
-        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
-            PV_V8_PAIR(mi, fb0)                                                                              \
-            PV_V8_PIN();                                                                                     \
-            fa[mi] = rdA(CUR, 1, mi);                                                                        \
-            if (mi == BPOS) { fb1[0] = rdB(CUR, 1, 0); fb1[1] = rdB(CUR, 1, 1); }                            \
-            PV_V8_PIN();                                                                                     \
-        }                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        __builtin_amdgcn_s_waitcnt(0x0F70 | NP);                                                             \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                  \
-            PV_V8_PAIR(mi, fb1)                                                                              \
-            PV_V8_PIN();                                                                                     \
-            fa[mi] = rdA(NXT, 0, mi);                                                                        \
-            if (mi == BPOS) { fb0[0] = rdB(NXT, 0, 0); fb0[1] = rdB(NXT, 0, 1); }                            \
-            issue_piece((KT) + 3, CUR, mi);                                                                  \
-            if (mi + MB < NP) issue_piece((KT) + 3, CUR, mi + MB);                                           \
-            PV_V8_PIN();                                                                                     \
-        }
-    static_assert(NP <= 2 * MB, "at most two DMA pieces behind an MFMA pair");
-    issue_all(0, ring0);
-    issue_all(1, ring1);
-    issue_all(2, ring2);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NP));
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA(ring0, 0, mi);
-    fb0[0] = rdB(ring0, 0, 0); fb0[1] = rdB(ring0, 0, 1);
-    {
-        int kt = 0;
-        for (; kt + 3 <= nk; kt += 3) {
-            PV_V8_STEP(kt, ring0, ring1)
-            PV_V8_STEP(kt + 1, ring1, ring2)
-            PV_V8_STEP(kt + 2, ring2, ring0)
-        }
-        if (kt < nk) { PV_V8_STEP(kt, ring0, ring1) }
-        if (kt + 1 < nk) { PV_V8_STEP(kt + 1, ring1, ring2) }
-    }
-#undef PV_V8_STEP
-#undef PV_V8_PAIR
-#undef PV_V8_PIN
-    PV_V8_FETCH_RES(0)
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
-    __syncthreads();
-    trace_stamp(p.trace, bid, 1);
-
-    constexpr int CLD = 64;
-    float* Cs = reinterpret_cast<float*>(wave < 3 ? ring0 + wave * (32 * CLD * 4) : ring1);
-    const pv_f32x2 e_b[4] = {unpack2(e_bias.x), unpack2(e_bias.y), unpack2(e_bias.z), unpack2(e_bias.w)};
-    const int64_t e_row0 = (int64_t)(m0 + (lane >> 3)) * p.ldo;
-    T* const o0_base = e_out0 ? e_out0 + e_row0 + e_col : nullptr;
-    T* const o1_base = reinterpret_cast<T*>(p.out1) + e_row0 + e_gn;
-    const float* Cr = Cs + (lane >> 3) * CLD + (lane & 7) * 8;
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                Cs[row * CLD + ni * 32 + l31] = acc[mi][ni][e];
-            }
-        __builtin_amdgcn_wave_barrier();
-        if (2 * mi + 1 < MB) { PV_V8_FETCH_RES((2 * mi + 1 < MB ? 2 * mi + 1 : 0)) }
-        if (2 * mi + 2 < MB) { PV_V8_FETCH_RES((2 * mi + 2 < MB ? 2 * mi + 2 : 0)) }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            if (mi * 32 + it * 8 < e_rows_left) {
-                const float4 x0 = *reinterpret_cast<const float4*>(Cr + it * 8 * CLD);
-                const float4 x1 = *reinterpret_cast<const float4*>(Cr + it * 8 * CLD + 4);
-                const int64_t ro = (int64_t)(mi * 32 + it * 8) * p.ldo;
-                epi8_bf16<EPI, ACT>(x0, x1, e_b, o0_base ? o0_base + ro : nullptr, o1_base + ro,
-                                    e_res[EPI == PV_EPI_RESID ? mi : 0][it]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef PV_V8_FETCH_RES
-    trace_stamp(p.trace, bid, 2);
-}
-
-template <typename T, int MB>
-int launch_v8(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + 32 * MB - 1) / (32 * MB), ntn = (p.N + 255) / 256;
-    {
-        constexpr double EBd = DT<T>::kBytes;
-        const double mn = (double)p.M * p.N;
-        double outs = 1.0;
-        if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-        if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-        const dim3 grid(ntm * ntn), block(256);
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        const bool timed = !g_pv_tuning.prof_markers &&
-                           pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
-        ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-#define PV_V8_LAUNCH(EPI, ACT)                                                                                      \
-    do {                                                                                                            \
-        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v8<T, MB, EPI, ACT>), grid, block, 0, stream, ev0, ev1, 0, p); \
-        else hipLaunchKernelGGL((gemm_kernel_v8<T, MB, EPI, ACT>), grid, block, 0, stream, p);                      \
-    } while (0)
-        if (p.epi == PV_EPI_BIAS) PV_V8_LAUNCH(PV_EPI_BIAS, 0);
-        else if (p.epi == PV_EPI_QKV) PV_V8_LAUNCH(PV_EPI_QKV, 0);
-        else if (p.epi == PV_EPI_RESID) PV_V8_LAUNCH(PV_EPI_RESID, 0);
-        else if (p.act == PV_ACT_GELU) PV_V8_LAUNCH(PV_EPI_ACT, PV_ACT_GELU);
-        else if (p.act == PV_ACT_QUICK_GELU) PV_V8_LAUNCH(PV_EPI_ACT, PV_ACT_QUICK_GELU);
-        else PV_V8_LAUNCH(PV_EPI_ACT, PV_ACT_RELU);
-#undef PV_V8_LAUNCH
-    }
-    PV_LAUNCH_CHECK("gemm_kernel_v8");
-    return PV_OK;
-}
-
 // v4 or v7 for this shape?  Cost model = rounds over the chip x time of one round, the round times being the
 // measured per-tile K-loop + epilogue of the two kernels at K = 768 on the B/32 shapes (tools/gemm_trace.py):
 // v4 25 us for 3 x (128 x 128) per CU, v7 26.5 us (MB = 4) / 32 us (MB = 5) for one (64*MB) x 256 per CU.
@@ -1530,10 +1267,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             if constexpr (EB == 2) {
                 if (p.vec_out && p.N % 8 == 0) {
                     const int pick = pick_v7(p);
-                    if (pick == 8 && ((int64_t)p.K * EB) % 64 == 0 &&
-                        ((uint64_t)p.M + 320) * (uint64_t)p.lda * EB < 0xffffff00ull && ((uint64_t)p.N + 320) * (uint64_t)p.ldb * EB < 0xffffff00ull)
-                        return launch_v8<T, 5>(p, stream);
-                    if (pick == 5 || pick == 8) return launch_v7<T, 5>(p, stream);
+                    if (pick == 5) return launch_v7<T, 5>(p, stream);
                     if (pick == 4) return launch_v7<T, 4>(p, stream);
                 }
             }
@@ -1547,7 +1281,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             p.M % (p.pG * p.pG) == 0 && img_bytes < 0xffffff00ull && (uint64_t)(p.N + 256) * p.ldb * EB < 0xffffff00ull &&
             !g_pv_tuning.gemm_v1 && !g_pv_tuning.gemm_v1patch) {
             const int pick = pick_v7(p);
-            if (pick == 5 || pick == 8) return launch_v7<T, 5>(p, stream);
+            if (pick == 5) return launch_v7<T, 5>(p, stream);
             if (pick == 4) return launch_v7<T, 4>(p, stream);
         }
     }
@@ -1586,14 +1320,13 @@ extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int3
 
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     p.dbg = g_pv_tuning.gemm_dbg;
-    p.prio = g_pv_tuning.gemm_prio;
     p.trace = nullptr;
     if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {
         if (g_trace_countdown-- == 0) {
             p.trace = g_trace_dev;
             const bool bf16_big = dtype == PV_DTYPE_BF16 && p.M > 0 && (p.ldo * 2) % 16 == 0 && p.N % 8 == 0;
             const int v7 = bf16_big ? pick_v7(p) : 0;           // (mirrors dispatch(): which kernel will trace this launch)
-            const int tm = v7 == 8 ? 160 : (v7 == 5 ? 320 : (v7 ? 256 : 128)), tn = v7 ? 256 : 128;
+            const int tm = v7 == 5 ? 320 : (v7 ? 256 : 128), tn = v7 ? 256 : 128;
             g_trace_info[0] = p.M; g_trace_info[1] = p.N; g_trace_info[2] = p.K; g_trace_info[3] = p.epi;
             g_trace_info[4] = ((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn); g_trace_info[5] = v7 ? 70 + v7 : 4;
             if (g_trace_info[4] > TRACE_MAX_WG) p.trace = nullptr;

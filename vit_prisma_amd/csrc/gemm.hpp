@@ -33,7 +33,6 @@ struct GemmParams {
     int64_t ldr;
     int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
     uint64_t* trace;         // debug: per-workgroup {t_start, t_loop_end, t_end, hw_id} (100 MHz wall clock) or NULL
-    int32_t prio;            // two-workgroups-per-CU kernel: which workgroup of a CU runs at raised wave priority (PvTuning::gemm_prio)
     int32_t dbg;             // ablation switches for kernel tuning (PV_GEMM_DBG): 1 = no DMA in the loop, 2 = no epilogue
 };
 
