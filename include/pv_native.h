@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 11
+#define PV_ABI_VERSION 12
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -260,6 +260,24 @@ typedef struct pv_sae_desc {
     float ln_eps;                    /* 1e-5, sae.py:80                                             */
 } pv_sae_desc;
 
+/* Transcoder (sae/transcoder.py:6-116; train_sae.py:299-301 hands train_step the pair (input, target)): the coder encodes
+ * one activation and reconstructs ANOTHER of the same width.  b_dec_out != NULL switches pv_sae_step / pv_sae_dense_step /
+ * pv_sae_grad_sqnorm_step / pv_sae_apply to it:
+ *   - pv_sae_state.b_dec only centres the encoder input (transcoder.py:35-37; its gradient is -W_enc gb_enc alone), the
+ *     decoder adds b_dec_out (:54-64; gradient colsum(dY));
+ *   - W_skip [d_in, d_in] (transcoder_with_skip_connection) or NULL: sae_out += x @ W_skip^T on the RAW input, before LN-out
+ *     (:73-76); gW_skip = dY^T x;
+ *   - loss, normaliser and `batch_mean` are the TARGET's (`target` [n_tokens, d_in], set before every step; :78);
+ *   - the clip norm covers the two extra tensors, pv_sae_apply runs plain Adam on them with the same clip coefficient.
+ * Single process only; the feature-parallel entry points refuse a transcoder state.  d_out == d_in. */
+typedef struct pv_sae_transcoder {
+    float *b_dec_out, *gb_dec_out, *mb_dec_out, *vb_dec_out;   /* [d_in]                                              */
+    float *W_skip, *gW_skip, *mW_skip, *vW_skip;               /* [d_in, d_in] (row o = output coordinate) or all NULL */
+    const float* target;                                       /* [n_tokens, d_in] of the coming step                  */
+    void* scratch;                                             /* pv_sae_transcoder_scratch_bytes (only with W_skip)   */
+    size_t scratch_bytes;
+} pv_sae_transcoder;
+
 /* fp32 master parameters in the reference's layouts (sae.py:537-555), their gradients, Adam
  * moments and training statistics -- all caller-owned (torch tensors), fp32 unless stated. */
 typedef struct pv_sae_state {
@@ -287,6 +305,7 @@ typedef struct pv_sae_state {
     uint16_t *W_enc16T;                            /* [d_sae, d_in] fp16 (B operand of the filter GEMM)               */
     float *enc_colsq;                              /* [d_sae] ||W_enc[:, j]||^2 (error bound of the filter)           */
     float *dec_inv_norm;                           /* [d_sae] scratch of PV_SAE_RENORM_DECODER (1 / ||W_dec[j]||), or NULL */
+    pv_sae_transcoder tc;                          /* all NULL: a plain autoencoder                                   */
 } pv_sae_state;
 
 /* Per-step outputs, caller-owned. */
@@ -300,6 +319,7 @@ typedef struct pv_sae_out {
 
 typedef struct pv_sae_plan pv_sae_plan;
 int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan);
+size_t pv_sae_transcoder_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens);   /* skip term + split-K partials of gW_skip */
 void pv_sae_plan_destroy(pv_sae_plan* plan);
 size_t pv_sae_workspace_bytes(const pv_sae_plan* plan);
 

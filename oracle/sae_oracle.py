@@ -1,5 +1,6 @@
 """ORACLE (test infrastructure, NOT product code) -- numpy restatement of ViT-Prisma's SAE forward, loss,
-backward and optimiser step: the top-k SAE (k given) and the ReLU + L1 SAE (k = None, l1_coefficient).
+backward and optimiser step: the top-k SAE (k given), the ReLU + L1 SAE (k = None, l1_coefficient) and the Transcoder
+(``target`` given; parameters ``b_dec_out`` and optionally ``W_skip`` in P).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
 
@@ -9,7 +10,8 @@ reference itself executed in the build container -- ``tests/golden/gen_golden_sa
 reference's real ``StandardSparseAutoencoder`` and ``VisionSAETrainer.train_step`` for three
 consecutive steps and dumps losses, gradients and post-step parameters
 (``tests/test_oracle_sae_vs_golden.py``); the ReLU + L1 form against ``tests/golden/sae_variants_steps.npz``
-(``relu_l1``: the reference's own classes through its own train_step, ``tests/golden/gen_golden_sae_variants.py``).
+(``relu_l1`` / ``relu_ghost`` / ``transcoder``: the reference's own classes through its own train_step,
+``tests/golden/gen_golden_sae_variants.py``).
 
 Citations are relative to /root/reference/src/vit_prisma/.
 """
@@ -43,7 +45,8 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
 
 
 def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
-                n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None) -> Dict[str, Array]:
+                n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None,
+                target: Optional[Array] = None) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
     :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
     (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
@@ -51,7 +54,11 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     batch_mean / n_global: the data-parallel form -- mean_n(x) over the GLOBAL
     batch and the global token count; default = this batch (single process, the reference).
     dead_mask [d_sae] bool (use_ghost_grads, training): adds _compute_ghost_residual_loss (sae/sae.py:151-179) -- also when
-    no feature is dead (ghost_out is then zero and the term is a constant: the reference adds it all the same)."""
+    no feature is dead (ghost_out is then zero and the term is a constant: the reference adds it all the same).
+    target [N, d_in] (Transcoder.forward, sae/transcoder.py:66-116): the activation to reconstruct; P then holds the decoder's
+    own bias ``b_dec_out`` (decode, :54-64; ``b_dec`` only centres the encoder input, :35-37) and optionally ``W_skip``
+    [d_in, d_in] (``sae_out += x @ W_skip.mT`` on the RAW input, before LN-out, :73-76); loss and normaliser against it
+    (:78; batch_mean is then the target's)."""
     dt = x.dtype.type
     N, d = x.shape
     if layer_norm:
@@ -67,12 +74,20 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         idx, vals = topk_mask(hidden_pre, k)                           # :576
         feats = np.zeros_like(hidden_pre)
         np.put_along_axis(feats, idx, vals, axis=-1)
-    pre_out = feats @ P["W_dec"] + P["b_dec"]                          # :584-591
+    if target is None:
+        pre_out = feats @ P["W_dec"] + P["b_dec"]                      # :584-591
+        y = x
+    else:
+        assert dead_mask is None, "ghost gradients of a transcoder are not restated here"
+        pre_out = feats @ P["W_dec"] + P["b_dec_out"]                  # transcoder.py:54-64
+        if P.get("W_skip") is not None:
+            pre_out = pre_out + x @ P["W_skip"].T                      # transcoder.py:73-74
+        y = target
     sae_out = pre_out * std + mu if layer_norm else pre_out            # :89-90 (no eps on the way out)
-    bm = x.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
-    nf = np.sqrt(((x - bm) ** 2).sum(axis=-1, keepdims=True))          # :145-147
+    bm = y.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
+    nf = np.sqrt(((y - bm) ** 2).sum(axis=-1, keepdims=True))          # :145-147
     ng = N if n_global is None else n_global
-    mse = ((sae_out - x) ** 2 / nf).sum() / dt(ng * d)                 # :146-148 (mean over N*d)
+    mse = ((sae_out - y) ** 2 / nf).sum() / dt(ng * d)                 # :146-148 (mean over N*d)
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()            # train_sae.py:364
     l1 = None
     loss = mse
@@ -96,7 +111,7 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         loss = loss + dt(ghost)
     return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
                 mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0,
-                ghost=gh, ghost_loss=None if gh is None else gh["loss"])
+                ghost=gh, ghost_loss=None if gh is None else gh["loss"], target=target)
 
 
 def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True,
@@ -108,7 +123,8 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     dt = x.dtype.type
     N, d = x.shape
     ng = N if n_global is None else n_global
-    d_out = dt(2.0) * (fw["sae_out"] - x) / fw["norm_factor"] / dt(ng * d)
+    tc = fw.get("target") is not None
+    d_out = dt(2.0) * (fw["sae_out"] - (fw["target"] if tc else x)) / fw["norm_factor"] / dt(ng * d)
     d_pre = d_out * fw["std"] if layer_norm else d_out
     feats = fw["feature_acts"]
     g = {}
@@ -125,7 +141,13 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     g["W_enc"] = fw["sae_in"].T @ d_hidden
     g["b_enc"] = d_hidden.sum(axis=0)
     d_sae_in = d_hidden @ P["W_enc"].T
-    g["b_dec"] = d_pre.sum(axis=0) - d_sae_in.sum(axis=0)             # decode bias + "sae_in = x_hat - b_dec"
+    if tc:                                                            # the two roles of b_dec are two parameters here
+        g["b_dec"] = -d_sae_in.sum(axis=0)
+        g["b_dec_out"] = d_pre.sum(axis=0)
+        if P.get("W_skip") is not None:
+            g["W_skip"] = d_pre.T @ x
+    else:
+        g["b_dec"] = d_pre.sum(axis=0) - d_sae_in.sum(axis=0)         # decode bias + "sae_in = x_hat - b_dec"
     return g
 
 
@@ -177,12 +199,12 @@ def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, 
 
 def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: Optional[int], lr: float,
                step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
-               dead_feature_window: Optional[int] = None) -> Dict[str, float]:
+               dead_feature_window: Optional[int] = None, target: Optional[Array] = None) -> Dict[str, float]:
     """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
     firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count)."""
     renorm_decoder(P)                                                   # :306-307
     dead = None if dead_feature_window is None else stats["n_fwd_since_fired"] > dead_feature_window      # :330-332 (use_ghost_grads)
-    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead)
+    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead, target=target)
     fired = (fw["feature_acts"] > 0).sum(axis=0)                        # :356-361
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0

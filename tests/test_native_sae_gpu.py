@@ -753,6 +753,129 @@ def test_relu_variants_trainer_runs_natively_and_matches_the_reference_fixture(v
         assert rel_fro(p.detach().cpu().numpy(), g[f"{variant}_s2_param_{n}"]) < (1e-3 if ghost else TOL), n
 
 
+# ---------------------------------------------------------------------------------------------------
+# Transcoder (sae/transcoder.py; pv_sae_transcoder) on the two fused steps
+# ---------------------------------------------------------------------------------------------------
+def fresh_transcoder(d_in, d_sae, skip):
+    P, opt, stats, T = fresh(d_in, d_sae)
+    rs = np.random.RandomState(5)
+    P["b_dec_out"] = (rs.standard_normal(d_in) * 0.05).astype(np.float32)
+    if skip:
+        P["W_skip"] = (rs.standard_normal((d_in, d_in)) / np.sqrt(d_in) * 0.3).astype(np.float32)
+    for n in ("b_dec_out", "W_skip"):
+        if n in P:
+            opt["m"][n], opt["v"][n] = np.zeros_like(P[n]), np.zeros_like(P[n])
+            T[n] = torch.from_numpy(P[n].copy()).cuda()
+    return P, opt, stats, T
+
+
+@pytest.mark.parametrize("d_in,d_sae,k,n,ln,skip", [(64, 512, 8, 256, True, True), (136, 1056, 16, 300, False, True),
+                                                    (768, 8192, 32, 1024, True, True), (768, 8192, 32, 1024, True, False),
+                                                    (64, 512, None, 256, True, True), (136, 1056, None, 300, False, False),
+                                                    (768, 8192, None, 1024, True, True)])
+def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
+    """A Transcoder (target activation, b_dec_out, optional W_skip) on the top-k step (k given) and on the dense ReLU + L1 step
+    (k = None) against the oracle's transcoder form (pinned to the reference's own Transcoder run by
+    tests/test_oracle_sae_vs_golden.py): losses, l0, every gradient tensor incl. the two extra ones, the clip norm,
+    parameters and statistics after the optimizer step; ragged shapes and the no-LayerNorm form included."""
+    l1c = 3e-3
+    P, opt, stats, T = fresh_transcoder(d_in, d_sae, skip)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k or 1, ln, n, b_dec_out=T["b_dec_out"], W_skip=T.get("W_skip"))
+    assert eng.transcoder
+    for t in range(2):
+        # (seeds 10..: token 381 of seed 0 has its 32nd and 33rd pre-activation at 768 -> 8192 within fp32 summation noise of each
+        # other -- profiles/r03_tp_near_tie_diag.txt -- and the top-k SET is what this test compares)
+        x, y = synth_sae_batch(n, d_in, seed=10 + t), synth_sae_batch(n, d_in, seed=50 + t)
+        Pc = {kk: v.copy() for kk, v in P.items()}
+        O.renorm_decoder(Pc)
+        fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
+        gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
+        before = stats["act_freq_scores"].copy()
+        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        if k is None:
+            eng.dense_step(xg, l1c, want_out=True, target=yg)
+            eng.grad_sqnorm()
+        else:
+            eng.step(xg, want_out=True, renorm_decoder=True, target=yg)
+            eng.grad_sqnorm(from_step=True)
+        torch.cuda.synchronize()
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - ref["loss"]) <= TOL * ref["loss"] and abs(sc[1] - ref["mse_loss"]) <= TOL * ref["mse_loss"], (sc, ref)
+        assert abs(sc[2] - ref["l0"]) <= TOL * ref["l0"], (sc, ref)
+        if k is not None:
+            # the top-k SET is discontinuous in hidden_pre: after an optimizer step the two parameter sets are ~1e-7 apart and a
+            # token whose k-th and (k+1)-th pre-activations lie within fp32 summation noise of each other may keep either one
+            # (measured: 1 token of 1024 at 768 -> 8192 in step 2, tools/tc_diag.py).  Such tokens must be near-ties in the
+            # oracle's own numbers; the comparison of everything behind the selection ends there.
+            same = (np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1) == np.sort(fw["idx"], axis=1)).all(axis=1)
+            if not same.all():
+                assert t > 0 and (~same).sum() <= 2
+                hs = -np.sort(-fw["hidden_pre"][~same], axis=1)
+                assert np.all((hs[:, k - 1] - hs[:, k]) <= 2e-6 * np.abs(fw["hidden_pre"]).max())
+                return
+        assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
+        if k is None:
+            assert abs(sc[4] - ref["l1_loss"]) <= TOL * ref["l1_loss"]
+            off = eng.lib.pv_debug_sae_ws_offset(eng._plan, b"hidden")
+            dH = eng.workspace[off:off + n * d_sae * 4].view(torch.float32).view(n, d_sae).cpu().numpy()
+            gate = dH != 0
+            differs = gate != (fw["feature_acts"] > 0)            # (ReLU gates within fp32 summation noise of zero: see the dense test)
+            assert differs.sum() <= 1e-5 * gate.size and np.all(np.abs(fw["hidden_pre"][differs]) < 1e-5 * np.abs(fw["hidden_pre"]).max())
+            if differs.any():
+                gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c, gate=gate)
+        else:
+            differs = np.zeros(1, bool)
+        assert sorted(gr) == sorted(P)
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr), (np.sqrt(sc[3]), grad_norm_of(gr))
+        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
+        for name in [m for m in P if m != "W_enc"]:
+            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
+        if differs.any():
+            return
+        fire_ref = stats["act_freq_scores"] - before
+        assert np.abs(eng.fire_count.cpu().numpy() - fire_ref).sum() <= TOL * fire_ref.sum()
+        eng.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name in P:
+            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name
+        assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
+
+
+def test_transcoder_trainer_runs_natively_and_matches_the_reference_fixture():
+    """is_transcoder (top-k, k = 8, with the skip connection) through VisionSAETrainer.train_step on the fused HIP step, against
+    what the REFERENCE's own Transcoder produced through its own train_step (tests/golden/sae_variants_steps.npz)."""
+    from vit_prisma_amd.sae import Transcoder
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, exp, N = 64, 8, 256
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
+        train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda", _dtype="float32", log_to_wandb=False, use_ghost_grads=False,
+        feature_sampling_window=1000, dead_feature_window=5000, lr_scheduler_name="constant", n_checkpoints=0, verbose=False,
+        is_transcoder=True, transcoder_with_skip_connection=True, d_out=64, out_hook_point_layer=6)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None).use_native(True)
+    model = tr.sparse_coder
+    assert type(model) is Transcoder
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"transcoder_init_{n}"]).cuda())
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    for t in range(3):
+        pair = torch.stack([torch.from_numpy(synth_sae_batch(N, d_in, seed=t)), torch.from_numpy(synth_sae_batch(N, d_in, seed=100 + t))],
+                           dim=1).cuda()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=model, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=pair, n_training_steps=t, n_training_tokens=t * N)
+        assert tr.last_step_native and l1 is None
+        want = g[f"transcoder_s{t}_scalars"]
+        for got, w in ((loss, want[0]), (mse, want[1]), (l0, want[3])):
+            assert abs(float(got) - w) <= TOL * abs(w), (t, float(got), w)
+        assert np.array_equal(act.cpu().numpy(), g[f"transcoder_s{t}_act_freq"]) and np.array_equal(since.cpu().numpy(), g[f"transcoder_s{t}_n_since"])
+    for n, p in model.named_parameters():
+        assert rel_fro(p.detach().cpu().numpy(), g[f"transcoder_s2_param_{n}"]) < TOL, n
+
+
 def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():
     """The store issues the NEXT refill's ViT forwards on a side stream while the current half buffer is served
     (sae/store.py: overlap_harvest): same images, same order, the same permutations drawn at the same points -- every batch

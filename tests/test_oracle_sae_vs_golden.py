@@ -108,3 +108,26 @@ def test_relu_ghost_three_steps_vs_reference_fixture():
         assert np.array_equal(stats["n_fwd_since_fired"], g[f"relu_ghost_s{t}_n_since"])
     for n in P:
         assert rel_fro(P[n], g[f"relu_ghost_s2_param_{n}"]) < 2e-5, n
+
+
+def test_transcoder_three_steps_vs_reference_fixture():
+    """The Transcoder form of the oracle (target given, b_dec_out, W_skip; top-k, k = 8) against the reference's own Transcoder
+    through its own train_step (transcoder of tests/golden/sae_variants_steps.npz)."""
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, d_sae, N = 64, 512, 256
+    names = [str(k) for k in g["transcoder_keys"]]
+    assert sorted(names) == ["W_dec", "W_enc", "W_skip", "b_dec", "b_dec_out", "b_enc"]
+    P = {n: g[f"transcoder_init_{n}"].copy() for n in names}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": g["transcoder_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), 8, lr=1e-3, step=t + 1,
+                           target=synth_sae_batch(N, d_in, seed=100 + t))
+        loss, mse, l1, l0 = g[f"transcoder_s{t}_scalars"][:4]
+        assert np.isnan(l1) and out["l1_loss"] is None
+        assert abs(out["loss"] - loss) <= 1e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        assert abs(out["l0"] - l0) <= 1e-6 * l0
+        assert np.array_equal(stats["act_freq_scores"], g[f"transcoder_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"transcoder_s{t}_n_since"])
+    for n in P:
+        assert rel_fro(P[n], g[f"transcoder_s2_param_{n}"]) < 1e-5, n

@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out,
     float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
     float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm,
-    const float* __restrict__ pre_sum = nullptr) {
+    const float* __restrict__ pre_sum = nullptr, const float* __restrict__ addend = nullptr) {
+    // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term x_in @ W_skip^T or nullptr
     // inv_norm != nullptr: set_decoder_norm_to_unit_norm is pending -- W_dec still holds the un-normalised rows and row j
     // stands for W_dec[j] * inv_norm[j] (the Adam kernel writes the normalised + updated row; see pv_sae_step)
     const int lane = threadIdx.x & 63;
@@ -337,6 +338,10 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     if constexpr (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < V4; ++i) acc[i] = ld4(pre_sum + (int64_t)n * d + col[i], ok[i]);
+    }
+    if (MODE == 0 && addend) {
+#pragma unroll
+        for (int i = 0; i < V4; ++i) acc[i] = ld4(addend + (int64_t)n * d + col[i], ok[i]);
     }
     for (int s = 0; MODE != 2 && s < k; s += 4) {
         float a[4];
@@ -912,11 +917,14 @@ __global__ __launch_bounds__(256) void sae_zero_empty_kernel(const uint32_t* __r
 
 // clip norm from the per-feature terms of the backward (+ gb_dec): one workgroup, fixed summation order
 __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restrict__ rowsq, int d_sae, const float* __restrict__ gb_dec,
-                                                            int d_in, float* __restrict__ scalars) {
+                                                            int d_in, float* __restrict__ scalars, const float* __restrict__ extra0,
+                                                            int n0, const float* __restrict__ extra1, int n1) {
     __shared__ float red[16];
     float s = 0.f;
     for (int j = threadIdx.x; j < d_sae; j += 1024) s += rowsq[j];
     for (int i = threadIdx.x; i < d_in; i += 1024) s += gb_dec[i] * gb_dec[i];
+    for (int i = threadIdx.x; i < n0; i += 1024) s += extra0[i] * extra0[i];          // transcoder: gb_dec_out, gW_skip
+    for (int i = threadIdx.x; i < n1; i += 1024) s += extra1[i] * extra1[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1439,6 +1447,60 @@ extern "C" int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t 
     return PV_OK;
 }
 
+// ---- transcoder (pv_sae_state.tc; sae/transcoder.py:6-116) ----------------------------------------------------------------
+// loss normaliser of the target: ||y_n - mean_n(y)||_2 (sae.py:145-147 as called by transcoder.py:78).  One wave per token.
+__global__ __launch_bounds__(256) void sae_target_norm_kernel(const float* __restrict__ y, const float* __restrict__ batch_mean,
+                                                              float* __restrict__ norm_out, int n_tok, int d) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    float cn = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float c = y[(int64_t)n * d + i] - batch_mean[i];
+        cn += c * c;
+    }
+    cn = wave_sum(cn);
+    if (lane == 0) norm_out[n] = sqrtf(cn);
+}
+
+int sae_tc_require(const pv_sae_desc& d, const pv_sae_state* st, int N) {
+    const pv_sae_transcoder& t = st->tc;
+    PV_REQUIRE(t.b_dec_out && t.gb_dec_out && t.target, "transcoder state: b_dec_out, gb_dec_out and target are required");
+    const bool any_skip = t.W_skip || t.gW_skip;
+    PV_REQUIRE(!any_skip || (t.W_skip && t.gW_skip), "transcoder state: W_skip and gW_skip come together");
+    if (t.W_skip) {
+        PV_REQUIRE(d.d_in % 8 == 0, "the skip connection's GEMMs need d_in to be a multiple of 8");
+        PV_REQUIRE(t.scratch && ((uintptr_t)t.scratch & 255) == 0 &&
+                       t.scratch_bytes >= ((size_t)N * d.d_in + (size_t)PV_SAE_SKIP_SPLITK * d.d_in * d.d_in) * 4,
+                   "transcoder scratch too small / misaligned (pv_sae_transcoder_scratch_bytes)");
+    }
+    return PV_OK;
+}
+
+extern "C" size_t pv_sae_transcoder_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens) {
+    if (!plan || n_tokens < 1) return 0;
+    const pv_sae_desc& d = plan->d;
+    return (size_t)pv_align_up((int64_t)(((size_t)n_tokens * d.d_in + (size_t)PV_SAE_SKIP_SPLITK * d.d_in * d.d_in) * 4), 256);
+}
+
+int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float* batch_mean, int N, unsigned char* wsb, const SaeWs& ws,
+                       hipStream_t stream) {
+    float* bmean = (float*)(wsb + ws.batch_mean);
+    const float* y = st->tc.target;
+    if (batch_mean) {
+        PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
+    } else {
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, y, (float*)(wsb + ws.colpart), N, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
+                           (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
+    }
+    hipLaunchKernelGGL(sae_target_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, y, (const float*)bmean,
+                       (float*)(wsb + ws.norm), N, d.d_in);
+    PV_LAUNCH_CHECK("sae_target_norm_kernel");
+    return PV_OK;
+}
+
 // ---- pieces of the step shared with the dense (ReLU + L1) step of sae_dense.hip --------------------------------------------
 // batch mean (given, or computed from x) -> ws.batch_mean; LN-in, sae_in, loss normaliser (+ the fp16 copy / row norms the
 // filtered encoder wants) -> ws.sae_in, ws.mu, ws.sd, ws.norm (ws.x16, ws.xnorm)
@@ -1472,6 +1534,21 @@ int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
                        nblk + ngb, d.d_in, 1.0f);
     PV_LAUNCH_CHECK("sae bias-grad kernels");
+    return PV_OK;
+}
+
+int sae_tc_bias_grads(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
+                      hipStream_t stream) {
+    const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+    float* colpart = (float*)(wsb + ws.colpart);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
+    hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                       colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->tc.gb_dec_out,
+                       nblk, d.d_in, 1.0f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
+                       (const float*)(colpart + (size_t)nblk * d.d_in), st->gb_dec, ngb, d.d_in, 1.0f);
+    PV_LAUNCH_CHECK("transcoder bias-grad kernels");
     return PV_OK;
 }
 
@@ -1541,6 +1618,7 @@ extern "C" int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, con
 extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t N, float* sae_out,
                               int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, float* scalars, void* workspace,
                               size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_forward: not available for a transcoder state (pv_sae_state.tc)");
     PV_REQUIRE(plan && st && x && sae_out && topk_idx && topk_val && workspace, "null argument");
     const pv_sae_desc& d = plan->d;
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
@@ -1600,8 +1678,24 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            st->dec_inv_norm, d.d_sae, d.d_in);
     }
     if (renorm) inv_norm = st->dec_inv_norm;
+    // transcoder (pv_sae_state.tc): the loss is taken against tc.target, the decoder adds b_dec_out and the skip term
+    const bool tc = sae_is_tc(st);
+    if (tc) {
+        PV_REQUIRE(n_global == N && !sparse, "transcoder: single process, complete gradient buffers");
+        const int rq = sae_tc_require(d, st, N);
+        if (rq) return rq;
+    }
     int rc = sae_encode_topk(plan, st, x, N, batch_mean, out->topk_idx, out->topk_val, true, wsb, ws, stream);
     if (rc) return rc;
+    const float* skip = nullptr;
+    if (tc) {
+        rc = sae_tc_target_norm(d, st, batch_mean, N, wsb, ws, stream);
+        if (rc) return rc;
+        rc = sae_tc_skip_forward(d, st, x, N, &skip, stream);
+        if (rc) return rc;
+    }
+    const float* y = tc ? st->tc.target : x;
+    const float* bdo = tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec;
 
     float* dY = (float*)(wsb + ws.dY);
     float* dh = (float*)(wsb + ws.dh);
@@ -1611,10 +1705,10 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
         const dim3 grid((N + 3) / 4), block(256);
 #define CALL(D)                                                                                                      \
-    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
                        (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)(wsb + ws.mu),      \
                        (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, dh,             \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm)
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
@@ -1672,8 +1766,12 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
-        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
         if (rc) return rc;
+        if (tc) {
+            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+            if (rc) return rc;
+        }
     }
     return PV_OK;
 }
@@ -1697,6 +1795,7 @@ __global__ __launch_bounds__(256) void sae_recount_kernel(const int32_t* __restr
 
 extern "C" int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int32_t* topk_idx, const float* topk_val, int32_t N,
                                  int32_t flags, float* partial, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_tp_partial: not available for a transcoder state (pv_sae_state.tc)");
     PV_REQUIRE(plan && st && topk_idx && topk_val && partial && st->W_dec, "null argument");
     const pv_sae_desc& d = plan->d;
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
@@ -1729,6 +1828,7 @@ extern "C" int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int3
 extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float* x, const float* pre_sum, const int32_t* topk_idx,
                                 const float* topk_val, int32_t N, int32_t n_global, int32_t flags, pv_sae_out* out,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_tp_finish: not available for a transcoder state (pv_sae_state.tc)");
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && pre_sum && topk_idx && topk_val && out && workspace, "null argument");
     PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
@@ -1933,8 +2033,13 @@ extern "C" int pv_sae_grad_sqnorm_step(pv_sae_plan* plan, const pv_sae_state* st
     PV_REQUIRE(plan && st && workspace && scalars && st->gb_dec, "null argument");
     const pv_sae_desc& d = plan->d;
     const SaeWs ws = sae_carve(d);
+    const bool tc = sae_is_tc(st);
+    PV_REQUIRE(!tc || st->tc.gb_dec_out, "transcoder state");
     hipLaunchKernelGGL(sqnorm_rowsq_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_,
-                       (const float*)((const unsigned char*)workspace + ws.rowsq), d.d_sae, (const float*)st->gb_dec, d.d_in, scalars);
+                       (const float*)((const unsigned char*)workspace + ws.rowsq), d.d_sae, (const float*)st->gb_dec, d.d_in, scalars,
+                       tc ? (const float*)st->tc.gb_dec_out : (const float*)nullptr, tc ? d.d_in : 0,
+                       (tc && st->tc.gW_skip) ? (const float*)st->tc.gW_skip : (const float*)nullptr,
+                       (tc && st->tc.gW_skip) ? d.d_in * d.d_in : 0);
     PV_LAUNCH_CHECK("sqnorm_rowsq_kernel");
     return PV_OK;
 }
@@ -2008,6 +2113,15 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     }
     hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, st->b_dec, (const float*)st->gb_dec,
                        st->mb_dec, st->vb_dec, scalars, c, 0, d.d_in);
+    if (sae_is_tc(st)) {                                               // transcoder: plain Adam on the decoder's own bias and the skip matrix
+        const pv_sae_transcoder& t = st->tc;
+        PV_REQUIRE(t.gb_dec_out && t.mb_dec_out && t.vb_dec_out && (!t.W_skip || (t.gW_skip && t.mW_skip && t.vW_skip)), "transcoder Adam state");
+        hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, t.b_dec_out, (const float*)t.gb_dec_out,
+                           t.mb_dec_out, t.vb_dec_out, scalars, c, 0, d.d_in);
+        if (t.W_skip)
+            hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in * d.d_in + 255) / 256), block, 0, stream, t.W_skip, (const float*)t.gW_skip,
+                               t.mW_skip, t.vW_skip, scalars, c, 0, d.d_in * d.d_in);
+    }
     PV_LAUNCH_CHECK("adam kernels");
     if (j_lo == 0 && j_hi == d.d_sae) plan->renorm_pending = false;      // (a sharded apply leaves the other ranks' rows to the all-gather)
     return PV_OK;

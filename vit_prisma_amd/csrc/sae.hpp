@@ -65,4 +65,18 @@ int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int
               hipStream_t stream);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream);
 int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);
+// transcoder (pv_sae_state.tc, sae/transcoder.py): helpers shared by the top-k step (sae.hip) and the dense step (sae_dense.hip)
+static inline bool sae_is_tc(const pv_sae_state* st) { return st->tc.b_dec_out != nullptr; }
+constexpr int PV_SAE_SKIP_SPLITK = 8;        // token splits of gW_skip = dY^T x (36 output tiles at d_in = 768 otherwise)
+int sae_tc_require(const pv_sae_desc& d, const pv_sae_state* st, int N);                                  // sae.hip: field checks
+// sae.hip: the loss normaliser of the TARGET (sae.py:145-147 on y) -> ws.norm; batch_mean = mean_n(target) or NULL (computed here)
+int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float* batch_mean, int N, unsigned char* wsb, const SaeWs& ws,
+                       hipStream_t stream);
+// sae.hip: gb_dec_out = colsum(dY), gb_dec = -W_enc gb_enc (the two roles of the autoencoder's b_dec are two parameters here)
+int sae_tc_bias_grads(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
+                      hipStream_t stream);
+// sae_dense.hip: skip term [N, d_in] = x @ W_skip^T at the head of tc.scratch (returns nullptr through *skip when there is no
+// W_skip); gW_skip = dY^T x
+int sae_tc_skip_forward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, int N, const float** skip, hipStream_t stream);
+int sae_tc_skip_backward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, const float* dY, int N, hipStream_t stream);
 constexpr int PV_SAE_DENSE_SPLITK = 4;       // K splits of the dense decoder GEMM (M = tokens, N = d_in: too few tiles otherwise)

@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            const float* __restrict__ sd, const float* __restrict__ norm,
                                                            float* __restrict__ sae_out, float* __restrict__ dY,
                                                            float* __restrict__ loss_partial, int n_tok, int d, float grad_scale,
-                                                           float* __restrict__ err_out) {
+                                                           float* __restrict__ err_out, const float* __restrict__ addend) {
+    // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term or nullptr
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -328,6 +329,10 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
         float4 a = *reinterpret_cast<const float4*>(kpart + (int64_t)n * d + c);
         for (int z = 1; z < splits; ++z) {
             const float4 t = *reinterpret_cast<const float4*>(kpart + z * zstride + (int64_t)n * d + c);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (addend) {
+            const float4 t = *reinterpret_cast<const float4*>(addend + (int64_t)n * d + c);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
         const float4 bd = *reinterpret_cast<const float4*>(b_dec + c);
@@ -402,6 +407,19 @@ __global__ __launch_bounds__(256) void ghost_rows_kernel(const float* __restrict
     if (lane == 0) part[n] = acc;
 }
 
+
+// out[i] = sum_z part[z * zstride + i] (fixed order): the split-K partials of gW_skip
+__global__ __launch_bounds__(256) void dense_sumz_kernel(const float* __restrict__ part, int splits, int64_t zstride, int64_t n,
+                                                         float* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 a = *reinterpret_cast<const float4*>(part + i);
+    for (int z = 1; z < splits; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(part + z * zstride + i);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = a;
+}
 }  // namespace
 
 namespace {
@@ -429,6 +447,41 @@ GhostWs ghost_carve(const pv_sae_desc& d, int N, int n_dead) {
     return w;
 }
 }  // namespace
+
+// ---- transcoder skip connection (sae/transcoder.py:73-76): two more GEMMs on the same kernel ---------------------------------
+int sae_tc_skip_forward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, int N, const float** skip, hipStream_t stream) {
+    *skip = nullptr;
+    if (!st->tc.W_skip) return PV_OK;
+    const int D = d.d_in;
+    float* buf = (float*)st->tc.scratch;                    // [N][D]
+    DenseGemm g = {};
+    g.A = x; g.lda = D; g.B = st->tc.W_skip; g.ldb = D; g.M = N; g.N = D; g.K = D; g.k_chunk = D;      // x @ W_skip^T: B as [N][K]
+    g.out = buf; g.ldo = D;
+    const int rc = launch_dense_gemm<false, false, DG_EPI_STORE>(g, 1, stream);
+    if (rc) return rc;
+    *skip = buf;
+    return PV_OK;
+}
+
+int sae_tc_skip_backward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, const float* dY, int N, hipStream_t stream) {
+    if (!st->tc.W_skip) return PV_OK;
+    const int D = d.d_in;
+    float* part = (float*)st->tc.scratch + (size_t)N * D;   // [S][D][D]
+    // gW_skip[o][i] = sum_n dY[n][o] x[n][i]: both operands row-major over the tokens, K = N split over the workgroups
+    int S = (N + DG_KSLAB - 1) / DG_KSLAB;
+    if (S > PV_SAE_SKIP_SPLITK) S = PV_SAE_SKIP_SPLITK;
+    DenseGemm g = {};
+    g.A = dY; g.lda = D; g.B = x; g.ldb = D; g.M = D; g.N = D; g.K = N;
+    g.k_chunk = ((N + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
+    g.out = part; g.ldo = D; g.out_zstride = (int64_t)D * D;
+    const int rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g, S, stream);
+    if (rc) return rc;
+    const int64_t n = (int64_t)D * D;
+    hipLaunchKernelGGL(dense_sumz_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (const float*)part, S, n, n,
+                       st->tc.gW_skip);
+    PV_LAUNCH_CHECK("dense_sumz_kernel");
+    return PV_OK;
+}
 
 extern "C" size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t n_dead) {
     if (!plan || n_tokens < 1 || n_dead < 0) return 0;
@@ -476,8 +529,22 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         int rc = pv_sae_renorm_decoder(plan, st, stream_);
         if (rc) return rc;
     }
+    // transcoder (pv_sae_state.tc): loss against tc.target, the decoder adds b_dec_out and the skip term
+    const bool tc = sae_is_tc(st);
+    if (tc) {
+        PV_REQUIRE(n_global == N && !ghost, "transcoder: single process, no ghost gradients");
+        const int rq = sae_tc_require(d, st, N);
+        if (rq) return rq;
+    }
     int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, false, wsb, ws, stream);
     if (rc) return rc;
+    const float* skip = nullptr;
+    if (tc) {
+        rc = sae_tc_target_norm(d, st, batch_mean, N, wsb, ws, stream);
+        if (rc) return rc;
+        rc = sae_tc_skip_forward(d, st, x, N, &skip, stream);
+        if (rc) return rc;
+    }
     float* f = (float*)(wsb + ws.hidden);                  // [N][F]: f, later dH
     float* sae_in = (float*)(wsb + ws.sae_in);
     float* dY = (float*)(wsb + ws.dY);
@@ -520,10 +587,10 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
         const float grad_scale = 2.0f / ((float)n_global * (float)D);
-        hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, (const float*)kpart, S, (int64_t)N * D,
-                           (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
-                           (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D, grad_scale,
-                           ghost ? (float*)(gwb + gw.err) : (float*)nullptr);
+        hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, tc ? st->tc.target : x, (const float*)kpart, S,
+                           (int64_t)N * D, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, (const float*)(wsb + ws.mu),
+                           (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
+                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip);
         PV_LAUNCH_CHECK("dense_finish_kernel");
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream);
         if (ghost) {
@@ -593,8 +660,12 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         g5.out = st->gW_enc; g5.ldo = D;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
-        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
         if (rc) return rc;
+        if (tc) {
+            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+            if (rc) return rc;
+        }
     }
     return PV_OK;
 }

@@ -26,9 +26,15 @@ from .. import _native as N
 
 class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
-                 layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False):
-        """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``."""
-        for t in (W_enc, W_dec, b_enc, b_dec):
+                 layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False,
+                 b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None):
+        """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``.
+        b_dec_out [d_in] (+ W_skip [d_in, d_in]): a Transcoder (sae/transcoder.py; pv_sae_transcoder) -- ``step`` /
+        ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input."""
+        self.transcoder = b_dec_out is not None
+        assert W_skip is None or self.transcoder, "W_skip belongs to a transcoder (pass b_dec_out)"
+        assert not (self.transcoder and inference), "the inference entry points do not serve a transcoder"
+        for t in (W_enc, W_dec, b_enc, b_dec) + tuple(t for t in (b_dec_out, W_skip) if t is not None):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
                 raise N.NativeError("native SAE needs contiguous fp32 CUDA parameters")
         self.lib = N.lib()
@@ -39,6 +45,11 @@ class NativeSAE:
         self.max_tokens = int(max_tokens)
         # the tensors whose version counters tell about outside edits (nn.Parameters when the trainer passes them)
         self._src = dict(W_enc=W_enc, W_dec=W_dec, b_enc=b_enc, b_dec=b_dec)
+        if self.transcoder:
+            assert tuple(b_dec_out.shape) == (self.d_in,) and (W_skip is None or tuple(W_skip.shape) == (self.d_in, self.d_in))
+            self._src["b_dec_out"] = b_dec_out
+            if W_skip is not None:
+                self._src["W_skip"] = W_skip
         self.params = {n: t.detach() for n, t in self._src.items()}
         desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
                          max_tokens=self.max_tokens, ln_eps=ln_eps)
@@ -48,6 +59,8 @@ class NativeSAE:
         dev = self.device
         nW = self.d_in * self.d_sae
         self.n_flat = 2 * nW + self.d_sae + self.d_in
+        if self.transcoder:
+            self.n_flat += self.d_in + (self.d_in * self.d_in if W_skip is not None else 0)
         f32 = dict(dtype=torch.float32, device=dev)
         self.inference = bool(inference)
         n_alloc = 0 if inference else self.n_flat
@@ -64,15 +77,22 @@ class NativeSAE:
             out["W_encT"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["W_dec"] = flat[o:o + nW].view(self.d_sae, self.d_in); o += nW
             out["b_enc"] = flat[o:o + self.d_sae]; o += self.d_sae
-            out["b_dec"] = flat[o:o + self.d_in]
+            out["b_dec"] = flat[o:o + self.d_in]; o += self.d_in
+            if self.transcoder:
+                out["b_dec_out"] = flat[o:o + self.d_in]; o += self.d_in
+                if "W_skip" in self._src:
+                    out["W_skip"] = flat[o:o + self.d_in * self.d_in].view(self.d_in, self.d_in)
             return out
 
         def param_layout(v: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-            return dict(W_enc=v["W_encT"].t(), W_dec=v["W_dec"], b_enc=v["b_enc"], b_dec=v["b_dec"])
+            out = dict(W_enc=v["W_encT"].t(), W_dec=v["W_dec"], b_enc=v["b_enc"], b_dec=v["b_dec"])
+            out.update({n: v[n] for n in ("b_dec_out", "W_skip") if n in v})
+            return out
 
         self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
         # views in the parameters' own layouts (W_enc: a transposed, non-contiguous view)
         self.g = dict(W_enc=self._g["W_encT"], W_dec=self._g["W_dec"], b_enc=self._g["b_enc"], b_dec=self._g["b_dec"])   # NB: g["W_enc"] is TRANSPOSED
+        self.g.update({n: self._g[n] for n in ("b_dec_out", "W_skip") if n in self._g})
         self.m, self.v = param_layout(self._m), param_layout(self._v)
         # encoder shadows
         self.W_encT = torch.empty(self.d_sae, self.d_in, **f32)
@@ -88,6 +108,11 @@ class NativeSAE:
         self.topk_val = torch.zeros(self.max_tokens, self.k, **f32)
         self.sae_out = torch.zeros(self.max_tokens, self.d_in, **f32)
         self.workspace = torch.empty(self.lib.pv_sae_workspace_bytes(self._plan), dtype=torch.uint8, device=dev)
+        self._tc_scratch = None
+        self._target: Optional[torch.Tensor] = None                # transcoder: the target of the coming / last step
+        if self.transcoder and W_skip is not None:
+            self._tc_scratch = torch.empty(self.lib.pv_sae_transcoder_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8,
+                                           device=dev)
         self.adam_step = 0
         self._shadow_key: Optional[Tuple[int, int]] = None
         self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
@@ -123,7 +148,32 @@ class NativeSAE:
             vW_enc=v["W_encT"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
             act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr(),
             W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(), enc_colsq=self.enc_colsq.data_ptr(),
-            dec_inv_norm=self.dec_inv_norm.data_ptr())
+            dec_inv_norm=self.dec_inv_norm.data_ptr(), tc=self._tc_state())
+
+    def _tc_state(self) -> N.SaeTranscoder:
+        if not self.transcoder:
+            return N.SaeTranscoder()
+        P, g, m, v = self.params, self._g, self._m, self._v
+        skip = "W_skip" in P
+        sc = self._tc_scratch
+        return N.SaeTranscoder(
+            b_dec_out=P["b_dec_out"].data_ptr(), gb_dec_out=g["b_dec_out"].data_ptr(), mb_dec_out=m["b_dec_out"].data_ptr(),
+            vb_dec_out=v["b_dec_out"].data_ptr(),
+            W_skip=P["W_skip"].data_ptr() if skip else None, gW_skip=g["W_skip"].data_ptr() if skip else None,
+            mW_skip=m["W_skip"].data_ptr() if skip else None, vW_skip=v["W_skip"].data_ptr() if skip else None,
+            target=self._target.data_ptr() if self._target is not None else None,
+            scratch=sc.data_ptr() if sc is not None else None, scratch_bytes=sc.numel() if sc is not None else 0)
+
+    def _set_target(self, x: torch.Tensor, target: Optional[torch.Tensor]) -> None:
+        if not self.transcoder:
+            assert target is None, "a target is a transcoder's business"
+            return
+        if target is None:
+            raise ValueError("transcoder step: the target activation is required")
+        t = target.to(torch.float32).contiguous()
+        if tuple(t.shape) != tuple(x.shape) or t.device != self.device:
+            raise ValueError(f"target {tuple(t.shape)} on {t.device} does not match the input {tuple(x.shape)} on {self.device}")
+        self._target = t
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -180,14 +230,16 @@ class NativeSAE:
 
     def step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
              update_stats: bool = True, want_out: bool = False, renorm_decoder: bool = False,
-             sparse_grads: bool = False) -> None:
+             sparse_grads: bool = False, target: Optional[torch.Tensor] = None) -> None:
         """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
         loss, mse_loss, l0 (device).  renorm_decoder: set_decoder_norm_to_unit_norm as part of the step (the rewrite of
         W_dec is fused into the following ``apply``) instead of a separate ``renorm_decoder()`` pass.  sparse_grads
         (PV_SAE_SPARSE_GRADS, single process): the gradient rows of features that kept no token are left unwritten and
         ``apply`` takes them as zero -- ``flat_g`` is then NOT a complete gradient and only ``grad_sqnorm(from_step=True)``
-        and ``apply`` may follow."""
+        and ``apply`` may follow.  target (transcoder engines): the activation to reconstruct; batch_mean is then ITS mean."""
         x = self._check_x(x)
+        self._set_target(x, target)
+        assert not (self.transcoder and sparse_grads), "transcoder: complete gradient buffers only"
         self._ensure_shadows()
         n = x.shape[0]
         st = self._state()
@@ -209,13 +261,15 @@ class NativeSAE:
 
     def dense_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
-                   renorm_decoder: bool = True, dead_mask: Optional[torch.Tensor] = None) -> None:
+                   renorm_decoder: bool = True, dead_mask: Optional[torch.Tensor] = None,
+                   target: Optional[torch.Tensor] = None) -> None:
         """The ReLU + L1 step (pv_sae_dense_step): forward + backward + statistics on dense fp32 MFMA GEMMs with fused
         epilogues; gradients are written into ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, ghost loss.  The
         engine's ``k`` plays no role.  dead_mask [d_sae] bool (use_ghost_grads: ``n_forward_passes_since_fired >
         dead_feature_window`` BEFORE this step, train_sae.py:330-332): adds the ghost residual loss and its gradient
-        (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs)."""
+        (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs).  target: as in ``step``."""
         x = self._check_x(x)
+        self._set_target(x, target)
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,

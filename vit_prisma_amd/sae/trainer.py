@@ -171,9 +171,14 @@ class VisionSAETrainer:
     # ---- native engine ----------------------------------------------------------------------------
     def _native_kind(self, sae, x: torch.Tensor) -> Optional[str]:
         """Which fused HIP step serves this SAE: "topk" (k-sparse step, sae.hip), "relu" (dense ReLU + L1 step,
-        sae_dense.hip) or None (PyTorch path: gated / transcoder / ghost gradients / other activations / CPU)."""
+        sae_dense.hip) or None (PyTorch path: gated / ghost gradients on top-k / other activations / CPU)."""
         cfg = sae.cfg
-        common = (x.is_cuda and isinstance(sae, StandardSparseAutoencoder) and cfg.dtype == torch.float32
+        from .variants import Transcoder
+        # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
+        # single process, no ghost gradients
+        is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in) and self.world == 1
+                 and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
+        common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
                   and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
@@ -193,8 +198,10 @@ class VisionSAETrainer:
     def _get_engine(self, sae, n_tokens: int):
         from .native_sae import NativeSAE
         eng = self._engine
-        stale = eng is not None and any(eng.params[n].data_ptr() != sae._parameters[n].data_ptr()
-                                        for n in ("W_enc", "W_dec", "b_enc", "b_dec"))     # e.g. b_dec.data re-bound by an init
+        tc_names = tuple(n for n in ("b_dec_out", "W_skip") if sae._parameters.get(n) is not None)
+        stale = eng is not None and (any(eng.params[n].data_ptr() != sae._parameters[n].data_ptr()
+                                         for n in ("W_enc", "W_dec", "b_enc", "b_dec") + tc_names)     # e.g. b_dec.data re-bound by an init
+                                     or tuple(n for n in ("b_dec_out", "W_skip") if n in eng.params) != tc_names)
         if eng is None or eng.max_tokens < n_tokens or stale:
             if self.world > 1 and eng is None:
                 # replicas must start from identical parameters (a per-rank b_dec initialisation, a different seed or a
@@ -211,12 +218,13 @@ class VisionSAETrainer:
             eng = NativeSAE(P_["W_enc"], P_["W_dec"], P_["b_enc"], P_["b_dec"],
                             k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
                             layer_norm=sae.cfg.normalize_activations == "layer_norm",
-                            max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world))
+                            max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world),
+                            **{n: P_[n] for n in tc_names})
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
                 eng.adam_step = old.adam_step
-            if self.world == 1:
+            if self.world == 1 and isinstance(sae, StandardSparseAutoencoder):
                 # one process: nobody but the kernels reads W_enc between steps -- they read its transposed master -- so the
                 # parameter's own layout is rewritten only when somebody asks for it (sae.W_enc, state_dict(), parameters())
                 eng.lazy_w_enc = True
@@ -324,7 +332,8 @@ class VisionSAETrainer:
         if self.world == 1:
             # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
             # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
-            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True)
+            tc = eng.transcoder                                 # (complete gradient buffers: the skip matrix and b_dec_out join the clip norm)
+            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=not tc, target=self._target if tc else None)
             eng.grad_sqnorm(from_step=True)                     # clip_grad_norm_ (the gradient is as the step wrote it)
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
@@ -348,7 +357,8 @@ class VisionSAETrainer:
             dead = None
             if sae.cfg.use_ghost_grads and sae.training:        # train_sae.py:330-332 (the mask is taken BEFORE this step's statistics)
                 dead = n_since_fired > sae.cfg.dead_feature_window
-            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True, dead_mask=dead)
+            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True, dead_mask=dead,
+                           target=self._target if eng.transcoder else None)
         else:
             import torch.distributed as dist
             W = self.world
