@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 12
+#define PV_ABI_VERSION 13
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -278,6 +278,20 @@ typedef struct pv_sae_transcoder {
     size_t scratch_bytes;
 } pv_sae_transcoder;
 
+/* Gated SAE (GatedSparseAutoencoder, sae.py:648-792, activation_fn_str = "relu"): gate path (sae_in @ W_enc + b_gate) > 0,
+ * magnitude path with shared weights sae_in @ (W_enc * exp(r_mag)) + b_mag, L1 on relu(gate pre-activation) weighted by the
+ * decoder row norms, auxiliary reconstruction of sae_in through the gate.  b_gate != NULL makes a state a gated one:
+ * pv_sae_gated_step is its train step, pv_sae_apply adds plain Adam on the three vectors.  pv_sae_state.b_enc exists (the
+ * reference keeps the parameter) but takes no part: its gradient is written as zero. */
+typedef struct pv_sae_gated {
+    float *b_gate, *r_mag, *b_mag;                 /* [d_sae]                                            */
+    float *gb_gate, *gr_mag, *gb_mag;
+    float *mb_gate, *mr_mag, *mb_mag;
+    float *vb_gate, *vr_mag, *vb_mag;
+    void* scratch;                                 /* pv_sae_gated_scratch_bytes                         */
+    size_t scratch_bytes;
+} pv_sae_gated;
+
 /* fp32 master parameters in the reference's layouts (sae.py:537-555), their gradients, Adam
  * moments and training statistics -- all caller-owned (torch tensors), fp32 unless stated. */
 typedef struct pv_sae_state {
@@ -306,6 +320,7 @@ typedef struct pv_sae_state {
     float *enc_colsq;                              /* [d_sae] ||W_enc[:, j]||^2 (error bound of the filter)           */
     float *dec_inv_norm;                           /* [d_sae] scratch of PV_SAE_RENORM_DECODER (1 / ||W_dec[j]||), or NULL */
     pv_sae_transcoder tc;                          /* all NULL: a plain autoencoder                                   */
+    pv_sae_gated gt;                               /* all NULL: not a gated SAE                                       */
 } pv_sae_state;
 
 /* Per-step outputs, caller-owned. */
@@ -419,6 +434,17 @@ size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, i
 int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
                       int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* One train step of a gated SAE (single process): forward + backward + statistics on the dense GEMM kernel -- the shared
+ * product sae_in @ W_enc once (both paths in its epilogue), the two decoder products (feature_acts and relu(gate)) as ONE GEMM
+ * over stacked rows, likewise their two backward products and the two terms of gW_dec.  Gradients WRITTEN into st->g* and
+ * st->gt.g* (gb_enc = 0); flags: PV_SAE_UPDATE_STATS, PV_SAE_RENORM_DECODER (REQUIRED: the L1 term's decoder norms are taken
+ * as 1, which is what train_sae.py:307 establishes before every forward).  scalars: 0 loss = mse + l1 + aux, 1 mse_loss, 2 l0,
+ * 4 l1_loss, 6 auxiliary reconstruction loss.  Follow with pv_sae_grad_sqnorm over the flat gradient buffer and pv_sae_apply.
+ * d_in % 8 == 0, d_sae % 8 == 0. */
+size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens);
+int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, int32_t flags, float l1_coefficient,
+                      pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

@@ -215,3 +215,77 @@ def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dic
     return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total,
                 l1_loss=None if fw["l1_loss"] is None else float(fw["l1_loss"]),
                 ghost_loss=None if fw["ghost_loss"] is None else float(fw["ghost_loss"]))
+
+
+# ---- Gated SAE (sae/sae.py:648-792), ReLU activation ----------------------------------------------------------------------
+def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, Array]:
+    """GatedSparseAutoencoder.forward (:730-771) with activation_fn_str = "relu": gate path (sae_in @ W_enc + b_gate) > 0 (:703-706),
+    magnitude path with shared weights sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712), L1 on relu(gate pre-activation)
+    weighted by the decoder row norms (:780-784), auxiliary reconstruction of sae_in through the gate (:786-792)."""
+    dt = x.dtype.type
+    N, d = x.shape
+    if layer_norm:
+        xh, mu, std = ln_in(x)
+    else:
+        xh, mu, std = x, np.zeros((N, 1), x.dtype), np.ones((N, 1), x.dtype)
+    S = xh - P["b_dec"]
+    gate_pre = S @ P["W_enc"] + P["b_gate"]
+    active = gate_pre > 0
+    mag_pre = S @ (P["W_enc"] * np.exp(P["r_mag"])) + P["b_mag"]
+    feats = np.where(active, np.maximum(mag_pre, dt(0)), dt(0))
+    pre_out = feats @ P["W_dec"] + P["b_dec"]
+    sae_out = pre_out * std + mu if layer_norm else pre_out
+    nf = np.sqrt(((x - x.mean(axis=0, keepdims=True)) ** 2).sum(axis=-1, keepdims=True))
+    mse = ((sae_out - x) ** 2 / nf).sum() / dt(N * d)
+    pg = np.maximum(gate_pre, dt(0))                                   # _compute_gate_activation :773-778
+    wn = np.linalg.norm(P["W_dec"], axis=1)
+    l1 = dt(l1_coefficient) * ((pg * wn).sum(axis=-1).sum() / dt(N))
+    via = pg @ P["W_dec"] + P["b_dec"]
+    aux = ((via - S) ** 2).sum(axis=-1).sum() / dt(N)
+    l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()
+    return dict(sae_in=S, gate_pre=gate_pre, mag_pre=mag_pre, feature_acts=feats, pg=pg, via=via, sae_out=sae_out, mu=mu, std=std,
+                norm_factor=nf, wn=wn, loss=dt(mse + l1 + aux), mse_loss=dt(mse), l1_loss=dt(l1), aux_loss=dt(aux), l0=l0)
+
+
+def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True, l1_coefficient: float = 0.0,
+                   gates: Optional[Tuple[Array, Array]] = None) -> Dict[str, Array]:
+    """loss.backward() of the gated forward.  b_enc takes no part in it (its .grad stays None in the reference: no entry here).
+    gates = (feature_acts > 0, gate_pre > 0) to use instead of the oracle's own (tests: entries within summation noise of zero)."""
+    dt = x.dtype.type
+    N, d = x.shape
+    S, feats, pg = fw["sae_in"], fw["feature_acts"], fw["pg"]
+    on_f, on_g = (feats > 0, fw["gate_pre"] > 0) if gates is None else gates
+    d_out = dt(2.0) * (fw["sae_out"] - x) / fw["norm_factor"] / dt(N * d)
+    dY = d_out * fw["std"] if layer_norm else d_out
+    dVia = dt(2.0) * (fw["via"] - S) / dt(N)
+    er = np.exp(P["r_mag"])
+    dM = np.where(on_f, dY @ P["W_dec"].T, dt(0))                      # (no gradient through the Heaviside gate)
+    dG = np.where(on_g, dVia @ P["W_dec"].T + dt(l1_coefficient) / dt(N) * fw["wn"], dt(0))
+    dP = dM * er + dG
+    g = {}
+    g["W_dec"] = feats.T @ dY + pg.T @ dVia + (dt(l1_coefficient) / dt(N)) * pg.sum(axis=0)[:, None] * (P["W_dec"] / fw["wn"][:, None])
+    g["W_enc"] = S.T @ dP
+    g["b_gate"] = dG.sum(axis=0)
+    g["b_mag"] = dM.sum(axis=0)
+    g["r_mag"] = (dM * (fw["mag_pre"] - P["b_mag"])).sum(axis=0)       # d (p e^r) / d r = p e^r = mag_pre - b_mag
+    dS = dP @ P["W_enc"].T - dVia                                      # through the two encoder paths and as the aux target
+    g["b_dec"] = dY.sum(axis=0) + dVia.sum(axis=0) - dS.sum(axis=0)
+    return g
+
+
+def gated_train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, lr: float, step: int,
+                     max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, float]:
+    """VisionSAETrainer.train_step (sae/train_sae.py:278-411) on a GatedSparseAutoencoder.  P, opt hold every parameter but b_enc
+    (untouched by the optimizer: no gradient)."""
+    renorm_decoder(P)
+    fw = gated_forward(P, x, layer_norm, l1_coefficient)
+    fired = (fw["feature_acts"] > 0).sum(axis=0)
+    stats["n_fwd_since_fired"] += 1
+    stats["n_fwd_since_fired"][fired > 0] = 0
+    stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
+    g = gated_backward(P, x, fw, layer_norm, l1_coefficient)
+    Pg = {k: P[k] for k in g}
+    total = clip_and_project(Pg, g, max_grad_norm)
+    adam_step(Pg, g, {k: opt["m"][k] for k in g}, {k: opt["v"][k] for k in g}, lr, step)
+    return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l1_loss=float(fw["l1_loss"]), aux_loss=float(fw["aux_loss"]),
+                l0=float(fw["l0"]), grad_norm=total)

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -64,11 +64,17 @@ class SaeTranscoder(C.Structure):
                                            "vW_skip", "target", "scratch")] + [("scratch_bytes", C.c_size_t)]
 
 
+class SaeGated(C.Structure):
+    """pv_sae_gated: all NULL = not a gated SAE."""
+    _fields_ = [(n, C.c_void_p) for n in ("b_gate", "r_mag", "b_mag", "gb_gate", "gr_mag", "gb_mag", "mb_gate", "mr_mag", "mb_mag",
+                                           "vb_gate", "vr_mag", "vb_mag", "scratch")] + [("scratch_bytes", C.c_size_t)]
+
+
 class SaeState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "W_enc", "W_dec", "b_enc", "b_dec", "gW_enc", "gW_dec", "gb_enc", "gb_dec",
         "mW_enc", "mW_dec", "mb_enc", "mb_dec", "vW_enc", "vW_dec", "vb_enc", "vb_dec",
-        "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq", "dec_inv_norm")] + [("tc", SaeTranscoder)]
+        "act_freq_scores", "n_fwd_since_fired", "W_encT", "W_enc16T", "enc_colsq", "dec_inv_norm")] + [("tc", SaeTranscoder), ("gt", SaeGated)]
 
 
 class SaeGhost(C.Structure):
@@ -93,7 +99,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_sae_tp_partial", "pv_sae_tp_finish", "pv_sae_tp_merge", "pv_sae_tp_bucket_pack", "pv_sae_tp_bucket_unpack",
-    "pv_sae_dense_step", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes",
+    "pv_sae_dense_step", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes", "pv_sae_gated_scratch_bytes", "pv_sae_gated_step",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -154,6 +160,9 @@ def lib() -> C.CDLL:
         L.pv_sae_ghost_workspace_bytes.restype = sz
         L.pv_sae_transcoder_scratch_bytes.argtypes = [vp, i32]
         L.pv_sae_transcoder_scratch_bytes.restype = sz
+        L.pv_sae_gated_scratch_bytes.argtypes = [vp, i32]
+        L.pv_sae_gated_scratch_bytes.restype = sz
+        L.pv_sae_gated_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_tp_merge.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.pv_sae_tp_bucket_pack.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.pv_sae_tp_bucket_unpack.argtypes = [vp, vp, vp, vp]

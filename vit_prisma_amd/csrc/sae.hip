@@ -1618,6 +1618,7 @@ extern "C" int pv_sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, con
 extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int32_t N, float* sae_out,
                               int32_t* topk_idx, float* topk_val, float* ln_mu, float* ln_std, float* scalars, void* workspace,
                               size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_gated(st), "this entry point does not serve a gated state (pv_sae_state.gt)");
     PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_forward: not available for a transcoder state (pv_sae_state.tc)");
     PV_REQUIRE(plan && st && x && sae_out && topk_idx && topk_val && workspace, "null argument");
     const pv_sae_desc& d = plan->d;
@@ -1678,6 +1679,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            st->dec_inv_norm, d.d_sae, d.d_in);
     }
     if (renorm) inv_norm = st->dec_inv_norm;
+    PV_REQUIRE(!sae_is_gated(st), "pv_sae_step does not serve a gated state: pv_sae_gated_step");
     // transcoder (pv_sae_state.tc): the loss is taken against tc.target, the decoder adds b_dec_out and the skip term
     const bool tc = sae_is_tc(st);
     if (tc) {
@@ -1795,6 +1797,7 @@ __global__ __launch_bounds__(256) void sae_recount_kernel(const int32_t* __restr
 
 extern "C" int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int32_t* topk_idx, const float* topk_val, int32_t N,
                                  int32_t flags, float* partial, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_gated(st), "this entry point does not serve a gated state (pv_sae_state.gt)");
     PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_tp_partial: not available for a transcoder state (pv_sae_state.tc)");
     PV_REQUIRE(plan && st && topk_idx && topk_val && partial && st->W_dec, "null argument");
     const pv_sae_desc& d = plan->d;
@@ -1828,6 +1831,7 @@ extern "C" int pv_sae_tp_partial(pv_sae_plan* plan, pv_sae_state* st, const int3
 extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float* x, const float* pre_sum, const int32_t* topk_idx,
                                 const float* topk_val, int32_t N, int32_t n_global, int32_t flags, pv_sae_out* out,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(!st || !sae_is_gated(st), "this entry point does not serve a gated state (pv_sae_state.gt)");
     PV_REQUIRE(!st || !sae_is_tc(st), "pv_sae_tp_finish: not available for a transcoder state (pv_sae_state.tc)");
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && pre_sum && topk_idx && topk_val && out && workspace, "null argument");
@@ -2121,6 +2125,16 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
         if (t.W_skip)
             hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in * d.d_in + 255) / 256), block, 0, stream, t.W_skip, (const float*)t.gW_skip,
                                t.mW_skip, t.vW_skip, scalars, c, 0, d.d_in * d.d_in);
+    }
+    if (sae_is_gated(st)) {                                            // gated SAE: plain Adam on b_gate, r_mag, b_mag
+        const pv_sae_gated& t = st->gt;
+        PV_REQUIRE(t.r_mag && t.b_mag && t.gb_gate && t.gr_mag && t.gb_mag && t.mb_gate && t.mr_mag && t.mb_mag && t.vb_gate && t.vr_mag && t.vb_mag,
+                   "gated Adam state");
+        PV_REQUIRE(j_lo == 0 && j_hi == d.d_sae, "gated SAE: the whole feature range");
+        const dim3 gv((d.d_sae + 255) / 256);
+        hipLaunchKernelGGL(adam_vec_kernel, gv, block, 0, stream, t.b_gate, (const float*)t.gb_gate, t.mb_gate, t.vb_gate, scalars, c, 0, d.d_sae);
+        hipLaunchKernelGGL(adam_vec_kernel, gv, block, 0, stream, t.r_mag, (const float*)t.gr_mag, t.mr_mag, t.vr_mag, scalars, c, 0, d.d_sae);
+        hipLaunchKernelGGL(adam_vec_kernel, gv, block, 0, stream, t.b_mag, (const float*)t.gb_mag, t.mb_mag, t.vb_mag, scalars, c, 0, d.d_sae);
     }
     PV_LAUNCH_CHECK("adam kernels");
     if (j_lo == 0 && j_hi == d.d_sae) plan->renorm_pending = false;      // (a sharded apply leaves the other ranks' rows to the all-gather)

@@ -79,4 +79,5 @@ int sae_tc_bias_grads(const pv_sae_desc& d, const pv_sae_state* st, const float*
 // W_skip); gW_skip = dY^T x
 int sae_tc_skip_forward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, int N, const float** skip, hipStream_t stream);
 int sae_tc_skip_backward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, const float* dY, int N, hipStream_t stream);
+static inline bool sae_is_gated(const pv_sae_state* st) { return st->gt.b_gate != nullptr; }
 constexpr int PV_SAE_DENSE_SPLITK = 4;       // K splits of the dense decoder GEMM (M = tokens, N = d_in: too few tiles otherwise)

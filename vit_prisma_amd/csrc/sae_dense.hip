@@ -37,7 +37,7 @@ constexpr int DG_TILE = DG_BM * DG_ROWB;      // 18432 >= 32 * 528
 constexpr int DG_CS_LD = 68;                  // fp32 staging row of the epilogue (floats)
 constexpr int DG_LDS = 4 * DG_TILE;           // As[2] + Bs[2] = 73728 >= 4 waves x 64 x 68 x 4
 
-enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3 };
+enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3, DG_EPI_GENC = 4 };
 
 struct DenseGemm {
     const float* A; int64_t lda;              // A_KM ? [K][lda] (M contiguous) : [M][lda] (K contiguous)
@@ -55,6 +55,13 @@ struct DenseGemm {
     float* dead_act; int64_t ldd;             // ENC: exp(hidden_pre) of the dead columns -> dead_act[row][slot];  DH: the ghost term of
                                               //      d loss / d hidden_pre, added to dH there
     const float* mul;                         // MUL: out = acc * mul (same shape and leading dimension as out)
+    // gated SAE (sae.py:699-716): GENC takes acc = sae_in @ W_enc and writes feature_acts = [acc + bias > 0] relu(acc e^cscale + bias2)
+    // to out, relu(acc + bias) to out2 (same leading dimension); colpart = firing counts, colpart2 / rowpart = sums of out2.
+    // DH with colpart2: additionally the column sums of dH * (the stored activation) (the gradient of r_mag)
+    const float* bias2;
+    const float* cscale;
+    float* out2;
+    float* colpart2;
 };
 
 // 16 bytes from global memory, or zeros (a plain branch: `ok ? *p : zero` makes hipcc select between two ADDRESSES and park the
@@ -193,10 +200,21 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     for (int i = 0; i < 8; ++i) csum[i] = 0.f;
     float rsum = 0.f;
     float b8[8];
-    if constexpr (EPI == DG_EPI_ENC) {
+    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_GENC) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) b8[i] = 0.f;
         if (col_ok) load8(p.bias + gn, b8);
+    }
+    float csum2[8], bm8[8], er8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { csum2[i] = 0.f; bm8[i] = 0.f; er8[i] = 1.f; }
+    if constexpr (EPI == DG_EPI_GENC) {
+        if (col_ok) {
+            load8(p.bias2 + gn, bm8);
+            load8(p.cscale + gn, er8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) er8[i] = expf(er8[i]);
+        }
     }
     int dslot[8];
 #pragma unroll
@@ -232,6 +250,19 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                     csum[i] += v[i] > 0.f ? 1.f : 0.f;                // firing counts (train_sae.py:356-364)
                     rsum += v[i];                                     // ||f||_1 (sae.py:617)
                 }
+            } else if constexpr (EPI == DG_EPI_GENC) {
+                float g8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float gate = v[i] + b8[i];                   // gating pre-activation (sae.py:703-706)
+                    const float mag = v[i] * er8[i] + bm8[i];          // sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712)
+                    g8[i] = fmaxf(gate, 0.f);                          // relu(gate): L1 + auxiliary path (:773-778)
+                    v[i] = gate > 0.f ? fmaxf(mag, 0.f) : 0.f;         // feature_acts (:714-716)
+                    csum[i] += v[i] > 0.f ? 1.f : 0.f;
+                    csum2[i] += g8[i];
+                    rsum += g8[i];
+                }
+                store8(p.out2 + (int64_t)gm * p.ldo + gn, g8);
             } else if constexpr (EPI == DG_EPI_DH) {
                 float f8[8];
                 load8(o, f8);                                          // the stored activation: the ReLU gate of the backward
@@ -240,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                     v[i] = f8[i] > 0.f ? v[i] + p.add : 0.f;           // d loss / d hidden_pre = (dF + l1 / N) [f > 0]
                     if (p.dead_slot && dslot[i] >= 0) v[i] += p.dead_act[(int64_t)gm * p.ldd + dslot[i]];    // + the ghost term (not gated)
                     csum[i] += v[i];                                  // gb_enc
+                    csum2[i] += v[i] * f8[i];
                 }
             } else if constexpr (EPI == DG_EPI_MUL) {
                 float m8[8];
@@ -250,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
             store8(o, v);
         }
     }
-    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_DH) {
+    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_DH || EPI == DG_EPI_GENC) {
         // the wave's 64 rows of each column: lanes with equal (lane & 7) hold the same 8 columns
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -260,7 +292,16 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         }
         const int rblk = tile_m * 2 + wm;
         if (lane < 8 && col_ok && m0 + wm * 64 < p.M) store8(p.colpart + (int64_t)rblk * p.N + gn, csum);
-        if constexpr (EPI == DG_EPI_ENC) {
+        if (EPI != DG_EPI_ENC && p.colpart2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                csum2[i] += __shfl_xor(csum2[i], 8, 64);
+                csum2[i] += __shfl_xor(csum2[i], 16, 64);
+                csum2[i] += __shfl_xor(csum2[i], 32, 64);
+            }
+            if (lane < 8 && col_ok && m0 + wm * 64 < p.M) store8(p.colpart2 + (int64_t)rblk * p.N + gn, csum2);
+        }
+        if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_GENC) {
             rsum = wave_sum(rsum);
             const int ncb = (p.N + 63) / 64;
             if (lane == 0 && m0 + wm * 64 < p.M && n0 + wn * 64 < p.N) p.rowpart[(int64_t)rblk * ncb + tile_n * 2 + wn] = rsum;
@@ -666,6 +707,254 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
             rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
             if (rc) return rc;
         }
+    }
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gated SAE step (GatedSparseAutoencoder, sae.py:648-792; pv_sae_gated).  hs [2N][F]: rows [0, N) feature_acts (later dM, then
+// dP), rows [N, 2N) relu(gate pre-activation) (later dG); dYs [2N][D]: rows [0, N) dY of the reconstruction, rows [N, 2N)
+// d aux / d (reconstruction through the gate).  Stacking the two row sets makes the two decoder products one GEMM, and
+// gW_dec = f^T dY + relu(gate)^T dVia one GEMM over K = 2N.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GatedWs {
+    size_t total, hs, dys, kpart, colpart2, auxpart, vec0, vec1, vec2, tmpd, cspart;
+};
+GatedWs gated_carve(const pv_sae_desc& d, int N) {
+    GatedWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    const size_t F = d.d_sae, D = d.d_in, n = N;
+    w.hs = take(2 * n * F * 4);
+    w.dys = take(2 * n * D * 4);
+    w.kpart = take((size_t)PV_SAE_DENSE_SPLITK * 2 * n * D * 4);
+    w.colpart2 = take(((n + 63) / 64) * F * 4);
+    w.auxpart = take(n * 4);
+    w.vec0 = take(F * 4);
+    w.vec1 = take(F * 4);
+    w.vec2 = take(F * 4);
+    w.tmpd = take(D * 4);
+    w.cspart = take((n / 16 + 2) * D * 4);
+    w.total = off + 256;
+    return w;
+}
+
+// rows [0, N): decoder output -> LN-out, mse partial, dY (as dense_finish_kernel); rows [N, 2N): reconstruction through the gate
+// -> auxiliary loss partial and its gradient (sae.py:786-792: sum_i (via - sae_in)^2, mean over the batch).  One wave per row.
+__global__ __launch_bounds__(256) void gated_finish_kernel(const float* __restrict__ x, const float* __restrict__ sae_in,
+                                                           const float* __restrict__ kpart, int splits, int64_t zstride,
+                                                           const float* __restrict__ b_dec, const float* __restrict__ mu,
+                                                           const float* __restrict__ sd, const float* __restrict__ norm,
+                                                           float* __restrict__ sae_out, float* __restrict__ dYs,
+                                                           float* __restrict__ loss_partial, float* __restrict__ aux_partial, int n_tok,
+                                                           int d, float grad_scale, float aux_scale /* 2 / N */) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= 2 * n_tok) return;
+    const bool second = r >= n_tok;
+    const int n = second ? r - n_tok : r;
+    const float m = mu[n], sdv = sd[n], nf = norm[n];
+    float lsum = 0.f;
+    for (int c = 4 * lane; c < d; c += 256) {
+        float4 a = *reinterpret_cast<const float4*>(kpart + (int64_t)r * d + c);
+        for (int z = 1; z < splits; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(kpart + z * zstride + (int64_t)r * d + c);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const float4 bd = *reinterpret_cast<const float4*>(b_dec + c);
+        float4 e, g;
+        if (!second) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + c);
+            float4 o;
+            o.x = (a.x + bd.x) * sdv + m; o.y = (a.y + bd.y) * sdv + m; o.z = (a.z + bd.z) * sdv + m; o.w = (a.w + bd.w) * sdv + m;
+            e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
+            if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + c) = o;
+            lsum += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;
+            g.x = grad_scale * e.x / nf * sdv; g.y = grad_scale * e.y / nf * sdv;
+            g.z = grad_scale * e.z / nf * sdv; g.w = grad_scale * e.w / nf * sdv;
+        } else {
+            const float4 sv = *reinterpret_cast<const float4*>(sae_in + (int64_t)n * d + c);
+            e.x = a.x + bd.x - sv.x; e.y = a.y + bd.y - sv.y; e.z = a.z + bd.z - sv.z; e.w = a.w + bd.w - sv.w;
+            lsum += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+            g.x = aux_scale * e.x; g.y = aux_scale * e.y; g.z = aux_scale * e.z; g.w = aux_scale * e.w;
+        }
+        *reinterpret_cast<float4*>(dYs + (int64_t)r * d + c) = g;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) (second ? aux_partial : loss_partial)[n] = lsum;
+}
+
+// scalars[0] = mse + l1 + aux (sae.py:748), one thread
+__global__ void gated_loss_kernel(float* __restrict__ scalars) { scalars[0] = scalars[1] + scalars[4] + scalars[6]; }
+
+// dP = dM e^r + dG, in place over dM (rows [0, N) of hs; dG = rows [N, 2N))
+__global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, const float* __restrict__ r_mag, int64_t n_rows, int F) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n_rows * F) return;
+    const int c = (int)(i % F);
+    float4 a = *reinterpret_cast<const float4*>(hs + i);
+    const float4 g = *reinterpret_cast<const float4*>(hs + n_rows * F + i);
+    const float4 r = *reinterpret_cast<const float4*>(r_mag + c);
+    a.x = a.x * expf(r.x) + g.x; a.y = a.y * expf(r.y) + g.y; a.z = a.z * expf(r.z) + g.z; a.w = a.w * expf(r.w) + g.w;
+    *reinterpret_cast<float4*>(hs + i) = a;
+}
+
+// per feature: gr_mag = sum_n dM (mag_pre - b_mag) = sum_n dM f - b_mag gb_mag (dM != 0 only where f = mag_pre > 0);
+// colsum(dP) = e^r gb_mag + gb_gate -> dpsum (the encoder-input term of gb_dec)
+__global__ __launch_bounds__(256) void gated_vec_kernel(const float* __restrict__ sdmf, const float* __restrict__ gb_mag,
+                                                        const float* __restrict__ gb_gate, const float* __restrict__ b_mag,
+                                                        const float* __restrict__ r_mag, float* __restrict__ gr_mag,
+                                                        float* __restrict__ dpsum, int F) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= F) return;
+    gr_mag[j] = sdmf[j] - b_mag[j] * gb_mag[j];
+    dpsum[j] = expf(r_mag[j]) * gb_mag[j] + gb_gate[j];
+}
+
+// gW_dec[j] += coef * pgsum[j] * W_dec[j] / ||W_dec[j]||: the decoder-norm factor of the L1 term (sae.py:780-784); one wave per row
+__global__ __launch_bounds__(256) void gated_l1_rows_kernel(float* __restrict__ gW_dec, const float* __restrict__ W_dec,
+                                                            const float* __restrict__ pgsum, float coef, int F, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= F) return;
+    float sq = 0.f;
+    for (int c = lane; c < d; c += 64) { const float w = W_dec[(int64_t)j * d + c]; sq += w * w; }
+    sq = wave_sum(sq);
+    const float s = coef * pgsum[j] / sqrtf(sq);
+    for (int c = lane; c < d; c += 64) gW_dec[(int64_t)j * d + c] += s * W_dec[(int64_t)j * d + c];
+}
+
+__global__ __launch_bounds__(256) void gated_axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+}  // namespace
+
+extern "C" size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens) {
+    if (!plan || n_tokens < 1) return 0;
+    return gated_carve(plan->d, n_tokens).total;
+}
+
+extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t flags, float l1_coefficient,
+                                 pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    PV_REQUIRE(plan && st && x && out && workspace && out->scalars, "null argument");
+    PV_REQUIRE(sae_is_gated(st) && !sae_is_tc(st), "pv_sae_gated_step needs a gated state (pv_sae_state.gt) and no transcoder");
+    const pv_sae_gated& t = st->gt;
+    PV_REQUIRE(t.r_mag && t.b_mag && t.gb_gate && t.gr_mag && t.gb_mag && t.scratch, "gated state");
+    PV_REQUIRE(st->W_dec && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec && st->W_encT, "state");
+    PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
+    PV_REQUIRE(flags & PV_SAE_RENORM_DECODER, "pv_sae_gated_step: PV_SAE_RENORM_DECODER is required (unit decoder rows in the L1 term)");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(d.d_in % 8 == 0 && d.d_sae % 8 == 0, "the gated step needs d_in and d_sae to be multiples of 8");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total && ((uintptr_t)workspace & 255) == 0, "workspace too small / misaligned");
+    const GatedWs gw = gated_carve(d, N);
+    PV_REQUIRE(t.scratch_bytes >= gw.total && ((uintptr_t)t.scratch & 255) == 0, "gated scratch too small / misaligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    unsigned char* gb = (unsigned char*)t.scratch;
+    plan->live_offs = nullptr;
+    plan->renorm_pending = false;
+    const int F = d.d_sae, D = d.d_in;
+    int rc = pv_sae_renorm_decoder(plan, st, stream_);                   // train_sae.py:307
+    if (rc) return rc;
+    rc = sae_prep(d, x, (const float*)st->b_dec, nullptr, N, false, wsb, ws, stream);
+    if (rc) return rc;
+    float* hs = (float*)(gb + gw.hs);
+    float* dYs = (float*)(gb + gw.dys);
+    float* kpart = (float*)(gb + gw.kpart);
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    float* colpart = (float*)(wsb + ws.dense_colpart);
+    float* colpart2 = (float*)(gb + gw.colpart2);
+    float* rowpart = (float*)(wsb + ws.dense_rowpart);
+    float* pgsum = (float*)(gb + gw.vec0);
+    float* sdmf = (float*)(gb + gw.vec1);
+    const int rblk = (N + 63) / 64, cblk = (F + 63) / 64, nb_f = (F + 255) / 256;
+    float* blk_tot = (float*)(wsb + ws.sqpart);
+    {
+        ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + 2.0 * N * F) * 4.0);
+        // G1: p = sae_in @ W_enc once; both paths in the epilogue
+        DenseGemm g = {};
+        g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
+        g.out = hs; g.ldo = F; g.out2 = hs + (size_t)N * F; g.bias = t.b_gate; g.bias2 = t.b_mag; g.cscale = t.r_mag;
+        g.colpart = colpart; g.colpart2 = colpart2; g.rowpart = rowpart;
+        rc = launch_dense_gemm<false, false, DG_EPI_GENC>(g, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
+                           out->fire_count ? out->fire_count : (float*)(wsb + ws.rowsq), (float*)nullptr, st->act_freq_scores,
+                           st->n_fwd_since_fired, update_stats, blk_tot);
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart2, rblk, F, pgsum,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+        PV_LAUNCH_CHECK("dense_colreduce_kernel");
+        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream);                        // l0
+        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)N, 4, -1, stream);       // l1 (unit decoder rows)
+    }
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 14.0 * N * (double)D * F, 0.0);
+        // G2: [f; relu(gate)] @ W_dec, split over K
+        const int S = PV_SAE_DENSE_SPLITK;
+        DenseGemm g = {};
+        g.A = hs; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = 2 * N; g.N = D; g.K = F;
+        g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
+        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)2 * N * D;
+        rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gated_finish_kernel, dim3((2 * N + 3) / 4), dim3(256), 0, stream, x, (const float*)sae_in, (const float*)kpart, S,
+                           (int64_t)2 * N * D, (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
+                           (const float*)(wsb + ws.norm), out->sae_out, dYs, (float*)(wsb + ws.loss_part), (float*)(gb + gw.auxpart), N, D,
+                           2.0f / ((float)N * (float)D), 2.0f / (float)N);
+        PV_LAUNCH_CHECK("gated_finish_kernel");
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)N * (float)D), 1, -1, stream);
+        sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / (float)N, 6, -1, stream);
+        hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
+        // G4: gW_dec = [f; relu(gate)]^T @ [dY; dVia] (K = 2N) + the decoder-norm factor of the L1 term
+        DenseGemm g4 = {};
+        g4.A = hs; g4.lda = F; g4.B = dYs; g4.ldb = D; g4.M = F; g4.N = D; g4.K = 2 * N; g4.k_chunk = 2 * N;
+        g4.out = st->gW_dec; g4.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gated_l1_rows_kernel, dim3((F + 3) / 4), dim3(256), 0, stream, st->gW_dec, (const float*)st->W_dec,
+                           (const float*)pgsum, l1_coefficient / (float)N, F, D);
+        // G3a: dM = (dY @ W_dec^T) [f > 0] over f; column sums = gb_mag, of dM * f = the raw term of gr_mag
+        DenseGemm g3 = {};
+        g3.A = dYs; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
+        g3.out = hs; g3.ldo = F; g3.colpart = colpart; g3.colpart2 = colpart2; g3.add = 0.f;
+        rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_mag,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart2, rblk, F, sdmf,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+        // G3b: dG = (dVia @ W_dec^T + l1 / N) [gate > 0] over relu(gate); column sums = gb_gate
+        g3.A = dYs + (size_t)N * D; g3.out = hs + (size_t)N * F; g3.colpart2 = nullptr; g3.add = l1_coefficient / (float)N;
+        rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_gate,
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+        // gr_mag; colsum(dP) parked in gb_enc for the bias-gradient kernels below
+        hipLaunchKernelGGL(gated_vec_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)sdmf, (const float*)t.gb_mag,
+                           (const float*)t.gb_gate, (const float*)t.b_mag, (const float*)t.r_mag, t.gr_mag, st->gb_enc, F);
+        // dP = dM e^r + dG, then G5: gW_enc^T = dP^T @ sae_in
+        hipLaunchKernelGGL(gated_dp_kernel, dim3((unsigned)(((int64_t)N * F / 4 + 255) / 256)), dim3(256), 0, stream, hs,
+                           (const float*)t.r_mag, (int64_t)N, F);
+        PV_LAUNCH_CHECK("gated elementwise kernels");
+        DenseGemm g5 = {};
+        g5.A = hs; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
+        g5.out = st->gW_enc; g5.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
+        if (rc) return rc;
+        // gb_dec = colsum(dY) + 2 colsum(dVia) - W_enc colsum(dP): b_dec sits in the decoder twice and in sae_in, which is also
+        // the auxiliary loss's target
+        rc = sae_gbdec(d, st, dYs, N, wsb, ws, stream);                   // colsum(dY) - W_enc gb_enc (= colsum(dP) for now)
+        if (rc) return rc;
+        rc = sae_colsum(dYs + (size_t)N * D, N, D, (float*)(gb + gw.tmpd), 2.0f, (float*)(gb + gw.cspart), stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gated_axpy_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, st->gb_dec, (const float*)(gb + gw.tmpd), D);
+        PV_LAUNCH_CHECK("gated_axpy_kernel");
+        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)F * 4, stream));      // b_enc takes no part in a gated SAE
     }
     return PV_OK;
 }

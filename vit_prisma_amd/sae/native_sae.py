@@ -27,14 +27,19 @@ from .. import _native as N
 class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
                  layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False,
-                 b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None):
+                 b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None,
+                 gated: Optional[Dict[str, torch.Tensor]] = None):
         """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``.
         b_dec_out [d_in] (+ W_skip [d_in, d_in]): a Transcoder (sae/transcoder.py; pv_sae_transcoder) -- ``step`` /
-        ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input."""
+        ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input.
+        gated = {b_gate, r_mag, b_mag} [d_sae] each: a GatedSparseAutoencoder (sae.py:648-792; pv_sae_gated) -- ``gated_step`` is
+        its train step (``b_enc`` is kept but plays no part)."""
         self.transcoder = b_dec_out is not None
+        self.gated = gated is not None
+        assert not (self.gated and (self.transcoder or inference)), "gated: training engine, no transcoder"
         assert W_skip is None or self.transcoder, "W_skip belongs to a transcoder (pass b_dec_out)"
         assert not (self.transcoder and inference), "the inference entry points do not serve a transcoder"
-        for t in (W_enc, W_dec, b_enc, b_dec) + tuple(t for t in (b_dec_out, W_skip) if t is not None):
+        for t in (W_enc, W_dec, b_enc, b_dec) + tuple(t for t in (b_dec_out, W_skip) if t is not None) + tuple((gated or {}).values()):
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
                 raise N.NativeError("native SAE needs contiguous fp32 CUDA parameters")
         self.lib = N.lib()
@@ -50,6 +55,9 @@ class NativeSAE:
             self._src["b_dec_out"] = b_dec_out
             if W_skip is not None:
                 self._src["W_skip"] = W_skip
+        if self.gated:
+            assert sorted(gated) == ["b_gate", "b_mag", "r_mag"] and all(tuple(t.shape) == (self.d_sae,) for t in gated.values())
+            self._src.update(gated)
         self.params = {n: t.detach() for n, t in self._src.items()}
         desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
                          max_tokens=self.max_tokens, ln_eps=ln_eps)
@@ -61,6 +69,8 @@ class NativeSAE:
         self.n_flat = 2 * nW + self.d_sae + self.d_in
         if self.transcoder:
             self.n_flat += self.d_in + (self.d_in * self.d_in if W_skip is not None else 0)
+        if self.gated:
+            self.n_flat += 3 * self.d_sae
         f32 = dict(dtype=torch.float32, device=dev)
         self.inference = bool(inference)
         n_alloc = 0 if inference else self.n_flat
@@ -82,17 +92,20 @@ class NativeSAE:
                 out["b_dec_out"] = flat[o:o + self.d_in]; o += self.d_in
                 if "W_skip" in self._src:
                     out["W_skip"] = flat[o:o + self.d_in * self.d_in].view(self.d_in, self.d_in)
+            if self.gated:
+                for name in ("b_gate", "r_mag", "b_mag"):
+                    out[name] = flat[o:o + self.d_sae]; o += self.d_sae
             return out
 
         def param_layout(v: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
             out = dict(W_enc=v["W_encT"].t(), W_dec=v["W_dec"], b_enc=v["b_enc"], b_dec=v["b_dec"])
-            out.update({n: v[n] for n in ("b_dec_out", "W_skip") if n in v})
+            out.update({n: v[n] for n in ("b_dec_out", "W_skip", "b_gate", "r_mag", "b_mag") if n in v})
             return out
 
         self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
         # views in the parameters' own layouts (W_enc: a transposed, non-contiguous view)
         self.g = dict(W_enc=self._g["W_encT"], W_dec=self._g["W_dec"], b_enc=self._g["b_enc"], b_dec=self._g["b_dec"])   # NB: g["W_enc"] is TRANSPOSED
-        self.g.update({n: self._g[n] for n in ("b_dec_out", "W_skip") if n in self._g})
+        self.g.update({n: self._g[n] for n in ("b_dec_out", "W_skip", "b_gate", "r_mag", "b_mag") if n in self._g})
         self.m, self.v = param_layout(self._m), param_layout(self._v)
         # encoder shadows
         self.W_encT = torch.empty(self.d_sae, self.d_in, **f32)
@@ -113,6 +126,9 @@ class NativeSAE:
         if self.transcoder and W_skip is not None:
             self._tc_scratch = torch.empty(self.lib.pv_sae_transcoder_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8,
                                            device=dev)
+        self._gt_scratch = None
+        if self.gated:
+            self._gt_scratch = torch.empty(self.lib.pv_sae_gated_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8, device=dev)
         self.adam_step = 0
         self._shadow_key: Optional[Tuple[int, int]] = None
         self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
@@ -148,7 +164,19 @@ class NativeSAE:
             vW_enc=v["W_encT"].data_ptr(), vW_dec=v["W_dec"].data_ptr(), vb_enc=v["b_enc"].data_ptr(), vb_dec=v["b_dec"].data_ptr(),
             act_freq_scores=self.act_freq_scores.data_ptr(), n_fwd_since_fired=self.n_fwd_since_fired.data_ptr(),
             W_encT=self.W_encT.data_ptr(), W_enc16T=self.W_enc16T.data_ptr(), enc_colsq=self.enc_colsq.data_ptr(),
-            dec_inv_norm=self.dec_inv_norm.data_ptr(), tc=self._tc_state())
+            dec_inv_norm=self.dec_inv_norm.data_ptr(), tc=self._tc_state(), gt=self._gt_state())
+
+    def _gt_state(self) -> N.SaeGated:
+        if not self.gated:
+            return N.SaeGated()
+        P, g, m, v = self.params, self._g, self._m, self._v
+        kw = {}
+        for name, short in (("b_gate", "b_gate"), ("r_mag", "r_mag"), ("b_mag", "b_mag")):
+            kw[short] = P[name].data_ptr()
+            kw["g" + short] = g[name].data_ptr()
+            kw["m" + short] = m[name].data_ptr()
+            kw["v" + short] = v[name].data_ptr()
+        return N.SaeGated(scratch=self._gt_scratch.data_ptr(), scratch_bytes=self._gt_scratch.numel(), **kw)
 
     def _tc_state(self) -> N.SaeTranscoder:
         if not self.transcoder:
@@ -295,6 +323,22 @@ class NativeSAE:
                                            C.byref(ghost) if ghost is not None else None,
                                            C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
                 "pv_sae_dense_step")
+        self._inv_norm_key = None
+        self._grad_fresh = False
+        self._grad_sparse = False
+
+    def gated_step(self, x: torch.Tensor, l1_coefficient: float, update_stats: bool = True, want_out: bool = False) -> None:
+        """One train step of a gated SAE (pv_sae_gated_step; single process): set_decoder_norm_to_unit_norm, forward, backward,
+        statistics; gradients in ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, -, auxiliary loss."""
+        assert self.gated
+        x = self._check_x(x)
+        n = x.shape[0]
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
+                       scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
+        N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, int(bool(update_stats)) | 2, float(l1_coefficient),
+                                           C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
+                "pv_sae_gated_step")
         self._inv_norm_key = None
         self._grad_fresh = False
         self._grad_sparse = False

@@ -171,20 +171,26 @@ class VisionSAETrainer:
     # ---- native engine ----------------------------------------------------------------------------
     def _native_kind(self, sae, x: torch.Tensor) -> Optional[str]:
         """Which fused HIP step serves this SAE: "topk" (k-sparse step, sae.hip), "relu" (dense ReLU + L1 step,
-        sae_dense.hip) or None (PyTorch path: gated / ghost gradients on top-k / other activations / CPU)."""
+        sae_dense.hip), "gated" (the gated SAE's dense step, sae_dense.hip) or None (PyTorch path: gated / ghost gradients on top-k / other activations / CPU)."""
         cfg = sae.cfg
         from .variants import Transcoder
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
         # single process, no ghost gradients
         is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in) and self.world == 1
                  and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
-        common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc) and cfg.dtype == torch.float32
+        from .variants import GatedSparseAutoencoder
+        # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own dense step (pv_sae_gated_step)
+        is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.activation_fn_str == "relu" and self.world == 1
+                    and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0)
+        common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
                   and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                   and self._native_pref is not False)
         if not common:
             return None
+        if is_gated:
+            return "gated"
         if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64 and not cfg.use_ghost_grads:
             return "topk"
         if (cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
@@ -200,7 +206,8 @@ class VisionSAETrainer:
         eng = self._engine
         tc_names = tuple(n for n in ("b_dec_out", "W_skip") if sae._parameters.get(n) is not None)
         stale = eng is not None and (any(eng.params[n].data_ptr() != sae._parameters[n].data_ptr()
-                                         for n in ("W_enc", "W_dec", "b_enc", "b_dec") + tc_names)     # e.g. b_dec.data re-bound by an init
+                                         for n in ("W_enc", "W_dec", "b_enc", "b_dec") + tc_names
+                                         + tuple(n for n in ("b_gate", "r_mag", "b_mag") if n in sae._parameters))     # e.g. b_dec.data re-bound by an init
                                      or tuple(n for n in ("b_dec_out", "W_skip") if n in eng.params) != tc_names)
         if eng is None or eng.max_tokens < n_tokens or stale:
             if self.world > 1 and eng is None:
@@ -219,7 +226,8 @@ class VisionSAETrainer:
                             k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
                             layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world),
-                            **{n: P_[n] for n in tc_names})
+                            **{n: P_[n] for n in tc_names},
+                            **({"gated": {n: P_[n] for n in ("b_gate", "r_mag", "b_mag")}} if "b_gate" in P_ else {}))
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
@@ -320,7 +328,19 @@ class VisionSAETrainer:
 
     def _native_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
         lr = optimizer.param_groups[0]["lr"]
-        if self._native_kind(sae, x) == "relu":
+        kind = self._native_kind(sae, x)
+        if kind == "gated":
+            eng = self._get_engine(sae, x.shape[0])
+            eng.act_freq_scores = act_freq_scores
+            eng.n_fwd_since_fired = n_since_fired
+            eng.gated_step(x, float(sae.l1_coefficient), update_stats=True)
+            eng.grad_sqnorm()
+            eng.apply(lr, self.cfg.max_grad_norm)
+            optimizer._opt_called = True
+            scheduler.step()
+            sc = eng.scalars.clone()
+            return sc[0], sc[1], sc[4], sc[2]
+        if kind == "relu":
             return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         if self._use_tp(sae):
             return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
