@@ -760,23 +760,27 @@ __global__ __launch_bounds__(256) void attn_lean_kernel(const AttnParams p) {
             tap_put(kt, sa);
         }
     };
+    u32x4_t kn1;
     {
         const u32x4_t k0 = fetch(rsK, 0);
+        kn1 = fetch(rsK, 1);
         *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;
     }
-    // per tile: issue the fetch of tile kt + 1 -> multiply tile kt out of LDS -> park the fetched tile in the other buffer
-    // -> flush the tap window when it is due -> barrier.  The flush comes LAST: its stores share vmcnt with the fetch, and
-    // a wave that waits for its tile behind freshly issued stores waits for HBM write latency at every flush.
+    // per tile: issue the fetch of tile kt + 2 -> multiply tile kt out of LDS -> park tile kt + 1 (fetched one iteration ago) in
+    // the other buffer -> flush the tap window when it is due -> barrier.  Loads and stores retire through ONE in-order counter
+    // (vmcnt): a tile that is waited for must have been requested BEFORE the stores of the last flush, or the wave sits out HBM
+    // write latency at every flush -- hence two tiles of fetch distance, and the flush behind the park.
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
-        const u32x4_t kn = fetch(rsK, kt + 1);
+        const u32x4_t kn2 = fetch(rsK, kt + 2);
         if (active) {
             if (kt + 1 < ntile) pass1_tile(kt, std::false_type{});
             else pass1_tile(kt, std::true_type{});
         }
-        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn;        // free since the barrier that ended tile kt - 1
+        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn1;       // free since the barrier that ended tile kt - 1
         if (active && sc_dst) tap_flush(sc_dst, kt);
         __syncthreads();
+        kn1 = kn2;
     }
     {   // merge the two lanes of a query
         const float mo = __shfl_xor(m, 32, 64), lo = __shfl_xor(l, 32, 64);
@@ -829,22 +833,27 @@ __global__ __launch_bounds__(256) void attn_lean_kernel(const AttnParams p) {
                 zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa[ks]), __builtin_bit_cast(bf16x8, vf), zacc[tn], 0, 0, 0);
             }
     };
+    u32x4_t vn1;
     {
         const u32x4_t k0 = fetch(rsK, 0), v0 = fetch(rsV, 0);
+        kn1 = fetch(rsK, 1);
+        vn1 = fetch(rsV, 1);
         *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;      // (everyone left pass 1's last tile, in Kst[(ntile - 1) & 1], through its closing barrier;
         stage_v(Vt[0], v0);                                      //  Kst[0] was last read one barrier earlier still when ntile is even)
     }
     __syncthreads();
     for (int kt = 0; kt < ntile; ++kt) {
-        const u32x4_t kn = fetch(rsK, kt + 1), vn = fetch(rsV, kt + 1);
+        const u32x4_t kn2 = fetch(rsK, kt + 2), vn2 = fetch(rsV, kt + 2);
         if (active) {
             if (kt + 1 < ntile) pass2_tile(kt, std::false_type{});
             else pass2_tile(kt, std::true_type{});
         }
-        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn;
-        stage_v(Vt[(kt + 1) & 1], vn);
+        *reinterpret_cast<u32x4_t*>(Kst[(kt + 1) & 1] + k_lds) = kn1;
+        stage_v(Vt[(kt + 1) & 1], vn1);
         if (active && pt_dst) tap_flush(pt_dst, kt);
         __syncthreads();
+        kn1 = kn2;
+        vn1 = vn2;
     }
     if (!active) return;
 
