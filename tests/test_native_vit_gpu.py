@@ -355,12 +355,12 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
         # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
         model.use_native(None)
-        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)])
+        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)])
         assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
-        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)]).cpu().numpy()) < FP32_TOL
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)]).cpu().numpy()) < FP32_TOL
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", scale_shift)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)])
         with pytest.raises(_native.NativeError):
             model.run_with_hooks(x, fwd_hooks=[("blocks.0.mlp.hook_pre", scale_shift)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
@@ -368,7 +368,8 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
 
 @pytest.mark.parametrize("arch_name,dtype", [("tiny", torch.float32), ("tiny-ragged", torch.float32), ("tiny", torch.bfloat16)])
 def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_plan(arch_name, dtype):
-    """Head ablation (attn.hook_z), edits of q / k / v and neuron ablation (mlp.hook_post) keep the HIP path: the plan is
+    """Head ablation (attn.hook_z), edits of q / k / v, of the attention scores and of the pattern, and neuron ablation
+    (mlp.hook_post) keep the HIP path: the plan is
     split INSIDE the block (pv_vit_forward_stage) -- the hook sees the stage's activation, the rest of the block resumes from
     what it returned, the residual stream it adds to is carried along.  Every result must equal the PyTorch hook path of the
     same model (prisma_tools/hook_point.py:44-45; models/layers/attention.py:135-152, 186-281; mlp.py:65-80), cache
@@ -391,7 +392,25 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
     def swap_heads(t, hook):
         return t.flip(2)
 
+    def no_cls_attention(t, hook):        # pattern [B, H, T, T]: nobody attends to the CLS token; rows renormalised
+        t = t.clone()
+        t[..., 0] = 0.0
+        return t / t.sum(-1, keepdim=True).clamp_min(1e-6)
+
+    def mask_scores(t, hook):             # scores [B, H, T, T], in place: head 0 cannot see the last key
+        t[:, 0, :, -1] = float("-inf")
+
+    def nan_row(t, hook):                 # a NaN score poisons its row: the reference's where(isnan) zeroes the pattern row
+        t[:, 1, 2, 3] = float("nan")
+
     cases = [
+        [("blocks.0.attn.hook_pattern", no_cls_attention)],
+        [(f"blocks.{nl - 1}.attn.hook_attn_scores", mask_scores)],
+        [("blocks.0.attn.hook_attn_scores", nan_row), ("blocks.0.attn.hook_pattern", half)],
+        [("blocks.1.attn.hook_q", half), ("blocks.1.attn.hook_attn_scores", mask_scores), ("blocks.1.attn.hook_pattern", no_cls_attention),
+         ("blocks.1.attn.hook_z", kill_head_1)],
+        [("blocks.0.attn.hook_v", swap_heads), ("blocks.0.attn.hook_pattern", half), ("blocks.0.hook_resid_mid", half)],
+        [(lambda n: n.endswith("attn.hook_pattern"), no_cls_attention)],
         [("blocks.0.attn.hook_z", kill_head_1)],
         [(f"blocks.{nl - 1}.attn.hook_z", half)],
         [("blocks.1.mlp.hook_post", kill_neurons)],
@@ -411,7 +430,7 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
             assert rel_fro(got.float().cpu().numpy(), want.float().cpu().numpy()) < tol
             assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
             for kw in ({}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post"))},
-                       {"stop_at_layer": nl - 1}):
+                       {"names_filter": lambda n: n.endswith(("hook_attn_scores", "hook_v", "hook_attn_out"))}, {"stop_at_layer": nl - 1}):
                 w_out, w_cache = ref.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
                 g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
                 assert model.last_run_native, model.native_fallback_reason
@@ -419,7 +438,10 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
                 assert rel_fro(g_out.float().cpu().numpy(), w_out.float().cpu().numpy()) < tol
                 for k in w_cache.keys():
                     a, b = g_cache[k].float().cpu().numpy(), w_cache[k].float().cpu().numpy()
-                    assert a.shape == b.shape and rel_fro(a, b) < tol, (k, kw)
+                    # (masked / poisoned scores: -inf and NaN must sit in the same places; the norm is taken over the rest)
+                    fin = np.isfinite(b)
+                    assert a.shape == b.shape and np.array_equal(np.isfinite(a), fin) and np.array_equal(np.isnan(a), np.isnan(b)), (k, kw)
+                    assert rel_fro(np.where(fin, a, 0.0), np.where(fin, b, 0.0)) < tol, (k, kw)
 
 
 def test_sae_substitution_style_eval_on_b32_bf16():

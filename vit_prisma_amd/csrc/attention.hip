@@ -923,6 +923,61 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     return PV_ERR_INVALID;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Resume behind a hooked hook_attn_scores / hook_pattern (see attention.hpp): a wave owns one query row of one (image, head).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_resume_kernel(const AttnParams p, int from_scores) {
+    __shared__ float prob[4][640];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;                 // (b * H + h) * T + t
+    const int T_ = p.T, H = p.H, dh = p.dh;
+    if (row >= (int64_t)p.B * H * T_) return;
+    const int t = (int)(row % T_);
+    const int64_t g = row / T_;
+    const int b = (int)(g / H), h = (int)(g - (int64_t)b * H);
+    float* pr = prob[wave];
+    const T* in = reinterpret_cast<const T*>(from_scores ? p.scores : p.pattern) + row * T_;
+    if (from_scores) {
+        float m = -INFINITY;
+        for (int c = lane; c < T_; c += 64) {
+            const float s = DT<T>::load(in + c);
+            pr[c] = s;
+            m = fmaxf(m, s);
+        }
+        m = wave_max(m);
+        float l = 0.f;
+        bool bad = false;
+        for (int c = lane; c < T_; c += 64) {
+            const float s = pr[c];
+            bad |= !(s == s);
+            const float e = expf(s - m);
+            pr[c] = e;
+            l += e;
+        }
+        l = wave_sum(l);
+        // a softmax row with a NaN (or nothing but -inf) in it is NaN throughout in the reference -> zeros (attention.py:149)
+        const bool row_bad = __builtin_amdgcn_ballot_w64(bad) != 0 || !(l > 0.f) || !(l < INFINITY) || !(m > -INFINITY) || !(m < INFINITY);
+        T* tap = p.pattern ? reinterpret_cast<T*>(p.pattern) + row * T_ : nullptr;
+        for (int c = lane; c < T_; c += 64) {
+            const float q = row_bad ? 0.f : DT<T>::round(pr[c] / l);
+            pr[c] = q;
+            if (tap) DT<T>::store(tap + c, q);
+        }
+    } else {
+        for (int c = lane; c < T_; c += 64) pr[c] = DT<T>::load(in + c);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // z[t, h, :] = sum_c pattern[c] v[c, h, :]  (attention.py:267-281); lane = d (two passes for d_head > 64 never occur: dh <= 64)
+    const T* vb = reinterpret_cast<const T*>(p.v) + ((int64_t)b * T_ * H + h) * dh;
+    const int64_t tok = (int64_t)H * dh;
+    if (lane < dh) {
+        float acc = 0.f;
+        for (int c = 0; c < T_; ++c) acc = fmaf(pr[c], DT<T>::load(vb + c * tok + lane), acc);
+        DT<T>::store(reinterpret_cast<T*>(p.z) + ((int64_t)b * T_ * H + h) * dh + (int64_t)t * tok + lane, acc);
+    }
+}
+
 }  // namespace
 
 int pv_attention_supported(int T, int dh) { return (T <= 640 && (dh == 64 || dh == 32)) ? 1 : 0; }
@@ -935,4 +990,17 @@ int pv_launch_attention(int dtype, AttnParams p, hipStream_t stream) {
     if (dtype == PV_DTYPE_F32) return dispatch_attn<float>(p, stream);
     pv_set_error("attention: unsupported dtype");
     return PV_ERR_INVALID;
+}
+
+int pv_launch_attention_resume(int dtype, AttnParams p, int from_scores, hipStream_t stream) {
+    PV_REQUIRE(p.v && p.z && (from_scores ? p.scores != nullptr : p.pattern != nullptr), "attention resume operands must be non-null");
+    PV_REQUIRE(p.T >= 1 && p.T <= 640 && p.dh >= 1 && p.dh <= 64, "attention resume: T <= 640, d_head <= 64");
+    const int64_t rows = (int64_t)p.B * p.H * p.T;
+    PV_REQUIRE((rows + 3) / 4 < (1ll << 31), "attention resume grid");
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == PV_DTYPE_BF16) hipLaunchKernelGGL(attn_resume_kernel<bf16_t>, grid, block, 0, stream, p, from_scores);
+    else if (dtype == PV_DTYPE_F32) hipLaunchKernelGGL(attn_resume_kernel<float>, grid, block, 0, stream, p, from_scores);
+    else { pv_set_error("attention resume: unsupported dtype"); return PV_ERR_INVALID; }
+    PV_LAUNCH_CHECK("attn_resume_kernel");
+    return PV_OK;
 }

@@ -183,7 +183,7 @@ extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
 }
 
 namespace {
-// entry_stage / exit_stage: PV_STAGE_* (positions inside a block: 0 entry, 1 q/k/v ready, 2 z ready, 3 resid_mid, 4 mlp post ready)
+// entry_stage / exit_stage: PV_STAGE_* (positions inside a block: entry, q/k/v ready, scores, pattern, z ready, resid_mid, mlp post ready)
 int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, const void* const* act_in, int32_t B,
                      int32_t first_block, int32_t entry_stage, int32_t n_blocks, int32_t exit_stage, int32_t run_head,
                      const pv_tap* taps, int32_t n_taps, void* workspace, size_t workspace_bytes, void* out, void* stream_);
@@ -225,6 +225,7 @@ extern "C" int pv_vit_forward_stage(pv_vit_plan* p, const void* images, const vo
                "empty or backward segment");
     if (entry_stage == PV_STAGE_QKV) PV_REQUIRE(act_in0 && act_in1 && act_in2, "entry at PV_STAGE_QKV needs q, k, v");
     if (entry_stage == PV_STAGE_Z || entry_stage == PV_STAGE_MLP_POST) PV_REQUIRE(act_in0, "entry at PV_STAGE_Z / PV_STAGE_MLP_POST needs the activation");
+    if (entry_stage == PV_STAGE_SCORES || entry_stage == PV_STAGE_PATTERN) PV_REQUIRE(act_in0 && act_in1, "entry at PV_STAGE_SCORES / PV_STAGE_PATTERN needs the activation and v");
     const void* act[3] = {act_in0, act_in1, act_in2};
     for (int i = 0; i < 3; ++i) PV_REQUIRE(!act[i] || pv_aligned16(act[i]), "activation inputs must be 16-byte aligned");
     return vit_forward_impl(p, images, resid_in, act, B, first_block, entry_stage, end_block, exit_stage, run_head, taps, n_taps,
@@ -370,7 +371,7 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
             q = const_cast<void*>(act_in[0]); k = const_cast<void*>(act_in[1]); v = const_cast<void*>(act_in[2]);
         }
         if (xs == PV_STAGE_QKV) break;
-        if (es < PV_STAGE_Z) {
+        if (es < PV_STAGE_SCORES) {
         // scores / pattern / z (attention.py:135-152, 246-281)
         z = pick(PV_SLOT_Z, l, ws.z);
         {
@@ -380,10 +381,19 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
             a.B = B; a.T = T; a.H = d.n_heads; a.dh = d.d_head; a.attn_scale = d.attn_scale;
             if ((rc = pv_launch_attention(dt, a, stream))) return rc;
         }
+        } else if (es == PV_STAGE_SCORES || es == PV_STAGE_PATTERN) {
+            // behind a hooked hook_attn_scores / hook_pattern: the rest of the core from the edited tensor and v
+            z = pick(PV_SLOT_Z, l, ws.z);
+            AttnParams a = {};
+            a.v = act_in[1]; a.z = z;
+            if (es == PV_STAGE_SCORES) { a.scores = const_cast<void*>(act_in[0]); a.pattern = tap_at(PV_SLOT_PATTERN, l); }
+            else a.pattern = const_cast<void*>(act_in[0]);
+            a.B = B; a.T = T; a.H = d.n_heads; a.dh = d.d_head; a.attn_scale = d.attn_scale;
+            if ((rc = pv_launch_attention_resume(dt, a, es == PV_STAGE_SCORES ? 1 : 0, stream))) return rc;
         } else {
             z = const_cast<void*>(act_in[0]);
         }
-        if (xs == PV_STAGE_Z) break;
+        if (xs == PV_STAGE_SCORES || xs == PV_STAGE_PATTERN || xs == PV_STAGE_Z) break;
         // attn_out = z W_O + b_O ; resid_mid = resid_pre + attn_out (attention.py:155-167 ; block :117-124)
         resid_mid = pick(PV_SLOT_RESID_MID, l, ws.resid_mid);
         {

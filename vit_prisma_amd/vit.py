@@ -453,7 +453,8 @@ class HookedViT(HookedRootModule):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
         if self._boundary_hooks() is None:
             return ("a hook is registered on a point the plan cannot be split at (supported: blocks.L.hook_resid_pre / hook_attn_out / "
-                    "hook_resid_mid / hook_mlp_out / hook_resid_post / attn.hook_q / attn.hook_k / attn.hook_v / attn.hook_z / mlp.hook_post)")
+                    "hook_resid_mid / hook_mlp_out / hook_resid_post / attn.hook_q / attn.hook_k / attn.hook_v / attn.hook_attn_scores / "
+                    "attn.hook_pattern / attn.hook_z / mlp.hook_post)")
         for mod in self._plain_modules:                    # (valid: the tree is the one this list was built from)
             if mod._forward_hooks or mod._forward_pre_hooks:
                 return "nn.Module hooks registered"
@@ -461,18 +462,21 @@ class HookedViT(HookedRootModule):
 
     # HookPoints a forward hook may sit on while the call stays on the native plan: the plan is split there
     _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.(hook_resid_pre|hook_attn_out|hook_resid_mid|hook_mlp_out|hook_resid_post|"
-                              r"attn\.hook_q|attn\.hook_k|attn\.hook_v|attn\.hook_z|mlp\.hook_post)$")
-    _NPOS = 5            # split positions per block: 0 entry | 1 q, k, v ready | 2 z ready | 3 after the attention half | 4 mlp post ready
+                              r"attn\.hook_q|attn\.hook_k|attn\.hook_v|attn\.hook_attn_scores|attn\.hook_pattern|attn\.hook_z|mlp\.hook_post)$")
+    # split positions per block (= PV_STAGE_*): 0 entry | 1 q, k, v ready | 2 scores | 3 pattern | 4 z ready | 5 after the attention
+    # half | 6 mlp post ready
+    _NPOS = 7
     _KIND_POS = {"hook_resid_pre": ("pre", 0), "attn.hook_q": ("q", 1), "attn.hook_k": ("k", 1), "attn.hook_v": ("v", 1),
-                 "attn.hook_z": ("z", 2), "hook_attn_out": ("attn", 3), "hook_resid_mid": ("mid", 3),
-                 "mlp.hook_post": ("mlppost", 4), "hook_mlp_out": ("mlp", 5), "hook_resid_post": ("post", 5)}
+                 "attn.hook_attn_scores": ("scores", 2), "attn.hook_pattern": ("pattern", 3),
+                 "attn.hook_z": ("z", 4), "hook_attn_out": ("attn", 5), "hook_resid_mid": ("mid", 5),
+                 "mlp.hook_post": ("mlppost", 6), "hook_mlp_out": ("mlp", 7), "hook_resid_post": ("post", 7)}
 
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
         """{position: {kind: HookPoint}} for every HookPoint that carries a forward hook, or None when some hook (a
         forward hook elsewhere, any backward hook) cannot be served by splitting the native plan.  Positions count
-        _NPOS per block: 5b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
-        fire there, in that order), 5b+1 = its q, k, v ("q", "k", "v"), 5b+2 = its z, 5b+3 = after its attention half
-        ("attn", then "mid"), 5b+4 = its MLP activation ("mlppost")."""
+        _NPOS = 7 per block: 7b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
+        fire there, in that order), 7b+1 = its q, k, v ("q", "k", "v"), 7b+2 = its attention scores, 7b+3 = its pattern, 7b+4 =
+        its z, 7b+5 = after its attention half ("attn", then "mid"), 7b+6 = its MLP activation ("mlppost")."""
         out: Dict[int, Dict[str, HookPoint]] = {}
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -554,10 +558,11 @@ class HookedViT(HookedRootModule):
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
                               remove_batch_dim=remove_batch_dim)
         # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
-        # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 + q, k, v | 1 attention core |
-        # 2 O-projection + residual | 3 ln2 + MLP up to the activation | 4 MLP output + residual.
+        # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 + q, k, v | 1 scores | 2 softmax |
+        # 3 pattern v | 4 O-projection + residual | 5 ln2 + MLP up to the activation | 6 MLP output + residual.
         wanted = set(names)
         cache: Dict[str, torch.Tensor] = {}
+        ST_O, ST_MLP = 4, 6                                      # stages of the O-projection / the MLP output
 
         def pos_of(name: str) -> int:
             """the stage that produces `name` (-1: embedding stage, NP * n_layers: final stage)"""
@@ -565,14 +570,18 @@ class HookedViT(HookedRootModule):
                 _, l, rest = name.split(".", 2)
                 if rest == "hook_resid_pre" or rest.startswith("ln1.") or rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
                     st = 0
-                elif rest.startswith("attn."):
+                elif rest == "attn.hook_attn_scores":
                     st = 1
-                elif rest in ("hook_attn_out", "hook_resid_mid"):
+                elif rest == "attn.hook_pattern":
                     st = 2
-                elif rest.startswith(("ln2.", "mlp.")):
+                elif rest.startswith("attn."):
                     st = 3
+                elif rest in ("hook_attn_out", "hook_resid_mid"):
+                    st = ST_O
+                elif rest.startswith(("ln2.", "mlp.")):
+                    st = 5
                 else:
-                    st = 4
+                    st = ST_MLP
                 return NP * int(l) + st
             return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
                 else NP * cfg.n_layers
@@ -595,46 +604,55 @@ class HookedViT(HookedRootModule):
                 forced = []
                 if not last:
                     pre_name, mid_name = f"blocks.{b1}.hook_resid_pre", f"blocks.{b1}.hook_resid_mid"
+                    v_name = f"blocks.{b1}.attn.hook_v"
                     if s1 == 0:
                         forced = [f"blocks.{blk}.hook_resid_post"]
                         if "mlp" in hooks:
-                            forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= NP * blk + 2 else [])
+                            forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= NP * blk + ST_O else [])
                     elif s1 == 1:
                         forced = [f"blocks.{b1}.attn.hook_{t}" for t in "qkv"] + ([pre_name] if pre_inside else [])
-                    elif s1 == 2:
+                    elif s1 in (2, 3):
+                        # the resumed attention core reads v next to the edited scores / pattern: tapped when this segment
+                        # computes it, carried from the previous segment's activations otherwise
+                        forced = [f"blocks.{b1}.attn." + ("hook_attn_scores" if s1 == 2 else "hook_pattern")]
+                        forced += ([v_name] if p0 <= NP * b1 else []) + ([pre_name] if pre_inside else [])
+                    elif s1 == 4:
                         forced = [f"blocks.{b1}.attn.hook_z"] + ([pre_name] if pre_inside else [])
-                    elif s1 == 3:
+                    elif s1 == 5:
                         forced = [mid_name]
                         if "attn" in hooks:
                             forced += [f"blocks.{b1}.hook_attn_out"] + ([pre_name] if pre_inside else [])
                     else:
-                        forced = [f"blocks.{b1}.mlp.hook_post"] + ([mid_name] if p0 <= NP * b1 + 2 else [])
+                        forced = [f"blocks.{b1}.mlp.hook_post"] + ([mid_name] if p0 <= NP * b1 + ST_O else [])
                 req = seg + [n for n in forced if n not in seg]
                 out, c = nv.forward(self, x if p0 == 0 else None, req, b1, last and run_head, first_block=p0 // NP,
                                     resid_in=resid if p0 > 0 else None, entry_stage=p0 % NP, exit_stage=s1, act_in=acts)
                 cache.update({k: v for k, v in c.items() if k in wanted})
             if last:
                 break
-            acts = ()
-            if s1 in (1, 2, 4):
+            prev_acts, acts = acts, ()
+            if s1 in (1, 2, 3, 4, 6):
                 # inside the attention half / the MLP: the hooks see the stage's activations (attention.py:135-152, 186-281;
                 # mlp.py:65-80), the rest of the block resumes from what they return; the residual stream the block adds to
                 # is carried along untouched
-                kinds = {1: ("q", "k", "v"), 2: ("z",), 4: ("mlppost",)}[s1]
+                kinds = {1: ("q", "k", "v"), 2: ("scores",), 3: ("pattern",), 4: ("z",), 6: ("mlppost",)}[s1]
                 vals = []
                 for kind in kinds:
-                    nm = f"blocks.{b1}." + {"q": "attn.hook_q", "k": "attn.hook_k", "v": "attn.hook_v", "z": "attn.hook_z",
-                                            "mlppost": "mlp.hook_post"}[kind]
+                    nm = f"blocks.{b1}." + {"q": "attn.hook_q", "k": "attn.hook_k", "v": "attn.hook_v", "scores": "attn.hook_attn_scores",
+                                            "pattern": "attn.hook_pattern", "z": "attn.hook_z", "mlppost": "mlp.hook_post"}[kind]
                     t = c[nm]
                     if kind in hooks:
                         t = hooks[kind](t)
                     if nm in wanted:
                         cache[nm] = t
                     vals.append(t)
+                if s1 in (2, 3):
+                    # v for the resumed core: this segment's tap, or what the previous position handed on ((q, k, v) | (scores, v))
+                    vals.append(c[v_name] if v_name in c else prev_acts[-1])
                 acts = tuple(vals)
-                carried = f"blocks.{b1}.hook_resid_mid" if s1 == 4 else f"blocks.{b1}.hook_resid_pre"
+                carried = f"blocks.{b1}.hook_resid_mid" if s1 == 6 else f"blocks.{b1}.hook_resid_pre"
                 resid = c.get(carried, seg_in)
-            elif s1 == 3:
+            elif s1 == 5:
                 # after block b1's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
                 # kernel's rounding (transformer_block.py:117-124), then hook_resid_mid
                 resid = c[f"blocks.{b1}.hook_resid_mid"]
