@@ -679,6 +679,7 @@ def test_bf16_long_sequence_attention_kernel(image_size, patch):
     with torch.no_grad():
         _, cache = model.run_with_cache(x)
         _, only_z = model.run_with_cache(x, names_filter="blocks.0.attn.hook_z")           # no taps at all
+        _, pat_z = model.run_with_cache(x, names_filter=lambda n: n.endswith(("attn.hook_pattern", "attn.hook_z")))   # no score tap
     assert model.last_run_native
     q, k, v = (cache["blocks.0.attn." + n].float() for n in ("hook_q", "hook_k", "hook_v"))
     s_ref = torch.einsum("bqhd,bkhd->bhqk", q, k) / 8.0
@@ -690,4 +691,11 @@ def test_bf16_long_sequence_attention_kernel(image_size, patch):
     z_ref = torch.einsum("bhqk,bkhd->bqhd", p_got, v)
     z_got = cache["blocks.0.attn.hook_z"].float()
     assert float((z_got - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6
-    assert torch.equal(only_z["blocks.0.attn.hook_z"], cache["blocks.0.attn.hook_z"])
+    # without the score tap the register-strip kernel runs (one exponential per score, p = e * (1 / sum)): same statements
+    # against the same fp32 recompute, and the same z whether or not the pattern is tapped
+    p2 = pat_z["blocks.0.attn.hook_pattern"].float()
+    assert p2.shape == (3, 2, T, T) and float((p2 - torch.softmax(s_got, dim=-1)).abs().max()) <= 2 ** -8
+    z2 = pat_z["blocks.0.attn.hook_z"].float()
+    assert float((z2 - torch.einsum("bhqk,bkhd->bqhd", p2, v)).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6
+    assert torch.equal(only_z["blocks.0.attn.hook_z"], pat_z["blocks.0.attn.hook_z"])
+    assert float((z2 - z_got).abs().max()) <= 2 ** -7 * float(z_ref.abs().max()) + 1e-6
