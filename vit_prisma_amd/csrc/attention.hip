@@ -576,7 +576,11 @@ int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
 //     aligned when T is odd; gfx950 global memory takes unaligned dwordx4 stores) -- no funnel shifts, no parity branch
 //   * workgroups dealt to the XCDs by whole heads (the query blocks of a head share one L2's copy of its K / V)
 // A single-pass variant (the wave's 32 x T score strip kept in LDS, QK^T computed once) was built and measured: 37 KB per
-// wave = one workgroup per CU = one wave per SIMD, 1.9 ms per layer against 0.66 ms here without taps -- removed.
+// wave = one workgroup per CU = one wave per SIMD, 1.9 ms per layer against 0.66 ms here without taps -- removed.  So was a
+// register-strip variant (round 3: 16 queries per wave on 16 x 16 MFMA tiles, exp(s - max) of the whole strip in 160 VGPRs, one
+// exponential per score, P handed to the P V product without leaving its registers; parity green): 1.22 ms without taps, 1.48 ms
+// with the pattern tap against 0.63 / 0.83 here -- per score it issues MORE instructions, because a wave of 16 queries pays the
+// same tile staging, fragment reads and MFMA issue as a wave of 32 (profiles/r03_notes.md 11).
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(2))) U4a2 { uint32_t x, y, z, w; };      // a 16-byte store at 2-byte alignment
@@ -879,263 +883,6 @@ __global__ __launch_bounds__(256) void attn_lean_kernel(const AttnParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Long-sequence variant WITHOUT the score tap (bf16, T > 64, d_head 64; the pattern tap is optional): a wave owns 16 query rows
-// and keeps exp(s - max) of its whole 16 x T strip in REGISTERS (16 x 16 MFMA tiles: 4 values per lane and tile, 160 VGPRs for
-// T <= 640), so every score is exponentiated ONCE.  The two-pass kernel above pays two quarter-rate v_exp per element and rounds
-// / unpacks every score tile twice with all of its other work attached; it is bound by VALU issue (0.63 ms per L/14@336 layer
-// without taps, profiles/r03_notes.md).  Three sweeps over the 32-key chunks of the head, the product swapped as above
-// (S^T = K Q^T: a lane holds 4 keys of ONE query):
-//   sweep 1 (K)  score tiles on MFMA 16x16x32, rounded to bf16 like the reference's score tensor -> row max only
-//   sweep 2 (K)  the same tiles again -> e = exp2((s - max) log2 e) into the register strip, row sum
-//   sweep 3 (V)  p = bf16(e / sum) -> pattern tap window, z^T += V^T P^T on MFMA.  The C layout of two score tiles IS the B
-//                operand of one 16x16x32 product under a fixed permutation of the chunk's keys (MFMA k index 8 g + j <-> key
-//                4 g + j, j < 4, and 16 + 4 g + j - 4 otherwise); the V^T fragment is read with the same permutation (two
-//                8-byte LDS reads), so P never leaves its registers
-// NaN / infinite rows: the sum is not finite (or zero) -> the row is written as zeros (attention.py:149).
-// K / V tiles shared by the four waves of a workgroup (64 consecutive queries of a head) as above.
-// ---------------------------------------------------------------------------------------------------
-constexpr int ST_WROW = 272;                // tap window row: 128 keys x 2 B + 16 pad (rows start 4 banks apart)
-constexpr int ST_NCH = 20;                  // 32-key chunks of a head: T <= 640
-
-template <bool PRESCALE>
-__global__ __launch_bounds__(256, 2) void attn_strip_kernel(const AttnParams p) {
-    constexpr int DH = 64;
-    __shared__ __attribute__((aligned(16))) unsigned char Kst[2][32 * 144];
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[2][DH * L2_VROW];
-    __shared__ __attribute__((aligned(16))) unsigned char win[4][16 * ST_WROW];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 15, g = lane >> 4;                 // this lane's query (column) and key group
-    const int T_ = p.T, H = p.H;
-    const int qblocks = (T_ + 63) / 64;
-    int bid = blockIdx.x;
-    {   // whole heads per XCD (see attn_lean_kernel)
-        const int heads = p.B * H, per_xcd = heads / 8;
-        if (bid < per_xcd * 8 * qblocks) {
-            const int xcd = bid & 7, i = bid >> 3;
-            bid = ((i / qblocks) * 8 + xcd) * qblocks + i % qblocks;
-        }
-    }
-    const int gh = bid / qblocks;                           // (image, head)
-    const int q0 = (bid - gh * qblocks) * 64 + wave * 16;
-    const bool active = q0 < T_;
-    const int b = gh / H, h = gh - b * H;
-    unsigned char* W = win[wave];
-    const unsigned tokb = (unsigned)H * DH * 2u;
-    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;
-    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
-    const int nch = (T_ + 31) / 32;
-    const float inv_scale = 1.0f / p.attn_scale;
-
-    // Q^T as the B operand: lane (query n, group g) holds d = 32 hh + 8 g .. + 7 (rows past T read 0)
-    u32x4_t qf[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        qf[hh] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + n) * tokb + hh * 64 + g * 16, 0, 0);
-        if (PRESCALE) {
-            uint32_t w[4] = {qf[hh].x, qf[hh].y, qf[hh].z, qf[hh].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                w[i] = pack_bf16x2(__uint_as_float(w[i] << 16) * inv_scale, __uint_as_float(w[i] & 0xffff0000u) * inv_scale);
-            qf[hh] = u32x4_t{w[0], w[1], w[2], w[3]};
-        }
-    }
-    // cooperative tile fetch / staging: as in attn_lean_kernel
-    const int t_key = threadIdx.x & 31, t_dc = threadIdx.x >> 5;
-    const unsigned tile_off = (unsigned)t_key * tokb + t_dc * 16;
-    const int k_lds = t_key * 144 + t_dc * 16;
-    auto fetch = [&](const __amdgpu_buffer_rsrc_t& rs, int c) -> u32x4_t {
-        if (c < nch) return __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)c * 32u * tokb + tile_off, 0, 0);
-        return u32x4_t{0, 0, 0, 0};
-    };
-    auto stage_v = [&](unsigned char* dst, const u32x4_t& v) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<unsigned short*>(dst + (t_dc * 8 + 2 * i) * L2_VROW + t_key * 2) = (unsigned short)(w[i] & 0xffffu);
-            *reinterpret_cast<unsigned short*>(dst + (t_dc * 8 + 2 * i + 1) * L2_VROW + t_key * 2) = (unsigned short)(w[i] >> 16);
-        }
-    };
-    // scores of keys c*32 + t*16 + 4 g + i (i < 4) against query n, rounded to bf16 like the reference's score tensor
-    auto score16 = [&](const unsigned char* kb, int t, float (&sc)[4]) {
-        const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (t * 16 + n) * 144 + g * 16);
-        const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (t * 16 + n) * 144 + 64 + g * 16);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, qf[0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, qf[1]), acc, 0, 0, 0);
-        if (!PRESCALE) acc = acc * inv_scale;
-        const uint32_t p0 = pack_bf16x2(acc[0], acc[1]), p1 = pack_bf16x2(acc[2], acc[3]);
-        sc[0] = __uint_as_float(p0 << 16); sc[1] = __uint_as_float(p0 & 0xffff0000u);
-        sc[2] = __uint_as_float(p1 << 16); sc[3] = __uint_as_float(p1 & 0xffff0000u);
-    };
-
-    // ---- sweep 1: row max
-    float m = -INFINITY;
-    u32x4_t kn1;
-    {
-        const u32x4_t k0 = fetch(rsK, 0);
-        kn1 = fetch(rsK, 1);
-        *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;
-    }
-    __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const u32x4_t kn2 = fetch(rsK, c + 2);
-        if (active) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float sc[4];
-                score16(Kst[c & 1], t, sc);
-                if (c + 1 == nch) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (c * 32 + t * 16 + 4 * g + i >= T_) sc[i] = -INFINITY;
-                }
-                m = fmaxf(fmaxf(fmaxf(m, sc[0]), fmaxf(sc[1], sc[2])), sc[3]);
-            }
-        }
-        *reinterpret_cast<u32x4_t*>(Kst[(c + 1) & 1] + k_lds) = kn1;
-        __syncthreads();
-        kn1 = kn2;
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float mb = (m > -INFINITY && m < INFINITY) ? -(m * PV_LOG2E) : 0.f;
-
-    // ---- sweep 2: the exponentials of the strip, row sum
-    float E[2 * ST_NCH][4];
-    float l = 0.f;
-    {
-        const u32x4_t k0 = fetch(rsK, 0);
-        kn1 = fetch(rsK, 1);
-        *reinterpret_cast<u32x4_t*>(Kst[0] + k_lds) = k0;      // (free: everyone left sweep 1's last chunk through its closing barrier)
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ST_NCH; ++c) {
-        if (c < nch) {
-            const u32x4_t kn2 = fetch(rsK, c + 2);
-            if (active) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float sc[4];
-                    score16(Kst[c & 1], t, sc);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float e = __builtin_amdgcn_exp2f(fmaf(sc[i], PV_LOG2E, mb));
-                        if (c + 1 == nch && c * 32 + t * 16 + 4 * g + i >= T_) e = 0.f;
-                        E[2 * c + t][i] = e;
-                        l += e;
-                    }
-                }
-            }
-            *reinterpret_cast<u32x4_t*>(Kst[(c + 1) & 1] + k_lds) = kn1;
-            __syncthreads();
-            kn1 = kn2;
-        }
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const bool row_ok = active && l > 0.f && l < INFINITY && m > -INFINITY && m < INFINITY;
-    const float inv_l = row_ok ? 1.0f / l : 0.f;
-
-    // ---- sweep 3: pattern tap + z
-    unsigned char* pt_dst = p.pattern ? reinterpret_cast<unsigned char*>(p.pattern) + (int64_t)gh * T_ * T_ * 2 : nullptr;
-    f32x4 zacc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) zacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int st_row = lane >> 4, st_ch = lane & 15;
-    auto tap_flush = [&](int c) {
-        if ((c & 3) != 3 && c + 1 < nch) return;
-        __builtin_amdgcn_wave_barrier();
-        const int k0 = (c & ~3) * 32;
-        const int nb = min(256, (T_ - k0) * 2);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = st_row + 4 * it;
-            if (q0 + row < T_ && st_ch * 16 < nb) {
-                const unsigned char* src = W + row * ST_WROW + st_ch * 16;
-                unsigned char* d = pt_dst + ((size_t)(uint32_t)((q0 + row) * T_ + k0 + st_ch * 8)) * 2;
-                if (st_ch * 16 + 16 <= nb) {
-                    const uint4 r = *reinterpret_cast<const uint4*>(src);
-                    *reinterpret_cast<U4a2*>(d) = U4a2{r.x, r.y, r.z, r.w};
-                } else {
-                    for (int e = 0; e < (nb - st_ch * 16) / 2; ++e)
-                        *reinterpret_cast<unsigned short*>(d + 2 * e) = *reinterpret_cast<const unsigned short*>(src + 2 * e);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    u32x4_t vn1;
-    {
-        const u32x4_t v0 = fetch(rsV, 0);
-        vn1 = fetch(rsV, 1);
-        stage_v(Vt[0], v0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < ST_NCH; ++c) {
-        if (c < nch) {
-            const u32x4_t vn2 = fetch(rsV, c + 2);
-            if (active) {
-                // the two tiles' probabilities, rounded, as the B operand (keys 4 g .. + 3 of tile 0, then of tile 1)
-                u32x4_t pb;
-                pb.x = pack_bf16x2(E[2 * c][0] * inv_l, E[2 * c][1] * inv_l);
-                pb.y = pack_bf16x2(E[2 * c][2] * inv_l, E[2 * c][3] * inv_l);
-                pb.z = pack_bf16x2(E[2 * c + 1][0] * inv_l, E[2 * c + 1][1] * inv_l);
-                pb.w = pack_bf16x2(E[2 * c + 1][2] * inv_l, E[2 * c + 1][3] * inv_l);
-                if (pt_dst) {
-                    *reinterpret_cast<uint2*>(W + n * ST_WROW + (c & 3) * 64 + 8 * g) = make_uint2(pb.x, pb.y);
-                    *reinterpret_cast<uint2*>(W + n * ST_WROW + (c & 3) * 64 + 32 + 8 * g) = make_uint2(pb.z, pb.w);
-                }
-                const unsigned char* vb = Vt[c & 1];
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const uint2 v0 = *reinterpret_cast<const uint2*>(vb + (dt * 16 + n) * L2_VROW + 8 * g);
-                    const uint2 v1 = *reinterpret_cast<const uint2*>(vb + (dt * 16 + n) * L2_VROW + 32 + 8 * g);
-                    const u32x4_t vf = {v0.x, v0.y, v1.x, v1.y};
-                    zacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pb), zacc[dt], 0, 0, 0);
-                }
-            }
-            stage_v(Vt[(c + 1) & 1], vn1);
-            if (active && pt_dst) tap_flush(c);
-            __syncthreads();
-            vn1 = vn2;
-        }
-    }
-    if (!active) return;
-    // z^T: lane holds d = 16 dt + 4 g .. + 3 of query n -> 8-byte stores into the query's row
-    if (q0 + n < T_) {
-        unsigned char* zr = reinterpret_cast<unsigned char*>(reinterpret_cast<bf16_t*>(p.z) + head_off) + (int64_t)(q0 + n) * tokb;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<uint2*>(zr + (dt * 16 + 4 * g) * 2) =
-                make_uint2(pack_bf16x2(zacc[dt][0], zacc[dt][1]), pack_bf16x2(zacc[dt][2], zacc[dt][3]));
-    }
-}
-
-int launch_attn_strip(const AttnParams& p, hipStream_t stream) {
-    const int heads = p.B * p.H, qblocks = (p.T + 63) / 64;
-    int ex = 0;
-    const bool pow2 = p.attn_scale > 0.f && std::frexp(p.attn_scale, &ex) == 0.5f;
-    {
-        const double bh = (double)heads, tt = (double)p.T * p.T;
-        const double bytes = (4.0 * bh * p.T * p.dh + (p.pattern ? 1.0 : 0.0) * bh * tt) * 2.0;
-        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
-        if (pow2) hipLaunchKernelGGL((attn_strip_kernel<true>), dim3(heads * qblocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attn_strip_kernel<false>), dim3(heads * qblocks), dim3(256), 0, stream, p);
-    }
-    PV_LAUNCH_CHECK("attn_strip_kernel");
-    return PV_OK;
-}
-
 int launch_attn_lean(const AttnParams& p, hipStream_t stream) {
     const int heads = p.B * p.H, qblocks = (p.T + 127) / 128;
     int ex = 0;
@@ -1165,9 +912,7 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     }
     if constexpr (sizeof(T) == 2) {
         if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
-            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 63) / 64) < (1ll << 31)) {
-            // without the score tap every exponential is taken once (register-resident strip); with it the two-pass kernel
-            if (!p.scores && p.T <= 32 * ST_NCH && !g_pv_tuning.attn_two_pass) return launch_attn_strip(p, stream);
+            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31)) {
             return launch_attn_lean(p, stream);
         }
     }

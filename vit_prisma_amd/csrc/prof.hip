@@ -102,7 +102,6 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "gemm_v1patch")) return &g_pv_tuning.gemm_v1patch;
     if (!strcmp(key, "attn_wg")) return &g_pv_tuning.attn_wg;
     if (!strcmp(key, "attn_direct")) return &g_pv_tuning.attn_direct;
-    if (!strcmp(key, "attn_two_pass")) return &g_pv_tuning.attn_two_pass;
     if (!strcmp(key, "prof_markers")) return &g_pv_tuning.prof_markers;
     if (!strcmp(key, "sae_exact")) return &g_pv_tuning.sae_exact;
     if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
@@ -131,7 +130,7 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
     if (!strcmp(key, "any")) {
         const PvTuning d;
         const PvTuning& t = g_pv_tuning;
-        *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct || t.attn_two_pass != d.attn_two_pass ||
+        *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct ||
                   t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg || t.gemm_loop != d.gemm_loop) ? 1 : 0;
         return PV_OK;
     }
