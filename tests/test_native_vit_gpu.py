@@ -691,11 +691,10 @@ def test_bf16_long_sequence_attention_kernel(image_size, patch):
     z_ref = torch.einsum("bhqk,bkhd->bqhd", p_got, v)
     z_got = cache["blocks.0.attn.hook_z"].float()
     assert float((z_got - z_ref).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6
-    # without the score tap the register-strip kernel runs (one exponential per score, p = e * (1 / sum)): same statements
-    # against the same fp32 recompute, and the same z whether or not the pattern is tapped
+    # without the score tap: the same statements against the same fp32 recompute, and the same z whichever taps are taken
     p2 = pat_z["blocks.0.attn.hook_pattern"].float()
     assert p2.shape == (3, 2, T, T) and float((p2 - torch.softmax(s_got, dim=-1)).abs().max()) <= 2 ** -8
     z2 = pat_z["blocks.0.attn.hook_z"].float()
     assert float((z2 - torch.einsum("bhqk,bkhd->bqhd", p2, v)).abs().max()) <= 2 ** -8 * float(z_ref.abs().max()) + 1e-6
     assert torch.equal(only_z["blocks.0.attn.hook_z"], pat_z["blocks.0.attn.hook_z"])
-    assert float((z2 - z_got).abs().max()) <= 2 ** -7 * float(z_ref.abs().max()) + 1e-6
+    assert torch.equal(only_z["blocks.0.attn.hook_z"], cache["blocks.0.attn.hook_z"])
