@@ -507,6 +507,9 @@ def main():
             # the ReLU + L1 SAE (every published CLIP SAE of the reference) on the dense fused step
             weak = None
             relu = leg("sae_relu_l1", lambda: sae_bench_leg(dev, dist=None, steps=8, warmup=2, activation="relu"))
+            from vit_prisma_amd.sae.bench_leg import sae_variants_leg
+            torch.cuda.empty_cache()
+            variants = leg("sae_variants", lambda: sae_variants_leg(dev))
         if rank == 0:
             line["sae"] = sae
             sae["end_to_end"] = e2e
@@ -514,6 +517,7 @@ def main():
                 sae["weak_scaling_data_parallel"] = weak
             else:
                 sae["relu_l1"] = relu
+                sae["variants"] = variants
             if world == 1 and not a.no_cpu_baseline:
                 sae["cpu_baseline"] = sae_cpu_baseline_torch(10.0)
                 sae["cpu_baseline"]["numpy_oracle"] = sae_cpu_baseline(6.0)

@@ -27,6 +27,7 @@ d=json.loads([l for l in open('$O/bench_full.json') if l.startswith('{"metric"')
 print('b32', d['value'], d['ms_per_step'], 'gemm', d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['traffic'], 'ok', d.get('ok'))
 s=d['sae']; print('sae', s['value'], s['ms_per_step'], s['roofline']['frac'], 'e2e', s['end_to_end']['value'], 'ref-store', s['end_to_end'].get('reference_store_shape',{}).get('value'))
 print('relu', s['relu_l1']['value'], s['relu_l1']['ms_per_step'], s['relu_l1']['roofline']['frac'])
+print('variants', {k: (v.get('value'), v.get('ms_per_step')) for k, v in s.get('variants', {}).items()})
 print('l14', d['l14_336_pattern']['value'], d['l14_336_pattern']['ms_per_step'])
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
 PY

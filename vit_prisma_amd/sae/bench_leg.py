@@ -166,6 +166,61 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     return res
 
 
+def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3) -> dict:
+    """Step-only times of the other coders of the reference on their fused HIP steps, through ``VisionSAETrainer.train_step`` at
+    the bench shape (768 -> 24576, 4096 tokens, single process): a top-k Transcoder with the skip connection (sae/transcoder.py)
+    and a Gated SAE with the ReLU magnitude path (sae.py:648-792)."""
+    from .config import VisionModelSAERunnerConfig
+    from .trainer import VisionSAETrainer
+    out = {}
+    for name, over in (("transcoder_topk_skip", dict(activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, is_transcoder=True,
+                                                     transcoder_with_skip_connection=True, d_out=D_IN, out_hook_point_layer=6)),
+                       ("gated_relu", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated", l1_coefficient=8e-5))):
+        cfg = VisionModelSAERunnerConfig(
+            hook_point_layer=6, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
+            normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
+            train_batch_size=N_TOKENS, lr=1e-3, max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant",
+            n_checkpoints=0, **over)
+        tr = VisionSAETrainer(cfg, model=None, dataset=None).use_native(True)
+        sae = tr.sparse_coder
+        with torch.no_grad():
+            for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+        st = list(tr.initialize_training_variables())
+        pair = cfg.is_transcoder
+        xs = [torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=i)).to(dev) for i in range(4)]
+        if pair:
+            xs = [torch.stack([x, torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=50 + i)).to(dev)], dim=1).contiguous()
+                  for i, x in enumerate(xs)]
+        else:
+            xs = [x[:, None, :].contiguous() for x in xs]
+        n_done = [0]
+        last = [None]
+
+        def step(x):
+            r = tr.train_step(sparse_autoencoder=sae, optimizer=st[3], scheduler=st[4], act_freq_scores=st[0],
+                              n_forward_passes_since_fired=st[1], n_frac_active_tokens=st[2], layer_acts=x, n_training_steps=n_done[0],
+                              n_training_tokens=n_done[0] * N_TOKENS)
+            last[0], st[0], st[1], st[2] = r[0], r[4], r[5], r[6]
+            n_done[0] += 1
+
+        for i in range(warmup):
+            step(xs[i % 4])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(xs[i % 4])
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        assert tr.last_step_native
+        out[name] = {"value": round(N_TOKENS * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+                     "steps": steps, "warmup": warmup, "final_loss": float(last[0]),
+                     "config": {"workload": f"{name}: 768 -> 24576, {N_TOKENS} tokens per step, Adam, clip 1.0, fused HIP step"}}
+        del tr, sae, xs
+        torch.cuda.empty_cache()
+    return out
+
+
 class _ResidentImages(torch.utils.data.Dataset):
     """Synthetic image set that lives in HBM: items are (image view, label) like the reference's datasets."""
 
