@@ -212,11 +212,14 @@ def test_native_equals_pytorch_hook_path_and_fallback_dispatch():
         assert torch.equal(c_h["blocks.0.hook_resid_mid"], c_h["blocks.0.hook_resid_pre"])
         _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_z", zero)])           # inside the block: split there too
         assert model.last_run_native and float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
-        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])
-        assert not model.last_run_native and float(c_h["blocks.0.attn.hook_pattern"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])           # ... and at the pattern
+        assert model.last_run_native and float(c_h["blocks.0.attn.hook_pattern"].abs().max()) == 0.0
+        assert float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])                # not splittable: PyTorch path
+        assert not model.last_run_native and float(c_h["blocks.0.mlp.hook_pre"].abs().max()) == 0.0
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])
+            model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])
     # weight edits are picked up (version counter) -> output changes
     model.use_native(True)
     with torch.no_grad():
