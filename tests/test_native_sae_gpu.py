@@ -753,6 +753,34 @@ def test_relu_variants_trainer_runs_natively_and_matches_the_reference_fixture(v
         assert rel_fro(p.detach().cpu().numpy(), g[f"{variant}_s2_param_{n}"]) < (1e-3 if ghost else TOL), n
 
 
+def test_step_is_bit_reproducible_from_run_to_run():
+    """The position of a pair inside its feature's list is drawn by an integer atomic in the selection kernel; the lists are
+    put into token order before the backward (csr_sort_short_kernel, sae_long_sort_kernel), so nothing the step computes depends
+    on that draw: two engines from the same state on the same batch agree BIT FOR BIT -- reconstruction, losses, every gradient
+    tensor, parameters and moments after the optimizer step -- at the bench shape, three steps in a row."""
+    d_in, d_sae, k, n = 768, 24576, 32, 4096
+    engines = []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        engines.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n))
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+        for e in engines:
+            e.step(x, want_out=True, renorm_decoder=True)
+            e.grad_sqnorm(from_step=True)
+        torch.cuda.synchronize()
+        a, b = engines
+        assert torch.equal(a.sae_out, b.sae_out) and torch.equal(a.scalars, b.scalars)
+        assert torch.equal(torch.sort(a.topk_idx[:n], dim=1).values, torch.sort(b.topk_idx[:n], dim=1).values)
+        assert torch.equal(a.flat_g, b.flat_g), float((a.flat_g - b.flat_g).abs().max())
+        for e in engines:
+            e.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name in ("W_dec", "b_enc", "b_dec"):
+            assert torch.equal(a.params[name], b.params[name]), name
+        assert torch.equal(a.W_encT, b.W_encT) and torch.equal(a.flat_m, b.flat_m) and torch.equal(a.flat_v, b.flat_v)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Transcoder (SURVEY.md 8f row 3; sae/transcoder.py; pv_sae_transcoder) on the two fused steps
 # ---------------------------------------------------------------------------------------------------

@@ -560,6 +560,30 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
     if (w != 0xffffffffu) pairs[offs[idx[p]] + w] = p;
 }
 
+// The position of a pair inside its feature's list was drawn by an integer atomic in the selection kernel: the SET of a list is
+// exact, its ORDER is whatever the atomics produced -- and the backward sums in list order, so gradients would agree from run to run
+// only up to fp32 summation order.  Short lists (<= BWD_LMAX = 64 pairs: one wave holds a whole list) are put into ascending pair
+// order here (a pair id is token * k + slot and a feature holds a token at most once: token order) with a 64-lane bitonic network;
+// the long lists get the same from sae_long_sort_kernel.  With both, every gradient is bit-reproducible.
+__global__ __launch_bounds__(256) void csr_sort_short_kernel(const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int d_sae) {
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= d_sae) return;
+    const uint32_t o = offs[f];
+    const int c = (int)(offs[f + 1] - o);
+    if (c < 2 || c > BWD_LMAX) return;                        // (wave-uniform)
+    int v = lane < c ? pairs[o + lane] : 0x7fffffff;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const int other = __shfl_xor(v, j, 64);
+            const bool up = (lane & k2) == 0, lower = (lane & j) == 0;
+            v = (lower == up) ? min(v, other) : max(v, other);
+        }
+    if (lane < c) pairs[o + lane] = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sparse backward:  gW_dec[j, :] = sum_p a_p dY[n_p, :],  gW_enc^T[j, :] = sum_p g_p sae_in[n_p, :],  gb_enc[j] = sum_p g_p
 // over the pairs p = (token n_p, feature j) of feature j's list (a = kept activation, g = dh).  One-wave-per-feature
@@ -1738,6 +1762,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            sae_long_ranged(N) ? 1 : 0);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
                            (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
+        hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
         const int ranged = sae_long_ranged(N) ? 1 : 0;
         if (ranged) {
             rc = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
@@ -1889,6 +1914,7 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
                            out->fire_count, d.d_sae, update_stats, (float*)nullptr, (float*)nullptr, sae_long_ranged(N) ? 1 : 0);
         hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, topk_idx,
                            (const uint32_t*)wposp, (const uint32_t*)offs, pairs, n_pairs);
+        hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
         const int ranged = sae_long_ranged(N) ? 1 : 0;
         if (ranged) {
             const int rcs = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
