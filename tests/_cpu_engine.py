@@ -65,6 +65,29 @@ class OracleEngine:
             self.n_fwd_since_fired += 1
             self.n_fwd_since_fired[self.fire_count > 0] = 0
 
+    def dense_step(self, x, l1_coefficient, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=True,
+                   dead_mask=None, target=None):
+        """The twin of NativeSAE.dense_step (pv_sae_dense_step): the ReLU + L1 form of the oracle."""
+        assert dead_mask is None and target is None
+        if renorm_decoder:
+            self.renorm_decoder()
+        P, xn = self._P(), x.numpy()
+        bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
+        fw = O.sae_forward(P, xn, None, batch_mean=bm, n_global=n_global, l1_coefficient=l1_coefficient)
+        g = O.sae_backward(P, xn, fw, n_global=n_global, l1_coefficient=l1_coefficient)
+        self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
+        for n in ("W_dec", "b_enc", "b_dec"):
+            self._g[n].copy_(torch.from_numpy(g[n]))
+        self.fire_count.copy_(torch.from_numpy((fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)))
+        self.scalars[0], self.scalars[1], self.scalars[2] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"])
+        self.scalars[4] = float(fw["l1_loss"])
+        if update_stats:
+            self.act_freq_scores += self.fire_count
+            self.n_fwd_since_fired += 1
+            self.n_fwd_since_fired[self.fire_count > 0] = 0
+
+    transcoder = False
+
     def grad_sqnorm(self, from_step=False):
         self.scalars[3] = float((self.flat_g.double() ** 2).sum())
 
