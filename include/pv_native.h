@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 13
+#define PV_ABI_VERSION 14
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -443,7 +443,8 @@ int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32
                       int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* One train step of a gated SAE (single process): forward + backward + statistics on the dense GEMM kernel -- the shared
+/* One train step of a gated SAE (batch_mean / n_global as in pv_sae_step: tokens may be sharded over ranks, the caller all-reduces
+ * the flat gradient buffer): forward + backward + statistics on the dense GEMM kernel -- the shared
  * product sae_in @ W_enc once (both paths in its epilogue), the two decoder products (feature_acts and relu(gate)) as ONE GEMM
  * over stacked rows, likewise their two backward products and the two terms of gW_dec.  Gradients WRITTEN into st->g* and
  * st->gt.g* (gb_enc = 0); flags: PV_SAE_UPDATE_STATS, PV_SAE_RENORM_DECODER (REQUIRED: the L1 term's decoder norms are taken
@@ -451,8 +452,8 @@ int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32
  * 4 l1_loss, 6 auxiliary reconstruction loss.  Follow with pv_sae_grad_sqnorm over the flat gradient buffer and pv_sae_apply.
  * d_in % 8 == 0, d_sae % 8 == 0. */
 size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens);
-int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, int32_t flags, float l1_coefficient,
-                      pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream);
+int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean, int32_t n_global,
+                      int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

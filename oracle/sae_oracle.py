@@ -218,7 +218,8 @@ def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dic
 
 
 # ---- Gated SAE (sae/sae.py:648-792), ReLU activation ----------------------------------------------------------------------
-def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, Array]:
+def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coefficient: float = 0.0,
+                  batch_mean: Optional[Array] = None, n_global: Optional[int] = None) -> Dict[str, Array]:
     """GatedSparseAutoencoder.forward (:730-771) with activation_fn_str = "relu": gate path (sae_in @ W_enc + b_gate) > 0 (:703-706),
     magnitude path with shared weights sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712), L1 on relu(gate pre-activation)
     weighted by the decoder row norms (:780-784), auxiliary reconstruction of sae_in through the gate (:786-792)."""
@@ -235,16 +236,18 @@ def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coe
     feats = np.where(active, np.maximum(mag_pre, dt(0)), dt(0))
     pre_out = feats @ P["W_dec"] + P["b_dec"]
     sae_out = pre_out * std + mu if layer_norm else pre_out
-    nf = np.sqrt(((x - x.mean(axis=0, keepdims=True)) ** 2).sum(axis=-1, keepdims=True))
-    mse = ((sae_out - x) ** 2 / nf).sum() / dt(N * d)
+    bm = x.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)      # (data-parallel form: the GLOBAL batch's)
+    ng = N if n_global is None else n_global
+    nf = np.sqrt(((x - bm) ** 2).sum(axis=-1, keepdims=True))
+    mse = ((sae_out - x) ** 2 / nf).sum() / dt(ng * d)
     pg = np.maximum(gate_pre, dt(0))                                   # _compute_gate_activation :773-778
     wn = np.linalg.norm(P["W_dec"], axis=1)
-    l1 = dt(l1_coefficient) * ((pg * wn).sum(axis=-1).sum() / dt(N))
+    l1 = dt(l1_coefficient) * ((pg * wn).sum(axis=-1).sum() / dt(ng))
     via = pg @ P["W_dec"] + P["b_dec"]
-    aux = ((via - S) ** 2).sum(axis=-1).sum() / dt(N)
+    aux = ((via - S) ** 2).sum(axis=-1).sum() / dt(ng)
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()
     return dict(sae_in=S, gate_pre=gate_pre, mag_pre=mag_pre, feature_acts=feats, pg=pg, via=via, sae_out=sae_out, mu=mu, std=std,
-                norm_factor=nf, wn=wn, loss=dt(mse + l1 + aux), mse_loss=dt(mse), l1_loss=dt(l1), aux_loss=dt(aux), l0=l0)
+                norm_factor=nf, wn=wn, n_global=ng, loss=dt(mse + l1 + aux), mse_loss=dt(mse), l1_loss=dt(l1), aux_loss=dt(aux), l0=l0)
 
 
 def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True, l1_coefficient: float = 0.0,
@@ -255,6 +258,7 @@ def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_no
     N, d = x.shape
     S, feats, pg = fw["sae_in"], fw["feature_acts"], fw["pg"]
     on_f, on_g = (feats > 0, fw["gate_pre"] > 0) if gates is None else gates
+    N = fw["n_global"]                                                 # (every mean is over the global batch)
     d_out = dt(2.0) * (fw["sae_out"] - x) / fw["norm_factor"] / dt(N * d)
     dY = d_out * fw["std"] if layer_norm else d_out
     dVia = dt(2.0) * (fw["via"] - S) / dt(N)

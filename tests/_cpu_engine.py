@@ -220,3 +220,62 @@ class OracleShardEngine(OracleEngine):
         self.fire_count.copy_(torch.from_numpy((feats > 0).sum(axis=0).astype(dt)))
         self.scalars[0] = self.scalars[1] = float(mse)
         self.scalars[2] = float((feats > 0).sum()) / N
+
+
+class OracleGatedEngine(OracleEngine):
+    """The twin of a NativeSAE built with ``gated=...`` (pv_sae_gated_step): the oracle's gated form."""
+    gated = True
+
+    def __init__(self, sae, max_tokens: int):
+        super().__init__(sae, 1, max_tokens)
+        for n in ("b_gate", "r_mag", "b_mag"):
+            self.params[n] = getattr(sae, n).data
+        nW = self.d_in * self.d_sae
+        base = 2 * nW + self.d_sae + self.d_in
+        self.n_flat = base + 3 * self.d_sae
+        self.flat_g, self.flat_m, self.flat_v = (torch.zeros(self.n_flat) for _ in range(3))
+
+        def views(flat):
+            v = dict(W_encT=flat[:nW].view(self.d_sae, self.d_in), W_dec=flat[nW:2 * nW].view(self.d_sae, self.d_in),
+                     b_enc=flat[2 * nW:2 * nW + self.d_sae], b_dec=flat[2 * nW + self.d_sae:base])
+            for i, n in enumerate(("b_gate", "r_mag", "b_mag")):
+                v[n] = flat[base + i * self.d_sae:base + (i + 1) * self.d_sae]
+            return v
+
+        self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
+
+    def gated_step(self, x, l1_coefficient, batch_mean=None, n_global=None, update_stats=True, want_out=False):
+        self.renorm_decoder()
+        P = {n: t.numpy() for n, t in self.params.items() if n != "b_enc"}
+        xn = x.numpy()
+        bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
+        fw = O.gated_forward(P, xn, l1_coefficient=l1_coefficient, batch_mean=bm, n_global=n_global)
+        g = O.gated_backward(P, xn, fw, l1_coefficient=l1_coefficient)
+        self.flat_g.zero_()
+        self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
+        for n in ("W_dec", "b_dec", "b_gate", "r_mag", "b_mag"):
+            self._g[n].copy_(torch.from_numpy(g[n]))
+        self.fire_count.copy_(torch.from_numpy((fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)))
+        sc = self.scalars
+        sc[0], sc[1], sc[2], sc[4], sc[6] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"]), float(fw["l1_loss"]), float(fw["aux_loss"])
+        if update_stats:
+            self.act_freq_scores += self.fire_count
+            self.n_fwd_since_fired += 1
+            self.n_fwd_since_fired[self.fire_count > 0] = 0
+
+    def apply(self, lr, max_grad_norm, j_lo=0, j_hi=None):
+        assert j_lo == 0 and j_hi in (None, self.d_sae)
+        self.adam_step += 1
+        total = float(self.scalars[3]) ** 0.5
+        coef = min(max_grad_norm / (total + 1e-6), 1.0) if max_grad_norm else 1.0
+        names = ("W_encT", "W_dec", "b_dec", "b_gate", "r_mag", "b_mag")                # (b_enc: no gradient, untouched)
+        W = {"W_encT": self.W_encT, **{n: self.params[n] for n in names[1:]}}
+        P = {n: W[n].numpy() for n in names}
+        g = {n: (self._g[n] * coef).numpy().copy() for n in names}
+        m = {n: self._m[n].numpy() for n in names}
+        v = {n: self._v[n].numpy() for n in names}
+        par = (g["W_dec"] * P["W_dec"]).sum(axis=1, keepdims=True)
+        g["W_dec"] -= par * P["W_dec"]
+        O.adam_step(P, g, m, v, lr, self.adam_step)
+        self.params["W_enc"].copy_(self.W_encT.t())
+

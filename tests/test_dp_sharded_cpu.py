@@ -181,3 +181,81 @@ def test_relu_l1_data_parallel_step_equals_single_process_oracle(world):
             assert rel_fro(out[n], P[n]) < 2e-5, (rank, n)
         assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
         assert frac == N * STEPS
+
+
+# ---- Gated SAE, data parallel: the same orchestration around pv_sae_gated_step (batch_mean / n_global)
+def _gated_worker(rank, world, port, q, init):
+    import torch.distributed as dist
+    from vit_prisma_amd.sae import GatedSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
+    from _cpu_engine import OracleGatedEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN, activation_fn_str="relu",
+        activation_fn_kwargs={}, l1_coefficient=L1C, architecture="gated", normalize_activations="layer_norm", b_dec_init_method="mean",
+        train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
+        seed=7 + rank)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None)
+    sae = tr.sparse_coder
+    assert type(sae) is GatedSparseAutoencoder
+    if rank == 0:
+        with torch.no_grad():
+            for n, v in init.items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+    tr._native_kind = lambda *a, **k: "gated"
+
+    def get_engine(s, n_tokens):
+        if tr._engine is None:
+            for p in s.parameters():
+                dist.broadcast(p.data, src=0)
+            tr._engine = OracleGatedEngine(s, n_tokens)
+        return tr._engine
+
+    tr._get_engine = get_engine
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    losses = []
+    for t in range(STEPS):
+        x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
+        xs = x[rank * (N // world):(rank + 1) * (N // world)][:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
+        losses.append((float(loss), float(mse), float(l1), float(l0), float(tr._engine.scalars[6])))
+        assert tr.last_step_native
+    out = {n: p.detach().numpy().copy() for n, p in sae.named_parameters()}
+    q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gated_data_parallel_step_equals_single_process_oracle():
+    world = 2
+    rs = np.random.RandomState(9)
+    init = dict(synth_sae_state(D_IN, D_SAE, 0))
+    for name, scale in (("b_gate", 0.05), ("r_mag", 0.2), ("b_mag", 0.05)):
+        init[name] = (rs.standard_normal(D_SAE) * scale).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gated_worker, args=(r, world, port, q, init)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = {k: v.copy() for k, v in init.items() if k != "b_enc"}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    want = [O.gated_train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), lr=1e-3, step=t + 1, l1_coefficient=L1C) for t in range(STEPS)]
+    for rank, out, losses, act, since in got:
+        for t, (loss, mse, l1, l0, aux) in enumerate(losses):
+            for gotv, key in ((loss, "loss"), (mse, "mse_loss"), (l1, "l1_loss"), (aux, "aux_loss")):
+                assert abs(gotv - want[t][key]) <= 1e-5 * abs(want[t][key]), (t, key, gotv, want[t][key])
+            assert abs(l0 - want[t]["l0"]) <= 1e-6 * want[t]["l0"]
+        for n in P:
+            assert rel_fro(out[n], P[n]) < 2e-5, (rank, n)
+        assert np.array_equal(out["b_enc"], init["b_enc"])
+        assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])

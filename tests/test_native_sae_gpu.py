@@ -970,6 +970,46 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln):
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
 
 
+@pytest.mark.parametrize("kind", ["gated", "relu_transcoder"])
+def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
+    """The data-parallel form of the gated step and of the ReLU transcoder step (batch_mean / n_global: tokens sharded over ranks,
+    gradients summed by the caller): two half batches with the GLOBAL mean and token count give gradients and losses that add up
+    to the whole batch's (one engine, the halves one after the other; statistics off)."""
+    d_in, d_sae, n, l1c = 136, 1056, 512, 3e-3
+    rs = np.random.RandomState(4)
+    P, opt, stats, T = fresh(d_in, d_sae)
+    kw = {}
+    if kind == "gated":
+        kw["gated"] = {m: torch.from_numpy((rs.standard_normal(d_sae) * s_).astype(np.float32)).cuda()
+                       for m, s_ in (("b_gate", 0.05), ("r_mag", 0.2), ("b_mag", 0.05))}
+    else:
+        kw["b_dec_out"] = torch.from_numpy((rs.standard_normal(d_in) * 0.05).astype(np.float32)).cuda()
+        kw["W_skip"] = torch.from_numpy((rs.standard_normal((d_in, d_in)) / np.sqrt(d_in) * 0.3).astype(np.float32)).cuda()
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, True, n, **kw)
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=0)).cuda()
+    y = torch.from_numpy(synth_sae_batch(n, d_in, seed=50)).cuda()
+    ref = y if kind != "gated" else x
+
+    def run(xs, ys, **kk):
+        if kind == "gated":
+            eng.gated_step(xs, l1c, update_stats=False, **kk)
+        else:
+            eng.dense_step(xs, l1c, update_stats=False, target=ys, **kk)
+        torch.cuda.synchronize()
+        return eng.flat_g.clone(), eng.scalars.clone(), eng.fire_count.clone()
+
+    g_all, sc_all, fire_all = run(x, y)
+    bm = ref.mean(dim=0)
+    h = n // 2
+    g0, sc0, f0 = run(x[:h].contiguous(), y[:h].contiguous(), batch_mean=bm, n_global=n)
+    g1, sc1, f1 = run(x[h:].contiguous(), y[h:].contiguous(), batch_mean=bm, n_global=n)
+    assert rel_fro((g0 + g1).cpu().numpy(), g_all.cpu().numpy()) < TOL
+    for slot in (0, 1, 4) + ((6,) if kind == "gated" else ()):
+        assert abs(float(sc0[slot] + sc1[slot]) - float(sc_all[slot])) <= TOL * abs(float(sc_all[slot])), slot
+    assert abs(float(sc0[2] + sc1[2]) / 2 - float(sc_all[2])) <= TOL * float(sc_all[2])
+    assert torch.equal(f0 + f1, fire_all)
+
+
 def test_gated_trainer_runs_natively_and_matches_the_reference_fixture():
     """architecture = "gated" (ReLU) through VisionSAETrainer.train_step on the HIP step, against what the REFERENCE's own
     GatedSparseAutoencoder produced through its own train_step (tests/golden/sae_variants_steps.npz)."""

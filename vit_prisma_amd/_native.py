@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -162,7 +162,7 @@ def lib() -> C.CDLL:
         L.pv_sae_transcoder_scratch_bytes.restype = sz
         L.pv_sae_gated_scratch_bytes.argtypes = [vp, i32]
         L.pv_sae_gated_scratch_bytes.restype = sz
-        L.pv_sae_gated_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_gated_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_tp_merge.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
         L.pv_sae_tp_bucket_pack.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.pv_sae_tp_bucket_unpack.argtypes = [vp, vp, vp, vp]

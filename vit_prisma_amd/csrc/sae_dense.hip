@@ -573,7 +573,7 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     // transcoder (pv_sae_state.tc): loss against tc.target, the decoder adds b_dec_out and the skip term
     const bool tc = sae_is_tc(st);
     if (tc) {
-        PV_REQUIRE(n_global == N && !ghost, "transcoder: single process, no ghost gradients");
+        PV_REQUIRE(!ghost, "transcoder: no ghost gradients");
         const int rq = sae_tc_require(d, st, N);
         if (rq) return rq;
     }
@@ -836,8 +836,9 @@ extern "C" size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_
     return gated_carve(plan->d, n_tokens).total;
 }
 
-extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t flags, float l1_coefficient,
-                                 pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean, int32_t n_global,
+                                 int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && out && workspace && out->scalars, "null argument");
     PV_REQUIRE(sae_is_gated(st) && !sae_is_tc(st), "pv_sae_gated_step needs a gated state (pv_sae_state.gt) and no transcoder");
@@ -848,6 +849,7 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     PV_REQUIRE(flags & PV_SAE_RENORM_DECODER, "pv_sae_gated_step: PV_SAE_RENORM_DECODER is required (unit decoder rows in the L1 term)");
     const pv_sae_desc& d = plan->d;
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
     PV_REQUIRE(d.d_in % 8 == 0 && d.d_sae % 8 == 0, "the gated step needs d_in and d_sae to be multiples of 8");
     const SaeWs ws = sae_carve(d);
     PV_REQUIRE(workspace_bytes >= ws.total && ((uintptr_t)workspace & 255) == 0, "workspace too small / misaligned");
@@ -861,7 +863,8 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     const int F = d.d_sae, D = d.d_in;
     int rc = pv_sae_renorm_decoder(plan, st, stream_);                   // train_sae.py:307
     if (rc) return rc;
-    rc = sae_prep(d, x, (const float*)st->b_dec, nullptr, N, false, wsb, ws, stream);
+    rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, false, wsb, ws, stream);
+    const float ng = (float)n_global;
     if (rc) return rc;
     float* hs = (float*)(gb + gw.hs);
     float* dYs = (float*)(gb + gw.dys);
@@ -890,7 +893,7 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
         PV_LAUNCH_CHECK("dense_colreduce_kernel");
         sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream);                        // l0
-        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)N, 4, -1, stream);       // l1 (unit decoder rows)
+        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / ng, 4, -1, stream);             // l1 (unit decoder rows)
     }
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 14.0 * N * (double)D * F, 0.0);
@@ -905,10 +908,10 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         hipLaunchKernelGGL(gated_finish_kernel, dim3((2 * N + 3) / 4), dim3(256), 0, stream, x, (const float*)sae_in, (const float*)kpart, S,
                            (int64_t)2 * N * D, (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
                            (const float*)(wsb + ws.norm), out->sae_out, dYs, (float*)(wsb + ws.loss_part), (float*)(gb + gw.auxpart), N, D,
-                           2.0f / ((float)N * (float)D), 2.0f / (float)N);
+                           2.0f / (ng * (float)D), 2.0f / ng);
         PV_LAUNCH_CHECK("gated_finish_kernel");
-        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)N * (float)D), 1, -1, stream);
-        sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / (float)N, 6, -1, stream);
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / (ng * (float)D), 1, -1, stream);
+        sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / ng, 6, -1, stream);
         hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
         // G4: gW_dec = [f; relu(gate)]^T @ [dY; dVia] (K = 2N) + the decoder-norm factor of the L1 term
         DenseGemm g4 = {};
@@ -917,7 +920,7 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(gated_l1_rows_kernel, dim3((F + 3) / 4), dim3(256), 0, stream, st->gW_dec, (const float*)st->W_dec,
-                           (const float*)pgsum, l1_coefficient / (float)N, F, D);
+                           (const float*)pgsum, l1_coefficient / ng, F, D);
         // G3a: dM = (dY @ W_dec^T) [f > 0] over f; column sums = gb_mag, of dM * f = the raw term of gr_mag
         DenseGemm g3 = {};
         g3.A = dYs; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
@@ -929,7 +932,7 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart2, rblk, F, sdmf,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
         // G3b: dG = (dVia @ W_dec^T + l1 / N) [gate > 0] over relu(gate); column sums = gb_gate
-        g3.A = dYs + (size_t)N * D; g3.out = hs + (size_t)N * F; g3.colpart2 = nullptr; g3.add = l1_coefficient / (float)N;
+        g3.A = dYs + (size_t)N * D; g3.out = hs + (size_t)N * F; g3.colpart2 = nullptr; g3.add = l1_coefficient / ng;
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_gate,

@@ -327,18 +327,22 @@ class NativeSAE:
         self._grad_fresh = False
         self._grad_sparse = False
 
-    def gated_step(self, x: torch.Tensor, l1_coefficient: float, update_stats: bool = True, want_out: bool = False) -> None:
-        """One train step of a gated SAE (pv_sae_gated_step; single process): set_decoder_norm_to_unit_norm, forward, backward,
-        statistics; gradients in ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, -, auxiliary loss."""
+    def gated_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
+                   n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False) -> None:
+        """One train step of a gated SAE (pv_sae_gated_step): set_decoder_norm_to_unit_norm, forward, backward, statistics;
+        gradients in ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, -, auxiliary loss.  batch_mean / n_global:
+        as in ``step`` (tokens sharded over ranks; the caller all-reduces ``flat_g``)."""
         assert self.gated
         x = self._check_x(x)
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
-        N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, int(bool(update_stats)) | 2, float(l1_coefficient),
-                                           C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
-                "pv_sae_gated_step")
+        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                           int(n_global if n_global is not None else n), int(bool(update_stats)) | 2,
+                                           float(l1_coefficient), C.byref(out), self.workspace.data_ptr(), self.workspace.numel(),
+                                           self._stream()), "pv_sae_gated_step")
         self._inv_norm_key = None
         self._grad_fresh = False
         self._grad_sparse = False

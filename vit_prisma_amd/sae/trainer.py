@@ -175,12 +175,13 @@ class VisionSAETrainer:
         cfg = sae.cfg
         from .variants import Transcoder
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
-        # single process, no ghost gradients
-        is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in) and self.world == 1
+        # no ghost gradients; with a process group on the dense (ReLU) step only
+        is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in)
+                 and (self.world == 1 or cfg.activation_fn_str == "relu")          # (multi-rank: on the dense step only)
                  and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own dense step (pv_sae_gated_step)
-        is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.activation_fn_str == "relu" and self.world == 1
+        is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.activation_fn_str == "relu"
                     and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0)
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
@@ -329,19 +330,8 @@ class VisionSAETrainer:
     def _native_step(self, sae, optimizer, scheduler, x, act_freq_scores, n_since_fired):
         lr = optimizer.param_groups[0]["lr"]
         kind = self._native_kind(sae, x)
-        if kind == "gated":
-            eng = self._get_engine(sae, x.shape[0])
-            eng.act_freq_scores = act_freq_scores
-            eng.n_fwd_since_fired = n_since_fired
-            eng.gated_step(x, float(sae.l1_coefficient), update_stats=True)
-            eng.grad_sqnorm()
-            eng.apply(lr, self.cfg.max_grad_norm)
-            optimizer._opt_called = True
-            scheduler.step()
-            sc = eng.scalars.clone()
-            return sc[0], sc[1], sc[4], sc[2]
-        if kind == "relu":
-            return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
+        if kind in ("relu", "gated"):
+            return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired, gated=kind == "gated")
         if self._use_tp(sae):
             return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         self._dp_flush()                                        # parameters of the previous step must have landed
@@ -364,38 +354,46 @@ class VisionSAETrainer:
         sc = eng.scalars.clone()
         return sc[0], sc[1], None, sc[2]
 
-    def _native_dense_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired):
-        """ReLU + L1 (sae.py:617-626) on the dense fused step (pv_sae_dense_step).  Multi-rank: tokens sharded, ONE all-reduce
-        of the flat gradient buffer and a replicated optimizer (the step is ~6 ms of fp32 GEMMs: the 151 MB are not what
-        bounds it), statistics and losses over the global batch like every other path."""
+    def _native_dense_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired, gated: bool = False):
+        """ReLU + L1 (sae.py:617-626; also a ReLU Transcoder) on the dense fused step (pv_sae_dense_step), or a Gated SAE on
+        pv_sae_gated_step.  Multi-rank: tokens sharded, ONE all-reduce of the flat gradient buffer and a replicated optimizer (the
+        step is 6-11 ms of fp32 GEMMs: the 151 MB are not what bounds it), statistics and losses over the global batch like every
+        other path."""
         self._dp_flush()
         eng = self._get_engine(sae, x.shape[0])
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
         l1 = float(sae.l1_coefficient)
+        target = self._target if eng.transcoder else None
+
+        def run(**kw):
+            if gated:
+                eng.gated_step(x, l1, **kw)
+            else:
+                eng.dense_step(x, l1, renorm_decoder=True, target=target, **kw)
+
         if self.world == 1:
             dead = None
-            if sae.cfg.use_ghost_grads and sae.training:        # train_sae.py:330-332 (the mask is taken BEFORE this step's statistics)
+            if sae.cfg.use_ghost_grads and sae.training and not gated:        # train_sae.py:330-332 (the mask is taken BEFORE this step's statistics)
                 dead = n_since_fired > sae.cfg.dead_feature_window
-            eng.dense_step(x, l1, update_stats=True, renorm_decoder=True, dead_mask=dead,
-                           target=self._target if eng.transcoder else None)
+            run(update_stats=True, **({} if gated else {"dead_mask": dead}))
         else:
             import torch.distributed as dist
             W = self.world
             n_global = x.shape[0] * W
-            bm = x.float().sum(dim=0)
-            dist.all_reduce(bm)                                 # global batch mean (sae.py:145)
-            eng.dense_step(x, l1, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
+            bm = (target if target is not None else x).float().sum(dim=0)
+            dist.all_reduce(bm)                                 # global batch mean of what the loss is taken against (sae.py:145)
+            run(batch_mean=bm / n_global, n_global=n_global, update_stats=False)
             d_sae = eng.d_sae
-            if self._small is None or self._small.numel() != d_sae + 5:
-                self._small = torch.empty(d_sae + 5, dtype=torch.float32, device=x.device)
+            if self._small is None or self._small.numel() != d_sae + 7:
+                self._small = torch.empty(d_sae + 7, dtype=torch.float32, device=x.device)
             small = self._small
             small[:d_sae].copy_(eng.fire_count)
-            small[d_sae:].copy_(eng.scalars[:5])
+            small[d_sae:].copy_(eng.scalars[:7])
             dist.all_reduce(eng.flat_g)                         # every rank's share of the gradient (scaled by 1 / N_global already)
-            dist.all_reduce(small)                              # fire counts | loss, mse, l0, -, l1 in one bucket
+            dist.all_reduce(small)                              # fire counts | loss, mse, l0, -, l1, ghost, aux in one bucket
             fire = small[:d_sae]
-            eng.scalars[:5].copy_(small[d_sae:])
+            eng.scalars[:7].copy_(small[d_sae:])
             eng.scalars[2] /= W                                 # l0 is a mean over tokens
             n_since_fired += 1                                  # train_sae.py:356-361 on the global batch
             n_since_fired[fire > 0] = 0
