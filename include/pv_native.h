@@ -276,8 +276,9 @@ typedef struct pv_sae_desc {
  *   - W_skip [d_in, d_in] (transcoder_with_skip_connection) or NULL: sae_out += x @ W_skip^T on the RAW input, before LN-out
  *     (:73-76); gW_skip = dY^T x;
  *   - loss, normaliser and `batch_mean` are the TARGET's (`target` [n_tokens, d_in], set before every step; :78);
- *   - the clip norm covers the two extra tensors, pv_sae_apply runs plain Adam on them with the same clip coefficient.
- * Single process only; the feature-parallel entry points refuse a transcoder state.  d_out == d_in. */
+ *   - the clip norm covers the two extra tensors, pv_sae_apply runs plain Adam on them with the same clip coefficient
+ *     (PV_SAE_SPARSE_GRADS works as for the plain step).
+ * pv_sae_step: single process only; pv_sae_dense_step also with tokens sharded over ranks (batch_mean = the target's global mean); the feature-parallel entry points refuse a transcoder state.  d_out == d_in. */
 typedef struct pv_sae_transcoder {
     float *b_dec_out, *gb_dec_out, *mb_dec_out, *vb_dec_out;   /* [d_in]                                              */
     float *W_skip, *gW_skip, *mW_skip, *vW_skip;               /* [d_in, d_in] (row o = output coordinate) or all NULL */

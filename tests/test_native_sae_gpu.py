@@ -825,7 +825,10 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
             eng.dense_step(xg, l1c, want_out=True, target=yg)
             eng.grad_sqnorm()
         else:
-            eng.step(xg, want_out=True, renorm_decoder=True, target=yg)
+            # the second step in the sparse-rows form the trainer uses (rows of features that kept no token neither written nor
+            # read: the gradient buffers are then not comparable row for row, the clip norm and the parameters are)
+            sparse = t == 1
+            eng.step(xg, want_out=True, renorm_decoder=True, target=yg, sparse_grads=sparse)
             eng.grad_sqnorm(from_step=True)
         torch.cuda.synchronize()
         sc = eng.scalars.cpu().numpy()
@@ -856,9 +859,13 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
             differs = np.zeros(1, bool)
         assert sorted(gr) == sorted(P)
         assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr), (np.sqrt(sc[3]), grad_norm_of(gr))
-        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
-        for name in [m for m in P if m != "W_enc"]:
-            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
+        if not (k is not None and t == 1):
+            assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
+            for name in [m for m in P if m != "W_enc"]:
+                assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
+        else:
+            for name in ("b_dec", "b_dec_out") + (("W_skip",) if skip else ()):
+                assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
         if differs.any():
             return
         fire_ref = stats["act_freq_scores"] - before

@@ -19,6 +19,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_sae_write -
 python $R/tools/pmc_traffic.py $O/pmc_sae_fetch $O/pmc_sae_write $O/pmc_traffic_sae.json "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/prof_sae.py (7 SAE train steps 768 -> 24576, k = 32, N = 4096); KB per launch; hbm_bytes = (2*FETCH + WRITE)*1024" > $O/pmc_traffic_sae.txt
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python $R/bench.py --no-sae --no-l14 --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
 python $R/tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --no-sae --no-l14 --no-cpu-baseline --steps 2 --warmup 1" > $O/pmc_mfma.txt 2>&1
+timeout 600 python $R/tools/tp_shard_times.py > $O/tp_shard_times.json 2> $O/tp_shard_times.err
 for n in vit sae relu l14; do cp $O/prof_$n/${n}_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done
 rm -rf $O/prof_vit $O/prof_sae $O/prof_relu $O/prof_l14 $O/pmc_fetch $O/pmc_write $O/pmc_sae_fetch $O/pmc_sae_write $O/pmc_mfma
 python - <<PY

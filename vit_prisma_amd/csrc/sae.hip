@@ -1707,7 +1707,7 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     // transcoder (pv_sae_state.tc): the loss is taken against tc.target, the decoder adds b_dec_out and the skip term
     const bool tc = sae_is_tc(st);
     if (tc) {
-        PV_REQUIRE(n_global == N && !sparse, "transcoder: single process, complete gradient buffers");
+        PV_REQUIRE(n_global == N, "transcoder on the top-k step: single process");
         const int rq = sae_tc_require(d, st, N);
         if (rq) return rq;
     }

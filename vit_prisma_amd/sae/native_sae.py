@@ -267,7 +267,6 @@ class NativeSAE:
         and ``apply`` may follow.  target (transcoder engines): the activation to reconstruct; batch_mean is then ITS mean."""
         x = self._check_x(x)
         self._set_target(x, target)
-        assert not (self.transcoder and sparse_grads), "transcoder: complete gradient buffers only"
         self._ensure_shadows()
         n = x.shape[0]
         st = self._state()

@@ -342,8 +342,7 @@ class VisionSAETrainer:
         if self.world == 1:
             # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
             # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
-            tc = eng.transcoder                                 # (complete gradient buffers: the skip matrix and b_dec_out join the clip norm)
-            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=not tc, target=self._target if tc else None)
+            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True, target=self._target if eng.transcoder else None)
             eng.grad_sqnorm(from_step=True)                     # clip_grad_norm_ (the gradient is as the step wrote it)
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
