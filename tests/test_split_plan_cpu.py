@@ -1,0 +1,229 @@
+"""The split native plan of HookedViT._run_with_cache_native (seven positions per block, hooks applied between segments, forced taps,
+carried residual stream and activations) on CPU: the HIP backend is replaced by a stand-in that computes a SEGMENT
+(first_block / entry_stage .. n_blocks / exit_stage, requested taps) with plain torch arithmetic on the model's own parameters and
+never touches a HookPoint -- so everything the orchestration gets wrong (a hook applied twice or not at all, a wrong resume
+tensor, a tap taken from the wrong segment, a cache entry not reflecting the hook) shows against the model's ordinary PyTorch hook
+path.  The kernels themselves are held to the same comparison on the GPU (tests/test_native_vit_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vit_prisma_amd import HookedViT, HookedViTConfig
+
+B, S, P = 3, 32, 8
+
+
+def ln(mod, x, taps, prefix, want):
+    x = x - x.mean(-1, keepdim=True)
+    scale = (x.pow(2).mean(-1, keepdim=True) + mod.eps).sqrt()
+    out = x / scale * mod.w + mod.b
+    if prefix + ".hook_scale" in want:
+        taps[prefix + ".hook_scale"] = scale
+    if prefix + ".hook_normalized" in want:
+        taps[prefix + ".hook_normalized"] = out
+    return out
+
+
+class SegmentBackend:
+    """What NativeViT.forward does, in torch, without HookPoints."""
+
+    def __init__(self):
+        self.calls = []
+
+    def forward(self, model, images, names, n_blocks, run_head, cache_device=None, remove_batch_dim=False, first_block=0,
+                resid_in=None, entry_mid=False, exit_mid=False, entry_stage=0, exit_stage=0, act_in=()):
+        es, xs = (5 if entry_mid else entry_stage), (5 if exit_mid else exit_stage)
+        self.calls.append((first_block, es, n_blocks, xs, bool(run_head)))
+        want, taps, cfg, m = set(names), {}, model.cfg, model
+
+        def tap(name, t):
+            if name in want:
+                taps[name] = t
+            return t
+
+        if resid_in is None:
+            assert first_block == 0 and es == 0
+            e = tap("hook_embed", m.embed(images))
+            e = torch.cat((m.cls_token.expand(images.shape[0], -1, -1), e), dim=1)
+            tap("hook_pos_embed", m.pos_embed(images))
+            resid = tap("hook_full_embed", e + m.pos_embed(images))
+        else:
+            assert images is None
+            resid = resid_in
+        out = None
+        last = n_blocks + 1 if xs else n_blocks
+        for l in range(first_block, last):
+            blk, pre = m.blocks[l], f"blocks.{l}."
+            e_ = es if l == first_block else 0
+            x_ = xs if (xs and l == n_blocks) else 99
+            a = blk.attn
+            if e_ < 5:
+                if e_ == 0:
+                    tap(pre + "hook_resid_pre", resid)
+                    h = ln(blk.ln1, resid, taps, pre + "ln1", want)
+                    q = tap(pre + "attn.hook_q", torch.einsum("btd,hde->bthe", h, a.W_Q) + a.b_Q)
+                    k = tap(pre + "attn.hook_k", torch.einsum("btd,hde->bthe", h, a.W_K) + a.b_K)
+                    v = tap(pre + "attn.hook_v", torch.einsum("btd,hde->bthe", h, a.W_V) + a.b_V)
+                elif e_ == 1:
+                    q, k, v = act_in
+                if x_ == 1:
+                    out = q
+                    break
+                if e_ < 2:
+                    scores = tap(pre + "attn.hook_attn_scores", torch.einsum("bqhe,bkhe->bhqk", q, k) / a.attn_scale)
+                elif e_ == 2:
+                    scores, v = act_in
+                if x_ == 2:
+                    out = scores
+                    break
+                if e_ < 3:
+                    pat = F.softmax(scores, dim=-1)
+                    pat = tap(pre + "attn.hook_pattern", torch.where(torch.isnan(pat), torch.zeros_like(pat), pat))
+                elif e_ == 3:
+                    pat, v = act_in
+                if x_ == 3:
+                    out = pat
+                    break
+                if e_ < 4:
+                    z = tap(pre + "attn.hook_z", torch.einsum("bkhe,bhqk->bqhe", v, pat))
+                else:
+                    (z,) = act_in
+                if x_ == 4:
+                    out = z
+                    break
+                attn_out = tap(pre + "hook_attn_out", torch.einsum("bqhe,hed->bqd", z, a.W_O) + a.b_O)
+                mid = tap(pre + "hook_resid_mid", resid + attn_out)
+            else:
+                mid = resid
+            if x_ == 5:
+                out = resid = mid
+                break
+            mlp = blk.mlp
+            if e_ < 6:
+                h2 = ln(blk.ln2, mid, taps, pre + "ln2", want)
+                pre_act = tap(pre + "mlp.hook_pre", h2 @ mlp.W_in + mlp.b_in)
+                post = tap(pre + "mlp.hook_post", mlp.act_fn(pre_act))
+            else:
+                (post,) = act_in
+            if x_ == 6:
+                out = post
+                break
+            mlp_out = tap(pre + "hook_mlp_out", post @ mlp.W_out + mlp.b_out)
+            resid = tap(pre + "hook_resid_post", mid + mlp_out)
+        if run_head:
+            x = ln(m.ln_final, resid, taps, "ln_final", want)
+            tap("hook_ln_final", x)
+            x = m.head(x[:, 0])
+            tap("hook_post_head_pre_normalize", x)
+            out = x
+        elif out is None:
+            out = resid
+        assert want <= set(taps), sorted(want - set(taps))
+        return out, taps
+
+
+@pytest.fixture()
+def model():
+    torch.manual_seed(0)
+    cfg = HookedViTConfig(n_layers=3, d_model=16, d_head=8, d_mlp=32, n_heads=2, patch_size=P, image_size=S, n_classes=5,
+                          return_type="logits")
+    m = HookedViT(cfg).eval()
+    backend = SegmentBackend()
+    m._get_native = lambda device: backend
+    m._backend = backend
+    return m
+
+
+def scale_shift(t, hook):
+    return t * 0.5 + 1.0
+
+
+def zero_cls(t, hook):                    # in place, returns None
+    t[:, 0] = 0.0
+
+
+def half(t, hook):
+    return t * 0.5
+
+
+def kill_head_1(t, hook):
+    t[:, :, 1] = 0.0
+
+
+def kill_neurons(t, hook):
+    t[..., ::3] = 0.0
+
+
+def swap_heads(t, hook):
+    return t.flip(2)
+
+
+def no_cls_attention(t, hook):
+    t = t.clone()
+    t[..., 0] = 0.0
+    return t / t.sum(-1, keepdim=True).clamp_min(1e-6)
+
+
+def mask_scores(t, hook):
+    t[:, 0, :, -1] = float("-inf")
+
+
+def nan_row(t, hook):
+    t[:, 1, 2, 3] = float("nan")
+
+
+NL = 3
+CASES = [
+    [("blocks.0.hook_resid_post", scale_shift)],
+    [(f"blocks.{NL - 1}.hook_resid_post", zero_cls)],
+    [("blocks.1.hook_resid_pre", scale_shift), ("blocks.0.hook_resid_post", zero_cls)],
+    [(lambda n: n.endswith("hook_resid_post"), scale_shift)],
+    [("blocks.0.hook_mlp_out", scale_shift)],
+    [("blocks.1.hook_resid_mid", zero_cls), ("blocks.1.hook_attn_out", scale_shift)],
+    [(lambda n: n.endswith(("hook_attn_out", "hook_resid_mid", "hook_mlp_out", "hook_resid_post")) or n == "blocks.1.hook_resid_pre", scale_shift)],
+    [("blocks.0.attn.hook_z", kill_head_1)],
+    [("blocks.1.mlp.hook_post", kill_neurons)],
+    [("blocks.0.attn.hook_q", half), ("blocks.0.attn.hook_k", kill_head_1), ("blocks.0.attn.hook_v", swap_heads)],
+    [("blocks.0.attn.hook_z", half), ("blocks.1.mlp.hook_post", kill_neurons), ("blocks.1.hook_attn_out", half)],
+    [(lambda n: n.endswith(("attn.hook_q", "attn.hook_z", "hook_resid_mid", "mlp.hook_post", "hook_resid_post")), half)],
+    [("blocks.0.attn.hook_pattern", no_cls_attention)],
+    [(f"blocks.{NL - 1}.attn.hook_attn_scores", mask_scores)],
+    [("blocks.0.attn.hook_attn_scores", nan_row), ("blocks.0.attn.hook_pattern", half)],
+    [("blocks.1.attn.hook_q", half), ("blocks.1.attn.hook_attn_scores", mask_scores), ("blocks.1.attn.hook_pattern", no_cls_attention),
+     ("blocks.1.attn.hook_z", kill_head_1)],
+    [("blocks.0.attn.hook_v", swap_heads), ("blocks.0.attn.hook_pattern", half), ("blocks.0.hook_resid_mid", half)],
+    [(lambda n: n.endswith(("attn.hook_attn_scores", "attn.hook_pattern", "attn.hook_z", "mlp.hook_post", "hook_mlp_out")), half)],
+    [(lambda n: n.startswith("blocks.") and n.split(".", 2)[2] in ("attn.hook_q", "attn.hook_k", "attn.hook_v", "attn.hook_attn_scores",
+                                                                   "attn.hook_pattern", "attn.hook_z", "hook_attn_out", "hook_resid_mid",
+                                                                   "mlp.hook_post", "hook_mlp_out", "hook_resid_post"), half)],
+]
+FORMS = [{}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post"))},
+         {"names_filter": lambda n: n.endswith(("hook_attn_scores", "hook_v", "hook_attn_out"))}, {"stop_at_layer": NL - 1},
+         {"names_filter": [], "stop_at_layer": 1}]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_split_plan_equals_the_hook_path(model, case):
+    hooks = CASES[case]
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    real_reason = model._native_reason
+    with torch.no_grad():
+        for kw in FORMS:
+            model.use_native(False)                                        # the ordinary PyTorch hook path
+            w_out, w_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+            assert not model.last_run_native
+            # the split plan on the stand-in backend: same dispatch, minus the "input is on a GPU" condition
+            model.use_native(True)
+            model._native_reason = lambda a, k: None if model._boundary_hooks() is not None else "a hook the plan cannot be split at"
+            model._backend.calls.clear()
+            try:
+                g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+            finally:
+                model._native_reason = real_reason
+            assert model.last_run_native and len(model._backend.calls) >= 1
+            assert list(g_cache.keys()) == list(w_cache.keys())
+            assert torch.allclose(g_out, w_out, atol=1e-5, equal_nan=True), kw
+            for k_ in w_cache.keys():
+                a, b = g_cache[k_], w_cache[k_]
+                assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5, equal_nan=True), (k_, kw)
+            assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
