@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 14
+#define PV_ABI_VERSION 15
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -195,27 +195,34 @@ int pv_vit_forward_seg(pv_vit_plan* plan, const void* images, const void* resid_
                        int32_t run_head, const pv_tap* taps, int32_t n_taps, void* workspace,
                        size_t workspace_bytes, void* out, void* stream);
 
-/* The finest form: segments that start / stop at any of a block's seven hookable positions, so that mutating hooks INSIDE the
+/* The finest form: segments that start / stop at any of a block's ten hookable positions, so that mutating hooks INSIDE the
  * attention half and the MLP keep the native path too (head ablation through attn.hook_z, neuron ablation through
- * mlp.hook_post, edits of attn.hook_q / hook_k / hook_v, of attn.hook_attn_scores and of attn.hook_pattern:
- * prisma_tools/hook_point.py:44-45 -- a hook's return value replaces the activation -- with models/layers/attention.py:135-152,
- * 186-281 and mlp.py:65-80).  Positions inside block L, in the order the block passes them: */
+ * mlp.hook_post, edits of attn.hook_q / hook_k / hook_v, of attn.hook_attn_scores, of attn.hook_pattern, of mlp.hook_pre and of the
+ * LayerNorm points ln1 / ln2 .hook_scale / .hook_normalized ("frozen LayerNorm"): prisma_tools/hook_point.py:44-45 -- a hook's
+ * return value replaces the activation -- with models/layers/attention.py:135-152, 186-281, mlp.py:65-80 and layer_norm.py:75-93).
+ * Positions inside block L, in the order the block passes them: */
 #define PV_STAGE_ENTRY 0      /* the residual stream entering the block (hook_resid_pre)                                  */
-#define PV_STAGE_QKV 1        /* q, k, v computed (attn.hook_q / hook_k / hook_v)                                          */
-#define PV_STAGE_SCORES 2     /* attention scores computed (attn.hook_attn_scores)                                         */
-#define PV_STAGE_PATTERN 3    /* softmax taken (attn.hook_pattern)                                                         */
-#define PV_STAGE_Z 4          /* attention core done (attn.hook_z)                                                        */
-#define PV_STAGE_MID 5        /* after the O-projection + residual add (hook_attn_out, hook_resid_mid) == entry_mid above  */
-#define PV_STAGE_MLP_POST 6   /* MLP activation computed (mlp.hook_post)                                                  */
+#define PV_STAGE_LN1 1        /* ln1 taken (ln1.hook_scale, ln1.hook_normalized)                                           */
+#define PV_STAGE_QKV 2        /* q, k, v computed (attn.hook_q / hook_k / hook_v)                                          */
+#define PV_STAGE_SCORES 3     /* attention scores computed (attn.hook_attn_scores)                                         */
+#define PV_STAGE_PATTERN 4    /* softmax taken (attn.hook_pattern)                                                         */
+#define PV_STAGE_Z 5          /* attention core done (attn.hook_z)                                                        */
+#define PV_STAGE_MID 6        /* after the O-projection + residual add (hook_attn_out, hook_resid_mid) == entry_mid above  */
+#define PV_STAGE_LN2 7        /* ln2 taken (ln2.hook_scale, ln2.hook_normalized)                                           */
+#define PV_STAGE_MLP_PRE 8    /* MLP pre-activation computed (mlp.hook_pre)                                                */
+#define PV_STAGE_MLP_POST 9   /* MLP activation computed (mlp.hook_post)                                                  */
 /*   exit_stage   != 0: the segment also runs block end_block up to that position and stops; the caller taps what the hook
- *                needs (PV_SLOT_Q / K / V, PV_SLOT_SCORES, PV_SLOT_PATTERN, PV_SLOT_Z, PV_SLOT_RESID_MID, PV_SLOT_MLP_POST; for
- *                SCORES / PATTERN also PV_SLOT_V, which the resumed attention core reads) and -- to resume -- the residual
- *                stream the rest of the block adds to (the block's resid_pre up to Z, its resid_mid for MLP_POST).  The
- *                attention core is one kernel: an exit at SCORES or PATTERN runs all of it and the later positions' results
- *                are simply not used.
+ *                needs (PV_SLOT_LN1_SCALE / LN1_NORM_F32 (bf16 mode; LN1_OUT in fp32 mode), PV_SLOT_Q / K / V, PV_SLOT_SCORES,
+ *                PV_SLOT_PATTERN, PV_SLOT_Z, PV_SLOT_RESID_MID, PV_SLOT_LN2_*, PV_SLOT_MLP_PRE, PV_SLOT_MLP_POST; for SCORES / PATTERN also
+ *                PV_SLOT_V, which the resumed attention core reads) and -- to resume -- the residual stream the rest of the block
+ *                adds to (the block's resid_pre up to Z, its resid_mid behind MID).  The attention core is one kernel and so is
+ *                the first MLP GEMM: an exit at SCORES / PATTERN / MLP_PRE runs all of it and the later positions' results are
+ *                simply not used.
  *   entry_stage  != 0: resume block first_block behind that position: resid_in = that residual stream, act_in0..2 = the
- *                (possibly edited) activations of the position: q, k, v [B, T, H, dh] | scores [B, H, T, T], v | pattern
- *                [B, H, T, T], v | z [B, T, H, dh] | post [B, T, d_mlp] (NULL for ENTRY / MID).  Behind SCORES / PATTERN the
+ *                (possibly edited) activations of the position: LN1 / LN2: the normalized tensor [B, T, d_model] in FP32 (what
+ *                hook_normalized carries in either dtype mode; it is rounded to the storage dtype here, layer_norm.py:93) | q, k, v
+ *                [B, T, H, dh] | scores [B, H, T, T], v | pattern [B, H, T, T], v | z [B, T, H, dh] | pre [B, T, d_mlp] (the
+ *                activation function is applied here) | post [B, T, d_mlp] (NULL for ENTRY / MID).  Behind SCORES / PATTERN the
  *                rest of the attention core (softmax, NaN -> 0, pattern tap; pattern v) runs on a one-wave-per-row kernel.
  *                images: only with first_block = entry_stage = 0. */
 int pv_vit_forward_stage(pv_vit_plan* plan, const void* images, const void* resid_in, const void* act_in0, const void* act_in1,

@@ -178,10 +178,11 @@ def test_cache_key_order_and_observe_only_points(model, x):
 def test_boundary_hook_classification_for_the_split_native_plan(model, x):
     """Which registered hooks the HIP plan can serve by splitting (HookedViT._boundary_hooks): forward hooks on the
     residual-stream points of a block -- hook_resid_pre (block >= 1), hook_attn_out, hook_resid_mid, hook_mlp_out,
-    hook_resid_post -- and on attn.hook_q / hook_k / hook_v, attn.hook_attn_scores, attn.hook_pattern, attn.hook_z and
-    mlp.hook_post inside it, keyed by position (seven per block: entry | q, k, v | scores | pattern | z | after the attention
-    half | mlp post); anything else (mlp pre, LayerNorm points, backward hooks, block 0's resid_pre) keeps the PyTorch path.
-    On CPU the call itself always runs in PyTorch."""
+    hook_resid_post -- and on every point inside it: ln1 / ln2 .hook_scale / .hook_normalized, attn.hook_q / hook_k / hook_v,
+    attn.hook_attn_scores, attn.hook_pattern, attn.hook_z, mlp.hook_pre, mlp.hook_post, keyed by position (ten per block: entry |
+    ln1 | q, k, v | scores | pattern | z | after the attention half | ln2 | mlp pre | mlp post); anything else (the embedding and
+    final stages, the flag-gated points, backward hooks, block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself
+    always runs in PyTorch."""
     ident = lambda t, hook: t  # noqa: E731
     assert model._boundary_hooks() == {}
     with model.hooks(fwd_hooks=[("blocks.0.hook_resid_post", ident), ("blocks.1.hook_resid_pre", ident),
@@ -189,17 +190,20 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
                                 ("blocks.1.hook_attn_out", ident), ("blocks.0.hook_resid_mid", ident),
                                 ("blocks.0.attn.hook_z", ident), ("blocks.1.attn.hook_q", ident), ("blocks.1.attn.hook_v", ident),
                                 ("blocks.1.mlp.hook_post", ident), ("blocks.0.attn.hook_pattern", ident),
-                                ("blocks.1.attn.hook_attn_scores", ident)]):
+                                ("blocks.1.attn.hook_attn_scores", ident), ("blocks.0.ln2.hook_scale", ident),
+                                ("blocks.1.mlp.hook_pre", ident), ("blocks.1.ln1.hook_normalized", ident),
+                                ("blocks.1.ln1.hook_scale", ident)]):
         bh = model._boundary_hooks()
-        assert sorted(bh) == [3, 4, 5, 7, 8, 9, 12, 13, 14]
-        assert sorted(bh[3]) == ["pattern"] and sorted(bh[4]) == ["z"] and sorted(bh[5]) == ["mid"] and sorted(bh[7]) == ["mlp", "post", "pre"]
-        assert sorted(bh[8]) == ["q", "v"] and sorted(bh[9]) == ["scores"] and sorted(bh[12]) == ["attn"]
-        assert sorted(bh[13]) == ["mlppost"] and sorted(bh[14]) == ["post"]
-        assert bh[7]["post"] is model.hook_dict["blocks.0.hook_resid_post"]
+        assert sorted(bh) == [4, 5, 6, 7, 10, 11, 12, 13, 16, 18, 19, 20]
+        assert sorted(bh[4]) == ["pattern"] and sorted(bh[5]) == ["z"] and sorted(bh[6]) == ["mid"] and sorted(bh[7]) == ["ln2s"]
+        assert sorted(bh[10]) == ["mlp", "post", "pre"] and sorted(bh[11]) == ["ln1n", "ln1s"] and sorted(bh[12]) == ["q", "v"]
+        assert sorted(bh[13]) == ["scores"] and sorted(bh[16]) == ["attn"] and sorted(bh[18]) == ["mlppre"]
+        assert sorted(bh[19]) == ["mlppost"] and sorted(bh[20]) == ["post"]
+        assert bh[10]["post"] is model.hook_dict["blocks.0.hook_resid_post"]
         out = model(x)                                   # CPU input: PyTorch path, result defined by the hooks
         assert out.shape[0] == B and not model.last_run_native
     assert model._boundary_hooks() == {}
-    for bad in ("blocks.0.hook_resid_pre", "hook_embed", "blocks.0.mlp.hook_pre", "blocks.0.ln1.hook_normalized"):
+    for bad in ("blocks.0.hook_resid_pre", "hook_embed", "ln_final.hook_normalized", "hook_ln_final"):
         with model.hooks(fwd_hooks=[(bad, ident)]):
             assert model._boundary_hooks() is None, bad
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):

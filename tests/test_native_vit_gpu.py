@@ -215,11 +215,13 @@ def test_native_equals_pytorch_hook_path_and_fallback_dispatch():
         _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.attn.hook_pattern", zero)])           # ... and at the pattern
         assert model.last_run_native and float(c_h["blocks.0.attn.hook_pattern"].abs().max()) == 0.0
         assert float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
-        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])                # not splittable: PyTorch path
-        assert not model.last_run_native and float(c_h["blocks.0.mlp.hook_pre"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])                # ... at the MLP pre-activation
+        assert model.last_run_native and float(c_h["blocks.0.mlp.hook_pre"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("hook_embed", zero)])                            # not splittable: PyTorch path
+        assert not model.last_run_native and float(c_h["hook_embed"].abs().max()) == 0.0
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])
+            model.run_with_cache(x, fwd_hooks=[("hook_embed", zero)])
     # weight edits are picked up (version counter) -> output changes
     model.use_native(True)
     with torch.no_grad():
@@ -358,21 +360,22 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
         # a hook anywhere else still works -- through the PyTorch path ("auto" mode; "force" raises instead)
         model.use_native(None)
-        out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)])
+        out = model.run_with_hooks(x, fwd_hooks=[("ln_final.hook_normalized", scale_shift)])
         assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
-        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)]).cpu().numpy()) < FP32_TOL
+        assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("ln_final.hook_normalized", scale_shift)]).cpu().numpy()) < FP32_TOL
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.ln2.hook_normalized", scale_shift)])
+            model.run_with_cache(x, fwd_hooks=[("ln_final.hook_normalized", scale_shift)])
         with pytest.raises(_native.NativeError):
-            model.run_with_hooks(x, fwd_hooks=[("blocks.0.mlp.hook_pre", scale_shift)])
+            model.run_with_hooks(x, fwd_hooks=[("hook_embed", scale_shift)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
 
 
 @pytest.mark.parametrize("arch_name,dtype", [("tiny", torch.float32), ("tiny-ragged", torch.float32), ("tiny", torch.bfloat16)])
 def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_plan(arch_name, dtype):
-    """Head ablation (attn.hook_z), edits of q / k / v, of the attention scores and of the pattern, and neuron ablation
-    (mlp.hook_post) keep the HIP path: the plan is
+    """Head ablation (attn.hook_z), edits of q / k / v, of the attention scores and of the pattern, frozen / edited LayerNorms
+    (ln1 / ln2 .hook_scale / .hook_normalized), edits of mlp.hook_pre and neuron ablation (mlp.hook_post) keep the HIP path: the
+    plan is
     split INSIDE the block (pv_vit_forward_stage) -- the hook sees the stage's activation, the rest of the block resumes from
     what it returned, the residual stream it adds to is carried along.  Every result must equal the PyTorch hook path of the
     same model (prisma_tools/hook_point.py:44-45; models/layers/attention.py:135-152, 186-281; mlp.py:65-80), cache
@@ -381,7 +384,7 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
     ref = _pytorch_twin(model)
     x = torch.from_numpy(synth_images(arch, 3, 5)).cuda().to(dtype)
     nl = arch["n_layers"]
-    tol = FP32_TOL if dtype == torch.float32 else 3e-2
+    base_tol = FP32_TOL if dtype == torch.float32 else 3e-2
 
     def half(t, hook):
         return t * 0.5
@@ -406,7 +409,18 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
     def nan_row(t, hook):                 # a NaN score poisons its row: the reference's where(isnan) zeroes the pattern row
         t[:, 1, 2, 3] = float("nan")
 
+    def freeze_scale(t, hook):            # "frozen LayerNorm": the scale [B, T, 1] replaced by a constant
+        return torch.full_like(t, 1.25)
+
+    def shift_pre(t, hook):
+        return t - 0.25
+
     cases = [
+        [("blocks.0.ln1.hook_scale", freeze_scale)],
+        [("blocks.1.ln2.hook_normalized", half), ("blocks.1.mlp.hook_pre", shift_pre)],
+        [("blocks.0.ln1.hook_scale", freeze_scale), ("blocks.0.ln1.hook_normalized", half), ("blocks.0.attn.hook_q", half),
+         ("blocks.0.ln2.hook_scale", half), ("blocks.0.mlp.hook_pre", kill_neurons), ("blocks.0.mlp.hook_post", half)],
+        [(lambda n: n.endswith(("ln1.hook_scale", "ln2.hook_normalized", "mlp.hook_pre")), half)],
         [("blocks.0.attn.hook_pattern", no_cls_attention)],
         [(f"blocks.{nl - 1}.attn.hook_attn_scores", mask_scores)],
         [("blocks.0.attn.hook_attn_scores", nan_row), ("blocks.0.attn.hook_pattern", half)],
@@ -426,7 +440,10 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
         [(f"blocks.{nl - 1}.mlp.hook_post", half), (f"blocks.{nl - 1}.hook_mlp_out", kill_head_1 if False else half)],
     ]
     with torch.no_grad():
-        for hooks in cases:
+        for ci, hooks in enumerate(cases):
+            # (bf16: the four LayerNorm cases rescale the stream -- a constant scale of 1.25 instead of ~1 -- and the two bf16
+            # pipelines, which round at different points by design, drift apart a little more behind them)
+            tol = base_tol * (2.0 if (dtype == torch.bfloat16 and ci < 4) else 1.0)
             want = ref.run_with_hooks(x.clone(), fwd_hooks=hooks)
             got = model.run_with_hooks(x.clone(), fwd_hooks=hooks)
             assert model.last_run_native, model.native_fallback_reason

@@ -1,4 +1,4 @@
-"""The split native plan of HookedViT._run_with_cache_native (seven positions per block, hooks applied between segments, forced taps,
+"""The split native plan of HookedViT._run_with_cache_native (ten positions per block, hooks applied between segments, forced taps,
 carried residual stream and activations) on CPU: the HIP backend is replaced by a stand-in that computes a SEGMENT
 (first_block / entry_stage .. n_blocks / exit_stage, requested taps) with plain torch arithmetic on the model's own parameters and
 never touches a HookPoint -- so everything the orchestration gets wrong (a hook applied twice or not at all, a wrong resume
@@ -32,7 +32,7 @@ class SegmentBackend:
 
     def forward(self, model, images, names, n_blocks, run_head, cache_device=None, remove_batch_dim=False, first_block=0,
                 resid_in=None, entry_mid=False, exit_mid=False, entry_stage=0, exit_stage=0, act_in=()):
-        es, xs = (5 if entry_mid else entry_stage), (5 if exit_mid else exit_stage)
+        es, xs = (6 if entry_mid else entry_stage), (6 if exit_mid else exit_stage)
         self.calls.append((first_block, es, n_blocks, xs, bool(run_head)))
         want, taps, cfg, m = set(names), {}, model.cfg, model
 
@@ -57,55 +57,75 @@ class SegmentBackend:
             e_ = es if l == first_block else 0
             x_ = xs if (xs and l == n_blocks) else 99
             a = blk.attn
-            if e_ < 5:
+            if e_ < 6:
                 if e_ == 0:
                     tap(pre + "hook_resid_pre", resid)
                     h = ln(blk.ln1, resid, taps, pre + "ln1", want)
+                elif e_ == 1:
+                    (h,) = act_in
+                    assert h.dtype == torch.float32
+                if x_ == 1:
+                    out = h
+                    break
+                if e_ < 2:
                     q = tap(pre + "attn.hook_q", torch.einsum("btd,hde->bthe", h, a.W_Q) + a.b_Q)
                     k = tap(pre + "attn.hook_k", torch.einsum("btd,hde->bthe", h, a.W_K) + a.b_K)
                     v = tap(pre + "attn.hook_v", torch.einsum("btd,hde->bthe", h, a.W_V) + a.b_V)
-                elif e_ == 1:
+                elif e_ == 2:
                     q, k, v = act_in
-                if x_ == 1:
+                if x_ == 2:
                     out = q
                     break
-                if e_ < 2:
+                if e_ < 3:
                     scores = tap(pre + "attn.hook_attn_scores", torch.einsum("bqhe,bkhe->bhqk", q, k) / a.attn_scale)
-                elif e_ == 2:
+                elif e_ == 3:
                     scores, v = act_in
-                if x_ == 2:
+                if x_ == 3:
                     out = scores
                     break
-                if e_ < 3:
+                if e_ < 4:
                     pat = F.softmax(scores, dim=-1)
                     pat = tap(pre + "attn.hook_pattern", torch.where(torch.isnan(pat), torch.zeros_like(pat), pat))
-                elif e_ == 3:
+                elif e_ == 4:
                     pat, v = act_in
-                if x_ == 3:
+                if x_ == 4:
                     out = pat
                     break
-                if e_ < 4:
+                if e_ < 5:
                     z = tap(pre + "attn.hook_z", torch.einsum("bkhe,bhqk->bqhe", v, pat))
                 else:
                     (z,) = act_in
-                if x_ == 4:
+                if x_ == 5:
                     out = z
                     break
                 attn_out = tap(pre + "hook_attn_out", torch.einsum("bqhe,hed->bqd", z, a.W_O) + a.b_O)
                 mid = tap(pre + "hook_resid_mid", resid + attn_out)
             else:
                 mid = resid
-            if x_ == 5:
+            if x_ == 6:
                 out = resid = mid
                 break
             mlp = blk.mlp
-            if e_ < 6:
-                h2 = ln(blk.ln2, mid, taps, pre + "ln2", want)
-                pre_act = tap(pre + "mlp.hook_pre", h2 @ mlp.W_in + mlp.b_in)
+            if e_ < 9:
+                if e_ < 7:
+                    h2 = ln(blk.ln2, mid, taps, pre + "ln2", want)
+                elif e_ == 7:
+                    (h2,) = act_in
+                    assert h2.dtype == torch.float32
+                if x_ == 7:
+                    out = h2
+                    break
+                if e_ < 8:
+                    pre_act = tap(pre + "mlp.hook_pre", h2 @ mlp.W_in + mlp.b_in)
+                else:
+                    (pre_act,) = act_in
+                if x_ == 8:
+                    out = pre_act
+                    break
                 post = tap(pre + "mlp.hook_post", mlp.act_fn(pre_act))
             else:
                 (post,) = act_in
-            if x_ == 6:
+            if x_ == 9:
                 out = post
                 break
             mlp_out = tap(pre + "hook_mlp_out", post @ mlp.W_out + mlp.b_out)
@@ -172,6 +192,14 @@ def nan_row(t, hook):
     t[:, 1, 2, 3] = float("nan")
 
 
+def freeze_scale(t, hook):                # "frozen LayerNorm": the scale replaced by a constant
+    return torch.full_like(t, 1.25)
+
+
+def shift_pre(t, hook):
+    return t - 0.25
+
+
 NL = 3
 CASES = [
     [("blocks.0.hook_resid_post", scale_shift)],
@@ -193,11 +221,18 @@ CASES = [
      ("blocks.1.attn.hook_z", kill_head_1)],
     [("blocks.0.attn.hook_v", swap_heads), ("blocks.0.attn.hook_pattern", half), ("blocks.0.hook_resid_mid", half)],
     [(lambda n: n.endswith(("attn.hook_attn_scores", "attn.hook_pattern", "attn.hook_z", "mlp.hook_post", "hook_mlp_out")), half)],
+    [("blocks.0.ln1.hook_scale", freeze_scale)],
+    [("blocks.1.ln2.hook_normalized", half), ("blocks.1.mlp.hook_pre", shift_pre)],
+    [("blocks.0.ln1.hook_scale", freeze_scale), ("blocks.0.ln1.hook_normalized", scale_shift), ("blocks.0.attn.hook_q", half),
+     ("blocks.0.ln2.hook_scale", half), ("blocks.0.mlp.hook_pre", kill_neurons), ("blocks.0.mlp.hook_post", half)],
+    [(lambda n: n.endswith(("ln1.hook_scale", "ln2.hook_normalized", "mlp.hook_pre")), half)],
     [(lambda n: n.startswith("blocks.") and n.split(".", 2)[2] in ("attn.hook_q", "attn.hook_k", "attn.hook_v", "attn.hook_attn_scores",
                                                                    "attn.hook_pattern", "attn.hook_z", "hook_attn_out", "hook_resid_mid",
-                                                                   "mlp.hook_post", "hook_mlp_out", "hook_resid_post"), half)],
+                                                                   "mlp.hook_post", "hook_mlp_out", "hook_resid_post", "ln1.hook_scale",
+                                                                   "ln1.hook_normalized", "ln2.hook_scale", "ln2.hook_normalized",
+                                                                   "mlp.hook_pre"), half)],
 ]
-FORMS = [{}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post"))},
+FORMS = [{}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post", "ln1.hook_scale", "ln2.hook_normalized"))},
          {"names_filter": lambda n: n.endswith(("hook_attn_scores", "hook_v", "hook_attn_out"))}, {"stop_at_layer": NL - 1},
          {"names_filter": [], "stop_at_layer": 1}]
 

@@ -1318,6 +1318,31 @@ extern "C" int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int3
     return PV_OK;
 }
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void act_rows_kernel(const T* __restrict__ pre, T* __restrict__ post, int64_t n8, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    load8(pre + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_any<T>(v[e], act);
+    store8(post + i * 8, v);
+}
+}  // namespace
+
+int pv_launch_act(int dtype, int act, const void* pre, void* post, int64_t n, hipStream_t stream) {
+    PV_REQUIRE(pre && post && n > 0 && n % 8 == 0 && pv_aligned16(pre) && pv_aligned16(post), "activation launcher arguments");
+    const int64_t n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256)), block(256);
+    if (dtype == PV_DTYPE_BF16)
+        hipLaunchKernelGGL(act_rows_kernel<bf16_t>, grid, block, 0, stream, reinterpret_cast<const bf16_t*>(pre), reinterpret_cast<bf16_t*>(post), n8, act);
+    else
+        hipLaunchKernelGGL(act_rows_kernel<float>, grid, block, 0, stream, reinterpret_cast<const float*>(pre), reinterpret_cast<float*>(post), n8, act);
+    PV_LAUNCH_CHECK("act_rows_kernel");
+    return PV_OK;
+}
+
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
     p.dbg = g_pv_tuning.gemm_dbg;
     p.trace = nullptr;

@@ -38,6 +38,9 @@ struct GemmParams {
 
 // dtype: PV_DTYPE_*.  Returns PV_OK / error code (pv_last_error has the message).
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream);
+// post[i] = act(pre[i]) with the instruction sequence of the GEMM epilogues (PV_EPI_ACT): the MLP resumed behind an edited
+// mlp.hook_pre (pv_vit_forward_stage, PV_STAGE_MLP_PRE).  n % 8 == 0, 16-byte aligned pointers.
+int pv_launch_act(int dtype, int act, const void* pre, void* post, int64_t n, hipStream_t stream);
 
 // debug: arm per-workgroup phase tracing for the `launch_idx`-th GEMM launch from now (0 = next), read it back
 // (blocks until the device is idle).  info = {M, N, K, epi, n_workgroups, kernel version}.

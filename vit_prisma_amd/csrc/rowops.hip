@@ -218,3 +218,24 @@ int pv_launch_transpose(int elem_bytes, const void* in, void* out, int batch, in
     PV_LAUNCH_CHECK("transpose_kernel");
     return PV_OK;
 }
+
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *reinterpret_cast<const float4*>(in + i * 4);
+    DT<T>::store(out + i * 4, v.x); DT<T>::store(out + i * 4 + 1, v.y);
+    DT<T>::store(out + i * 4 + 2, v.z); DT<T>::store(out + i * 4 + 3, v.w);
+}
+}  // namespace
+
+int pv_launch_cast_from_f32(int dtype, const float* in, void* out, int64_t n, hipStream_t stream) {
+    PV_REQUIRE(in && out && n > 0 && n % 4 == 0 && pv_aligned16(in), "cast launcher arguments");
+    const int64_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    if (dtype == PV_DTYPE_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, grid, block, 0, stream, in, reinterpret_cast<bf16_t*>(out), n4);
+    else hipLaunchKernelGGL(cast_from_f32_kernel<float>, grid, block, 0, stream, in, reinterpret_cast<float*>(out), n4);
+    PV_LAUNCH_CHECK("cast_from_f32_kernel");
+    return PV_OK;
+}

@@ -22,6 +22,9 @@ struct LnParams {
 };
 
 int pv_launch_ln(int dtype, const LnParams& p, hipStream_t stream);
+// out[i] = T(in[i]) (round to the storage dtype; a plain copy in fp32 mode): the LayerNorm output rebuilt from an edited
+// hook_normalized tensor (pv_vit_forward_stage, PV_STAGE_LN1 / PV_STAGE_LN2).  n % 4 == 0.
+int pv_launch_cast_from_f32(int dtype, const float* in, void* out, int64_t n, hipStream_t stream);
 int pv_launch_l2norm(int dtype, const void* x, void* out, int rows, int n, hipStream_t stream);
 int pv_launch_transpose(int elem_bytes, const void* in, void* out, int batch, int R, int C, hipStream_t stream);
 // bf16 NCHW images -> [B*G*G][Kp] patch rows (im2col once per batch, zero-padded to Kp columns), and the matching row padding

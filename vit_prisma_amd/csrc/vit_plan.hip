@@ -183,7 +183,7 @@ extern "C" size_t pv_vit_workspace_bytes(const pv_vit_plan* p, int32_t batch) {
 }
 
 namespace {
-// entry_stage / exit_stage: PV_STAGE_* (positions inside a block: entry, q/k/v ready, scores, pattern, z ready, resid_mid, mlp post ready)
+// entry_stage / exit_stage: PV_STAGE_* (positions inside a block: entry, ln1, q/k/v ready, scores, pattern, z ready, resid_mid, ln2, mlp pre, mlp post ready)
 int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, const void* const* act_in, int32_t B,
                      int32_t first_block, int32_t entry_stage, int32_t n_blocks, int32_t exit_stage, int32_t run_head,
                      const pv_tap* taps, int32_t n_taps, void* workspace, size_t workspace_bytes, void* out, void* stream_);
@@ -224,7 +224,9 @@ extern "C" int pv_vit_forward_stage(pv_vit_plan* p, const void* images, const vo
     PV_REQUIRE(first_block < end_block || entry_stage < exit_stage || (first_block == end_block && !exit_stage && !entry_stage),
                "empty or backward segment");
     if (entry_stage == PV_STAGE_QKV) PV_REQUIRE(act_in0 && act_in1 && act_in2, "entry at PV_STAGE_QKV needs q, k, v");
-    if (entry_stage == PV_STAGE_Z || entry_stage == PV_STAGE_MLP_POST) PV_REQUIRE(act_in0, "entry at PV_STAGE_Z / PV_STAGE_MLP_POST needs the activation");
+    if (entry_stage == PV_STAGE_Z || entry_stage == PV_STAGE_MLP_POST || entry_stage == PV_STAGE_LN1 || entry_stage == PV_STAGE_LN2 ||
+        entry_stage == PV_STAGE_MLP_PRE)
+        PV_REQUIRE(act_in0, "entry at PV_STAGE_LN1 / Z / LN2 / MLP_PRE / MLP_POST needs the activation");
     if (entry_stage == PV_STAGE_SCORES || entry_stage == PV_STAGE_PATTERN) PV_REQUIRE(act_in0 && act_in1, "entry at PV_STAGE_SCORES / PV_STAGE_PATTERN needs the activation and v");
     const void* act[3] = {act_in0, act_in1, act_in2};
     for (int i = 0; i < 3; ++i) PV_REQUIRE(!act[i] || pv_aligned16(act[i]), "activation inputs must be 16-byte aligned");
@@ -344,9 +346,10 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
         if (es >= PV_STAGE_MID) {
             resid_mid = resid;
         } else {
-        if (es < PV_STAGE_QKV) {
+        void* ln1 = nullptr;
+        if (es < PV_STAGE_LN1) {
         // ln1 (transformer_block.py:106-109 ; layer_norm.py:75-93)
-        void* ln1 = pick(PV_SLOT_LN1_OUT, l, ws.ln_out);
+        ln1 = pick(PV_SLOT_LN1_OUT, l, ws.ln_out);
         {
             LnParams L = {};
             L.x = resid_pre; L.ldx = dm; L.rows = M; L.d = dm; L.eps = d.eps; L.do_ln = 1;
@@ -356,6 +359,18 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
             L.out = ln1;
             if ((rc = pv_launch_ln(dt, L, stream))) return rc;
         }
+        } else if (es == PV_STAGE_LN1) {
+            // behind a hooked ln1.hook_scale / hook_normalized: the (edited) fp32 normalized tensor, rounded to the storage
+            // dtype like the module's own last step (layer_norm.py:93)
+            if (bf16) {
+                ln1 = wsb + ws.ln_out;
+                if ((rc = pv_launch_cast_from_f32(dt, (const float*)act_in[0], ln1, (int64_t)M * dm, stream))) return rc;
+            } else {
+                ln1 = const_cast<void*>(act_in[0]);
+            }
+        }
+        if (xs == PV_STAGE_LN1) break;
+        if (es < PV_STAGE_QKV) {
         // q, k, v (attention.py:186-244) as one GEMM against the packed [3*H*dh][d] shadow
         q = pick(PV_SLOT_Q, l, ws.q);
         k = pick(PV_SLOT_K, l, ws.k);
@@ -410,8 +425,10 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
         }
         void* post;
         if (es < PV_STAGE_MLP_POST) {
+        void* ln2 = nullptr;
+        if (es < PV_STAGE_LN2) {
         // ln2 (block :130)
-        void* ln2 = pick(PV_SLOT_LN2_OUT, l, ws.ln_out);
+        ln2 = pick(PV_SLOT_LN2_OUT, l, ws.ln_out);
         {
             LnParams L = {};
             L.x = resid_mid; L.ldx = dm; L.rows = M; L.d = dm; L.eps = d.eps; L.do_ln = 1;
@@ -421,8 +438,18 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
             L.out = ln2;
             if ((rc = pv_launch_ln(dt, L, stream))) return rc;
         }
-        // mlp (mlp.py:65-80): pre -> act -> post
+        } else if (es == PV_STAGE_LN2) {
+            if (bf16) {
+                ln2 = wsb + ws.ln_out;
+                if ((rc = pv_launch_cast_from_f32(dt, (const float*)act_in[0], ln2, (int64_t)M * dm, stream))) return rc;
+            } else {
+                ln2 = const_cast<void*>(act_in[0]);
+            }
+        }
+        if (xs == PV_STAGE_LN2) break;
         post = pick(PV_SLOT_MLP_POST, l, ws.mlp_post);
+        if (es < PV_STAGE_MLP_PRE) {
+        // mlp (mlp.py:65-80): pre -> act -> post
         {
             GemmParams g = {};
             g.A = ln2; g.lda = dm; g.a_mode = PV_A_PLAIN; g.Bt = S.WinT; g.ldb = dm;
@@ -430,6 +457,11 @@ int vit_forward_impl(pv_vit_plan* p, const void* images, const void* resid_in, c
             g.out0 = tap_at(PV_SLOT_MLP_PRE, l); g.out1 = post; g.ldo = dmlp;
             if ((rc = pv_launch_gemm(dt, g, stream))) return rc;
         }
+        } else {
+            // behind a hooked mlp.hook_pre: the activation function on the edited pre-activation (mlp.py:67-72)
+            if ((rc = pv_launch_act(dt, d.activation, act_in[0], post, (int64_t)M * dmlp, stream))) return rc;
+        }
+        if (xs == PV_STAGE_MLP_PRE) break;
         } else {
             post = const_cast<void*>(act_in[0]);
         }

@@ -226,14 +226,15 @@ class NativeViT:
         """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
         With ``resid_in`` ([B, T, d_model]) the forward is RESUMED at block ``first_block`` from that residual
         (``images`` is ignored, names of earlier stages must not be requested).  Positions inside a block
-        (``entry_stage`` / ``exit_stage``, pv_vit_forward_stage; PV_STAGE_*): 0 block entry, 1 q / k / v ready, 2 attention scores,
-        3 pattern, 4 z ready, 5 after the attention half (``entry_mid`` / ``exit_mid`` = 5), 6 mlp post ready.  A segment that exits
-        at a stage runs block ``n_blocks`` up to it; one that enters at a stage gets the residual stream the rest of the block adds
-        to in ``resid_in`` and the (hook-edited) activations of the stage in ``act_in``: (q, k, v) | (scores, v) | (pattern, v) |
-        (z,) | (post,).  Returns (model_out, {name: tensor}); for an exit inside the attention half or the MLP model_out is the
-        stage's (first) activation."""
-        entry_stage = 5 if entry_mid else int(entry_stage)
-        exit_stage = 5 if exit_mid else int(exit_stage)
+        (``entry_stage`` / ``exit_stage``, pv_vit_forward_stage; PV_STAGE_*): 0 block entry, 1 ln1 taken, 2 q / k / v ready,
+        3 attention scores, 4 pattern, 5 z ready, 6 after the attention half (``entry_mid`` / ``exit_mid`` = 6), 7 ln2 taken,
+        8 mlp pre ready, 9 mlp post ready.  A segment that exits at a stage runs block ``n_blocks`` up to it; one that enters at a
+        stage gets the residual stream the rest of the block adds to in ``resid_in`` and the (hook-edited) activations of the stage
+        in ``act_in``: (normalized fp32,) | (q, k, v) | (scores, v) | (pattern, v) | (z,) | (normalized fp32,) | (pre,) | (post,).
+        Returns (model_out, {name: tensor}); for an exit inside the attention half or the MLP model_out is the stage's (first)
+        activation."""
+        entry_stage = 6 if entry_mid else int(entry_stage)
+        exit_stage = 6 if exit_mid else int(exit_stage)
         cfg = self.cfg
         T = self.n_tokens
         if resid_in is not None:
@@ -258,18 +259,21 @@ class NativeViT:
         specs: Dict[str, TapSpec] = {n: tap_spec(n, cfg, B, T) for n in names}
         out_name = None
         if not run_head:
-            out_name = {0: None, 1: f"blocks.{n_blocks}.attn.hook_q", 2: f"blocks.{n_blocks}.attn.hook_attn_scores",
-                        3: f"blocks.{n_blocks}.attn.hook_pattern", 4: f"blocks.{n_blocks}.attn.hook_z",
-                        5: f"blocks.{n_blocks}.hook_resid_mid", 6: f"blocks.{n_blocks}.mlp.hook_post"}[exit_stage] \
+            out_name = {0: None, 1: f"blocks.{n_blocks}.ln1.hook_normalized", 2: f"blocks.{n_blocks}.attn.hook_q",
+                        3: f"blocks.{n_blocks}.attn.hook_attn_scores", 4: f"blocks.{n_blocks}.attn.hook_pattern",
+                        5: f"blocks.{n_blocks}.attn.hook_z", 6: f"blocks.{n_blocks}.hook_resid_mid",
+                        7: f"blocks.{n_blocks}.ln2.hook_normalized", 8: f"blocks.{n_blocks}.mlp.hook_pre",
+                        9: f"blocks.{n_blocks}.mlp.hook_post"}[exit_stage] \
                 or final_residual_name(cfg, n_blocks)
             if out_name not in specs:
                 specs[out_name] = tap_spec(out_name, cfg, B, T)
         acts = []
+        act_dtype = torch.float32 if entry_stage in (1, 7) else cfg.dtype      # (the LayerNorm points carry fp32 in either mode)
         for t in act_in:
             if t.device != self.device:
                 raise N.NativeError(f"activation on {t.device}, model on {self.device}")
-            acts.append(t.to(cfg.dtype).contiguous())
-        want_acts = {0: 0, 1: 3, 2: 2, 3: 2, 4: 1, 5: 0, 6: 1}[entry_stage]
+            acts.append(t.to(act_dtype).contiguous())
+        want_acts = {0: 0, 1: 1, 2: 3, 3: 2, 4: 2, 5: 1, 6: 0, 7: 1, 8: 1, 9: 1}[entry_stage]
         if len(acts) != want_acts:
             raise ValueError(f"entry_stage {entry_stage} takes {want_acts} activation tensors, got {len(acts)}")
         # unique buffers -> slab offsets

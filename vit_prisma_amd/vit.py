@@ -453,8 +453,8 @@ class HookedViT(HookedRootModule):
             return "autograd is recording (use torch.no_grad() / requires_grad_(False))"
         if self._boundary_hooks() is None:
             return ("a hook is registered on a point the plan cannot be split at (supported: blocks.L.hook_resid_pre / hook_attn_out / "
-                    "hook_resid_mid / hook_mlp_out / hook_resid_post / attn.hook_q / attn.hook_k / attn.hook_v / attn.hook_attn_scores / "
-                    "attn.hook_pattern / attn.hook_z / mlp.hook_post)")
+                    "hook_resid_mid / hook_mlp_out / hook_resid_post / ln1.* / attn.hook_q / attn.hook_k / attn.hook_v / "
+                    "attn.hook_attn_scores / attn.hook_pattern / attn.hook_z / ln2.* / mlp.hook_pre / mlp.hook_post)")
         for mod in self._plain_modules:                    # (valid: the tree is the one this list was built from)
             if mod._forward_hooks or mod._forward_pre_hooks:
                 return "nn.Module hooks registered"
@@ -462,21 +462,26 @@ class HookedViT(HookedRootModule):
 
     # HookPoints a forward hook may sit on while the call stays on the native plan: the plan is split there
     _BOUNDARY_RE = re.compile(r"blocks\.(\d+)\.(hook_resid_pre|hook_attn_out|hook_resid_mid|hook_mlp_out|hook_resid_post|"
-                              r"attn\.hook_q|attn\.hook_k|attn\.hook_v|attn\.hook_attn_scores|attn\.hook_pattern|attn\.hook_z|mlp\.hook_post)$")
-    # split positions per block (= PV_STAGE_*): 0 entry | 1 q, k, v ready | 2 scores | 3 pattern | 4 z ready | 5 after the attention
-    # half | 6 mlp post ready
-    _NPOS = 7
-    _KIND_POS = {"hook_resid_pre": ("pre", 0), "attn.hook_q": ("q", 1), "attn.hook_k": ("k", 1), "attn.hook_v": ("v", 1),
-                 "attn.hook_attn_scores": ("scores", 2), "attn.hook_pattern": ("pattern", 3),
-                 "attn.hook_z": ("z", 4), "hook_attn_out": ("attn", 5), "hook_resid_mid": ("mid", 5),
-                 "mlp.hook_post": ("mlppost", 6), "hook_mlp_out": ("mlp", 7), "hook_resid_post": ("post", 7)}
+                              r"ln1\.hook_scale|ln1\.hook_normalized|ln2\.hook_scale|ln2\.hook_normalized|"
+                              r"attn\.hook_q|attn\.hook_k|attn\.hook_v|attn\.hook_attn_scores|attn\.hook_pattern|attn\.hook_z|"
+                              r"mlp\.hook_pre|mlp\.hook_post)$")
+    # split positions per block (= PV_STAGE_*): 0 entry | 1 ln1 taken | 2 q, k, v ready | 3 scores | 4 pattern | 5 z ready | 6 after the
+    # attention half | 7 ln2 taken | 8 mlp pre ready | 9 mlp post ready
+    _NPOS = 10
+    _KIND_POS = {"hook_resid_pre": ("pre", 0), "ln1.hook_scale": ("ln1s", 1), "ln1.hook_normalized": ("ln1n", 1),
+                 "attn.hook_q": ("q", 2), "attn.hook_k": ("k", 2), "attn.hook_v": ("v", 2),
+                 "attn.hook_attn_scores": ("scores", 3), "attn.hook_pattern": ("pattern", 4),
+                 "attn.hook_z": ("z", 5), "hook_attn_out": ("attn", 6), "hook_resid_mid": ("mid", 6),
+                 "ln2.hook_scale": ("ln2s", 7), "ln2.hook_normalized": ("ln2n", 7), "mlp.hook_pre": ("mlppre", 8),
+                 "mlp.hook_post": ("mlppost", 9), "hook_mlp_out": ("mlp", 10), "hook_resid_post": ("post", 10)}
 
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
         """{position: {kind: HookPoint}} for every HookPoint that carries a forward hook, or None when some hook (a
         forward hook elsewhere, any backward hook) cannot be served by splitting the native plan.  Positions count
-        _NPOS = 7 per block: 7b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
-        fire there, in that order), 7b+1 = its q, k, v ("q", "k", "v"), 7b+2 = its attention scores, 7b+3 = its pattern, 7b+4 =
-        its z, 7b+5 = after its attention half ("attn", then "mid"), 7b+6 = its MLP activation ("mlppost")."""
+        _NPOS = 10 per block: 10b = the residual stream entering block b (kinds "mlp", "post" of block b-1 and "pre" of block b
+        fire there, in that order), +1 = its ln1 ("ln1s", then "ln1n"), +2 = its q, k, v, +3 = its attention scores, +4 = its
+        pattern, +5 = its z, +6 = after its attention half ("attn", then "mid"), +7 = its ln2, +8 = its MLP pre-activation,
+        +9 = its MLP activation."""
         out: Dict[int, Dict[str, HookPoint]] = {}
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -487,6 +492,8 @@ class HookedViT(HookedRootModule):
             if m is None:
                 return None
             kind, off = self._KIND_POS[m.group(2)]
+            if kind.startswith("ln") and self.cfg.normalization_type not in ("LN", "LNPre"):
+                return None
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
                 return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
@@ -558,33 +565,46 @@ class HookedViT(HookedRootModule):
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
                               remove_batch_dim=remove_batch_dim)
         # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
-        # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 + q, k, v | 1 scores | 2 softmax |
-        # 3 pattern v | 4 O-projection + residual | 5 ln2 + MLP up to the activation | 6 MLP output + residual.
+        # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 | 1 q, k, v | 2 scores | 3 softmax |
+        # 4 pattern v | 5 O-projection + residual | 6 ln2 | 7 MLP up to the pre-activation | 8 activation | 9 MLP output + residual.
         wanted = set(names)
         cache: Dict[str, torch.Tensor] = {}
-        ST_O, ST_MLP = 4, 6                                      # stages of the O-projection / the MLP output
+        ST_QKV, ST_O, ST_MLP = 1, 5, 9                          # stages of q / k / v, the O-projection, the MLP output
 
         def pos_of(name: str) -> int:
             """the stage that produces `name` (-1: embedding stage, NP * n_layers: final stage)"""
             if name.startswith("blocks."):
                 _, l, rest = name.split(".", 2)
-                if rest == "hook_resid_pre" or rest.startswith("ln1.") or rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
+                if rest == "hook_resid_pre" or rest.startswith("ln1."):
                     st = 0
+                elif rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
+                    st = ST_QKV
                 elif rest == "attn.hook_attn_scores":
-                    st = 1
-                elif rest == "attn.hook_pattern":
                     st = 2
-                elif rest.startswith("attn."):
+                elif rest == "attn.hook_pattern":
                     st = 3
+                elif rest.startswith("attn."):
+                    st = 4
                 elif rest in ("hook_attn_out", "hook_resid_mid"):
                     st = ST_O
-                elif rest.startswith(("ln2.", "mlp.")):
-                    st = 5
+                elif rest.startswith("ln2."):
+                    st = 6
+                elif rest == "mlp.hook_pre":
+                    st = 7
+                elif rest.startswith("mlp."):
+                    st = 8
                 else:
                     st = ST_MLP
                 return NP * int(l) + st
             return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
                 else NP * cfg.n_layers
+
+        def renormalize(ln_mod: nn.Module, x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+            """hook_normalized's tensor from an edited hook_scale, as the module computes it (layer_norm.py:88-93, :38-45)"""
+            xc = x.to(torch.float32) if cfg.dtype not in (torch.float32, torch.float64) else x
+            xc = xc - xc.mean(-1, keepdim=True)
+            out = xc / scale
+            return out * ln_mod.w + ln_mod.b if isinstance(ln_mod, LayerNorm) else out
 
         p0, resid, acts, out = 0, None, (), None
         for q in bounds + [None]:
@@ -605,25 +625,33 @@ class HookedViT(HookedRootModule):
                 if not last:
                     pre_name, mid_name = f"blocks.{b1}.hook_resid_pre", f"blocks.{b1}.hook_resid_mid"
                     v_name = f"blocks.{b1}.attn.hook_v"
+                    pre_f = [pre_name] if pre_inside else []
+                    mid_f = [mid_name] if p0 <= NP * b1 + ST_O else []           # resid_mid is produced inside this segment
                     if s1 == 0:
                         forced = [f"blocks.{blk}.hook_resid_post"]
                         if "mlp" in hooks:
                             forced += [f"blocks.{blk}.hook_mlp_out"] + ([f"blocks.{blk}.hook_resid_mid"] if p0 <= NP * blk + ST_O else [])
                     elif s1 == 1:
-                        forced = [f"blocks.{b1}.attn.hook_{t}" for t in "qkv"] + ([pre_name] if pre_inside else [])
-                    elif s1 in (2, 3):
+                        forced = [f"blocks.{b1}.ln1.hook_scale", f"blocks.{b1}.ln1.hook_normalized"] + pre_f
+                    elif s1 == 2:
+                        forced = [f"blocks.{b1}.attn.hook_{t}" for t in "qkv"] + pre_f
+                    elif s1 in (3, 4):
                         # the resumed attention core reads v next to the edited scores / pattern: tapped when this segment
                         # computes it, carried from the previous segment's activations otherwise
-                        forced = [f"blocks.{b1}.attn." + ("hook_attn_scores" if s1 == 2 else "hook_pattern")]
-                        forced += ([v_name] if p0 <= NP * b1 else []) + ([pre_name] if pre_inside else [])
-                    elif s1 == 4:
-                        forced = [f"blocks.{b1}.attn.hook_z"] + ([pre_name] if pre_inside else [])
+                        forced = [f"blocks.{b1}.attn." + ("hook_attn_scores" if s1 == 3 else "hook_pattern")]
+                        forced += ([v_name] if p0 <= NP * b1 + ST_QKV else []) + pre_f
                     elif s1 == 5:
+                        forced = [f"blocks.{b1}.attn.hook_z"] + pre_f
+                    elif s1 == 6:
                         forced = [mid_name]
                         if "attn" in hooks:
-                            forced += [f"blocks.{b1}.hook_attn_out"] + ([pre_name] if pre_inside else [])
+                            forced += [f"blocks.{b1}.hook_attn_out"] + pre_f
+                    elif s1 == 7:
+                        forced = [f"blocks.{b1}.ln2.hook_scale", f"blocks.{b1}.ln2.hook_normalized"] + mid_f
+                    elif s1 == 8:
+                        forced = [f"blocks.{b1}.mlp.hook_pre"] + mid_f
                     else:
-                        forced = [f"blocks.{b1}.mlp.hook_post"] + ([mid_name] if p0 <= NP * b1 + ST_O else [])
+                        forced = [f"blocks.{b1}.mlp.hook_post"] + mid_f
                 req = seg + [n for n in forced if n not in seg]
                 out, c = nv.forward(self, x if p0 == 0 else None, req, b1, last and run_head, first_block=p0 // NP,
                                     resid_in=resid if p0 > 0 else None, entry_stage=p0 % NP, exit_stage=s1, act_in=acts)
@@ -631,28 +659,48 @@ class HookedViT(HookedRootModule):
             if last:
                 break
             prev_acts, acts = acts, ()
-            if s1 in (1, 2, 3, 4, 6):
+            if s1 in (1, 7):
+                # a LayerNorm of block b1: hook_scale, then hook_normalized recomputed from the (edited) scale as the module does,
+                # then hook_normalized's own hooks; the block resumes from the fp32 tensor they leave (rounded to the storage
+                # dtype by the kernel, layer_norm.py:93)
+                which = "ln1" if s1 == 1 else "ln2"
+                carried = f"blocks.{b1}.hook_resid_pre" if s1 == 1 else f"blocks.{b1}.hook_resid_mid"
+                resid = c.get(carried, seg_in)
+                s_name, n_name = f"blocks.{b1}.{which}.hook_scale", f"blocks.{b1}.{which}.hook_normalized"
+                scale, norm = c[s_name], c[n_name]
+                if which + "s" in hooks:
+                    scale = hooks[which + "s"](scale)
+                    norm = renormalize(getattr(self.blocks[b1], which), resid, scale)
+                if which + "n" in hooks:
+                    norm = hooks[which + "n"](norm)
+                if s_name in wanted:
+                    cache[s_name] = scale
+                if n_name in wanted:
+                    cache[n_name] = norm
+                acts = (norm,)
+            elif s1 in (2, 3, 4, 5, 8, 9):
                 # inside the attention half / the MLP: the hooks see the stage's activations (attention.py:135-152, 186-281;
                 # mlp.py:65-80), the rest of the block resumes from what they return; the residual stream the block adds to
                 # is carried along untouched
-                kinds = {1: ("q", "k", "v"), 2: ("scores",), 3: ("pattern",), 4: ("z",), 6: ("mlppost",)}[s1]
+                kinds = {2: ("q", "k", "v"), 3: ("scores",), 4: ("pattern",), 5: ("z",), 8: ("mlppre",), 9: ("mlppost",)}[s1]
                 vals = []
                 for kind in kinds:
                     nm = f"blocks.{b1}." + {"q": "attn.hook_q", "k": "attn.hook_k", "v": "attn.hook_v", "scores": "attn.hook_attn_scores",
-                                            "pattern": "attn.hook_pattern", "z": "attn.hook_z", "mlppost": "mlp.hook_post"}[kind]
+                                            "pattern": "attn.hook_pattern", "z": "attn.hook_z", "mlppre": "mlp.hook_pre",
+                                            "mlppost": "mlp.hook_post"}[kind]
                     t = c[nm]
                     if kind in hooks:
                         t = hooks[kind](t)
                     if nm in wanted:
                         cache[nm] = t
                     vals.append(t)
-                if s1 in (2, 3):
+                if s1 in (3, 4):
                     # v for the resumed core: this segment's tap, or what the previous position handed on ((q, k, v) | (scores, v))
                     vals.append(c[v_name] if v_name in c else prev_acts[-1])
                 acts = tuple(vals)
-                carried = f"blocks.{b1}.hook_resid_mid" if s1 == 6 else f"blocks.{b1}.hook_resid_pre"
+                carried = f"blocks.{b1}.hook_resid_mid" if s1 >= 8 else f"blocks.{b1}.hook_resid_pre"
                 resid = c.get(carried, seg_in)
-            elif s1 == 5:
+            elif s1 == 6:
                 # after block b1's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
                 # kernel's rounding (transformer_block.py:117-124), then hook_resid_mid
                 resid = c[f"blocks.{b1}.hook_resid_mid"]
