@@ -192,3 +192,36 @@ def test_trainer_feature_parallel_world2_equals_single_process_oracle():
             assert abs(l - rl) <= 1e-5 * abs(rl) and abs(l0 - rl0) < 1e-6
         assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
         assert frac == STEPS * N
+
+
+def test_auto_mode_takes_feature_parallel_only_where_its_kernels_can_run():
+    """use_feature_parallel(None): feature parallel needs world <= 8 (pv_sae_tp_merge), a shard of at least k features and a whole
+    number of 4-feature groups per shard; everywhere else the token-sharded step (no such limits) must be chosen, and
+    use_feature_parallel(True) keeps asking for the feature-parallel one."""
+    from vit_prisma_amd.sae.config import VisionModelSAERunnerConfig
+    from vit_prisma_amd.sae.trainer import VisionSAETrainer
+
+    def trainer(d_in, exp, k, world):
+        cfg = VisionModelSAERunnerConfig(hook_point_layer=1, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp,
+                                         activation_fn_str="topk", activation_fn_kwargs={"k": k}, _device="cpu", log_to_wandb=False,
+                                         n_checkpoints=0)
+        tr = VisionSAETrainer(cfg, model=None, dataset=None)
+        tr.world = world
+        return tr
+
+    tr = trainer(64, 8, 8, 2)
+    assert tr._use_tp(tr.sparse_coder)                                       # 512 features over 2 ranks: fine
+    assert trainer(64, 8, 8, 8)._use_tp(trainer(64, 8, 8, 8).sparse_coder)
+    for d_in, exp, k, world in ((64, 8, 8, 16),        # two nodes: the merge kernel ranks the candidates of at most 8 ranks
+                                (64, 1, 32, 4),         # a shard of 16 features cannot hold k = 32 candidates
+                                (24, 1, 4, 2),          # a 12-feature shard ... is fine (multiple of 4)
+                                (28, 1, 2, 2),          # a 14-feature shard is not a whole number of 4-feature groups
+                                (64, 8, 8, 3)):         # 512 does not divide by 3
+        tr = trainer(d_in, exp, k, world)
+        want = (d_in, exp, k, world) == (24, 1, 4, 2)
+        assert tr._use_tp(tr.sparse_coder) == want, (d_in, exp, k, world)
+        tr.use_feature_parallel(True)
+        assert tr._use_tp(tr.sparse_coder)                                   # forced: the hard error stays with the kernels
+        tr.use_feature_parallel(False)
+        assert not tr._use_tp(tr.sparse_coder)
+    assert not trainer(64, 8, 8, 1)._use_tp(trainer(64, 8, 8, 1).sparse_coder)

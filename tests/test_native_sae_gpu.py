@@ -247,6 +247,80 @@ def test_native_data_parallel_world2_equals_single_process_oracle():
     assert leg_tps > 0 and e2e_tps > 0
 
 
+def _rccl_world1_worker(port, q, mode):
+    """ONE rank in a process group on the nccl backend (= RCCL on ROCm): the trainer is told to take its multi-rank code paths
+    (force_distributed_paths), so every collective of the 8-GPU job -- the in-place reduce_scatter_tensor of the gradient rows,
+    the asynchronous all_gather_into_tensor of the updated parameter rows, the packed small buckets, the feature-parallel step's
+    all-gathers / all-reduces, the dense step's flat-gradient all-reduce -- is issued on RCCL with the tensors it gets there."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dev = torch.device("cuda:0")
+    d_in, d_sae, k, N = 768, 8192, 32, 1024
+    relu = mode == "relu_dp"
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in,
+        activation_fn_str="relu" if relu else "topk", activation_fn_kwargs={} if relu else {"k": k}, l1_coefficient=3e-3,
+        normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda",
+        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0)
+    sae = StandardSparseAutoencoder(cfg)
+    with torch.no_grad():
+        for n, v in synth_sae_state(d_in, d_sae, 0).items():
+            getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True).force_distributed_paths(True)
+    tr.use_feature_parallel(mode == "topk_tp")
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    out = []
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(N, d_in, seed=10 + t)).to(dev)[:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t, n_training_tokens=t * N)
+        assert tr.last_step_native
+        out.append((float(loss), float(l0)))
+    took = {"topk_dp": tr._engine is not None and tr._fp is None and not tr._engine.lazy_w_enc,
+            "topk_tp": tr._fp is not None, "relu_dp": tr._engine is not None}[mode]
+    tr.sync_parameters()
+    q.put((out, {n: getattr(sae, n).detach().cpu().numpy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}, act.cpu().numpy(), took,
+           dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["topk_dp", "topk_tp", "relu_dp"])
+def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
+    """the trainer's data-parallel step (sharded optimizer), its feature-parallel step and the dense step's
+    data-parallel form, each through torch.distributed on the NCCL backend (RCCL) with a world of one rank, against the
+    single-process oracle after three steps (768 -> 8192, 1024 tokens).  What a one-GPU box can execute of the 8-GPU job: the same
+    calls on the same backend; the arithmetic of more than one rank is covered by the gloo tests above and on CPU."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q, mode))
+    p.start()
+    out, params, act, took, backend = q.get(timeout=800)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and took and backend == "nccl"
+    d_in, d_sae, k, N = 768, 8192, 32, 1024
+    relu = mode == "relu_dp"
+    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    for t in range(3):
+        ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=10 + t), None if relu else k, lr=1e-3, step=t + 1,
+                           l1_coefficient=3e-3 if relu else 0.0)
+        assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
+    for n in P:
+        assert rel_fro(params[n], P[n]) < TOL, n
+    assert np.abs(act - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
+
+
 # ---------------------------------------------------------------------------------------------------
 # the filtered encoder (sae_enc.hip): fp16 MFMA filter + exact fp32 re-scoring must be indistinguishable from the
 # exact fp32 GEMM + streaming top-k it replaces
@@ -635,8 +709,13 @@ def test_feature_parallel_simulated_world_equals_single_process_oracle(world, d_
 # ---------------------------------------------------------------------------------------------------
 # the dense fused step: ReLU + L1 SAEs (pv_sae_dense_step, csrc/sae_dense.hip)
 # ---------------------------------------------------------------------------------------------------
+# (the last four: the shape bench.py times this step at -- 768 -> 24576, 4096 tokens -- and the x64 SAEs every published CLIP-B/32 SAE of
+# the reference is, docs/sae_table.md:12-36 -- 768 -> 49152)
+@pytest.mark.timeout(1200)
 @pytest.mark.parametrize("d_in,d_sae,n,ln,ghost", [(64, 512, 256, True, False), (136, 1056, 300, False, False), (768, 8192, 1024, True, False),
-                                                   (64, 512, 256, True, True), (136, 1056, 300, False, True), (768, 8192, 1024, True, True)])
+                                                   (64, 512, 256, True, True), (136, 1056, 300, False, True), (768, 8192, 1024, True, True),
+                                                   (768, 24576, 4096, True, False), (768, 24576, 4096, True, True),
+                                                   (768, 49152, 1024, True, False), (768, 49152, 1024, True, True)])
 def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
     """pv_sae_dense_step + grad_sqnorm + apply against the ReLU + L1 form of the oracle (pinned to the reference fixtures by
     tests/test_oracle_sae_vs_golden.py): losses, l0, every gradient tensor, parameters, statistics; ragged shapes (partial
@@ -700,6 +779,44 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
             assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < gtol, name
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
         assert np.abs(eng.n_fwd_since_fired.cpu().numpy() - stats["n_fwd_since_fired"]).sum() <= 2
+
+
+@pytest.mark.parametrize("kind", ["relu", "gated"])
+def test_dense_steps_see_an_outside_edit_of_w_enc(kind):
+    """dense_step / gated_step read the encoder through its transposed master W_encT: an in-place edit of the W_enc parameter between
+    two steps (load_state_dict, an optimizer of the caller, resampling: the version counter moves) must reach the kernels, and the
+    following apply must not write the stale copy back over it."""
+    d_in, d_sae, n, l1c = 64, 512, 256, 3e-3
+    P, opt, stats, T = fresh(d_in, d_sae)
+    kw = {}
+    if kind == "gated":
+        rs = np.random.RandomState(9)
+        kw["gated"] = {m: torch.from_numpy((rs.standard_normal(d_sae) * s_).astype(np.float32)).cuda()
+                       for m, s_ in (("b_gate", 0.05), ("r_mag", 0.2), ("b_mag", 0.05))}
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=0)).cuda()
+
+    def run(eng):
+        (eng.gated_step if kind == "gated" else eng.dense_step)(x, l1c, want_out=True)
+        torch.cuda.synchronize()
+        return eng.sae_out[:n].clone(), eng.scalars.clone()
+
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, True, n, **kw)
+    out0, _ = run(eng)
+    with torch.no_grad():
+        T["W_enc"].mul_(0.5)                                       # the outside edit (bumps the version counter)
+    out1, sc1 = run(eng)
+    assert not torch.equal(out0, out1)
+    # a fresh engine over the edited parameters is the truth
+    T2 = {m: v.clone() for m, v in T.items()}
+    kw2 = {"gated": {m: v.clone() for m, v in kw["gated"].items()}} if kind == "gated" else {}
+    ref = NativeSAE(T2["W_enc"], T2["W_dec"], T2["b_enc"], T2["b_dec"], 1, True, n, **kw2)
+    out_ref, sc_ref = run(ref)
+    assert torch.equal(out1, out_ref) and torch.equal(sc1[:3], sc_ref[:3])
+    for e in (eng, ref):
+        e.grad_sqnorm()
+        e.apply(1e-3, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.W_encT, ref.W_encT) and torch.equal(T["W_enc"], T2["W_enc"])
 
 
 def grad_norm_of(g):
@@ -797,10 +914,14 @@ def fresh_transcoder(d_in, d_sae, skip):
     return P, opt, stats, T
 
 
+@pytest.mark.timeout(1200)
 @pytest.mark.parametrize("d_in,d_sae,k,n,ln,skip", [(64, 512, 8, 256, True, True), (136, 1056, 16, 300, False, True),
                                                     (768, 8192, 32, 1024, True, True), (768, 8192, 32, 1024, True, False),
                                                     (64, 512, None, 256, True, True), (136, 1056, None, 300, False, False),
-                                                    (768, 8192, None, 1024, True, True)])
+                                                    (768, 8192, None, 1024, True, True),
+                                                    # the benchmarked shape (768 -> 24576, 4096 tokens) and the published x64 width, both steps
+                                                    (768, 24576, 32, 4096, True, True), (768, 24576, None, 4096, True, True),
+                                                    (768, 49152, 32, 1024, True, True), (768, 49152, None, 1024, True, False)])
 def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
     """A Transcoder (target activation, b_dec_out, optional W_skip) on the top-k step (k given) and on the dense ReLU + L1 step
     (k = None) against the oracle's transcoder form (pinned to the reference's own Transcoder run by
@@ -914,7 +1035,9 @@ def test_transcoder_trainer_runs_natively_and_matches_the_reference_fixture():
 # ---------------------------------------------------------------------------------------------------
 # Gated SAE (sae.py:648-792; pv_sae_gated_step)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d_in,d_sae,n,ln", [(64, 512, 256, True), (136, 1056, 300, False), (768, 8192, 1024, True)])
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("d_in,d_sae,n,ln", [(64, 512, 256, True), (136, 1056, 300, False), (768, 8192, 1024, True),
+                                             (768, 24576, 4096, True), (768, 49152, 1024, True)])      # (the benchmarked and the published shapes)
 def test_gated_step_vs_oracle(d_in, d_sae, n, ln):
     """pv_sae_gated_step + grad_sqnorm + apply against the oracle's gated form (pinned to the reference's own
     GatedSparseAutoencoder run by tests/test_oracle_sae_vs_golden.py): the four losses, l0, every gradient tensor, the clip norm,
@@ -1066,10 +1189,12 @@ def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():
     images = torch.from_numpy(synth_images(arch, 32, 3))
     ds = [(images[i], 0) for i in range(32)]
 
-    def serve(overlap: bool):
+    def serve(overlap: bool, legacy: bool = False):
         torch.manual_seed(1234)
         store = VisionActivationsStore(cfg, vit, ds, create_dataloader=False)
         store.overlap_harvest = overlap                         # (set before the first refill is scheduled)
+        if legacy:                                              # one forward per store batch + the reference's buf[...] = acts copy
+            store.HARVEST_IMAGES, store.direct_tap = 0, False
         store.storage_buffer = store.get_buffer(cfg.n_batches_in_buffer)
         store.dataloader = store.get_data_loader()
         out = []
@@ -1087,6 +1212,52 @@ def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():
     assert len(sync_batches) == len(over_batches)
     for a, b in zip(sync_batches, over_batches):
         assert a.shape == b.shape and torch.equal(a, b)
+    # store batches coalesced into one forward (4-image store batches -> one 16-image forward per refill here) and the harvest
+    # kernel storing straight into the buffer slice: the same bits as one forward per store batch + the copy
+    n0 = vit._native.n_forward
+    legacy_batches, _ = serve(False, legacy=True)
+    n_legacy = vit._native.n_forward - n0
+    n0 = vit._native.n_forward
+    again, _ = serve(False)
+    assert n_legacy >= 2 * (vit._native.n_forward - n0) > 0
+    for a, b in zip(sync_batches, legacy_batches):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("vit_dtype", [torch.float32, torch.bfloat16])
+def test_store_taps_straight_into_its_buffer(vit_dtype):
+    """VisionActivationsStore._harvest_raw: the kernel that produces blocks.L.hook_resid_post writes it into the store's own
+    buffer slice (pv_tap.dst = the slice: "caching costs one extra HBM store"), several store batches per forward -- and the rows
+    are those of a plain run_with_cache on the same images, widened to cfg.dtype exactly as the reference's assignment
+    (activations_store.py:326-355) would."""
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=64, expansion_factor=8, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", b_dec_init_method="mean",
+        train_batch_size=64, lr=1e-3, max_grad_norm=1.0, _device="cuda", log_to_wandb=False,
+        lr_scheduler_name="constant", n_checkpoints=0, context_size=17, store_batch_size=4, n_batches_in_buffer=4)
+    arch = ARCHS["tiny"]
+    vit = HookedViT(HookedViTConfig(**arch, dtype=vit_dtype, device="cuda"))
+    vit.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()})
+    vit = vit.to(vit_dtype).cuda().eval()
+    images = torch.from_numpy(synth_images(arch, 32, 3)).to(vit_dtype)
+    ds = [(images[i], 0) for i in range(32)]
+    store = VisionActivationsStore(cfg, vit, ds, create_dataloader=False)
+    store.image_dataloader_iter = iter([images[i:i + 4].cuda() for i in range(0, 32, 4)])        # (fixed order)
+    buf, _ = store._harvest_raw(4)
+    torch.cuda.synchronize()
+    assert vit.last_run_native and buf.dtype == vit_dtype and tuple(buf.shape) == (16, 17, 1, 64)
+    with torch.no_grad():
+        _, cache = vit.run_with_cache(images[:16].cuda(), names_filter=[cfg.hook_point], stop_at_layer=2)
+    assert torch.equal(buf[:, :, 0, :], cache[cfg.hook_point])
+    # the arena was not involved: the forward's only tap went to the buffer
+    assert buf.data_ptr() != cache[cfg.hook_point].data_ptr()
+    torch.manual_seed(0)
+    store._prefetched = None
+    store.image_dataloader_iter = iter([images[i:i + 4].cuda() for i in range(0, 32, 4)])
+    rows = store.get_buffer(4)
+    torch.manual_seed(0)
+    perm = torch.randperm(16 * 17, device="cuda")
+    assert rows.dtype == cfg.dtype and torch.equal(rows, cache[cfg.hook_point].reshape(-1, 1, 64)[perm].to(cfg.dtype))
 
 
 def test_checkpoint_mid_run_and_lazy_w_enc_match_the_torch_path(tmp_path):

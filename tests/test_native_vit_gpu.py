@@ -38,6 +38,8 @@ FP32_TOL = 1e-4
 # torch's norm, the test with numpy's.
 BF16_SLACK = 1.0 + 1e-4
 SCALE_SLACK_SMALL, SCALE_SLACK_BENCH = 1.15, 1.05
+# intra-block hooks on the tiny models in bf16: HIP error vs the fp32 run, as a multiple of the PyTorch bf16 path's own error
+INTRA_BLOCK_RATIO = 1.5
 
 
 def bf16_limit(key: str, budget_rel_fro: float, scale_slack: float = SCALE_SLACK_SMALL) -> float:
@@ -384,7 +386,6 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
     ref = _pytorch_twin(model)
     x = torch.from_numpy(synth_images(arch, 3, 5)).cuda().to(dtype)
     nl = arch["n_layers"]
-    base_tol = FP32_TOL if dtype == torch.float32 else 3e-2
 
     def half(t, hook):
         return t * 0.5
@@ -439,15 +440,36 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
         [(lambda n: n.endswith(("attn.hook_q", "attn.hook_z", "hook_resid_mid", "mlp.hook_post", "hook_resid_post")), half)],
         [(f"blocks.{nl - 1}.mlp.hook_post", half), (f"blocks.{nl - 1}.hook_mlp_out", kill_head_1 if False else half)],
     ]
+    # bf16: no hand-set tolerance.  The error budget of every tensor is what the PyTorch hook path of the SAME model in bf16 loses
+    # against its own fp32 run under the same hooks; the HIP path's distance to that fp32 run is held to INTRA_BLOCK_RATIO x the
+    # budget (tiny tensors: a few hundred elements per key, so which way single roundings fall moves the ratio; the B/32-size
+    # statement against the reference's own budget is test_mutating_hooks_on_b32_vs_reference_fixture...).  A budget of exactly
+    # zero (a frozen scale, a zeroed tensor) demands equality.
+    ref32 = x32 = None
+    if dtype == torch.bfloat16:
+        m32, _, _ = build(arch_name, torch.float32)
+        ref32, x32 = _pytorch_twin(m32), x.float()
+    worst = [0.0, None]
+
+    def held(a, b, b32, tag):
+        if dtype == torch.float32:
+            assert rel_fro(a, b) < FP32_TOL, tag
+            return
+        budget, err = rel_fro(b, b32), rel_fro(a, b32)
+        if budget == 0.0:
+            assert np.array_equal(a, b), tag
+            return
+        if err / budget > worst[0]:
+            worst[0], worst[1] = err / budget, tag
+        assert err <= INTRA_BLOCK_RATIO * budget, (tag, err, budget)
+
     with torch.no_grad():
         for ci, hooks in enumerate(cases):
-            # (bf16: the four LayerNorm cases rescale the stream -- a constant scale of 1.25 instead of ~1 -- and the two bf16
-            # pipelines, which round at different points by design, drift apart a little more behind them)
-            tol = base_tol * (2.0 if (dtype == torch.bfloat16 and ci < 4) else 1.0)
             want = ref.run_with_hooks(x.clone(), fwd_hooks=hooks)
             got = model.run_with_hooks(x.clone(), fwd_hooks=hooks)
             assert model.last_run_native, model.native_fallback_reason
-            assert rel_fro(got.float().cpu().numpy(), want.float().cpu().numpy()) < tol
+            w32 = ref32.run_with_hooks(x32.clone(), fwd_hooks=hooks).cpu().numpy() if ref32 is not None else None
+            held(got.float().cpu().numpy(), want.float().cpu().numpy(), w32, (ci, "out"))
             assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
             for kw in ({}, {"names_filter": lambda n: "resid" in n or n.endswith(("hook_z", "hook_pattern", "mlp.hook_post"))},
                        {"names_filter": lambda n: n.endswith(("hook_attn_scores", "hook_v", "hook_attn_out"))}, {"stop_at_layer": nl - 1}):
@@ -455,13 +477,24 @@ def test_hooks_inside_the_attention_half_and_the_mlp_run_on_the_split_native_pla
                 g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
                 assert model.last_run_native, model.native_fallback_reason
                 assert list(g_cache.keys()) == list(w_cache.keys())
-                assert rel_fro(g_out.float().cpu().numpy(), w_out.float().cpu().numpy()) < tol
+                f_out = f_cache = None
+                if ref32 is not None:
+                    f_out, f_cache = ref32.run_with_cache(x32.clone(), fwd_hooks=hooks, **kw)
+                    f_out = f_out.cpu().numpy()
+                held(g_out.float().cpu().numpy(), w_out.float().cpu().numpy(), f_out, (ci, "out", sorted(kw)))
                 for k in w_cache.keys():
                     a, b = g_cache[k].float().cpu().numpy(), w_cache[k].float().cpu().numpy()
                     # (masked / poisoned scores: -inf and NaN must sit in the same places; the norm is taken over the rest)
                     fin = np.isfinite(b)
                     assert a.shape == b.shape and np.array_equal(np.isfinite(a), fin) and np.array_equal(np.isnan(a), np.isnan(b)), (k, kw)
-                    assert rel_fro(np.where(fin, a, 0.0), np.where(fin, b, 0.0)) < tol, (k, kw)
+                    b32 = None
+                    if f_cache is not None:
+                        b32 = f_cache[k].float().cpu().numpy()
+                        assert np.array_equal(np.isfinite(b32), fin), (k, kw)
+                        b32 = np.where(fin, b32, 0.0)
+                    held(np.where(fin, a, 0.0), np.where(fin, b, 0.0), b32, (ci, k, sorted(kw)))
+    if dtype == torch.bfloat16:
+        print(f"[intra-block hooks, bf16 {arch_name}] worst error / budget = {worst[0]:.3f} at {worst[1]}")
 
 
 def test_sae_substitution_style_eval_on_b32_bf16():
@@ -647,22 +680,50 @@ def _hook_cases():
     def edit_cls(t, hook):
         t[:, 0] = 0.25
 
+    def kill_head_3(t, hook):                 # [B, T, H, dh], in place
+        t[:, :, 3] = 0.0
+
+    def no_cls_attention(t, hook):            # pattern [B, H, T, T]
+        t = t.clone()
+        t[..., 0] = 0.0
+        return t / t.sum(-1, keepdim=True).clamp_min(1e-6)
+
+    def mask_last_key(t, hook):               # scores [B, H, T, T], in place
+        t[:, 0, :, -1] = float("-inf")
+
+    def kill_neurons(t, hook):                # [B, T, d_mlp], in place
+        t[..., ::3] = 0.0
+
+    def freeze_scale(t, hook):                # [B, T, 1]
+        return torch.full_like(t, 2.0)
+
+    # (the same functions as tests/golden/gen_golden_vit_hooks.py ran through the REFERENCE)
     return {"A": [("blocks.6.hook_resid_post", scale_shift)],
-            "B": [("blocks.3.hook_attn_out", zero), ("blocks.9.hook_resid_mid", edit_cls)]}
+            "B": [("blocks.3.hook_attn_out", zero), ("blocks.9.hook_resid_mid", edit_cls)],
+            "C": [("blocks.5.attn.hook_z", kill_head_3)],
+            "D": [("blocks.4.attn.hook_pattern", no_cls_attention)],
+            "E": [("blocks.7.attn.hook_attn_scores", mask_last_key)],
+            "F": [("blocks.8.mlp.hook_post", kill_neurons)],
+            "G": [("blocks.2.ln1.hook_scale", freeze_scale)]}
 
 
 def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
     """SURVEY.md 8f row 1 at the real size: run_with_cache(fwd_hooks=[replacing / ablating / in-place hooks]) on the split
     native plan against what the REFERENCE produced for the same hooks (tests/golden/vit_b32_hooks_bs4.json, generated by
-    executing it): fp32 fingerprints at 1e-4, bf16 held to the reference's own bf16 error under the same hooks."""
+    executing it): fp32 fingerprints at 1e-4, bf16 held to the reference's own bf16 error under the same hooks.  Cases A / B
+    hook the residual stream; C-G hook INSIDE a block (pv_vit_forward_stage: head ablation on attn.hook_z, an edited and
+    renormalised attn.hook_pattern, a -inf mask on attn.hook_attn_scores, neuron ablation on mlp.hook_post, a frozen
+    ln1.hook_scale -- hook_point.py:44-45, attention.py:135-152, 267-281)."""
     with open(os.path.join(GOLDEN, "vit_b32_hooks_bs4.json")) as f:
         G = json.load(f)
-    keys = G["keys"]
     m32, arch, _ = build("clip-vit-b32", torch.float32)
     m16, _, _ = build("clip-vit-b32", torch.bfloat16)
     imgs = synth_images(arch, G["batch"], G["seed"])
-    for name, hooks in _hook_cases().items():
+    cases = _hook_cases()
+    assert sorted(cases) == sorted(G["cases"])
+    for name, hooks in cases.items():
         want = G["cases"][name]
+        keys = want.get("keys", G["keys"])
         out, cache = run(m32, imgs, torch.float32, fwd_hooks=hooks, names_filter=keys)
         assert list(cache.keys()) == keys
         for k in keys + ["__out__"]:
@@ -678,10 +739,14 @@ def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
             got = (out16 if k == "__out__" else cache16[k]).float().cpu().numpy()
             budget = want["bf16_budget"][k]
             if budget == 0.0:
-                assert np.abs(got).max() == 0.0, (name, k)               # the zero-ablated tensor itself
+                assert np.array_equal(got, ref), (name, k)               # the zero-ablated tensor / the frozen scale itself
             else:
                 # (4-image fixture with a rewritten residual stream: hook_scale held to the round-2 bar of 1.25 x here)
                 assert rel_fro(got, ref) <= bf16_limit(k, budget, 1.25), (name, k, rel_fro(got, ref), budget)
+        if name == "E":       # the masked key gets exactly zero attention from head 0, in both modes
+            for c in (cache, cache16):
+                pat = c["blocks.7.attn.hook_pattern"]
+                assert float(pat[:, 0, :, -1].abs().max()) == 0.0 and float(pat[:, 1, :, -1].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("image_size,patch", [(224, 16), (208, 13), (400, 16), (176, 16), (256, 16)])

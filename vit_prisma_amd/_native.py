@@ -122,6 +122,13 @@ def lib() -> C.CDLL:
     if L.pv_abi_version() != ABI_VERSION:
         raise NativeError(f"libpvnative ABI {L.pv_abi_version()} != binding {ABI_VERSION}; rebuild")
     L.pv_build_id.restype = C.c_char_p
+    # a prebuilt library with the right ABI number but built from OTHER sources than the ones beside it (a stale .so that
+    # travelled with an edited tree) must not load silently: include/pv_native.h promises it
+    from .build import source_id
+    got, want = L.pv_build_id().decode(), source_id()
+    if got != want and os.environ.get("PV_ALLOW_STALE_LIB", "0") != "1":
+        raise NativeError(f"{LIB_PATH} was built from other sources (build id {got}, tree {want}): run "
+                          "`python -m vit_prisma_amd.build` (PV_ALLOW_STALE_LIB=1 loads it anyway)")
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     L.pv_last_error.argtypes = [C.c_char_p, sz]
     L.pv_last_error.restype = None

@@ -194,6 +194,96 @@ class ActivationCache:
             stack = self.apply_ln_to_stack(stack, layer, pos_slice=pos_slice)
         return (stack, labels) if return_labels else stack
 
+    def get_neuron_results(self, layer: int, neuron_slice: Union[Slice, SliceInput] = None,
+                           pos_slice: Union[Slice, SliceInput] = None) -> torch.Tensor:
+        """What every neuron of ``layer``'s MLP writes into the residual stream: ``post[..., n, None] * W_out[n]`` ->
+        [..., pos, neurons, d_model]; not cached (activation_cache.py:523-562).  The reference accepts only ``Slice`` objects
+        here (its ``isinstance(x, SliceInput)`` on a subscripted Union raises TypeError for anything else); plain slice inputs
+        are accepted as well."""
+        if not isinstance(neuron_slice, Slice):
+            neuron_slice = Slice(neuron_slice)
+        if not isinstance(pos_slice, Slice):
+            pos_slice = Slice(pos_slice)
+        neuron_acts = self[("post", layer, "mlp")]
+        W_out = self.model.blocks[layer].mlp.W_out
+        # (order matters: a position slice may collapse its dimension, so it is applied while the position is still at -2)
+        neuron_acts = pos_slice.apply(neuron_acts, dim=-2)
+        neuron_acts = neuron_slice.apply(neuron_acts, dim=-1)
+        W_out = neuron_slice.apply(W_out, dim=0)
+        return neuron_acts[..., None] * W_out
+
+    def stack_neuron_results(self, layer: int, pos_slice: Union[Slice, SliceInput] = None,
+                             neuron_slice: Union[Slice, SliceInput] = None, return_labels: bool = False,
+                             incl_remainder: bool = False, apply_ln: bool = False):
+        """Every neuron's contribution to the residual stream entering ``layer`` (labels "L{l}N{n}"), optionally with the rest of
+        the stream as a last component (activation_cache.py:564-654, including its corner cases: with no layers below and
+        ``incl_remainder`` the result is a one-element LIST, as there)."""
+        if layer is None or layer == -1:
+            layer = self.model.cfg.n_layers
+        if not isinstance(neuron_slice, Slice):
+            neuron_slice = Slice(neuron_slice)
+        if not isinstance(pos_slice, Slice):
+            pos_slice = Slice(pos_slice)
+        neuron_labels = neuron_slice.apply(torch.arange(self.model.cfg.d_mlp), dim=0)
+        if neuron_labels.ndim == 0:
+            neuron_labels = neuron_labels[None]
+        parts: List[torch.Tensor] = []
+        labels: List[str] = []
+        for l in range(layer):
+            parts.append(self.get_neuron_results(l, pos_slice=pos_slice, neuron_slice=neuron_slice))
+            labels.extend(f"L{l}N{int(h)}" for h in neuron_labels)
+        if parts:
+            components = torch.cat(parts, dim=-2).movedim(-2, 0)          # [neurons of all layers, ..., d_model]
+            if incl_remainder:
+                remainder = self[("resid_post", layer - 1)] - components.sum(dim=0)
+                components = torch.cat([components, remainder[None]], dim=0)
+                labels.append("remainder")
+        elif incl_remainder:
+            components = [pos_slice.apply(self[("resid_post", layer - 1)], dim=-2)]
+        else:
+            components = torch.zeros(0, *pos_slice.apply(self["hook_embed"], dim=-2).shape, device=self.model.cfg.device)
+        if apply_ln:
+            components = self.apply_ln_to_stack(components, layer, pos_slice=pos_slice)
+        return (components, labels) if return_labels else components
+
+    def get_full_resid_decomposition(self, layer: Optional[int] = None, mlp_input: bool = False, expand_neurons: bool = True,
+                                     apply_ln: bool = False, pos_slice: Union[Slice, SliceInput] = None,
+                                     return_labels: bool = False):
+        """The residual stream entering ``layer`` as [every head's result | every neuron's result (or the MLP outputs) | embed |
+        pos_embed | accumulated biases] (activation_cache.py:737-826).  As in the reference, ``hook_embed`` holds the patch tokens
+        only ([batch, tokens - 1, d_model]: the CLS row is added afterwards, base_vit.py:169-181), so for a ViT with a CLS token
+        the concatenation only goes through when ``pos_slice`` collapses the position dimension."""
+        if layer is None or layer == -1:
+            layer = self.model.cfg.n_layers
+        if not isinstance(pos_slice, Slice):
+            pos_slice = Slice(pos_slice)
+        head_stack, labels = self.stack_head_results(layer + (1 if mlp_input else 0), pos_slice=pos_slice, return_labels=True)
+        components = [head_stack]
+        if not self.model.cfg.attn_only and layer > 0:
+            if expand_neurons:
+                neuron_stack, neuron_labels = self.stack_neuron_results(layer, pos_slice=pos_slice, return_labels=True)
+                labels.extend(neuron_labels)
+                components.append(neuron_stack)
+            else:
+                mlp_stack, mlp_labels = self.decompose_resid(layer, mlp_input=mlp_input, pos_slice=pos_slice, incl_embeds=False,
+                                                             mode="mlp", return_labels=True)
+                labels.extend(mlp_labels)
+                components.append(mlp_stack)
+        if self.has_embed:
+            labels.append("embed")
+            components.append(pos_slice.apply(self["embed"], -2)[None])
+        if self.has_pos_embed:
+            labels.append("pos_embed")
+            components.append(pos_slice.apply(self["pos_embed"], -2)[None])
+        # (without the neuron expansion the MLP biases are already inside the MLP outputs)
+        bias = self.model.accumulated_bias(layer, mlp_input, include_mlp_biases=expand_neurons)
+        labels.append("bias")
+        components.append(bias.expand((1,) + head_stack.shape[1:]))
+        residual_stack = torch.cat(components, dim=0)
+        if apply_ln:
+            residual_stack = self.apply_ln_to_stack(residual_stack, layer, pos_slice=pos_slice, mlp_input=mlp_input)
+        return (residual_stack, labels) if return_labels else residual_stack
+
     def apply_ln_to_stack(self, residual_stack: torch.Tensor, layer: Optional[int] = None, mlp_input: bool = False,
                           pos_slice: Union[Slice, SliceInput] = None, batch_slice: Union[Slice, SliceInput] = None,
                           has_batch_dim: bool = True) -> torch.Tensor:

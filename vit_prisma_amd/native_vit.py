@@ -222,8 +222,13 @@ class NativeViT:
                 cache_device=None, remove_batch_dim: bool = False, first_block: int = 0,
                 resid_in: Optional[torch.Tensor] = None, entry_mid: bool = False,
                 exit_mid: bool = False, entry_stage: int = 0, exit_stage: int = 0,
-                act_in: Sequence[torch.Tensor] = ()) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+                act_in: Sequence[torch.Tensor] = (),
+                tap_dst: Optional[Dict[str, torch.Tensor]] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """Runs the tapped forward.  ``names``: requested HookPoint names in firing order.
+        ``tap_dst`` {name: tensor}: the caller's OWN destination for a requested activation (the activation store's buffer
+        slice): the producing kernel stores straight into it and the cache entry IS that tensor -- taken only when the tensor
+        is exactly what the tap writes (device, dtype, shape, contiguous, 256-byte aligned); otherwise the entry comes out of
+        the arena as usual and the caller copies.
         With ``resid_in`` ([B, T, d_model]) the forward is RESUMED at block ``first_block`` from that residual
         (``images`` is ignored, names of earlier stages must not be requested).  Positions inside a block
         (``entry_stage`` / ``exit_stage``, pv_vit_forward_stage; PV_STAGE_*): 0 block entry, 1 ln1 taken, 2 q / k / v ready,
@@ -278,11 +283,20 @@ class NativeViT:
             raise ValueError(f"entry_stage {entry_stage} takes {want_acts} activation tensors, got {len(acts)}")
         # unique buffers -> slab offsets
         offsets: Dict[Tuple[int, int], Tuple[int, TapSpec]] = {}
+        external: Dict[Tuple[int, int], torch.Tensor] = {}
         total = 0
         for n, s in specs.items():
             if s.slot < 0:
                 continue
             key = (s.slot, s.layer)
+            dst = tap_dst.get(n) if tap_dst else None
+            if (dst is not None and key not in offsets and key not in external and dst.device == self.device and dst.dtype == s.dtype
+                    and tuple(dst.shape) == tuple(s.shape) and dst.is_contiguous() and dst.data_ptr() % _ALIGN == 0
+                    and cache_device is None and not remove_batch_dim):
+                external[key] = dst
+                continue
+            if key in external:
+                continue
             if key not in offsets:
                 nbytes = _ESIZE[s.dtype]
                 for dim in s.shape:
@@ -296,9 +310,12 @@ class NativeViT:
         slab = self.arena.acquire(total)
         base = slab.data_ptr()
 
-        taps = (N.Tap * max(len(offsets), 1))()
+        n_taps = len(offsets) + len(external)
+        taps = (N.Tap * max(n_taps, 1))()
         for i, ((slot, layer), (off, _)) in enumerate(offsets.items()):
             taps[i] = N.Tap(slot=slot, layer=layer, dst=base + off)
+        for i, ((slot, layer), dst) in enumerate(external.items()):
+            taps[len(offsets) + i] = N.Tap(slot=slot, layer=layer, dst=dst.data_ptr())
         ws = self._get_workspace(B)
         cur = torch.cuda.current_stream(self.device)
         stream = cur.cuda_stream
@@ -308,7 +325,7 @@ class NativeViT:
         if last is not None and last[0] != stream:
             cur.wait_event(last[1])
         if resid_in is None and not exit_stage:
-            N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, len(offsets),
+            N.check(self.lib.pv_vit_forward(self._plan, images.data_ptr(), B, n_blocks, int(run_head), taps, n_taps,
                                             ws.data_ptr(), ws.numel(), (base + out_off) if run_head else None, stream),
                     "pv_vit_forward")
         else:
@@ -316,7 +333,7 @@ class NativeViT:
             N.check(self.lib.pv_vit_forward_stage(self._plan, images.data_ptr() if resid_in is None else None,
                                                   None if resid_in is None else resid_in.data_ptr(), ap[0], ap[1], ap[2], B,
                                                   first_block, entry_stage, n_blocks, exit_stage, int(run_head), taps,
-                                                  len(offsets), ws.data_ptr(), ws.numel(),
+                                                  n_taps, ws.data_ptr(), ws.numel(),
                                                   (base + out_off) if run_head else None, stream),
                     "pv_vit_forward_stage")
         self.n_forward += 1
@@ -341,6 +358,8 @@ class NativeViT:
                 t = model.pos_embed.W_pos.detach().unsqueeze(0).expand(B, -1, -1)
                 if cache_device is not None:
                     t = t.to(cache_device)
+            elif (s.slot, s.layer) in external:
+                t = external[(s.slot, s.layer)]
             else:
                 off, _ = offsets[(s.slot, s.layer)]
                 t = view(src, off, s.dtype, s.shape)
@@ -349,6 +368,8 @@ class NativeViT:
             cache[n] = t[0] if remove_batch_dim else t
         if run_head:
             out = view(slab, out_off, cfg.dtype, (B, n_out))
+        elif (specs[out_name].slot, specs[out_name].layer) in external:
+            out = external[(specs[out_name].slot, specs[out_name].layer)]
         else:
             off, s = offsets[(specs[out_name].slot, specs[out_name].layer)]
             out = view(slab, off, s.dtype, s.shape)

@@ -297,6 +297,7 @@ class NativeSAE:
         (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs).  target: as in ``step``."""
         x = self._check_x(x)
         self._set_target(x, target)
+        self._ensure_shadows()                                    # (the encoder is read as W_encT: an outside edit of W_enc must reach it)
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
@@ -333,6 +334,7 @@ class NativeSAE:
         as in ``step`` (tokens sharded over ranks; the caller all-reduces ``flat_g``)."""
         assert self.gated
         x = self._check_x(x)
+        self._ensure_shadows()                                    # (as in step / dense_step)
         n = x.shape[0]
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,

@@ -325,6 +325,29 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         self._native_sync()
         return super().named_parameters(*args, **kwargs)
 
+    # the paths that read ``self._parameters`` directly: .to() / .half() / .cpu() (Module._apply), copy.deepcopy, pickling
+    def _apply(self, fn, *args, **kwargs):
+        self._native_sync()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __deepcopy__(self, memo):
+        self._native_sync()
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_native_sync_fn":                           # (the copy is not the module the engine trains)
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        self._native_sync()
+        state = dict(self.__dict__)
+        state.pop("_native_sync_fn", None)
+        return state
+
     def _native_reason(self, x: torch.Tensor, need_hidden_pre: bool = False) -> Optional[str]:
         cfg = self.cfg
         if getattr(self, "_native_pref", None) is False:

@@ -47,6 +47,7 @@ class VisionActivationsStore:
         # at the same points -- the batches served are identical to the synchronous store's.  ``overlap_harvest = False``
         # turns it off.
         self.overlap_harvest = torch.device(cfg.device).type == "cuda"
+        self.direct_tap = True                               # harvest kernels store straight into the buffer (see _harvest_raw)
         self._prefetched = None                              # (n_batches, buf, buf_out, event) of the refill in flight
         self._side_stream = None
         rank, world = _dist_info()
@@ -124,18 +125,43 @@ class VisionActivationsStore:
             return pick(names), pick(out_names)
         return pick(names)
 
+    # images per ViT forward while a buffer is harvested: the reference runs one forward per store batch (32 images by default,
+    # config.py:352) -- ~100 launch-bound kernels each on this hardware.  Consecutive store batches are independent images, and
+    # the HIP forward's bits do not depend on the batch an image sits in (tests: digests at bs 1 / 3 / 77 / 300 / 512), so
+    # ceil(HARVEST_IMAGES / store_batch_size) DataLoader batches go through ONE run_with_cache: same images, same order, same
+    # buffer rows, same bits.
+    HARVEST_IMAGES = 256
+
+    def _direct_tap_name(self) -> Optional[str]:
+        """The single hook point whose [images, ctx, d_in] activation IS a buffer slice, or None (several layers, a head index,
+        CLS only, patches only, a transcoder: those assemble the rows in ``get_activations``)."""
+        cfg = self.cfg
+        if (cfg.is_transcoder or isinstance(cfg.hook_point_layer, list) or cfg.hook_point_head_index is not None
+                or cfg.cls_token_only or cfg.use_patches_only):
+            return None
+        return cfg.hook_point
+
     def _harvest_raw(self, n_batches_in_buffer: int):
-        """The ViT part of ``get_buffer``: (buf [bs * n_batches, ctx, n_layers, d_in], buf_out or None), rows in harvest order."""
+        """The ViT part of ``get_buffer``: (buf [bs * n_batches, ctx, n_layers, d_in], buf_out or None), rows in harvest order.
+        Where the activation of the one configured hook point is exactly a slice of the buffer, the producing kernel stores it
+        THERE (``tap_dst``: no arena copy, no ``buf[...] = acts`` pass); the buffer is then held in the ViT's activation dtype
+        (bf16 under a bf16 ViT: the values the reference's assignment would widen, bit for bit) and ``get_buffer`` widens the
+        shuffled rows to cfg.dtype."""
         cfg = self.cfg
         bs = cfg.store_batch_size
         total = bs * n_batches_in_buffer
         n_layers = len(self._layers())
         ctx = cfg.context_size
-        buf = torch.zeros((total, ctx, n_layers, cfg.d_in), dtype=cfg.dtype, device=cfg.device)
+        direct = self._direct_tap_name()
+        model_dtype = getattr(getattr(self.model, "cfg", None), "dtype", None)
+        on_hip = getattr(self.model, "native_mode", "off") != "off" and torch.device(cfg.device).type == "cuda"
+        native = direct is not None and on_hip and self.direct_tap and model_dtype in (torch.float32, torch.bfloat16)
+        buf = torch.zeros((total, ctx, n_layers, cfg.d_in), dtype=model_dtype if native else cfg.dtype, device=cfg.device)
         buf_out = None
         if cfg.is_transcoder:
             ol = cfg.out_hook_point_layer
             buf_out = torch.zeros((total, ctx, len(ol) if isinstance(ol, list) else 1, cfg.d_out), dtype=cfg.dtype, device=cfg.device)
+        group = max(1, self.HARVEST_IMAGES // bs) if on_hip else 1      # (the PyTorch path's matmuls are not batch-size invariant bit for bit)
         # the ViT is constant while one buffer is harvested: skip the per-call weight-version compare inside this loop
         # only (an edit of the model between buffers is picked up by the next one)
         freeze = getattr(self.model, "freeze_native_weights", None)
@@ -143,8 +169,20 @@ class VisionActivationsStore:
         if freeze is not None:
             freeze(True)
         try:
-            for start in range(0, total, bs):
-                acts = self.get_activations(next(self.image_dataloader_iter))
+            start = 0
+            while start < total:
+                g = min(group, (total - start) // bs)
+                images = [next(self.image_dataloader_iter) for _ in range(g)]
+                images = images[0] if g == 1 else torch.cat(images, dim=0)
+                rows = g * bs
+                dst = buf[start:start + rows]
+                if native:
+                    self.model._tap_dst = {direct: dst.view(rows, ctx, cfg.d_in)}
+                try:
+                    acts = self.get_activations(images)
+                finally:
+                    if native:
+                        self.model._tap_dst = None
                 acts_out = None
                 if cfg.is_transcoder:
                     acts, acts_out = acts
@@ -152,11 +190,13 @@ class VisionActivationsStore:
                     acts = acts[:, 1:, :, :]
                     acts_out = acts_out[:, 1:, :, :] if acts_out is not None else None
                 if acts_out is not None:
-                    buf_out[start:start + bs, ...] = acts_out
+                    buf_out[start:start + rows, ...] = acts_out
                 # the reference's assignment (activations_store.py:345): a [bs, 1, L, d] CLS-only harvest broadcasts over
-                # context_size, any other token-count mismatch raises
-                buf[start:start + bs, ...] = acts
-                self.n_tokens_harvested += bs * ctx
+                # context_size, any other token-count mismatch raises.  Skipped when the kernel already stored the rows here.
+                if not (native and acts.data_ptr() == dst.data_ptr() and acts.dtype == dst.dtype and acts.shape == dst.shape):
+                    dst[...] = acts
+                self.n_tokens_harvested += rows * ctx
+                start += rows
         finally:
             if freeze is not None:
                 freeze(was_frozen)
@@ -194,8 +234,8 @@ class VisionActivationsStore:
         buf = buf.reshape(-1, n_layers, cfg.d_in)
         perm = torch.randperm(buf.shape[0], device=buf.device)
         if buf_out is not None:
-            return buf[perm], buf_out.reshape(-1, buf_out.shape[2], cfg.d_out)[perm]
-        return buf[perm]
+            return buf[perm].to(cfg.dtype), buf_out.reshape(-1, buf_out.shape[2], cfg.d_out)[perm]
+        return buf[perm].to(cfg.dtype)                            # (a no-op unless the rows were tapped in the ViT's narrower dtype)
 
     def get_data_loader(self) -> Iterator[Any]:
         """Mix a fresh half buffer into the stored one, keep half, serve the other half

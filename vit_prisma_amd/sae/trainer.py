@@ -88,8 +88,24 @@ class VisionSAETrainer:
         self.rank, self.world = _dist_info()
         self._feature_parallel: Optional[bool] = None       # multi-rank native top-k step: None = auto (feature parallel when d_sae
                                                             # divides by the world size), True / False = forced
+        self._force_dist = False                            # see _mr
         self._fp = None                                     # FeatureParallelSAE (this rank's shard engine + choreography)
         self._fp_dirty = False                              # the module's parameters lag behind the shards
+
+    @property
+    def _mr(self) -> bool:
+        """Do the steps take their multi-rank form (collectives, sharded optimizer / feature shards)?  With more than one rank,
+        or when ``force_distributed_paths`` asked for it in a process group of ONE rank -- the same calls on the same backend
+        (the in-place reduce_scatter_tensor / all_gather_into_tensor / packed buckets on RCCL), which is how a one-GPU box
+        executes the code an 8-GPU job runs."""
+        return self.world > 1 or self._force_dist
+
+    def force_distributed_paths(self, flag: bool = True) -> "VisionSAETrainer":
+        import torch.distributed as dist
+        if flag and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("force_distributed_paths needs an initialised torch.distributed process group")
+        self._force_dist = bool(flag)
+        return self
 
     def use_native(self, flag: Optional[bool]) -> "VisionSAETrainer":
         """True: the fused HIP step or an error; False: always the PyTorch path; None (default): native when supported."""
@@ -109,10 +125,16 @@ class VisionSAETrainer:
         return self
 
     def _use_tp(self, sae) -> bool:
-        if self.world <= 1 or self._feature_parallel is False:
+        if not self._mr or self._feature_parallel is False:
             return False
         if self._feature_parallel is None:
-            return int(sae.cfg.d_sae) % self.world == 0
+            # auto: only where the feature-parallel kernels can run (pv_sae_tp_merge ranks the candidates of at most 8 ranks,
+            # a shard must hold at least k features and a whole number of 4-feature groups); anything else -- two nodes, small
+            # or odd shards -- takes the token-sharded step, which has no such limits.  use_feature_parallel(True) keeps the
+            # hard error.
+            d_sae, k = int(sae.cfg.d_sae), int((sae.cfg.activation_fn_kwargs or {}).get("k", 1))
+            shard = d_sae // self.world
+            return d_sae % self.world == 0 and self.world <= 8 and shard >= k and shard % 4 == 0
         return True
 
     # ---- bookkeeping ------------------------------------------------------------------------------
@@ -177,7 +199,7 @@ class VisionSAETrainer:
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
         # no ghost gradients; with a process group on the dense (ReLU) step only
         is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in)
-                 and (self.world == 1 or cfg.activation_fn_str == "relu")          # (multi-rank: on the dense step only)
+                 and (not self._mr or cfg.activation_fn_str == "relu")             # (multi-rank: on the dense step only)
                  and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own dense step (pv_sae_gated_step)
@@ -195,7 +217,7 @@ class VisionSAETrainer:
         if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64 and not cfg.use_ghost_grads:
             return "topk"
         if (cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
-                and not (cfg.use_ghost_grads and self.world > 1)):           # (ghost gradients natively: single process)
+                and not (cfg.use_ghost_grads and self._mr)):                 # (ghost gradients natively: single process)
             return "relu"
         return None
 
@@ -211,7 +233,7 @@ class VisionSAETrainer:
                                          + tuple(n for n in ("b_gate", "r_mag", "b_mag") if n in sae._parameters))     # e.g. b_dec.data re-bound by an init
                                      or tuple(n for n in ("b_dec_out", "W_skip") if n in eng.params) != tc_names)
         if eng is None or eng.max_tokens < n_tokens or stale:
-            if self.world > 1 and eng is None:
+            if self._mr and eng is None:
                 # replicas must start from identical parameters (a per-rank b_dec initialisation, a different seed or a
                 # caller-supplied module would otherwise never converge: every rank applies the same summed gradient).
                 # Only at the FIRST creation, which every rank reaches in its first step: a later re-creation (a larger
@@ -233,7 +255,7 @@ class VisionSAETrainer:
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
                 eng.adam_step = old.adam_step
-            if self.world == 1 and isinstance(sae, StandardSparseAutoencoder):
+            if not self._mr and isinstance(sae, StandardSparseAutoencoder):
                 # one process: nobody but the kernels reads W_enc between steps -- they read its transposed master -- so the
                 # parameter's own layout is rewritten only when somebody asks for it (sae.W_enc, state_dict(), parameters())
                 eng.lazy_w_enc = True
@@ -244,7 +266,7 @@ class VisionSAETrainer:
     # ---- data-parallel plumbing ----------------------------------------------------------------------
     def _shard(self, d_sae: int):
         """This rank's feature rows, or None when the optimizer cannot be sharded evenly on 16-byte boundaries."""
-        if self.world == 1 or d_sae % (4 * self.world) != 0:
+        if not self._mr or d_sae % (4 * self.world) != 0:
             return None
         n = d_sae // self.world
         return self.rank * n, (self.rank + 1) * n
@@ -339,7 +361,7 @@ class VisionSAETrainer:
         # statistics tensors are the caller's: the kernels update them in place
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
-        if self.world == 1:
+        if not self._mr:
             # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
             # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
             eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True, target=self._target if eng.transcoder else None)
@@ -371,7 +393,7 @@ class VisionSAETrainer:
             else:
                 eng.dense_step(x, l1, renorm_decoder=True, target=target, **kw)
 
-        if self.world == 1:
+        if not self._mr:
             dead = None
             if sae.cfg.use_ghost_grads and sae.training and not gated:        # train_sae.py:330-332 (the mask is taken BEFORE this step's statistics)
                 dead = n_since_fired > sae.cfg.dead_feature_window
