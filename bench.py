@@ -506,7 +506,14 @@ def main():
         else:
             # the ReLU + L1 SAE (every published CLIP SAE of the reference) on the dense fused step
             weak = None
-            relu = leg("sae_relu_l1", lambda: sae_bench_leg(dev, dist=None, steps=8, warmup=2, activation="relu"))
+            # ReLU + L1: the run from the synthetic init once L0 has collapsed (10 warm-up steps; the first ~5 are dense), the same run
+            # from step 1 (dense, then sparse), and the L0 of the published x64 SAEs (3.5 % of the features: dense)
+            relu = leg("sae_relu_l1", lambda: sae_bench_leg(dev, dist=None, steps=20, warmup=10, activation="relu"))
+            relu_init = leg("sae_relu_l1_from_init", lambda: sae_bench_leg(dev, dist=None, steps=10, warmup=0, activation="relu"))
+            relu_pub = leg("sae_relu_l1_published_l0", lambda: sae_bench_leg(dev, dist=None, steps=5, warmup=2, activation="relu",
+                                                                              relu_target_l0=0.035 * 24576))
+            relu_l64 = leg("sae_relu_l1_l0_64", lambda: sae_bench_leg(dev, dist=None, steps=10, warmup=2, activation="relu",
+                                                                       relu_target_l0=64.0))
             from vit_prisma_amd.sae.bench_leg import sae_variants_leg
             torch.cuda.empty_cache()
             variants = leg("sae_variants", lambda: sae_variants_leg(dev))
@@ -517,6 +524,11 @@ def main():
                 sae["weak_scaling_data_parallel"] = weak
             else:
                 sae["relu_l1"] = relu
+                if isinstance(relu, dict):
+                    pick = ("value", "unit", "ms_per_step", "steps", "warmup", "l0", "sparse_steps", "dense_steps", "config", "roofline", "error")
+                    relu["from_init"] = {k: relu_init.get(k) for k in pick if isinstance(relu_init, dict) and k in relu_init}
+                    relu["published_l0"] = {k: relu_pub.get(k) for k in pick if isinstance(relu_pub, dict) and k in relu_pub}
+                    relu["l0_64"] = {k: relu_l64.get(k) for k in pick if isinstance(relu_l64, dict) and k in relu_l64}
                 sae["variants"] = variants
             if world == 1 and not a.no_cpu_baseline:
                 sae["cpu_baseline"] = sae_cpu_baseline_torch(10.0)

@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 15
+#define PV_ABI_VERSION 16
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -450,6 +450,35 @@ size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, i
 int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
                       int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The ReLU + L1 step, sparse where the batch allows it ("ReLU is top-k with threshold 0 and a variable k"): same contract, flags,
+ * scalars and follow-up calls as pv_sae_dense_step (no ghost gradients here), same results -- exact fp32 values on both paths.
+ * ONE product over all features (the fp16 MFMA filter of pv_sae_step with the per-token threshold -B_n, B_n = the proven error band
+ * of the fp16 product, and the exact fp32 re-scoring of every survivor against W_encT) yields each token's POSITIVE activations as
+ * a list of at most sp->cap (feature, value) pairs; decode, the CSR by feature, the sparse backward and the bias gradients then run
+ * on pv_sae_step's kernels with k = cap (L1 term = the sum of the kept values, its gradient l1_coefficient / N on every kept pair).
+ * If some token of the batch cannot be held -- more positives than cap, a candidate slot overflow (the first, dense steps of a
+ * training run; the published x64 SAEs with L0 ~ 600-2000, docs/sae_table.md) -- the device-side word *mode is raised, the sparse
+ * kernels leave at once and the five dense GEMMs of pv_sae_dense_step run: decided on the GPU, no host round trip.
+ *   sp->cap          kept activations per token the sparse form can hold: a multiple of 4 in [4, 256]
+ *   sp->workspace    caller-owned, pv_sae_relu_workspace_bytes(plan, n_tokens, cap) bytes, 256-byte aligned.  Its first word is the
+ *                    mode of the last step (0 = ran sparse, 1 = ran dense); the kept pairs follow (tests: pv_debug_sae_relu_offset)
+ * sp == NULL, or a plan the filter does not cover (d_sae % 256, d_sae < 2048, d_in % 8): the dense step.
+ * Requires the encoder shadows of pv_sae_state (W_encT, W_enc16T, enc_colsq) to be current.
+ * Replaces sae/sae.py:557-645 (L1 :617-626) + sae/train_sae.py:328-392, like pv_sae_dense_step. */
+typedef struct pv_sae_relu_sparse {
+    int32_t cap;
+    int32_t reserved;
+    void* workspace;
+    size_t workspace_bytes;
+} pv_sae_relu_sparse;
+size_t pv_sae_relu_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap);
+/* byte offset of a named region of that workspace ("mode": uint32; "idx": int32 [n_tokens][cap]; "val": float [n_tokens][cap];
+ * "tok_cnt": uint32 [n_tokens]), or (size_t)-1 */
+size_t pv_debug_sae_relu_offset(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap, const char* name);
+int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
+                     int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp, pv_sae_out* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* One train step of a gated SAE (batch_mean / n_global as in pv_sae_step: tokens may be sharded over ranks, the caller all-reduces
  * the flat gradient buffer): forward + backward + statistics on the dense GEMM kernel -- the shared

@@ -88,6 +88,10 @@ class OracleEngine:
 
     transcoder = False
 
+    def relu_step(self, x, l1_coefficient, cap=None, **kw):
+        """The twin of NativeSAE.relu_step (pv_sae_relu_step): sparse or dense is the kernels' business -- the same step either way."""
+        return self.dense_step(x, l1_coefficient, **kw)
+
     def grad_sqnorm(self, from_step=False):
         self.scalars[3] = float((self.flat_g.double() ** 2).sum())
 

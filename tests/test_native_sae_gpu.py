@@ -1307,3 +1307,149 @@ def test_checkpoint_mid_run_and_lazy_w_enc_match_the_torch_path(tmp_path):
             assert rel_fro(ck, synth_sae_state(64, 512, 0)["W_enc"]) > 2e-2
     for n in runs[True]:
         assert rel_fro(runs[True][n], runs[False][n]) < TOL, n
+
+# ---------------------------------------------------------------------------------------------------
+# the ReLU + L1 step, sparse where the batch allows it (pv_sae_relu_step: fp16 filter with the threshold -B_n, exact fp32
+# re-scoring, per-token lists of the positive activations on the k-sparse kernels; the dense GEMMs when a token cannot be held)
+# ---------------------------------------------------------------------------------------------------
+def _shift_b_enc_for_l0(P, x, ln, want_l0):
+    """Move b_enc down so that a token keeps about want_l0 features on this batch: the regime a trained ReLU SAE with a strong L1
+    term lives in (and the one bench.py's ReLU leg settles into after ~6 steps from the synthetic init)."""
+    fw = O.sae_forward(P, x, None, layer_norm=ln)
+    q = np.quantile(fw["hidden_pre"].ravel()[::7], 1.0 - want_l0 / P["W_enc"].shape[1])
+    P["b_enc"] -= np.float32(q)
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("d_in,d_sae,n,ln,l0,tc", [(64, 2048, 256, True, 12, False), (136, 2304, 300, False, 20, False),
+                                                    (768, 8192, 1024, True, 24, False), (768, 8192, 1024, True, 24, True),
+                                                    (768, 24576, 4096, True, 32, False), (768, 49152, 1024, True, 60, False)])
+def test_relu_step_sparse_vs_oracle(d_in, d_sae, n, ln, l0, tc):
+    """relu_step in its sparse form against the ReLU + L1 oracle: the step must report mode 0, keep exactly the oracle's positive
+    entries (sets equal up to entries within fp32 summation noise of zero) with the exact fp32 values, and give the losses,
+    l0, reconstruction, every gradient tensor, the clip norm, parameters and statistics of the reference's train step -- ragged
+    shapes, no LayerNorm, a Transcoder with the skip connection, the bench shape (768 -> 24576 x 4096) and the x64 width included."""
+    l1c = 3e-3
+    P, opt, stats, T = (fresh_transcoder(d_in, d_sae, True) if tc else fresh(d_in, d_sae))
+    _shift_b_enc_for_l0(P, synth_sae_batch(n, d_in, seed=10), ln, l0)
+    T["b_enc"].copy_(torch.from_numpy(P["b_enc"]))
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, ln, n, **({"b_dec_out": T["b_dec_out"], "W_skip": T["W_skip"]} if tc else {}))
+    for t in range(2):
+        x = synth_sae_batch(n, d_in, seed=10 + t)
+        y = synth_sae_batch(n, d_in, seed=50 + t) if tc else None
+        Pc = {kk: v.copy() for kk, v in P.items()}
+        O.renorm_decoder(Pc)
+        fw = O.sae_forward(Pc, x, None, layer_norm=ln, l1_coefficient=l1c, target=y)
+        before = stats["act_freq_scores"].copy()
+        ref = O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        eng.relu_step(torch.from_numpy(x).cuda(), l1c, want_out=True, target=torch.from_numpy(y).cuda() if tc else None)
+        eng.grad_sqnorm()
+        torch.cuda.synchronize()
+        assert int(eng.relu_mode.item()) == 0, "the sparse form should hold this batch"
+        idx, val, cnt = (v.cpu().numpy() for v in eng.relu_pairs())
+        gate = np.zeros((n, d_sae), bool)
+        rows = np.repeat(np.arange(n), cnt)
+        cols = np.concatenate([idx[i, :cnt[i]] for i in range(n)]) if cnt.sum() else np.zeros(0, np.int64)
+        gate[rows, cols] = True
+        assert gate.sum() == cnt.sum()                                   # no feature twice in a token's list
+        differs = gate != (fw["feature_acts"] > 0)
+        assert differs.sum() <= 1e-5 * gate.size and np.all(np.abs(fw["hidden_pre"][differs]) < 1e-5 * np.abs(fw["hidden_pre"]).max())
+        # values: the exact fp32 pre-activations (descending within a token)
+        vals = np.concatenate([val[i, :cnt[i]] for i in range(n)])
+        assert np.all(vals > 0) and all(np.all(np.diff(val[i, :cnt[i]]) <= 0) for i in range(0, n, max(1, n // 64)))
+        assert np.abs(vals - fw["hidden_pre"][rows, cols]).max() <= 1e-5 * np.abs(fw["hidden_pre"]).max()
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - ref["loss"]) <= TOL * ref["loss"] and abs(sc[1] - ref["mse_loss"]) <= TOL * ref["mse_loss"], (sc, ref)
+        assert abs(sc[4] - ref["l1_loss"]) <= TOL * ref["l1_loss"] and abs(sc[2] - ref["l0"]) <= TOL * ref["l0"] + 1e-6, (sc, ref)
+        assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
+        gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c, gate=gate if differs.any() else None)
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr)
+        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
+        for name in [m for m in gr if m != "W_enc"]:
+            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
+        if differs.any():
+            return
+        fire_ref = stats["act_freq_scores"] - before
+        assert np.array_equal(eng.fire_count.cpu().numpy(), fire_ref)
+        eng.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name in P:
+            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name
+        assert np.array_equal(eng.act_freq_scores.cpu().numpy(), stats["act_freq_scores"])
+        assert np.array_equal(eng.n_fwd_since_fired.cpu().numpy(), stats["n_fwd_since_fired"])
+
+
+@pytest.mark.parametrize("d_in,d_sae,n", [(64, 2048, 256), (768, 8192, 1024)])
+def test_relu_step_goes_dense_exactly_when_a_token_cannot_be_held(d_in, d_sae, n):
+    """The device-side switch: with a capacity of exactly the largest token's count the step runs sparse, with one group of four
+    less it must raise its mode word and run the dense GEMMs -- bit for bit what dense_step computes -- and the two forms agree to
+    summation-order noise.  At the synthetic init (half of all features positive) the step is dense whatever the capacity."""
+    l1c = 3e-3
+    P, opt, stats, T = fresh(d_in, d_sae)
+    x = synth_sae_batch(n, d_in, seed=3)
+    _shift_b_enc_for_l0(P, x, True, 20)
+    Pc = {kk: v.copy() for kk, v in P.items()}
+    O.renorm_decoder(Pc)
+    cnt = (O.sae_forward(Pc, x, None, layer_norm=True)["feature_acts"] > 0).sum(axis=1)
+    cap_ok = int((cnt.max() + 3) // 4 * 4)
+    xg = torch.from_numpy(x).cuda()
+
+    def run(step, **kw):
+        Tl = {m: torch.from_numpy(v.copy()).cuda() for m, v in P.items()}
+        eng = NativeSAE(Tl["W_enc"], Tl["W_dec"], Tl["b_enc"], Tl["b_dec"], 1, True, n)
+        getattr(eng, step)(xg, l1c, want_out=True, **kw)
+        eng.grad_sqnorm()
+        torch.cuda.synchronize()
+        return eng
+
+    sparse = run("relu_step", cap=cap_ok)
+    dense_forced = run("relu_step", cap=cap_ok - 4)
+    dense = run("dense_step")
+    assert int(sparse.relu_mode.item()) == 0 and int(dense_forced.relu_mode.item()) == 1
+    assert int(sparse.relu_pairs()[2].max().item()) == int(cnt.max())
+    for a in ("flat_g", "scalars", "sae_out", "fire_count"):
+        assert torch.equal(getattr(dense_forced, a), getattr(dense, a)), a
+    assert rel_fro(sparse.flat_g.cpu().numpy(), dense.flat_g.cpu().numpy()) < 1e-5
+    assert rel_fro(sparse.sae_out.cpu().numpy(), dense.sae_out.cpu().numpy()) < 1e-5
+    assert torch.allclose(sparse.scalars[:5], dense.scalars[:5], rtol=1e-5, atol=0) and torch.equal(sparse.fire_count, dense.fire_count)
+    # the init state: 50 % of the features fire
+    P0, _, _, T0 = fresh(d_in, d_sae)
+    eng = NativeSAE(T0["W_enc"], T0["W_dec"], T0["b_enc"], T0["b_dec"], 1, True, n)
+    eng.relu_step(xg, l1c)
+    ref = NativeSAE(*(T0[m].clone() for m in ("W_enc", "W_dec", "b_enc", "b_dec")), 1, True, n)
+    ref.dense_step(xg, l1c)
+    torch.cuda.synchronize()
+    assert int(eng.relu_mode.item()) == 1 and torch.equal(eng.flat_g, ref.flat_g) and torch.equal(eng.scalars, ref.scalars)
+    assert torch.equal(eng.act_freq_scores, ref.act_freq_scores) and torch.equal(eng.n_fwd_since_fired, ref.n_fwd_since_fired)
+
+
+def test_relu_step_is_bit_reproducible_and_follows_a_collapsing_run():
+    """(a) two engines from the same state agree bit for bit over steps that run dense, then sparse; (b) bench.py's ReLU leg from
+    the synthetic init (768 -> 8192 here): L0 falls from half of the features to a few within ~8 steps -- the step must change
+    form on its own (mode 1, later 0) and track the oracle through the transition."""
+    d_in, d_sae, n, l1c = 768, 8192, 1024, 8e-5
+    P, opt, stats, _ = fresh(d_in, d_sae)
+    engines = []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        engines.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, True, n))
+    modes = []
+    for t in range(12):
+        x = synth_sae_batch(n, d_in, seed=t % 4)
+        ref = O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, l1_coefficient=l1c)
+        xg = torch.from_numpy(x).cuda()
+        for e in engines:
+            e.relu_step(xg, l1c, want_out=True)
+            e.grad_sqnorm()
+        torch.cuda.synchronize()
+        a, b = engines
+        assert torch.equal(a.flat_g, b.flat_g) and torch.equal(a.scalars, b.scalars) and torch.equal(a.sae_out, b.sae_out), t
+        modes.append(int(a.relu_mode.item()))
+        sc = a.scalars.cpu().numpy()
+        # (a ReLU gate within fp32 noise of zero may fall either way: losses at 1e-4, l0 to a handful of entries)
+        assert abs(sc[0] - ref["loss"]) <= 2e-4 * abs(ref["loss"]) and abs(sc[2] - ref["l0"]) <= 1e-3 * ref["l0"] + 0.01, (t, sc, ref)
+        for e in engines:
+            e.apply(1e-3, 1.0)
+    torch.cuda.synchronize()
+    assert modes[0] == 1 and modes[-1] == 0 and modes == sorted(modes, reverse=True), modes
+    assert torch.equal(engines[0].W_encT, engines[1].W_encT) and torch.equal(engines[0].params["W_dec"], engines[1].params["W_dec"])

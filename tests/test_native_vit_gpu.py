@@ -518,14 +518,16 @@ def test_sae_substitution_style_eval_on_b32_bf16():
         assert float(c["blocks.7.hook_resid_post"].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("tile", ["5", "4", "0"])
-@pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40), (645, 264, 96), (1931, 1032, 1056)])
+@pytest.mark.parametrize("tile", ["5", "4", "0", "9"])
+@pytest.mark.parametrize("M,N,K", [(700, 520, 200), (333, 264, 72), (1024, 768, 768), (97, 8, 40), (645, 264, 96), (1931, 1032, 1056),
+                                   (1000, 520, 192), (2241, 776, 320)])
 @pytest.mark.parametrize("loop", [-1, 0, 2])
 def test_bf16_gemm_kernels_on_ragged_shapes(tile, M, N, K, loop, tuning):
     """pv_gemm_bias against an fp32 torch reference on shapes that are multiples of nothing: partial row / column
     tiles, K that ends inside a 64-byte slab (K = 200, 72, 40: the barrier-then-fetch loop) or is a whole number of
     slabs not divisible by the 4-step unrolling (K = 96, 1056: the software-pipelined loop unless gemm_loop = 0),
-    N = 8 (one 16-byte chunk)."""
+    N = 8 (one 16-byte chunk); K = 192, 320, 768: whole 128-byte slabs, an odd number of them too (the full-line loops; tile 9 =
+    the four-wave 320 x 256 kernel, which takes exactly these and leaves the rest to the eight-wave one)."""
     import ctypes as C
     tuning("gemm_tile", int(tile))
     tuning("gemm_loop", loop)
@@ -627,13 +629,13 @@ def _digests(model, bs_list):
 
 
 def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning):
-    """At 77 and 300 images (partial row tiles in every GEMM) the three bf16 GEMM kernels -- 128 x 128 (v4), 256 x 256 and
-    320 x 256 (v7) -- must give BIT-identical digests over all 214 cache tensors: they accumulate every output element
+    """At 77 and 300 images (partial row tiles in every GEMM) the bf16 GEMM kernels -- 128 x 128 (v4), 256 x 256 and
+    320 x 256 on eight waves (v7), 320 x 256 on four (v9) -- must give BIT-identical digests over all 214 cache tensors: they accumulate every output element
     in the same K order and share one activation / rounding sequence (act_any in gemm.hip).  Consequence, checked last:
     an image's cache rows are the same bits at bs = 1 (v4 picked) and inside a 300-image batch (v7 picked)."""
     model, arch, _ = build("clip-vit-b32", torch.bfloat16)
     ref = None
-    for tile, loop in ((None, -1), (0, -1), (4, -1), (5, -1), (4, 0), (5, 0), (4, 2), (5, 2)):   # loop 0: barrier-then-fetch K loop, -1: pipelined, 2: full-line slabs
+    for tile, loop in ((None, -1), (0, -1), (4, -1), (5, -1), (4, 0), (5, 0), (4, 2), (5, 2), (9, -1)):   # loop 0: barrier-then-fetch K loop, -1: pipelined, 2: full-line slabs; tile 9: four waves
         tuning("reset")
         if tile is not None:
             tuning("gemm_tile", tile)

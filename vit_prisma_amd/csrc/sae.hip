@@ -316,13 +316,18 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out,
     float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
     float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm,
-    const float* __restrict__ pre_sum = nullptr, const float* __restrict__ addend = nullptr) {
+    const float* __restrict__ pre_sum = nullptr, const float* __restrict__ addend = nullptr, float dh_add = 0.f,
+    const uint32_t* __restrict__ tok_cnt = nullptr, const uint32_t* __restrict__ gate = nullptr) {
+    // the sparse form of the ReLU + L1 step (pv_sae_relu_step): k = the per-token capacity, tok_cnt[n] = the pairs token n holds
+    // (front-packed; the rest of the row are holes), dh_add = l1_coefficient / N_global (the L1 term's gradient on every kept
+    // activation, sae.py:617-626), gate: the step's mode word -- nonzero = the step runs on the dense GEMMs, leave at once
     // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term x_in @ W_skip^T or nullptr
     // inv_norm != nullptr: set_decoder_norm_to_unit_norm is pending -- W_dec still holds the un-normalised rows and row j
     // stands for W_dec[j] * inv_norm[j] (the Adam kernel writes the normalised + updated row; see pv_sae_step)
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
+    if (gate && *gate != 0u) return;
     bool ok[V4];
     int col[V4];
 #pragma unroll
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     for (int i = 0; i < V4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* ir = idx + (int64_t)n * k;
     const float* vr = val + (int64_t)n * k;
+    const int k_walk = tok_cnt ? min(k, (int)((tok_cnt[n] + 3u) & ~3u)) : k;       // (slots beyond it are holes)
     if constexpr (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < V4; ++i) acc[i] = ld4(pre_sum + (int64_t)n * d + col[i], ok[i]);
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
 #pragma unroll
         for (int i = 0; i < V4; ++i) acc[i] = ld4(addend + (int64_t)n * d + col[i], ok[i]);
     }
-    for (int s = 0; MODE != 2 && s < k; s += 4) {
+    for (int s = 0; MODE != 2 && s < k_walk; s += 4) {
         float a[4];
         float4 w[4][V4];
 #pragma unroll
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     lsum = wave_sum(lsum);
     if (lane == 0) loss_partial[n] = lsum;
     if (!want_grad) return;
-    for (int s = 0; s < k; s += 4) {
+    for (int s = 0; s < k_walk; s += 4) {
         float dot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -415,15 +421,17 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
         // TopK backward: gradient reaches only selected entries; ReLU gate on the kept value
         if (lane < 4 && s + lane < k) {
             const float dsel = lane == 0 ? dot[0] : (lane == 1 ? dot[1] : (lane == 2 ? dot[2] : dot[3]));
-            dh[(int64_t)n * k + s + lane] = vr[s + lane] > 0.f ? dsel : 0.f;
+            dh[(int64_t)n * k + s + lane] = vr[s + lane] > 0.f ? dsel + dh_add : 0.f;
         }
     }
 }
 
 // deterministic scalar reduction: out[slot] = scale * sum(v[0..n))
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ v, float* __restrict__ out, int n,
-                                                         float scale, int slot, int slot2) {
+                                                         float scale, int slot, int slot2, const uint32_t* __restrict__ gate = nullptr,
+                                                         uint32_t want = 0u) {
     __shared__ float red[4];
+    if (gate && *gate != want) return;                          // (pv_sae_relu_step: only in the mode this sum belongs to)
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += v[i];
     s = block_sum_256(s, red);
@@ -517,7 +525,9 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
                                                        int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
-                                                       float* __restrict__ rowsq_sparse, int ranged) {
+                                                       float* __restrict__ rowsq_sparse, int ranged,
+                                                       const uint32_t* __restrict__ gate = nullptr) {
+    if (gate && *gate != 0u) update_stats = 0;                    // (pv_sae_relu_step in dense mode: the dense path owns the statistics)
     const int j = blockIdx.x * 256 + threadIdx.x;
     {   // the cuts at and beyond the total (all threads of the grid: a feature shard of the feature-parallel step keeps a
         // fraction of the N k pairs the cut array is sized for -- 7 of 8 cuts lie beyond the total at world 8)
@@ -703,10 +713,11 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
     const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    float* __restrict__ rowsq, int d, int k, int n_chunks) {
+    float* __restrict__ rowsq, int d, int k, int n_chunks, const uint32_t* __restrict__ gate = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= n_chunks) return;
+    if (gate && *gate != 0u) return;
     const uint32_t q0 = chunk_start[wv], q1 = chunk_start[wv + 1];
     if (q0 >= q1) return;
     bool ok[V4];
@@ -791,7 +802,8 @@ __global__ __launch_bounds__(512) void sae_backward_seg_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ seg_range, const uint32_t* __restrict__ n_long,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ seg_rows,
-    float* __restrict__ seg_b, int d, int k, int max_segs, int ranged) {
+    float* __restrict__ seg_b, int d, int k, int max_segs, int ranged, const uint32_t* __restrict__ gate = nullptr) {
+    if (gate && *gate != 0u) return;                               // (uniform over the grid: no barrier is skipped by a part of a workgroup)
     constexpr int NW = 8;                                          // waves per workgroup (token-range form: 512 threads)
     __shared__ __attribute__((aligned(16))) float part[NW * 2 * 256 * V4];      // [wave][gd | ge][256 V4] (token-range form)
     __shared__ float part_b[NW];
@@ -871,7 +883,8 @@ template <int V4>
 __global__ __launch_bounds__(256) void sae_backward_long_kernel(
     const int32_t* __restrict__ long_list, const uint32_t* __restrict__ n_long, const float* __restrict__ seg_rows,
     const float* __restrict__ seg_b, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    float* __restrict__ rowsq, int d, int max_segs) {
+    float* __restrict__ rowsq, int d, int max_segs, const uint32_t* __restrict__ gate = nullptr) {
+    if (gate && *gate != 0u) return;
     const int lane = threadIdx.x & 63;
     const uint32_t nl = n_long[0];
     bool ok[V4];
@@ -920,9 +933,11 @@ __global__ __launch_bounds__(256) void sae_backward_long_kernel(
 template <int V4>
 __global__ __launch_bounds__(256) void sae_zero_empty_kernel(const uint32_t* __restrict__ offs, float* __restrict__ gW_dec,
                                                              float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-                                                             float* __restrict__ rowsq, int d_sae, int d) {
+                                                             float* __restrict__ rowsq, int d_sae, int d,
+                                                             const uint32_t* __restrict__ gate = nullptr) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gate && *gate != 0u) return;
     if (j >= d_sae || offs[j + 1] != offs[j]) return;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1395,6 +1410,31 @@ SaeWs sae_carve(const pv_sae_desc& d) {
     return w;
 }
 
+// The buffers of the sparse ReLU + L1 step that depend on its per-token capacity (pv_sae_relu_step; caller-owned workspace)
+ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap) {
+    ReluWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    const size_t N = (size_t)n_tokens, P = N * (size_t)cap, ntn = (size_t)(d.d_sae + 255) / 256;
+    w.mode = take(256);
+    w.idx = take(P * 4);
+    w.val = take(P * 4);
+    w.tok_cnt = take(N * 4);
+    w.l1part = take(N * 4);
+    w.cand_cnt = take(N * ntn * 4);
+    w.cand = take(N * ntn * (size_t)PV_SAE_RELU_SLOTS * 8);
+    w.dh = take(P * 4);
+    w.cursor = take((P / BWD_CH + 8) * 4);
+    w.wpos = take(P * 4);
+    w.max_segs = (int)sae_max_segs(P);
+    w.seg_range = take((size_t)w.max_segs * 8);
+    w.seg_rows = take((size_t)w.max_segs * 2 * (size_t)d.d_in * 4);
+    w.seg_b = take((size_t)w.max_segs * 4);
+    w.pairs = take(P * 4);
+    w.total = off + 256;
+    return w;
+}
+
 extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan) {
     PV_REQUIRE(desc && out_plan, "null argument");
     PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 16 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1024");
@@ -1586,8 +1626,9 @@ int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* 
 }
 
 // out[slot] (and out[slot2] when >= 0) = scale * sum(v[0..n)), one workgroup, fixed order
-void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v, out, n, scale, slot, slot2);
+void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream, const uint32_t* gate,
+                    uint32_t want) {
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, v, out, n, scale, slot, slot2, gate, want);
 }
 
 // want_csr: also count the kept pairs per feature (ws.cnt) and record their positions (ws.wpos) for the backward
@@ -1670,6 +1711,96 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
     return PV_OK;
 }
 
+// Everything of the k-sparse step behind the selection: decode + LN-out + loss + dY + dh, the CSR by feature, the sparse backward,
+// the bias gradients.  Shared by pv_sae_step (k = the plan's k) and by the sparse form of the ReLU + L1 step (pv_sae_relu_step:
+// k = the per-token capacity, tok_cnt / dh_add / gate as described at sae_decode_kernel; the k-dependent buffers come in through tb).
+int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
+                    const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
+                    const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
+                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream) {
+    const pv_sae_desc& d = plan->d;
+    const int n_pairs = N * k;
+    int rc = PV_OK;
+    float* dY = (float*)(wsb + ws.dY);
+    float* dh = tb.dh;
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
+        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        const dim3 grid((N + 3) / 4), block(256);
+#define CALL(D)                                                                                                      \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
+                       topk_idx, topk_val, (const float*)(wsb + ws.mu),      \
+                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, dY, dh,             \
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip, dh_add, tok_cnt, gate)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel");
+        // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), scalars, N,
+                           1.0f / ((float)n_global * (float)d.d_in), 1, 0);                  // scalars[0] = loss == scalars[1] = mse
+        // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
+        uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
+        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
+        uint32_t* chunk_start = tb.chunk_start;
+        int32_t* pairs = tb.pairs;
+        int32_t* long_list = (int32_t*)(wsb + ws.long_list);
+        uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
+        const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
+        float* rowsq = (float*)(wsb + ws.rowsq);
+        const int max_segs = tb.max_segs;
+        uint32_t* seg_range = tb.seg_range;
+        float* seg_rows = tb.seg_rows;
+        float* seg_b = tb.seg_b;
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
+                           scalars, 1.0f / (float)N);
+        hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
+                           max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
+                           fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr,
+                           sae_long_ranged(N) ? 1 : 0, gate);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, topk_idx,
+                           (const uint32_t*)tb.wpos, (const uint32_t*)offs, pairs, n_pairs);
+        hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
+        const int ranged = sae_long_ranged(N) ? 1 : 0;
+        if (ranged) {
+            rc = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
+            if (rc) return rc;
+        }
+        PV_LAUNCH_CHECK("csr kernels");
+        const dim3 gridf((max_chunks + 3) / 4);
+        // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
+        // the long-list combine.  PV_SAE_SPARSE_GRADS: the rows of features no token kept are not touched at all -- pv_sae_apply
+        // takes their gradient as zero from the feature offsets this step leaves in the workspace (about half of the features
+        // on a trained-like batch: 2 x 39 MB not written here and not read there)
+        plan->live_offs = sparse ? offs : nullptr;
+#define CALL(D)                                                                                                        \
+    if (!sparse)                                                                                                       \
+        hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
+                           st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in, gate);                                         \
+    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
+                       (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh, \
+                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks, gate); \
+    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
+                       (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx, \
+                       topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
+                       d.d_in, k, max_segs, ranged, gate);                                                                       \
+    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
+                       (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
+                       st->gb_enc, rowsq, d.d_in, max_segs, gate)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_backward_kernel");
+        // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
+        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        if (rc) return rc;
+        if (tc) {
+            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+            if (rc) return rc;
+        }
+    }
+    return PV_OK;
+}
+
 extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
                            int32_t n_global, int32_t flags, pv_sae_out* out, void* workspace,
                            size_t workspace_bytes, void* stream_) {
@@ -1723,83 +1854,13 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     const float* y = tc ? st->tc.target : x;
     const float* bdo = tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec;
 
-    float* dY = (float*)(wsb + ws.dY);
-    float* dh = (float*)(wsb + ws.dh);
-    float* sae_in = (float*)(wsb + ws.sae_in);
-    {
-        ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
-        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
-        const dim3 grid((N + 3) / 4), block(256);
-#define CALL(D)                                                                                                      \
-    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
-                       (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)(wsb + ws.mu),      \
-                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, dh,             \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip)
-        V4_DISPATCH(d.d_in, CALL);
-#undef CALL
-        PV_LAUNCH_CHECK("sae_decode_kernel");
-        // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), out->scalars, N,
-                           1.0f / ((float)n_global * (float)d.d_in), 1, 0);                  // scalars[0] = loss == scalars[1] = mse
-        // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
-        uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
-        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
-        uint32_t* chunk_start = (uint32_t*)(wsb + ws.cursor);
-        int32_t* pairs = (int32_t*)(wsb + ws.pairs);
-        int32_t* long_list = (int32_t*)(wsb + ws.long_list);
-        uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
-        const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
-        float* rowsq = (float*)(wsb + ws.rowsq);
-        const int max_segs = (int)sae_max_segs((size_t)n_pairs);
-        uint32_t* seg_range = (uint32_t*)(wsb + ws.seg_range);
-        float* seg_rows = (float*)(wsb + ws.seg_rows);
-        float* seg_b = (float*)(wsb + ws.seg_b);
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
-                           out->scalars, 1.0f / (float)N);
-        hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
-                           max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
-                           out->fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr,
-                           sae_long_ranged(N) ? 1 : 0);
-        hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, (const int32_t*)out->topk_idx,
-                           (const uint32_t*)(wsb + ws.wpos), (const uint32_t*)offs, pairs, n_pairs);
-        hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
-        const int ranged = sae_long_ranged(N) ? 1 : 0;
-        if (ranged) {
-            rc = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
-            if (rc) return rc;
-        }
-        PV_LAUNCH_CHECK("csr kernels");
-        const dim3 gridf((max_chunks + 3) / 4);
-        // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
-        // the long-list combine.  PV_SAE_SPARSE_GRADS: the rows of features no token kept are not touched at all -- pv_sae_apply
-        // takes their gradient as zero from the feature offsets this step leaves in the workspace (about half of the features
-        // on a trained-like batch: 2 x 39 MB not written here and not read there)
-        plan->live_offs = sparse ? offs : nullptr;
-#define CALL(D)                                                                                                        \
-    if (!sparse)                                                                                                       \
-        hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
-                           st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in);                                               \
-    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
-                       (const int32_t*)pairs, (const int32_t*)out->topk_idx, (const float*)out->topk_val, (const float*)dh, \
-                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks); \
-    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
-                       (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, (const int32_t*)out->topk_idx, \
-                       (const float*)out->topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
-                       d.d_in, k, max_segs, ranged);                                                                             \
-    hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
-                       (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
-                       st->gb_enc, rowsq, d.d_in, max_segs)
-        V4_DISPATCH(d.d_in, CALL);
-#undef CALL
-        PV_LAUNCH_CHECK("sae_backward_kernel");
-        // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
-        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
-        if (rc) return rc;
-        if (tc) {
-            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
-            if (rc) return rc;
-        }
-    }
+    SaeTail tb;
+    tb.dh = (float*)(wsb + ws.dh); tb.chunk_start = (uint32_t*)(wsb + ws.cursor); tb.wpos = (uint32_t*)(wsb + ws.wpos);
+    tb.seg_range = (uint32_t*)(wsb + ws.seg_range); tb.seg_rows = (float*)(wsb + ws.seg_rows); tb.seg_b = (float*)(wsb + ws.seg_b);
+    tb.pairs = (int32_t*)(wsb + ws.pairs); tb.max_segs = (int)sae_max_segs((size_t)n_pairs);
+    rc = sae_sparse_tail(plan, st, x, N, n_global, k, out->topk_idx, out->topk_val, out->sae_out, out->scalars, out->fire_count,
+                         update_stats, sparse, inv_norm, tb, wsb, ws, y, bdo, skip, tc, 0.0f, nullptr, nullptr, stream);
+    if (rc) return rc;
     return PV_OK;
 }
 

@@ -58,12 +58,39 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
 void sae_topk_rows(const float* hidden, int32_t* idx_out, float* val_out, int d_sae, int k, int n_rows, const int32_t* row_list,
                    const uint32_t* n_list, int slots, uint32_t* feat_cnt, uint32_t* wpos, hipStream_t stream);
 
+// ---- the sparse form of the ReLU + L1 step (pv_sae_relu_step, sae_dense.hip) -------------------------------------------------
+constexpr int PV_SAE_RELU_SLOTS = 32;        // candidate slots per (token, 256-feature tile) of the ReLU filter
+constexpr int PV_SAE_RELU_CAP_MAX = 256;     // kept activations per token the sparse form can hold, at most
+// the fp16 filter + exact re-scoring applies (otherwise pv_sae_relu_step always runs the dense GEMMs)
+static inline bool pv_sae_relu_sparse_ok(const pv_sae_desc& d) {
+    return d.d_sae % 256 == 0 && d.d_sae >= 2048 && d.d_in % 8 == 0 && d.d_in >= 32 && !g_pv_tuning.sae_exact;
+}
+struct SaeTail {                             // the k-dependent buffers of sae_sparse_tail
+    float* dh; uint32_t* chunk_start; uint32_t* wpos; uint32_t* seg_range; float* seg_rows; float* seg_b; int32_t* pairs;
+    int max_segs;
+};
+struct ReluWs {
+    size_t total, mode, idx, val, tok_cnt, l1part, cand_cnt, cand, dh, cursor, wpos, seg_range, seg_rows, seg_b, pairs;
+    int max_segs;
+};
+ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap);
+// sae_enc.hip: the positive entries of relu(sae_in W_enc + b_enc) per token (see the definition); raises *mode when a token cannot be held
+int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
+                    float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
+                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+// sae.hip: everything of the k-sparse step behind the selection (see the definition)
+int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
+                    const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
+                    const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
+                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream);
+
 // sae.hip, shared with sae_dense.hip: see the definitions
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
              unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
               hipStream_t stream);
-void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream);
+void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream,
+                    const uint32_t* gate = nullptr, uint32_t want = 0u);
 int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);
 // transcoder (pv_sae_state.tc, sae/transcoder.py): helpers shared by the top-k step (sae.hip) and the dense step (sae_dense.hip)
 static inline bool sae_is_tc(const pv_sae_state* st) { return st->tc.b_dec_out != nullptr; }

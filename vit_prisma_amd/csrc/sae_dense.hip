@@ -26,6 +26,7 @@
 // row-contiguous k-slices ([K][rows]: four 4-byte LDS reads, lanes on consecutive rows).  f^T, dH^T, dY and sae_in of G4 / G5
 // are therefore the buffers as they lie, read "the other way".
 #include "sae.hpp"
+#include <cstring>
 
 namespace {
 
@@ -62,6 +63,9 @@ struct DenseGemm {
     const float* cscale;
     float* out2;
     float* colpart2;
+    // pv_sae_relu_step: the step's mode word (device).  Non-NULL: the kernel runs only when *gate == 1 (the sparse attempt could not
+    // hold the batch); NULL: always.
+    const uint32_t* gate;
 };
 
 // 16 bytes from global memory, or zeros (a plain branch: `ok ? *p : zero` makes hipcc select between two ADDRESSES and park the
@@ -75,6 +79,7 @@ __device__ __forceinline__ uint4 ld16_or_zero(const float* ptr, bool ok) {
 template <bool A_KM, bool B_KN, int EPI>
 __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (p.gate && *p.gate != 1u) return;                   // (uniform over the grid)
     unsigned char* As = smem;
     unsigned char* Bs = smem + 2 * DG_TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,8 +336,9 @@ int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
 __global__ __launch_bounds__(256) void dense_colreduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ out,
                                                               float* __restrict__ out2, float* __restrict__ act_freq,
                                                               float* __restrict__ n_since_fired, int update_stats,
-                                                              float* __restrict__ block_tot) {
+                                                              float* __restrict__ block_tot, const uint32_t* __restrict__ gate = nullptr) {
     __shared__ float red[4];
+    if (gate && *gate != 1u) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
     if (j < d) {
@@ -359,8 +365,10 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            const float* __restrict__ sd, const float* __restrict__ norm,
                                                            float* __restrict__ sae_out, float* __restrict__ dY,
                                                            float* __restrict__ loss_partial, int n_tok, int d, float grad_scale,
-                                                           float* __restrict__ err_out, const float* __restrict__ addend) {
+                                                           float* __restrict__ err_out, const float* __restrict__ addend,
+                                                           const uint32_t* __restrict__ gate = nullptr) {
     // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term or nullptr
+    if (gate && *gate != 1u) return;
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -393,7 +401,8 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
 }
 
 // scalars[0] = mse + l1 (+ ghost) (sae.py:628), one thread
-__global__ void dense_loss_kernel(float* __restrict__ scalars, int ghost) {
+__global__ void dense_loss_kernel(float* __restrict__ scalars, int ghost, const uint32_t* __restrict__ gate = nullptr, uint32_t want = 1u) {
+    if (gate && *gate != want) return;
     if (!ghost) scalars[5] = 0.f;
     scalars[0] = scalars[1] + scalars[4] + scalars[5];
 }
@@ -529,12 +538,10 @@ extern "C" size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t 
     return ghost_carve(plan->d, n_tokens, n_dead).total;
 }
 
-// One train step of the ReLU + L1 SAE on N tokens: forward + backward + statistics; gradients are WRITTEN into st->g*
-// (complete buffers: pv_sae_grad_sqnorm and pv_sae_apply follow as usual).  scalars: 0 loss, 1 mse_loss, 2 l0, 4 l1_loss.
-extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
-                                 int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
-                                 void* workspace, size_t workspace_bytes, void* stream_) {
-    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+namespace {
+// validation shared by pv_sae_dense_step and pv_sae_relu_step
+int dense_require(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t n_global, int update_stats, pv_sae_out* out,
+                  void* workspace) {
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->scalars, "pv_sae_out.scalars");
     PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
@@ -544,48 +551,44 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
     PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
     PV_REQUIRE(d.d_in % 8 == 0 && d.d_sae % 8 == 0, "the dense step needs d_in and d_sae to be multiples of 8");
-    // ghost gradients (sae.py:151-179; train_sae.py:337-346): the caller lists the dead features (n_forward_passes_since_fired
-    // > dead_feature_window BEFORE this step's statistics) and owns the extra workspace
-    GhostWs gw = {};
-    unsigned char* gwb = nullptr;
-    const int nd = ghost ? ghost->n_dead : 0;
-    if (ghost) {
-        PV_REQUIRE(n_global == N, "ghost gradients: single process only");
-        PV_REQUIRE(nd >= 0 && nd <= d.d_sae && ghost->workspace && (nd == 0 || (ghost->dead_idx && ghost->dead_slot)), "pv_sae_ghost");
-        gw = ghost_carve(d, N, nd);
-        PV_REQUIRE(ghost->workspace_bytes >= gw.total && ((uintptr_t)ghost->workspace & 255) == 0, "ghost workspace too small / misaligned");
-        gwb = (unsigned char*)ghost->workspace;
-    }
-    const SaeWs ws = sae_carve(d);
-    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
-    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
+    return PV_OK;
+}
+
+// renorm (flags), LN-in / sae_in / loss normaliser, the transcoder's target normaliser and skip term: what both forms of the
+// ReLU + L1 step start from
+int dense_prepare(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, const float* batch_mean, int flags, bool want_filter_inputs,
+                  unsigned char* wsb, const SaeWs& ws, const float** skip, void* stream_) {
+    const pv_sae_desc& d = plan->d;
     hipStream_t stream = (hipStream_t)stream_;
-    unsigned char* wsb = (unsigned char*)workspace;
     plan->live_offs = nullptr;
     plan->renorm_pending = false;
-    const int F = d.d_sae, D = d.d_in;
-
     // set_decoder_norm_to_unit_norm (train_sae.py:307): the dense GEMMs read W_dec as it lies, so the rows are rewritten here
     if (flags & PV_SAE_RENORM_DECODER) {
         int rc = pv_sae_renorm_decoder(plan, st, stream_);
         if (rc) return rc;
     }
-    // transcoder (pv_sae_state.tc): loss against tc.target, the decoder adds b_dec_out and the skip term
-    const bool tc = sae_is_tc(st);
-    if (tc) {
-        PV_REQUIRE(!ghost, "transcoder: no ghost gradients");
-        const int rq = sae_tc_require(d, st, N);
-        if (rq) return rq;
-    }
-    int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, false, wsb, ws, stream);
+    int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, want_filter_inputs, wsb, ws, stream);
     if (rc) return rc;
-    const float* skip = nullptr;
-    if (tc) {
+    *skip = nullptr;
+    if (sae_is_tc(st)) {
         rc = sae_tc_target_norm(d, st, batch_mean, N, wsb, ws, stream);
         if (rc) return rc;
-        rc = sae_tc_skip_forward(d, st, x, N, &skip, stream);
+        rc = sae_tc_skip_forward(d, st, x, N, skip, stream);
         if (rc) return rc;
     }
+    return PV_OK;
+}
+
+// The five GEMMs + their small kernels (see the file header); `gate` as in DenseGemm.
+int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t n_global, int update_stats,
+                    float l1_coefficient, const pv_sae_ghost* ghost, const GhostWs& gw, pv_sae_out* out, unsigned char* wsb,
+                    const SaeWs& ws, const float* skip, const uint32_t* gate, hipStream_t stream) {
+    const pv_sae_desc& d = plan->d;
+    const int F = d.d_sae, D = d.d_in;
+    const bool tc = sae_is_tc(st);
+    unsigned char* gwb = ghost ? (unsigned char*)ghost->workspace : nullptr;
+    const int nd = ghost ? ghost->n_dead : 0;
+    int rc = PV_OK;
     float* f = (float*)(wsb + ws.hidden);                  // [N][F]: f, later dH
     float* sae_in = (float*)(wsb + ws.sae_in);
     float* dY = (float*)(wsb + ws.dY);
@@ -602,7 +605,7 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         // (W_enc is read as its transposed fp32 master W_encT [F][D] -- the copy Adam runs in, always current; the parameter's
         // own layout may be materialised lazily)
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
-        g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart;
+        g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart; g.gate = gate;
         if (nd > 0) {
             PV_HIP_CHECK(hipMemsetAsync(gwb + gw.dead_act, 0, (size_t)N * gw.n_pad * 4, stream));       // (padding columns stay zero)
             g.dead_slot = ghost->dead_slot; g.dead_act = (float*)(gwb + gw.dead_act); g.ldd = gw.n_pad;
@@ -612,10 +615,10 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         // firing counts, statistics, l0, l1
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
                            out->fire_count ? out->fire_count : (float*)(wsb + ws.rowsq), (float*)nullptr, st->act_freq_scores,
-                           st->n_fwd_since_fired, update_stats, blk_tot);
+                           st->n_fwd_since_fired, update_stats, blk_tot, gate);
         PV_LAUNCH_CHECK("dense_colreduce_kernel");
-        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream);                       // l0 (train_sae.py:364)
-        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)n_global, 4, -1, stream);  // l1_loss (sae.py:617-626)
+        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream, gate, 1u);                       // l0 (train_sae.py:364)
+        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)n_global, 4, -1, stream, gate, 1u);  // l1_loss (sae.py:617-626)
     }
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * N * (double)D * F, 0.0);
@@ -624,16 +627,16 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         DenseGemm g = {};
         g.A = f; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = N; g.N = D; g.K = F;
         g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
-        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)N * D;
+        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)N * D; g.gate = gate;
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
         const float grad_scale = 2.0f / ((float)n_global * (float)D);
         hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, tc ? st->tc.target : x, (const float*)kpart, S,
                            (int64_t)N * D, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, (const float*)(wsb + ws.mu),
                            (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
-                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip);
+                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate);
         PV_LAUNCH_CHECK("dense_finish_kernel");
-        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream);
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream, gate, 1u);
         if (ghost) {
             // ghost forward: G0 = exp(hidden_pre[:, dead]) @ W_dec[dead]; loss and d loss / d G0 per token; then the part of
             // d loss / d hidden_pre that reaches the dead columns, dHd = (dG0 @ W_dec[dead]^T) * exp(hidden_pre[:, dead])
@@ -668,11 +671,11 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
                 if (rc) return rc;
             }
         }
-        hipLaunchKernelGGL(dense_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, ghost ? 1 : 0);
+        hipLaunchKernelGGL(dense_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, ghost ? 1 : 0, gate, 1u);
         // G4: gW_dec = f^T @ dY
         DenseGemm g4 = {};
         g4.A = f; g4.lda = F; g4.B = dY; g4.ldb = D; g4.M = F; g4.N = D; g4.K = N; g4.k_chunk = N;
-        g4.out = st->gW_dec; g4.ldo = D;
+        g4.out = st->gW_dec; g4.ldo = D; g4.gate = gate;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
         if (nd > 0) {                                                 // gW_dec[dead] += exp(hidden_pre[:, dead])^T @ dG0
@@ -688,17 +691,17 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         // G3: dH = (dY @ W_dec^T + l1 / N) [f > 0], over f
         DenseGemm g3 = {};
         g3.A = dY; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
-        g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global;
+        g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global; g3.gate = gate;
         if (nd > 0) { g3.dead_slot = ghost->dead_slot; g3.dead_act = (float*)(gwb + gw.dhd); g3.ldd = gw.n_pad; }      // + the ghost term
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, st->gb_enc,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, gate);
         PV_LAUNCH_CHECK("dense_colreduce_kernel");
         // G5: gW_enc^T = dH^T @ sae_in
         DenseGemm g5 = {};
         g5.A = f; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
-        g5.out = st->gW_enc; g5.ldo = D;
+        g5.out = st->gW_enc; g5.ldo = D; g5.gate = gate;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
         rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
@@ -709,6 +712,145 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         }
     }
     return PV_OK;
+}
+
+// scalars[4] = l1_loss of the sparse form, scalars[5] = 0, scalars[0] = mse + l1 -- when the step ran sparse (*mode == 0)
+__global__ __launch_bounds__(256) void relu_sparse_scalars_kernel(const float* __restrict__ l1part, int n, float scale,
+                                                                  float* __restrict__ scalars, const uint32_t* __restrict__ mode) {
+    __shared__ float red[4];
+    if (*mode != 0u) return;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += l1part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l1 = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+        scalars[4] = l1;
+        scalars[5] = 0.f;
+        scalars[0] = scalars[1] + l1;
+    }
+}
+__global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+}  // namespace
+
+// One train step of the ReLU + L1 SAE on N tokens: forward + backward + statistics; gradients are WRITTEN into st->g*
+// (complete buffers: pv_sae_grad_sqnorm and pv_sae_apply follow as usual).  scalars: 0 loss, 1 mse_loss, 2 l0, 4 l1_loss.
+extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                                 int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    int rc = dense_require(plan, st, x, N, n_global, update_stats, out, workspace);
+    if (rc) return rc;
+    const pv_sae_desc& d = plan->d;
+    // ghost gradients (sae.py:151-179; train_sae.py:337-346): the caller lists the dead features (n_forward_passes_since_fired
+    // > dead_feature_window BEFORE this step's statistics) and owns the extra workspace
+    GhostWs gw = {};
+    const int nd = ghost ? ghost->n_dead : 0;
+    if (ghost) {
+        PV_REQUIRE(n_global == N, "ghost gradients: single process only");
+        PV_REQUIRE(nd >= 0 && nd <= d.d_sae && ghost->workspace && (nd == 0 || (ghost->dead_idx && ghost->dead_slot)), "pv_sae_ghost");
+        gw = ghost_carve(d, N, nd);
+        PV_REQUIRE(ghost->workspace_bytes >= gw.total && ((uintptr_t)ghost->workspace & 255) == 0, "ghost workspace too small / misaligned");
+    }
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
+    unsigned char* wsb = (unsigned char*)workspace;
+    if (sae_is_tc(st)) {
+        PV_REQUIRE(!ghost, "transcoder: no ghost gradients");
+        const int rq = sae_tc_require(d, st, N);
+        if (rq) return rq;
+    }
+    const float* skip = nullptr;
+    rc = dense_prepare(plan, st, x, N, batch_mean, flags, false, wsb, ws, &skip, stream_);
+    if (rc) return rc;
+    return dense_step_body(plan, st, x, N, n_global, update_stats, l1_coefficient, ghost, gw, out, wsb, ws, skip, nullptr, (hipStream_t)stream_);
+}
+
+// The same step, sparse where the batch allows it ("ReLU is top-k with threshold 0 and a variable k", sae_enc.hip: relu_select_kernel):
+// ONE product over all features -- the fp16 filter with the threshold -B_n and the exact fp32 re-scoring of its survivors -- gives
+// every token's positive activations as a list of at most sp->cap pairs; decode, CSR, the sparse backward and the bias gradients
+// then run on the k-sparse kernels of sae.hip with k = cap (the L1 term: sum of the kept values; its gradient l1 / N on every kept
+// pair).  A batch some token of which cannot be held (more positives than cap, a candidate slot overflow: the early, dense phase of
+// training; the published x64 SAEs with L0 ~ 600-2000) raises the step's device-side mode word, the sparse kernels leave at once
+// and the five dense GEMMs run instead -- decided on the GPU, no host round trip, same results either way (exact fp32 values on
+// both paths).  sp == NULL or a plan the filter does not cover: the dense step.
+extern "C" size_t pv_sae_relu_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap) {
+    if (!plan || n_tokens < 1 || cap < 4 || cap > PV_SAE_RELU_CAP_MAX || cap % 4) return 0;
+    return relu_carve(plan->d, n_tokens, cap).total;
+}
+
+extern "C" size_t pv_debug_sae_relu_offset(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap, const char* name) {
+    if (!plan || !name || n_tokens < 1 || cap < 4 || cap > PV_SAE_RELU_CAP_MAX || cap % 4) return (size_t)-1;
+    const ReluWs w = relu_carve(plan->d, n_tokens, cap);
+    if (!strcmp(name, "mode")) return w.mode;
+    if (!strcmp(name, "idx")) return w.idx;
+    if (!strcmp(name, "val")) return w.val;
+    if (!strcmp(name, "tok_cnt")) return w.tok_cnt;
+    return (size_t)-1;
+}
+
+extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                                int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp, pv_sae_out* out,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    int rc = dense_require(plan, st, x, N, n_global, update_stats, out, workspace);
+    if (rc) return rc;
+    const pv_sae_desc& d = plan->d;
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total, "workspace too small");
+    PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
+    unsigned char* wsb = (unsigned char*)workspace;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool tc = sae_is_tc(st);
+    if (tc) {
+        const int rq = sae_tc_require(d, st, N);
+        if (rq) return rq;
+    }
+    const bool sparse = sp && pv_sae_relu_sparse_ok(d) && st->W_enc16T && st->enc_colsq;
+    ReluWs rw = {};
+    unsigned char* rwb = nullptr;
+    if (sp) {
+        PV_REQUIRE(sp->cap >= 4 && sp->cap <= PV_SAE_RELU_CAP_MAX && sp->cap % 4 == 0, "pv_sae_relu_sparse.cap: a multiple of 4 in [4, 256]");
+        rw = relu_carve(d, N, sp->cap);
+        PV_REQUIRE(sp->workspace && sp->workspace_bytes >= rw.total && ((uintptr_t)sp->workspace & 255) == 0,
+                   "pv_sae_relu_sparse workspace too small / misaligned (pv_sae_relu_workspace_bytes)");
+        rwb = (unsigned char*)sp->workspace;
+    }
+    const float* skip = nullptr;
+    rc = dense_prepare(plan, st, x, N, batch_mean, flags, sparse, wsb, ws, &skip, stream_);
+    if (rc) return rc;
+    uint32_t* mode = sp ? (uint32_t*)(rwb + rw.mode) : nullptr;
+    if (sparse) {
+        const int cap = sp->cap;
+        int32_t* idx = (int32_t*)(rwb + rw.idx);
+        float* val = (float*)(rwb + rw.val);
+        uint32_t* tok_cnt = (uint32_t*)(rwb + rw.tok_cnt);
+        float* l1part = (float*)(rwb + rw.l1part);
+        {
+            ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae, ((double)N * d.d_in + (double)d.d_in * d.d_sae) * 2.0);
+            rc = sae_encode_relu(d, st, N, cap, idx, val, tok_cnt, l1part, (uint32_t*)(rwb + rw.cand_cnt), rwb + rw.cand,
+                                 (uint32_t*)(wsb + ws.cnt), (uint32_t*)(rwb + rw.wpos), mode, wsb, ws, stream);
+            if (rc) return rc;
+        }
+        SaeTail tb;
+        tb.dh = (float*)(rwb + rw.dh); tb.chunk_start = (uint32_t*)(rwb + rw.cursor); tb.wpos = (uint32_t*)(rwb + rw.wpos);
+        tb.seg_range = (uint32_t*)(rwb + rw.seg_range); tb.seg_rows = (float*)(rwb + rw.seg_rows); tb.seg_b = (float*)(rwb + rw.seg_b);
+        tb.pairs = (int32_t*)(rwb + rw.pairs); tb.max_segs = rw.max_segs;
+        rc = sae_sparse_tail(plan, st, x, N, n_global, cap, idx, val, out->sae_out, out->scalars, out->fire_count, update_stats,
+                             /*sparse grads*/ false, /*inv_norm*/ nullptr, tb, wsb, ws, tc ? (const float*)st->tc.target : x,
+                             tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, skip, tc, l1_coefficient / (float)n_global,
+                             tok_cnt, mode, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(relu_sparse_scalars_kernel, dim3(1), dim3(256), 0, stream, (const float*)l1part, N,
+                           l1_coefficient / (float)n_global, out->scalars, (const uint32_t*)mode);
+        PV_LAUNCH_CHECK("relu_sparse_scalars_kernel");
+    } else if (mode) {
+        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, mode, 1u);
+    }
+    GhostWs gw = {};
+    return dense_step_body(plan, st, x, N, n_global, update_stats, l1_coefficient, nullptr, gw, out, wsb, ws, skip, mode, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -690,6 +690,160 @@ __global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// ReLU encoder in sparse form (pv_sae_relu_step): f = relu(sae_in W_enc + b_enc) as per-token lists of its POSITIVE entries.
+// "ReLU is top-k with threshold 0 and a variable k": the same fp16 filter GEMM runs with the per-token threshold -B_n (the
+// error band of the fp16 product, see the file header: exact_j > 0  =>  a_j > -B_n), every survivor is re-scored EXACTLY in fp32
+// against W_encT, and the ones whose exact value is positive are the token's activations -- values those of the exact fp32
+// encoder.  A token's list holds at most `cap` pairs; a token with more positives than that, a candidate slot that overflowed or
+// more than PV_SAE_CAND_CAP survivors raise the step's `mode` word: the step then runs on the dense GEMMs instead (sae_dense.hip),
+// so nothing is ever approximated.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__ xnorm, const float* __restrict__ wmax_sq, int d_in,
+                                                       float* __restrict__ thr, int n_tok, uint32_t* __restrict__ mode) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n == 0) *mode = 0u;
+    if (n >= n_tok) return;
+    const float wmx = sqrtf(*wmax_sq);
+    const float c2 = 2.98023224e-8f * sqrtf((float)d_in);
+    const float B = xnorm[n] * (ENC_C1 * wmx + c2) + c2 * wmx;
+    thr[n] = (B == B) ? -B : -INFINITY;                        // (a NaN bound lets everything through: the slots overflow -> dense)
+}
+
+// One workgroup per token: candidates -> exact values -> the positive ones, ranked by (value desc, feature asc) -> idx / val /
+// wpos [cap] (holes: val 0, wpos ~0), tok_cnt, the token's sum of activations (the L1 term).
+template <int V4>
+__global__ __launch_bounds__(256) void relu_select_kernel(
+    const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
+    const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+    uint32_t* __restrict__ tok_cnt, float* __restrict__ l1part, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos,
+    uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots) {
+    __shared__ int32_t cidx[PV_SAE_CAND_CAP];
+    __shared__ float rval[PV_SAE_CAND_CAP];
+    __shared__ uint32_t tcnt[256];
+    __shared__ float sval[256];                              // the kept values in rank order (cap <= 256)
+    __shared__ float red[4];
+    __shared__ uint32_t sh_bad, sh_m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    uint32_t myc = 0;
+    if (tid < ntn) myc = tile_cnt[row * ntn + tid];
+    tcnt[tid] = tid < ntn ? myc : 0u;
+    if (tid == 0) { sh_bad = 0u; sh_m = 0u; }
+    __syncthreads();
+    if (tid < ntn && myc == 0xffffffffu) sh_bad = 1u;
+    __syncthreads();
+    bool bad = sh_bad != 0u;
+    uint32_t n = 0, off = 0;
+    if (!bad) {
+        for (int t = 0; t < ntn; ++t) {
+            const uint32_t c = tcnt[t];
+            off += t < tid ? c : 0u;
+            n += c;
+        }
+        bad = n > (uint32_t)PV_SAE_CAND_CAP;
+    }
+    if (!bad && tid < ntn && myc > 0u) {
+        const int2* src = cand + (row * ntn + tid) * slots;
+        for (uint32_t e = 0; e < myc; ++e) cidx[off + e] = src[e].x;
+    }
+    __syncthreads();
+    const uint32_t nr = bad ? 0u : n;
+    // exact fp32 re-scoring of every candidate: a wave per candidate, four in flight (as in sae_select_kernel)
+    bool ok[V4];
+    int col[V4];
+    float4 xr[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+        xr[i] = ok[i] ? *reinterpret_cast<const float4*>(sae_in + row * d + col[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (uint32_t c0 = wave; c0 < nr; c0 += 16) {
+        int jj[4];
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + 4 * u;
+            jj[u] = cidx[c < nr ? c : c0];
+            const float* w = W_encT + (int64_t)jj[u] * d;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                if (ok[i]) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + col[i]);
+                    a = fmaf(xr[i].x, wv.x, a); a = fmaf(xr[i].y, wv.y, a); a = fmaf(xr[i].z, wv.z, a); a = fmaf(xr[i].w, wv.w, a);
+                }
+            }
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
+        if (lane < 4) {
+            const uint32_t c = c0 + 4 * lane;
+            const float av = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+            const int jv = lane == 0 ? jj[0] : (lane == 1 ? jj[1] : (lane == 2 ? jj[2] : jj[3]));
+            if (c < nr) rval[c] = av + b_enc[jv];
+        }
+    }
+    __syncthreads();
+    // how many are positive (NaN counts as not positive, like torch's relu keeps NaN -- a NaN pre-activation poisons the dense path
+    // the same way: such a token is sent there)
+    uint32_t mine = 0;
+    bool nan_seen = false;
+    for (uint32_t c = tid; c < nr; c += 256) {
+        const float v = rval[c];
+        mine += v > 0.f ? 1u : 0u;
+        nan_seen = nan_seen || (v != v);
+    }
+    if (mine) atomicAdd(&sh_m, mine);
+    if (nan_seen) sh_bad = 1u;
+    __syncthreads();
+    const uint32_t m = sh_m;
+    bad = bad || sh_bad != 0u || m > (uint32_t)cap;
+    if (bad) {                                                 // (uniform) this token cannot be held: the whole step goes dense
+        if (tid == 0) { atomicOr(mode, 1u); tok_cnt[row] = 0u; l1part[row] = 0.f; }
+        for (int s = tid; s < cap; s += 256) {
+            idx_out[row * cap + s] = 0;
+            val_out[row * cap + s] = 0.f;
+            wpos[row * cap + s] = 0xffffffffu;
+        }
+        return;
+    }
+    sval[tid] = 0.f;
+    __syncthreads();
+    for (uint32_t c = tid; c < nr; c += 256) {
+        const float vc = rval[c];
+        if (!(vc > 0.f)) continue;
+        const int32_t ic = cidx[c];
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < nr; ++o) {
+            const float vo = rval[o];
+            rank += (vo > vc) || (vo == vc && cidx[o] < ic);
+        }
+        idx_out[row * cap + rank] = ic;
+        val_out[row * cap + rank] = vc;
+        wpos[row * cap + rank] = atomicAdd(&feat_cnt[ic], 1u);
+        sval[rank] = vc;
+    }
+    for (int s = (int)m + tid; s < cap; s += 256) {           // the rest of the row: holes
+        idx_out[row * cap + s] = 0;
+        val_out[row * cap + s] = 0.f;
+        wpos[row * cap + s] = 0xffffffffu;
+    }
+    __syncthreads();
+    // the token's L1 term, summed in rank order (the candidates arrive in whatever order the filter's LDS atomics drew)
+    const float lsum = wave_sum(sval[tid]);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        tok_cnt[row] = m;
+        l1part[row] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
     const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
     const dim3 grid(ntm * ntn), block(512);
@@ -755,5 +909,34 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
                        (const uint32_t*)fb_count, (float*)(wsb + ws.hidden), d.d_in, d.d_sae);
     PV_LAUNCH_CHECK("sae_fb_hidden_kernel");
     sae_topk_rows((const float*)(wsb + ws.hidden), topk_idx, topk_val, d.d_sae, d.k, N, fb_list, fb_count, PV_SAE_FB_SLOTS, feat_cnt, wpos, stream);
+    return PV_OK;
+}
+
+int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
+                    float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
+                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+    PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
+    PV_REQUIRE(cap >= 4 && cap <= PV_SAE_RELU_CAP_MAX && cap % 4 == 0, "cap");
+    float* wmax = (float*)(wsb + ws.wmax);
+    uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
+    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count, feat_cnt);
+    hipLaunchKernelGGL(relu_thr_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)(wsb + ws.xnorm), (const float*)wmax,
+                       d.d_in, (float*)(wsb + ws.thr), N, mode);
+    PV_LAUNCH_CHECK("relu_thr_kernel");
+    EncParams p = {};
+    p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
+    p.B = st->W_enc16T; p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes;
+    p.bias = st->b_enc; p.bias_stride = 1; p.out = nullptr; p.thr = (const float*)(wsb + ws.thr);
+    p.cnt = cand_cnt; p.cand = (int2*)cand; p.slots = PV_SAE_RELU_SLOTS;
+    int rc = launch_enc_gemm(1, p, stream);
+    if (rc) return rc;
+    const int ntn = d.d_sae / 256;
+#define CALL(D)                                                                                                                 \
+    hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                    \
+                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)cand_cnt, (const int2*)cand, idx, val, \
+                       tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
+    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
+#undef CALL
+    PV_LAUNCH_CHECK("relu_select_kernel");
     return PV_OK;
 }

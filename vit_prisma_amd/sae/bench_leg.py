@@ -48,13 +48,18 @@ def _pmc_step_traffic() -> dict:
 
 
 def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5, feature_parallel: bool = True,
-                  weak: bool = False, activation: str = "topk") -> dict:
+                  weak: bool = False, activation: str = "topk", relu_target_l0: Optional[float] = None) -> dict:
     """Step-only: ``VisionSAETrainer.train_step`` (the reference's call, train_sae.py:278-411) on batches resident in HBM.
     With a process group: feature_parallel (default) = the feature-sharded step of sae/feature_parallel.py (tokens / candidates
     all-gathered, partial reconstructions all-reduced; no gradient or parameter traffic); otherwise every rank takes 4096 / W
     tokens of the same global batch and the trainer's sharded-optimizer step runs (reduce-scatter of gradient rows, local
     clip / project / Adam on 1 / W of the features, asynchronous all-gather of the parameters).  weak: 4096 tokens per rank
-    (data parallel).  activation "relu": the ReLU + L1 SAE on the dense fused step (l1_coefficient 8e-5) instead of top-k."""
+    (data parallel).  activation "relu": the ReLU + L1 SAE (l1_coefficient 8e-5) instead of top-k, on pv_sae_relu_step -- sparse where
+    the batch allows it, the dense GEMMs otherwise, decided on the GPU; the leg counts the steps of either kind.  From the synthetic
+    init the first ~5 steps are dense (half of all features fire), then L0 collapses under the L1 term and the step runs sparse:
+    ``warmup`` decides which regime is timed.  relu_target_l0: shift b_enc so that a token keeps about that many features from the
+    first step on (e.g. 0.035 * d_sae: the L0 of the reference's published x64 SAEs, docs/sae_table.md:12-36) and stop the encoder
+    bias from training the regime away (lr 0: the step's arithmetic and traffic are those of training, the state stays put)."""
     from .config import VisionModelSAERunnerConfig
     from .sae import StandardSparseAutoencoder
     from .trainer import VisionSAETrainer
@@ -74,9 +79,18 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     with torch.no_grad():
         for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
             getattr(sae, n).copy_(torch.from_numpy(v))
+    if relu and relu_target_l0 is not None:
+        with torch.no_grad():
+            xb = torch.from_numpy(synth_sae_batch(512, D_IN, seed=0)).to(dev)
+            xh = (xb - xb.mean(-1, keepdim=True)) / (xb.std(-1, keepdim=True) + 1e-5)
+            h = (xh - sae.b_dec) @ sae.W_enc + sae.b_enc
+            sae.b_enc -= torch.quantile(h.flatten()[::97].float(), 1.0 - float(relu_target_l0) / D_SAE)
+            del xb, xh, h
+        cfg.lr = 0.0
     tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True)
     tr.use_feature_parallel(feature_parallel)
     st = list(tr.initialize_training_variables())                 # act_freq, n_since_fired, n_frac, optimizer, scheduler
+    n_dense = torch.zeros(1, dtype=torch.int32, device=dev)       # steps of the timed region that ran on the dense GEMMs (device-side count)
     batches = [torch.from_numpy(synth_sae_batch(n_global, D_IN, seed=i)).to(dev)[rank * n_local:(rank + 1) * n_local][:, None, :].contiguous()
                for i in range(4)]
     n_done = [0]
@@ -86,9 +100,12 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
             sparse_autoencoder=sae, optimizer=st[3], scheduler=st[4], act_freq_scores=st[0], n_forward_passes_since_fired=st[1],
             n_frac_active_tokens=st[2], layer_acts=x, n_training_steps=n_done[0], n_training_tokens=n_done[0] * n_global)
         n_done[0] += 1
+        if relu and getattr(tr._engine, "_relu_ws", None) is not None:
+            n_dense.add_(tr._engine.relu_mode)                    # (asynchronous: a device word added to a device counter)
 
     for i in range(warmup):
         step(batches[i % 4])
+    n_dense.zero_()
     torch.cuda.synchronize(dev)
     N.prof_reset()
     N.prof_enable(True)
@@ -117,20 +134,37 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     app = N.prof_read("sae_apply")
     ms_step = elapsed / steps * 1e3
     if relu:
-        # dense step: five fp32 MFMA GEMMs of 2 N d_in d_sae FLOP each (sae_dense.hip); bound by the fp32 matrix peak
-        flops = 10.0 * n_local * D_IN * D_SAE
-        tf = flops / (ms_step * 1e-3) / 1e12
+        dense_steps = int(n_dense.item())
+        sparse_steps = steps - dense_steps
+        # dense steps: five fp32 MFMA GEMMs of 2 N d_in d_sae FLOP each (sae_dense.hip), bound by the fp32 matrix peak; sparse steps:
+        # the top-k step's traffic (1.4 GB of algorithmic HBM bytes), bound by HBM
+        if dense_steps == steps:
+            flops = 10.0 * n_local * D_IN * D_SAE
+            tf = flops / (ms_step * 1e-3) / 1e12
+            roof = {"kernel": "whole step vs 10 N d_in d_sae FLOP (five dense fp32 GEMMs)", "bound": "mfma", "achieved": round(tf, 1),
+                    "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_TFLOPS, 4)}
+        elif dense_steps == 0:
+            gbs = 1.4e9 / (ms_step * 1e-3) / 1e9
+            roof = {"kernel": "whole step vs the 1.4 GB of algorithmic HBM bytes of a k-sparse step (SURVEY.md 8d)", "bound": "hbm",
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        else:
+            roof = {"kernel": "mixed: some steps dense (MFMA-bound), some sparse (HBM-bound) -- no single roof", "bound": "n/a",
+                    "achieved": None, "peak": None, "unit": None, "frac": None}
         return {
-            "metric": "SAE train-step tokens/sec, ReLU + L1 SAE (dense fused step, batches resident in HBM)",
+            "metric": "SAE train-step tokens/sec, ReLU + L1 SAE (pv_sae_relu_step: sparse where the batch allows, batches resident in HBM)",
             "value": round(n_global * steps / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_step, 3), "dtype": "f32",
             "config": {"workload": f"ReLU + L1 SAE 768 -> 24576 (32x), l1_coefficient 8e-5, {n_global} tokens per step, Adam, clip 1.0",
-                       "arithmetic": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs with fused ReLU / L1 / loss / gate epilogues"},
-            "final_loss": loss, "l0": float(eng.scalars[2].item()),
-            "roofline": {"kernel": "whole step vs 10 N d_in d_sae FLOP (five dense fp32 GEMMs)", "bound": "mfma", "achieved": round(tf, 1),
-                         "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_TFLOPS, 4)},
-            "kernels": {"encoder_gemm": {"avg_us": round(enc["ms"] * 1e3 / max(enc["launches"], 1), 1)},
-                        "decoder_and_backward_gemms": {"avg_us": round(bwd["ms"] * 1e3 / max(bwd["launches"], 1), 1)},
+                       "regime": (f"b_enc shifted to L0 ~ {relu_target_l0:g} per token, lr 0 (state held)" if relu_target_l0 is not None else
+                                  f"training run from the synthetic init, steps {warmup + 1}..{warmup + steps} timed (the first ~5 steps of "
+                                  "this run are dense: half of all features fire; the L1 term then collapses L0 to a few features)"),
+                       "arithmetic": "sparse steps: fp16 MFMA filter at the threshold -B_n + exact fp32 re-scoring, k-sparse kernels; dense "
+                                     "steps: exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32); exact fp32 values either way",
+                       "per_token_capacity": int(getattr(eng, "relu_cap", 0))},
+            "final_loss": loss, "l0": float(eng.scalars[2].item()), "sparse_steps": sparse_steps, "dense_steps": dense_steps,
+            "roofline": roof,
+            "kernels": {"encoder": {"avg_us": round(enc["ms"] * 1e3 / max(enc["launches"], 1), 1)},
+                        "decoder_and_backward": {"avg_us": round(bwd["ms"] * 1e3 / max(bwd["launches"], 1), 1)},
                         "clip_project_adam": {"avg_us": round(app["ms"] * 1e3 / max(app["launches"], 1), 1)}},
         }
     # algorithmic HBM bytes of one step, SURVEY.md 8(d): Adam 7 x 151.1 MB = 1.06 GB + W_enc / W_dec reads for forward and

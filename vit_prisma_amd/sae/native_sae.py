@@ -130,6 +130,8 @@ class NativeSAE:
         if self.gated:
             self._gt_scratch = torch.empty(self.lib.pv_sae_gated_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8, device=dev)
         self.adam_step = 0
+        self.relu_cap = 256                                        # per-token capacity of relu_step's sparse form
+        self._relu_ws: Optional[torch.Tensor] = None
         self._shadow_key: Optional[Tuple[int, int]] = None
         self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
         self._grad_fresh = False                                   # gradient buffers exactly as the last step wrote them
@@ -326,6 +328,61 @@ class NativeSAE:
         self._inv_norm_key = None
         self._grad_fresh = False
         self._grad_sparse = False
+
+    def relu_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
+                  n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
+                  renorm_decoder: bool = True, target: Optional[torch.Tensor] = None, cap: Optional[int] = None) -> None:
+        """The ReLU + L1 step, sparse where the batch allows it (pv_sae_relu_step): ONE fp16-filtered product over all features +
+        exact fp32 re-scoring gives every token's positive activations as a list of at most ``cap`` pairs and the k-sparse kernels do
+        the rest; a batch some token of which holds more than that runs on the dense GEMMs of ``dense_step`` instead -- decided on the
+        GPU (``relu_mode``: 0 sparse, 1 dense; a device word), same results either way.  Contract, scalars and follow-up calls as
+        ``dense_step`` (no ghost gradients: those stay with ``dense_step``)."""
+        x = self._check_x(x)
+        self._set_target(x, target)
+        self._ensure_shadows()
+        n = x.shape[0]
+        cap = int(cap if cap is not None else self.relu_cap)
+        key = (self.max_tokens, cap)
+        if getattr(self, "_relu_key", None) != key:
+            need = self.lib.pv_sae_relu_workspace_bytes(self._plan, self.max_tokens, cap)
+            if not need:
+                raise ValueError(f"relu_step: cap must be a multiple of 4 in [4, 256], got {cap}")
+            self._relu_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self._relu_key = key
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
+                       scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
+        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        sp = N.SaeReluSparse(cap=cap, reserved=0, workspace=self._relu_ws.data_ptr(), workspace_bytes=self._relu_ws.numel())
+        self._relu_last = (n, cap)
+        N.check(self.lib.pv_sae_relu_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                          int(n_global if n_global is not None else n),
+                                          int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient), C.byref(sp),
+                                          C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
+                "pv_sae_relu_step")
+        self._inv_norm_key = None
+        self._grad_fresh = False
+        self._grad_sparse = False
+
+    def _relu_region(self, name: bytes, dtype: torch.dtype, shape) -> torch.Tensor:
+        n, cap = self._relu_last
+        off = self.lib.pv_debug_sae_relu_offset(self._plan, n, cap, name)
+        numel = 1
+        for s_ in shape:
+            numel *= s_
+        return self._relu_ws[off:off + numel * 4].view(dtype).view(shape)
+
+    @property
+    def relu_mode(self) -> torch.Tensor:
+        """Device word of the last ``relu_step``: 0 = it ran sparse, 1 = on the dense GEMMs."""
+        return self._relu_region(b"mode", torch.int32, (1,))
+
+    def relu_pairs(self):
+        """(idx [N, cap] int32, val [N, cap], count [N] int32) of the last ``relu_step`` that ran sparse: token n keeps the features
+        idx[n, :count[n]] with the activations val[n, :count[n]] (value descending); for tests."""
+        n, cap = self._relu_last
+        return (self._relu_region(b"idx", torch.int32, (n, cap)), self._relu_region(b"val", torch.float32, (n, cap)),
+                self._relu_region(b"tok_cnt", torch.int32, (n,)))
 
     def gated_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False) -> None:

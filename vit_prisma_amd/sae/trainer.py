@@ -390,8 +390,12 @@ class VisionSAETrainer:
         def run(**kw):
             if gated:
                 eng.gated_step(x, l1, **kw)
-            else:
+            elif kw.get("dead_mask") is not None:                 # ghost gradients: exp(hidden_pre) of the dead columns is a dense quantity
                 eng.dense_step(x, l1, renorm_decoder=True, target=target, **kw)
+            else:
+                # sparse where the batch allows it, the dense GEMMs otherwise: the GPU decides (NativeSAE.relu_step)
+                kw.pop("dead_mask", None)
+                eng.relu_step(x, l1, renorm_decoder=True, target=target, **kw)
 
         if not self._mr:
             dead = None
