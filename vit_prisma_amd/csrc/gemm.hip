@@ -1559,7 +1559,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             p.M % (p.pG * p.pG) == 0 && img_bytes < 0xffffff00ull && (uint64_t)(p.N + 256) * p.ldb * EB < 0xffffff00ull &&
             !g_pv_tuning.gemm_v1 && !g_pv_tuning.gemm_v1patch) {
             const int pick = pick_v7(p);
-            if (pick == 5) return launch_v7<T, 5>(p, stream);
+            if (pick == 5 || pick == 9) return launch_v7<T, 5>(p, stream);      // (the four-wave kernel takes plain A operands only)
             if (pick == 4) return launch_v7<T, 4>(p, stream);
         }
     }

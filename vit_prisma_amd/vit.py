@@ -562,8 +562,9 @@ class HookedViT(HookedRootModule):
         # a hook at the very end fires only if its point is produced: "pre" of block n_blocks is not
         bounds = sorted(q for q in bh if q < end_pos or (q == end_pos and ("post" in bh[q] or "mlp" in bh[q])))
         if not bounds:
-            return nv.forward(self, x, names, n_blocks, run_head, cache_device=device,
-                              remove_batch_dim=remove_batch_dim, tap_dst=getattr(self, "_tap_dst", None))
+            tap_dst = getattr(self, "_tap_dst", None)             # (the activation store's own buffer slice, sae/store.py)
+            return nv.forward(self, x, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
+                              **({"tap_dst": tap_dst} if tap_dst else {}))
         # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
         # Stage t = the computation between positions t and t + 1 (of block t // NP): 0 ln1 | 1 q, k, v | 2 scores | 3 softmax |
         # 4 pattern v | 5 O-projection + residual | 6 ln2 | 7 MLP up to the pre-activation | 8 activation | 9 MLP output + residual.
