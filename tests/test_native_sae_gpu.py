@@ -333,8 +333,12 @@ def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
         ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=10 + t), None if relu else k, lr=1e-3, step=t + 1,
                            l1_coefficient=3e-3 if relu else 0.0)
         assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
+    # (relu_dp runs from the synthetic init, where half of all pre-activations are positive: a few of the 6.3 M per step lie within fp32
+    # summation noise of zero and take the other side of the ReLU than numpy's; Adam turns those entries into lr-sized differences --
+    # measured 1.8e-4 on W_enc after three steps with every loss within 1e-4)
+    ptol = 5e-4 if relu else TOL
     for n in P:
-        assert rel_fro(params[n], P[n]) < TOL, n
+        assert rel_fro(params[n], P[n]) < ptol, n
     assert np.abs(act - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
 
 
@@ -821,11 +825,11 @@ def test_dense_steps_see_an_outside_edit_of_w_enc(kind):
     out0, _ = run(eng)
     with torch.no_grad():
         T["W_enc"].mul_(0.5)                                       # the outside edit (bumps the version counter)
-    out1, sc1 = run(eng)
-    assert not torch.equal(out0, out1)
-    # a fresh engine over the edited parameters is the truth
+    # a fresh engine over a copy of the edited parameters is the truth (copied BEFORE the next step: a step renormalises W_dec in place)
     T2 = {m: v.clone() for m, v in T.items()}
     kw2 = {"gated": {m: v.clone() for m, v in kw["gated"].items()}} if kind == "gated" else {}
+    out1, sc1 = run(eng)
+    assert rel_fro(out0.cpu().numpy(), out1.cpu().numpy()) > 1e-2   # the edit reached the kernels
     ref = NativeSAE(T2["W_enc"], T2["W_dec"], T2["b_enc"], T2["b_dec"], 1, True, n, **kw2)
     out_ref, sc_ref = run(ref)
     assert torch.equal(out1, out_ref) and torch.equal(sc1[:3], sc_ref[:3])
@@ -1090,7 +1094,8 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln):
         tok_err = np.linalg.norm(got_out - fw["sae_out"], axis=1) / np.linalg.norm(fw["sae_out"], axis=1)
         off = tok_err > TOL
         if off.any():
-            assert off.sum() <= 4 and np.all(np.abs(fw["gate_pre"][off]).min(axis=1) < 2e-6 * np.abs(fw["gate_pre"]).max()), (off.sum(), tok_err.max())
+            # (at most a handful of the n * d_sae gates: 4 up to 8 M of them, 2e-7 of them beyond -- 7 of 100 M at 768 -> 24576 x 4096)
+            assert off.sum() <= max(4, int(2e-7 * n * d_sae)) and np.all(np.abs(fw["gate_pre"][off]).min(axis=1) < 2e-6 * np.abs(fw["gate_pre"]).max()), (off.sum(), tok_err.max())
             assert rel_fro(got_out, fw["sae_out"]) < 1e-3
             return
         assert rel_fro(got_out, fw["sae_out"]) < TOL
@@ -1431,9 +1436,10 @@ def test_relu_step_goes_dense_exactly_when_a_token_cannot_be_held(d_in, d_sae, n
     assert torch.allclose(sparse.scalars[:5], dense.scalars[:5], rtol=1e-5, atol=0) and torch.equal(sparse.fire_count, dense.fire_count)
     # the init state: 50 % of the features fire
     P0, _, _, T0 = fresh(d_in, d_sae)
+    T1 = {m: v.clone() for m, v in T0.items()}                  # (before any step: a step renormalises W_dec in place)
     eng = NativeSAE(T0["W_enc"], T0["W_dec"], T0["b_enc"], T0["b_dec"], 1, True, n)
     eng.relu_step(xg, l1c)
-    ref = NativeSAE(*(T0[m].clone() for m in ("W_enc", "W_dec", "b_enc", "b_dec")), 1, True, n)
+    ref = NativeSAE(T1["W_enc"], T1["W_dec"], T1["b_enc"], T1["b_dec"], 1, True, n)
     ref.dense_step(xg, l1c)
     torch.cuda.synchronize()
     assert int(eng.relu_mode.item()) == 1 and torch.equal(eng.flat_g, ref.flat_g) and torch.equal(eng.scalars, ref.scalars)

@@ -47,6 +47,8 @@ class SegmentBackend:
             e = torch.cat((m.cls_token.expand(images.shape[0], -1, -1), e), dim=1)
             tap("hook_pos_embed", m.pos_embed(images))
             resid = tap("hook_full_embed", e + m.pos_embed(images))
+            if cfg.layer_norm_pre:
+                resid = tap("hook_ln_pre", ln(m.ln_pre, resid, taps, "ln_pre", want))
         else:
             assert images is None
             resid = resid_in
@@ -135,23 +137,36 @@ class SegmentBackend:
             tap("hook_ln_final", x)
             x = m.head(x[:, 0])
             tap("hook_post_head_pre_normalize", x)
-            out = x
+            out = F.normalize(x, dim=-1) if cfg.normalize_output else x
         elif out is None:
             out = resid
         assert want <= set(taps), sorted(want - set(taps))
         return out, taps
 
 
-@pytest.fixture()
-def model():
+def _make_model(**extra):
     torch.manual_seed(0)
     cfg = HookedViTConfig(n_layers=3, d_model=16, d_head=8, d_mlp=32, n_heads=2, patch_size=P, image_size=S, n_classes=5,
-                          return_type="logits")
+                          return_type="logits", **extra)
     m = HookedViT(cfg).eval()
+    with torch.no_grad():                                 # (no parameter at its trivial initial value)
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
     backend = SegmentBackend()
     m._get_native = lambda device: backend
     m._backend = backend
     return m
+
+
+@pytest.fixture()
+def model():
+    return _make_model()
+
+
+@pytest.fixture()
+def model_ln_pre():
+    return _make_model(layer_norm_pre=True, normalize_output=True)
 
 
 def scale_shift(t, hook):
@@ -262,3 +277,59 @@ def test_split_plan_equals_the_hook_path(model, case):
                 a, b = g_cache[k_], w_cache[k_]
                 assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5, equal_nan=True), (k_, kw)
             assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+
+
+# ---- hooks on the embedding stage and on the final stage: those stages run on the model's own PyTorch modules (their HookPoints fire as
+# in the reference, base_vit.py:169-185, 192-217), every block stays on the plan -- resumed at block 0 from the residual stream the
+# embedding stage left, stopped before ln_final
+EDGE_CASES = [
+    [("hook_embed", scale_shift)],
+    [("hook_pos_embed", half), ("blocks.0.hook_resid_pre", zero_cls)],
+    [("hook_full_embed", zero_cls)],                                        # observe-only, but an in-place edit reaches the stream
+    [("blocks.0.hook_resid_pre", scale_shift)],
+    [("ln_final.hook_normalized", half)],
+    [("ln_final.hook_scale", freeze_scale)],
+    [("hook_ln_final", scale_shift)],                                       # observe-only: the return value is dropped
+    [("hook_post_head_pre_normalize", half)],
+    [("hook_embed", half), ("blocks.1.attn.hook_z", kill_head_1), ("ln_final.hook_normalized", half)],
+    [("hook_embed", zero_cls), ("blocks.0.ln1.hook_scale", freeze_scale), ("blocks.2.hook_resid_post", half), ("ln_final.hook_scale", half)],
+    [(lambda n: not n.startswith("blocks.") and n != "hook_pos_embed", half)],
+]
+EDGE_CASES_LN_PRE = [
+    [("ln_pre.hook_scale", freeze_scale)],
+    [("ln_pre.hook_normalized", half), ("hook_ln_pre", scale_shift)],
+    [("hook_ln_pre", zero_cls), ("blocks.0.attn.hook_q", half), ("hook_post_head_pre_normalize", half)],
+]
+
+
+def _edge(model, hooks):
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    real_reason = model._native_reason
+    with torch.no_grad():
+        for kw in FORMS + [{"stop_at_layer": 0}, {"names_filter": lambda n: not n.startswith("blocks.")}]:
+            model.use_native(False)
+            w_out, w_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+            model.use_native(True)
+            model._native_reason = lambda a, k: None if model._boundary_hooks() is not None else "a hook the plan cannot be split at"
+            model._backend.calls.clear()
+            try:
+                g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+            finally:
+                model._native_reason = real_reason
+            assert model.last_run_native
+            assert list(g_cache.keys()) == list(w_cache.keys()), kw
+            assert torch.allclose(g_out, w_out, atol=1e-5), kw
+            for k_ in w_cache.keys():
+                a, b = g_cache[k_], w_cache[k_]
+                assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5), (k_, kw)
+            assert all(len(hp.fwd_hooks) == 0 and len(hp._forward_hooks) == 0 for hp in model.hook_dict.values())
+
+
+@pytest.mark.parametrize("case", range(len(EDGE_CASES)))
+def test_embedding_and_final_stage_hooks_keep_the_blocks_on_the_plan(model, case):
+    _edge(model, EDGE_CASES[case])
+
+
+@pytest.mark.parametrize("case", range(len(EDGE_CASES_LN_PRE) + len(EDGE_CASES)))
+def test_embedding_and_final_stage_hooks_with_ln_pre(model_ln_pre, case):
+    _edge(model_ln_pre, (EDGE_CASES_LN_PRE + EDGE_CASES)[case])

@@ -1225,280 +1225,6 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// v9: the 320 x 256 tile of v7<5> on FOUR waves -- one per SIMD, the whole 512-entry register file each.  A wave owns 160 x 128
-// outputs (5 x 4 accumulator blocks = 320 registers), so a 16-element k-step is 9 fragment reads (5 of A, 4 of B) for 20 MFMAs
-// where the 8-wave layout reads 14: 36 % fewer LDS fragment bytes per MFMA (the K loops of this family are bound by the LDS
-// serving DMA writes and fragment reads together: profiles/r03_notes.md section 9).  Same 128-byte K slabs, two 72 KB slots, swizzle,
-// barrier placement and tile order as v7's full-line form; every output element accumulates in the same K order through the same
-// instruction, and the epilogue is the same routine: results are bit-identical to v7 / v4.
-// Whole 128-byte slabs and a plain A operand only (every GEMM of the B/32 and L/14 forwards).
-// ---------------------------------------------------------------------------------------------------
-// hipcc keeps every MFMA accumulator in the AGPR half of the register file: with 320 of them it shuttles blocks between the halves
-// (848 v_accvgpr_read + 1088 v_accvgpr_write per 160 MFMAs) and spills.  The matrix instruction takes its accumulator from either
-// half, so the instruction is written out with the register class named: 16 blocks in the 256 AGPRs, 4 in VGPRs.
-typedef int pv_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mfma_bf16_a(f32x16& c, const uint4& a, const uint4& b) {
-    const pv_i32x4 av = __builtin_bit_cast(pv_i32x4, a), bv = __builtin_bit_cast(pv_i32x4, b);
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
-}
-__device__ __forceinline__ void mfma_bf16_v(f32x16& c, const uint4& a, const uint4& b) {
-    const pv_i32x4 av = __builtin_bit_cast(pv_i32x4, a), bv = __builtin_bit_cast(pv_i32x4, b);
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
-}
-
-template <typename T, int EPI, int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_kernel_v9(const GemmParams p) {
-    static_assert(sizeof(T) == 2, "v9 is a bf16 kernel");
-    constexpr int MB = 5, NB = 4, TM = 320, TN = 256;
-    constexpr int A2 = TM * 128, SLOT = (TM + TN) * 128;
-    static_assert(2 * SLOT <= 160 * 1024, "one workgroup per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[SLOT];
-    constexpr int EB = 2;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
-    const int nblk = (ntn + 7) / 8;
-    const int wblk = (ntn + nblk - 1) / nblk;
-    const int blk = swz / (ntm * wblk);
-    const int rem = swz - blk * (ntm * wblk);
-    const int wcur = min(wblk, ntn - blk * wblk);
-    const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
-    const int m0 = tile_m * TM, n0 = tile_n * TN;
-    trace_stamp(p.trace, bid, 0);
-
-    const unsigned Kb = (unsigned)p.K * EB;
-    const int nk2 = (int)(Kb / 128);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.A), 0, (int)((unsigned)p.M * (unsigned)p.lda * EB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * (unsigned)p.ldb * EB), 0x00020000);
-
-    // a DMA piece = 8 rows x 128 B = 8 whole cache lines; A has 40 per slab (piece j * 4 + wave), B 32: 10 + 8 per wave
-    constexpr int NPA = 10, NPB = 8;
-    const int prow = lane >> 3;
-    const int psw = ((lane >> 4) + 4 * (wave & 1)) & 7;            // (row >> 1) & 7 of the row this lane fetches
-    const unsigned pcol = (unsigned)(((lane & 7) ^ psw) * 16);
-    const unsigned pA0 = (unsigned)(m0 + wave * 8 + prow) * (unsigned)p.lda * EB + pcol;
-    const unsigned pB0 = (unsigned)(n0 + wave * 8 + prow) * (unsigned)p.ldb * EB + pcol;
-    const unsigned strideA = 32u * (unsigned)p.lda * EB, strideB = 32u * (unsigned)p.ldb * EB;
-    const bool b_tail = n0 + TN > p.N;                              // (rows of B beyond N: the descriptor zero-fills, but the 32-bit offset must not wrap)
-    auto issue_piece = [&](int kt, unsigned char* slot, int j) {
-        const unsigned kbase = (unsigned)kt * 128;
-        const bool dead = (kt >= nk2);
-        if (j < NPA) {
-            const unsigned o = dead ? 0xffffff00u : pA0 + ((unsigned)j * strideA + kbase);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slot + (j * 4 + wave) * 1024), 16, o, 0, 0, 0);
-        } else {
-            const int jb = j - NPA;
-            const bool off = dead | (b_tail & (n0 + (jb * 4 + wave) * 8 >= p.N));
-            const unsigned o = off ? 0xffffff00u : pB0 + ((unsigned)jb * strideB + kbase);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slot + A2 + (jb * 4 + wave) * 1024), 16, o, 0, 0, 0);
-        }
-    };
-
-    f32x16 accA[MB - 1][NB], accV[NB];                              // row blocks 0..3 in AGPRs, row block 4 in VGPRs
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-#pragma unroll
-        for (int i = 0; i < MB - 1; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) accA[i][j][e] = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accV[j][e] = 0.0f;
-    }
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int fsw = (l31 >> 1) & 7;
-    const int a_row2 = (wm * 32 * MB + l31) * 128, b_row2 = A2 + (wn * 32 * NB + l31) * 128;
-    int fco[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) fco[h] = ((2 * h + half) ^ fsw) * 16;
-    auto rdA = [&](const unsigned char* slot, int h, int mi) {
-        return *reinterpret_cast<const uint4*>(slot + a_row2 + mi * 4096 + fco[h]);
-    };
-    auto rdB = [&](const unsigned char* slot, int h, int ni) {
-        return *reinterpret_cast<const uint4*>(slot + b_row2 + ni * 4096 + fco[h]);
-    };
-
-    // epilogue operands in flight before the K loop: the bias chunks of the lane's two 64-column halves
-    int e_gn[2], e_col[2];
-    bool e_live[2];
-    uint4 e_bias[2];
-    T* e_out0[2];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        e_gn[nh] = n0 + wn * 128 + nh * 64 + (lane & 7) * 8;
-        e_live[nh] = e_gn[nh] < p.N;
-        e_col[nh] = e_gn[nh];
-        e_out0[nh] = reinterpret_cast<T*>(p.out0);
-        e_bias[nh] = make_uint4(0, 0, 0, 0);
-        if (e_live[nh]) {
-            const T* bias = reinterpret_cast<const T*>(p.bias0);
-            if constexpr (EPI == PV_EPI_QKV) {
-                const int which = e_gn[nh] / p.nsplit;
-                e_col[nh] = e_gn[nh] - which * p.nsplit;
-                if (which == 1) { e_out0[nh] = reinterpret_cast<T*>(p.out1); bias = reinterpret_cast<const T*>(p.bias1); }
-                if (which == 2) { e_out0[nh] = reinterpret_cast<T*>(p.out2); bias = reinterpret_cast<const T*>(p.bias2); }
-            }
-            if (bias) e_bias[nh] = *reinterpret_cast<const uint4*>(bias + e_col[nh]);
-        }
-    }
-    const int e_rows_left = p.M - (m0 + wm * 32 * MB + (lane >> 3));       // row mi * 32 + it * 8 of this lane is real iff < e_rows_left
-
-    uint4 fa[MB], fb[2][NB];
-#define PV_V9_GROUP(MI, H)                                                                                     \
-    _Pragma("unroll") for (int ni = 0; ni < NB; ++ni) {                                                        \
-        if ((MI) < MB - 1) mfma_bf16_a(accA[(MI) < MB - 1 ? (MI) : 0][ni], fa[MI], fb[(H) & 1][ni]);           \
-        else mfma_bf16_v(accV[ni], fa[MI], fb[(H) & 1][ni]);                                                   \
-    }                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
-    // slab KT in CUR (visible), slab KT+1 arriving in NXT; fa / fb[0] hold k-step 0 of slab KT.  The barrier of slab KT+1 sits before
-    // the LAST k-step of slab KT (every read of CUR has been issued by then); the A pieces of slab KT+2 go out behind that k-step's
-    // MFMA groups into the slot the barrier freed, the B pieces of slab KT+1 behind the first k-step's.
-#define PV_V9_STEP(KT, CUR, NXT)                                                                               \
-    _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                                            \
-        if (h == 3) {                                                                                          \
-            __builtin_amdgcn_s_waitcnt(0x0F70);                                                                \
-            __builtin_amdgcn_s_barrier();                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
-        }                                                                                                      \
-        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                    \
-            PV_V9_GROUP(mi, h)                                                                                 \
-            fa[mi] = h < 3 ? rdA(CUR, h < 3 ? h + 1 : 0, mi) : rdA(NXT, 0, mi);                                \
-            if (mi == 1 || mi == 2) {                                                                          \
-                const int nb = (mi - 1) * 2;                                                                   \
-                fb[(h + 1) & 1][nb] = h < 3 ? rdB(CUR, h < 3 ? h + 1 : 0, nb) : rdB(NXT, 0, nb);               \
-                fb[(h + 1) & 1][nb + 1] = h < 3 ? rdB(CUR, h < 3 ? h + 1 : 0, nb + 1) : rdB(NXT, 0, nb + 1);   \
-            }                                                                                                  \
-            if (h == 3) { issue_piece((KT) + 2, CUR, 2 * mi); issue_piece((KT) + 2, CUR, 2 * mi + 1); }        \
-            if (h == 0 && mi < 4) { issue_piece((KT) + 1, NXT, NPA + 2 * mi); issue_piece((KT) + 1, NXT, NPA + 2 * mi + 1); } \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
-        }                                                                                                      \
-    }
-#pragma unroll
-    for (int j = 0; j < NPA + NPB; ++j) issue_piece(0, ring0, j);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < NPA; ++j) issue_piece(1, ring1, j);          // (the B pieces of slab 1 ride on step 0's first k-step)
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA(ring0, 0, mi);
-#pragma unroll
-    for (int ni = 0; ni < NB; ++ni) fb[0][ni] = rdB(ring0, 0, ni);
-    int kt = 0;
-    for (; kt + 2 <= nk2; kt += 2) {
-        PV_V9_STEP(kt, ring0, ring1)
-        PV_V9_STEP(kt + 1, ring1, ring0)
-    }
-    if (kt < nk2) { PV_V9_STEP(kt, ring0, ring1) }
-#undef PV_V9_STEP
-#undef PV_V9_GROUP
-    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches
-    __syncthreads();
-    // (the matrix instructions above are opaque to hipcc's hazard recognizer: let the last of them retire before its result is read)
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    trace_stamp(p.trace, bid, 1);
-
-    // epilogue: a wave's 32 x 128 block mi goes through its own 16 KB of LDS as two [32][64] halves (the layout and the lane ->
-    // chunk mapping of v7), a lane owns 8 columns of rows (lane >> 3) + 8 it of each half; residual rows one block ahead
-    constexpr int CLD = 64;
-    float* Cs = reinterpret_cast<float*>(ring0 + wave * (2 * 32 * CLD * 4));
-    pv_f32x2 e_b[2][4];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        e_b[nh][0] = unpack2(e_bias[nh].x); e_b[nh][1] = unpack2(e_bias[nh].y);
-        e_b[nh][2] = unpack2(e_bias[nh].z); e_b[nh][3] = unpack2(e_bias[nh].w);
-    }
-    const int64_t e_row0 = (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldo;
-    T* o0_base[2];
-    T* o1_base[2];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        o0_base[nh] = e_out0[nh] ? e_out0[nh] + e_row0 + e_col[nh] : nullptr;
-        o1_base[nh] = reinterpret_cast<T*>(p.out1) + e_row0 + e_gn[nh];
-    }
-    const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (lane >> 3)) * p.ldr;
-    uint4 e_res[2][8];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) e_res[b][c] = make_uint4(0, 0, 0, 0);
-#define PV_V9_FETCH_RES(MI)                                                                                    \
-    if constexpr (EPI == PV_EPI_RESID) {                                                                       \
-        _Pragma("unroll") for (int nh = 0; nh < 2; ++nh)                                                       \
-            _Pragma("unroll") for (int it = 0; it < 4; ++it)                                                   \
-                if (e_live[nh] && (MI) * 32 + it * 8 < e_rows_left)                                            \
-                    e_res[(MI) & 1][nh * 4 + it] =                                                             \
-                        *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr + e_gn[nh]); \
-    }
-    PV_V9_FETCH_RES(0)
-    const float* Cr = Cs + (lane >> 3) * CLD + (lane & 7) * 8;
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < NB; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                Cs[(ni >> 1) * (32 * CLD) + row * CLD + (ni & 1) * 32 + l31] = mi < MB - 1 ? accA[mi < MB - 1 ? mi : 0][ni][e] : accV[ni][e];
-            }
-        __builtin_amdgcn_wave_barrier();
-        if (mi + 1 < MB) { PV_V9_FETCH_RES((mi + 1 < MB ? mi + 1 : 0)) }
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (e_live[nh] && mi * 32 + it * 8 < e_rows_left) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(Cr + nh * (32 * CLD) + it * 8 * CLD);
-                    const float4 x1 = *reinterpret_cast<const float4*>(Cr + nh * (32 * CLD) + it * 8 * CLD + 4);
-                    const int64_t ro = (int64_t)(mi * 32 + it * 8) * p.ldo;
-                    epi8_bf16<EPI, ACT>(x0, x1, e_b[nh], o0_base[nh] ? o0_base[nh] + ro : nullptr, o1_base[nh] + ro,
-                                        e_res[mi & 1][nh * 4 + it]);
-                }
-            }
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef PV_V9_FETCH_RES
-    trace_stamp(p.trace, bid, 2);
-}
-
-template <typename T>
-int launch_v9(const GemmParams& p, hipStream_t stream) {
-    const int ntm = (p.M + 319) / 320, ntn = (p.N + 255) / 256;
-    constexpr double EBd = DT<T>::kBytes;
-    const double mn = (double)p.M * p.N;
-    double outs = 1.0;
-    if (p.epi == PV_EPI_RESID) outs = 2.0 + (p.out0 ? 1.0 : 0.0);
-    if (p.epi == PV_EPI_ACT) outs = 1.0 + (p.out0 ? 1.0 : 0.0);
-    const dim3 grid(ntm * ntn), block(256);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool timed = !g_pv_tuning.prof_markers &&
-                       pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
-    ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
-#define PV_V9_LAUNCH(EPI, ACT)                                                                                     \
-    do {                                                                                                           \
-        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v9<T, EPI, ACT>), grid, block, 0, stream, ev0, ev1, 0, p);   \
-        else hipLaunchKernelGGL((gemm_kernel_v9<T, EPI, ACT>), grid, block, 0, stream, p);                         \
-    } while (0)
-    if (p.epi == PV_EPI_BIAS) PV_V9_LAUNCH(PV_EPI_BIAS, 0);
-    else if (p.epi == PV_EPI_QKV) PV_V9_LAUNCH(PV_EPI_QKV, 0);
-    else if (p.epi == PV_EPI_RESID) PV_V9_LAUNCH(PV_EPI_RESID, 0);
-    else if (p.act == PV_ACT_GELU) PV_V9_LAUNCH(PV_EPI_ACT, PV_ACT_GELU);
-    else if (p.act == PV_ACT_QUICK_GELU) PV_V9_LAUNCH(PV_EPI_ACT, PV_ACT_QUICK_GELU);
-    else PV_V9_LAUNCH(PV_EPI_ACT, PV_ACT_RELU);
-#undef PV_V9_LAUNCH
-    PV_LAUNCH_CHECK("gemm_kernel_v9");
-    return PV_OK;
-}
-
 // v4 or v7 for this shape?  Cost model = rounds over the chip x time of one round, the round times being the
 // measured per-tile K-loop + epilogue of the two kernels at K = 768 on the B/32 shapes (tools/gemm_trace.py):
 // v4 25 us for 3 x (128 x 128) per CU, v7 26.5 us (MB = 4) / 32 us (MB = 5) for one (64*MB) x 256 per CU.
@@ -1541,10 +1267,6 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             if constexpr (EB == 2) {
                 if (p.vec_out && p.N % 8 == 0) {
                     const int pick = pick_v7(p);
-                    if (pick == 9) {
-                        if (((int64_t)p.K * EB) % 128 == 0) return launch_v9<T>(p, stream);
-                        return launch_v7<T, 5>(p, stream);
-                    }
                     if (pick == 5) return launch_v7<T, 5>(p, stream);
                     if (pick == 4) return launch_v7<T, 4>(p, stream);
                 }
@@ -1559,7 +1281,7 @@ int dispatch(GemmParams& p, hipStream_t stream) {
             p.M % (p.pG * p.pG) == 0 && img_bytes < 0xffffff00ull && (uint64_t)(p.N + 256) * p.ldb * EB < 0xffffff00ull &&
             !g_pv_tuning.gemm_v1 && !g_pv_tuning.gemm_v1patch) {
             const int pick = pick_v7(p);
-            if (pick == 5 || pick == 9) return launch_v7<T, 5>(p, stream);      // (the four-wave kernel takes plain A operands only)
+            if (pick == 5) return launch_v7<T, 5>(p, stream);
             if (pick == 4) return launch_v7<T, 4>(p, stream);
         }
     }

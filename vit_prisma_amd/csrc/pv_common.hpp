@@ -142,8 +142,7 @@ __device__ __forceinline__ float pv_act(float x, int act) {
 // bench.py records pv_debug_get_tuning("any") in its JSON line and refuses to run when it is non-zero.
 // ---------------------------------------------------------------------------------------------
 struct PvTuning {
-    int gemm_tile = -1;      // -1 auto; 0 = 128 x 128 kernel (v4); 4 / 5 = one-workgroup-per-CU kernel with a 256 / 320 x 256 tile;
-                             // 9 = the 320 x 256 tile on four waves (one per SIMD, 160 x 128 per wave) where K is whole 128-byte slabs
+    int gemm_tile = -1;      // -1 auto; 0 = 128 x 128 kernel (v4); 4 / 5 = one-workgroup-per-CU kernel with a 256 / 320 x 256 tile
     int gemm_v1 = 0;         // 1: register-staged 128 x 128 kernel for everything
     int gemm_v1patch = 0;    // 1: register-staged kernel for the patch embedding only
     int attn_wg = 0;         // 1: workgroup-per-(image, head, query block) attention kernel for every shape

@@ -468,6 +468,12 @@ class HookedViT(HookedRootModule):
     # split positions per block (= PV_STAGE_*): 0 entry | 1 ln1 taken | 2 q, k, v ready | 3 scores | 4 pattern | 5 z ready | 6 after the
     # attention half | 7 ln2 taken | 8 mlp pre ready | 9 mlp post ready
     _NPOS = 10
+    # hooks on the embedding stage / the final stage: those two stages then run on the model's own PyTorch modules (a conv, a
+    # LayerNorm, a [B, d] x [d, n_classes] product -- under 1 % of the forward), their HookPoints firing as usual, and every block
+    # stays on the HIP plan, resumed from / stopped at the residual stream (special keys of _boundary_hooks())
+    _EMBED_POS, _FINAL_POS = -1, 1 << 30
+    _EMBED_NAMES = ("hook_embed", "hook_pos_embed", "hook_full_embed", "ln_pre.hook_scale", "ln_pre.hook_normalized", "hook_ln_pre")
+    _FINAL_NAMES = ("ln_final.hook_scale", "ln_final.hook_normalized", "hook_ln_final", "hook_post_head_pre_normalize")
     _KIND_POS = {"hook_resid_pre": ("pre", 0), "ln1.hook_scale": ("ln1s", 1), "ln1.hook_normalized": ("ln1n", 1),
                  "attn.hook_q": ("q", 2), "attn.hook_k": ("k", 2), "attn.hook_v": ("v", 2),
                  "attn.hook_attn_scores": ("scores", 3), "attn.hook_pattern": ("pattern", 4),
@@ -488,6 +494,12 @@ class HookedViT(HookedRootModule):
                 return None
             if not hp._forward_hooks:
                 continue
+            if name in self._EMBED_NAMES:
+                out.setdefault(self._EMBED_POS, {})[name] = hp
+                continue
+            if name in self._FINAL_NAMES:
+                out.setdefault(self._FINAL_POS, {})[name] = hp
+                continue
             m = self._BOUNDARY_RE.fullmatch(name)
             if m is None:
                 return None
@@ -496,7 +508,8 @@ class HookedViT(HookedRootModule):
                 return None
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
-                return None               # blocks.0.hook_resid_pre is produced inside the embedding stage
+                out.setdefault(self._EMBED_POS, {})[name] = hp      # blocks.0.hook_resid_pre is the embedding stage's last tensor
+                continue
             out.setdefault(pos, {})[kind] = hp
         return out
 
@@ -555,14 +568,105 @@ class HookedViT(HookedRootModule):
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        bh = dict(self._boundary_hooks() or {})
+        embed_hooked = bh.pop(self._EMBED_POS, None) is not None
+        final_hooked = (bh.pop(self._FINAL_POS, None) is not None) and run_head
+        if not embed_hooked and not final_hooked:
+            return self._run_native_segments(x, None, names, n_blocks, run_head, bh, device, remove_batch_dim)
+        # hooks on the embedding / final stage: that stage on the PyTorch modules (hooks fire as usual), the blocks on the HIP plan
+        wanted = set(names)
+        cache: Dict[str, torch.Tensor] = {}
+        start = None
+        if embed_hooked:
+            start, rec = self._torch_embedding_stage(x, wanted, n_blocks)
+            cache.update(rec)
+        inner = [n for n in names if n not in cache and not (final_hooked and n in self._FINAL_NAMES)
+                 and not (embed_hooked and (n in self._EMBED_NAMES or n == "blocks.0.hook_resid_pre"))]
+        if n_blocks > 0 or (run_head and not final_hooked) or start is None:
+            out, c = self._run_native_segments(x, start, inner, n_blocks, run_head and not final_hooked, bh, None, False)
+            cache.update(c)
+        else:
+            out = start                                          # stop_at_layer = 0 behind a hooked embedding stage
+        if final_hooked:
+            out, rec = self._torch_final_stage(out, wanted)
+            cache.update(rec)
+        ordered: Dict[str, torch.Tensor] = {}
+        for n in names:
+            t = cache[n]
+            if device is not None:
+                t = t.to(device)
+            ordered[n] = t[0] if remove_batch_dim else t
+        return out, ordered
+
+    def _recording_hooks(self, which, wanted, rec):
+        """forward hooks that note what the HookPoints of `which` pass on (registered behind the caller's hooks, like the caching
+        hooks of the PyTorch path: the cache holds the post-hook value); returns the handles"""
+        handles = []
+        for n in which:
+            hp = self.hook_dict.get(n)
+            if hp is not None and n in wanted:
+                handles.append(hp.register_forward_hook(lambda m, i, o, n=n: rec.__setitem__(n, o)))
+        return handles
+
+    def _torch_embedding_stage(self, x: torch.Tensor, wanted, n_blocks: int):
+        """base_vit.py:169-185 on the model's own modules: (the residual stream entering block 0, {name: cached tensor})."""
+        cfg = self.cfg
+        rec: Dict[str, torch.Tensor] = {}
+        first = "blocks.0.hook_resid_pre"
+        handles = self._recording_hooks(self._EMBED_NAMES + ((first,) if n_blocks > 0 else ()), wanted, rec)
+        try:
+            inp = x.to(cfg.dtype) if x.dtype != cfg.dtype else x
+            embed = self.hook_embed(self.embed(inp))
+            if cfg.use_cls_token:
+                embed = torch.cat((self.cls_token.expand(inp.shape[0], -1, -1), embed), dim=1)
+            residual = embed + self.hook_pos_embed(self.pos_embed(inp))
+            self.hook_full_embed(residual)                       # observe-only
+            if cfg.layer_norm_pre:
+                residual = self.hook_ln_pre(self.ln_pre(residual))
+            if n_blocks > 0:
+                residual = self.blocks[0].hook_resid_pre(residual)
+        finally:
+            for h in handles:
+                h.remove()
+        return residual.contiguous(), rec
+
+    def _torch_final_stage(self, residual: torch.Tensor, wanted):
+        """base_vit.py:192-217 on the model's own modules: (model output, {name: cached tensor})."""
+        cfg = self.cfg
+        rec: Dict[str, torch.Tensor] = {}
+        handles = self._recording_hooks(self._FINAL_NAMES, wanted, rec)
+        try:
+            x = self.ln_final(residual)
+            self.hook_ln_final(x)                                # observe-only
+            if cfg.classification_type == "gaap":
+                x = x.mean(dim=1)
+            elif cfg.classification_type == "cls":
+                x = x[:, 0]
+            if cfg.return_type != "pre_logits":
+                x = self.head(x)
+            self.hook_post_head_pre_normalize(x)                 # observe-only
+            if cfg.normalize_output:
+                x = F.normalize(x, dim=-1)
+        finally:
+            for h in handles:
+                h.remove()
+        return x, rec
+
+    def _run_native_segments(self, x: torch.Tensor, start_resid: Optional[torch.Tensor], names, n_blocks: int, run_head: bool, bh,
+                             device, remove_batch_dim: bool):
+        """The blocks (+ the head) on the HIP plan, split at the hooked positions of `bh`; start_resid: resume at block 0 from
+        this residual stream instead of starting from the pixels (the embedding stage ran elsewhere)."""
+        cfg = self.cfg
         nv = self._get_native(x.device)
-        bh = self._boundary_hooks() or {}
         NP = self._NPOS
         end_pos = NP * n_blocks
         # a hook at the very end fires only if its point is produced: "pre" of block n_blocks is not
         bounds = sorted(q for q in bh if q < end_pos or (q == end_pos and ("post" in bh[q] or "mlp" in bh[q])))
         if not bounds:
             tap_dst = getattr(self, "_tap_dst", None)             # (the activation store's own buffer slice, sae/store.py)
+            if start_resid is not None:
+                return nv.forward(self, None, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
+                                  first_block=0, resid_in=start_resid)
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
                               **({"tap_dst": tap_dst} if tap_dst else {}))
         # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
@@ -607,18 +711,19 @@ class HookedViT(HookedRootModule):
             out = xc / scale
             return out * ln_mod.w + ln_mod.b if isinstance(ln_mod, LayerNorm) else out
 
-        p0, resid, acts, out = 0, None, (), None
+        p0, resid, acts, out = 0, start_resid, (), None
+        from_pixels = start_resid is None
         for q in bounds + [None]:
             last = q is None
             p1 = end_pos if last else q
             b1, s1 = divmod(p1, NP)                             # the segment ends at position s1 of block b1
             blk = b1 if s1 else b1 - 1                          # the block its last stage lies in
             seg = [n for n in names if (p0 == 0 or pos_of(n) >= p0) and pos_of(n) < (NP * cfg.n_layers + 1 if last else p1)
-                   and not (p0 > 0 and p0 % NP == 0 and n == f"blocks.{p0 // NP}.hook_resid_pre")]     # (the resumed tensor: set by hand)
+                   and not ((p0 > 0 or not from_pixels) and p0 % NP == 0 and n == f"blocks.{p0 // NP}.hook_resid_pre")]     # (the resumed tensor: set by hand)
             hooks = {} if last else bh[q]
             c: Dict[str, torch.Tensor] = {}
             seg_in = resid
-            pre_inside = p0 < NP * b1 or p0 == 0                # block b1's entry lies inside this segment
+            pre_inside = p0 < NP * b1 or (p0 == 0 and from_pixels)     # block b1's entry lies inside this segment
             if p0 == p1 and not (last and run_head):
                 out = resid                                   # nothing left to run: the hooked residual is the output
             else:
@@ -654,8 +759,9 @@ class HookedViT(HookedRootModule):
                     else:
                         forced = [f"blocks.{b1}.mlp.hook_post"] + mid_f
                 req = seg + [n for n in forced if n not in seg]
-                out, c = nv.forward(self, x if p0 == 0 else None, req, b1, last and run_head, first_block=p0 // NP,
-                                    resid_in=resid if p0 > 0 else None, entry_stage=p0 % NP, exit_stage=s1, act_in=acts)
+                start_px = p0 == 0 and from_pixels
+                out, c = nv.forward(self, x if start_px else None, req, b1, last and run_head, first_block=p0 // NP,
+                                    resid_in=None if start_px else resid, entry_stage=p0 % NP, exit_stage=s1, act_in=acts)
                 cache.update({k: v for k, v in c.items() if k in wanted})
             if last:
                 break
