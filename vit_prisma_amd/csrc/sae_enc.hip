@@ -47,6 +47,8 @@ struct EncParams {
     uint32_t* cnt;            //         [M][ntn] hits of (token, N-tile); 0xffffffff = more than `slots`
     int2* cand;               //         [M][ntn][slots] (feature, bits of a)
     int32_t slots;            //         pv_sae_tile_slots(plan)
+    uint32_t* mode;           // ReLU filter (pv_sae_relu_step) or NULL: the step's mode word -- a row with more hits than slots raises it
+                              // (the step then runs dense), and a tile that finds it raised skips its hit lists
 };
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -370,6 +372,16 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         // with more than HCAP hits: massive ties) are marked overflowed: those tokens take the exact path.
         constexpr int HCAP = SLOT / 8;
         uint2* hlist = reinterpret_cast<uint2*>(ring0);
+        if (tid == 0) hit_n = p.mode ? __hip_atomic_load(p.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __syncthreads();                                           // (ONE read of the word per workgroup)
+        const bool dense_already = hit_n != 0u;
+        __syncthreads();
+        if (dense_already) {
+            // the step is dense already -- half of all features positive, as at the start of a run: compacting ~32 K hits per tile
+            // would cost more than the K loop
+            if (tid < 256 && m0 + tid < p.M) p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = 0xffffffffu;
+            return;
+        }
         if (tid == 0) hit_n = 0u;
         if (tid < 256) rowcnt[tid] = 0u;
         __syncthreads();
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
             p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)p.slots ? 0xffffffffu : c;
+            if (p.mode && c > (uint32_t)p.slots) atomicOr(p.mode, 1u);
         }
     }
 }
@@ -715,9 +728,9 @@ __global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__
 template <int V4>
 __global__ __launch_bounds__(256) void relu_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
-    const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
-    uint32_t* __restrict__ tok_cnt, float* __restrict__ l1part, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos,
-    uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots) {
+    const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ thr, int32_t* __restrict__ idx_out,
+    float* __restrict__ val_out, uint32_t* __restrict__ tok_cnt, float* __restrict__ l1part, uint32_t* __restrict__ feat_cnt,
+    uint32_t* __restrict__ wpos, uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots) {
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ float rval[PV_SAE_CAND_CAP];
     __shared__ uint32_t tcnt[256];
@@ -726,10 +739,14 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
     __shared__ uint32_t sh_bad, sh_m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
+    // another token has already sent the step to the dense GEMMs: nothing this workgroup computes would be used (the mode word only
+    // ever goes 0 -> 1 within a step; a stale 0 costs time, never correctness)
+    if (tid == 0) { sh_bad = __hip_atomic_load(mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1u : 0u; sh_m = 0u; }
+    __syncthreads();                                           // (ONE read of the word per workgroup: every thread sees the same answer)
+    const bool already_dense = sh_bad != 0u;
     uint32_t myc = 0;
-    if (tid < ntn) myc = tile_cnt[row * ntn + tid];
+    if (tid < ntn && !already_dense) myc = tile_cnt[row * ntn + tid];
     tcnt[tid] = tid < ntn ? myc : 0u;
-    if (tid == 0) { sh_bad = 0u; sh_m = 0u; }
     __syncthreads();
     if (tid < ntn && myc == 0xffffffffu) sh_bad = 1u;
     __syncthreads();
@@ -744,10 +761,22 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
         bad = n > (uint32_t)PV_SAE_CAND_CAP;
     }
     if (!bad && tid < ntn && myc > 0u) {
+        // candidates whose filter value lies above +B_n are positive for certain (exact >= a - B_n > 0): more of those than the list
+        // can hold settles the matter before a single row of W_enc is gathered (the published L0 of 600 - 2000 ends here)
         const int2* src = cand + (row * ntn + tid) * slots;
-        for (uint32_t e = 0; e < myc; ++e) cidx[off + e] = src[e].x;
+        const float Bn = -thr[row];
+        uint32_t sure = 0;
+        for (uint32_t e = 0; e < myc; ++e) {
+            const int2 c = src[e];
+            cidx[off + e] = c.x;
+            sure += __int_as_float(c.y) > Bn ? 1u : 0u;
+        }
+        if (sure) atomicAdd(&sh_m, sure);
     }
     __syncthreads();
+    if (!bad && sh_m > (uint32_t)cap) bad = true;
+    __syncthreads();
+    if (tid == 0) sh_m = 0u;
     const uint32_t nr = bad ? 0u : n;
     // exact fp32 re-scoring of every candidate: a wave per candidate, four in flight (as in sae_select_kernel)
     bool ok[V4];
@@ -927,14 +956,14 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
     p.B = st->W_enc16T; p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes;
     p.bias = st->b_enc; p.bias_stride = 1; p.out = nullptr; p.thr = (const float*)(wsb + ws.thr);
-    p.cnt = cand_cnt; p.cand = (int2*)cand; p.slots = PV_SAE_RELU_SLOTS;
+    p.cnt = cand_cnt; p.cand = (int2*)cand; p.slots = PV_SAE_RELU_SLOTS; p.mode = mode;
     int rc = launch_enc_gemm(1, p, stream);
     if (rc) return rc;
     const int ntn = d.d_sae / 256;
 #define CALL(D)                                                                                                                 \
     hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                    \
-                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)cand_cnt, (const int2*)cand, idx, val, \
-                       tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
+                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)cand_cnt, (const int2*)cand,           \
+                       (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
 #undef CALL
     PV_LAUNCH_CHECK("relu_select_kernel");
