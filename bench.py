@@ -419,6 +419,18 @@ def main():
         "share_of_step": round(gemm["ms"] / (ms_per_step * a.steps), 4),
         "traffic": None,
     }
+    # per GEMM instance: both roofs (the bf16 MFMA peak and the HBM floor of its own algorithmic bytes), max of the two fractions --
+    # the O-projection and MLP-1 move the most bytes per flop of the four
+    inst = {}
+    for nm, tag in N.GEMM_TAGS.items():
+        g_ = N.prof_read_tag("gemm", tag)
+        if g_["launches"]:
+            tf_ = g_["flops"] / max(g_["ms"], 1e-9) / 1e9
+            gb_ = g_["bytes"] / max(g_["ms"], 1e-9) / 1e6
+            inst[nm] = {"launches": g_["launches"], "avg_launch_us": round(g_["ms"] * 1e3 / g_["launches"], 2),
+                        "TFLOPs": round(tf_, 1), "frac_mfma": round(tf_ / peak_tf, 4), "GBps_algorithmic": round(gb_, 1),
+                        "frac_hbm": round(gb_ / PEAK_HBM_GBS, 4), "frac": round(max(tf_ / peak_tf, gb_ / PEAK_HBM_GBS), 4)}
+    roofline["instances"] = inst
     tr = pmc_traffic("gemm_kernel") if a.dtype == "bf16" and a.batch == 512 else None
     if tr is not None:
         roofline["traffic"] = tr["bytes_per_launch"]

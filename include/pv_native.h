@@ -248,6 +248,9 @@ int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t 
 int pv_prof_enable(int32_t on);
 int pv_prof_reset(void);
 int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
+/* The same over the launches of that family that carried one instance tag (GEMMs: 1 = QKV, 2 = O-projection, 3 = MLP-1, 4 = MLP-2,
+ * 0 = the others; tagged by pv_vit_forward's GEMM launcher from epilogue and shape): per-instance roofline fractions. */
+int pv_prof_read_tag(int32_t kind, int32_t tag, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
 /* Debug only (tools/gemm_trace.py): per-workgroup phase stamps {t_start, t_loop_end, t_end, hw_id} (100 MHz wall
  * clock) of the launch_idx-th plain GEMM launch from now; read blocks until the device is idle.

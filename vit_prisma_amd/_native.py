@@ -98,7 +98,7 @@ EXPORTS = [
     "pv_abi_version", "pv_build_id", "pv_last_error",
     "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
     "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_vit_forward_stage", "pv_gemm_bias", "pv_transpose_batched",
-    "pv_prof_enable", "pv_prof_reset", "pv_prof_read",
+    "pv_prof_enable", "pv_prof_reset", "pv_prof_read", "pv_prof_read_tag",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
@@ -246,6 +246,16 @@ def prof_read(kind: str) -> dict:
     """{'launches', 'ms', 'flops', 'bytes'} of one kernel family since the last reset."""
     n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
     check(lib().pv_prof_read(PROF_KINDS[kind], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "pv_prof_read")
+    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+
+
+GEMM_TAGS = {"qkv": 1, "o_proj": 2, "mlp1": 3, "mlp2": 4, "other": 0}
+
+
+def prof_read_tag(kind: str, tag: int) -> dict:
+    """``prof_read`` restricted to the launches that carried one instance tag (GEMM_TAGS)."""
+    n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    check(lib().pv_prof_read_tag(PROF_KINDS[kind], int(tag), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "pv_prof_read_tag")
     return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
 
 

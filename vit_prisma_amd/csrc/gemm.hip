@@ -1344,6 +1344,9 @@ int pv_launch_act(int dtype, int act, const void* pre, void* post, int64_t n, hi
 }
 
 int pv_launch_gemm(int dtype, GemmParams p, hipStream_t stream) {
+    // instance tag for the per-instance roofline (bench.py): 1 QKV, 2 O-projection, 3 MLP-1, 4 MLP-2, 0 everything else
+    struct TagScope { TagScope(int t) { pv_prof_set_tag(t); } ~TagScope() { pv_prof_set_tag(0); } }
+        tag_scope(p.epi == PV_EPI_QKV ? 1 : p.epi == PV_EPI_ACT ? 3 : p.epi == PV_EPI_RESID ? (p.K > p.N ? 4 : 2) : 0);
     p.dbg = g_pv_tuning.gemm_dbg;
     p.trace = nullptr;
     if (g_trace_countdown >= 0 && p.a_mode == PV_A_PLAIN && !p.b_kn) {

@@ -5,14 +5,23 @@
 namespace {
 struct Pool {
     std::vector<hipEvent_t> start, stop;
+    std::vector<double> ev_flops, ev_bytes;      // per event: what its launcher declared
+    std::vector<int> ev_tag;                     // per event: the instance tag current at its launch (pv_prof_set_tag)
     size_t used = 0;
     double flops = 0, bytes = 0;
+    void note(size_t tok, double fl, double by, int tag) {
+        if (ev_flops.size() <= tok) { ev_flops.resize(tok + 1); ev_bytes.resize(tok + 1); ev_tag.resize(tok + 1); }
+        ev_flops[tok] = fl; ev_bytes[tok] = by; ev_tag[tok] = tag;
+    }
 };
 Pool g_pool[PV_PROF__COUNT];
 bool g_on = false;
 uint32_t g_mask = 0xffffffffu;
 constexpr size_t kMaxEvents = 16384;
+int g_tag = 0;
 }  // namespace
+
+void pv_prof_set_tag(int tag) { g_tag = tag; }
 
 bool pv_prof_on() { return g_on; }
 bool pv_prof_on(int kind) { return g_on && ((g_mask >> kind) & 1u); }
@@ -29,6 +38,7 @@ int pv_prof_begin(int kind, hipStream_t stream, double flops, double bytes) {
     const int tok = (int)p.used++;
     p.flops += flops;
     p.bytes += bytes;
+    p.note((size_t)tok, flops, bytes, g_tag);
     (void)hipEventRecord(p.start[tok], stream);
     return tok;
 }
@@ -46,6 +56,7 @@ bool pv_prof_events(int kind, double flops, double bytes, hipEvent_t* start, hip
     const size_t tok = p.used++;
     p.flops += flops;
     p.bytes += bytes;
+    p.note(tok, flops, bytes, g_tag);
     *start = p.start[tok];
     *stop = p.stop[tok];
     return true;
@@ -84,6 +95,27 @@ extern "C" int pv_prof_read(int32_t kind, int64_t* launches, double* total_ms, d
     if (total_ms) *total_ms = ms;
     if (flops) *flops = p.flops;
     if (bytes) *bytes = p.bytes;
+    return PV_OK;
+}
+
+// The same for the launches of `kind` that carried instance tag `tag` (GEMMs: 1 QKV, 2 O-projection, 3 MLP-1, 4 MLP-2, 0 others --
+// pv_launch_gemm tags its launch by epilogue and shape): the per-instance roofline fractions of bench.py.
+extern "C" int pv_prof_read_tag(int32_t kind, int32_t tag, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+    PV_REQUIRE(kind >= 0 && kind < PV_PROF__COUNT, "profile kind");
+    Pool& p = g_pool[kind];
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i < p.used; ++i) {
+        if (p.ev_tag[i] != tag) continue;
+        PV_HIP_CHECK(hipEventSynchronize(p.stop[i]));
+        float t = 0;
+        PV_HIP_CHECK(hipEventElapsedTime(&t, p.start[i], p.stop[i]));
+        ms += t; fl += p.ev_flops[i]; by += p.ev_bytes[i]; ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
     return PV_OK;
 }
 

@@ -14,6 +14,8 @@ enum {
     PV_PROF__COUNT = 7
 };
 
+// instance tag attached to the events recorded from now on (pv_prof_read_tag sums one tag's launches); 0 = untagged
+void pv_prof_set_tag(int tag);
 bool pv_prof_on();
 bool pv_prof_on(int kind);      // enabled AND this kernel family selected (pv_prof_enable's mask)
 // Records a start event on `stream`; returns a token (< 0 when disabled / pool exhausted).
