@@ -454,6 +454,16 @@ int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32
                       int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_ghost* ghost, pv_sae_out* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ghost gradients of a TOP-K SAE (use_ghost_grads with activation_fn_str = "topk"): run AFTER pv_sae_step on the same batch -- complete
+ * gradient buffers (no PV_SAE_SPARSE_GRADS), the decoder renormalised in place beforehand (pv_sae_renorm_decoder; not the deferred
+ * PV_SAE_RENORM_DECODER), out->sae_out = the reconstruction that step wrote.  Adds the ghost residual loss (scalars[5]; scalars[0] = mse +
+ * ghost) and its gradient to the dead features' rows of gW_dec / gW_enc^T / gb_enc and to gb_dec.  exp(hidden_pre) of the dead features comes
+ * from one small GEMM (the k-sparse encoder never materialises hidden_pre).  `ghost` as for pv_sae_dense_step (the dead list is taken BEFORE
+ * the step's statistics).  Follow with pv_sae_grad_sqnorm over the whole flat buffer and pv_sae_apply.  Single process, no transcoder.
+ * Replaces sae/sae.py:151-179 behind TopK (:795-810), train_sae.py:330-346. */
+int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const pv_sae_ghost* ghost, pv_sae_out* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* The ReLU + L1 step, sparse where the batch allows it ("ReLU is top-k with threshold 0 and a variable k"): same contract, flags,
  * scalars and follow-up calls as pv_sae_dense_step (no ghost gradients here), same results -- exact fp32 values on both paths.
  * ONE product over all features (the fp16 MFMA filter of pv_sae_step with the per-token threshold -B_n, B_n = the proven error band

@@ -1,5 +1,6 @@
 """Golden fixtures for the other sparse coders by EXECUTING THE REFERENCE (build container only):
-the reference's StandardSparseAutoencoder with ReLU + L1 (+ ghost gradients), GatedSparseAutoencoder and Transcoder are
+the reference's StandardSparseAutoencoder with ReLU + L1 (+ ghost gradients) and with top-k + ghost gradients, GatedSparseAutoencoder
+and Transcoder are
 run through its own VisionSAETrainer.train_step (/root/reference/src/vit_prisma/sae/train_sae.py:278-411) for 3 steps at
 d_in = 64, d_sae = 512, N = 256.
 
@@ -31,6 +32,7 @@ VARIANTS = {
     "relu_l1": dict(activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3, use_ghost_grads=False),
     "relu_ghost": dict(activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3, use_ghost_grads=True,
                        dead_feature_window=1),
+    "topk_ghost": dict(activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=True, dead_feature_window=1),
     "gated": dict(architecture="gated", activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3,
                   use_ghost_grads=False),
     "transcoder": dict(is_transcoder=True, transcoder_with_skip_connection=True, d_out=64, out_hook_point_layer=6,
@@ -82,7 +84,7 @@ def run(variant, over):
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: 1.0)
     act, since, frac = torch.zeros(cfg.d_sae), torch.zeros(cfg.d_sae), 0
-    if variant == "relu_ghost":
+    if variant in ("relu_ghost", "topk_ghost"):
         since[::3] = 5.0                       # a third of the features count as dead (window 1): ghost grads are live
     blob[f"{variant}_since0"] = since.clone().numpy()
     for t in range(3):

@@ -840,6 +840,88 @@ def test_dense_steps_see_an_outside_edit_of_w_enc(kind):
     assert torch.equal(eng.W_encT, ref.W_encT) and torch.equal(T["W_enc"], T2["W_enc"])
 
 
+@pytest.mark.parametrize("d_in,d_sae,k,n,ln", [(64, 512, 8, 256, True), (136, 1056, 16, 300, False), (768, 8192, 32, 1024, True)])
+def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
+    """Ghost gradients on the top-k step (pv_sae_step + pv_sae_topk_ghost; sae.py:151-179 behind TopK :795-810) against the oracle's
+    top-k + ghost form (pinned to the reference's own topk_ghost run by tests/test_oracle_sae_vs_golden.py): every fifth feature counts
+    as dead; losses (mse, ghost, total), l0, the reconstruction, every gradient tensor, the clip norm.  One step, gradients at 5e-4
+    where the dead rows are concerned: exp(hidden_pre) turns the absolute fp32 summation noise of hidden_pre into a relative error
+    of the ghost activations (see test_relu_l1_dense_step_vs_oracle)."""
+    window = 3
+    P, opt, stats, T = fresh(d_in, d_sae)
+    stats["n_fwd_since_fired"][::5] = 10.0
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, ln, n)
+    eng.n_fwd_since_fired.copy_(torch.from_numpy(stats["n_fwd_since_fired"]))
+    x = synth_sae_batch(n, d_in, seed=10)
+    Pc = {kk: v.copy() for kk, v in P.items()}
+    O.renorm_decoder(Pc)
+    dead = stats["n_fwd_since_fired"] > window
+    fw = O.sae_forward(Pc, x, k, layer_norm=ln, dead_mask=dead)
+    gr = O.sae_backward(Pc, x, fw, layer_norm=ln)
+    before = stats["act_freq_scores"].copy()
+    ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=1, layer_norm=ln, dead_feature_window=window)
+    xg = torch.from_numpy(x).cuda()
+    dead_g = eng.n_fwd_since_fired > window                          # (before the step's statistics, train_sae.py:330-332)
+    eng.renorm_decoder()
+    eng.step(xg, want_out=True, renorm_decoder=False, sparse_grads=False)
+    eng.topk_ghost(xg, dead_g)
+    eng.grad_sqnorm()
+    torch.cuda.synchronize()
+    sc = eng.scalars.cpu().numpy()
+    assert abs(sc[0] - ref["loss"]) <= TOL * ref["loss"] and abs(sc[1] - ref["mse_loss"]) <= TOL * ref["mse_loss"], (sc, ref)
+    assert abs(sc[5] - ref["ghost_loss"]) <= TOL * ref["ghost_loss"] and abs(sc[2] - ref["l0"]) < 1e-4, (sc, ref)
+    assert np.array_equal(np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1), np.sort(fw["idx"], axis=1))
+    assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
+    gtol = 5e-4
+    assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= gtol * grad_norm_of(gr)
+    assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < gtol
+    for name in ("W_dec", "b_enc", "b_dec"):
+        assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < gtol, name
+    # the live features' rows are what the plain top-k step gives them (the ghost term reaches dead features only)
+    live = ~dead
+    assert rel_fro(eng.g["W_dec"].cpu().numpy()[live], gr["W_dec"][live]) < TOL
+    assert np.array_equal(eng.fire_count.cpu().numpy(), stats["act_freq_scores"] - before)
+    eng.apply(1e-3, 1.0)
+    torch.cuda.synchronize()
+    for name in P:
+        # (Adam's g / (|g| + 1e-8) on the dead features' ~1e-9 gradient entries: see the ReLU ghost test)
+        assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < 1e-3, name
+
+
+def test_topk_ghost_trainer_runs_natively_and_matches_the_reference_fixture():
+    """activation_fn_str = "topk" with use_ghost_grads through VisionSAETrainer.train_step on the HIP path, against what the REFERENCE's
+    own classes produced through its own train_step (topk_ghost of tests/golden/sae_variants_steps.npz): three steps, losses and the
+    ghost loss at 1e-4, statistics (a handful of entries may differ after a ghost step, as for the ReLU form), parameters at 1e-3."""
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, exp, N = 64, 8, 256
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
+        train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda", _dtype="float32", log_to_wandb=False, use_ghost_grads=True,
+        feature_sampling_window=1000, dead_feature_window=1, lr_scheduler_name="constant", n_checkpoints=0, verbose=False)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None).use_native(True)
+    model = tr.sparse_coder
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"topk_ghost_init_{n}"]).cuda())
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    since.copy_(torch.from_numpy(g["topk_ghost_since0"]).cuda())
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(N, d_in, seed=t)).cuda()[:, None, :]
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=model, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t, n_training_tokens=t * N)
+        assert tr.last_step_native and l1 is None
+        want = g[f"topk_ghost_s{t}_scalars"]
+        for got, w in ((loss, want[0]), (mse, want[1]), (l0, want[3]), (tr._engine.scalars[5], want[4])):
+            assert abs(float(got) - w) <= TOL * abs(w), (t, float(got), w)
+        af = g[f"topk_ghost_s{t}_act_freq"]
+        assert np.abs(act.cpu().numpy() - af).sum() <= 1e-3 * af.sum()
+        assert (since.cpu().numpy() != g[f"topk_ghost_s{t}_n_since"]).sum() <= 2
+    for n, p in model.named_parameters():
+        assert rel_fro(p.detach().cpu().numpy(), g[f"topk_ghost_s2_param_{n}"]) < 1e-3, n
+
+
 def grad_norm_of(g):
     return float(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g.values())))
 

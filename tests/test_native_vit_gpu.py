@@ -831,15 +831,12 @@ def test_mutating_hooks_on_b32_vs_reference_fixture_fp32_and_bf16_budget():
                 assert float(pat[:, 0, :, -1].abs().max()) == 0.0 and float(pat[:, 1, :, -1].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("lean", [0, 1])
 @pytest.mark.parametrize("image_size,patch", [(224, 16), (208, 13), (400, 16), (176, 16), (256, 16), (336, 14)])
-def test_bf16_long_sequence_attention_kernel(image_size, patch, lean, tuning):
-    """The T > 64 bf16 attention kernels -- the strip-in-LDS form (a workgroup per 32 queries, its four waves splitting the key
-    tiles; the default) and the two-pass 128-query form (tuning key attn_lean) -- on token counts other than L/14's 577: T = 197 (odd: head blocks of the taps only
+def test_bf16_long_sequence_attention_kernel(image_size, patch):
+    """The T > 64 bf16 attention kernel on token counts other than L/14's 577: T = 197 (odd: head blocks of the taps only
     2-byte aligned, one full tap window + a ragged one), 257 (one key past a tile edge), 626 (> 4 windows, last one ragged),
     122 (even, < one window), 257 again at another patch size, and 577 itself.  scores / pattern / z against an fp32 recompute from the
     q, k, v the same run cached."""
-    tuning("attn_lean", lean)
     cfg = dict(n_layers=1, d_model=128, n_heads=2, d_head=64, d_mlp=256, patch_size=patch, image_size=image_size, n_channels=3,
                n_classes=16, eps=1e-5, layer_norm_pre=True, normalize_output=True, return_type="class_logits",
                activation_name="gelu", use_cls_token=True, normalization_type="LN", classification_type="cls")

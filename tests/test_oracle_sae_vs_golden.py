@@ -110,6 +110,29 @@ def test_relu_ghost_three_steps_vs_reference_fixture():
         assert rel_fro(P[n], g[f"relu_ghost_s2_param_{n}"]) < 2e-5, n
 
 
+def test_topk_ghost_three_steps_vs_reference_fixture():
+    """Ghost gradients on a top-k SAE (sae.py:151-179 behind TopK :795-810; the dead mask of train_sae.py:330-332): the oracle's
+    top-k + ghost form against the reference's own run (topk_ghost of tests/golden/sae_variants_steps.npz)."""
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, d_sae, N, k = 64, 512, 256, 8
+    P = {n: g[f"topk_ghost_init_{n}"].copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": g["topk_ghost_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    assert (stats["n_fwd_since_fired"] > 1).sum() > 100
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), k, lr=1e-3, step=t + 1, dead_feature_window=1)
+        loss, mse, _, l0, ghost = g[f"topk_ghost_s{t}_scalars"][:5]
+        assert abs(out["loss"] - loss) <= 2e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        assert abs(out["ghost_loss"] - ghost) <= 2e-5 * abs(ghost) and out["l0"] == l0, (t, out, ghost)
+        assert np.array_equal(stats["act_freq_scores"], g[f"topk_ghost_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"topk_ghost_s{t}_n_since"])
+    # (a dead feature's only gradient here is the ghost term: entries of ~1e-9, where fp32 summation-order noise -- numpy against torch --
+    # is an ABSOLUTE error that Adam's g / (|g| + 1e-8) turns into lr-sized differences on those columns of W_enc: 3.2e-4 after three
+    # steps with every loss of every step within 2e-5; the ReLU form above keeps its dead features' L1-free gradient larger)
+    for n in P:
+        assert rel_fro(P[n], g[f"topk_ghost_s2_param_{n}"]) < (1e-3 if n == "W_enc" else 2e-4), (n, rel_fro(P[n], g[f"topk_ghost_s2_param_{n}"]))   # (W_dec's dead rows: the same effect, 8e-5)
+
+
 def test_transcoder_three_steps_vs_reference_fixture():
     """The Transcoder form of the oracle (target given, b_dec_out, W_skip; top-k, k = 8) against the reference's own Transcoder
     through its own train_step (transcoder of tests/golden/sae_variants_steps.npz)."""

@@ -5,8 +5,6 @@ import torch
 from vit_prisma_amd import HookedViT, HookedViTConfig, _native as N
 from vit_prisma_amd.synth import ARCHS, synth_vit_state
 dev = torch.device("cuda:0")
-if os.environ.get("PV_ATTN_LEAN"):
-    N.set_tuning("attn_lean", int(os.environ["PV_ATTN_LEAN"]))      # 1: the two-pass 128-query kernel, 0: the strip-in-LDS kernel
 arch = ARCHS["clip-vit-l14-336"]
 model = HookedViT(HookedViTConfig(**arch, dtype=torch.bfloat16, device="cuda"))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)

@@ -103,7 +103,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_sae_tp_partial", "pv_sae_tp_finish", "pv_sae_tp_merge", "pv_sae_tp_bucket_pack", "pv_sae_tp_bucket_unpack",
-    "pv_sae_dense_step", "pv_sae_relu_step", "pv_sae_relu_workspace_bytes", "pv_debug_sae_relu_offset", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes", "pv_sae_gated_scratch_bytes", "pv_sae_gated_step",
+    "pv_sae_dense_step", "pv_sae_topk_ghost", "pv_sae_relu_step", "pv_sae_relu_workspace_bytes", "pv_debug_sae_relu_offset", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes", "pv_sae_gated_scratch_bytes", "pv_sae_gated_step",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -167,6 +167,7 @@ def lib() -> C.CDLL:
         L.pv_sae_tp_finish.argtypes = [vp, C.POINTER(SaeState), vp, vp, vp, vp, i32, i32, i32, C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_dense_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeGhost),
                                         C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_topk_ghost.argtypes = [vp, C.POINTER(SaeState), vp, i32, C.POINTER(SaeGhost), C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_relu_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeReluSparse),
                                        C.POINTER(SaeOut), vp, sz, vp]
         L.pv_sae_relu_workspace_bytes.argtypes = [vp, i32, i32]

@@ -580,7 +580,10 @@ int launch_attn_wave(const AttnParams& p, hipStream_t stream) {
 // register-strip variant (round 3: 16 queries per wave on 16 x 16 MFMA tiles, exp(s - max) of the whole strip in 160 VGPRs, one
 // exponential per score, P handed to the P V product without leaving its registers; parity green): 1.22 ms without taps, 1.48 ms
 // with the pattern tap against 0.63 / 0.83 here -- per score it issues MORE instructions, because a wave of 16 queries pays the
-// same tile staging, fragment reads and MFMA issue as a wave of 32 (profiles/r03_notes.md 11).
+// same tile staging, fragment reads and MFMA issue as a wave of 32 (profiles/r03_notes.md 11).  Round 4: a workgroup per 32 queries with
+// the whole [32][T] strip in LDS and the key tiles split over its four waves (QK^T and the exponential once per score, the pattern tap
+// as ONE flat stream per workgroup; parity green): 1.36 ms without taps, 1.61 ms with the pattern tap -- 62 KB of LDS = 8 waves per CU,
+// four serial phases between workgroup barriers, no tile sharing: latency-bound (profiles/r04_l14_attention_strip_in_lds_ab.json).
 // ---------------------------------------------------------------------------------------------------
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(2))) U4a2 { uint32_t x, y, z, w; };      // a 16-byte store at 2-byte alignment
@@ -898,289 +901,6 @@ int launch_attn_lean(const AttnParams& p, hipStream_t stream) {
     return PV_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Long-sequence variant, second form (bf16, T > 64, d_head 64): a WORKGROUP owns 32 query rows of one (image, head) and keeps
-// their whole score / pattern strip [32][T] in LDS (37 KB at T = 577); its four waves split the KEY tiles.
-//   A  wave w takes the key tiles kt = w, w + 4, ...: S^T tile = K Q^T on MFMA (K fragments straight from global: no other wave
-//      wants this tile), scaled + rounded to bf16 like the reference's score tensor, laid into the strip as the query's row;
-//      running max per query
-//   B  (barrier) the rows are dealt to the waves, 8 each, a lane owning key pairs: e = exp(s - max) ONCE per score, kept in
-//      registers across the row sum, p = e / sum rounded to bf16 back into the strip (attention.py:148-150: a row with a NaN /
-//      infinite score is NaN throughout in the reference -> zeros)
-//   C  (barrier) z partial = P V over the wave's key tiles on MFMA (P fragments = 16-byte reads of the strip, V^T staged per wave)
-//   D  hook_pattern (and hook_attn_scores, between A and B): the strip IS the tap -- rows q0 .. q0 + 31 of the head's [T][T]
-//      block are CONTIGUOUS in HBM, and they leave as one flat stream: consecutive lanes write consecutive 16 bytes, a workgroup
-//      its ~37 KB, consecutive workgroups of an XCD consecutive blocks.  The lean kernel above writes the same bytes as
-//      32 x 256-byte pieces 1154 bytes apart per wave every four tiles (3.2 TB/s measured for that pattern against 5.1 - 5.9 for a
-//      sequential stream: profiles/r03_hbm_write_bandwidth_probe.txt) and computes every score twice
-//   E  (barrier) the four partial z blocks meet in the strip's memory; bf16 rows out
-// Against the lean kernel: QK^T once instead of twice, one exponential per score instead of two, no K / V tile sharing (hence no
-// per-tile workgroup barrier: four barriers per workgroup in all), ~0.6 x the wave instructions per score.
-// ---------------------------------------------------------------------------------------------------
-constexpr int ST_MAXTILE = 20;                       // T <= 640
-constexpr int ST_ROW = ST_MAXTILE * 64 + 16;         // strip row: 20 key tiles x 64 B + 16 B (rows then start 4 banks apart)
-
-template <int DH, bool PRESCALE>
-__global__ __launch_bounds__(256) void attn_strip_kernel(const AttnParams p) {
-    static_assert(DH == 64, "d_head 64");
-    __shared__ __attribute__((aligned(16))) unsigned char strip[32 * ST_ROW];            // scores, then pattern, then the z partials
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[4][DH * L2_VROW];           // per wave: V^T tile [d][32 keys]
-    __shared__ float red_m[4][32];
-    constexpr int NKS = DH / 16;
-    constexpr int NTN = DH / 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int T_ = p.T, H = p.H;
-    const int qblocks = (T_ + 31) / 32;
-    int bid = blockIdx.x;
-    {   // whole heads per XCD (see the lean kernel): the blocks of a head share one L2's copy of its K / V, and an XCD's writes are
-        // consecutive blocks of consecutive heads
-        const int heads = p.B * H, per_xcd = heads / 8;
-        if (bid < per_xcd * 8 * qblocks) {
-            const int xcd = bid & 7, i = bid >> 3;
-            bid = ((i / qblocks) * 8 + xcd) * qblocks + i % qblocks;
-        }
-    }
-    const int g = bid / qblocks;                            // (image, head)
-    const int q0 = (bid - g * qblocks) * 32;
-    const int b = g / H, h = g - b * H;
-    const int half = lane >> 5, l31 = lane & 31;
-    const unsigned tokb = (unsigned)H * DH * 2u;
-    const int64_t head_off = ((int64_t)b * T_ * H + h) * DH;
-    const int span = (int)((unsigned)(T_ - 1) * tokb + DH * 2u);
-    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.q) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.k) + head_off), 0, span, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.v) + head_off), 0, span, 0x00020000);
-    const int ntile = (T_ + 31) / 32;
-    const int n_rows = min(32, T_ - q0);                    // real query rows of this block
-    const float inv_scale = 1.0f / p.attn_scale;
-    const f32x2_t inv_scale2 = {inv_scale, inv_scale};
-
-    // Q as the B operand (columns = the block's queries): lane (query l31, half) holds d-chunk (2 ks + half); rows >= T read 0
-    u32x4_t qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (unsigned)(q0 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
-        if (PRESCALE) {
-            uint32_t w[4] = {qf[ks].x, qf[ks].y, qf[ks].z, qf[ks].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                w[i] = pack_bf16x2(__uint_as_float(w[i] << 16) * inv_scale, __uint_as_float(w[i] & 0xffff0000u) * inv_scale);
-            qf[ks] = u32x4_t{w[0], w[1], w[2], w[3]};
-        }
-    }
-
-    // ---- A: scores of the wave's key tiles -> strip; running max
-    auto k_frag = [&](int kt, u32x4_t (&kf)[NKS]) {          // key row kt * 32 + l31 (rows >= T read 0), d-chunk 2 ks + half
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            kf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsK, (unsigned)(kt * 32 + l31) * tokb + (2 * ks + half) * 16, 0, 0);
-    };
-    float m = -INFINITY;
-    {
-        u32x4_t kf[NKS], kn[NKS];
-        if (wave < ntile) k_frag(wave, kf);
-        for (int kt = wave; kt < ntile; kt += 4) {
-            if (kt + 4 < ntile) k_frag(kt + 4, kn);
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[ks]), __builtin_bit_cast(bf16x8, qf[ks]), acc, 0, 0, 0);
-            // this lane: query l31, keys kt * 32 + key_of(e), key_of(e) = (e & 3) + 8 (e >> 2) + 4 half
-            uint32_t pk[8];
-            const bool tail = kt + 1 == ntile;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                f32x2_t t = {acc[2 * i], acc[2 * i + 1]};
-                if (!PRESCALE) t = t * inv_scale2;
-                pk[i] = pack_bf16x2(t.x, t.y);
-                float s0 = __uint_as_float(pk[i] << 16), s1 = __uint_as_float(pk[i] & 0xffff0000u);
-                if (tail) {
-                    if (kt * 32 + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * half >= T_) s0 = -INFINITY;
-                    if (kt * 32 + ((2 * i + 1) & 3) + 8 * ((2 * i + 1) >> 2) + 4 * half >= T_) s1 = -INFINITY;
-                }
-                m = fmaxf(m, fmaxf(s0, s1));
-            }
-            // C layout -> the query's row: keys ks * 16 + half * 8 + 0..7 are 16 contiguous bytes (as to_rows of the lean kernel)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 0], pk[4 * ks + 2], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
-                *reinterpret_cast<u32x4_t*>(strip + l31 * ST_ROW + kt * 64 + (2 * ks + half) * 16) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
-            }
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) kf[ks] = kn[ks];
-        }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        if (half == 0) red_m[wave][l31] = m;
-    }
-    __syncthreads();
-
-    // the strip as a tap: rows [q0, q0 + n_rows) of the head's [T][T] block, T * 2 bytes each, contiguous in HBM.  16-byte pieces of
-    // a row at the row's own 2-byte alignment; the last piece of a row is partial when T * 2 is not a multiple of 16
-    const int cpr = (T_ * 2 + 15) / 16;                      // pieces per row
-    const int last_bytes = T_ * 2 - (cpr - 1) * 16;
-    auto tap_out = [&](unsigned char* dst_head) {
-        const int items = n_rows * cpr;
-        for (int it = threadIdx.x; it < items; it += 256) {
-            const int row = it / cpr, c = it - row * cpr;
-            const unsigned char* src = strip + row * ST_ROW + c * 16;
-            unsigned char* d = dst_head + ((size_t)(uint32_t)((q0 + row) * T_)) * 2 + c * 16;
-            if (c + 1 < cpr || last_bytes == 16) {
-                const uint4 r = *reinterpret_cast<const uint4*>(src);
-                *reinterpret_cast<U4a2*>(d) = U4a2{r.x, r.y, r.z, r.w};
-            } else {
-                for (int e = 0; e < last_bytes / 2; ++e)
-                    *reinterpret_cast<unsigned short*>(d + 2 * e) = *reinterpret_cast<const unsigned short*>(src + 2 * e);
-            }
-        }
-    };
-    if (p.scores) {
-        tap_out(reinterpret_cast<unsigned char*>(p.scores) + (int64_t)g * T_ * T_ * 2);
-        __syncthreads();                                      // (the strip is rewritten below)
-    }
-
-    // ---- B: softmax of the wave's 8 rows, a lane owning the key pairs lane, lane + 64, ...  Three sweeps over the 8 rows (exponentials,
-    // the row sums, the normalised values) rather than one row after the other: eight independent reductions in flight
-    {
-        constexpr int NP = (ST_MAXTILE * 16 + 63) / 64;       // key pairs per lane, at most (T <= 640: 5)
-        const int npair = (T_ + 1) / 2;
-        float e0[8][NP], e1[8][NP], sum[8], M[8];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr;
-            M[rr] = fmaxf(fmaxf(red_m[0][row], red_m[1][row]), fmaxf(red_m[2][row], red_m[3][row]));
-            sum[rr] = 0.f;
-            const unsigned char* rp = strip + row * ST_ROW;
-            const float nb = -(M[rr] * PV_LOG2E);
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int j = lane + 64 * i;
-                e0[rr][i] = e1[rr][i] = 0.f;
-                if (j < npair && row < n_rows) {
-                    const uint32_t w = *reinterpret_cast<const uint32_t*>(rp + 4 * j);
-                    e0[rr][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(__uint_as_float(w << 16), PV_LOG2E, nb));
-                    e1[rr][i] = 2 * j + 1 < T_ ? __builtin_amdgcn_exp2f(__builtin_fmaf(__uint_as_float(w & 0xffff0000u), PV_LOG2E, nb)) : 0.f;
-                    sum[rr] += e0[rr][i] + e1[rr][i];
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) sum[rr] += __shfl_xor(sum[rr], o, 64);
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr;
-            // a row with an infinite / NaN score (or none at all) is NaN throughout in the reference -> zeros (attention.py:149)
-            const bool row_ok = sum[rr] > 0.f && sum[rr] < INFINITY && M[rr] > -INFINITY && M[rr] < INFINITY;
-            const float inv = row_ok ? 1.0f / sum[rr] : 0.f;
-            unsigned char* rp = strip + row * ST_ROW;
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int j = lane + 64 * i;
-                if (j < npair && row < n_rows)
-                    *reinterpret_cast<uint32_t*>(rp + 4 * j) = pack_bf16x2(row_ok ? e0[rr][i] * inv : 0.f, row_ok ? e1[rr][i] * inv : 0.f);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- C: z partial of the wave's key tiles
-    f32x16 zacc[NTN];
-#pragma unroll
-    for (int tn = 0; tn < NTN; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) zacc[tn][e] = 0.f;
-    {
-        unsigned char* vb = Vt[wave];
-        // the wave moves its 32-key V tile itself: lane -> key lane & 31, d-chunks (lane >> 5) + 2 i
-        auto v_fetch = [&](int kt, u32x4_t (&vv)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                vv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsV, (unsigned)(kt * 32 + l31) * tokb + (half + 2 * i) * 16, 0, 0);
-        };
-        u32x4_t vv[4], vn[4];
-        if (wave < ntile) v_fetch(wave, vv);
-        for (int kt = wave; kt < ntile; kt += 4) {
-            if (kt + 4 < ntile) v_fetch(kt + 4, vn);
-            __builtin_amdgcn_wave_barrier();                  // (the previous tile's fragment reads are behind us: same wave, in-order LDS)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t w[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
-                const int dc = half + 2 * i;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    *reinterpret_cast<unsigned short*>(vb + (dc * 8 + 2 * u) * L2_VROW + l31 * 2) = (unsigned short)(w[u] & 0xffffu);
-                    *reinterpret_cast<unsigned short*>(vb + (dc * 8 + 2 * u + 1) * L2_VROW + l31 * 2) = (unsigned short)(w[u] >> 16);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint4 pa = *reinterpret_cast<const uint4*>(strip + l31 * ST_ROW + kt * 64 + (2 * ks + half) * 16);
-#pragma unroll
-                for (int tn = 0; tn < NTN; ++tn) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(vb + (tn * 32 + l31) * L2_VROW + (16 * ks + 8 * half) * 2);
-                    zacc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pa), __builtin_bit_cast(bf16x8, vf), zacc[tn], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) vv[i] = vn[i];
-        }
-    }
-
-    // ---- D: hook_pattern
-    if (p.pattern) tap_out(reinterpret_cast<unsigned char*>(p.pattern) + (int64_t)g * T_ * T_ * 2);
-    __syncthreads();                                          // every read of the strip (P fragments, the tap) is done
-
-    // ---- E: the four partial z blocks [32 queries][DH] meet in the strip's memory; row = query, as fp32
-    {
-        float* zr = reinterpret_cast<float*>(strip) + wave * (32 * DH);
-#pragma unroll
-        for (int tn = 0; tn < NTN; ++tn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-                zr[row * DH + tn * 32 + l31] = zacc[tn][e];
-            }
-    }
-    __syncthreads();
-    {
-        const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;             // 32 rows x 8 chunks of 8 d-values
-        if (row < n_rows) {
-            const float* z0 = reinterpret_cast<const float*>(strip) + row * DH + ch * 8;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (z0[e] + z0[32 * DH + e]) + (z0[2 * 32 * DH + e] + z0[3 * 32 * DH + e]);
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            bf16_t* zb = reinterpret_cast<bf16_t*>(p.z) + head_off;
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(zb) + (int64_t)(q0 + row) * tokb + ch * 16) = o;
-        }
-    }
-}
-
-int launch_attn_strip(const AttnParams& p, hipStream_t stream) {
-    const int heads = p.B * p.H, qblocks = (p.T + 31) / 32;
-    int ex = 0;
-    const bool pow2 = p.attn_scale > 0.f && std::frexp(p.attn_scale, &ex) == 0.5f;
-    {
-        const double bh = (double)heads, tt = (double)p.T * p.T;
-        const double bytes = (4.0 * bh * p.T * p.dh + ((p.scores ? 1.0 : 0.0) + (p.pattern ? 1.0 : 0.0)) * bh * tt) * 2.0;
-        ProfScope prof(PV_PROF_ATTN, stream, 4.0 * bh * tt * p.dh, bytes);
-        if (pow2) hipLaunchKernelGGL((attn_strip_kernel<64, true>), dim3(heads * qblocks), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attn_strip_kernel<64, false>), dim3(heads * qblocks), dim3(256), 0, stream, p);
-    }
-    PV_LAUNCH_CHECK("attn_strip_kernel");
-    return PV_OK;
-}
-
 template <typename T>
 int dispatch_attn(AttnParams& p, hipStream_t stream) {
     p.Tpad = (p.T + 31) / 32 * 32;
@@ -1195,9 +915,7 @@ int dispatch_attn(AttnParams& p, hipStream_t stream) {
     }
     if constexpr (sizeof(T) == 2) {
         if (p.T > 64 && p.dh == 64 && pv_aligned16(p.z) && !g_pv_tuning.attn_wg &&
-            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 31) / 32) < (1ll << 31)) {
-            // strip-in-LDS form (a workgroup per 32 queries) unless the tuning key attn_lean asks for the two-pass form
-            if (!g_pv_tuning.attn_lean && (int64_t)p.T * p.T * 2 < (1ll << 31)) return launch_attn_strip(p, stream);
+            (int64_t)p.T * p.H * p.dh * 2 < (1ll << 31) && (int64_t)p.B * p.H * ((p.T + 127) / 128) < (1ll << 31)) {
             return launch_attn_lean(p, stream);
         }
     }

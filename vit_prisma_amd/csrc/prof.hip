@@ -130,7 +130,6 @@ namespace {
 int* tuning_field(const char* key) {
     if (!key) return nullptr;
     if (!strcmp(key, "gemm_tile")) return &g_pv_tuning.gemm_tile;
-    if (!strcmp(key, "attn_lean")) return &g_pv_tuning.attn_lean;
     if (!strcmp(key, "gemm_v1")) return &g_pv_tuning.gemm_v1;
     if (!strcmp(key, "gemm_v1patch")) return &g_pv_tuning.gemm_v1patch;
     if (!strcmp(key, "attn_wg")) return &g_pv_tuning.attn_wg;
@@ -163,7 +162,7 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
     if (!strcmp(key, "any")) {
         const PvTuning d;
         const PvTuning& t = g_pv_tuning;
-        *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_lean != d.attn_lean || t.attn_direct != d.attn_direct ||
+        *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct ||
                   t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg || t.gemm_loop != d.gemm_loop) ? 1 : 0;
         return PV_OK;
     }

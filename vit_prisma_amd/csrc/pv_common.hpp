@@ -146,7 +146,6 @@ struct PvTuning {
     int gemm_v1 = 0;         // 1: register-staged 128 x 128 kernel for everything
     int gemm_v1patch = 0;    // 1: register-staged kernel for the patch embedding only
     int attn_wg = 0;         // 1: workgroup-per-(image, head, query block) attention kernel for every shape
-    int attn_lean = 0;       // 1: the two-pass 128-query long-sequence attention kernel instead of the strip-in-LDS one (T > 64)
     int attn_direct = 0;     // 1: the one-wave-per-head attention kernel loads its Q / K fragments straight from global (no whole-row staging)
     int prof_markers = 0;    // 1: time v7 launches with hipEventRecord markers instead of dispatch-packet events
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)

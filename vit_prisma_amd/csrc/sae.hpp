@@ -77,7 +77,7 @@ ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap);
 // sae_enc.hip: the positive entries of relu(sae_in W_enc + b_enc) per token (see the definition); raises *mode when a token cannot be held
 int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
                     float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
-                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
 // sae.hip: everything of the k-sparse step behind the selection (see the definition)
 int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
                     const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,

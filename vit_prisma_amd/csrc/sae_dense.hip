@@ -38,7 +38,7 @@ constexpr int DG_TILE = DG_BM * DG_ROWB;      // 18432 >= 32 * 528
 constexpr int DG_CS_LD = 68;                  // fp32 staging row of the epilogue (floats)
 constexpr int DG_LDS = 4 * DG_TILE;           // As[2] + Bs[2] = 73728 >= 4 waves x 64 x 68 x 4
 
-enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3, DG_EPI_GENC = 4 };
+enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3, DG_EPI_GENC = 4, DG_EPI_EXPB = 5 };   // EXPB: out = exp(acc + bias)
 
 struct DenseGemm {
     const float* A; int64_t lda;              // A_KM ? [K][lda] (M contiguous) : [M][lda] (K contiguous)
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     for (int i = 0; i < 8; ++i) csum[i] = 0.f;
     float rsum = 0.f;
     float b8[8];
-    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_GENC) {
+    if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_GENC || EPI == DG_EPI_EXPB) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) b8[i] = 0.f;
         if (col_ok) load8(p.bias + gn, b8);
@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                     csum[i] += v[i];                                  // gb_enc
                     csum2[i] += v[i] * f8[i];
                 }
+            } else if constexpr (EPI == DG_EPI_EXPB) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __expf(v[i] + b8[i]);       // exp(hidden_pre) of the dead features (sae.py:163), as DG_EPI_ENC writes it
             } else if constexpr (EPI == DG_EPI_MUL) {
                 float m8[8];
                 load8(p.mul + (int64_t)gm * p.ldo + gn, m8);
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void dense_sumz_kernel(const float* __restrict
 
 namespace {
 struct GhostWs {
-    size_t total, dead_act, dhd, wdd, g0, dg0, err, tmpw, colmean, part, colpart;
+    size_t total, dead_act, dhd, wdd, g0, dg0, err, tmpw, colmean, part, colpart, vec_a, vec_b, colpart_p;
     int n_pad;
 };
 GhostWs ghost_carve(const pv_sae_desc& d, int N, int n_dead) {
@@ -493,8 +496,37 @@ GhostWs ghost_carve(const pv_sae_desc& d, int N, int n_dead) {
     w.colmean = take(D * 4);
     w.part = take(n * 4);
     w.colpart = take((n / 16 + 2) * D * 4);
+    w.vec_a = take((P + 8) * 4);                       // pv_sae_topk_ghost: b_enc of the dead features / column sums over them
+    w.vec_b = take((P + 8) * 4);
+    w.colpart_p = take((n / 16 + 2) * (P + 8) * 4);
     w.total = off + 256;
     return w;
+}
+
+// out[s] = src[idx[s]] for s < n, pad_value up to n_pad
+__global__ __launch_bounds__(256) void ghost_gather_vec_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n, int n_pad,
+                                                               float pad_value, float* __restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_pad) out[s] = s < n ? src[idx[s]] : pad_value;
+}
+// dst[idx[s]] += add[s]
+__global__ __launch_bounds__(256) void ghost_scatter_add_vec_kernel(float* __restrict__ dst, const int32_t* __restrict__ idx, int n,
+                                                                    const float* __restrict__ add) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) dst[idx[s]] += add[s];
+}
+// err = sae_out - y
+__global__ __launch_bounds__(256) void ghost_err_kernel(const float* __restrict__ sae_out, const float* __restrict__ y, float* __restrict__ err,
+                                                        int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = reinterpret_cast<const float4*>(sae_out)[i], b = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(err)[i] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+}
+// scalars[0] = mse + ghost residual loss (top-k: no L1 term), scalars[4] = 0
+__global__ void topk_ghost_loss_kernel(float* __restrict__ scalars) {
+    scalars[4] = 0.f;
+    scalars[0] = scalars[1] + scalars[5];
 }
 }  // namespace
 
@@ -831,7 +863,7 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
         {
             ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae, ((double)N * d.d_in + (double)d.d_in * d.d_sae) * 2.0);
             rc = sae_encode_relu(d, st, N, cap, idx, val, tok_cnt, l1part, (uint32_t*)(rwb + rw.cand_cnt), rwb + rw.cand,
-                                 (uint32_t*)(wsb + ws.cnt), (uint32_t*)(rwb + rw.wpos), mode, wsb, ws, stream);
+                                 (uint32_t*)(wsb + ws.cnt), (uint32_t*)(rwb + rw.wpos), mode, (const float*)out->scalars, wsb, ws, stream);
             if (rc) return rc;
         }
         SaeTail tb;
@@ -851,6 +883,108 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
     }
     GhostWs gw = {};
     return dense_step_body(plan, st, x, N, n_global, update_stats, l1_coefficient, nullptr, gw, out, wsb, ws, skip, mode, stream);
+}
+
+// Ghost gradients on a TOP-K SAE (use_ghost_grads with activation_fn_str = "topk": SparseAutoencoder._compute_ghost_residual_loss,
+// sae.py:151-179, behind TopK :795-810; the dead mask of train_sae.py:330-332).  Runs AFTER pv_sae_step on the same batch (complete
+// gradient buffers: no PV_SAE_SPARSE_GRADS; the decoder renormalised in place beforehand: pv_sae_renorm_decoder, no
+// PV_SAE_RENORM_DECODER) and adds what the ghost term contributes: exp(hidden_pre) of the dead features is ONE small GEMM
+// (sae_in against the gathered rows of W_encT, exp in its epilogue -- the k-sparse encoder never materialises hidden_pre), the
+// ghost reconstruction, its loss (scalars[5]; scalars[0] = mse + ghost) and gradient as in pv_sae_dense_step, and the gradient
+// reaches the dead features' rows of gW_dec, gW_enc^T, gb_enc (row scatter-adds) and gb_dec (recomputed).  The per-feature
+// norm terms of the step are stale afterwards: follow with pv_sae_grad_sqnorm over the whole flat buffer, then pv_sae_apply.
+// out->sae_out must be the reconstruction pv_sae_step wrote; ghost as for pv_sae_dense_step.  Single process, no transcoder.
+extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const pv_sae_ghost* ghost, pv_sae_out* out,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(plan && st && x && ghost && out && workspace, "null argument");
+    PV_REQUIRE(out->sae_out && out->scalars, "pv_sae_out: sae_out (as pv_sae_step wrote it) and scalars are required");
+    PV_REQUIRE(st->W_dec && st->W_encT && st->b_enc && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
+    PV_REQUIRE(!sae_is_tc(st) && !sae_is_gated(st), "top-k ghost gradients: plain SAE only");
+    PV_REQUIRE(!plan->renorm_pending, "top-k ghost gradients need the decoder renormalised IN PLACE before the step (pv_sae_renorm_decoder), "
+                                      "not deferred (PV_SAE_RENORM_DECODER)");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && N <= d.max_tokens, "n_tokens exceeds plan max_tokens");
+    PV_REQUIRE(d.d_in % 8 == 0, "d_in must be a multiple of 8");
+    const int nd = ghost->n_dead, D = d.d_in;
+    PV_REQUIRE(nd >= 0 && nd <= d.d_sae && ghost->workspace && (nd == 0 || (ghost->dead_idx && ghost->dead_slot)), "pv_sae_ghost");
+    const GhostWs gw = ghost_carve(d, N, nd);
+    PV_REQUIRE(ghost->workspace_bytes >= gw.total && ((uintptr_t)ghost->workspace & 255) == 0, "ghost workspace too small / misaligned");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total && ((uintptr_t)workspace & 255) == 0, "workspace too small / misaligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    unsigned char* gwb = (unsigned char*)ghost->workspace;
+    const float* sae_in = (const float*)(wsb + ws.sae_in);
+    const float* dY = (const float*)(wsb + ws.dY);
+    float* err = (float*)(gwb + gw.err);
+    float* g0 = (float*)(gwb + gw.g0);
+    float* dg0 = (float*)(gwb + gw.dg0);
+    float* act = (float*)(gwb + gw.dead_act);
+    float* wdd = (float*)(gwb + gw.wdd);
+    float* tmpw = (float*)(gwb + gw.tmpw);
+    float* dhd = (float*)(gwb + gw.dhd);
+    const int P = gw.n_pad;
+    int rc = PV_OK;
+    hipLaunchKernelGGL(ghost_err_kernel, dim3((unsigned)(((int64_t)N * D / 4 + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)out->sae_out, x, err, (int64_t)N * D / 4);
+    if (nd > 0) {
+        // E = exp(sae_in @ W_enc[:, dead] + b_enc[dead]): the rows of W_encT of the dead features, gathered (tmpw holds them until it is
+        // needed for the gradients); padding columns get a bias of -1e30 (E = 0 there)
+        hipLaunchKernelGGL(ghost_gather_rows_kernel, dim3(P), dim3(256), 0, stream, (const float*)st->W_encT, ghost->dead_idx, nd, P, D, tmpw);
+        hipLaunchKernelGGL(ghost_gather_vec_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, (const float*)st->b_enc, ghost->dead_idx, nd, P,
+                           -1e30f, (float*)(gwb + gw.vec_a));
+        DenseGemm ge = {};
+        ge.A = sae_in; ge.lda = D; ge.B = tmpw; ge.ldb = D; ge.M = N; ge.N = P; ge.K = D; ge.k_chunk = D;
+        ge.out = act; ge.ldo = P; ge.bias = (const float*)(gwb + gw.vec_a);
+        rc = launch_dense_gemm<false, false, DG_EPI_EXPB>(ge, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ghost_gather_rows_kernel, dim3(P), dim3(256), 0, stream, (const float*)st->W_dec, ghost->dead_idx, nd, P, D, wdd);
+        DenseGemm gg = {};
+        gg.A = act; gg.lda = P; gg.B = wdd; gg.ldb = D; gg.M = N; gg.N = D; gg.K = P; gg.k_chunk = P;
+        gg.out = g0; gg.ldo = D;
+        rc = launch_dense_gemm<false, true, DG_EPI_STORE>(gg, 1, stream);
+        if (rc) return rc;
+    } else {
+        PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
+    }
+    rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0,
+                       (const float*)(gwb + gw.colmean), (const float*)out->scalars, dg0, (float*)(gwb + gw.part), N, D,
+                       1.0f / ((float)N * (float)D));
+    PV_LAUNCH_CHECK("ghost_rows_kernel");
+    sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, 1.0f / ((float)N * (float)D), 5, -1, stream);
+    hipLaunchKernelGGL(topk_ghost_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
+    if (nd > 0) {
+        // dHd = (dG0 @ W_dec[dead]^T) * E: what reaches hidden_pre of the dead features, for every token
+        DenseGemm gb = {};
+        gb.A = dg0; gb.lda = D; gb.B = wdd; gb.ldb = D; gb.M = N; gb.N = P; gb.K = D; gb.k_chunk = D;
+        gb.out = dhd; gb.ldo = P; gb.mul = act;
+        rc = launch_dense_gemm<false, false, DG_EPI_MUL>(gb, 1, stream);
+        if (rc) return rc;
+        // gW_dec[dead] += E^T @ dG0
+        DenseGemm gt = {};
+        gt.A = act; gt.lda = P; gt.B = dg0; gt.ldb = D; gt.M = P; gt.N = D; gt.K = N; gt.k_chunk = N; gt.out = tmpw; gt.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(gt, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ghost_scatter_add_rows_kernel, dim3(nd), dim3(256), 0, stream, st->gW_dec, ghost->dead_idx, nd, D, (const float*)tmpw);
+        // gW_enc^T[dead] += dHd^T @ sae_in
+        DenseGemm gu = {};
+        gu.A = dhd; gu.lda = P; gu.B = sae_in; gu.ldb = D; gu.M = P; gu.N = D; gu.K = N; gu.k_chunk = N; gu.out = tmpw; gu.ldo = D;
+        rc = launch_dense_gemm<true, true, DG_EPI_STORE>(gu, 1, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ghost_scatter_add_rows_kernel, dim3(nd), dim3(256), 0, stream, st->gW_enc, ghost->dead_idx, nd, D, (const float*)tmpw);
+        // gb_enc[dead] += colsum(dHd); gb_dec = colsum(dY) - W_enc gb_enc again
+        rc = sae_colsum(dhd, N, P, (float*)(gwb + gw.vec_b), 1.0f, (float*)(gwb + gw.colpart_p), stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ghost_scatter_add_vec_kernel, dim3((nd + 255) / 256), dim3(256), 0, stream, st->gb_enc, ghost->dead_idx, nd,
+                           (const float*)(gwb + gw.vec_b));
+        PV_LAUNCH_CHECK("ghost scatter kernels");
+        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        if (rc) return rc;
+    }
+    plan->live_offs = nullptr;
+    return PV_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -95,6 +95,15 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
     const int tile_m = rem / wcur, tile_n = blk * wblk + (rem - tile_m * wcur);
     const int m0 = tile_m * TM, n0 = tile_n * TN;
 
+    if constexpr (MODE == 1) {
+        if (p.mode) {                                             // (ReLU filter) the step is dense already: nothing to filter
+            if (tid == 0) hit_n = __hip_atomic_load(p.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool skip = hit_n != 0u;
+            __syncthreads();
+            if (skip) return;
+        }
+    }
     const unsigned Kb = (unsigned)p.K * 2u;
     const int nk = (int)((Kb + 63) / 64);
     const bool ktail = (Kb % 64) != 0;
@@ -712,10 +721,20 @@ __global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restr
 // more than PV_SAE_CAND_CAP survivors raise the step's `mode` word: the step then runs on the dense GEMMs instead (sae_dense.hip),
 // so nothing is ever approximated.
 // ---------------------------------------------------------------------------------------------------
+// mode[0] = the step's mode word, mode[1] = dense steps in a row whose sparse attempt was skipped.  The attempt itself costs ~0.5 ms when
+// it fails (one filter GEMM over all features): while the run is far from the sparse regime -- the previous step ran dense and kept more
+// than twice the capacity per token on average (scalars[2] = its l0) -- the step goes dense at once (the filter GEMM and the selection
+// leave on the raised word) and only every eighth such step probes.  Which form runs never changes a result.
 __global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__ xnorm, const float* __restrict__ wmax_sq, int d_in,
-                                                       float* __restrict__ thr, int n_tok, uint32_t* __restrict__ mode) {
+                                                       float* __restrict__ thr, int n_tok, uint32_t* __restrict__ mode,
+                                                       const float* __restrict__ scalars, int cap) {
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n == 0) *mode = 0u;
+    if (n == 0) {
+        const bool far = mode[0] == 1u && scalars && scalars[2] > 2.0f * (float)cap;
+        const uint32_t streak = far ? mode[1] + 1u : 0u;
+        mode[1] = streak;
+        mode[0] = (far && (streak & 7u) != 0u) ? 1u : 0u;
+    }
     if (n >= n_tok) return;
     const float wmx = sqrtf(*wmax_sq);
     const float c2 = 2.98023224e-8f * sqrtf((float)d_in);
@@ -943,14 +962,14 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
 
 int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
                     float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
-                    unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
     PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
     PV_REQUIRE(cap >= 4 && cap <= PV_SAE_RELU_CAP_MAX && cap % 4 == 0, "cap");
     float* wmax = (float*)(wsb + ws.wmax);
     uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
     hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count, feat_cnt);
     hipLaunchKernelGGL(relu_thr_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)(wsb + ws.xnorm), (const float*)wmax,
-                       d.d_in, (float*)(wsb + ws.thr), N, mode);
+                       d.d_in, (float*)(wsb + ws.thr), N, mode, prev_scalars, cap);
     PV_LAUNCH_CHECK("relu_thr_kernel");
     EncParams p = {};
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;

@@ -305,20 +305,7 @@ class NativeSAE:
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
         bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
-        ghost = None
-        if dead_mask is not None:
-            idx = torch.nonzero(dead_mask.to(self.device), as_tuple=False).flatten().to(torch.int32)     # (synchronises: n_dead is a launch size)
-            nd = int(idx.numel())
-            slot = torch.full((self.d_sae,), -1, dtype=torch.int32, device=self.device)
-            if nd:
-                slot[idx.long()] = torch.arange(nd, dtype=torch.int32, device=self.device)
-            need = self.lib.pv_sae_ghost_workspace_bytes(self._plan, n, nd)
-            gws = getattr(self, "_ghost_ws", None)
-            if gws is None or gws.numel() < need:
-                self._ghost_ws = gws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self._ghost_keep = (idx, slot)                        # (alive until the kernels have run)
-            ghost = N.SaeGhost(n_dead=nd, dead_idx=idx.data_ptr() if nd else None, dead_slot=slot.data_ptr(),
-                               workspace=gws.data_ptr(), workspace_bytes=gws.numel())
+        ghost = self._ghost_struct(dead_mask, n) if dead_mask is not None else None
         N.check(self.lib.pv_sae_dense_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                            int(n_global if n_global is not None else n),
                                            int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient),
@@ -383,6 +370,39 @@ class NativeSAE:
         n, cap = self._relu_last
         return (self._relu_region(b"idx", torch.int32, (n, cap)), self._relu_region(b"val", torch.float32, (n, cap)),
                 self._relu_region(b"tok_cnt", torch.int32, (n,)))
+
+    def _ghost_struct(self, dead_mask: torch.Tensor, n: int) -> "N.SaeGhost":
+        """pv_sae_ghost for the features ``dead_mask`` marks (one device read-back: their number sizes three small GEMMs)."""
+        idx = torch.nonzero(dead_mask.to(self.device), as_tuple=False).flatten().to(torch.int32)     # (synchronises: n_dead is a launch size)
+        nd = int(idx.numel())
+        slot = torch.full((self.d_sae,), -1, dtype=torch.int32, device=self.device)
+        if nd:
+            slot[idx.long()] = torch.arange(nd, dtype=torch.int32, device=self.device)
+        need = self.lib.pv_sae_ghost_workspace_bytes(self._plan, n, nd)
+        gws = getattr(self, "_ghost_ws", None)
+        if gws is None or gws.numel() < need:
+            self._ghost_ws = gws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ghost_keep = (idx, slot)                            # (alive until the kernels have run)
+        return N.SaeGhost(n_dead=nd, dead_idx=idx.data_ptr() if nd else None, dead_slot=slot.data_ptr(),
+                          workspace=gws.data_ptr(), workspace_bytes=gws.numel())
+
+    def topk_ghost(self, x: torch.Tensor, dead_mask: torch.Tensor) -> None:
+        """Ghost gradients of a top-k SAE (pv_sae_topk_ghost; sae.py:151-179 with train_sae.py:330-346), added to what the
+        preceding ``step(x, renorm_decoder=False, sparse_grads=False, want_out=True)`` left (the decoder renormalised by
+        ``renorm_decoder()`` before it): scalars[5] = ghost residual loss, scalars[0] = mse + ghost, the dead features' gradient rows
+        and gb_dec updated.  dead_mask [d_sae] bool = ``n_forward_passes_since_fired > dead_feature_window`` BEFORE that step.
+        Follow with ``grad_sqnorm()`` (the full pass) and ``apply``."""
+        x = self._check_x(x)
+        n = x.shape[0]
+        assert not self.transcoder and not self.gated
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr(), topk_idx=None, topk_val=None, scalars=self.scalars.data_ptr(),
+                       fire_count=self.fire_count.data_ptr())
+        ghost = self._ghost_struct(dead_mask, n)
+        N.check(self.lib.pv_sae_topk_ghost(self._plan, C.byref(st), x.data_ptr(), n, C.byref(ghost), C.byref(out),
+                                           self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_topk_ghost")
+        self._grad_fresh = False                                  # (the per-feature norm terms of the step no longer describe the buffers)
+        self._grad_sparse = False
 
     def gated_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False) -> None:

@@ -214,7 +214,9 @@ class VisionSAETrainer:
             return None
         if is_gated:
             return "gated"
-        if cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64 and not cfg.use_ghost_grads:
+        if (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
+                # ghost gradients on top-k (pv_sae_topk_ghost): single process, plain SAE, d_in a multiple of 8
+                and (not cfg.use_ghost_grads or (not self._mr and not is_tc and cfg.d_in % 8 == 0))):
             return "topk"
         if (cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
                 and not (cfg.use_ghost_grads and self._mr)):                 # (ghost gradients natively: single process)
@@ -361,7 +363,17 @@ class VisionSAETrainer:
         # statistics tensors are the caller's: the kernels update them in place
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
-        if not self._mr:
+        ghost = bool(sae.cfg.use_ghost_grads) and sae.training and not eng.transcoder
+        if not self._mr and ghost:
+            # top-k + ghost gradients (sae.py:151-179; the mask of train_sae.py:330-332 is taken BEFORE this step's statistics): the
+            # k-sparse step with complete gradient buffers over a decoder renormalised in place, then the ghost term's additions
+            dead = n_since_fired > sae.cfg.dead_feature_window
+            eng.renorm_decoder()
+            eng.step(x, update_stats=True, renorm_decoder=False, sparse_grads=False, want_out=True)
+            eng.topk_ghost(x, dead)
+            eng.grad_sqnorm()
+            eng.apply(lr, self.cfg.max_grad_norm)
+        elif not self._mr:
             # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
             # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
             eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True, target=self._target if eng.transcoder else None)
