@@ -119,3 +119,47 @@ def test_trainer_run_end_to_end_on_the_tiny_model(tmp_path, b_dec_init):
     assert ck and os.path.exists(os.path.join(cfg.checkpoint_path, "config.json"))
     back = StandardSparseAutoencoder.load_from_pretrained(os.path.join(cfg.checkpoint_path, ck[0]))
     assert torch.allclose(back.W_dec, sae.W_dec) and float((back.W_dec.norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+def test_load_hooked_model_offline_from_a_local_open_clip_checkpoint(tmp_path):
+    """The notebook entry point (models/model_loader.py:278-368) through the ``vit_prisma`` alias: config from the architecture table of
+    the named model, weights from a LOCAL open_clip checkpoint (the build has no network), same forward as a HookedViT loaded by hand."""
+    import torch
+    import vit_prisma_amd
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    vit_prisma_amd.install_as("vit_prisma", force=True)
+    try:
+        from vit_prisma.models.model_loader import load_hooked_model, list_available_models
+        name = "open-clip:laion/CLIP-ViT-B-32-DataComp.XL-s13B-b90K"
+        assert name in list_available_models()
+        arch = ARCHS["clip-vit-b32"]
+        # an open_clip-layout checkpoint of the B/32 shape (random values), written to disk
+        g = torch.Generator().manual_seed(0)
+        d, L, p, T, ncls = arch["d_model"], arch["n_layers"], arch["patch_size"], 50, arch["n_classes"]
+        sd = {"visual.class_embedding": torch.randn(d, generator=g) * 0.1, "visual.positional_embedding": torch.randn(T, d, generator=g) * 0.1,
+              "visual.conv1.weight": torch.randn(d, 3, p, p, generator=g) * 0.02, "visual.ln_pre.weight": torch.ones(d), "visual.ln_pre.bias": torch.zeros(d),
+              "visual.ln_post.weight": torch.ones(d), "visual.ln_post.bias": torch.zeros(d), "visual.proj": torch.randn(d, ncls, generator=g) * 0.03}
+        for l in range(L):
+            o = f"visual.transformer.resblocks.{l}"
+            sd.update({o + ".attn.in_proj_weight": torch.randn(3 * d, d, generator=g) * 0.03, o + ".attn.in_proj_bias": torch.zeros(3 * d),
+                       o + ".attn.out_proj.weight": torch.randn(d, d, generator=g) * 0.03, o + ".attn.out_proj.bias": torch.zeros(d),
+                       o + ".ln_1.weight": torch.ones(d), o + ".ln_1.bias": torch.zeros(d), o + ".ln_2.weight": torch.ones(d), o + ".ln_2.bias": torch.zeros(d),
+                       o + ".mlp.c_fc.weight": torch.randn(4 * d, d, generator=g) * 0.03, o + ".mlp.c_fc.bias": torch.zeros(4 * d),
+                       o + ".mlp.c_proj.weight": torch.randn(d, 4 * d, generator=g) * 0.03, o + ".mlp.c_proj.bias": torch.zeros(d)})
+        path = str(tmp_path / "open_clip_b32.pt")
+        torch.save(sd, path)
+        model = load_hooked_model(name, device="cpu", local_path=path)
+        assert type(model).__name__ == "HookedViT" and model.cfg.n_layers == 12 and model.cfg.d_model == 768 and model.cfg.model_name == name
+        assert torch.equal(model.blocks[3].mlp.W_in, sd["visual.transformer.resblocks.3.mlp.c_fc.weight"].t())
+        x = torch.randn(2, 3, 224, 224, generator=g)
+        with torch.no_grad():
+            out, cache = model.run_with_cache(x)
+        assert out.shape == (2, 512) and len(cache) == 214
+        import pytest
+        with pytest.raises(FileNotFoundError):
+            load_hooked_model(name, device="cpu")                                   # pretrained weights cannot be downloaded here
+        rnd = load_hooked_model("openai/clip-vit-large-patch14-336", device="cpu", pretrained=False, dtype="bfloat16")
+        assert rnd.cfg.n_layers == 24 and rnd.cfg.dtype == torch.bfloat16 and next(rnd.parameters()).dtype == torch.bfloat16
+    finally:
+        from vit_prisma_amd.compat import uninstall
+        uninstall("vit_prisma")

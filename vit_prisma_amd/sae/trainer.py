@@ -226,6 +226,30 @@ class VisionSAETrainer:
     def _native_ok(self, sae, x: torch.Tensor) -> bool:
         return self._native_kind(sae, x) is not None
 
+    def _native_why_not(self, sae) -> str:
+        """Best-effort diagnosis for the one-time fallback warning (the limits of ``_native_kind``)."""
+        cfg = sae.cfg
+        why = []
+        if cfg.dtype != torch.float32:
+            why.append(f"dtype {cfg.dtype} (the fused steps keep fp32 master weights)")
+        if cfg.d_in > 1024 or cfg.d_in % 4:
+            why.append(f"d_in = {cfg.d_in} (supported: multiples of 4 up to 1024; ViT-H/14's 1280 is not)")
+        if cfg.d_sae > 65536 or cfg.d_sae % 4:
+            why.append(f"d_sae = {cfg.d_sae} (supported: multiples of 4 up to 65536)")
+        if cfg.activation_fn_str == "topk" and not 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64:
+            why.append(f"k = {cfg.activation_fn_kwargs.get('k')} (supported: 1..64)")
+        if cfg.activation_fn_str not in ("topk", "relu"):
+            why.append(f"activation {cfg.activation_fn_str!r}")
+        if getattr(cfg, "architecture", "standard") == "gated" and cfg.activation_fn_str != "relu":
+            why.append("the top-k form of the gated SAE")
+        if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
+            why.append("a transcoder with d_out != d_in")
+        if cfg.normalize_activations not in ("layer_norm", "none", None):
+            why.append(f"normalize_activations = {cfg.normalize_activations!r}")
+        if cfg.use_ghost_grads and self._mr:
+            why.append("ghost gradients with more than one rank")
+        return "; ".join(why) or "a parameter is not a contiguous fp32 CUDA tensor"
+
     def _get_engine(self, sae, n_tokens: int):
         from .native_sae import NativeSAE
         eng = self._engine
@@ -341,6 +365,12 @@ class VisionSAETrainer:
             raise NativeError("use_native(True): this SAE configuration / input is not served by the fused HIP step "
                               f"(activation {hp.activation_fn_str!r}, architecture {getattr(hp, 'architecture', 'standard')!r}, "
                               f"device {sae_in.device})")
+        if not native and sae_in.is_cuda and self._native_pref is None and not getattr(self, "_warned_torch_path", False):
+            # auto mode on a GPU: say ONCE why this run is not on the fused kernels (a silent PyTorch path is ~1000 x slower)
+            self._warned_torch_path = True
+            import warnings
+            warnings.warn("vit_prisma_amd: VisionSAETrainer trains this SAE on the PyTorch path, not on the MI355X kernels: "
+                          + self._native_why_not(sparse_autoencoder), stacklevel=2)
         if native:
             loss, mse_loss, l1_loss, l0 = self._native_step(sparse_autoencoder, optimizer, scheduler, sae_in,
                                                             act_freq_scores, n_forward_passes_since_fired)
