@@ -180,9 +180,10 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
     residual-stream points of a block -- hook_resid_pre (block >= 1), hook_attn_out, hook_resid_mid, hook_mlp_out,
     hook_resid_post -- and on every point inside it: ln1 / ln2 .hook_scale / .hook_normalized, attn.hook_q / hook_k / hook_v,
     attn.hook_attn_scores, attn.hook_pattern, attn.hook_z, mlp.hook_pre, mlp.hook_post, keyed by position (ten per block: entry |
-    ln1 | q, k, v | scores | pattern | z | after the attention half | ln2 | mlp pre | mlp post); anything else (the embedding and
-    final stages, the flag-gated points, backward hooks, block 0's resid_pre) keeps the PyTorch path.  On CPU the call itself
-    always runs in PyTorch."""
+    ln1 | q, k, v | scores | pattern | z | after the attention half | ln2 | mlp pre | mlp post); hooks on the embedding stage (incl.
+    block 0's resid_pre) and on the final stage are classified under two special keys -- those stages then run on the model's own
+    modules and the blocks stay on the plan; anything else (the flag-gated points, backward hooks) keeps the PyTorch path.  On CPU the
+    call itself always runs in PyTorch."""
     ident = lambda t, hook: t  # noqa: E731
     assert model._boundary_hooks() == {}
     with model.hooks(fwd_hooks=[("blocks.0.hook_resid_post", ident), ("blocks.1.hook_resid_pre", ident),
@@ -203,7 +204,11 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
         out = model(x)                                   # CPU input: PyTorch path, result defined by the hooks
         assert out.shape[0] == B and not model.last_run_native
     assert model._boundary_hooks() == {}
-    for bad in ("blocks.0.hook_resid_pre", "hook_embed", "ln_final.hook_normalized", "hook_ln_final"):
+    for name, key in (("blocks.0.hook_resid_pre", model._EMBED_POS), ("hook_embed", model._EMBED_POS), ("hook_pos_embed", model._EMBED_POS),
+                      ("ln_final.hook_normalized", model._FINAL_POS), ("hook_ln_final", model._FINAL_POS)):
+        with model.hooks(fwd_hooks=[(name, ident)]):
+            assert list(model._boundary_hooks()) == [key], name
+    for bad in ("blocks.0.hook_mlp_in", "blocks.1.attn.hook_result", "blocks.0.hook_q_input"):       # flag-gated: never fire by default
         with model.hooks(fwd_hooks=[(bad, ident)]):
             assert model._boundary_hooks() is None, bad
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):

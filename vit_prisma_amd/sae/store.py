@@ -128,9 +128,9 @@ class VisionActivationsStore:
     # images per ViT forward while a buffer is harvested: the reference runs one forward per store batch (32 images by default,
     # config.py:352) -- ~100 launch-bound kernels each on this hardware.  Consecutive store batches are independent images, and
     # the HIP forward's bits do not depend on the batch an image sits in (tests: digests at bs 1 / 3 / 77 / 300 / 512), so
-    # ceil(HARVEST_IMAGES / store_batch_size) DataLoader batches go through ONE run_with_cache: same images, same order, same
-    # buffer rows, same bits.
-    HARVEST_IMAGES = 256
+    # up to HARVEST_IMAGES / store_batch_size DataLoader batches go through ONE run_with_cache: same images, same order, same
+    # buffer rows, same bits.  (512: a half-buffer refill of the reference's default store shape -- 10 batches of 32 -- is one forward.)
+    HARVEST_IMAGES = 512
 
     def _direct_tap_name(self) -> Optional[str]:
         """The single hook point whose [images, ctx, d_in] activation IS a buffer slice, or None (several layers, a head index,
