@@ -128,7 +128,21 @@ def cpu_baseline_torch(seconds: float, bs: int = 32) -> dict:
     return {"value": round(bs / med, 1), "unit": "images/s", "cores": nt, "kind": "port",
             "sample": f"median of {len(times)} x run_with_cache(all 214 hooks) of CLIP ViT-B/32 at bs={bs}, fp32, PyTorch CPU hook path "
                       f"(the reference's algorithm op for op) at the best thread count of a sweep {sweep} (s per forward) on a "
-                      f"{ncpu}-thread host ({_usable_cpus()} usable), {med * 1e3:.0f} ms per forward"}
+                      f"{ncpu}-thread host ({_usable_cpus()} usable), {med * 1e3:.0f} ms per forward" + _port_vs_reference("vit")}
+
+
+def _port_vs_reference(which: str) -> str:
+    """What the build-container measurement of the REFERENCE'S OWN classes beside this port says (tools/cpu_reference_vs_port.py ->
+    profiles/r04_cpu_reference_vs_port.json; /root/reference does not exist on the GPU box, so 'kind' stays 'port')."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_vs_port.json")) as f:
+            d = json.load(f)[which]
+        ref = d.get("reference_images_per_s", d.get("reference_tokens_per_s"))
+        port = d.get("port_images_per_s", d.get("port_tokens_per_s"))
+        return (f"; the reference's own classes timed beside this port on the {json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_reference_vs_port.json')))['host']['cores']} "
+                f"cores of the build container: reference {ref}, port {port} (profiles/r04_cpu_reference_vs_port.json)")
+    except Exception:
+        return ""
 
 
 def sae_cpu_baseline_torch(seconds: float) -> dict:
@@ -171,7 +185,8 @@ def sae_cpu_baseline_torch(seconds: float) -> dict:
     med = _median(times)
     return {"value": round(n_tok / med, 1), "unit": "tokens/s", "cores": nt, "kind": "port",
             "sample": f"median of {len(times)} full train steps of {n_tok} tokens (768 -> 24576, k=32), fp32, PyTorch CPU autograd path "
-                      f"(the reference trainer's algorithm) at the best thread count of a sweep {sweep} (s per step), {med * 1e3:.0f} ms per step"}
+                      f"(the reference trainer's algorithm) at the best thread count of a sweep {sweep} (s per step), {med * 1e3:.0f} ms per step"
+                      + _port_vs_reference("sae")}
 
 
 def cpu_baseline(seconds: float) -> dict:

@@ -1,5 +1,7 @@
-"""A few ReLU + L1 dense train steps (768 -> 24576, N = 4096) for rocprofv3 --kernel-trace --stats."""
+"""A few ReLU + L1 train steps (768 -> 24576, N = 4096) for rocprofv3 --kernel-trace --stats: pv_sae_relu_step in its sparse form (b_enc
+shifted so that a token keeps ~16 features from the first step on: the regime the run from the synthetic init settles into), or
+PV_RELU_L0=860 for the dense form at the published L0."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vit_prisma_amd.sae.bench_leg import sae_bench_leg
-print(sae_bench_leg(torch.device("cuda", 0), steps=4, warmup=2, activation="relu"))
+print(sae_bench_leg(torch.device("cuda", 0), steps=5, warmup=2, activation="relu", relu_target_l0=float(os.environ.get("PV_RELU_L0", "16"))))
