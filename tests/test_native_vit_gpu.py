@@ -219,11 +219,17 @@ def test_native_equals_pytorch_hook_path_and_fallback_dispatch():
         assert float(c_h["blocks.0.attn.hook_z"].abs().max()) == 0.0
         _, c_h = model.run_with_cache(x, fwd_hooks=[("blocks.0.mlp.hook_pre", zero)])                # ... at the MLP pre-activation
         assert model.last_run_native and float(c_h["blocks.0.mlp.hook_pre"].abs().max()) == 0.0
-        _, c_h = model.run_with_cache(x, fwd_hooks=[("hook_embed", zero)])                            # not splittable: PyTorch path
-        assert not model.last_run_native and float(c_h["hook_embed"].abs().max()) == 0.0
+        _, c_h = model.run_with_cache(x, fwd_hooks=[("hook_embed", zero)])     # embedding stage on the modules, blocks on the plan
+        assert model.last_run_native and float(c_h["hook_embed"].abs().max()) == 0.0
+        # a plain nn.Module hook is invisible to the plan: auto mode takes the PyTorch path, force mode raises
+        seen = []
+        handle = model.blocks[0].register_forward_hook(lambda m, i, o: seen.append(1))
+        _, c_h = model.run_with_cache(x)
+        assert not model.last_run_native and seen and "nn.Module hooks" in model.native_fallback_reason
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("hook_embed", zero)])
+            model.run_with_cache(x)
+        handle.remove()
     # weight edits are picked up (version counter) -> output changes
     model.use_native(True)
     with torch.no_grad():
