@@ -477,6 +477,13 @@ int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32
  *   sp->workspace    caller-owned, pv_sae_relu_workspace_bytes(plan, n_tokens, cap) bytes, 256-byte aligned.  Its first word is the
  *                    mode of the last step (0 = ran sparse, 1 = ran dense); the kept pairs follow (tests: pv_debug_sae_relu_offset)
  * sp == NULL, or a plan the filter does not cover (d_sae % 256, d_sae < 2048, d_in % 8): the dense step.
+ * Two more flags than pv_sae_dense_step takes:
+ *   PV_SAE_RENORM_DECODER (+ PV_SAE_INV_NORM_VALID) is DEFERRED as in pv_sae_step where the sparse form applies and
+ *       st->dec_inv_norm is given (inverse row norms now, the rows rewritten by pv_sae_apply; a step that turns out dense rewrites
+ *       them itself, in place, before its GEMMs and leaves dec_inv_norm = 1); in place, first, otherwise.
+ *   PV_SAE_SPARSE_GRADS (single-process training): a step that ran sparse leaves the gradient rows of features no token kept
+ *       unwritten, as pv_sae_step does; a step that ran dense marks every feature live and derives the per-feature clip-norm terms
+ *       from its complete rows.  Only pv_sae_grad_sqnorm_step and pv_sae_apply may follow.
  * Requires the encoder shadows of pv_sae_state (W_encT, W_enc16T, enc_colsq) to be current.
  * Replaces sae/sae.py:557-645 (L1 :617-626) + sae/train_sae.py:328-392, like pv_sae_dense_step. */
 typedef struct pv_sae_relu_sparse {

@@ -90,6 +90,7 @@ class OracleEngine:
 
     def relu_step(self, x, l1_coefficient, cap=None, **kw):
         """The twin of NativeSAE.relu_step (pv_sae_relu_step): sparse or dense is the kernels' business -- the same step either way."""
+        kw.pop("sparse_grads", None)
         return self.dense_step(x, l1_coefficient, **kw)
 
     def grad_sqnorm(self, from_step=False):

@@ -1499,9 +1499,12 @@ def test_relu_step_goes_dense_exactly_when_a_token_cannot_be_held(d_in, d_sae, n
     xg = torch.from_numpy(x).cuda()
 
     def run(step, **kw):
+        # (the decoder renormalised by the one in-place kernel beforehand: relu_step defers its renorm -- 1 / |row| now, the rows
+        # rewritten later -- which rounds differently from dense_step's in-place division; the bit-for-bit claim is about the step)
         Tl = {m: torch.from_numpy(v.copy()).cuda() for m, v in P.items()}
         eng = NativeSAE(Tl["W_enc"], Tl["W_dec"], Tl["b_enc"], Tl["b_dec"], 1, True, n)
-        getattr(eng, step)(xg, l1c, want_out=True, **kw)
+        eng.renorm_decoder()
+        getattr(eng, step)(xg, l1c, want_out=True, renorm_decoder=False, **kw)
         eng.grad_sqnorm()
         torch.cuda.synchronize()
         return eng
@@ -1520,18 +1523,36 @@ def test_relu_step_goes_dense_exactly_when_a_token_cannot_be_held(d_in, d_sae, n
     P0, _, _, T0 = fresh(d_in, d_sae)
     T1 = {m: v.clone() for m, v in T0.items()}                  # (before any step: a step renormalises W_dec in place)
     eng = NativeSAE(T0["W_enc"], T0["W_dec"], T0["b_enc"], T0["b_dec"], 1, True, n)
-    eng.relu_step(xg, l1c)
+    eng.renorm_decoder()
+    eng.relu_step(xg, l1c, renorm_decoder=False)
     ref = NativeSAE(T1["W_enc"], T1["W_dec"], T1["b_enc"], T1["b_dec"], 1, True, n)
-    ref.dense_step(xg, l1c)
+    ref.renorm_decoder()
+    ref.dense_step(xg, l1c, renorm_decoder=False)
     torch.cuda.synchronize()
     assert int(eng.relu_mode.item()) == 1 and torch.equal(eng.flat_g, ref.flat_g) and torch.equal(eng.scalars, ref.scalars)
     assert torch.equal(eng.act_freq_scores, ref.act_freq_scores) and torch.equal(eng.n_fwd_since_fired, ref.n_fwd_since_fired)
+    # ... and with the renorm left to the steps (deferred in relu_step: a dense step rewrites the rows itself before its GEMMs;
+    # in place, first, in dense_step): the same step to rounding
+    _, _, _, T2 = fresh(d_in, d_sae)
+    T3 = {m: v.clone() for m, v in T2.items()}
+    a = NativeSAE(T2["W_enc"], T2["W_dec"], T2["b_enc"], T2["b_dec"], 1, True, n)
+    b = NativeSAE(T3["W_enc"], T3["W_dec"], T3["b_enc"], T3["b_dec"], 1, True, n)
+    for t in range(2):
+        a.relu_step(xg, l1c); a.grad_sqnorm(); a.apply(1e-3, 1.0)
+        b.dense_step(xg, l1c); b.grad_sqnorm(); b.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        assert int(a.relu_mode.item()) == 1
+        assert torch.allclose(a.scalars[:5], b.scalars[:5], rtol=1e-5, atol=0), t
+        for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            assert rel_fro(a.params[name].cpu().numpy(), b.params[name].cpu().numpy()) < 1e-6, (t, name)
 
 
-def test_relu_step_is_bit_reproducible_and_follows_a_collapsing_run():
+@pytest.mark.parametrize("sg", [False, True])
+def test_relu_step_is_bit_reproducible_and_follows_a_collapsing_run(sg):
     """(a) two engines from the same state agree bit for bit over steps that run dense, then sparse; (b) bench.py's ReLU leg from
     the synthetic init (768 -> 8192 here): L0 falls from half of the features to a few within ~8 steps -- the step must change
-    form on its own (mode 1, later 0) and track the oracle through the transition."""
+    form on its own (mode 1, later 0) and track the oracle through the transition.  sg: as the single-process trainer runs it
+    (PV_SAE_SPARSE_GRADS, the clip norm from the step's per-feature terms, the decoder renorm deferred across both forms)."""
     d_in, d_sae, n, l1c = 768, 8192, 1024, 8e-5
     P, opt, stats, _ = fresh(d_in, d_sae)
     engines = []
@@ -1544,8 +1565,8 @@ def test_relu_step_is_bit_reproducible_and_follows_a_collapsing_run():
         ref = O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, l1_coefficient=l1c)
         xg = torch.from_numpy(x).cuda()
         for e in engines:
-            e.relu_step(xg, l1c, want_out=True)
-            e.grad_sqnorm()
+            e.relu_step(xg, l1c, want_out=True, sparse_grads=sg)
+            e.grad_sqnorm(from_step=sg)
         torch.cuda.synchronize()
         a, b = engines
         assert torch.equal(a.flat_g, b.flat_g) and torch.equal(a.scalars, b.scalars) and torch.equal(a.sae_out, b.sae_out), t
@@ -1558,3 +1579,47 @@ def test_relu_step_is_bit_reproducible_and_follows_a_collapsing_run():
     torch.cuda.synchronize()
     assert modes[0] == 1 and modes[-1] == 0 and modes == sorted(modes, reverse=True), modes
     assert torch.equal(engines[0].W_encT, engines[1].W_encT) and torch.equal(engines[0].params["W_dec"], engines[1].params["W_dec"])
+
+
+@pytest.mark.parametrize("d_in,d_sae,n,l0", [(768, 8192, 1024, 24), (64, 2048, 256, 0)])
+def test_relu_sparse_gradient_step_lands_on_the_same_parameters_as_the_complete_one(d_in, d_sae, n, l0):
+    """PV_SAE_SPARSE_GRADS on relu_step (what the single-process trainer passes).  A step that ran SPARSE leaves the gradient rows of
+    features no token kept untouched (poison stays exactly there) and apply takes them as zero; a step that ran DENSE (l0 = 0: the
+    synthetic init, half of all features positive) writes complete buffers and marks every feature live.  Either way the clip norm
+    from the step's per-feature terms equals the full pass's and parameters + Adam moments land where the complete-gradient run's do."""
+    l1c = 3e-3
+    P, _, _, _ = fresh(d_in, d_sae)
+    if l0:
+        _shift_b_enc_for_l0(P, synth_sae_batch(n, d_in, seed=0), True, l0)
+    engs = []
+    for _ in range(2):
+        T = {m: torch.from_numpy(v.copy()).cuda() for m, v in P.items()}
+        engs.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, True, n))
+    full, sparse = engs
+    for t in range(3):
+        x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+        full.relu_step(x, l1c); full.grad_sqnorm(); full.apply(1e-3, 1.0)
+        sparse.flat_g.fill_(float("nan"))
+        sparse.relu_step(x, l1c, sparse_grads=True)
+        torch.cuda.synchronize()
+        mode = int(sparse.relu_mode.item())
+        assert mode == int(full.relu_mode.item()) == (0 if l0 else 1)
+        empty = sparse.fire_count == 0
+        if mode == 0:
+            assert int(empty.sum()) > 0
+            assert bool(torch.isnan(sparse.g["W_dec"][empty]).all()) and bool(torch.isnan(sparse.g["W_enc"][empty]).all())
+            assert bool(torch.isfinite(sparse.g["W_dec"][~empty]).all()) and bool(torch.isfinite(sparse.g["b_enc"]).all())
+        else:
+            assert bool(torch.isfinite(sparse.flat_g[:sparse.n_flat]).all())
+        with pytest.raises(RuntimeError):
+            sparse.grad_sqnorm()
+        sparse.grad_sqnorm(from_step=True)
+        sparse.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for i in (0, 1, 2, 3, 4):                            # loss, mse, l0, clip norm, l1
+            assert abs(float(sparse.scalars[i]) - float(full.scalars[i])) <= 2e-6 * abs(float(full.scalars[i])), (t, i)
+        for name in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            assert rel_fro(sparse.params[name].cpu().numpy(), full.params[name].cpu().numpy()) < 1e-6, (t, name)
+        assert rel_fro(sparse.flat_m.cpu().numpy(), full.flat_m.cpu().numpy()) < 1e-5, t
+        assert rel_fro(sparse.flat_v.cpu().numpy(), full.flat_v.cpu().numpy()) < 1e-5, t
+        assert bool(torch.isfinite(sparse.flat_m).all()) and bool(torch.isfinite(sparse.flat_v).all())

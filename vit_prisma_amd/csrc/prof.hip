@@ -136,6 +136,7 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "attn_direct")) return &g_pv_tuning.attn_direct;
     if (!strcmp(key, "prof_markers")) return &g_pv_tuning.prof_markers;
     if (!strcmp(key, "sae_exact")) return &g_pv_tuning.sae_exact;
+    if (!strcmp(key, "enc_rounds")) return &g_pv_tuning.enc_rounds;
     if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
     if (!strcmp(key, "gemm_loop")) return &g_pv_tuning.gemm_loop;
     return nullptr;

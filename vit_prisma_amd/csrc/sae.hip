@@ -1717,7 +1717,8 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
                     const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
                     const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
-                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream) {
+                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
+                    bool bias_grads) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
@@ -1791,13 +1792,23 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
-        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
-        if (rc) return rc;
-        if (tc) {
-            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+        // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)
+        if (bias_grads) {
+            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
             if (rc) return rc;
+            if (tc) {
+                rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+                if (rc) return rc;
+            }
         }
     }
+    return PV_OK;
+}
+
+int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t stream) {
+    hipLaunchKernelGGL(dec_inv_norm_kernel, dim3((d.d_sae + 15) / 16), dim3(256), 0, stream, (const float*)st->W_dec, st->dec_inv_norm,
+                       d.d_sae, d.d_in);
+    PV_LAUNCH_CHECK("dec_inv_norm_kernel");
     return PV_OK;
 }
 

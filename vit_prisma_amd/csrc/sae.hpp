@@ -82,7 +82,10 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
 int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
                     const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
                     const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
-                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream);
+                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
+                    bool bias_grads = true);
+// sae.hip: dec_inv_norm[j] = 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm)
+int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t stream);
 
 // sae.hip, shared with sae_dense.hip: see the definitions
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,

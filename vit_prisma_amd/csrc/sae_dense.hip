@@ -614,7 +614,7 @@ int dense_prepare(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, co
 // The five GEMMs + their small kernels (see the file header); `gate` as in DenseGemm.
 int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t n_global, int update_stats,
                     float l1_coefficient, const pv_sae_ghost* ghost, const GhostWs& gw, pv_sae_out* out, unsigned char* wsb,
-                    const SaeWs& ws, const float* skip, const uint32_t* gate, hipStream_t stream) {
+                    const SaeWs& ws, const float* skip, const uint32_t* gate, hipStream_t stream, bool bias_grads = true) {
     const pv_sae_desc& d = plan->d;
     const int F = d.d_sae, D = d.d_in;
     const bool tc = sae_is_tc(st);
@@ -736,11 +736,13 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g5.out = st->gW_enc; g5.ldo = D; g5.gate = gate;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
-        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
-        if (rc) return rc;
-        if (tc) {
-            rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+        if (bias_grads) {                                     // (false: pv_sae_relu_step runs them once behind both of its forms)
+            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
             if (rc) return rc;
+            if (tc) {
+                rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+                if (rc) return rc;
+            }
         }
     }
     return PV_OK;
@@ -764,6 +766,50 @@ __global__ __launch_bounds__(256) void relu_sparse_scalars_kernel(const float* _
     }
 }
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+
+// pv_sae_relu_step with the decoder renorm deferred (PV_SAE_RENORM_DECODER on a plan the sparse form covers): the sparse kernels use
+// W_dec[j] * inv[j] on the fly; when the step turns out dense (*gate == 1) the five GEMMs read W_dec as it lies, so the rows are
+// rewritten here -- the same products, stored -- and inv[j] = 1 tells pv_sae_apply that nothing is left to scale.  A wave per row.
+__global__ __launch_bounds__(256) void relu_dense_renorm_kernel(float* __restrict__ W, float* __restrict__ inv, int rows, int d,
+                                                                const uint32_t* __restrict__ gate) {
+    if (*gate != 1u) return;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    const float s = inv[j];
+    for (int c = 4 * lane; c < d; c += 256) {
+        float4 w = *reinterpret_cast<const float4*>(W + (int64_t)j * d + c);
+        w.x *= s; w.y *= s; w.z *= s; w.w *= s;
+        *reinterpret_cast<float4*>(W + (int64_t)j * d + c) = w;
+    }
+    if (lane == 0) inv[j] = 1.0f;
+}
+
+// PV_SAE_SPARSE_GRADS on pv_sae_relu_step, behind a step that ran DENSE (gate == NULL: always; else *gate == 1): the gradient buffers
+// are complete, so every feature is marked live for pv_sae_apply (offs[j] = j) and the per-feature terms of the clip norm, which the
+// sparse backward leaves as a by-product, are taken from the rows here (rowsq[j] = |gW_dec[j]|^2 + |gW_enc^T[j]|^2 + gb_enc[j]^2).
+__global__ __launch_bounds__(256) void relu_dense_live_kernel(const float* __restrict__ gW_dec, const float* __restrict__ gW_encT,
+                                                              const float* __restrict__ gb_enc, uint32_t* __restrict__ offs,
+                                                              float* __restrict__ rowsq, int rows, int d,
+                                                              const uint32_t* __restrict__ gate) {
+    if (gate && *gate != 1u) return;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    float sq = 0.f;
+    for (int c = 4 * lane; c < d; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(gW_dec + (int64_t)j * d + c);
+        const float4 b = *reinterpret_cast<const float4*>(gW_encT + (int64_t)j * d + c);
+        sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w);
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+        const float gb = gb_enc[j];
+        rowsq[j] = sq + gb * gb;
+        offs[j] = (uint32_t)j;
+        if (j == rows - 1) offs[rows] = (uint32_t)rows;
+    }
+}
 }  // namespace
 
 // One train step of the ReLU + L1 SAE on N tokens: forward + backward + statistics; gradients are WRITTEN into st->g*
@@ -841,6 +887,12 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
         if (rq) return rq;
     }
     const bool sparse = sp && pv_sae_relu_sparse_ok(d) && st->W_enc16T && st->enc_colsq;
+    // PV_SAE_SPARSE_GRADS (single-process training): a step that ran sparse leaves the rows of features no token kept unwritten, as
+    // pv_sae_step does; a step that ran dense marks every feature live.  Either way pv_sae_grad_sqnorm_step / pv_sae_apply follow.
+    const bool sparse_grads = (flags & PV_SAE_SPARSE_GRADS) != 0;
+    // PV_SAE_RENORM_DECODER: deferred as in pv_sae_step where the sparse form applies (inverse norms now, the rows rewritten by
+    // pv_sae_apply -- or here, in place, when the step turns out dense); otherwise W_dec is renormalised in place first
+    const bool defer = sparse && (flags & PV_SAE_RENORM_DECODER) && st->dec_inv_norm;
     ReluWs rw = {};
     unsigned char* rwb = nullptr;
     if (sp) {
@@ -851,9 +903,16 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
         rwb = (unsigned char*)sp->workspace;
     }
     const float* skip = nullptr;
-    rc = dense_prepare(plan, st, x, N, batch_mean, flags, sparse, wsb, ws, &skip, stream_);
+    rc = dense_prepare(plan, st, x, N, batch_mean, defer ? (flags & ~PV_SAE_RENORM_DECODER) : flags, sparse, wsb, ws, &skip, stream_);
     if (rc) return rc;
     uint32_t* mode = sp ? (uint32_t*)(rwb + rw.mode) : nullptr;
+    if (defer) {
+        if (!(flags & PV_SAE_INV_NORM_VALID)) {
+            rc = sae_dec_inv_norm(d, st, stream);
+            if (rc) return rc;
+        }
+        plan->renorm_pending = true;
+    }
     if (sparse) {
         const int cap = sp->cap;
         int32_t* idx = (int32_t*)(rwb + rw.idx);
@@ -871,9 +930,9 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
         tb.seg_range = (uint32_t*)(rwb + rw.seg_range); tb.seg_rows = (float*)(rwb + rw.seg_rows); tb.seg_b = (float*)(rwb + rw.seg_b);
         tb.pairs = (int32_t*)(rwb + rw.pairs); tb.max_segs = rw.max_segs;
         rc = sae_sparse_tail(plan, st, x, N, n_global, cap, idx, val, out->sae_out, out->scalars, out->fire_count, update_stats,
-                             /*sparse grads*/ false, /*inv_norm*/ nullptr, tb, wsb, ws, tc ? (const float*)st->tc.target : x,
-                             tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, skip, tc, l1_coefficient / (float)n_global,
-                             tok_cnt, mode, stream);
+                             sparse_grads, defer ? (const float*)st->dec_inv_norm : (const float*)nullptr, tb, wsb, ws,
+                             tc ? (const float*)st->tc.target : x, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, skip, tc,
+                             l1_coefficient / (float)n_global, tok_cnt, mode, stream, /*bias_grads*/ false);
         if (rc) return rc;
         hipLaunchKernelGGL(relu_sparse_scalars_kernel, dim3(1), dim3(256), 0, stream, (const float*)l1part, N,
                            l1_coefficient / (float)n_global, out->scalars, (const uint32_t*)mode);
@@ -881,8 +940,32 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
     } else if (mode) {
         hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, mode, 1u);
     }
+    if (defer) {
+        hipLaunchKernelGGL(relu_dense_renorm_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, st->W_dec, st->dec_inv_norm, d.d_sae,
+                           d.d_in, (const uint32_t*)mode);
+        PV_LAUNCH_CHECK("relu_dense_renorm_kernel");
+    }
     GhostWs gw = {};
-    return dense_step_body(plan, st, x, N, n_global, update_stats, l1_coefficient, nullptr, gw, out, wsb, ws, skip, mode, stream);
+    rc = dense_step_body(plan, st, x, N, n_global, update_stats, l1_coefficient, nullptr, gw, out, wsb, ws, skip, mode, stream,
+                         /*bias_grads*/ false);
+    if (rc) return rc;
+    // gb_dec = colsum(dY) - W_enc gb_enc (transcoder: its two bias gradients, gW_skip): from the dY and gb_enc of whichever form ran
+    const float* dY = (const float*)(wsb + ws.dY);
+    rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
+    if (rc) return rc;
+    if (tc) {
+        rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
+        if (rc) return rc;
+    }
+    if (sparse_grads) {
+        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
+        hipLaunchKernelGGL(relu_dense_live_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const float*)st->gW_dec,
+                           (const float*)st->gW_enc, (const float*)st->gb_enc, offs, (float*)(wsb + ws.rowsq), d.d_sae, d.d_in,
+                           sparse ? (const uint32_t*)mode : (const uint32_t*)nullptr);
+        PV_LAUNCH_CHECK("relu_dense_live_kernel");
+        plan->live_offs = offs;
+    }
+    return PV_OK;
 }
 
 // Ghost gradients on a TOP-K SAE (use_ghost_grads with activation_fn_str = "topk": SparseAutoencoder._compute_ghost_residual_loss,

@@ -64,7 +64,7 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 // 4-slot LDS ring three slabs ahead, counted vmcnt across a raw s_barrier) on fp16 operands, with an epilogue that
 // stores nothing but the hits.  MODE 0: plain fp32 store of acc + bias (the sample of pass 0).
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, int LP = 0>
+template <int MODE, int LP = 0, bool ONE = false>
 __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p) {
     constexpr int MB = 4, TM = 64 * MB, TN = 256;
     constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
@@ -375,11 +375,11 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         // Hits are ~0.8 % of the tile (~2 per token row).  Nothing global is contended for them: every (token, N-tile) pair
         // owns pv_sae_tile_slots() candidate slots and a count word that only this workgroup writes (a device-scope atomic
         // per hit on per-token counters cost more than the whole K loop: ~0.8 M atomics per step queue up behind a few dozen
-        // memory channels).  The hits are compacted into LDS with no round trip -- per 32-row block a lane builds the
-        // bitmap of its 32 accumulators, a wave scan + ONE LDS atomic per wave hands out list positions -- then every
+        // memory channels).  The hits are compacted into LDS with no round trip -- a lane builds the bitmaps of its
+        // accumulators, a wave scan + ONE LDS atomic per wave hands out list positions -- then every
         // list entry draws its slot from an LDS per-row counter and is stored.  Rows with more hits than slots (or a tile
         // with more than HCAP hits: massive ties) are marked overflowed: those tokens take the exact path.
-        constexpr int HCAP = SLOT / 8;
+        constexpr int HCAP = (LP == 2 ? 2 * SLOT : SLOT) / 8;     // (ring0: SLOT bytes, 2 SLOT in the full-line form)
         uint2* hlist = reinterpret_cast<uint2*>(ring0);
         if (tid == 0) hit_n = p.mode ? __hip_atomic_load(p.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         __syncthreads();                                           // (ONE read of the word per workgroup)
@@ -395,10 +395,9 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         if (tid < 256) rowcnt[tid] = 0u;
         __syncthreads();
         const float* trw = trow + wm * 32 * MB;
-        uint32_t flushed = 0;                                      // list positions below this were flushed by earlier blocks
-#pragma unroll
-        for (int mi = 0; mi < MB; ++mi) {                          // one 32-row block (64 rows of the tile) per round
-            uint32_t m = 0;                                        // bit (g * 8 + s * 2 + ni)
+        // bitmap of the hits among this lane's 32 accumulators of block mi: bit (g * 8 + s * 2 + ni)
+        auto block_mask = [&](int mi) {
+            uint32_t m = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r0 = mi * 32 + 8 * g + 4 * half;
@@ -412,8 +411,56 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                         m |= (hit ? 1u : 0u) << (g * 8 + s * 2 + ni);
                     }
             }
-            if (__ballot(m != 0u) != 0ull) {                       // (wave-uniform)
-                const int nh = __popc(m);
+            return m;
+        };
+        // the hits of block mi into the list from position pos on (returns the next position)
+        // (eb: the bias values again, behind an asm barrier in the one-round form -- otherwise hipcc keeps all 128 sums acc + bias
+        // of the bitmap pass alive for this one and spills)
+        float eb[2] = {bias[0], bias[1]};
+        auto block_emit = [&](int mi, uint32_t m, uint32_t pos) {
+            if (m != 0u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            if (m & (1u << (g * 8 + s * 2 + ni))) {
+                                const int lrow = wm * 32 * MB + mi * 32 + 8 * g + 4 * half + s;
+                                if (pos < (uint32_t)HCAP)
+                                    hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
+                                                            __float_as_uint(acc[mi][ni][4 * g + s] + eb[ni]));
+                                else
+                                    atomicOr(&rowcnt[lrow], 0x80000000u);
+                                ++pos;
+                            }
+                        }
+            }
+            return pos;
+        };
+        // list entries [0, nhit) -> each draws its slot from the LDS per-row counter and is stored
+        auto flush = [&](uint32_t nhit) {
+            for (uint32_t e = tid; e < nhit; e += 512) {
+                const uint2 h = hlist[e];
+                const int lrow = (int)(h.x >> 8);
+                const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
+                if (li < (uint32_t)p.slots)
+                    p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * p.slots + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
+            }
+        };
+        // ONE (the launcher: expected hits per tile = 256 rows x slots / 4 -- the slot count is 4 x the mean + 6 -- fit the list
+        // twice over: the bench shape, the ReLU filter): one compaction round for the whole tile -- all bitmaps, one wave scan, one
+        // LDS atomic per wave, one flush.  Otherwise (small d_sae, large k) a round per 32-row block, each with its own flush.
+        if constexpr (ONE) {
+            uint32_t mk[MB];
+            int nh = 0;
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+                mk[mi] = block_mask(mi);
+                nh += __popc(mk[mi]);
+            }
+            asm volatile("" : "+v"(eb[0]), "+v"(eb[1]));
+            if (__ballot(nh != 0) != 0ull) {                       // (wave-uniform)
                 int incl = nh;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -423,40 +470,39 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                 uint32_t base = 0;
                 if (lane == 63) base = atomicAdd(&hit_n, (uint32_t)incl);
                 base = __shfl(base, 63, 64);
-                uint32_t pos = base + (uint32_t)(incl - nh) - flushed;
-                if (m != 0u) {
+                uint32_t pos = base + (uint32_t)(incl - nh);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                for (int mi = 0; mi < MB; ++mi) pos = block_emit(mi, mk[mi], pos);
+            }
+            __syncthreads();
+            flush(min(hit_n, (uint32_t)HCAP));
+            __syncthreads();
+        } else {
+            uint32_t flushed = 0;                                  // list positions below this were flushed by earlier blocks
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+            for (int mi = 0; mi < MB; ++mi) {                      // one 32-row block (64 rows of the tile) per round
+                const uint32_t m = block_mask(mi);
+                if (__ballot(m != 0u) != 0ull) {                   // (wave-uniform)
+                    const int nh = __popc(m);
+                    int incl = nh;
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) {
-                                if (m & (1u << (g * 8 + s * 2 + ni))) {
-                                    const int lrow = wm * 32 * MB + mi * 32 + 8 * g + 4 * half + s;
-                                    if (pos < (uint32_t)HCAP)
-                                        hlist[pos] = make_uint2((uint32_t)(lrow << 8 | (wn * 64 + ni * 32 + l31)),
-                                                                __float_as_uint(acc[mi][ni][4 * g + s] + bias[ni]));
-                                    else
-                                        atomicOr(&rowcnt[lrow], 0x80000000u);
-                                    ++pos;
-                                }
-                            }
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int up = __shfl_up(incl, o, 64);
+                        if (lane >= o) incl += up;
+                    }
+                    uint32_t base = 0;
+                    if (lane == 63) base = atomicAdd(&hit_n, (uint32_t)incl);
+                    base = __shfl(base, 63, 64);
+                    block_emit(mi, m, base + (uint32_t)(incl - nh) - flushed);
                 }
+                // flush this block's hits (beyond HCAP of the block's 64 x 256 elements the rows are marked overflowed above).
+                // hit_n keeps counting; `flushed` rebases the positions of the next block.
+                __syncthreads();
+                const uint32_t total = hit_n;
+                flush(min(total - flushed, (uint32_t)HCAP));
+                flushed = total;
+                __syncthreads();
             }
-            // flush this block's hits (the list holds HCAP = 4096 of the block's 64 x 256 elements: beyond that the rows
-            // are marked overflowed above).  hit_n keeps counting; `flushed` rebases the positions of the next block.
-            __syncthreads();
-            const uint32_t total = hit_n;
-            const uint32_t nhit = min(total - flushed, (uint32_t)HCAP);
-            for (uint32_t e = tid; e < nhit; e += 512) {
-                const uint2 h = hlist[e];
-                const int lrow = (int)(h.x >> 8);
-                const uint32_t li = atomicAdd(&rowcnt[lrow], 1u) & 0x7fffffffu;
-                if (li < (uint32_t)p.slots)
-                    p.cand[((int64_t)(m0 + lrow) * ntn + tile_n) * p.slots + li] = make_int2(n0 + (int)(h.x & 255u), (int)h.y);
-            }
-            flushed = total;
-            __syncthreads();
         }
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
@@ -901,7 +947,9 @@ int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
     if (g_pv_tuning.gemm_loop != 0 && p.K % 32 == 0) lp = (p.K % 64 == 0 && g_pv_tuning.gemm_loop != 1) ? 2 : 1;
 #define PV_ENC_LAUNCH(MODE)                                                                              \
     do {                                                                                                 \
-        if (lp == 2) hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 2>), grid, block, 0, stream, p);      \
+        if (lp == 2 && MODE == 1 && p.slots * 128 <= 2 * 256 * 128 / 8 && !g_pv_tuning.enc_rounds)       \
+            hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 2, MODE == 1>), grid, block, 0, stream, p);    \
+        else if (lp == 2) hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 2>), grid, block, 0, stream, p); \
         else if (lp == 1) hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 1>), grid, block, 0, stream, p); \
         else hipLaunchKernelGGL((sae_enc_gemm_kernel<MODE, 0>), grid, block, 0, stream, p);              \
     } while (0)

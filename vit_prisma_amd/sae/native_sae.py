@@ -318,12 +318,15 @@ class NativeSAE:
 
     def relu_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                   n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
-                  renorm_decoder: bool = True, target: Optional[torch.Tensor] = None, cap: Optional[int] = None) -> None:
+                  renorm_decoder: bool = True, target: Optional[torch.Tensor] = None, cap: Optional[int] = None,
+                  sparse_grads: bool = False) -> None:
         """The ReLU + L1 step, sparse where the batch allows it (pv_sae_relu_step): ONE fp16-filtered product over all features +
         exact fp32 re-scoring gives every token's positive activations as a list of at most ``cap`` pairs and the k-sparse kernels do
         the rest; a batch some token of which holds more than that runs on the dense GEMMs of ``dense_step`` instead -- decided on the
         GPU (``relu_mode``: 0 sparse, 1 dense; a device word), same results either way.  Contract, scalars and follow-up calls as
-        ``dense_step`` (no ghost gradients: those stay with ``dense_step``)."""
+        ``dense_step`` (no ghost gradients: those stay with ``dense_step``).  renorm_decoder is deferred as in ``step`` (inverse norms
+        now, rows rewritten by ``apply``; a step that goes dense rewrites them itself).  sparse_grads (single process): as in ``step``
+        -- only ``grad_sqnorm(from_step=True)`` and ``apply`` may follow (a step that ran dense marks every feature live)."""
         x = self._check_x(x)
         self._set_target(x, target)
         self._ensure_shadows()
@@ -342,14 +345,16 @@ class NativeSAE:
         bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
         sp = N.SaeReluSparse(cap=cap, reserved=0, workspace=self._relu_ws.data_ptr(), workspace_bytes=self._relu_ws.numel())
         self._relu_last = (n, cap)
+        inv_valid = renorm_decoder and self._inv_norm_key is not None and self._inv_norm_key == self._w_dec_key()
         N.check(self.lib.pv_sae_relu_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                           int(n_global if n_global is not None else n),
-                                          int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient), C.byref(sp),
+                                          int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0) |
+                                          (8 if sparse_grads else 0), float(l1_coefficient), C.byref(sp),
                                           C.byref(out), self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
                 "pv_sae_relu_step")
         self._inv_norm_key = None
-        self._grad_fresh = False
-        self._grad_sparse = False
+        self._grad_fresh = bool(sparse_grads)                     # (the per-feature clip-norm terms exist in that form only)
+        self._grad_sparse = bool(sparse_grads)
 
     def _relu_region(self, name: bytes, dtype: torch.dtype, shape) -> torch.Tensor:
         n, cap = self._relu_last

@@ -437,7 +437,7 @@ class VisionSAETrainer:
             else:
                 # sparse where the batch allows it, the dense GEMMs otherwise: the GPU decides (NativeSAE.relu_step)
                 kw.pop("dead_mask", None)
-                eng.relu_step(x, l1, renorm_decoder=True, target=target, **kw)
+                eng.relu_step(x, l1, renorm_decoder=True, target=target, sparse_grads=not self._mr, **kw)
 
         if not self._mr:
             dead = None
@@ -465,7 +465,8 @@ class VisionSAETrainer:
             n_since_fired += 1                                  # train_sae.py:356-361 on the global batch
             n_since_fired[fire > 0] = 0
             act_freq_scores += fire
-        eng.grad_sqnorm()                                       # clip_grad_norm_ over the whole (summed) gradient
+        # clip_grad_norm_ over the whole (summed) gradient; single-process relu_step: from the per-feature terms the step left
+        eng.grad_sqnorm(from_step=not self._mr)
         eng.apply(lr, self.cfg.max_grad_norm)
         optimizer._opt_called = True
         scheduler.step()
