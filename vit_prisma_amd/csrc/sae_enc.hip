@@ -639,7 +639,58 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     }
     const uint32_t nc = bad ? 0u : n;
     __syncthreads();
-    if (!bad) {
+    // t = the k-th largest filter value (with multiplicity).  Round 3 ranked every candidate against every other out of LDS
+    // (~190 x 190 compares per token: 75 of the kernel's 133 us, measured by running the pass twice); now ONE wave runs a radix
+    // select over the ordered keys in registers -- four keys per lane, a ballot + popcount per key and bit, starting below the
+    // keys' common prefix and stopping as soon as the survivors are exactly the ones still wanted (~10 bits on ordinary data) --
+    // while the other waves wait at the barrier.  More than 256 candidates (heavy ties, small d_sae): the all-pairs ranking.
+#ifdef PV_SEL_RANK2                                            // (timing ablation, tools/build_variant.sh: the pass twice)
+    for (int rep = 0; rep < 2; ++rep)
+#endif
+    if (!bad && nc <= 256u) {
+        if (wave == 0) {
+            uint32_t key[4];
+            uint32_t alive = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t c = (uint32_t)lane + 64u * i;
+                key[i] = c < nc ? ckey[c] : 0u;
+                alive |= c < nc ? (1u << i) : 0u;
+            }
+            auto alive_minmax = [&](uint32_t& mn, uint32_t& mx) {
+                mn = 0xffffffffu; mx = 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (alive & (1u << i)) { mn = min(mn, key[i]); mx = max(mx, key[i]); }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+                }
+            };
+            uint32_t kmin, kmax;
+            alive_minmax(kmin, kmax);
+            uint32_t krem = (uint32_t)k, n_alive = nc;
+            if (kmin != kmax) {
+                for (int b = 31 - __clz((int)(kmin ^ kmax)); b >= 0; --b) {       // (everything below is wave-uniform)
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        cnt += (uint32_t)__popcll(__ballot(((alive >> i) & 1u) != 0u && ((key[i] >> b) & 1u) != 0u));
+                    const bool take1 = cnt >= krem;                               // the k-th largest has this bit set
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((((key[i] >> b) & 1u) != 0u) != take1) alive &= ~(1u << i);
+                    if (take1) n_alive = cnt;
+                    else { krem -= cnt; n_alive -= cnt; }
+                    if (n_alive == krem || krem == 1u) break;
+                }
+                alive_minmax(kmin, kmax);
+            }
+            // survivors == wanted: the smallest of them; one wanted (or all survivors equal): the largest
+            if (lane == 0) sh_t = n_alive == krem ? kmin : kmax;
+        }
+    } else if (!bad) {
         for (uint32_t c = tid; c < nc; c += 256) {
             const uint32_t kc = ckey[c];
             const int32_t ic = cidx[c];
@@ -660,6 +711,9 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
             if (ord2f(ckey[c]) >= lo) {
                 const uint32_t pos = atomicAdd(&sh_nr, 1u);
                 if (pos < (uint32_t)PV_SAE_RESCORE_MAX) ridx[pos] = cidx[c];
+#ifdef PV_SEL_NO_RESCORE                                       // (timing ablation: the filter value stands in for the exact one)
+                if (pos < (uint32_t)PV_SAE_RESCORE_MAX) rval[pos] = ord2f(ckey[c]);
+#endif
             }
         }
     }
@@ -670,6 +724,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
         if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
         return;
     }
+#ifndef PV_SEL_NO_RESCORE
     // exact fp32 re-scoring: a wave per candidate, four candidates (4 x V4 16-byte loads per lane) in flight
     bool ok[V4];
     int col[V4];
@@ -709,6 +764,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
             if (c < nr) rval[c] = av + b_enc[jv];
         }
     }
+#endif
     __syncthreads();
     for (uint32_t c = tid; c < nr; c += 256) {
         const float vc = rval[c];
