@@ -12,9 +12,10 @@ from .hooked_root_module import HookedRootModule
 from .compat import install_as
 from .vit import (Attention, Head, HookedViT, LayerNorm, LayerNormPre, MLP, PatchEmbedding, PosEmbedding,
                   TransformerBlock)
+from .sae_vit import HookedSAEViT
 
 __all__ = [
-    "ActivationCache", "HookedViTConfig", "HookPoint", "LensHandle", "HookedRootModule", "HookedViT",
+    "ActivationCache", "HookedViTConfig", "HookPoint", "LensHandle", "HookedRootModule", "HookedViT", "HookedSAEViT",
     "Attention", "Head", "LayerNorm", "LayerNormPre", "MLP", "PatchEmbedding", "PosEmbedding",
     "TransformerBlock", "install_as",
 ]

@@ -6,7 +6,7 @@
     from vit_prisma.sae.config import VisionModelSAERunnerConfig
 
 Registers ``sys.modules`` aliases for the reference's import paths that sit on the hot path
-(/root/reference/src/vit_prisma/{models/base_vit, models/model_loader (offline form), models/layers/*, configs/HookedViTConfig,
+(/root/reference/src/vit_prisma/{models/base_vit (HookedViT, HookedSAEViT), models/model_loader (offline form), models/layers/*, configs/HookedViTConfig,
 prisma_tools/{hook_point, hooked_root_module, activation_cache, lens_handle}, sae/{config, sae,
 train_sae}, sae/training/{activations_store, geometric_median, get_scheduler}}.py).  Reference SAE
 checkpoints pickle ``vit_prisma.sae.config.VisionModelSAERunnerConfig`` inside the ``.pt``
@@ -55,7 +55,7 @@ def install_as(name: str = "vit_prisma", force: bool = False) -> None:
     tree = {
         "": (True, _public(A, A.__all__)),
         "models": (True, {}),
-        "models.base_vit": (False, _public(vit)),
+        "models.base_vit": (False, {**_public(vit), "HookedSAEViT": A.HookedSAEViT}),
         "models.model_loader": (False, _public(model_loader, ["load_hooked_model", "load_config", "list_available_models"])),
         "models.layers": (True, {}),
         **{f"models.layers.{k}": (False, v) for k, v in layers.items()},
