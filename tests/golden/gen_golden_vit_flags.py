@@ -1,0 +1,30 @@
+"""Golden caches of the reference run with its flag-gated HookPoints enabled (build container only): use_attn_result,
+use_split_qkv_input, use_attn_in, use_hook_mlp_in (transformer_block.py:88-129, attention.py:155-183) on the tiny model, fp32.
+
+    python tests/golden/gen_golden_vit_flags.py     ->  tests/golden/vit_tiny_flags.npz
+
+Two configurations: "all" (the four flags) and "result_mlp" (use_attn_result + use_hook_mlp_in: no head dimension on the block
+inputs).  Every cache tensor, the key order and the output."""
+import os, sys
+import numpy as np, torch
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+from gen_golden_vit import build_reference_model, run_ref
+from vit_prisma_amd.synth import synth_images
+
+blob = {}
+for tag, flags in (("all", dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)),
+                   ("result_mlp", dict(use_attn_result=True, use_hook_mlp_in=True)),
+                   ("attn_in", dict(use_attn_in=True)), ("split", dict(use_split_qkv_input=True))):
+    model, arch = build_reference_model("tiny")
+    for k, v in flags.items():
+        setattr(model.cfg, k, v)
+    out, cache = run_ref(model, synth_images(arch, 2, 1))
+    blob[f"{tag}::__out__"] = out.numpy()
+    blob[f"{tag}::__keys__"] = np.array(list(cache.cache_dict.keys()))
+    for k, v in cache.cache_dict.items():
+        if tag in ("all", "result_mlp") or k.startswith("blocks.0.hook_") or k.startswith("blocks.0.ln1."):    # (the others: keys only)
+            blob[f"{tag}::{k}"] = np.ascontiguousarray(v.numpy())
+    print(tag, len(cache.cache_dict), [(k, tuple(v.shape)) for k, v in cache.cache_dict.items() if k.startswith("blocks.0.")])
+np.savez_compressed(os.path.join(HERE, "vit_tiny_flags.npz"), **blob)
+print(os.path.getsize(os.path.join(HERE, "vit_tiny_flags.npz")) // 1024, "kB")

@@ -905,3 +905,34 @@ def test_hooked_sae_vit_splice_takes_the_pytorch_path_and_the_plan_returns_after
         model.reset_saes()
         out2, c2 = model.run_with_cache(x)
         assert model.last_run_native and torch.equal(out2, out0) and list(c2.keys()) == list(c0.keys())
+
+
+@pytest.mark.parametrize("tag,flags", [("all", dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)),
+                                       ("result_mlp", dict(use_attn_result=True, use_hook_mlp_in=True))])
+def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
+    """use_attn_result / use_split_qkv_input / use_attn_in / use_hook_mlp_in (transformer_block.py:88-129, attention.py:155-183): a caching
+    run stays on the HIP plan, the flag-gated entries are derived from its taps -- keys, order, shapes, dtypes and values of the
+    reference's own run (tests/golden/vit_tiny_flags.npz); a hook on such a point takes the PyTorch path and says so."""
+    G = np.load(os.path.join(GOLDEN, "vit_tiny_flags.npz"))
+    arch = ARCHS["tiny"]
+    model = HookedViT(HookedViTConfig(**arch, **flags, dtype=torch.float32, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.cuda().eval()
+    x = torch.from_numpy(synth_images(arch, 2, 1)).cuda()
+    keys = [str(k) for k in G[f"{tag}::__keys__"]]
+    with torch.no_grad():
+        out, cache = model.run_with_cache(x)
+        assert model.last_run_native, model.native_fallback_reason
+        assert list(cache.keys()) == keys
+        assert rel_fro(out.cpu().numpy(), G[f"{tag}::__out__"]) < FP32_TOL
+        for k in keys:
+            g = G[f"{tag}::{k}"]
+            assert cache[k].shape == g.shape and cache[k].dtype == torch.float32, k
+            assert rel_fro(cache[k].cpu().numpy(), g) < FP32_TOL, k
+        # the helpers that read the per-head result
+        per_head = cache.stack_head_results(layer=-1)
+        assert per_head.shape[0] == arch["n_layers"] * arch["n_heads"]
+        name = "blocks.0.attn.hook_result"
+        out_h, cache_h = model.run_with_cache(x, fwd_hooks=[(name, lambda t, hook: t * 0.5)])
+        assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+        assert torch.allclose(cache_h[name], cache[name] * 0.5, rtol=1e-4, atol=1e-6)

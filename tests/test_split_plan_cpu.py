@@ -333,3 +333,49 @@ def test_embedding_and_final_stage_hooks_keep_the_blocks_on_the_plan(model, case
 @pytest.mark.parametrize("case", range(len(EDGE_CASES_LN_PRE) + len(EDGE_CASES)))
 def test_embedding_and_final_stage_hooks_with_ln_pre(model_ln_pre, case):
     _edge(model_ln_pre, (EDGE_CASES_LN_PRE + EDGE_CASES)[case])
+
+
+# ---- flag-gated HookPoints (use_attn_in / use_split_qkv_input / use_attn_result / use_hook_mlp_in): the plan runs as always, their cache
+# entries are derived from what it tapped; a forward hook ON such a point (or on ln1 while the block inputs carry a head dimension)
+# takes the PyTorch path
+FLAG_SETS = [dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True),
+             dict(use_attn_result=True, use_hook_mlp_in=True), dict(use_attn_in=True), dict(use_split_qkv_input=True)]
+FLAG_HOOKS = [[], [("blocks.0.hook_resid_pre", scale_shift), ("blocks.1.attn.hook_z", kill_head_1), ("blocks.1.hook_resid_mid", half)],
+              [("blocks.0.attn.hook_pattern", no_cls_attention), ("blocks.2.mlp.hook_post", kill_neurons), ("hook_embed", half)]]
+
+
+@pytest.mark.parametrize("flags", range(len(FLAG_SETS)))
+def test_flag_gated_points_are_derived_from_the_plan(flags):
+    model = _make_model(**FLAG_SETS[flags])
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    real_reason = model._native_reason
+    forms = FORMS + [{"names_filter": lambda n: n.endswith(("hook_result", "hook_mlp_in", "hook_attn_in", "hook_k_input", "ln1.hook_scale"))},
+                     {"remove_batch_dim": True}]
+    with torch.no_grad():
+        for hooks in FLAG_HOOKS:
+            for kw in forms:
+                xi = x[:1] if kw.get("remove_batch_dim") else x
+                model.use_native(False)
+                w_out, w_cache = model.run_with_cache(xi.clone(), fwd_hooks=hooks, **kw)
+                model.use_native(True)
+                model._native_reason = lambda a, k: None if model._boundary_hooks() is not None else "a hook the plan cannot be split at"
+                try:
+                    g_out, g_cache = model.run_with_cache(xi.clone(), fwd_hooks=hooks, **kw)
+                finally:
+                    model._native_reason = real_reason
+                assert model.last_run_native
+                assert list(g_cache.keys()) == list(w_cache.keys()), kw
+                assert torch.allclose(g_out, w_out, atol=1e-5), kw
+                for k_ in w_cache.keys():
+                    a, b = g_cache[k_], w_cache[k_]
+                    assert a.shape == b.shape and a.dtype == b.dtype and torch.allclose(a, b, atol=1e-5), (k_, kw)
+    # a hook on a flag-gated point, or on ln1 under per-head block inputs: not splittable
+    flagged = {"use_attn_result": "blocks.0.attn.hook_result", "use_split_qkv_input": "blocks.1.hook_v_input",
+               "use_attn_in": "blocks.0.hook_attn_in", "use_hook_mlp_in": "blocks.2.hook_mlp_in"}
+    for flag, name in flagged.items():
+        if FLAG_SETS[flags].get(flag):
+            with model.hooks(fwd_hooks=[(name, half)]):
+                assert model._boundary_hooks() is None
+    if FLAG_SETS[flags].get("use_attn_in") or FLAG_SETS[flags].get("use_split_qkv_input"):
+        with model.hooks(fwd_hooks=[("blocks.0.ln1.hook_scale", freeze_scale)]):
+            assert model._boundary_hooks() is None

@@ -91,3 +91,26 @@ def test_shorthand_indexing():
     # (with a cls token hook_embed has T-1 positions, so incl_embeds=True cannot stack -- same in the reference)
     dec, labels = cache.decompose_resid(return_labels=True, incl_embeds=False)
     assert labels == ["0_attn_out", "0_mlp_out", "1_attn_out", "1_mlp_out"] and dec.shape == (4, 1, 17, 64)
+
+
+def test_flag_gated_hook_points_match_the_reference_run():
+    """tests/golden/vit_tiny_flags.npz (the reference run with use_attn_result / use_split_qkv_input / use_attn_in / use_hook_mlp_in):
+    key order, shapes and values of the PyTorch path, and the firing order the tap planner states."""
+    import numpy as np
+    G = np.load(os.path.join(GOLDEN, "vit_tiny_flags.npz"))
+    for tag, flags in (("all", dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)),
+                       ("result_mlp", dict(use_attn_result=True, use_hook_mlp_in=True)), ("attn_in", dict(use_attn_in=True)),
+                       ("split", dict(use_split_qkv_input=True))):
+        arch = ARCHS["tiny"]
+        model = HookedViT(HookedViTConfig(**arch, **flags))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+        model.eval()
+        keys = [str(k) for k in G[f"{tag}::__keys__"]]
+        assert hook_order(model.cfg, model.cfg.n_layers, True) == keys
+        with torch.no_grad():
+            out, cache = model.run_with_cache(torch.from_numpy(synth_images(arch, 2, 1)))
+        assert list(cache.keys()) == keys
+        assert np.allclose(out.numpy(), G[f"{tag}::__out__"], atol=1e-5)
+        for k in keys:
+            if f"{tag}::{k}" in G.files:
+                assert cache[k].shape == G[f"{tag}::{k}"].shape and np.allclose(cache[k].numpy(), G[f"{tag}::{k}"], atol=2e-5), (tag, k)

@@ -141,8 +141,6 @@ class NativeViT:
             return "classification_type"
         if getattr(cfg, "is_video_transformer", False) or getattr(cfg, "use_bert_block", False) or cfg.attn_only:
             return "architecture variant"
-        if cfg.use_attn_result or cfg.use_split_qkv_input or cfg.use_attn_in or cfg.use_hook_mlp_in:
-            return "per-head input/result hooks enabled"
         if cfg.d_model % 8 or cfg.d_mlp % 8 or cfg.d_model > 2048:
             return "d_model/d_mlp alignment"
         if n_tokens > 640 or cfg.d_head not in (32, 64):

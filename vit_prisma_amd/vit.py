@@ -32,7 +32,7 @@ from .activation_cache import ActivationCache
 from .configs import HookedViTConfig
 from .hook_points import HookPoint
 from .hooked_root_module import HookedRootModule, names_filter_to_fn
-from .tap_plan import hook_order, resolve_n_blocks
+from .tap_plan import FLAG_POINTS, hook_order, resolve_n_blocks
 
 
 def _as_cfg(cfg: Union[Dict, HookedViTConfig]) -> HookedViTConfig:
@@ -506,6 +506,8 @@ class HookedViT(HookedRootModule):
             kind, off = self._KIND_POS[m.group(2)]
             if kind.startswith("ln") and self.cfg.normalization_type not in ("LN", "LNPre"):
                 return None
+            if kind.startswith("ln1") and (self.cfg.use_attn_in or self.cfg.use_split_qkv_input):
+                return None                                       # (per-head block inputs: ln1's HookPoints carry a head dimension there)
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
                 out.setdefault(self._EMBED_POS, {})[name] = hp      # blocks.0.hook_resid_pre is the embedding stage's last tensor
@@ -563,11 +565,63 @@ class HookedViT(HookedRootModule):
 
     def _run_with_cache_native(self, x: torch.Tensor, remove_batch_dim: bool, names_filter=None, device=None,
                                stop_at_layer: Optional[int] = None, **_ignored):
+        """The caching run on the HIP plan.  With flag-gated HookPoints enabled (cfg.use_attn_in / use_split_qkv_input /
+        use_attn_result / use_hook_mlp_in) the plan runs as always -- without a hook on them those points do not change the forward
+        -- and their cache entries are derived afterwards from what the plan tapped (transformer_block.py:88-129,
+        attention.py:155-183): hook_attn_in / hook_q_input / k / v = the block input with a head dimension (a stride-0 view: the
+        reference materialises H copies), ln1's two points carry that head dimension too, attn.hook_result = z against W_O per head
+        (one einsum per layer), hook_mlp_in = hook_resid_mid.  A forward hook ON such a point takes the PyTorch path."""
+        cfg = self.cfg
+        if not (cfg.use_attn_in or cfg.use_split_qkv_input or cfg.use_attn_result or cfg.use_hook_mlp_in):
+            return self._run_with_cache_plan(x, remove_batch_dim, names_filter, device, stop_at_layer)
+        keep = names_filter_to_fn(names_filter)
+        run_head = stop_at_layer is None
+        n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
+        wanted = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        source = {"hook_attn_in": "hook_resid_pre", "hook_q_input": "hook_resid_pre", "hook_k_input": "hook_resid_pre",
+                  "hook_v_input": "hook_resid_pre", "attn.hook_result": "attn.hook_z", "hook_mlp_in": "hook_resid_mid"}
+
+        def split(name: str):
+            """("blocks.L.", rest) of a block's point, ("", name) otherwise"""
+            if name.startswith("blocks."):
+                _, l, rest = name.split(".", 2)
+                return f"blocks.{l}.", rest
+            return "", name
+
+        need = set()
+        for n in wanted:
+            pre, rest = split(n)
+            need.add(pre + source[rest] if rest in FLAG_POINTS else n)
+        out, got = self._run_with_cache_plan(x, False, lambda n: n in need, None, stop_at_layer)
+        H = cfg.n_heads
+        headed = cfg.use_attn_in or cfg.use_split_qkv_input
+        cache: Dict[str, torch.Tensor] = {}
+        for n in wanted:
+            pre, rest = split(n)
+            if rest in FLAG_POINTS:
+                src = got[pre + source[rest]]
+                if rest == "attn.hook_result":
+                    t = torch.einsum("bphd,hdm->bphm", src, self.blocks[int(pre.split(".")[1])].attn.W_O)
+                elif rest == "hook_mlp_in":
+                    t = src
+                else:
+                    t = src.unsqueeze(2).expand(-1, -1, H, -1)
+            elif headed and rest in ("ln1.hook_scale", "ln1.hook_normalized"):
+                t = got[n].unsqueeze(2).expand(-1, -1, H, -1)
+            else:
+                t = got[n]
+            if device is not None:
+                t = t.to(device)
+            cache[n] = t[0] if remove_batch_dim else t
+        return out, cache
+
+    def _run_with_cache_plan(self, x: torch.Tensor, remove_batch_dim: bool, names_filter=None, device=None,
+                             stop_at_layer: Optional[int] = None):
         cfg = self.cfg
         keep = names_filter_to_fn(names_filter)
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
-        names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        names = [n for n in hook_order(cfg, n_blocks, run_head, flags=False) if keep(n)]
         bh = dict(self._boundary_hooks() or {})
         embed_hooked = bh.pop(self._EMBED_POS, None) is not None
         final_hooked = (bh.pop(self._FINAL_POS, None) is not None) and run_head
