@@ -1,5 +1,5 @@
 # radix-select threshold in the select kernel: SAE GPU tests, kernel stats, bench (SAE legs)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4j; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4m; rm -rf $O; mkdir -p $O
 cd $R
 T0=$(date +%s)
 timeout 700 python -m pytest tests/test_native_sae_gpu.py -m gpu -q -p no:cacheprovider --timeout=300 > $O/t_sae.log 2>&1; echo "sae tests rc=$? $(( $(date +%s) - T0 ))s"; tail -4 $O/t_sae.log

@@ -43,9 +43,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // stage 1: partial[blk][c] over CS_ROWS-row blocks -- rows / 16 workgroups (256 at N = 4096: every CU busy), 16
 // independent loads in flight per thread
 constexpr int CS_ROWS = 16;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                             int rows, int d) {
-    const int r0 = blockIdx.x * CS_ROWS;
+__device__ __forceinline__ void colsum_partial_body(int bid, const float* __restrict__ x, float* __restrict__ partial, int rows, int d) {
+    const int r0 = bid * CS_ROWS;
     for (int c = threadIdx.x; c < d; c += 256) {
         float v[CS_ROWS];
 #pragma unroll
@@ -53,8 +52,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < CS_ROWS; ++i) s += v[i];          // fixed order
-        partial[(int64_t)blockIdx.x * d + c] = s;
+        partial[(int64_t)bid * d + c] = s;
     }
+}
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                             int rows, int d) {
+    colsum_partial_body(blockIdx.x, x, partial, rows, d);
 }
 // stage 2: out[c] = scale * sum_blk partial[blk][c]; 64 columns per workgroup, 16 partial streams per column (the
 // 256 partial rows of a 4096-token batch are 16 loads per thread instead of a 64-deep serial chain)
@@ -467,13 +470,31 @@ static inline bool sae_long_ranged(int n_tokens) { return (size_t)n_tokens * 4 +
 // single-workgroup exclusive scan over the d_sae counts, staged through LDS in blocks of 32768 features (one block for
 // the 24 576-feature bench shape, two for the x64 SAEs of docs/sae_table.md: 49 152): coalesced load, per-thread contiguous
 // runs scanned out of LDS, shuffles across threads, coalesced store, the running total carried into the next block
+// loss_part (optional): this workgroup also reduces the decode kernel's per-token loss terms, scalars[0] = scalars[1] = loss_scale *
+// their sum in a fixed order (the step's loss; it used to be a launch of its own in front of this one)
 __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ n_long, int d_sae,
-                                                        float* __restrict__ scalars, float inv_tokens) {
+                                                        float* __restrict__ scalars, float inv_tokens,
+                                                        const float* __restrict__ loss_part = nullptr, int n_loss = 0,
+                                                        float loss_scale = 0.f) {
     constexpr int BLK = 32768;
     __shared__ uint32_t buf[BLK];
     __shared__ uint32_t wsum[16];
+    __shared__ float lsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (loss_part) {
+        float s = 0.f;
+        for (int i = tid; i < n_loss; i += 1024) s += loss_part[i];
+        s = wave_sum(s);
+        if (lane == 0) lsum[wv] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < 16; ++w) t += lsum[w];               // fixed order
+            scalars[0] = t * loss_scale;
+            scalars[1] = t * loss_scale;
+        }
+    }
     uint32_t carry = 0;
     for (int b0 = 0; b0 < d_sae; b0 += BLK) {
         const int nb = min(BLK, d_sae - b0);
@@ -520,19 +541,26 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
 //     exactly one list, so the scatter is disjoint; the cuts at and beyond the total are filled by the whole grid;
 //   * long lists (> BWD_LMAX pairs): registered in long_list {feature, first segment, #segments} with their
 //     BWD_SEG-pair segments in seg_range (two device counters, zeroed by the scan kernel).
-__global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restrict__ offs, uint32_t* __restrict__ chunk_start,
+struct CsrPostArgs {
+    const uint32_t* offs; uint32_t* chunk_start; int max_chunks; int32_t* long_list; uint32_t* n_long; uint32_t* seg_range; int max_segs;
+    float* act_freq; float* n_since_fired; float* fire_count; int d_sae; int update_stats; float* gb_enc_sparse; float* rowsq_sparse;
+    int ranged; const uint32_t* gate;
+};
+// bid / nblocks: this workgroup's index among the nblocks that run the post pass (a launch of its own, or a block range of
+// csr_post_fill_kernel)
+__device__ __forceinline__ void csr_post_body(int bid, int nblocks, const uint32_t* __restrict__ offs, uint32_t* __restrict__ chunk_start,
                                                        int max_chunks, int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
                                                        uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
                                                        float* __restrict__ n_since_fired, float* __restrict__ fire_count,
                                                        int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
                                                        float* __restrict__ rowsq_sparse, int ranged,
-                                                       const uint32_t* __restrict__ gate = nullptr) {
+                                                       const uint32_t* __restrict__ gate) {
     if (gate && *gate != 0u) update_stats = 0;                    // (pv_sae_relu_step in dense mode: the dense path owns the statistics)
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    {   // the cuts at and beyond the total (all threads of the grid: a feature shard of the feature-parallel step keeps a
+    const int j = bid * 256 + threadIdx.x;
+    {   // the cuts at and beyond the total (all threads of the pass: a feature shard of the feature-parallel step keeps a
         // fraction of the N k pairs the cut array is sized for -- 7 of 8 cuts lie beyond the total at world 8)
         const uint32_t total = offs[d_sae];
-        for (uint32_t w = (total + BWD_CH - 1) / BWD_CH + (uint32_t)j; w <= (uint32_t)max_chunks; w += gridDim.x * 256u) chunk_start[w] = total;
+        for (uint32_t w = (total + BWD_CH - 1) / BWD_CH + (uint32_t)j; w <= (uint32_t)max_chunks; w += (uint32_t)nblocks * 256u) chunk_start[w] = total;
     }
     if (j >= d_sae) return;
     const uint32_t beg = offs[j], end = offs[j + 1], c = end - beg;
@@ -562,12 +590,44 @@ __global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
-                                                       const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int n_pairs) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void csr_post_kernel(const uint32_t* __restrict__ offs, uint32_t* __restrict__ chunk_start,
+                                                       int max_chunks, int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                       uint32_t* __restrict__ seg_range, int max_segs, float* __restrict__ act_freq,
+                                                       float* __restrict__ n_since_fired, float* __restrict__ fire_count,
+                                                       int d_sae, int update_stats, float* __restrict__ gb_enc_sparse,
+                                                       float* __restrict__ rowsq_sparse, int ranged,
+                                                       const uint32_t* __restrict__ gate = nullptr) {
+    csr_post_body(blockIdx.x, gridDim.x, offs, chunk_start, max_chunks, long_list, n_long, seg_range, max_segs, act_freq, n_since_fired,
+                  fire_count, d_sae, update_stats, gb_enc_sparse, rowsq_sparse, ranged, gate);
+}
+
+__device__ __forceinline__ void csr_fill_body(int bid, const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
+                                              const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int n_pairs) {
+    const int p = bid * 256 + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t w = wpos[p];
     if (w != 0xffffffffu) pairs[offs[idx[p]] + w] = p;
+}
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
+                                                       const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int n_pairs) {
+    csr_fill_body(blockIdx.x, idx, wpos, offs, pairs, n_pairs);
+}
+
+// The three passes behind the scan that depend on nothing but it and the decode kernel, as ONE launch (they were three): blocks
+// [0, nb_post) = csr_post, [nb_post, nb_post + nb_fill) = csr_fill, the rest (cs_x != NULL) = the 16-row partial column sums of dY
+// that the bias gradients start from.
+__global__ __launch_bounds__(256) void csr_post_fill_kernel(const CsrPostArgs a, int nb_post, const int32_t* __restrict__ idx,
+                                                            const uint32_t* __restrict__ wpos, int32_t* __restrict__ pairs, int n_pairs,
+                                                            int nb_fill, const float* __restrict__ cs_x, float* __restrict__ cs_partial,
+                                                            int cs_rows, int cs_d) {
+    const int b = blockIdx.x;
+    if (b < nb_post)
+        csr_post_body(b, nb_post, a.offs, a.chunk_start, a.max_chunks, a.long_list, a.n_long, a.seg_range, a.max_segs, a.act_freq,
+                      a.n_since_fired, a.fire_count, a.d_sae, a.update_stats, a.gb_enc_sparse, a.rowsq_sparse, a.ranged, a.gate);
+    else if (b < nb_post + nb_fill)
+        csr_fill_body(b - nb_post, idx, wpos, a.offs, pairs, n_pairs);
+    else
+        colsum_partial_body(b - nb_post - nb_fill, cs_x, cs_partial, cs_rows, cs_d);
 }
 
 // The position of a pair inside its feature's list was drawn by an integer atomic in the selection kernel: the SET of a list is
@@ -1286,6 +1346,25 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, co
     V[i] = v;
 }
 
+// two vectors in one launch (b_enc's feature range and b_dec): blocks [0, nb0) take the first
+__global__ __launch_bounds__(256) void adam_vec2_kernel(float* __restrict__ W0, const float* __restrict__ G0, float* __restrict__ M0,
+                                                        float* __restrict__ V0, int lo0, int hi0, int nb0, float* __restrict__ W1,
+                                                        const float* __restrict__ G1, float* __restrict__ M1, float* __restrict__ V1,
+                                                        int hi1, const float* __restrict__ scalars, AdamC c) {
+    const bool first = (int)blockIdx.x < nb0;
+    const int i = first ? lo0 + blockIdx.x * 256 + threadIdx.x : ((int)blockIdx.x - nb0) * 256 + threadIdx.x;
+    if (i >= (first ? hi0 : hi1)) return;
+    float* W = first ? W0 : W1;
+    const float* G = first ? G0 : G1;
+    float* M = first ? M0 : M1;
+    float* V = first ? V0 : V1;
+    const float coef = clip_coef(scalars, c.max_norm);
+    float m = M[i], v = V[i];
+    W[i] = adam_update(W[i], G[i] * coef, m, v, c);
+    M[i] = m;
+    V[i] = v;
+}
+
 // 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm): a wave takes four rows, all loads in flight
 __global__ __launch_bounds__(256) void dec_inv_norm_kernel(const float* __restrict__ W, float* __restrict__ inv, int rows, int d) {
     const int lane = threadIdx.x & 63;
@@ -1588,11 +1667,12 @@ int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const flo
 }
 
 // gb_dec = colsum(dY) - W_enc @ gb_enc (the encoder-input path of b_dec): both terms as partial rows of one column sum
+// have_colsum: the partial column sums of dY are in ws.colpart already (csr_post_fill_kernel)
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
-              hipStream_t stream) {
+              hipStream_t stream, bool have_colsum) {
     const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
     float* colpart = (float*)(wsb + ws.colpart);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
+    if (!have_colsum) hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
     hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
                        colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
@@ -1737,9 +1817,6 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
-        // loss = mse_loss = sum / (N_global * d_in) (sae.py:148; topk: loss == mse_loss, :620-626)
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wsb + ws.loss_part), scalars, N,
-                           1.0f / ((float)n_global * (float)d.d_in), 1, 0);                  // scalars[0] = loss == scalars[1] = mse
         // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
         uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
@@ -1753,14 +1830,22 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         uint32_t* seg_range = tb.seg_range;
         float* seg_rows = tb.seg_rows;
         float* seg_b = tb.seg_b;
+        // (the scan's workgroup also reduces the loss: loss = mse_loss = sum / (N_global * d_in), sae.py:148; topk: loss == mse_loss,
+        // :620-626 -- scalars[0] = scalars[1])
         hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
-                           scalars, 1.0f / (float)N);
-        hipLaunchKernelGGL(csr_post_kernel, dim3((d.d_sae + 255) / 256), block, 0, stream, (const uint32_t*)offs, chunk_start,
-                           max_chunks, long_list, n_long, seg_range, max_segs, st->act_freq_scores, st->n_fwd_since_fired,
-                           fire_count, d.d_sae, update_stats, sparse ? st->gb_enc : nullptr, sparse ? rowsq : nullptr,
-                           sae_long_ranged(N) ? 1 : 0, gate);
-        hipLaunchKernelGGL(csr_fill_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, stream, topk_idx,
-                           (const uint32_t*)tb.wpos, (const uint32_t*)offs, pairs, n_pairs);
+                           scalars, 1.0f / (float)N, (const float*)(wsb + ws.loss_part), N, 1.0f / ((float)n_global * (float)d.d_in));
+        // chunk cuts / long lists / statistics, the scatter of the pairs and (autoencoder) the partial column sums of dY: one launch
+        const bool cs_here = bias_grads && !tc;
+        {
+            CsrPostArgs pa;
+            pa.offs = offs; pa.chunk_start = chunk_start; pa.max_chunks = max_chunks; pa.long_list = long_list; pa.n_long = n_long;
+            pa.seg_range = seg_range; pa.max_segs = max_segs; pa.act_freq = st->act_freq_scores; pa.n_since_fired = st->n_fwd_since_fired;
+            pa.fire_count = fire_count; pa.d_sae = d.d_sae; pa.update_stats = update_stats; pa.gb_enc_sparse = sparse ? st->gb_enc : nullptr;
+            pa.rowsq_sparse = sparse ? rowsq : nullptr; pa.ranged = sae_long_ranged(N) ? 1 : 0; pa.gate = gate;
+            const int nb_post = (d.d_sae + 255) / 256, nb_fill = (n_pairs + 255) / 256, nb_cs = cs_here ? (N + CS_ROWS - 1) / CS_ROWS : 0;
+            hipLaunchKernelGGL(csr_post_fill_kernel, dim3(nb_post + nb_fill + nb_cs), block, 0, stream, pa, nb_post, topk_idx,
+                               (const uint32_t*)tb.wpos, pairs, n_pairs, nb_fill, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
+        }
         hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
         const int ranged = sae_long_ranged(N) ? 1 : 0;
         if (ranged) {
@@ -1794,7 +1879,7 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)
         if (bias_grads) {
-            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
+            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream, cs_here);
             if (rc) return rc;
             if (tc) {
                 rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
@@ -2210,11 +2295,13 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
             V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         }
-        hipLaunchKernelGGL(adam_vec_kernel, dim3((nj + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
-                           st->mb_enc, st->vb_enc, scalars, c, j_lo, j_hi);
     }
-    hipLaunchKernelGGL(adam_vec_kernel, dim3((d.d_in + 255) / 256), block, 0, stream, st->b_dec, (const float*)st->gb_dec,
-                       st->mb_dec, st->vb_dec, scalars, c, 0, d.d_in);
+    {   // b_enc's feature range and b_dec: one launch
+        const int nb0 = (nj + 255) / 256;
+        hipLaunchKernelGGL(adam_vec2_kernel, dim3(nb0 + (d.d_in + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
+                           st->mb_enc, st->vb_enc, j_lo, j_hi, nb0, st->b_dec, (const float*)st->gb_dec, st->mb_dec, st->vb_dec, d.d_in,
+                           scalars, c);
+    }
     if (sae_is_tc(st)) {                                               // transcoder: plain Adam on the decoder's own bias and the skip matrix
         const pv_sae_transcoder& t = st->tc;
         PV_REQUIRE(t.gb_dec_out && t.mb_dec_out && t.vb_dec_out && (!t.W_skip || (t.gW_skip && t.mW_skip && t.vW_skip)), "transcoder Adam state");

@@ -91,7 +91,7 @@ int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t s
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
              unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
-              hipStream_t stream);
+              hipStream_t stream, bool have_colsum = false);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream,
                     const uint32_t* gate = nullptr, uint32_t want = 0u);
 int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);
