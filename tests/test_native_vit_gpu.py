@@ -873,38 +873,66 @@ def test_bf16_long_sequence_attention_kernel(image_size, patch):
     assert torch.equal(only_z["blocks.0.attn.hook_z"], cache["blocks.0.attn.hook_z"])
 
 
-def test_hooked_sae_vit_splice_takes_the_pytorch_path_and_the_plan_returns_after_reset():
-    """HookedSAEViT (base_vit.py:827-1086): with an SAE spliced in place of a HookPoint the module tree is not the plan's forward --
-    the call runs on PyTorch (and says why); the same intervention as a forward hook stays on the plan and gives the same result;
-    after reset_saes the model is back on the plan, bit for bit what it computed before."""
+def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
+    """HookedSAEViT (base_vit.py:827-1086) on the GPU: SAEs spliced in place of a block's HookPoints are served by the HIP plan (split
+    there, the SAE called on the tapped tensor) -- outputs, cache keys and the tensors around the splice of the reference's own run
+    (tests/golden/sae_vit_tiny.npz) with one SAE attached, two, one removed, all removed; a splice the plan cannot serve takes the
+    PyTorch path and says why."""
     from vit_prisma_amd import HookedSAEViT
     from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig
     from vit_prisma_amd.synth import synth_sae_state
+    G = np.load(os.path.join(GOLDEN, "sae_vit_tiny.npz"))
     arch = ARCHS["tiny"]
     model = HookedSAEViT(HookedViTConfig(**arch, dtype=torch.float32, device="cuda"))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
-    model = model.cuda().eval()
+    model = model.cuda().eval().use_native(True)
     x = torch.from_numpy(synth_images(arch, 2, 1)).cuda()
-    cfg = VisionModelSAERunnerConfig(hook_point_layer=0, layer_subtype="hook_resid_post", d_in=arch["d_model"], expansion_factor=4,
-                                     activation_fn_str="relu", activation_fn_kwargs={}, normalize_activations="layer_norm",
-                                     initialization_method="independent", b_dec_init_method="mean", _device="cuda", _dtype="float32",
-                                     log_to_wandb=False, use_ghost_grads=False, verbose=False)
-    sae = StandardSparseAutoencoder(cfg).cuda().eval()
+
+    def make_sae(layer, subtype, act, kw, seed):
+        cfg = VisionModelSAERunnerConfig(hook_point_layer=layer, layer_subtype=subtype, d_in=arch["d_model"], expansion_factor=4,
+                                         activation_fn_str=act, activation_fn_kwargs=kw, normalize_activations="layer_norm",
+                                         initialization_method="independent", b_dec_init_method="mean", _device="cuda", _dtype="float32",
+                                         log_to_wandb=False, use_ghost_grads=False, verbose=False)
+        sae = StandardSparseAutoencoder(cfg).cuda().eval()
+        with torch.no_grad():
+            for name, val in synth_sae_state(arch["d_model"], arch["d_model"] * 4, seed=seed).items():
+                getattr(sae, name).copy_(torch.from_numpy(val))
+        return sae
+
+    def check(tag):
+        with torch.no_grad():
+            out, cache = model.run_with_cache(x)
+        assert model.last_run_native, model.native_fallback_reason
+        assert list(cache.keys()) == [str(k) for k in G[f"{tag}_keys"]], tag
+        assert rel_fro(out.cpu().numpy(), G[f"{tag}_out"]) < FP32_TOL, tag
+        for key in G.files:
+            if key.startswith(tag + "::"):
+                name = key.split("::", 1)[1]
+                assert cache[name].shape == G[key].shape and rel_fro(cache[name].cpu().numpy(), G[key]) < FP32_TOL, key
+        return out
+
+    out0 = check("plain")
+    a = make_sae(0, "hook_resid_post", "relu", {}, 3)
+    b = make_sae(1, "hook_mlp_out", "topk", {"k": 8}, 4)
+    model.add_sae(a)
+    check("one")
     with torch.no_grad():
-        for name, val in synth_sae_state(arch["d_model"], arch["d_model"] * 4, seed=3).items():
-            getattr(sae, name).copy_(torch.from_numpy(val))
-        out0, c0 = model.run_with_cache(x)
-        assert model.last_run_native
-        hooked = model.run_with_hooks(x, fwd_hooks=[(cfg.hook_point, lambda t, hook: sae(t)[0])])
-        assert model.last_run_native
-        model.add_sae(sae)
-        out1, c1 = model.run_with_cache(x)
-        assert not model.last_run_native and "module tree" in model.native_fallback_reason
-        assert cfg.hook_point + ".hook_hidden_post" in c1 and cfg.hook_point not in c1
-        assert rel_fro(out1.cpu().numpy(), hooked.cpu().numpy()) < FP32_TOL
-        model.reset_saes()
-        out2, c2 = model.run_with_cache(x)
-        assert model.last_run_native and torch.equal(out2, out0) and list(c2.keys()) == list(c0.keys())
+        plain_call = model(x)                                        # no caching: the SAE runs on its own HIP engine inside the split
+        assert model.last_run_native and rel_fro(plain_call.cpu().numpy(), G["one_forward"]) < FP32_TOL
+    model.add_sae(b)
+    check("two")
+    model.reset_saes(a.cfg.hook_point)
+    check("only_b")
+    model.reset_saes()
+    assert torch.equal(check("reset"), out0)
+    # not splittable: the embedding stage
+    e = make_sae(0, "hook_resid_pre", "relu", {}, 5)
+    model.use_native(None)
+    model.add_sae(e)
+    with torch.no_grad():
+        model.run_with_cache(x)
+    assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+    model.reset_saes()
 
 
 @pytest.mark.parametrize("tag,flags", [("all", dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)),

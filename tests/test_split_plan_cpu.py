@@ -379,3 +379,84 @@ def test_flag_gated_points_are_derived_from_the_plan(flags):
     if FLAG_SETS[flags].get("use_attn_in") or FLAG_SETS[flags].get("use_split_qkv_input"):
         with model.hooks(fwd_hooks=[("blocks.0.ln1.hook_scale", freeze_scale)]):
             assert model._boundary_hooks() is None
+
+
+# ---- modules spliced in place of HookPoints (HookedSAEViT.add_sae): served by the plan like a hook at that point; the spliced
+# module's own HookPoints take the replaced point's place in the cache
+class _ToySAE(torch.nn.Module):
+    """The shape of a spliced SAE: own HookPoints, returns the tensor the block continues from."""
+
+    def __init__(self, d, hook_point, seed):
+        super().__init__()
+        from vit_prisma_amd.hook_points import HookPoint
+        import types
+        g = torch.Generator().manual_seed(seed)
+        self.W_enc = torch.nn.Parameter(torch.randn(d, 3 * d, generator=g) * 0.3)
+        self.W_dec = torch.nn.Parameter(torch.randn(3 * d, d, generator=g) * 0.3)
+        self.hook_sae_in, self.hook_hidden_post, self.hook_sae_out = HookPoint(), HookPoint(), HookPoint()
+        self.cfg = types.SimpleNamespace(hook_point=hook_point, return_out_only=False)
+        self.dtype = torch.float32
+
+    def forward(self, x):
+        f = self.hook_hidden_post(torch.relu(self.hook_sae_in(x) @ self.W_enc))
+        return self.hook_sae_out(f @ self.W_dec)
+
+
+def _make_sae_model():
+    from vit_prisma_amd import HookedSAEViT
+    torch.manual_seed(0)
+    cfg = HookedViTConfig(n_layers=3, d_model=16, d_head=8, d_mlp=32, n_heads=2, patch_size=P, image_size=S, n_classes=5,
+                          return_type="logits")
+    m = HookedSAEViT(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.ndim == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    backend = SegmentBackend()
+    m._get_native = lambda device: backend
+    m._backend = backend
+    return m
+
+
+SPLICES = [["blocks.0.hook_resid_post"], ["blocks.1.hook_mlp_out", "blocks.2.hook_resid_mid"], ["blocks.1.hook_resid_pre", "blocks.0.attn.hook_z"],
+           ["blocks.2.hook_attn_out", "blocks.2.hook_resid_post"]]
+
+
+@pytest.mark.parametrize("case", range(len(SPLICES)))
+def test_spliced_modules_are_served_by_the_plan(case):
+    model = _make_sae_model()
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    d_of = lambda name: 8 if name.endswith("hook_z") else 16  # noqa: E731
+    for i, name in enumerate(SPLICES[case]):
+        model.add_sae(_ToySAE(d_of(name), name, seed=i))
+    real_reason = model._native_reason
+    user_hooks = [[], [("blocks.0.hook_resid_mid", half), (SPLICES[case][0] + ".hook_hidden_post", kill_neurons)]]
+    with torch.no_grad():
+        for hooks in user_hooks:
+            for kw in FORMS + [{"names_filter": lambda n: n.endswith(("hook_sae_in", "hook_sae_out", "hook_resid_post"))}]:
+                model.use_native(False)
+                w_out, w_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                assert not model.last_run_native
+                model.use_native(True)
+                model._native_reason = lambda a, k: None if (model._tree_matches() and model._boundary_hooks() is not None) else "no"
+                model._backend.calls.clear()
+                try:
+                    g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                finally:
+                    model._native_reason = real_reason
+                assert model.last_run_native and len(model._backend.calls) >= 1
+                assert list(g_cache.keys()) == list(w_cache.keys()), (kw, list(g_cache.keys()), list(w_cache.keys()))
+                assert torch.allclose(g_out, w_out, atol=1e-5), kw
+                for k_ in w_cache.keys():
+                    assert g_cache[k_].shape == w_cache[k_].shape and torch.allclose(g_cache[k_], w_cache[k_], atol=1e-5), (k_, kw)
+                assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
+    # where the plan cannot be split: the embedding stage, a LayerNorm point, block 0's entry
+    model.reset_saes()
+    assert model._tree_matches() and model._boundary_hooks() == {}
+    for name in ("hook_embed", "blocks.1.ln1.hook_normalized", "blocks.0.hook_resid_pre"):
+        model.add_sae(_ToySAE(16, name, seed=5))
+        assert model._tree_matches() and model._boundary_hooks() is None, name
+        model.reset_saes()
+    # any other edit of the tree is still a reason to leave the plan
+    model.blocks[1].hook_resid_post = torch.nn.Identity()
+    assert not model._tree_matches()

@@ -6,9 +6,12 @@ return the reconstruction alone, sae/sae.py:631-635), so every later forward / `
 downstream and the SAE's own HookPoints (``<hook_point>.hook_sae_in`` / ``hook_hidden_pre`` / ``hook_hidden_post`` /
 ``hook_sae_out``) in the cache; ``reset_saes`` puts HookPoints (or the previously attached SAEs) back.
 
-A spliced module tree is not the forward the HIP plan computes: such calls run on the PyTorch path (``HookedViT._native_reason``
-reports "the module tree was modified"), with the SAE itself on its own HIP engine where it qualifies.  The same intervention
-WITHOUT leaving the plan is a forward hook: ``model.run_with_hooks(x, fwd_hooks=[(hook_point, lambda t, hook: sae(t)[0])])``.
+On a GPU the forward stays on the HIP plan where the splice sits on a block's HookPoint (``hook_resid_pre`` of blocks >= 1,
+``hook_attn_out``, ``hook_resid_mid``, ``hook_mlp_out``, ``hook_resid_post``, ``attn.hook_q / k / v / z / ...``, ``mlp.hook_pre /
+hook_post``) and the SAE computes in the model's dtype: the plan is split there exactly as for a forward hook, the SAE is called on
+the tapped tensor (on its own HIP engine unless one of its HookPoints is hooked or cached) and the block resumes from its output;
+the SAE's HookPoints take the replaced point's place in the cache.  A splice anywhere else (embedding / final stage, a LayerNorm
+point) or in another dtype runs on the PyTorch path (``native_fallback_reason`` says so).
 
 One deliberate deviation: the reference's ``saes()`` context reads ``sae.cfg.hook_name`` (:1074, :1075), a field its SAE config
 does not have (``hook_point`` is the one ``add_sae`` uses, :862) -- the temporary-attachment entry points raise AttributeError

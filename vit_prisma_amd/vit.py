@@ -19,7 +19,7 @@ backward hooks, per-head input hooks, training mode) and on machines without a G
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple, Union
+from typing import Dict, List, Optional, Tuple, Union
 
 import re
 
@@ -435,7 +435,7 @@ class HookedViT(HookedRootModule):
         # construction (an SAE spliced in place of a HookPoint as HookedSAEViT.add_sae does, a swapped block, an
         # extra layer) must go through PyTorch.  Every module's children are compared (by identity) with the ones this
         # object was built with (~15 us for B/32).
-        if any(tuple(m._modules.items()) != kids for m, kids in self._module_signature):
+        if not self._tree_matches():
             return "the module tree was modified after construction (spliced / replaced sub-modules)"
         if not x.is_cuda:
             return "input is not on a GPU"
@@ -481,6 +481,28 @@ class HookedViT(HookedRootModule):
                  "ln2.hook_scale": ("ln2s", 7), "ln2.hook_normalized": ("ln2n", 7), "mlp.hook_pre": ("mlppre", 8),
                  "mlp.hook_post": ("mlppost", 9), "hook_mlp_out": ("mlp", 10), "hook_resid_post": ("post", 10)}
 
+    def _spliced(self) -> Dict[str, nn.Module]:
+        """{hook point name: module standing in its place} -- the SAEs HookedSAEViT.add_sae spliced in (empty otherwise)"""
+        return getattr(self, "acts_to_saes", None) or {}
+
+    def _tree_matches(self) -> bool:
+        """Is the module tree the one this object was built with (children compared by identity, ~15 us for B/32) -- except for
+        the modules registered in ``acts_to_saes``, each standing in place of ONE HookPoint (a splice the plan serves like a hook
+        at that point)?"""
+        spliced = None
+        for m, kids in self._module_signature:
+            cur = tuple(m._modules.items())
+            if cur == kids:
+                continue
+            if spliced is None:
+                spliced = set(map(id, self._spliced().values()))
+            if len(cur) != len(kids):
+                return False
+            for (n1, c1), (n0, c0) in zip(cur, kids):
+                if n1 != n0 or (c1 is not c0 and not (id(c1) in spliced and isinstance(c0, HookPoint))):
+                    return False
+        return True
+
     def _boundary_hooks(self) -> Optional[Dict[int, Dict[str, HookPoint]]]:
         """{position: {kind: HookPoint}} for every HookPoint that carries a forward hook, or None when some hook (a
         forward hook elsewhere, any backward hook) cannot be served by splitting the native plan.  Positions count
@@ -489,11 +511,26 @@ class HookedViT(HookedRootModule):
         pattern, +5 = its z, +6 = after its attention half ("attn", then "mid"), +7 = its ln2, +8 = its MLP pre-activation,
         +9 = its MLP activation."""
         out: Dict[int, Dict[str, HookPoint]] = {}
+        spliced = self._spliced()
+        for name, mod in spliced.items():
+            # a module spliced in place of a block's HookPoint: called on the tapped tensor like the HookPoint's hooks would be
+            # (it returns what the block continues from: an SAE with cfg.return_out_only).  Elsewhere, or in another dtype than
+            # the plan's: the PyTorch path.
+            m = self._BOUNDARY_RE.fullmatch(name)
+            if m is None or getattr(mod, "dtype", self.cfg.dtype) != self.cfg.dtype:
+                return None
+            kind, off = self._KIND_POS[m.group(2)]
+            pos = self._NPOS * int(m.group(1)) + off
+            if pos == 0 or kind.startswith("ln"):
+                return None
+            out.setdefault(pos, {})[kind] = mod
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
                 return None
             if not hp._forward_hooks:
                 continue
+            if spliced and any(name.startswith(x + ".") for x in spliced):
+                continue                                          # a spliced module's own HookPoints fire inside its forward
             if name in self._EMBED_NAMES:
                 out.setdefault(self._EMBED_POS, {})[name] = hp
                 continue
@@ -616,6 +653,45 @@ class HookedViT(HookedRootModule):
         return out, cache
 
     def _run_with_cache_plan(self, x: torch.Tensor, remove_batch_dim: bool, names_filter=None, device=None,
+                             stop_at_layer: Optional[int] = None):
+        """The plan's own points; with modules spliced in place of HookPoints (HookedSAEViT) their own HookPoints
+        (``<point>.hook_sae_in`` ...) take the replaced point's place in the cache, recorded while the module runs."""
+        spliced = self._spliced()
+        if not spliced:
+            return self._run_with_cache_core(x, remove_batch_dim, names_filter, device, stop_at_layer)
+        cfg = self.cfg
+        keep = names_filter_to_fn(names_filter)
+        run_head = stop_at_layer is None
+        n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
+        expanded: List[str] = []
+        for n in hook_order(cfg, n_blocks, run_head, flags=False):
+            expanded += [k for k in self.hook_dict if k.startswith(n + ".")] if n in spliced else [n]
+        wanted = [n for n in expanded if keep(n)]
+        inner = [n for n in wanted if any(n.startswith(x_ + ".") for x_ in spliced)]
+        plan_names = [n for n in wanted if n not in inner]
+        rec: Dict[str, torch.Tensor] = {}
+        added = []
+        for n in inner:                                          # (HookPoint-level hooks: the module then runs its hookable forward)
+            hp = self.hook_dict[n]
+            hp.add_hook(lambda t, hook, n=n: rec.__setitem__(n, t.detach()))
+            added.append((hp, hp.fwd_hooks[-1]))
+        try:
+            out, got = self._run_with_cache_core(x, False, plan_names, None, stop_at_layer)
+        finally:
+            for hp, h in added:
+                h.hook.remove()
+                hp.fwd_hooks.remove(h)
+        cache: Dict[str, torch.Tensor] = {}
+        for n in wanted:
+            t = rec.get(n) if n in rec else got.get(n)
+            if t is None:
+                continue                                          # (a spliced module behind stop_at_layer never ran)
+            if device is not None:
+                t = t.to(device)
+            cache[n] = t[0] if remove_batch_dim else t
+        return out, cache
+
+    def _run_with_cache_core(self, x: torch.Tensor, remove_batch_dim: bool, names_filter=None, device=None,
                              stop_at_layer: Optional[int] = None):
         cfg = self.cfg
         keep = names_filter_to_fn(names_filter)
