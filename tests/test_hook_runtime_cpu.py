@@ -208,9 +208,15 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
                       ("ln_final.hook_normalized", model._FINAL_POS), ("hook_ln_final", model._FINAL_POS)):
         with model.hooks(fwd_hooks=[(name, ident)]):
             assert list(model._boundary_hooks()) == [key], name
-    for bad in ("blocks.0.hook_mlp_in", "blocks.1.attn.hook_result", "blocks.0.hook_q_input"):       # flag-gated: never fire by default
-        with model.hooks(fwd_hooks=[(bad, ident)]):
-            assert model._boundary_hooks() is None, bad
+    for name, flag in (("blocks.0.hook_mlp_in", "use_hook_mlp_in"), ("blocks.1.attn.hook_result", "use_attn_result"),
+                       ("blocks.0.hook_q_input", "use_split_qkv_input")):
+        with model.hooks(fwd_hooks=[(name, ident)]):
+            assert model._boundary_hooks() == {}, name                  # flag off: the point is never called, the hook cannot fire
+            setattr(model.cfg, flag, True)                              # flag on: that block runs on its own module
+            try:
+                assert model._boundary_hooks() == {model._TORCH_POS: {int(name.split(".")[1]): True}}, name
+            finally:
+                setattr(model.cfg, flag, False)
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):
         assert model._boundary_hooks() is None
 

@@ -925,8 +925,21 @@ def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
     check("only_b")
     model.reset_saes()
     assert torch.equal(check("reset"), out0)
-    # not splittable: the embedding stage
+    # a splice on block 0's entry: that block on its own module, the rest on the plan -- the same numbers as the PyTorch path
     e = make_sae(0, "hook_resid_pre", "relu", {}, 5)
+    model.add_sae(e)
+    with torch.no_grad():
+        out_n, c_n = model.run_with_cache(x)
+        assert model.last_run_native
+        model.use_native(False)
+        out_t, c_t = model.run_with_cache(x)
+        model.use_native(True)
+    assert list(c_n.keys()) == list(c_t.keys()) and rel_fro(out_n.cpu().numpy(), out_t.cpu().numpy()) < FP32_TOL
+    for k in c_t.keys():
+        assert rel_fro(c_n[k].cpu().numpy(), c_t[k].cpu().numpy()) < FP32_TOL, k
+    model.reset_saes()
+    # on the embedding stage: the PyTorch path, and it says why
+    e.cfg.hook_point = "hook_embed"
     model.use_native(None)
     model.add_sae(e)
     with torch.no_grad():
@@ -940,7 +953,8 @@ def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
 def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
     """use_attn_result / use_split_qkv_input / use_attn_in / use_hook_mlp_in (transformer_block.py:88-129, attention.py:155-183): a caching
     run stays on the HIP plan, the flag-gated entries are derived from its taps -- keys, order, shapes, dtypes and values of the
-    reference's own run (tests/golden/vit_tiny_flags.npz); a hook on such a point takes the PyTorch path and says so."""
+    reference's own run (tests/golden/vit_tiny_flags.npz); a hook ON such a point sends that block to its own PyTorch module and leaves
+    the others on the plan."""
     G = np.load(os.path.join(GOLDEN, "vit_tiny_flags.npz"))
     arch = ARCHS["tiny"]
     model = HookedViT(HookedViTConfig(**arch, **flags, dtype=torch.float32, device="cuda"))
@@ -961,6 +975,13 @@ def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
         per_head = cache.stack_head_results(layer=-1)
         assert per_head.shape[0] == arch["n_layers"] * arch["n_heads"]
         name = "blocks.0.attn.hook_result"
-        out_h, cache_h = model.run_with_cache(x, fwd_hooks=[(name, lambda t, hook: t * 0.5)])
-        assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+        hooks = [(name, lambda t, hook: t * 0.5), ("blocks.1.hook_mlp_in", lambda t, hook: t + 1.0), ("blocks.1.attn.hook_z", lambda t, hook: t * 2.0)]
+        out_h, cache_h = model.run_with_cache(x, fwd_hooks=hooks)
+        assert model.last_run_native, model.native_fallback_reason
         assert torch.allclose(cache_h[name], cache[name] * 0.5, rtol=1e-4, atol=1e-6)
+        model.use_native(False)
+        out_t, cache_t = model.run_with_cache(x, fwd_hooks=hooks)
+        model.use_native(None)
+        assert list(cache_h.keys()) == list(cache_t.keys()) and rel_fro(out_h.cpu().numpy(), out_t.cpu().numpy()) < FP32_TOL
+        for k in cache_t.keys():
+            assert cache_h[k].shape == cache_t[k].shape and rel_fro(cache_h[k].cpu().numpy(), cache_t[k].cpu().numpy()) < FP32_TOL, k

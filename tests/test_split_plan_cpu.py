@@ -369,16 +369,48 @@ def test_flag_gated_points_are_derived_from_the_plan(flags):
                 for k_ in w_cache.keys():
                     a, b = g_cache[k_], w_cache[k_]
                     assert a.shape == b.shape and a.dtype == b.dtype and torch.allclose(a, b, atol=1e-5), (k_, kw)
-    # a hook on a flag-gated point, or on ln1 under per-head block inputs: not splittable
-    flagged = {"use_attn_result": "blocks.0.attn.hook_result", "use_split_qkv_input": "blocks.1.hook_v_input",
-               "use_attn_in": "blocks.0.hook_attn_in", "use_hook_mlp_in": "blocks.2.hook_mlp_in"}
-    for flag, name in flagged.items():
-        if FLAG_SETS[flags].get(flag):
-            with model.hooks(fwd_hooks=[(name, half)]):
-                assert model._boundary_hooks() is None
-    if FLAG_SETS[flags].get("use_attn_in") or FLAG_SETS[flags].get("use_split_qkv_input"):
-        with model.hooks(fwd_hooks=[("blocks.0.ln1.hook_scale", freeze_scale)]):
-            assert model._boundary_hooks() is None
+    # a hook ON a flag-gated point (or on ln1 under per-head block inputs) changes that block's forward: the block runs on its own
+    # module, the blocks around it stay on the plan
+    def head_edit(t, hook):
+        t = t.clone()
+        t[:, :, 1] = t[:, :, 1] * 0.5
+        return t
+
+    F_ = FLAG_SETS[flags]
+    mixed = []
+    if F_.get("use_attn_result"):
+        mixed.append([("blocks.1.attn.hook_result", head_edit), ("blocks.0.hook_resid_post", half)])
+    if F_.get("use_split_qkv_input"):
+        mixed.append([("blocks.0.hook_v_input", head_edit), ("blocks.2.hook_q_input", half), ("blocks.1.attn.hook_z", kill_head_1)])
+    if F_.get("use_attn_in"):
+        mixed.append([("blocks.2.hook_attn_in", head_edit), ("hook_embed", half)])
+        mixed.append([("blocks.0.hook_attn_in", head_edit), ("blocks.1.hook_attn_in", half), ("blocks.1.hook_resid_pre", scale_shift),
+                      ("blocks.2.hook_resid_pre", half)])
+    if F_.get("use_hook_mlp_in"):
+        mixed.append([("blocks.1.hook_mlp_in", scale_shift), ("blocks.1.hook_mlp_out", half), ("blocks.2.hook_resid_pre", half),
+                      ("ln_final.hook_normalized", half)])
+    if F_.get("use_attn_in") or F_.get("use_split_qkv_input"):
+        mixed.append([("blocks.1.ln1.hook_scale", freeze_scale), ("blocks.0.ln2.hook_normalized", half)])
+    with torch.no_grad():
+        for hooks in mixed:
+            for kw in forms:
+                xi = x[:1] if kw.get("remove_batch_dim") else x
+                model.use_native(False)
+                w_out, w_cache = model.run_with_cache(xi.clone(), fwd_hooks=hooks, **kw)
+                model.use_native(True)
+                model._native_reason = lambda a, k: None if model._boundary_hooks() is not None else "a hook the plan cannot be split at"
+                model._backend.calls.clear()
+                try:
+                    g_out, g_cache = model.run_with_cache(xi.clone(), fwd_hooks=hooks, **kw)
+                finally:
+                    model._native_reason = real_reason
+                assert model.last_run_native, hooks
+                assert list(g_cache.keys()) == list(w_cache.keys()), (hooks, kw)
+                assert torch.allclose(g_out, w_out, atol=1e-5), (hooks, kw)
+                for k_ in w_cache.keys():
+                    a, b = g_cache[k_], w_cache[k_]
+                    assert a.shape == b.shape and a.dtype == b.dtype and torch.allclose(a, b, atol=1e-5), (k_, hooks, kw)
+                assert all(len(hp.fwd_hooks) == 0 and len(hp._forward_hooks) == 0 for hp in model.hook_dict.values())
 
 
 # ---- modules spliced in place of HookPoints (HookedSAEViT.add_sae): served by the plan like a hook at that point; the spliced
@@ -450,13 +482,31 @@ def test_spliced_modules_are_served_by_the_plan(case):
                 for k_ in w_cache.keys():
                     assert g_cache[k_].shape == w_cache[k_].shape and torch.allclose(g_cache[k_], w_cache[k_], atol=1e-5), (k_, kw)
                 assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
-    # where the plan cannot be split: the embedding stage, a LayerNorm point, block 0's entry
+    # a splice the plan cannot serve at a block's point (a LayerNorm point, block 0's entry): that block on its own module; on the
+    # embedding stage: the PyTorch path
     model.reset_saes()
     assert model._tree_matches() and model._boundary_hooks() == {}
-    for name in ("hook_embed", "blocks.1.ln1.hook_normalized", "blocks.0.hook_resid_pre"):
-        model.add_sae(_ToySAE(16, name, seed=5))
-        assert model._tree_matches() and model._boundary_hooks() is None, name
-        model.reset_saes()
+    model.add_sae(_ToySAE(16, "hook_embed", seed=5))
+    assert model._tree_matches() and model._boundary_hooks() is None
+    model.reset_saes()
+    with torch.no_grad():
+        for name in ("blocks.1.ln2.hook_normalized", "blocks.0.hook_resid_pre"):
+            model.add_sae(_ToySAE(16, name, seed=5))
+            assert model._tree_matches() and list(model._boundary_hooks()) == [model._TORCH_POS], name
+            for kw in FORMS:
+                model.use_native(False)
+                w_out, w_cache = model.run_with_cache(x.clone(), **kw)
+                model.use_native(True)
+                model._native_reason = lambda a, k: None if (model._tree_matches() and model._boundary_hooks() is not None) else "no"
+                try:
+                    g_out, g_cache = model.run_with_cache(x.clone(), **kw)
+                finally:
+                    model._native_reason = real_reason
+                assert model.last_run_native and list(g_cache.keys()) == list(w_cache.keys()), (name, kw)
+                assert torch.allclose(g_out, w_out, atol=1e-5)
+                for k_ in w_cache.keys():
+                    assert torch.allclose(g_cache[k_], w_cache[k_], atol=1e-5), (k_, name, kw)
+            model.reset_saes()
     # any other edit of the tree is still a reason to leave the plan
     model.blocks[1].hook_resid_post = torch.nn.Identity()
     assert not model._tree_matches()

@@ -472,6 +472,12 @@ class HookedViT(HookedRootModule):
     # LayerNorm, a [B, d] x [d, n_classes] product -- under 1 % of the forward), their HookPoints firing as usual, and every block
     # stays on the HIP plan, resumed from / stopped at the residual stream (special keys of _boundary_hooks())
     _EMBED_POS, _FINAL_POS = -1, 1 << 30
+    # blocks that must run on their own PyTorch module (special key of _boundary_hooks(): {block index: True}): a forward hook on one
+    # of the block's flag-gated points (hook_attn_in, hook_q_input / k / v, attn.hook_result, hook_mlp_in) or on ln1 while the block
+    # inputs carry a head dimension, a module spliced on one of its LayerNorm points or on block 0's entry.  Every HookPoint of such a
+    # block fires inside its module's forward; the blocks around it stay on the HIP plan.
+    _TORCH_POS = -2
+    _FLAG_RE = re.compile(r"blocks\.(\d+)\.(hook_attn_in|hook_q_input|hook_k_input|hook_v_input|attn\.hook_result|hook_mlp_in)$")
     _EMBED_NAMES = ("hook_embed", "hook_pos_embed", "hook_full_embed", "ln_pre.hook_scale", "ln_pre.hook_normalized", "hook_ln_pre")
     _FINAL_NAMES = ("ln_final.hook_scale", "ln_final.hook_normalized", "hook_ln_final", "hook_post_head_pre_normalize")
     _KIND_POS = {"hook_resid_pre": ("pre", 0), "ln1.hook_scale": ("ln1s", 1), "ln1.hook_normalized": ("ln1n", 1),
@@ -522,7 +528,8 @@ class HookedViT(HookedRootModule):
             kind, off = self._KIND_POS[m.group(2)]
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0 or kind.startswith("ln"):
-                return None
+                out.setdefault(self._TORCH_POS, {})[int(m.group(1))] = True
+                continue
             out.setdefault(pos, {})[kind] = mod
         for name, hp in self.hook_dict.items():
             if hp._backward_hooks:
@@ -539,12 +546,20 @@ class HookedViT(HookedRootModule):
                 continue
             m = self._BOUNDARY_RE.fullmatch(name)
             if m is None:
-                return None
+                f = self._FLAG_RE.fullmatch(name)
+                if f is None:
+                    return None
+                flag = {"hook_attn_in": "use_attn_in", "attn.hook_result": "use_attn_result", "hook_mlp_in": "use_hook_mlp_in"}.get(
+                    f.group(2), "use_split_qkv_input")
+                if getattr(self.cfg, flag):                       # (with its flag off the point is never called: the hook cannot fire)
+                    out.setdefault(self._TORCH_POS, {})[int(f.group(1))] = True
+                continue
             kind, off = self._KIND_POS[m.group(2)]
             if kind.startswith("ln") and self.cfg.normalization_type not in ("LN", "LNPre"):
                 return None
             if kind.startswith("ln1") and (self.cfg.use_attn_in or self.cfg.use_split_qkv_input):
-                return None                                       # (per-head block inputs: ln1's HookPoints carry a head dimension there)
+                out.setdefault(self._TORCH_POS, {})[int(m.group(1))] = True     # (ln1's HookPoints carry a head dimension there)
+                continue
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
                 out.setdefault(self._EMBED_POS, {})[name] = hp      # blocks.0.hook_resid_pre is the embedding stage's last tensor
@@ -607,7 +622,8 @@ class HookedViT(HookedRootModule):
         -- and their cache entries are derived afterwards from what the plan tapped (transformer_block.py:88-129,
         attention.py:155-183): hook_attn_in / hook_q_input / k / v = the block input with a head dimension (a stride-0 view: the
         reference materialises H copies), ln1's two points carry that head dimension too, attn.hook_result = z against W_O per head
-        (one einsum per layer), hook_mlp_in = hook_resid_mid.  A forward hook ON such a point takes the PyTorch path."""
+        (one einsum per layer), hook_mlp_in = hook_resid_mid.  A forward hook ON such a point changes that block's forward: the block
+        runs on its own PyTorch module (_run_blocks_mixed), the others stay on the plan."""
         cfg = self.cfg
         if not (cfg.use_attn_in or cfg.use_split_qkv_input or cfg.use_attn_result or cfg.use_hook_mlp_in):
             return self._run_with_cache_plan(x, remove_batch_dim, names_filter, device, stop_at_layer)
@@ -625,17 +641,20 @@ class HookedViT(HookedRootModule):
                 return f"blocks.{l}.", rest
             return "", name
 
-        need = set()
+        need = set(wanted)                                       # (a block that runs on its own module records its flag-gated points itself)
         for n in wanted:
             pre, rest = split(n)
-            need.add(pre + source[rest] if rest in FLAG_POINTS else n)
+            if rest in FLAG_POINTS:
+                need.add(pre + source[rest])
         out, got = self._run_with_cache_plan(x, False, lambda n: n in need, None, stop_at_layer)
         H = cfg.n_heads
         headed = cfg.use_attn_in or cfg.use_split_qkv_input
         cache: Dict[str, torch.Tensor] = {}
         for n in wanted:
             pre, rest = split(n)
-            if rest in FLAG_POINTS:
+            if n in got and rest in FLAG_POINTS:
+                t = got[n]
+            elif rest in FLAG_POINTS:
                 src = got[pre + source[rest]]
                 if rest == "attn.hook_result":
                     t = torch.einsum("bphd,hdm->bphm", src, self.blocks[int(pre.split(".")[1])].attn.W_O)
@@ -643,7 +662,7 @@ class HookedViT(HookedRootModule):
                     t = src
                 else:
                     t = src.unsqueeze(2).expand(-1, -1, H, -1)
-            elif headed and rest in ("ln1.hook_scale", "ln1.hook_normalized"):
+            elif headed and rest in ("ln1.hook_scale", "ln1.hook_normalized") and got[n].ndim == 3:
                 t = got[n].unsqueeze(2).expand(-1, -1, H, -1)
             else:
                 t = got[n]
@@ -664,7 +683,7 @@ class HookedViT(HookedRootModule):
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
         expanded: List[str] = []
-        for n in hook_order(cfg, n_blocks, run_head, flags=False):
+        for n in hook_order(cfg, n_blocks, run_head):
             expanded += [k for k in self.hook_dict if k.startswith(n + ".")] if n in spliced else [n]
         wanted = [n for n in expanded if keep(n)]
         inner = [n for n in wanted if any(n.startswith(x_ + ".") for x_ in spliced)]
@@ -697,23 +716,30 @@ class HookedViT(HookedRootModule):
         keep = names_filter_to_fn(names_filter)
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
-        names = [n for n in hook_order(cfg, n_blocks, run_head, flags=False) if keep(n)]
+        names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        on_plan = [n for n in names if self._FLAG_RE.fullmatch(n) is None]      # (flag-gated points exist in torch blocks only)
         bh = dict(self._boundary_hooks() or {})
         embed_hooked = bh.pop(self._EMBED_POS, None) is not None
         final_hooked = (bh.pop(self._FINAL_POS, None) is not None) and run_head
-        if not embed_hooked and not final_hooked:
-            return self._run_native_segments(x, None, names, n_blocks, run_head, bh, device, remove_batch_dim)
-        # hooks on the embedding / final stage: that stage on the PyTorch modules (hooks fire as usual), the blocks on the HIP plan
+        tblocks = sorted(l for l in (bh.pop(self._TORCH_POS, None) or {}) if l < n_blocks)
+        if not embed_hooked and not final_hooked and not tblocks:
+            return self._run_native_segments(x, None, on_plan, n_blocks, run_head, bh, device, remove_batch_dim)
+        # hooks on the embedding / final stage, blocks that need their own module: those on PyTorch (their hooks fire as usual),
+        # every other block on the HIP plan
         wanted = set(names)
         cache: Dict[str, torch.Tensor] = {}
         start = None
         if embed_hooked:
-            start, rec = self._torch_embedding_stage(x, wanted, n_blocks)
+            # (block 0's hook_resid_pre belongs to the embedding stage's tail -- unless block 0 runs on its module, which fires it)
+            start, rec = self._torch_embedding_stage(x, wanted, 0 if (tblocks and tblocks[0] == 0) else n_blocks)
             cache.update(rec)
-        inner = [n for n in names if n not in cache and not (final_hooked and n in self._FINAL_NAMES)
+        inner = [n for n in on_plan if n not in cache and not (final_hooked and n in self._FINAL_NAMES)
                  and not (embed_hooked and (n in self._EMBED_NAMES or n == "blocks.0.hook_resid_pre"))]
-        if n_blocks > 0 or (run_head and not final_hooked) or start is None:
-            out, c = self._run_native_segments(x, start, inner, n_blocks, run_head and not final_hooked, bh, None, False)
+        head_on_plan = run_head and not final_hooked
+        if tblocks:
+            out = self._run_blocks_mixed(x, start, inner, n_blocks, head_on_plan, bh, tblocks, cache, wanted)
+        elif n_blocks > 0 or head_on_plan or start is None:
+            out, c = self._run_native_segments(x, start, inner, n_blocks, head_on_plan, bh, None, False)
             cache.update(c)
         else:
             out = start                                          # stop_at_layer = 0 behind a hooked embedding stage
@@ -722,11 +748,68 @@ class HookedViT(HookedRootModule):
             cache.update(rec)
         ordered: Dict[str, torch.Tensor] = {}
         for n in names:
+            if n not in cache:
+                continue                                          # (a flag-gated point of a block on the plan: derived by the caller)
             t = cache[n]
             if device is not None:
                 t = t.to(device)
             ordered[n] = t[0] if remove_batch_dim else t
         return out, ordered
+
+    def _run_blocks_mixed(self, x, start, names, n_blocks: int, run_head: bool, bh, tblocks, cache, wanted):
+        """Blocks 0 .. n_blocks - 1 (+ the head) where the blocks of `tblocks` run on their own PyTorch module (every HookPoint of
+        such a block fires inside it: transformer_block.py:80-138) and the runs of blocks between them on the HIP plan, resumed from
+        / stopped at the residual stream.  Fills `cache`, returns the output."""
+        NP = self._NPOS
+        resid, b = start, 0
+        for L in list(tblocks) + [None]:
+            stop = n_blocks if L is None else L
+            head_here = L is None and run_head
+            if stop > b or head_here or resid is None:
+                # the hooks of this run of plan blocks: strictly inside it as they are; at its end only what belongs to its last block
+                # (the next block's hook_resid_pre fires inside that block's module); at its start hook_resid_pre of block b by hand
+                sub = {}
+                for q, kinds in bh.items():
+                    if NP * b < q < NP * stop:
+                        sub[q] = kinds
+                    elif q == NP * stop and stop > b:
+                        k_ = kinds if L is None else {k: v for k, v in kinds.items() if k in ("mlp", "post")}
+                        if k_:
+                            sub[q] = k_
+                if resid is not None and b > 0 and stop > b:
+                    pre = bh.get(NP * b, {}).get("pre")
+                    if pre is not None:
+                        resid = pre(resid)
+                    if f"blocks.{b}.hook_resid_pre" in wanted:
+                        cache[f"blocks.{b}.hook_resid_pre"] = resid
+
+                def mine(n: str) -> bool:
+                    if n.startswith("blocks."):
+                        return b <= int(n.split(".", 2)[1]) < stop
+                    return (n in self._FINAL_NAMES and head_here) or (n not in self._FINAL_NAMES and b == 0 and resid is None)
+
+                seg_names = [n for n in names if mine(n) and not (resid is not None and n == f"blocks.{b}.hook_resid_pre")]
+                resid, c = self._run_native_segments(x, resid, seg_names, stop, head_here, sub, None, False,
+                                                     first_block=b)
+                cache.update(c)
+            if L is None:
+                break
+            resid, rec = self._torch_block_stage(L, resid, wanted)
+            cache.update(rec)
+            b = L + 1
+        return resid
+
+    def _torch_block_stage(self, l: int, resid: torch.Tensor, wanted):
+        """Block l on its own module (transformer_block.py:80-138): (its output, {name: cached tensor} of its HookPoints)."""
+        rec: Dict[str, torch.Tensor] = {}
+        pre = f"blocks.{l}."
+        handles = self._recording_hooks([n for n in self.hook_dict if n.startswith(pre)], wanted, rec)
+        try:
+            out = self.blocks[l](resid)
+        finally:
+            for h in handles:
+                h.remove()
+        return out.contiguous(), rec
 
     def _recording_hooks(self, which, wanted, rec):
         """forward hooks that note what the HookPoints of `which` pass on (registered behind the caller's hooks, like the caching
@@ -783,9 +866,9 @@ class HookedViT(HookedRootModule):
         return x, rec
 
     def _run_native_segments(self, x: torch.Tensor, start_resid: Optional[torch.Tensor], names, n_blocks: int, run_head: bool, bh,
-                             device, remove_batch_dim: bool):
-        """The blocks (+ the head) on the HIP plan, split at the hooked positions of `bh`; start_resid: resume at block 0 from
-        this residual stream instead of starting from the pixels (the embedding stage ran elsewhere)."""
+                             device, remove_batch_dim: bool, first_block: int = 0):
+        """The blocks (+ the head) on the HIP plan, split at the hooked positions of `bh`; start_resid: resume at block
+        `first_block` from this residual stream instead of starting from the pixels (what lies before ran elsewhere)."""
         cfg = self.cfg
         nv = self._get_native(x.device)
         NP = self._NPOS
@@ -796,7 +879,7 @@ class HookedViT(HookedRootModule):
             tap_dst = getattr(self, "_tap_dst", None)             # (the activation store's own buffer slice, sae/store.py)
             if start_resid is not None:
                 return nv.forward(self, None, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
-                                  first_block=0, resid_in=start_resid)
+                                  first_block=first_block, resid_in=start_resid)
             return nv.forward(self, x, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
                               **({"tap_dst": tap_dst} if tap_dst else {}))
         # ---- split plan: [0, q1) -> hooks -> [q1, q2) -> ... -> [qk, end) (+ head); positions count NP per block.
@@ -841,8 +924,9 @@ class HookedViT(HookedRootModule):
             out = xc / scale
             return out * ln_mod.w + ln_mod.b if isinstance(ln_mod, LayerNorm) else out
 
-        p0, resid, acts, out = 0, start_resid, (), None
+        p0, resid, acts, out = NP * first_block, start_resid, (), None
         from_pixels = start_resid is None
+        assert first_block == 0 or not from_pixels
         for q in bounds + [None]:
             last = q is None
             p1 = end_pos if last else q
