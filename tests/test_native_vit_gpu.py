@@ -366,15 +366,18 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
                 for k in w_cache.keys():
                     a, b = g_cache[k].float().cpu().numpy(), w_cache[k].float().cpu().numpy()
                     assert a.shape == b.shape and rel_fro(a, b) < FP32_TOL, (k, kw)
-        # a hook on a point the forward never fires by default (flag-gated, transformer_block.py:88-104, 125-129) cannot be served by
-        # splitting the plan: PyTorch path in "auto" mode, an error in "force" mode
+        # a hook on a point the forward never calls with its flag off (flag-gated, transformer_block.py:88-104, 125-129) cannot fire:
+        # the run stays on the plan and equals the PyTorch path's; a backward hook is what the plan cannot serve -- PyTorch path in
+        # "auto" mode, an error in "force" mode
         model.use_native(None)
         out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_in", scale_shift)])
-        assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+        assert model.last_run_native
         assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_in", scale_shift)]).cpu().numpy()) < FP32_TOL
+        model.run_with_cache(x, incl_bwd=True)
+        assert not model.last_run_native and "backward" in model.native_fallback_reason
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, fwd_hooks=[("blocks.0.hook_mlp_in", scale_shift)])
+            model.run_with_cache(x, incl_bwd=True)
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
 
 

@@ -735,7 +735,7 @@ __device__ __forceinline__ void epi8_bf16(const float4& x0, const float4& x1, co
     } else {
         // the stored (bf16-rounded) value is what the reference carries on: transformer_block.py:122-124, :134;
         // mlp.py:67-72
-        if (o0) *reinterpret_cast<uint4*>(o0) = r;
+        if (o0) pv_store16_stream<pv_u32x4_a16>(o0, r.x, r.y, r.z, r.w);     // (o0 = the tap-only output of these two epilogues)
         const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
         uint4 y;
         if constexpr (EPI == PV_EPI_RESID) {

@@ -101,6 +101,27 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = a;
 }
 
+// 16 bytes to a TAP-ONLY destination (a cache entry nothing on the device reads back: the pre-activation / attn_out / mlp_out taps
+// of the GEMM epilogues, LayerNorm's fp32 hook_normalized, the attention scores / pattern): a nontemporal store, so that the tap
+// stream does not push the next kernel's operands (the tensor written beside it) out of the L2 / MALL.  Measured on the B/32
+// forward: MLP-2 131 -> 115 us with its A operand (mlp.hook_post) no longer evicted by the mlp.hook_pre tap (profiles/r04_notes.md).
+// V: one of the vector types below (the destination's alignment).  -DPV_NO_NT (A/B builds): plain stores.
+typedef uint32_t pv_u32x4_a16 __attribute__((ext_vector_type(4)));
+typedef uint32_t pv_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t pv_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+template <typename V>
+__device__ __forceinline__ void pv_store16_stream(void* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+#ifdef PV_NO_NT
+    *reinterpret_cast<V*>(p) = V{x, y, z, w};
+#else
+    __builtin_nontemporal_store(V{x, y, z, w}, reinterpret_cast<V*>(p));
+#endif
+}
+__device__ __forceinline__ void store8_stream(float* p, const float (&v)[8]) {
+    pv_store16_stream<pv_u32x4_a16>(p, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    pv_store16_stream<pv_u32x4_a16>(p + 4, __float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------

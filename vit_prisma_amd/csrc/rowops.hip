@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnParams p) {
             load8(reinterpret_cast<const T*>(p.b) + ch * 8, b);
 #pragma unroll
             for (int i = 0; i < 8; ++i) y[i] = (x[c][i] / scale) * w[i] + b[i];
-            if (p.norm_f32_out) store8(p.norm_f32_out + (int64_t)row * d + ch * 8, y);
+            if (p.norm_f32_out) store8_stream(p.norm_f32_out + (int64_t)row * d + ch * 8, y);   // (the fp32 tap of bf16 mode)
             if (p.out) store8(reinterpret_cast<T*>(p.out) + (int64_t)row * d + ch * 8, y);
         }
     }

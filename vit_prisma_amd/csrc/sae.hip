@@ -308,6 +308,26 @@ __device__ __forceinline__ float4 ld4(const float* p, bool ok) {
     return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+// The optimizer state (both Adam moments, 302 MB) and the gradients are touched ONCE per step: streamed past the caches
+// (nontemporal), so that what the next step gathers by row -- W_dec, W_enc^T and its fp16 copy, 188 MB, written by the same
+// kernels -- is what stays in the 256 MB MALL.  -DPV_NO_NT (A/B builds): plain accesses.
+typedef float pv_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p, bool ok) {
+#ifdef PV_NO_NT
+    return ld4(p, ok);
+#else
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const pv_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pv_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, const float4& v) {
+#ifdef PV_NO_NT
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    __builtin_nontemporal_store(pv_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<pv_f32x4*>(p));
+#endif
+}
 
 // MODE 0: the whole thing.  The feature-parallel step cuts it at the reconstruction: MODE 1 = this rank's PARTIAL
 // reconstruction sum_s val_s W_dec[idx_s] only (written to sae_out, no b_dec, no LN-out); MODE 2 = everything behind it, the
@@ -1137,9 +1157,9 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
         ok[i] = col < d;
         const int64_t o = (int64_t)j * d + col;
         w[i] = ld4(W + o, ok[i]);
-        g[i] = ld4(G + o, ok[i] && live);
-        m[i] = ld4(M + o, ok[i]);
-        v[i] = ld4(V + o, ok[i]);
+        g[i] = ld4_stream(G + o, ok[i] && live);
+        m[i] = ld4_stream(M + o, ok[i]);
+        v[i] = ld4_stream(V + o, ok[i]);
     }
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
@@ -1159,8 +1179,8 @@ __global__ __launch_bounds__(256) void adam_wdec_kernel(float* __restrict__ W, c
         wn.z = adam_update(w[i].z, g[i].z - dot * w[i].z, m[i].z, v[i].z, c);
         wn.w = adam_update(w[i].w, g[i].w - dot * w[i].w, m[i].w, v[i].w, c);
         *reinterpret_cast<float4*>(W + o) = wn;
-        *reinterpret_cast<float4*>(M + o) = m[i];
-        *reinterpret_cast<float4*>(V + o) = v[i];
+        st4_stream(M + o, m[i]);
+        st4_stream(V + o, v[i]);
         sq += wn.x * wn.x + wn.y * wn.y + wn.z * wn.z + wn.w * wn.w;
     }
     // the next step's set_decoder_norm_to_unit_norm needs 1 / ||row|| of what was just written: leave it behind
@@ -1193,9 +1213,9 @@ __global__ __launch_bounds__(256) void adam_wenct_kernel(float* __restrict__ WT,
         ok[i] = col < d;
         const int64_t o = (int64_t)j * d + col;
         w[i] = ld4(WT + o, ok[i]);
-        g[i] = ld4(GT + o, ok[i] && live);
-        m[i] = ld4(MT + o, ok[i]);
-        v[i] = ld4(VT + o, ok[i]);
+        g[i] = ld4_stream(GT + o, ok[i] && live);
+        m[i] = ld4_stream(MT + o, ok[i]);
+        v[i] = ld4_stream(VT + o, ok[i]);
     }
     float sq = 0.f;
     bool big = false;
@@ -1209,8 +1229,8 @@ __global__ __launch_bounds__(256) void adam_wenct_kernel(float* __restrict__ WT,
         wn.z = adam_update(w[i].z, g[i].z * coef, m[i].z, v[i].z, c);
         wn.w = adam_update(w[i].w, g[i].w * coef, m[i].w, v[i].w, c);
         *reinterpret_cast<float4*>(WT + o) = wn;
-        *reinterpret_cast<float4*>(MT + o) = m[i];
-        *reinterpret_cast<float4*>(VT + o) = v[i];
+        st4_stream(MT + o, m[i]);
+        st4_stream(VT + o, v[i]);
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const h4 hv = {(_Float16)wn.x, (_Float16)wn.y, (_Float16)wn.z, (_Float16)wn.w};
         *reinterpret_cast<h4*>(W16T + o) = hv;
