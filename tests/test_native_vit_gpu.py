@@ -373,11 +373,12 @@ def test_boundary_hooks_run_on_the_split_native_plan(arch_name):
         out = model.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_in", scale_shift)])
         assert model.last_run_native
         assert rel_fro(out.cpu().numpy(), ref.run_with_hooks(x, fwd_hooks=[("blocks.0.hook_mlp_in", scale_shift)]).cpu().numpy()) < FP32_TOL
-        model.run_with_cache(x, incl_bwd=True)
-        assert not model.last_run_native and "backward" in model.native_fallback_reason
+        ident = lambda t, hook: None  # noqa: E731
+        model.run_with_hooks(x, bwd_hooks=[("blocks.0.hook_resid_post", ident)])
+        assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
         model.use_native(True)
         with pytest.raises(_native.NativeError):
-            model.run_with_cache(x, incl_bwd=True)
+            model.run_with_hooks(x, bwd_hooks=[("blocks.0.hook_resid_post", ident)])
         assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
 
 
