@@ -28,3 +28,16 @@ for tag, flags in (("all", dict(use_attn_result=True, use_split_qkv_input=True, 
     print(tag, len(cache.cache_dict), [(k, tuple(v.shape)) for k, v in cache.cache_dict.items() if k.startswith("blocks.0.")])
 np.savez_compressed(os.path.join(HERE, "vit_tiny_flags.npz"), **blob)
 print(os.path.getsize(os.path.join(HERE, "vit_tiny_flags.npz")) // 1024, "kB")
+
+# ---- the same at CLIP ViT-B/32 size (bs = 2, fp32, the four flags): fingerprints only (oracle/vit_oracle.fingerprint) -> vit_b32_flags_bs2.json
+import json
+from oracle.vit_oracle import fingerprint
+model, arch = build_reference_model("clip-vit-b32")
+for k in ("use_attn_result", "use_split_qkv_input", "use_attn_in", "use_hook_mlp_in"):
+    setattr(model.cfg, k, True)
+out, cache = run_ref(model, synth_images(arch, 2, 1))
+big = {"keys": list(cache.cache_dict.keys()), "out": fingerprint(out.numpy()),
+       "cache": {k: fingerprint(v.numpy()) for k, v in cache.cache_dict.items()}}
+with open(os.path.join(HERE, "vit_b32_flags_bs2.json"), "w") as f:
+    json.dump(big, f)
+print("b32 flags", len(big["keys"]), os.path.getsize(os.path.join(HERE, "vit_b32_flags_bs2.json")) // 1024, "kB")

@@ -989,3 +989,42 @@ def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
         assert list(cache_h.keys()) == list(cache_t.keys()) and rel_fro(out_h.cpu().numpy(), out_t.cpu().numpy()) < FP32_TOL
         for k in cache_t.keys():
             assert cache_h[k].shape == cache_t[k].shape and rel_fro(cache_h[k].cpu().numpy(), cache_t[k].cpu().numpy()) < FP32_TOL, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flag_gated_hook_points_at_b32_size_vs_reference_fixture(dtype):
+    """The four flags at CLIP ViT-B/32 size (286 cache entries per forward, bs = 2): fp32 against the reference's own run,
+    fingerprinted (tests/golden/vit_b32_flags_bs2.json: key order, shapes, l2, sampled values); bf16: keys / shapes / dtypes, and the
+    derived entries consistent with what they are derived from."""
+    with open(os.path.join(GOLDEN, "vit_b32_flags_bs2.json")) as f:
+        G = json.load(f)
+    arch = ARCHS["clip-vit-b32"]
+    flags = dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)
+    model = HookedViT(HookedViTConfig(**arch, **flags, dtype=dtype, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.to(dtype).cuda().eval().use_native(True)
+    x = torch.from_numpy(synth_images(arch, 2, 1)).cuda().to(dtype)
+    with torch.no_grad():
+        out, cache = model.run_with_cache(x)
+    assert model.last_run_native and list(cache.keys()) == G["keys"] and len(cache) == 286
+    H = arch["n_heads"]
+    for k in G["keys"]:
+        got = cache[k]
+        assert list(got.shape) == G["cache"][k]["shape"], k
+        if dtype == torch.float32:
+            fp = fingerprint(got.cpu().numpy())
+            assert abs(fp["l2"] - G["cache"][k]["l2"]) <= FP32_TOL * G["cache"][k]["l2"], k
+            vw = np.array(G["cache"][k]["vals"])
+            assert np.max(np.abs(np.array(fp["vals"]) - vw)) <= 1e-3 * max(np.max(np.abs(vw)), G["cache"][k]["l2"] / np.sqrt(got.numel())), k
+    if dtype == torch.float32:
+        fo = fingerprint(out.cpu().numpy())
+        assert abs(fo["l2"] - G["out"]["l2"]) <= FP32_TOL * G["out"]["l2"]
+    for l in (0, 11):
+        p = f"blocks.{l}."
+        assert torch.equal(cache[p + "hook_attn_in"], cache[p + "hook_resid_pre"].unsqueeze(2).expand(-1, -1, H, -1))
+        assert torch.equal(cache[p + "hook_mlp_in"], cache[p + "hook_resid_mid"])
+        assert cache[p + "ln1.hook_scale"].dtype == torch.float32 and cache[p + "attn.hook_result"].dtype == dtype
+        # the per-head results sum to the O-projection's output (attention.py:170-183), to the rounding of the storage dtype
+        summed = cache[p + "attn.hook_result"].float().sum(2) + model.blocks[l].attn.b_O.detach().float()
+        tol = 2e-5 if dtype == torch.float32 else 3e-2
+        assert rel_fro(summed.cpu().numpy(), cache[p + "hook_attn_out"].float().cpu().numpy()) < tol, l
