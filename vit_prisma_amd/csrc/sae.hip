@@ -321,6 +321,20 @@ __device__ __forceinline__ float4 ld4_stream(const float* p, bool ok) {
     return make_float4(v.x, v.y, v.z, v.w);
 #endif
 }
+__device__ __forceinline__ float ld1_stream(const float* p) {
+#ifdef PV_NO_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void st1_stream(float* p, float v) {
+#ifdef PV_NO_NT
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 __device__ __forceinline__ void st4_stream(float* p, const float4& v) {
 #ifdef PV_NO_NT
     *reinterpret_cast<float4*>(p) = v;
@@ -1297,9 +1311,9 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                     const bool in = j < j_hi && i < d_in;
                     const int64_t o = (int64_t)j * d_in + i;
                     wv[u][r] = in ? WT[o] : 0.f;
-                    gv[u][r] = (in && live[r]) ? GT[o] : 0.f;
-                    mv[u][r] = in ? MT[o] : 0.f;
-                    vv[u][r] = in ? VT[o] : 0.f;
+                    gv[u][r] = (in && live[r]) ? ld1_stream(GT + o) : 0.f;      // (optimizer state and gradients: streamed, see ld4_stream)
+                    mv[u][r] = in ? ld1_stream(MT + o) : 0.f;
+                    vv[u][r] = in ? ld1_stream(VT + o) : 0.f;
                 }
         }
 #pragma unroll
@@ -1313,8 +1327,8 @@ __global__ __launch_bounds__(256) void wenc_rows_kernel(float* __restrict__ W, f
                     if constexpr (MODE == 0) {
                         float m = mv[u][r], v = vv[u][r];
                         wn = adam_update(wv[u][r], gv[u][r] * coef, m, v, c);
-                        MT[o] = m;
-                        VT[o] = v;
+                        st1_stream(MT + o, m);
+                        st1_stream(VT + o, v);
                         WT[o] = wn;
                     } else if constexpr (MODE == 1) {
                         wn = WT[o];
