@@ -942,13 +942,23 @@ def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
     for k in c_t.keys():
         assert rel_fro(c_n[k].cpu().numpy(), c_t[k].cpu().numpy()) < FP32_TOL, k
     model.reset_saes()
-    # on the embedding stage: the PyTorch path, and it says why
+    # on the embedding stage: that stage on the model's own modules, the blocks on the plan
     e.cfg.hook_point = "hook_embed"
-    model.use_native(None)
     model.add_sae(e)
     with torch.no_grad():
-        model.run_with_cache(x)
-    assert not model.last_run_native and "cannot be split" in model.native_fallback_reason
+        out_n, c_n = model.run_with_cache(x)
+        assert model.last_run_native
+        model.use_native(False)
+        out_t, c_t = model.run_with_cache(x)
+        model.use_native(True)
+    assert list(c_n.keys()) == list(c_t.keys()) and "hook_embed.hook_sae_out" in c_n and "hook_embed" not in c_n
+    assert rel_fro(out_n.cpu().numpy(), out_t.cpu().numpy()) < FP32_TOL
+    model.reset_saes()
+    # in another dtype than the model's: the PyTorch path, and it says why
+    model.use_native(None)
+    model.add_sae(make_sae(1, "hook_resid_post", "relu", {}, 6).double())
+    model.acts_to_saes["blocks.1.hook_resid_post"].dtype = torch.float64
+    assert model._boundary_hooks() is None
     model.reset_saes()
 
 

@@ -483,16 +483,14 @@ def test_spliced_modules_are_served_by_the_plan(case):
                     assert g_cache[k_].shape == w_cache[k_].shape and torch.allclose(g_cache[k_], w_cache[k_], atol=1e-5), (k_, kw)
                 assert all(len(hp.fwd_hooks) == 0 for hp in model.hook_dict.values())
     # a splice the plan cannot serve at a block's point (a LayerNorm point, block 0's entry): that block on its own module; on the
-    # embedding stage: the PyTorch path
+    # embedding / final stage: that stage on the model's own modules (as for a hook there), every block on the plan
     model.reset_saes()
     assert model._tree_matches() and model._boundary_hooks() == {}
-    model.add_sae(_ToySAE(16, "hook_embed", seed=5))
-    assert model._tree_matches() and model._boundary_hooks() is None
-    model.reset_saes()
     with torch.no_grad():
-        for name in ("blocks.1.ln2.hook_normalized", "blocks.0.hook_resid_pre"):
-            model.add_sae(_ToySAE(16, name, seed=5))
-            assert model._tree_matches() and list(model._boundary_hooks()) == [model._TORCH_POS], name
+        for name, key in (("blocks.1.ln2.hook_normalized", model._TORCH_POS), ("blocks.0.hook_resid_pre", model._TORCH_POS),
+                          ("hook_embed", model._EMBED_POS), ("hook_post_head_pre_normalize", model._FINAL_POS)):
+            model.add_sae(_ToySAE(5 if name.startswith("hook_post") else 16, name, seed=5))
+            assert model._tree_matches() and list(model._boundary_hooks()) == [key], name
             for kw in FORMS:
                 model.use_native(False)
                 w_out, w_cache = model.run_with_cache(x.clone(), **kw)

@@ -11,8 +11,9 @@ On a GPU the forward stays on the HIP plan where the splice sits on a block's Ho
 hook_post``) and the SAE computes in the model's dtype: the plan is split there exactly as for a forward hook, the SAE is called on
 the tapped tensor (on its own HIP engine unless one of its HookPoints is hooked or cached) and the block resumes from its output;
 the SAE's HookPoints take the replaced point's place in the cache.  A splice on a block's LayerNorm point or on block 0's entry
-sends that block to its own module (the others stay on the plan); on the embedding / final stage, or in another dtype than the
-model's, the call runs on the PyTorch path (``native_fallback_reason`` says so).
+sends that block to its own module (the others stay on the plan); on the embedding / final stage that stage runs on the model's own
+modules (as for a hook there); in another dtype than the model's the call runs on the PyTorch path (``native_fallback_reason`` says
+so).
 
 One deliberate deviation: the reference's ``saes()`` context reads ``sae.cfg.hook_name`` (:1074, :1075), a field its SAE config
 does not have (``hook_point`` is the one ``add_sae`` uses, :862) -- the temporary-attachment entry points raise AttributeError

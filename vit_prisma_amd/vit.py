@@ -523,8 +523,18 @@ class HookedViT(HookedRootModule):
             # (it returns what the block continues from: an SAE with cfg.return_out_only).  Elsewhere, or in another dtype than
             # the plan's: the PyTorch path.
             m = self._BOUNDARY_RE.fullmatch(name)
-            if m is None or getattr(mod, "dtype", self.cfg.dtype) != self.cfg.dtype:
+            if getattr(mod, "dtype", self.cfg.dtype) != self.cfg.dtype:
                 return None
+            if m is None:
+                # on the embedding / final stage: that stage runs on the model's own modules anyway when it is hooked, and the
+                # spliced module is then simply what the stage calls
+                if name in self._EMBED_NAMES:
+                    out.setdefault(self._EMBED_POS, {})[name] = mod
+                elif name in self._FINAL_NAMES:
+                    out.setdefault(self._FINAL_POS, {})[name] = mod
+                else:
+                    return None
+                continue
             kind, off = self._KIND_POS[m.group(2)]
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0 or kind.startswith("ln"):
