@@ -180,11 +180,16 @@ class SparseAutoencoder(HookedRootModule, ABC):
         self.b_dec.data = all_activations.mean(dim=0).to(self.dtype).to(self.device)
 
     @torch.no_grad()
+    def initialize_b_dec_with_geometric_median(self, all_activations: torch.Tensor):
+        """b_dec <- the geometric median of the activations (sae.py:210-226; Weiszfeld, at most 100 iterations)."""
+        from .geometric_median import compute_geometric_median
+        self.initialize_b_dec_with_precalculated(compute_geometric_median(all_activations, maxiter=100).median)
+
+    @torch.no_grad()
     def initialize_b_dec(self, all_activations: torch.Tensor):
         method = self.cfg.b_dec_init_method
         if method == "geometric_median":
-            from .geometric_median import compute_geometric_median
-            self.initialize_b_dec_with_precalculated(compute_geometric_median(all_activations, maxiter=100).median)
+            self.initialize_b_dec_with_geometric_median(all_activations)
         elif method == "mean":
             self.initialize_b_dec_with_mean(all_activations)
         elif method != "zeros":
