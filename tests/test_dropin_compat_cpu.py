@@ -51,14 +51,14 @@ def test_import_aliases_cover_the_reference_paths():
 @pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="the reference tree only exists in the build container")
 def test_the_references_own_offline_tests_pass_against_this_build(tmp_path):
     files = [os.path.join(REF_TESTS, f) for f in ("test_hooks.py", "test_cache_hook_names.py", "test_weight_properties.py",
-                                                   "sae/test_load_VisionModelSAERunnerConfig.py")]
+                                                   "sae/test_load_VisionModelSAERunnerConfig.py", "models/test_models.py")]
     code = ("import sys, pytest, vit_prisma_amd\n"
             "vit_prisma_amd.install_as('vit_prisma')\n"
             f"sys.exit(pytest.main({files!r} + ['-q', '-p', 'no:cacheprovider']))\n")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "17 passed" in r.stdout, r.stdout[-500:]
+    assert "22 passed" in r.stdout, r.stdout[-500:]
 
 
 def test_checkpoints_written_by_the_reference_load_and_reproduce_its_output():
