@@ -163,3 +163,23 @@ def test_load_hooked_model_offline_from_a_local_open_clip_checkpoint(tmp_path):
     finally:
         from vit_prisma_amd.compat import uninstall
         uninstall("vit_prisma")
+
+
+def test_offline_loader_configs_carry_the_reference_registry_overrides():
+    """Every model name the offline loader knows resolves to the config fields the reference's registry lays over the downloaded
+    config (models/model_config_registry.py, applied by its load_config :201-203) -- read out of the reference into
+    tests/golden/model_registry.json by gen_golden_model_registry.py.  Round-4 advisor finding: 'openai/clip-vit-base-patch32'
+    came back with the open_clip B/32 values (eps 1e-5, L2-normalised output) instead of its own (1e-6, not normalised)."""
+    import json
+    from vit_prisma_amd.model_loader import MODEL_ARCH, load_config
+    with open(os.path.join(os.path.dirname(__file__), "golden", "model_registry.json")) as f:
+        reg = json.load(f)
+    assert sorted(reg) == sorted(MODEL_ARCH)
+    for name, fields in reg.items():
+        cfg = load_config(name, device="cpu")
+        for k, v in fields.items():
+            if k == "architecture":                       # (a loader-internal tag of the reference, not a HookedViTConfig field)
+                continue
+            assert getattr(cfg, k) == v, (name, k, getattr(cfg, k), v)
+    a, b = load_config("openai/clip-vit-base-patch32", device="cpu"), load_config("open-clip:laion/CLIP-ViT-B-32-DataComp.XL-s13B-b90K", device="cpu")
+    assert (a.eps, a.normalize_output) == (1e-6, False) and (b.eps, b.normalize_output) == (1e-5, True)

@@ -1350,6 +1350,7 @@ def test_store_taps_straight_into_its_buffer(vit_dtype):
     buf, _ = store._harvest_raw(4)
     torch.cuda.synchronize()
     assert vit.last_run_native and buf.dtype == vit_dtype and tuple(buf.shape) == (16, 17, 1, 64)
+    assert store.n_buffer_copies == 0          # (round-4 advisor: the `buf[...] = acts` pass ran on a stacked copy although the kernel had written the rows)
     with torch.no_grad():
         _, cache = vit.run_with_cache(images[:16].cuda(), names_filter=[cfg.hook_point], stop_at_layer=2)
     assert torch.equal(buf[:, :, 0, :], cache[cfg.hook_point])

@@ -115,3 +115,26 @@ def test_alias_module_exposes_the_class():
         assert Aliased is HookedSAEViT
     finally:
         uninstall("vit_prisma")
+
+
+def test_hooks_registered_before_a_splice_are_gone_after_reset():
+    """reset_saes restores the ORIGINAL HookPoint object (the tree the HIP plan was built for), but like the reference's fresh
+    HookPoint() (base_vit.py:903) it carries no hooks afterwards -- a permanent hook registered on the point before add_sae must
+    not come back to life (round-4 advisor finding)."""
+    model, arch, x = build()
+    a = make_sae(arch, 0, "hook_resid_post", "relu", {}, 3)
+    fired = []
+    name = a.cfg.hook_point
+    original = model.hook_dict[name]
+    model.add_perma_hook(name, lambda t, hook: fired.append(1))
+    with torch.no_grad():
+        model(x)
+        assert fired == [1]
+        model.add_sae(a)
+        model(x)                                   # (the SAE stands in the point's place: the hook does not fire)
+        assert fired == [1]
+        model.reset_saes()
+        assert model.hook_dict[name] is original and not original.fwd_hooks and not original.has_hooks()
+        model(x)
+    assert fired == [1]
+    assert model._tree_matches()

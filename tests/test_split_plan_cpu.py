@@ -434,11 +434,11 @@ class _ToySAE(torch.nn.Module):
         return self.hook_sae_out(f @ self.W_dec)
 
 
-def _make_sae_model():
+def _make_sae_model(**flags):
     from vit_prisma_amd import HookedSAEViT
     torch.manual_seed(0)
     cfg = HookedViTConfig(n_layers=3, d_model=16, d_head=8, d_mlp=32, n_heads=2, patch_size=P, image_size=S, n_classes=5,
-                          return_type="logits")
+                          return_type="logits", **flags)
     m = HookedSAEViT(cfg).eval()
     with torch.no_grad():
         for p_ in m.parameters():
@@ -508,3 +508,58 @@ def test_spliced_modules_are_served_by_the_plan(case):
     # any other edit of the tree is still a reason to leave the plan
     model.blocks[1].hook_resid_post = torch.nn.Identity()
     assert not model._tree_matches()
+
+
+# a module spliced in place of a HookPoint TOGETHER with flag-gated HookPoints (round-4 advisor finding: KeyError on the spliced
+# name): the splice's own HookPoints stand in the cache where the replaced point stood, the flag-gated entries are derived as
+# without a splice -- and a splice on the very tensor a flag-gated point is derived from (block input / z / resid_mid) sends that
+# block to its own module, whose flag-gated points then see the module's output as in the reference
+SPLICE_X_FLAG = [(dict(use_attn_result=True), ["blocks.1.hook_resid_post"]),
+                 (dict(use_attn_in=True), ["blocks.1.hook_resid_post", "blocks.2.hook_attn_out"]),
+                 (dict(use_split_qkv_input=True), ["blocks.0.hook_mlp_out"]),
+                 (dict(use_hook_mlp_in=True), ["blocks.1.hook_resid_post"]),
+                 (dict(use_hook_mlp_in=True), ["blocks.1.hook_resid_mid"]),                   # the source of hook_mlp_in itself
+                 (dict(use_attn_in=True, use_split_qkv_input=True), ["blocks.1.hook_resid_pre"]),  # the source of hook_attn_in / q, k, v inputs
+                 (dict(use_attn_result=True), ["blocks.2.attn.hook_z", "blocks.0.hook_resid_mid"]),  # the source of attn.hook_result
+                 (dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True),
+                  ["blocks.0.hook_resid_post", "blocks.2.hook_mlp_out"])]
+
+
+@pytest.mark.parametrize("case", range(len(SPLICE_X_FLAG)))
+def test_spliced_modules_together_with_flag_gated_points(case):
+    flags, splices = SPLICE_X_FLAG[case]
+    model = _make_sae_model(**flags)
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    d_of = lambda name: 8 if name.endswith("hook_z") else 16  # noqa: E731
+    for i, name in enumerate(splices):
+        model.add_sae(_ToySAE(d_of(name), name, seed=i))
+    real_reason = model._native_reason
+    forms = FORMS + [{"names_filter": lambda n: n.endswith(("hook_sae_in", "hook_sae_out", "hook_result", "hook_mlp_in", "hook_attn_in",
+                                                            "hook_k_input", "hook_resid_post"))}]
+    with torch.no_grad():
+        for hooks in ([], [("blocks.0.hook_attn_out", half)]):
+            for kw in forms:
+                model.use_native(False)
+                w_out, w_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                model.use_native(True)
+                model._native_reason = lambda a, k: None if (model._tree_matches() and model._boundary_hooks() is not None) else "no"
+                try:
+                    g_out, g_cache = model.run_with_cache(x.clone(), fwd_hooks=hooks, **kw)
+                finally:
+                    model._native_reason = real_reason
+                assert model.last_run_native
+                assert list(g_cache.keys()) == list(w_cache.keys()), (kw, list(g_cache.keys()), list(w_cache.keys()))
+                assert torch.allclose(g_out, w_out, atol=1e-5), kw
+                for k_ in w_cache.keys():
+                    a, b = g_cache[k_], w_cache[k_]
+                    assert a.shape == b.shape and a.dtype == b.dtype and torch.allclose(a, b, atol=1e-5), (k_, kw)
+    # the derived hook_mlp_in owns its storage (an in-place edit must not reach hook_resid_mid)
+    if flags.get("use_hook_mlp_in") and "blocks.1.hook_resid_mid" not in splices:
+        model.use_native(True)
+        model._native_reason = lambda a, k: None
+        try:
+            with torch.no_grad():
+                _, c = model.run_with_cache(x.clone())
+        finally:
+            model._native_reason = real_reason
+        assert c["blocks.0.hook_mlp_in"].data_ptr() != c["blocks.0.hook_resid_mid"].data_ptr()

@@ -2,8 +2,8 @@
 /root/reference/src/vit_prisma/models/model_loader.py:278-368; aliased as ``vit_prisma.models.model_loader`` by ``install_as``).
 
 The reference resolves ``model_name`` to a config and to weights by downloading from HuggingFace (model_loader.py:397-407, 775-784);
-there is no network here.  This loader therefore takes the config from the architecture tables of ``synth.ARCHS`` (what ``load_config``
-would have produced for these names) and the weights from a LOCAL open_clip / HuggingFace CLIP checkpoint
+there is no network here.  This loader therefore takes the config from the architecture tables of ``synth.ARCHS`` plus the
+per-name overrides of the reference registry (``NAME_OVERRIDES``) -- what ``load_config`` would have produced for these names, SURVEY.md 8a -- and the weights from a LOCAL open_clip / HuggingFace CLIP checkpoint
 (``local_path=...``: a ``.safetensors`` / ``.pt`` / ``.bin`` file, converted by ``weights.py`` exactly as the reference's converters do) --
 or none (``pretrained=False``: the reference's initialisation).  Everything else about the signature is the reference's; the options
 that rewrite weights (``fold_ln``, ``center_writing_weights``, ``refactor_factored_attn_matrices``) are not implemented and raise
@@ -30,6 +30,13 @@ MODEL_ARCH = {
     "openai/clip-vit-base-patch32": "clip-vit-b32",
     "openai/clip-vit-large-patch14-336": "clip-vit-l14-336",
 }
+# per-name overrides the reference registry applies on top of the architecture (models/model_config_registry.py:83-92, applied by
+# its load_config :201-203): the HuggingFace OpenAI B/32 entry runs with eps = 1e-6 and WITHOUT the L2-normalised output, unlike the
+# open_clip B/32 entries (BASE_OPEN_CLIP_CONFIGS["ViT-B"], :43-49).  Pinned by tests/golden/model_registry.json (values read out of
+# the reference's registry by tests/golden/gen_golden_model_registry.py).
+NAME_OVERRIDES = {
+    "openai/clip-vit-base-patch32": {"eps": 1e-6, "normalize_output": False},
+}
 DTYPE_FROM_STRING = {"float32": torch.float32, "fp32": torch.float32, "float16": torch.float16, "fp16": torch.float16,
                      "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
 
@@ -43,6 +50,7 @@ def load_config(model_name: str, dtype: torch.dtype = torch.float32, device: str
         raise ValueError(f"{model_name!r}: offline build knows {list_available_models()} (no network: configs cannot be downloaded)")
     kw = dict(ARCHS[MODEL_ARCH[model_name]])
     kw["model_name"] = model_name
+    kw.update(NAME_OVERRIDES.get(model_name, {}))
     kw.update(overrides)
     return HookedViTConfig(**kw, dtype=dtype, device=device)
 

@@ -41,6 +41,7 @@ class VisionActivationsStore:
         self.model = model.to(cfg.device)
         self.dataset = dataset
         self.n_tokens_harvested = 0                          # rows written into buffers so far (bench: harvested / trained)
+        self.n_buffer_copies = 0                             # `buf[...] = acts` passes taken (0 while the producing kernel writes the rows itself)
         # The next refill's ViT forwards do not depend on the SAE being trained: on a GPU they are issued on a side stream as
         # soon as the current half buffer is being served and overlap the train steps (whose many small kernels leave most of
         # the chip idle); the refill then only waits for an event.  Same images, same order, same random permutations drawn
@@ -119,7 +120,9 @@ class VisionActivationsStore:
                 if cfg.cls_token_only:
                     a = a[:, 0:1]
                 acts.append(a)
-            return torch.stack(acts, dim=2)
+            if len(acts) == 1:
+                return acts[0].unsqueeze(2)                   # (a view: torch.stack would copy -- and hide from _harvest_raw that the kernel
+            return torch.stack(acts, dim=2)                   #  already wrote these rows into the buffer slice)
 
         if cfg.is_transcoder:
             return pick(names), pick(out_names)
@@ -195,6 +198,7 @@ class VisionActivationsStore:
                 # context_size, any other token-count mismatch raises.  Skipped when the kernel already stored the rows here.
                 if not (native and acts.data_ptr() == dst.data_ptr() and acts.dtype == dst.dtype and acts.shape == dst.shape):
                     dst[...] = acts
+                    self.n_buffer_copies += 1
                 self.n_tokens_harvested += rows * ctx
                 start += rows
         finally:

@@ -79,7 +79,14 @@ class HookedSAEViT(HookedViT):
             setattr(parent, leaf, prev_sae)
             self.acts_to_saes[act_name] = prev_sae
         else:
-            setattr(parent, leaf, self._original_hook_points.get(act_name) or HookPoint())
+            hp = self._original_hook_points.get(act_name) or HookPoint()
+            # the reference installs a FRESH HookPoint() here (base_vit.py:903): hooks that sat on the point before the splice --
+            # permanent ones included -- are gone afterwards.  The original object comes back (the tree the HIP plan was built
+            # for), stripped the same way.
+            hp.remove_hooks("fwd", including_permanent=True)
+            hp.remove_hooks("bwd", including_permanent=True)
+            hp.clear_context()
+            setattr(parent, leaf, hp)
             del self.acts_to_saes[act_name]
 
     def reset_saes(self, act_names: Optional[Union[str, Sequence[str]]] = None,
@@ -101,7 +108,8 @@ class HookedSAEViT(HookedViT):
     def setup(self) -> None:
         super().setup()
         # the HookPoint objects this model was built with: reset_saes puts THEM back (the reference installs a fresh HookPoint(),
-        # base_vit.py:903 -- observationally the same, and here the restored tree is again the one the HIP plan was built for)
+        # base_vit.py:903; _reset_sae strips the restored object of its hooks so that it behaves like one -- and here the restored tree is again the
+        # one the HIP plan was built for)
         if not hasattr(self, "_original_hook_points"):
             self._original_hook_points = dict(self.hook_dict)
 

@@ -537,7 +537,12 @@ class HookedViT(HookedRootModule):
                 continue
             kind, off = self._KIND_POS[m.group(2)]
             pos = self._NPOS * int(m.group(1)) + off
-            if pos == 0 or kind.startswith("ln"):
+            # (a splice on the tensor a flag-gated point is derived from -- the block input under use_attn_in / use_split_qkv_input,
+            # z under use_attn_result, resid_mid under use_hook_mlp_in: that point then sees the MODULE's output, which no tap holds;
+            # the block runs on its own module and records its flag-gated points itself)
+            feeds_flag_point = {"pre": self.cfg.use_attn_in or self.cfg.use_split_qkv_input, "z": self.cfg.use_attn_result,
+                                "mid": self.cfg.use_hook_mlp_in}.get(kind, False)
+            if pos == 0 or kind.startswith("ln") or feeds_flag_point:
                 out.setdefault(self._TORCH_POS, {})[int(m.group(1))] = True
                 continue
             out.setdefault(pos, {})[kind] = mod
@@ -632,7 +637,9 @@ class HookedViT(HookedRootModule):
         -- and their cache entries are derived afterwards from what the plan tapped (transformer_block.py:88-129,
         attention.py:155-183): hook_attn_in / hook_q_input / k / v = the block input with a head dimension (a stride-0 view: the
         reference materialises H copies), ln1's two points carry that head dimension too, attn.hook_result = z against W_O per head
-        (one einsum per layer), hook_mlp_in = hook_resid_mid.  A forward hook ON such a point changes that block's forward: the block
+        (one einsum per layer), hook_mlp_in = a copy of hook_resid_mid.  The head-dimension entries are stride-0 ``expand`` views of the
+        tensor they come from (the reference holds H copies: 12x the bytes at B/32): an in-place write into one raises torch's
+        overlapping-memory error instead of silently reaching its siblings -- ``.clone()`` it first.  A forward hook ON such a point changes that block's forward: the block
         runs on its own PyTorch module (_run_blocks_mixed), the others stay on the plan."""
         cfg = self.cfg
         if not (cfg.use_attn_in or cfg.use_split_qkv_input or cfg.use_attn_result or cfg.use_hook_mlp_in):
@@ -640,7 +647,12 @@ class HookedViT(HookedRootModule):
         keep = names_filter_to_fn(names_filter)
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
-        wanted = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
+        # (modules spliced in place of HookPoints: their own HookPoints stand where the replaced point stood, as in _run_with_cache_plan)
+        spliced = self._spliced()
+        expanded: List[str] = []
+        for n in hook_order(cfg, n_blocks, run_head):
+            expanded += [k for k in self.hook_dict if k.startswith(n + ".")] if n in spliced else [n]
+        wanted = [n for n in expanded if keep(n)]
         source = {"hook_attn_in": "hook_resid_pre", "hook_q_input": "hook_resid_pre", "hook_k_input": "hook_resid_pre",
                   "hook_v_input": "hook_resid_pre", "attn.hook_result": "attn.hook_z", "hook_mlp_in": "hook_resid_mid"}
 
@@ -665,13 +677,17 @@ class HookedViT(HookedRootModule):
             if n in got and rest in FLAG_POINTS:
                 t = got[n]
             elif rest in FLAG_POINTS:
-                src = got[pre + source[rest]]
+                src = got.get(pre + source[rest])
+                if src is None:
+                    continue                                      # (behind stop_at_layer)
                 if rest == "attn.hook_result":
                     t = torch.einsum("bphd,hdm->bphm", src, self.blocks[int(pre.split(".")[1])].attn.W_O)
                 elif rest == "hook_mlp_in":
-                    t = src
+                    t = src.clone()                               # (its own storage, like the reference's: an in-place edit of one entry must not reach hook_resid_mid)
                 else:
                     t = src.unsqueeze(2).expand(-1, -1, H, -1)
+            elif n not in got:
+                continue                                          # (a spliced module behind stop_at_layer never ran)
             elif headed and rest in ("ln1.hook_scale", "ln1.hook_normalized") and got[n].ndim == 3:
                 t = got[n].unsqueeze(2).expand(-1, -1, H, -1)
             else:
