@@ -43,8 +43,9 @@ extern "C" {
 #define PV_ACT_RELU 2
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
- * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*). */
-#define PV_ABI_VERSION 16
+ * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
+ * gemm_persist / gemm_stagger tuning keys). */
+#define PV_ABI_VERSION 17
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -235,6 +236,18 @@ int pv_vit_forward_stage(pv_vit_plan* plan, const void* images, const void* resi
 int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const void* Bt, int64_t ldb,
                  const void* bias, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                  void* stream);
+/* The same product with one of the forward's fused epilogues (kernel-level tests and A/B timings of the epilogues the ViT plan uses;
+ * models/layers/attention.py:186-244, mlp.py:65-80, transformer_block.py:122-134):
+ *   epi 0 (bias):      out0 = acc + bias
+ *   epi 2 (residual):  t = round_T(acc + bias); out0 (may be NULL) = t; out1 = t + resid
+ *   epi 3 (activation): t = round_T(acc + bias); out0 (may be NULL) = t; out1 = act(t)         (act = PV_ACT_*)
+ * A [M, K] (lda), Bt [N, K] (ldb), bias [N], resid [M, ldr], outputs [M, ldo]; all of dtype T. */
+#define PV_GEMM_EPI_BIAS 0
+#define PV_GEMM_EPI_RESID 2
+#define PV_GEMM_EPI_ACT 3
+int pv_gemm_epilogue(int32_t dtype, int32_t epi, int32_t act, const void* A, int64_t lda, const void* Bt, int64_t ldb,
+                     const void* bias, const void* resid, int64_t ldr, void* out0, void* out1, int64_t ldo,
+                     int32_t M, int32_t N, int32_t K, void* stream);
 /* out[b][c][r] = in[b][r][c], element size 2 or 4 bytes. */
 int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t batch, int32_t R,
                          int32_t C, void* stream);
@@ -262,7 +275,8 @@ int pv_debug_gemm_trace_read(uint64_t* host_out, int32_t max_wg, int32_t* info6)
 /* Debug only (tests, A/B measurements): kernel-choice overrides.  The launch path never reads the environment;
  * these process-global switches are the only way to force a kernel.  Keys: "gemm_tile" (-1 auto, 0 = 128 x 128,
  * 4 / 5 = one-workgroup-per-CU 256 / 320 x 256), "gemm_v1", "gemm_v1patch", "attn_wg", "prof_markers", "sae_exact",
- * "gemm_dbg" (ablations, -DPV_TUNING builds only); key "reset" restores every default.
+ * "gemm_dbg" (ablations, -DPV_TUNING builds only), "gemm_loop", "gemm_persist" (-1 auto / 0 never / 1 wherever legal: the persistent
+ * form of the one-workgroup-per-CU GEMM), "gemm_stagger" (its start-skew A/B knob); key "reset" restores every default.
  * pv_debug_get_tuning("any") = 1 when anything is overridden: bench.py records it and refuses to measure then. */
 int pv_debug_set_tuning(const char* key, int32_t value);
 int pv_debug_get_tuning(const char* key, int32_t* value);

@@ -16,6 +16,9 @@ model = model.to(torch.bfloat16).to(dev).eval().use_native(True)
 BS = int(os.environ.get('BS', '512'))
 images = torch.randn(BS, 3, 224, 224, device=dev).bfloat16()
 L = N.lib()
+if os.environ.get('PV_PERSIST') is not None:
+    N.set_tuning('gemm_persist', int(os.environ['PV_PERSIST']))
+    print('gemm_persist =', os.environ['PV_PERSIST'])
 L.pv_debug_gemm_trace_arm.argtypes = [ctypes.c_int32]
 L.pv_debug_gemm_trace_read.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
 with torch.no_grad():

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -97,7 +97,7 @@ _lib: Optional[C.CDLL] = None
 EXPORTS = [
     "pv_abi_version", "pv_build_id", "pv_last_error",
     "pv_vit_plan_create", "pv_vit_plan_destroy", "pv_vit_shadow_bytes", "pv_vit_plan_set_weights",
-    "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_vit_forward_stage", "pv_gemm_bias", "pv_transpose_batched",
+    "pv_vit_workspace_bytes", "pv_vit_forward", "pv_vit_forward_from", "pv_vit_forward_seg", "pv_vit_forward_stage", "pv_gemm_bias", "pv_gemm_epilogue", "pv_transpose_batched",
     "pv_prof_enable", "pv_prof_reset", "pv_prof_read", "pv_prof_read_tag",
     "pv_sae_plan_create", "pv_sae_plan_destroy", "pv_sae_workspace_bytes", "pv_sae_renorm_decoder",
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
@@ -149,6 +149,7 @@ def lib() -> C.CDLL:
     L.pv_vit_forward_seg.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_vit_forward_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(Tap), i32, vp, sz, vp, vp]
     L.pv_gemm_bias.argtypes = [i32, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, vp]
+    L.pv_gemm_epilogue.argtypes = [i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, vp]
     L.pv_transpose_batched.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     L.pv_prof_enable.argtypes = [i32]
     L.pv_prof_read.argtypes = [i32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),

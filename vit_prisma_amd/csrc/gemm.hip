@@ -1180,6 +1180,281 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v7(const GemmParams p) {
     trace_stamp(p.trace, bid, 2);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// v8: the v7 full-line kernel made PERSISTENT.  One 512-thread workgroup per CU walks its tiles (virtual block ids bid,
+// bid + grid, ...: the same XCD-aware tile order as v7) and the K slabs of consecutive tiles form ONE stream through the
+// two-slot ring: the prefetches v7 issues off the end of its K loop (dead DMAs there) are the NEXT tile's first slab and the
+// A pieces of its second, so a tile's store epilogue runs with the next tile's operands already in LDS / in flight, the
+// next K loop starts without a launch, a DMA prologue or a drained store queue in front of it, and the workgroups of a
+// launch drift apart instead of computing together and then storing together (profiles/r02_gemm_phase_trace.txt).
+//   * what changes against v7 LP == 2: the epilogue's transposition no longer borrows the ring (it holds the next tile's
+//     slab): 2 KB per wave of dedicated LDS (the 16 KB the two 72 KB slots leave), 8 rows per pass instead of 32;
+//     no workgroup barrier and no vmcnt(0) between K loop and epilogue; slab indices past the tile's end address the next
+//     tile (selects on a uniform condition: no branch around an LDS-DMA)
+//   * the MFMA / fragment-read / DMA-issue order inside the K loop is v7's, and so is the k order of every output's fp32 sum:
+//     results are bit-identical to v7's
+//   * legal where v7's full-line loop is: plain A operand, K a whole EVEN number of 128-byte slabs (the two slots alternate
+//     per slab: an odd count would swap their roles from tile to tile)
+// ---------------------------------------------------------------------------------------------------
+// the lane id, computed where it is asked for (asm volatile: neither hoisted nor merged with an earlier copy) -- what the epilogue of
+// the persistent kernel derives its addresses from, so that none of them lives through the K loop
+__device__ __forceinline__ int lane_id_here() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <typename T, int MB, int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v8(const GemmParams p, const int ntiles, const int stagger) {
+    static_assert(sizeof(T) == 2, "v8 is a bf16 kernel");
+    constexpr int TM = 64 * MB;
+    constexpr int TN = 256;
+    constexpr int A2 = TM * 128, B2 = TN * 128, SLOT2 = A2 + B2;      // one slot: (TM + TN) rows x 128 bytes of K
+    constexpr int STAGE = 8 * 2048;                                   // epilogue transposition: 8 rows x 64 fp32 per wave
+    static_assert(MB >= 4, "four B pieces ride on the first k-step's MFMA pairs");
+    static_assert(2 * SLOT2 + STAGE <= 160 * 1024, "one workgroup per CU");
+    // four LDS objects (A / B part of either slot: hipcc's alias scopes are per object -- gemm_kernel_v4), laid out A0 | A1 | B0 | B1 so
+    // that the two slots of an operand sit within one 16-bit ds_read offset of each other: ONE address register per k-step and
+    // operand serves both slots (8 registers instead of 16; the loop body runs at the 256-register limit)
+    __shared__ __attribute__((aligned(16))) unsigned char ringA0[A2];
+    __shared__ __attribute__((aligned(16))) unsigned char ringA1[A2];
+    __shared__ __attribute__((aligned(16))) unsigned char ringB0[B2];
+    __shared__ __attribute__((aligned(16))) unsigned char ringB1[B2];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[STAGE];
+    constexpr int EB = 2;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
+    const int nblk = (ntn + 7) / 8;
+    const int wblk = (ntn + nblk - 1) / nblk;
+    // virtual block id -> tile origin (v7's mapping with the virtual grid size: bid and bid + k * gridDim.x sit on the same XCD)
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        const int blk = swz / (ntm * wblk);
+        const int rem = swz - blk * (ntm * wblk);
+        const int wcur = min(wblk, ntn - blk * wblk);
+        const int tile_m = rem / wcur;
+        m0 = tile_m * TM;
+        n0 = (blk * wblk + (rem - tile_m * wcur)) * TN;
+    };
+    const unsigned Kb = (unsigned)p.K * EB;
+    const int nk2 = (int)(Kb / 128);
+    const unsigned ldaB = (unsigned)p.lda * EB, ldbB = (unsigned)p.ldb * EB;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((unsigned)p.M * ldaB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bt), 0, (int)((unsigned)p.N * ldbB), 0x00020000);
+
+    // DMA pieces (1 KiB = 8 rows x 128 B): per-lane part of the source offset; the tile's origin and the slab are uniform terms
+    const int prow = lane >> 3;
+    const int psw = ((lane >> 4) + 4 * (wave & 1)) & 7;            // (row >> 1) & 7 of the piece row this lane fetches
+    const unsigned pcol = (unsigned)(((lane & 7) ^ psw) * 16);
+    const unsigned lpA = (unsigned)(wave * 8 + prow) * ldaB + pcol;
+    const unsigned lpB = (unsigned)(wave * 8 + prow) * ldbB + pcol;
+    const unsigned strideA = 64u * ldaB, strideB = 64u * ldbB;
+    unsigned uA, uB, uAn = 0, uBn = 0;                              // this tile's / the next tile's uniform origin terms
+    bool dead_n = true;
+    // piece j of slab s (s >= nk2: slab s - nk2 of the NEXT tile) into `slot`
+    auto issue_piece = [&](int s, unsigned char* slotA, unsigned char* slotB, int j) {
+        const bool nx = s >= nk2;
+        const unsigned sb = (unsigned)(nx ? s - nk2 : s) * 128u;
+        const bool dead = nx & dead_n;
+        if (j < MB) {
+            unsigned o = lpA + ((nx ? uAn : uA) + (unsigned)j * strideA + sb);
+            o = dead ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(slotA + (j * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        } else {
+            const int jb = j - MB;
+            unsigned o = lpB + ((nx ? uBn : uB) + (unsigned)jb * strideB + sb);
+            o = dead ? 0xffffff00u : o;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(slotB + (jb * 8 + wave) * 1024), 16, o, 0, 0, 0);
+        }
+    };
+    const int fsw = (l31 >> 1) & 7;
+    const int a_row2 = (wm * 32 * MB + l31) * 128, b_row2 = (wn * 64 + l31) * 128;
+    int fco[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) fco[h] = ((2 * h + half) ^ fsw) * 16;
+    auto rdA2 = [&](const unsigned char* slotA, int h, int mi) {
+        return *reinterpret_cast<const uint4*>(slotA + a_row2 + mi * 4096 + fco[h]);
+    };
+    auto rdB2 = [&](const unsigned char* slotB, int h, int ni) {
+        return *reinterpret_cast<const uint4*>(slotB + b_row2 + ni * 4096 + fco[h]);
+    };
+
+    f32x16 acc[MB][2];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+#define PV_V8_PAIR(MI, H)                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
+        acc[MI][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                \
+            __builtin_bit_cast(bf16x8, fa[MI]), __builtin_bit_cast(bf16x8, fb[(H) & 1][ni]), acc[MI][ni], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+    // slab KT in CUR (visible), slab KT+1 arriving in NXT; fa / fb[0] hold k-step 0 of slab KT (v7's PV_V7_FSTEP)
+#define PV_V8_FSTEP(KT, CA, CB, NA, NB)                                                                       \
+    _Pragma("unroll") for (int h = 0; h < 4; ++h) {                                                           \
+        if (h == 3) {                                                                                         \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                               \
+            __builtin_amdgcn_s_barrier();                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < MB; ++mi) {                                                   \
+            PV_V8_PAIR(mi, h)                                                                                 \
+            fa[mi] = h < 3 ? rdA2(CA, h < 3 ? h + 1 : 0, mi) : rdA2(NA, 0, mi);                               \
+            if (mi == 1) {                                                                                    \
+                fb[(h + 1) & 1][0] = h < 3 ? rdB2(CB, h < 3 ? h + 1 : 0, 0) : rdB2(NB, 0, 0);                 \
+                fb[(h + 1) & 1][1] = h < 3 ? rdB2(CB, h < 3 ? h + 1 : 0, 1) : rdB2(NB, 0, 1);                 \
+            }                                                                                                 \
+            if (h == 3) issue_piece((KT) + 2, CA, CB, mi);                                                    \
+            if (h == 0 && mi < 4) issue_piece((KT) + 1, NA, NB, MB + mi);                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                     \
+    }
+#define PV_V8_EVEN(KT) PV_V8_FSTEP(KT, ringA0, ringB0, ringA1, ringB1)
+#define PV_V8_ODD(KT) PV_V8_FSTEP(KT, ringA1, ringB1, ringA0, ringB0)
+
+    int vb = blockIdx.x;
+    int m0, n0;
+    tile_of(vb, m0, n0);
+    uA = (unsigned)m0 * ldaB; uB = (unsigned)n0 * ldbB;
+    if (stagger > 0) {
+        // (A/B knob: workgroups of a launch start a fraction of a tile apart -- see profiles/r05_notes.md)
+        const int k = ((blockIdx.x >> 3) & 3) * stagger;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    trace_stamp(p.trace, vb, 0);
+    // the stream's head: slab 0 of the first tile entirely, the A pieces of its slab 1, k-step 0's fragments
+#pragma unroll
+    for (int j = 0; j < (MB + 4); ++j) issue_piece(0, ringA0, ringB0, j);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < MB; ++j) issue_piece(1, ringA1, ringB1, j);
+
+    for (;;) {
+        const int vbn = vb + (int)gridDim.x;
+        const bool has_next = vbn < ntiles;
+        int m0n = 0, n0n = 0;
+        if (has_next) tile_of(vbn, m0n, n0n);
+        uAn = (unsigned)m0n * ldaB; uBn = (unsigned)n0n * ldbB;
+        dead_n = !has_next;
+
+        // epilogue operands of THIS tile in flight under its K loop (v7): bias chunk + residual rows of block 0.  Only the loaded
+        // registers live through the loop; every address is recomputed behind it (the loop body runs at the register limit).
+        uint4 e_bias = make_uint4(0, 0, 0, 0);
+        constexpr int NRES = EPI == PV_EPI_RESID ? MB : 1;
+        uint4 e_res[NRES][4];
+#pragma unroll
+        for (int mi = 0; mi < NRES; ++mi)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) e_res[mi][it] = make_uint4(0, 0, 0, 0);
+#define PV_V8_EPI_GEOMETRY()                                                                                          \
+        const int e_lane = lane_id_here();                                                                            \
+        const int e_gn = n0 + wn * 64 + (e_lane & 7) * 8;                                                             \
+        const bool e_live = e_gn < p.N;                                                                               \
+        const int e_rows_left = e_live ? p.M - (m0 + wm * 32 * MB + (e_lane >> 3)) : 0;                               \
+        int e_col = e_gn;                                                                                             \
+        T* e_out0 = reinterpret_cast<T*>(p.out0);                                                                     \
+        const T* e_biasp = reinterpret_cast<const T*>(p.bias0);                                                       \
+        if constexpr (EPI == PV_EPI_QKV) {                                                                            \
+            const int which = e_gn / p.nsplit;                                                                        \
+            e_col = e_gn - which * p.nsplit;                                                                          \
+            if (which == 1) { e_out0 = reinterpret_cast<T*>(p.out1); e_biasp = reinterpret_cast<const T*>(p.bias1); } \
+            if (which == 2) { e_out0 = reinterpret_cast<T*>(p.out2); e_biasp = reinterpret_cast<const T*>(p.bias2); } \
+        }                                                                                                             \
+        const T* e_rbase = reinterpret_cast<const T*>(p.resid) + (int64_t)(m0 + wm * 32 * MB + (e_lane >> 3)) * p.ldr + e_gn;
+#define PV_V8_FETCH_RES(MI)                                                                          \
+        if constexpr (EPI == PV_EPI_RESID) {                                                         \
+            _Pragma("unroll") for (int it = 0; it < 4; ++it)                                         \
+                if ((MI) * 32 + it * 8 < e_rows_left)                                                \
+                    e_res[MI][it] = *reinterpret_cast<const uint4*>(e_rbase + (int64_t)((MI) * 32 + it * 8) * p.ldr); \
+        }
+        // k-step 0's fragments of the tile's first slab (visible since the last barrier of the previous tile's loop; that loop's
+        // last refills fetched the same values, but carrying 36 registers across the epilogue costs the loop body spills)
+        uint4 fa[MB], fb[2][2];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) fa[mi] = rdA2(ringA0, 0, mi);
+        fb[0][0] = rdB2(ringB0, 0, 0); fb[0][1] = rdB2(ringB0, 0, 1);
+        int kt = 0;
+        do {                                                       // (nk2 >= 2 and even: the launcher's condition)
+            PV_V8_EVEN(kt)
+            if (kt == 0) {
+                // The epilogue's operands are fetched HERE -- inside the loop, behind the first slab's wait (which also covered the
+                // previous tile's stores) and in front of the second's, which retires them: hipcc then knows them landed when the
+                // epilogue reads them.  Fetched in front of the loop, their first use behind it (the next tile's pieces in flight)
+                // is answered with a vmcnt(0); named as used inside the loop, the queue is flushed in the loop's preheader.
+                PV_V8_EPI_GEOMETRY()
+                (void)e_out0;
+                if (e_live && e_biasp) e_bias = *reinterpret_cast<const uint4*>(e_biasp + e_col);
+                if constexpr (MB < 5) { PV_V8_FETCH_RES(0) }        // (MB = 5: sixteen more registers through the loop body spill)
+            }
+            PV_V8_ODD(kt + 1)
+            kt += 2;
+        } while (kt + 2 <= nk2);
+        trace_stamp(p.trace, vb, 1);
+
+        // ---- store epilogue: 8 rows x 64 columns per pass through the wave's own 2 KB (the ring holds the next tile)
+        PV_V8_EPI_GEOMETRY()
+        (void)e_biasp;
+        const pv_f32x2 e_b[4] = {unpack2(e_bias.x), unpack2(e_bias.y), unpack2(e_bias.z), unpack2(e_bias.w)};
+        const int64_t e_row0 = (int64_t)(m0 + wm * 32 * MB + (e_lane >> 3)) * p.ldo;
+        T* const o0_base = e_out0 ? e_out0 + e_row0 + e_col : nullptr;
+        T* const o1_base = reinterpret_cast<T*>(p.out1) + e_row0 + e_gn;
+        float* const Cs = reinterpret_cast<float*>(stage + wave * 2048);
+        const float* const Cr = Cs + (e_lane >> 3) * 64 + (e_lane & 7) * 8;
+        float* const Cw = Cs + (e_lane >> 5) * 256 + (e_lane & 31);
+        if constexpr (MB >= 5) { PV_V8_FETCH_RES(0) }
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        Cw[j * 64 + ni * 32] = acc[mi][ni][4 * it + j];
+                __builtin_amdgcn_wave_barrier();
+                if (it == 0) {
+                    // residual rows two blocks ahead, as v7
+                    if (2 * mi + 1 < MB) { PV_V8_FETCH_RES((2 * mi + 1 < MB ? 2 * mi + 1 : 0)) }
+                    if (2 * mi + 2 < MB) { PV_V8_FETCH_RES((2 * mi + 2 < MB ? 2 * mi + 2 : 0)) }
+                }
+                if (mi * 32 + it * 8 < e_rows_left) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(Cr);
+                    const float4 x1 = *reinterpret_cast<const float4*>(Cr + 4);
+                    const int64_t ro = (int64_t)(mi * 32 + it * 8) * p.ldo;
+                    epi8_bf16<EPI, ACT>(x0, x1, e_b, o0_base ? o0_base + ro : nullptr, o1_base + ro,
+                                        e_res[EPI == PV_EPI_RESID ? mi : 0][it]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#undef PV_V8_EPI_GEOMETRY
+#undef PV_V8_FETCH_RES
+        trace_stamp(p.trace, vb, 2);
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        vb = vbn; m0 = m0n; n0 = n0n; uA = uAn; uB = uBn;
+        trace_stamp(p.trace, vb, 0);
+    }
+#undef PV_V8_EVEN
+#undef PV_V8_ODD
+#undef PV_V8_FSTEP
+#undef PV_V8_PAIR
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // the dead prefetches behind the last tile must land before the LDS is handed on
+}
+
 template <typename T, int MB>
 int launch_v7(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + 64 * MB - 1) / (64 * MB), ntn = (p.N + 255) / 256;
@@ -1197,10 +1472,31 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         int loop_sel = 0;
         if (p.a_mode == PV_A_PLAIN && kbytes % 64 == 0 && g_pv_tuning.gemm_loop != 0)
             loop_sel = (kbytes % 128 == 0 && g_pv_tuning.gemm_loop != 1) ? 2 : 1;
+        // persistent form (v8): the full-line loop's shapes with an even slab count, when the launch has more tiles than CUs
+        // (gemm_persist: -1 auto, 0 never, 1 wherever legal)
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+            n_cu -= n_cu % 8;                                   // (a multiple of the XCD count: bid and bid + grid on one XCD)
+            if (n_cu <= 0) n_cu = 8;
+        }
+        const int ntiles = ntm * ntn;
+        const bool persist = loop_sel == 2 && (kbytes / 128) % 2 == 0 && g_pv_tuning.gemm_persist != 0 &&
+                             (g_pv_tuning.gemm_persist > 0 || ntiles > n_cu);
+        const dim3 pgrid(ntiles < n_cu ? ntiles : n_cu);
+        const int stagger = g_pv_tuning.gemm_stagger;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         const bool timed = !g_pv_tuning.prof_markers &&
                            pv_prof_events(PV_PROF_GEMM, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd, &ev0, &ev1);
         ProfScope prof(timed ? PV_PROF__COUNT : PV_PROF_GEMM, stream, 2.0 * mn * p.K, ((double)p.M * p.K + (double)p.N * p.K + outs * mn) * EBd);
+#define PV_V8_LAUNCH(EPI, ACT)                                                                                                   \
+    do {                                                                                                                         \
+        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v8<T, MB, EPI, ACT>), pgrid, block, 0, stream, ev0, ev1, 0, p, ntiles, stagger); \
+        else hipLaunchKernelGGL((gemm_kernel_v8<T, MB, EPI, ACT>), pgrid, block, 0, stream, p, ntiles, stagger);                  \
+    } while (0)
 #define PV_V7_LAUNCH_LP(EPI, ACT, LP)                                                                                   \
     do {                                                                                                                \
         if (timed) hipExtLaunchKernelGGL((gemm_kernel_v7<T, MB, EPI, ACT, LP>), grid, block, 0, stream, ev0, ev1, 0, p); \
@@ -1208,7 +1504,8 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
     } while (0)
 #define PV_V7_LAUNCH(EPI, ACT)                                                   \
     do {                                                                         \
-        if (loop_sel == 2) PV_V7_LAUNCH_LP(EPI, ACT, 2);                         \
+        if (persist) PV_V8_LAUNCH(EPI, ACT);                                     \
+        else if (loop_sel == 2) PV_V7_LAUNCH_LP(EPI, ACT, 2);                    \
         else if (loop_sel) PV_V7_LAUNCH_LP(EPI, ACT, 1);                         \
         else PV_V7_LAUNCH_LP(EPI, ACT, 0);                                       \
     } while (0)
@@ -1220,6 +1517,7 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
         else PV_V7_LAUNCH(PV_EPI_ACT, PV_ACT_RELU);
 #undef PV_V7_LAUNCH
 #undef PV_V7_LAUNCH_LP
+#undef PV_V8_LAUNCH
     }
     PV_LAUNCH_CHECK("gemm_kernel_v7");
     return PV_OK;

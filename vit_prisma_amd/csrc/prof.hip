@@ -139,6 +139,8 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "enc_rounds")) return &g_pv_tuning.enc_rounds;
     if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
     if (!strcmp(key, "gemm_loop")) return &g_pv_tuning.gemm_loop;
+    if (!strcmp(key, "gemm_persist")) return &g_pv_tuning.gemm_persist;
+    if (!strcmp(key, "gemm_stagger")) return &g_pv_tuning.gemm_stagger;
     return nullptr;
 }
 }  // namespace
@@ -164,7 +166,8 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
         const PvTuning d;
         const PvTuning& t = g_pv_tuning;
         *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct ||
-                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.gemm_dbg != d.gemm_dbg || t.gemm_loop != d.gemm_loop) ? 1 : 0;
+                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.enc_rounds != d.enc_rounds || t.gemm_dbg != d.gemm_dbg ||
+                  t.gemm_loop != d.gemm_loop || t.gemm_persist != d.gemm_persist || t.gemm_stagger != d.gemm_stagger) ? 1 : 0;
         return PV_OK;
     }
     const int* f = tuning_field(key);

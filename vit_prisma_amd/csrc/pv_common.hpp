@@ -176,6 +176,9 @@ struct PvTuning {
                              // slabs, two slots) where K is a whole number of 128-byte slabs, else the pipelined 64-byte-slab form,
                              // else (patch gather, K tails) the barrier-then-fetch loop; 0 = barrier-then-fetch everywhere;
                              // 1 = pipelined 64-byte slabs where legal; 2 = as auto
+    int gemm_persist = -1;   // persistent form of the full-line kernel (one workgroup per CU walks its tiles, the K slabs of consecutive tiles one
+                             // stream): -1 auto = where the launch has more tiles than CUs, 0 = never, 1 = wherever it is legal
+    int gemm_stagger = 0;    // A/B knob of the persistent form: start delay step between workgroups (units of 127 x 64 clocks), 0 = none
 };
 extern PvTuning g_pv_tuning;
 

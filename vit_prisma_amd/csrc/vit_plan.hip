@@ -536,6 +536,16 @@ extern "C" int pv_gemm_bias(int32_t dtype, const void* A, int64_t lda, const voi
     return pv_launch_gemm(dtype, g, (hipStream_t)stream);
 }
 
+extern "C" int pv_gemm_epilogue(int32_t dtype, int32_t epi, int32_t act, const void* A, int64_t lda, const void* Bt, int64_t ldb,
+                                const void* bias, const void* resid, int64_t ldr, void* out0, void* out1, int64_t ldo,
+                                int32_t M, int32_t N, int32_t K, void* stream) {
+    PV_REQUIRE(epi == PV_GEMM_EPI_BIAS || epi == PV_GEMM_EPI_RESID || epi == PV_GEMM_EPI_ACT, "pv_gemm_epilogue: epi");
+    GemmParams g = {};
+    g.A = A; g.lda = lda; g.a_mode = PV_A_PLAIN; g.Bt = Bt; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.epi = epi; g.act = act; g.bias0 = bias; g.out0 = out0; g.out1 = out1; g.ldo = ldo; g.resid = resid; g.ldr = ldr;
+    return pv_launch_gemm(dtype, g, (hipStream_t)stream);
+}
+
 extern "C" int pv_transpose_batched(int32_t elem_bytes, const void* in, void* out, int32_t batch,
                                     int32_t R, int32_t C, void* stream) {
     PV_REQUIRE(in && out, "null argument");
