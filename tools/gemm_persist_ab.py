@@ -26,7 +26,7 @@ def run(epi, A, B, bias, res, o0, o1, M, Nn, K):
                                o0.data_ptr(), o1.data_ptr() if o1 is not None else None, Nn, M, Nn, K, st), "gemm")
 
 
-variants = [("v7", 0, 0), ("v8", 1, 0), ("v8s1", 1, 1), ("v8s2", 1, 2), ("v8s4", 1, 4)]
+variants = [("v7", 0, 0), ("v8", 1, 0)]            # (name, gemm_persist, gemm_stagger)
 for name, epi, M, Nn, K in shapes:
     A = torch.randn(M, K, device=dev).bfloat16(); B = (torch.randn(Nn, K, device=dev) * 0.05).bfloat16()
     bias = torch.randn(Nn, device=dev).bfloat16()
@@ -70,7 +70,7 @@ model = model.to(torch.bfloat16).to(dev).eval().use_native(True)
 images = torch.randn(512, 3, 224, 224, device=dev).bfloat16()
 ref_cache = None
 with torch.no_grad():
-    for tag, persist, stag in [("auto", -1, 0), ("off", 0, 0), ("all", 1, 0), ("auto", -1, 0), ("off", 0, 0), ("all", 1, 0), ("auto+s2", -1, 2)]:
+    for tag, persist, stag in [("auto", -1, 0), ("off", 0, 0), ("all", 1, 0), ("auto", -1, 0), ("off", 0, 0), ("all", 1, 0)]:
         N.set_tuning("reset"); N.set_tuning("gemm_persist", persist); N.set_tuning("gemm_stagger", stag)
         for _ in range(3):
             out, cache = model.run_with_cache(images)

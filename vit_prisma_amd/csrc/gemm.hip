@@ -1213,9 +1213,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(const GemmParams p, con
     constexpr int STAGE = 8 * 2048;                                   // epilogue transposition: 8 rows x 64 fp32 per wave
     static_assert(MB >= 4, "four B pieces ride on the first k-step's MFMA pairs");
     static_assert(2 * SLOT2 + STAGE <= 160 * 1024, "one workgroup per CU");
-    // four LDS objects (A / B part of either slot: hipcc's alias scopes are per object -- gemm_kernel_v4), laid out A0 | A1 | B0 | B1 so
-    // that the two slots of an operand sit within one 16-bit ds_read offset of each other: ONE address register per k-step and
-    // operand serves both slots (8 registers instead of 16; the loop body runs at the 256-register limit)
+    // four LDS objects, the A / B part of either slot (hipcc's alias scopes are per object -- gemm_kernel_v4: the ds_reads of one slot
+    // must not be taken to alias the DMA writes in flight to the other)
     __shared__ __attribute__((aligned(16))) unsigned char ringA0[A2];
     __shared__ __attribute__((aligned(16))) unsigned char ringA1[A2];
     __shared__ __attribute__((aligned(16))) unsigned char ringB0[B2];
