@@ -74,3 +74,51 @@ model.reset_saes()
 snap("reset")
 np.savez_compressed(os.path.join(HERE, "sae_vit_tiny.npz"), **blob)
 print({k: getattr(v, "shape", None) for k, v in blob.items()})
+
+# ---- round 5: the same at CLIP ViT-B/32 size (bs = 4, fp32): a top-k SAE (768 -> 3072, k = 32) in place of blocks.6.hook_resid_post and a
+# ReLU SAE in place of blocks.3.hook_mlp_out; every cache entry of the reference's run fingerprinted (oracle/vit_oracle.fingerprint)
+#     -> tests/golden/sae_vit_b32_bs4.json
+# (no bf16 budget: the reference's SAE config is fp32 only -- config.py:14-45 -- and a splice in another dtype than the model's takes the
+# PyTorch path here)
+import json
+from oracle.vit_oracle import fingerprint  # noqa: E402
+
+archB = ARCHS["clip-vit-b32"]
+modelB = HookedSAEViT(HookedViTConfig(**archB, dtype=torch.float32, device="cpu"))
+modelB.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(archB, 0).items()}, strict=True)
+modelB.eval()
+xB = torch.from_numpy(synth_images(archB, 4, 1))
+
+
+def make_sae_b(layer, subtype, act, kw, seed):
+    cfg = Cfg(hook_point_layer=layer, layer_subtype=subtype, d_in=archB["d_model"], expansion_factor=4, activation_fn_str=act,
+              activation_fn_kwargs=kw, normalize_activations="layer_norm", initialization_method="independent",
+              b_dec_init_method="mean", _device="cpu", _dtype="float32", log_to_wandb=False, use_ghost_grads=False, verbose=False)
+    sae = SAE(cfg)
+    with torch.no_grad():
+        for name, val in synth_sae_state(archB["d_model"], archB["d_model"] * 4, seed=seed).items():
+            getattr(sae, name).copy_(torch.from_numpy(val))
+    sae.eval()
+    return sae
+
+
+def snap_b():
+    with torch.no_grad():
+        out, cache = modelB.run_with_cache(xB)
+    return {"keys": list(cache.cache_dict.keys()), "out": fingerprint(out.numpy()),
+            "cache": {k: fingerprint(np.ascontiguousarray(v.numpy())) for k, v in cache.cache_dict.items()}}
+
+
+big = {"arch": "clip-vit-b32", "batch": 4, "seed": 1,
+       "saes": [{"layer": 6, "subtype": "hook_resid_post", "act": "topk", "kw": {"k": 32}, "seed": 7},
+                {"layer": 3, "subtype": "hook_mlp_out", "act": "relu", "kw": {}, "seed": 8}]}
+sa = make_sae_b(6, "hook_resid_post", "topk", {"k": 32}, 7)
+sb = make_sae_b(3, "hook_mlp_out", "relu", {}, 8)
+modelB.add_sae(sa)
+big["one"] = snap_b()
+modelB.add_sae(sb)
+big["two"] = snap_b()
+modelB.reset_saes()
+with open(os.path.join(HERE, "sae_vit_b32_bs4.json"), "w") as f:
+    json.dump(big, f)
+print("sae_vit_b32_bs4.json", len(big["one"]["keys"]), len(big["two"]["keys"]), os.path.getsize(os.path.join(HERE, "sae_vit_b32_bs4.json")) // 1024, "kB")

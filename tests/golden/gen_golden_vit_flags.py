@@ -41,3 +41,21 @@ big = {"keys": list(cache.cache_dict.keys()), "out": fingerprint(out.numpy()),
 with open(os.path.join(HERE, "vit_b32_flags_bs2.json"), "w") as f:
     json.dump(big, f)
 print("b32 flags", len(big["keys"]), os.path.getsize(os.path.join(HERE, "vit_b32_flags_bs2.json")) // 1024, "kB")
+
+# ---- round 5: the reference's OWN bf16 run with the four flags against its fp32 run (same images): the per-key error budget the bf16 HIP
+# mode is held to on the flag-gated entries too (as vit_b32_bf16_budget*.json does for the 214 plain entries) -> vit_b32_flags_bf16_budget_bs2.json
+model16, _ = build_reference_model("clip-vit-b32", dtype=torch.bfloat16)
+for k in ("use_attn_result", "use_split_qkv_input", "use_attn_in", "use_hook_mlp_in"):
+    setattr(model16.cfg, k, True)
+out16, cache16 = run_ref(model16, synth_images(arch, 2, 1))
+assert list(cache16.cache_dict.keys()) == big["keys"]
+budget = {}
+for k, v32 in cache.cache_dict.items():
+    a, b_ = v32.double(), cache16.cache_dict[k].double()
+    budget[k] = {"rel_fro": float((a - b_).norm() / a.norm().clamp_min(1e-30)), "dtype_bf16_run": str(cache16.cache_dict[k].dtype)}
+budget["__out__"] = {"rel_fro": float((out.double() - out16.double()).norm() / out.double().norm()), "dtype_bf16_run": str(out16.dtype)}
+with open(os.path.join(HERE, "vit_b32_flags_bf16_budget_bs2.json"), "w") as f:
+    json.dump({"arch": "clip-vit-b32", "batch": 2, "seed": 1, "flags": ["use_attn_result", "use_split_qkv_input", "use_attn_in", "use_hook_mlp_in"],
+               "budget": budget}, f)
+rel = sorted(v["rel_fro"] for v in budget.values())
+print("b32 flags bf16 budget rel_fro min / median / max", rel[0], rel[len(rel) // 2], rel[-1], os.path.getsize(os.path.join(HERE, "vit_b32_flags_bf16_budget_bs2.json")) // 1024, "kB")

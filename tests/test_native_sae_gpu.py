@@ -732,6 +732,38 @@ def test_feature_parallel_simulated_world_equals_single_process_oracle(world, d_
 # ---------------------------------------------------------------------------------------------------
 # (the last four: the shape bench.py times this step at -- 768 -> 24576, 4096 tokens -- and the x64 SAEs every published CLIP-B/32 SAE of
 # the reference is, docs/sae_table.md:12-36 -- 768 -> 49152)
+def fp32_noise_floor(Pc, x, k, ln, dead, l1c=0.0, gate=None):
+    """How far is the fp32 ORACLE itself from the same computation carried in float64?  Per gradient tensor, the rel-Frobenius distance
+    between the oracle's fp32 gradients and its float64 ones (same gates / same top-k sets).  The ghost term puts exp(hidden_pre) of the
+    dead columns into the gradients, which turns the ABSOLUTE fp32 summation noise of hidden_pre into a RELATIVE error of those
+    entries: two correct fp32 implementations differ by this much, whatever their summation orders.  The ghost tests hold the kernels
+    to a multiple of this floor per tensor (ghost_tolerances) instead of a constant argued in a comment (round-4 review).  None when float64 picks another top-k set (a tie within fp32 noise)."""
+    P64 = {kk: v.astype(np.float64) for kk, v in Pc.items()}
+    x64 = x.astype(np.float64)
+    fw32 = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead)
+    fw64 = O.sae_forward(P64, x64, k, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead)
+    if k is not None and not np.array_equal(np.sort(fw32["idx"], axis=1), np.sort(fw64["idx"], axis=1)):
+        return None
+    g = gate if gate is not None else (None if k is not None else fw32["feature_acts"] > 0)
+    kw = {} if k is not None else dict(l1_coefficient=l1c, gate=g)
+    gr32 = O.sae_backward(Pc, x, fw32, layer_norm=ln, **kw)
+    gr64 = O.sae_backward(P64, x64, fw64, layer_norm=ln, **kw)
+    return {name: rel_fro(gr32[name], gr64[name]) for name in gr32}
+
+
+def ghost_tolerances(floor):
+    """name -> min(5e-4, max(TOL, 6 x floor[name])) (and "max": the largest of them); None when no floor could be taken (the caller keeps the old
+    constant).  6 x: numpy's matmul sums in blocks, the MFMA chain of the kernels sums the K = d_in (768) products of an entry in k order --
+    measured on the GPU, the kernels sit at 1.2 ... 3.5 x the oracle's own floor (3.5 x: gW_dec at 768 -> 49152).  The bound so derived is
+    2e-4 ... 5e-4 depending on the shape (5e-4 only without LayerNorm, where |hidden_pre| reaches ~50) and never looser than the constant
+    it replaces."""
+    if floor is None:
+        return None
+    tol = {name: min(5e-4, max(TOL, 6.0 * v)) for name, v in floor.items()}
+    tol["max"] = max(tol.values())
+    return tol
+
+
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("d_in,d_sae,n,ln,ghost", [(64, 512, 256, True, False), (136, 1056, 300, False, False), (768, 8192, 1024, True, False),
                                                    (64, 512, 256, True, True), (136, 1056, 300, False, True), (768, 8192, 1024, True, True),
@@ -786,10 +818,13 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
         assert differs.sum() <= 1e-5 * gate.size and np.all(np.abs(fw["hidden_pre"][differs]) < 1e-5 * np.abs(fw["hidden_pre"]).max())
         if differs.any():
             gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c, gate=gate)
-        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= gtol * grad_norm_of(gr)
-        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < gtol
+        # ghost: per-tensor bounds DERIVED from the oracle's own fp32-vs-float64 distance on this very batch (fp32_noise_floor)
+        gt = ghost_tolerances(fp32_noise_floor(Pc, x, None, ln, dead, l1c, gate if differs.any() else None)) if ghost else None
+        tol_of = (lambda name: gt[name]) if gt else (lambda name: gtol)
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= (gt["max"] if gt else gtol) * grad_norm_of(gr)
+        assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < tol_of("W_enc")
         for name in ("W_dec", "b_enc", "b_dec"):
-            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < gtol, name
+            assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < tol_of(name), name
         if differs.any():
             return                   # (the oracle's own step continued under its own gates: later steps are not comparable)
         fire_ref = stats["act_freq_scores"] - before
@@ -873,10 +908,12 @@ def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
     assert np.array_equal(np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1), np.sort(fw["idx"], axis=1))
     assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
     gtol = 5e-4
-    assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= gtol * grad_norm_of(gr)
-    assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < gtol
+    gt = ghost_tolerances(fp32_noise_floor(Pc, x, k, ln, dead))          # derived per-tensor bounds (None: float64 broke a top-k tie differently)
+    tol_of = (lambda name: gt[name]) if gt else (lambda name: gtol)
+    assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= (gt["max"] if gt else gtol) * grad_norm_of(gr)
+    assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < tol_of("W_enc")
     for name in ("W_dec", "b_enc", "b_dec"):
-        assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < gtol, name
+        assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < tol_of(name), name
     # the live features' rows are what the plain top-k step gives them (the ghost term reaches dead features only)
     live = ~dead
     assert rel_fro(eng.g["W_dec"].cpu().numpy()[live], gr["W_dec"][live]) < TOL

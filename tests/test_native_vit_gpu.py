@@ -962,6 +962,54 @@ def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
     model.reset_saes()
 
 
+def test_hooked_sae_vit_at_b32_size_vs_reference_fixture():
+    """HookedSAEViT at CLIP ViT-B/32 size (bs = 4, fp32): a top-k SAE (768 -> 3072, k = 32) in place of blocks.6.hook_resid_post, then a ReLU
+    SAE in place of blocks.3.hook_mlp_out as well -- served by the HIP plan (split at the splice, the SAE on its own HIP engine or its
+    hookable forward); every one of the 217 / 220 cache entries and the output against the reference's own run of its class
+    (tests/golden/sae_vit_b32_bs4.json, fingerprints; gen_golden_sae_vit.py).  Round 4 had this on the tiny model only."""
+    from vit_prisma_amd import HookedSAEViT
+    from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig
+    from vit_prisma_amd.synth import synth_sae_state
+    with open(os.path.join(GOLDEN, "sae_vit_b32_bs4.json")) as f:
+        G = json.load(f)
+    arch = ARCHS["clip-vit-b32"]
+    model = HookedSAEViT(HookedViTConfig(**arch, dtype=torch.float32, device="cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model = model.cuda().eval().use_native(True)
+    x = torch.from_numpy(synth_images(arch, G["batch"], G["seed"])).cuda()
+
+    def check(tag):
+        with torch.no_grad():
+            out, cache = model.run_with_cache(x)
+        torch.cuda.synchronize()
+        assert model.last_run_native, model.native_fallback_reason
+        assert list(cache.keys()) == G[tag]["keys"], tag
+        for k in G[tag]["keys"]:
+            want = G[tag]["cache"][k]
+            got = cache[k].float().cpu().numpy()
+            assert list(got.shape) == want["shape"], (tag, k)
+            fp = fingerprint(got)
+            assert abs(fp["l2"] - want["l2"]) <= FP32_TOL * max(want["l2"], 1e-30), (tag, k, fp["l2"], want["l2"])
+            vw = np.array(want["vals"])
+            assert np.max(np.abs(np.array(fp["vals"]) - vw)) <= 1e-3 * max(np.max(np.abs(vw)), want["l2"] / np.sqrt(max(got.size, 1))), (tag, k)
+        fo = fingerprint(out.cpu().numpy())
+        assert abs(fo["l2"] - G[tag]["out"]["l2"]) <= FP32_TOL * G[tag]["out"]["l2"], tag
+
+    for i, (tag, spec) in enumerate(zip(("one", "two"), G["saes"])):
+        cfg = VisionModelSAERunnerConfig(hook_point_layer=spec["layer"], layer_subtype=spec["subtype"], d_in=arch["d_model"], expansion_factor=4,
+                                         activation_fn_str=spec["act"], activation_fn_kwargs=spec["kw"], normalize_activations="layer_norm",
+                                         initialization_method="independent", b_dec_init_method="mean", _device="cuda", _dtype="float32",
+                                         log_to_wandb=False, use_ghost_grads=False, verbose=False)
+        sae = StandardSparseAutoencoder(cfg).cuda().eval()
+        with torch.no_grad():
+            for name, val in synth_sae_state(arch["d_model"], arch["d_model"] * 4, seed=spec["seed"]).items():
+                getattr(sae, name).copy_(torch.from_numpy(val))
+        model.add_sae(sae)
+        check(tag)
+    model.reset_saes()
+    assert model._tree_matches()
+
+
 @pytest.mark.parametrize("tag,flags", [("all", dict(use_attn_result=True, use_split_qkv_input=True, use_attn_in=True, use_hook_mlp_in=True)),
                                        ("result_mlp", dict(use_attn_result=True, use_hook_mlp_in=True))])
 def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
@@ -1004,8 +1052,9 @@ def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_flag_gated_hook_points_at_b32_size_vs_reference_fixture(dtype):
     """The four flags at CLIP ViT-B/32 size (286 cache entries per forward, bs = 2): fp32 against the reference's own run,
-    fingerprinted (tests/golden/vit_b32_flags_bs2.json: key order, shapes, l2, sampled values); bf16: keys / shapes / dtypes, and the
-    derived entries consistent with what they are derived from."""
+    fingerprinted (tests/golden/vit_b32_flags_bs2.json: key order, shapes, l2, sampled values); bf16: keys / shapes / dtypes, every entry
+    held to the reference's own bf16 error with the flags on (vit_b32_flags_bf16_budget_bs2.json), and the derived entries consistent with
+    what they are derived from."""
     with open(os.path.join(GOLDEN, "vit_b32_flags_bs2.json")) as f:
         G = json.load(f)
     arch = ARCHS["clip-vit-b32"]
@@ -1029,6 +1078,42 @@ def test_flag_gated_hook_points_at_b32_size_vs_reference_fixture(dtype):
     if dtype == torch.float32:
         fo = fingerprint(out.cpu().numpy())
         assert abs(fo["l2"] - G["out"]["l2"]) <= FP32_TOL * G["out"]["l2"]
+    else:
+        # bf16: EVERY one of the 286 entries against fp32 truth -- the oracle's 214 plain entries and the flag-gated ones derived from them in
+        # fp32 as the reference's forward defines them (transformer_block.py:88-129, attention.py:155-183) -- held to the error the
+        # REFERENCE's own bf16 run with the four flags has on the same images (tests/golden/vit_b32_flags_bf16_budget_bs2.json, generated by
+        # executing the reference: gen_golden_vit_flags.py).  Round 4 only checked this mode for self-consistency.
+        with open(os.path.join(GOLDEN, "vit_b32_flags_bf16_budget_bs2.json")) as f:
+            B = json.load(f)["budget"]
+        sd = synth_vit_state(arch, 0)
+        o_ref, c_ref = vit_forward(sd, arch, synth_images(arch, 2, 1))
+        Hn = arch["n_heads"]
+        headed = lambda a: np.broadcast_to(a[:, :, None, :], a.shape[:2] + (Hn,) + a.shape[2:])      # noqa: E731
+        bad = []
+        for k in G["keys"]:
+            if k.startswith("blocks."):
+                _, l, rest = k.split(".", 2)
+                pb = f"blocks.{l}."
+                if rest in ("hook_attn_in", "hook_q_input", "hook_k_input", "hook_v_input"):
+                    truth = headed(c_ref[pb + "hook_resid_pre"])
+                elif rest in ("ln1.hook_scale", "ln1.hook_normalized"):
+                    truth = headed(c_ref[k])
+                elif rest == "hook_mlp_in":
+                    truth = c_ref[pb + "hook_resid_mid"]
+                elif rest == "attn.hook_result":
+                    truth = np.einsum("bphd,hdm->bphm", c_ref[pb + "attn.hook_z"].astype(np.float64),
+                                      sd[pb + "attn.W_O"].astype(np.float64)).astype(np.float32)
+                else:
+                    truth = c_ref[k]
+            else:
+                truth = c_ref[k]
+            got = cache[k].float().cpu().numpy()
+            assert got.shape == tuple(truth.shape), k
+            err = rel_fro(got, truth)
+            if err > bf16_limit(k, B[k]["rel_fro"]):
+                bad.append((k, err, B[k]["rel_fro"]))
+        assert not bad, (bad[:8], len(bad))
+        assert rel_fro(out.float().cpu().numpy(), o_ref) <= B["__out__"]["rel_fro"] * BF16_SLACK
     for l in (0, 11):
         p = f"blocks.{l}."
         assert torch.equal(cache[p + "hook_attn_in"], cache[p + "hook_resid_pre"].unsqueeze(2).expand(-1, -1, H, -1))

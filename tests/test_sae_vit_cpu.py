@@ -138,3 +138,40 @@ def test_hooks_registered_before_a_splice_are_gone_after_reset():
         model(x)
     assert fired == [1]
     assert model._tree_matches()
+
+
+@pytest.mark.timeout(600)
+def test_spliced_saes_at_b32_size_match_the_reference_run():
+    """The package's PyTorch path of HookedSAEViT at CLIP ViT-B/32 size (bs = 4, fp32; a top-k SAE in place of blocks.6.hook_resid_post, then a
+    ReLU SAE in place of blocks.3.hook_mlp_out as well) against the reference's own run of its class: key order, shapes and
+    fingerprints of all 217 / 220 cache entries (tests/golden/sae_vit_b32_bs4.json; the GPU suite holds the HIP plan to the same file)."""
+    import json
+    from oracle.vit_oracle import fingerprint
+    with open(os.path.join(GOLDEN, "sae_vit_b32_bs4.json")) as f:
+        G = json.load(f)
+    arch = ARCHS["clip-vit-b32"]
+    model = HookedSAEViT(HookedViTConfig(**arch, dtype=torch.float32, device="cpu"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    model.eval()
+    x = torch.from_numpy(synth_images(arch, G["batch"], G["seed"]))
+    for tag, spec in zip(("one", "two"), G["saes"]):
+        cfg = VisionModelSAERunnerConfig(hook_point_layer=spec["layer"], layer_subtype=spec["subtype"], d_in=arch["d_model"], expansion_factor=4,
+                                         activation_fn_str=spec["act"], activation_fn_kwargs=spec["kw"], normalize_activations="layer_norm",
+                                         initialization_method="independent", b_dec_init_method="mean", _device="cpu", _dtype="float32",
+                                         log_to_wandb=False, use_ghost_grads=False, verbose=False)
+        sae = StandardSparseAutoencoder(cfg)
+        with torch.no_grad():
+            for name, val in synth_sae_state(arch["d_model"], arch["d_model"] * 4, seed=spec["seed"]).items():
+                getattr(sae, name).copy_(torch.from_numpy(val))
+        sae.eval()
+        model.add_sae(sae)
+        with torch.no_grad():
+            out, cache = model.run_with_cache(x)
+        assert list(cache.cache_dict.keys()) == G[tag]["keys"], tag
+        for k in G[tag]["keys"]:
+            want = G[tag]["cache"][k]
+            got = cache[k].numpy()
+            assert list(got.shape) == want["shape"], (tag, k)
+            fp = fingerprint(np.ascontiguousarray(got))
+            assert abs(fp["l2"] - want["l2"]) <= 1e-4 * max(want["l2"], 1e-30), (tag, k)
+        assert abs(fingerprint(out.numpy())["l2"] - G[tag]["out"]["l2"]) <= 1e-4 * G[tag]["out"]["l2"]
