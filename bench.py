@@ -530,6 +530,11 @@ def main():
         if world > 1:
             # SURVEY.md 8(d) config 4 asks for both: strong (global batch 4096, above) and weak (4096 tokens per GPU) scaling
             weak = leg("sae_weak", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=False, weak=True))
+            # ... and the OTHER partitioning of the strong-scaling step beside the one `sae` ran (--sae-parallel feature, the default: features
+            # sharded for good; "data": north_star's -- tokens sharded by image batch, the gradient rows reduce-scattered, the optimizer
+            # sharded): no hardware curve exists for either (profiles/README.md), the first 8-GPU run decides between them
+            torch.cuda.empty_cache()
+            other = leg("sae_other_partitioning", lambda: sae_bench_leg(dev, dist=dist, feature_parallel=not fp))
         else:
             # the ReLU + L1 SAE (every published CLIP SAE of the reference) on the dense fused step
             weak = None
@@ -549,6 +554,7 @@ def main():
             sae["end_to_end"] = e2e
             if weak is not None:
                 sae["weak_scaling_data_parallel"] = weak
+                sae["strong_scaling_data_parallel" if fp else "strong_scaling_feature_parallel"] = other
             else:
                 sae["relu_l1"] = relu
                 if isinstance(relu, dict):
