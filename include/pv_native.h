@@ -45,7 +45,7 @@ extern "C" {
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
  * gemm_persist / gemm_stagger tuning keys). */
-#define PV_ABI_VERSION 17
+#define PV_ABI_VERSION 18
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -525,6 +525,17 @@ int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_
 size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens);
 int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean, int32_t n_global,
                       int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same step, sparse where the batch allows it (as pv_sae_relu_step is to pv_sae_dense_step): a gated SAE's forward and every
+ * gradient behind it vanish where the gate is shut (gate_pre <= 0, sae.py:703-716), so ONE fp16-filtered product over all features
+ * + the exact fp32 re-scoring of its survivors gives each token's OPEN gates as a list of at most sp->cap pairs {feature_acts,
+ * relu(gate_pre)}; the two decoder products, the CSR by feature and the sparse backward then run on the k-sparse kernels over
+ * [feature_acts; relu(gate_pre)] stacked as 2 n_tokens rows -- the dense form's stacking.  A batch some token of which cannot be held
+ * raises the device-side mode word (sp->workspace, as pv_sae_relu_step) and the dense GEMMs run instead; exact fp32 values either
+ * way.  sp->workspace: pv_sae_gated_sparse_workspace_bytes.  Needs the encoder shadows (W_enc16T, enc_colsq) current, else dense. */
+size_t pv_sae_gated_sparse_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap);
+int pv_sae_gated_step_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
+                             int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp, pv_sae_out* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* sum of squares of the flat gradient buffer (all four tensors) -> scalars[3] (device), for
  * clip_grad_norm_ (train_sae.py:394-397); called after the (optional) gradient all-reduce.

@@ -1175,33 +1175,65 @@ def test_transcoder_trainer_runs_natively_and_matches_the_reference_fixture():
 # ---------------------------------------------------------------------------------------------------
 # Gated SAE (sae.py:648-792; pv_sae_gated_step)
 # ---------------------------------------------------------------------------------------------------
+def _shut_gates(P, x, ln, open_max):
+    """b_gate shifted so that no token of batch x has more than open_max gates open (a trained gated SAE: L0 of tens): the regime the
+    sparse form of the step is for."""
+    pre = O.gated_forward({**P, "b_enc": None}, x, layer_norm=ln)["gate_pre"]
+    kth = -np.partition(-pre, open_max, axis=1)[:, open_max]
+    P["b_gate"] = (P["b_gate"] - kth.max()).astype(np.float32)
+
+
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("d_in,d_sae,n,ln", [(64, 512, 256, True), (136, 1056, 300, False), (768, 8192, 1024, True),
-                                             (768, 24576, 4096, True), (768, 49152, 1024, True)])      # (the benchmarked and the published shapes)
-def test_gated_step_vs_oracle(d_in, d_sae, n, ln):
-    """pv_sae_gated_step + grad_sqnorm + apply against the oracle's gated form (pinned to the reference's own
+@pytest.mark.parametrize("d_in,d_sae,n,ln,form", [
+    (64, 512, 256, True, "dense"), (136, 1056, 300, False, "dense"), (768, 8192, 1024, True, "dense"),
+    (768, 24576, 4096, True, "dense"), (768, 49152, 1024, True, "dense"),      # (the benchmarked and the published shapes)
+    # a batch whose gates are mostly shut runs SPARSE (pv_sae_gated_step_sparse; "fallback": the same batch with a capacity it cannot
+    # be held in -- the mode word sends it to the dense GEMMs; "forced": sparse=False)
+    (768, 8192, 1024, True, "sparse"), (256, 2048, 300, False, "sparse"), (768, 24576, 4096, True, "sparse"),
+    (1024, 16384, 512, True, "sparse"), (768, 8192, 1024, True, "fallback"), (768, 8192, 1024, True, "forced")])
+def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
+    """pv_sae_gated_step(_sparse) + grad_sqnorm + apply against the oracle's gated form (pinned to the reference's own
     GatedSparseAutoencoder run by tests/test_oracle_sae_vs_golden.py): the four losses, l0, every gradient tensor, the clip norm,
     parameters and statistics after the optimizer step; ragged shapes and the no-LayerNorm form included."""
     l1c = 3e-3
+    # (Adam's first step moves every weight by lr: at 1e-3 it opens hundreds of gates per token on the second batch)
+    lr = 1e-3 if form == "dense" else 2e-5
     P, opt, stats, T = fresh(d_in, d_sae)
     rs = np.random.RandomState(9)
     for name, scale in (("b_gate", 0.05), ("r_mag", 0.2), ("b_mag", 0.05)):
         P[name] = (rs.standard_normal(d_sae) * scale).astype(np.float32)
         opt["m"][name], opt["v"][name] = np.zeros_like(P[name]), np.zeros_like(P[name])
+    if form != "dense":
+        _shut_gates(P, synth_sae_batch(n, d_in, seed=0), ln, 128)
+    for name in ("b_gate", "r_mag", "b_mag"):
         T[name] = torch.from_numpy(P[name].copy()).cuda()
     b_enc0 = P.pop("b_enc")
     eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, ln, n, gated={m: T[m] for m in ("b_gate", "r_mag", "b_mag")})
+    kw = {"sparse": False} if form == "forced" else ({"cap": 8} if form == "fallback" else {})
     for t in range(2):
         x = synth_sae_batch(n, d_in, seed=t)
         Pc = {kk: v.copy() for kk, v in P.items()}
         O.renorm_decoder(Pc)
         fw = O.gated_forward(Pc, x, layer_norm=ln, l1_coefficient=l1c)
+        if form != "dense":
+            # with tens of open gates per token ONE gate within fp32 summation noise of zero moves the token's reconstruction by percents
+            # (see below): such tokens -- picked by the oracle alone, before the kernel runs -- are replaced by a copy of a safe one, so
+            # that every tensor of the sparse form is compared entry for entry
+            risky = np.abs(fw["gate_pre"]).min(axis=1) < 1e-5 * np.abs(fw["gate_pre"]).max()
+            if risky.any():
+                x[risky] = x[np.flatnonzero(~risky)[0]]
+                fw = O.gated_forward(Pc, x, layer_norm=ln, l1_coefficient=l1c)
         gr = O.gated_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
         before = stats["act_freq_scores"].copy()
-        ref = O.gated_train_step(P, opt, stats, x, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c)
-        eng.gated_step(torch.from_numpy(x).cuda(), l1c, want_out=True)
+        ref = O.gated_train_step(P, opt, stats, x, lr=lr, step=t + 1, layer_norm=ln, l1_coefficient=l1c)
+        eng.gated_step(torch.from_numpy(x).cuda(), l1c, want_out=True, **kw)
         eng.grad_sqnorm()
         torch.cuda.synchronize()
+        if form != "forced":
+            # which form ran: sparse exactly when the filter applies to the shape and every token's open gates fit the capacity
+            open_max = int((fw["gate_pre"] > 0).sum(axis=1).max())
+            assert eng.gated_mode == (0 if form == "sparse" else 1), (form, eng.gated_mode, open_max, float(ref["l0"]))
+            assert (open_max <= 256) == (form != "dense") and (form != "fallback" or open_max > 8)
         sc = eng.scalars.cpu().numpy()
         for slot, key in ((0, "loss"), (1, "mse_loss"), (4, "l1_loss"), (6, "aux_loss"), (2, "l0")):
             assert abs(sc[slot] - ref[key]) <= TOL * abs(ref[key]), (key, sc, ref)
@@ -1233,7 +1265,7 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln):
         assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr)
         fire_ref = stats["act_freq_scores"] - before
         assert np.abs(eng.fire_count.cpu().numpy() - fire_ref).sum() <= TOL * fire_ref.sum()
-        eng.apply(1e-3, 1.0)
+        eng.apply(lr, 1.0)
         torch.cuda.synchronize()
         for name in P:
             assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name

@@ -1524,11 +1524,12 @@ SaeWs sae_carve(const pv_sae_desc& d) {
 }
 
 // The buffers of the sparse ReLU + L1 step that depend on its per-token capacity (pv_sae_relu_step; caller-owned workspace)
-ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap) {
+// (copies = 2: the gated step's lists, every pair held twice -- see sae_gated_sparse)
+ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap, int copies) {
     ReluWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
-    const size_t N = (size_t)n_tokens, P = N * (size_t)cap, ntn = (size_t)(d.d_sae + 255) / 256;
+    const size_t N = (size_t)n_tokens, P = N * (size_t)cap * (size_t)copies, ntn = (size_t)(d.d_sae + 255) / 256;
     w.mode = take(256);
     w.idx = take(P * 4);
     w.val = take(P * 4);
@@ -1825,34 +1826,21 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
     return PV_OK;
 }
 
-// Everything of the k-sparse step behind the selection: decode + LN-out + loss + dY + dh, the CSR by feature, the sparse backward,
-// the bias gradients.  Shared by pv_sae_step (k = the plan's k) and by the sparse form of the ReLU + L1 step (pv_sae_relu_step:
-// k = the per-token capacity, tok_cnt / dh_add / gate as described at sae_decode_kernel; the k-dependent buffers come in through tb).
-int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
-                    const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
-                    const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
-                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
-                    bool bias_grads) {
+// The backward of a k-sparse step behind its decode kernel: the CSR by feature (counts and within-list positions came out of the
+// selection), then the three backward kernels -- every row of gW_dec / gW_enc^T / gb_enc written exactly once.  N tokens of k slots;
+// dY / sae_in hold N rows, dh N k entries.  loss_part (optional): the N per-token loss terms, scalars[0] = scalars[1] = loss_scale * sum.
+// cnt_in: the per-feature pair counts when they are not the selection's (ws.cnt).  cs_here: also the 16-row partial column sums of dY.
+int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
+                     const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
+                     const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
+                     const uint32_t* gate, hipStream_t stream, const uint32_t* cnt_in) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
-    float* dY = (float*)(wsb + ws.dY);
-    float* dh = tb.dh;
-    float* sae_in = (float*)(wsb + ws.sae_in);
+    const dim3 block(256);
     {
-        ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
-        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
-        const dim3 grid((N + 3) / 4), block(256);
-#define CALL(D)                                                                                                      \
-    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
-                       topk_idx, topk_val, (const float*)(wsb + ws.mu),      \
-                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, dY, dh,             \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip, dh_add, tok_cnt, gate)
-        V4_DISPATCH(d.d_in, CALL);
-#undef CALL
-        PV_LAUNCH_CHECK("sae_decode_kernel");
         // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
-        uint32_t* cnt = (uint32_t*)(wsb + ws.cnt);
+        const uint32_t* cnt = cnt_in ? cnt_in : (const uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
         uint32_t* chunk_start = tb.chunk_start;
         int32_t* pairs = tb.pairs;
@@ -1866,10 +1854,9 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         float* seg_b = tb.seg_b;
         // (the scan's workgroup also reduces the loss: loss = mse_loss = sum / (N_global * d_in), sae.py:148; topk: loss == mse_loss,
         // :620-626 -- scalars[0] = scalars[1])
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)cnt, offs, n_long, d.d_sae,
-                           scalars, 1.0f / (float)N, (const float*)(wsb + ws.loss_part), N, 1.0f / ((float)n_global * (float)d.d_in));
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, offs, n_long, d.d_sae,
+                           scalars, 1.0f / (float)N, loss_part, loss_part ? N : 0, loss_scale);
         // chunk cuts / long lists / statistics, the scatter of the pairs and (autoencoder) the partial column sums of dY: one launch
-        const bool cs_here = bias_grads && !tc;
         {
             CsrPostArgs pa;
             pa.offs = offs; pa.chunk_start = chunk_start; pa.max_chunks = max_chunks; pa.long_list = long_list; pa.n_long = n_long;
@@ -1910,6 +1897,40 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_backward_kernel");
+    }
+    return PV_OK;
+}
+
+// Everything of the k-sparse step behind the selection: decode + LN-out + loss + dY + dh, the CSR by feature, the sparse backward,
+// the bias gradients.  Shared by pv_sae_step (k = the plan's k) and by the sparse form of the ReLU + L1 step (pv_sae_relu_step:
+// k = the per-token capacity, tok_cnt / dh_add / gate as described at sae_decode_kernel; the k-dependent buffers come in through tb).
+int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int k, const int32_t* topk_idx,
+                    const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
+                    const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
+                    const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
+                    bool bias_grads) {
+    const pv_sae_desc& d = plan->d;
+    const int n_pairs = N * k;
+    int rc = PV_OK;
+    float* dY = (float*)(wsb + ws.dY);
+    float* dh = tb.dh;
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
+        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        const dim3 grid((N + 3) / 4), block(256);
+#define CALL(D)                                                                                                      \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
+                       topk_idx, topk_val, (const float*)(wsb + ws.mu),      \
+                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, dY, dh,             \
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip, dh_add, tok_cnt, gate)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel");
+        const bool cs_here = bias_grads && !tc;
+        rc = sae_csr_backward(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
+                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)d.d_in), cs_here, gate, stream, nullptr);
+        if (rc) return rc;
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)
         if (bias_grads) {
@@ -1921,6 +1942,211 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
             }
         }
     }
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The gated step in sparse form (pv_sae_gated_step_sparse; the dense form and the mathematics: pv_sae_gated_step, sae_dense.hip).
+// A gated SAE's forward is sparse in the OPEN GATES: feature_acts, relu(gate_pre) and every gradient behind them vanish where
+// gate_pre <= 0 (sae.py:703-716, :773-792).  The selection (relu_select_kernel<GATED>) leaves, per token, the list of its open gates
+// with both values per pair; from there the step is the k-sparse machinery run on 2 N "tokens", exactly as the dense form stacks
+// [feature_acts; relu(gate_pre)] into one 2N-row operand:
+//     rows [0, N):   val = feature_acts,    dY = d mse / d reconstruction,        dh = dP = dM e^r + dG,  sae_in = the encoder input
+//     rows [N, 2N):  val = relu(gate_pre),  dY = d aux / d (reconstruction via the gate),  dh = 0,        sae_in = 0
+// so that sae_csr_backward's  gW_dec[j] = sum val dY,  gW_enc^T[j] = sum dh sae_in,  gb_enc[j] = sum dh  are the gated step's
+// gW_dec (both decoder products), gW_enc^T and colsum(dP) (parked in gb_enc for gb_dec, as the dense form does).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// encoder input as 2N rows (the second N zero) + the constant LN-out terms of the pass through the gate (no LN-out there: mu 0, std 1,
+// loss normaliser 1)
+__global__ __launch_bounds__(256) void gated_stage_kernel(const float* __restrict__ sae_in, float* __restrict__ sae_in2, int64_t n4,
+                                                          float* __restrict__ mu0, float* __restrict__ one, int n_tok,
+                                                          const uint32_t* __restrict__ gate) {
+    if (*gate != 0u) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_tok) { mu0[i] = 0.f; one[i] = 1.f; }
+    if (i >= 2 * n4) return;
+    const float4 v = i < n4 ? reinterpret_cast<const float4*>(sae_in)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(sae_in2)[i] = v;
+}
+
+// threads [0, n_half): dh of the pair's two copies, the second copy's position in its feature's list (behind all first copies);
+// threads [n_half, n_half + F): the doubled counts (ALWAYS: the CSR kernels behind read them in either mode)
+__global__ __launch_bounds__(256) void gated_pairs_kernel(const int32_t* __restrict__ idx, uint32_t* __restrict__ wpos,
+                                                          const uint32_t* __restrict__ cnt_g, uint32_t* __restrict__ cnt2,
+                                                          const float* __restrict__ dM, const float* __restrict__ dG,
+                                                          const float* __restrict__ r_mag, float* __restrict__ dh2, int n_half, int F,
+                                                          const uint32_t* __restrict__ gate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_half) {
+        const int j = i - n_half;
+        if (j < F) cnt2[j] = 2u * cnt_g[j];
+        return;
+    }
+    if (*gate != 0u) return;
+    const uint32_t w = wpos[i];
+    float g = 0.f;
+    if (w != 0xffffffffu) {                                     // (a hole's dM / dG were never written)
+        const int j = idx[i];
+        g = dM[i] * expf(r_mag[j]) + dG[i];                    // dP = dM e^r + dG (sae.py:708-712 backwards)
+        wpos[n_half + i] = w + cnt_g[j];
+    }
+    dh2[i] = g;
+    dh2[n_half + i] = 0.f;
+}
+
+// per feature, over the first copies of its list (ascending token order): gb_gate = sum dG, gb_mag = sum dM, gr_mag = sum dM (mag_pre
+// - b_mag) = sum dM f - b_mag gb_mag, pgsum = sum relu(gate_pre) (the decoder-norm factor of the L1 term), the firing count of
+// feature_acts + the statistics (train_sae.py:356-361).  One wave per feature.
+__global__ __launch_bounds__(256) void gated_feat_kernel(const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs,
+                                                         const float* __restrict__ val2, const float* __restrict__ dM,
+                                                         const float* __restrict__ dG, const float* __restrict__ b_mag, int n_half, int F,
+                                                         float* __restrict__ gb_gate, float* __restrict__ gb_mag,
+                                                         float* __restrict__ gr_mag, float* __restrict__ pgsum,
+                                                         float* __restrict__ fire_count, float* __restrict__ act_freq,
+                                                         float* __restrict__ n_since_fired, int update_stats,
+                                                         const uint32_t* __restrict__ gate) {
+    if (*gate != 0u) return;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= F) return;
+    const uint32_t beg = offs[j], end = offs[j + 1];
+    float sg = 0.f, sm = 0.f, smf = 0.f, sp = 0.f, fired = 0.f;
+    for (uint32_t q = beg + lane; q < end; q += 64) {
+        const int p = pairs[q];
+        if (p >= n_half) continue;
+        const float f = val2[p], m = dM[p];
+        sg += dG[p];
+        sm += m;
+        smf += m * f;
+        sp += val2[n_half + p];
+        fired += f > 0.f ? 1.f : 0.f;
+    }
+    sg = wave_sum(sg); sm = wave_sum(sm); smf = wave_sum(smf); sp = wave_sum(sp); fired = wave_sum(fired);
+    if (lane != 0) return;
+    gb_gate[j] = sg;
+    gb_mag[j] = sm;
+    gr_mag[j] = smf - b_mag[j] * sm;
+    pgsum[j] = sp;
+    if (fire_count) fire_count[j] = fired;
+    if (update_stats) {
+        act_freq[j] += fired;
+        n_since_fired[j] = fired > 0.f ? 0.f : n_since_fired[j] + 1.f;
+    }
+}
+
+// scalars: 1 mse, 6 aux, 4 l1, 2 l0, 0 their sum (sae.py:748); fixed summation order
+__global__ __launch_bounds__(256) void gated_sparse_scalars_kernel(const float* __restrict__ mse_part, const float* __restrict__ aux_part,
+                                                                   const float* __restrict__ l1part, const float* __restrict__ l0part,
+                                                                   int n_tok, float s_mse, float s_aux, float s_l1, float s_l0,
+                                                                   float* __restrict__ scalars, const uint32_t* __restrict__ gate) {
+    if (*gate != 0u) return;
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f, c = 0.f, e = 0.f;
+    for (int i = threadIdx.x; i < n_tok; i += 256) { a += mse_part[i]; b += aux_part[i]; c += l1part[i]; e += l0part[i]; }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; red[3][wv] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mse = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * s_mse;
+        const float aux = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * s_aux;
+        const float l1 = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * s_l1;
+        scalars[1] = mse; scalars[6] = aux; scalars[4] = l1;
+        scalars[2] = ((red[3][0] + red[3][1]) + (red[3][2] + red[3][3])) * s_l0;
+        scalars[0] = mse + l1 + aux;
+    }
+}
+}  // namespace
+
+GatedSparseWs gated_sparse_carve(const pv_sae_desc& d, int n_tokens, int cap) {
+    GatedSparseWs w;
+    w.rw = relu_carve(d, n_tokens, cap, 2);
+    size_t off = w.rw.total;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    const size_t N = (size_t)n_tokens, P = N * (size_t)cap;
+    w.dM = take(P * 4);
+    w.dG = take(P * 4);
+    w.cnt2 = take((size_t)d.d_sae * 4);
+    w.mu0 = take(N * 4);
+    w.one = take(N * 4);
+    w.l0part = take(N * 4);
+    w.sae_in2 = take(2 * N * (size_t)d.d_in * 4);
+    w.total = off + 256;
+    return w;
+}
+
+// dYs: [2N, d_in] (rows as above; the dense form's layout), auxpart: [N], pgsum: [d_sae] -- regions of the gated scratch the two
+// forms share, so that everything behind them (the decoder-norm term, gb_dec) runs once.  Leaves colsum(dP) in st->gb_enc.
+int sae_gated_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int cap, float l1_coefficient,
+                     int update_stats, unsigned char* rwb, const GatedSparseWs& gs, pv_sae_out* out, unsigned char* wsb, const SaeWs& ws,
+                     float* dYs, float* auxpart, float* pgsum, hipStream_t stream) {
+    const pv_sae_desc& d = plan->d;
+    const pv_sae_gated& t = st->gt;
+    const ReluWs& rw = gs.rw;
+    const int D = d.d_in, F = d.d_sae, n_half = N * cap;
+    const float ng = (float)n_global;
+    uint32_t* mode = (uint32_t*)(rwb + rw.mode);
+    int32_t* idx2 = (int32_t*)(rwb + rw.idx);
+    float* val2 = (float*)(rwb + rw.val);
+    uint32_t* wpos2 = (uint32_t*)(rwb + rw.wpos);
+    uint32_t* tok_cnt = (uint32_t*)(rwb + rw.tok_cnt);
+    float* l1part = (float*)(rwb + rw.l1part);
+    float* l0part = (float*)(rwb + gs.l0part);
+    float* dM = (float*)(rwb + gs.dM);
+    float* dG = (float*)(rwb + gs.dG);
+    float* dh2 = (float*)(rwb + rw.dh);
+    uint32_t* cnt2 = (uint32_t*)(rwb + gs.cnt2);
+    uint32_t* cnt_g = (uint32_t*)(wsb + ws.cnt);
+    float* sae_in2 = (float*)(rwb + gs.sae_in2);
+    const float* sae_in = (const float*)(wsb + ws.sae_in);
+    int rc;
+    {
+        ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F) * 2.0);
+        rc = sae_encode_relu(d, st, N, cap, idx2, val2, tok_cnt, l1part, (uint32_t*)(rwb + rw.cand_cnt), rwb + rw.cand, cnt_g, wpos2, mode,
+                             (const float*)out->scalars, wsb, ws, stream, l0part);
+        if (rc) return rc;
+    }
+    ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * n_half * (double)D * 2.0, 0.0);
+    const int64_t n4 = (int64_t)N * D / 4;
+    hipLaunchKernelGGL(gated_stage_kernel, dim3((unsigned)((2 * n4 + 255) / 256)), dim3(256), 0, stream, sae_in, sae_in2, n4,
+                       (float*)(rwb + gs.mu0), (float*)(rwb + gs.one), N, (const uint32_t*)mode);
+    PV_LAUNCH_CHECK("gated_stage_kernel");
+    const dim3 grid((N + 3) / 4), block(256);
+    // the reconstruction (feature_acts; LN-out, mse, dY, dM) and the reconstruction through the gate (relu(gate_pre) against sae_in:
+    // sae.py:786-792; dG carries the L1 term's l1 / N as the ReLU step's dh does)
+#define CALL(V)                                                                                                                   \
+    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec,           \
+                       (const int32_t*)idx2, (const float*)val2, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),           \
+                       (const float*)(wsb + ws.norm), out->sae_out, dYs, dM, (float*)(wsb + ws.loss_part), N, D, cap,                \
+                       2.0f / (ng * (float)D), 1, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f,           \
+                       (const uint32_t*)tok_cnt, (const uint32_t*)mode);                                                              \
+    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, sae_in, (const float*)st->W_dec, (const float*)st->b_dec,      \
+                       (const int32_t*)idx2, (const float*)(val2 + n_half), (const float*)(rwb + gs.mu0), (const float*)(rwb + gs.one), \
+                       (const float*)(rwb + gs.one), (float*)nullptr, dYs + (size_t)N * D, dG, auxpart, N, D, cap, 2.0f / ng, 1,      \
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, l1_coefficient / ng,                      \
+                       (const uint32_t*)tok_cnt, (const uint32_t*)mode)
+    V4_DISPATCH(D, CALL);
+#undef CALL
+    PV_LAUNCH_CHECK("sae_decode_kernel (gated)");
+    hipLaunchKernelGGL(gated_pairs_kernel, dim3((n_half + F + 255) / 256), block, 0, stream, (const int32_t*)idx2, wpos2,
+                       (const uint32_t*)cnt_g, cnt2, (const float*)dM, (const float*)dG, (const float*)t.r_mag, dh2, n_half, F,
+                       (const uint32_t*)mode);
+    PV_LAUNCH_CHECK("gated_pairs_kernel");
+    SaeTail tb;
+    tb.dh = dh2; tb.chunk_start = (uint32_t*)(rwb + rw.cursor); tb.wpos = wpos2; tb.seg_range = (uint32_t*)(rwb + rw.seg_range);
+    tb.seg_rows = (float*)(rwb + rw.seg_rows); tb.seg_b = (float*)(rwb + rw.seg_b); tb.pairs = (int32_t*)(rwb + rw.pairs);
+    tb.max_segs = rw.max_segs;
+    rc = sae_csr_backward(plan, st, 2 * N, cap, idx2, val2, dh2, dYs, sae_in2, out->scalars, nullptr, 0, false, tb, wsb, ws, nullptr, 0.f,
+                          false, mode, stream, cnt2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gated_feat_kernel, dim3((F + 3) / 4), block, 0, stream, (const uint32_t*)(wsb + ws.offs), (const int32_t*)tb.pairs,
+                       (const float*)val2, (const float*)dM, (const float*)dG, (const float*)t.b_mag, n_half, F, t.gb_gate, t.gb_mag,
+                       t.gr_mag, pgsum, out->fire_count, st->act_freq_scores, st->n_fwd_since_fired, update_stats, (const uint32_t*)mode);
+    hipLaunchKernelGGL(gated_sparse_scalars_kernel, dim3(1), block, 0, stream, (const float*)(wsb + ws.loss_part), (const float*)auxpart,
+                       (const float*)l1part, (const float*)l0part, N, 1.0f / (ng * (float)D), 1.0f / ng, l1_coefficient / ng,
+                       1.0f / (float)N, out->scalars, (const uint32_t*)mode);
+    PV_LAUNCH_CHECK("gated sparse kernels");
     return PV_OK;
 }
 

@@ -1107,9 +1107,11 @@ __global__ __launch_bounds__(256) void gated_finish_kernel(const float* __restri
                                                            const float* __restrict__ sd, const float* __restrict__ norm,
                                                            float* __restrict__ sae_out, float* __restrict__ dYs,
                                                            float* __restrict__ loss_partial, float* __restrict__ aux_partial, int n_tok,
-                                                           int d, float grad_scale, float aux_scale /* 2 / N */) {
+                                                           int d, float grad_scale, float aux_scale /* 2 / N */,
+                                                           const uint32_t* __restrict__ gate) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gate && *gate != 1u) return;                           // (gate: as in DenseGemm)
     if (r >= 2 * n_tok) return;
     const bool second = r >= n_tok;
     const int n = second ? r - n_tok : r;
@@ -1145,11 +1147,16 @@ __global__ __launch_bounds__(256) void gated_finish_kernel(const float* __restri
 }
 
 // scalars[0] = mse + l1 + aux (sae.py:748), one thread
-__global__ void gated_loss_kernel(float* __restrict__ scalars) { scalars[0] = scalars[1] + scalars[4] + scalars[6]; }
+__global__ void gated_loss_kernel(float* __restrict__ scalars, const uint32_t* __restrict__ gate) {
+    if (gate && *gate != 1u) return;
+    scalars[0] = scalars[1] + scalars[4] + scalars[6];
+}
 
 // dP = dM e^r + dG, in place over dM (rows [0, N) of hs; dG = rows [N, 2N))
-__global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, const float* __restrict__ r_mag, int64_t n_rows, int F) {
+__global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, const float* __restrict__ r_mag, int64_t n_rows, int F,
+                                                       const uint32_t* __restrict__ gate) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (gate && *gate != 1u) return;
     if (i >= n_rows * F) return;
     const int c = (int)(i % F);
     float4 a = *reinterpret_cast<const float4*>(hs + i);
@@ -1164,8 +1171,9 @@ __global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, c
 __global__ __launch_bounds__(256) void gated_vec_kernel(const float* __restrict__ sdmf, const float* __restrict__ gb_mag,
                                                         const float* __restrict__ gb_gate, const float* __restrict__ b_mag,
                                                         const float* __restrict__ r_mag, float* __restrict__ gr_mag,
-                                                        float* __restrict__ dpsum, int F) {
+                                                        float* __restrict__ dpsum, int F, const uint32_t* __restrict__ gate) {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    if (gate && *gate != 1u) return;
     if (j >= F) return;
     gr_mag[j] = sdmf[j] - b_mag[j] * gb_mag[j];
     dpsum[j] = expf(r_mag[j]) * gb_mag[j] + gb_gate[j];
@@ -1177,6 +1185,7 @@ __global__ __launch_bounds__(256) void gated_l1_rows_kernel(float* __restrict__ 
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= F) return;
+    if (pgsum[j] == 0.f) return;                               // (no token opened this gate: a zero term; most rows of a sparse step)
     float sq = 0.f;
     for (int c = lane; c < d; c += 64) { const float w = W_dec[(int64_t)j * d + c]; sq += w * w; }
     sq = wave_sum(sq);
@@ -1195,9 +1204,12 @@ extern "C" size_t pv_sae_gated_scratch_bytes(const pv_sae_plan* plan, int32_t n_
     return gated_carve(plan->d, n_tokens).total;
 }
 
-extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean, int32_t n_global,
-                                 int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace, size_t workspace_bytes,
-                                 void* stream_) {
+// sp != NULL (pv_sae_gated_step_sparse): the step runs sparse where the batch allows it, as pv_sae_relu_step does -- the open gates of
+// every token as a list of at most sp->cap pairs (sae_gated_sparse, sae.hip); a batch that cannot be held raises the device-side mode
+// word and the dense GEMMs below run instead (every kernel of either form leaves at once in the other's mode; same results either way).
+static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean, int32_t n_global,
+                           int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp, pv_sae_out* out, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     PV_REQUIRE(plan && st && x && out && workspace && out->scalars, "null argument");
     PV_REQUIRE(sae_is_gated(st) && !sae_is_tc(st), "pv_sae_gated_step needs a gated state (pv_sae_state.gt) and no transcoder");
@@ -1217,12 +1229,23 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     hipStream_t stream = (hipStream_t)stream_;
     unsigned char* wsb = (unsigned char*)workspace;
     unsigned char* gb = (unsigned char*)t.scratch;
+    const bool sparse = sp && pv_sae_relu_sparse_ok(d) && st->W_enc16T && st->enc_colsq;
+    GatedSparseWs gs = {};
+    unsigned char* rwb = nullptr;
+    if (sp) {
+        PV_REQUIRE(sp->cap >= 4 && sp->cap <= PV_SAE_RELU_CAP_MAX && sp->cap % 4 == 0, "pv_sae_relu_sparse.cap: a multiple of 4 in [4, 256]");
+        gs = gated_sparse_carve(d, N, sp->cap);
+        PV_REQUIRE(sp->workspace && sp->workspace_bytes >= gs.total && ((uintptr_t)sp->workspace & 255) == 0,
+                   "pv_sae_relu_sparse workspace too small / misaligned (pv_sae_gated_sparse_workspace_bytes)");
+        rwb = (unsigned char*)sp->workspace;
+    }
+    const uint32_t* mode = sp ? (const uint32_t*)(rwb + gs.rw.mode) : nullptr;
     plan->live_offs = nullptr;
     plan->renorm_pending = false;
     const int F = d.d_sae, D = d.d_in;
     int rc = pv_sae_renorm_decoder(plan, st, stream_);                   // train_sae.py:307
     if (rc) return rc;
-    rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, false, wsb, ws, stream);
+    rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, sparse, wsb, ws, stream);
     const float ng = (float)n_global;
     if (rc) return rc;
     float* hs = (float*)(gb + gw.hs);
@@ -1236,23 +1259,30 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     float* sdmf = (float*)(gb + gw.vec1);
     const int rblk = (N + 63) / 64, cblk = (F + 63) / 64, nb_f = (F + 255) / 256;
     float* blk_tot = (float*)(wsb + ws.sqpart);
+    if (sparse) {
+        rc = sae_gated_sparse(plan, st, x, N, n_global, sp->cap, l1_coefficient, update_stats, rwb, gs, out, wsb, ws, dYs,
+                              (float*)(gb + gw.auxpart), pgsum, stream);
+        if (rc) return rc;
+    } else if (mode) {
+        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)(rwb + gs.rw.mode), 1u);
+    }
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + 2.0 * N * F) * 4.0);
         // G1: p = sae_in @ W_enc once; both paths in the epilogue
         DenseGemm g = {};
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = hs; g.ldo = F; g.out2 = hs + (size_t)N * F; g.bias = t.b_gate; g.bias2 = t.b_mag; g.cscale = t.r_mag;
-        g.colpart = colpart; g.colpart2 = colpart2; g.rowpart = rowpart;
+        g.colpart = colpart; g.colpart2 = colpart2; g.rowpart = rowpart; g.gate = mode;
         rc = launch_dense_gemm<false, false, DG_EPI_GENC>(g, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
                            out->fire_count ? out->fire_count : (float*)(wsb + ws.rowsq), (float*)nullptr, st->act_freq_scores,
-                           st->n_fwd_since_fired, update_stats, blk_tot);
+                           st->n_fwd_since_fired, update_stats, blk_tot, mode);
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart2, rblk, F, pgsum,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, mode);
         PV_LAUNCH_CHECK("dense_colreduce_kernel");
-        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream);                        // l0
-        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / ng, 4, -1, stream);             // l1 (unit decoder rows)
+        sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream, mode, 1u);                        // l0
+        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / ng, 4, -1, stream, mode, 1u);             // l1 (unit decoder rows)
     }
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 14.0 * N * (double)D * F, 0.0);
@@ -1261,62 +1291,81 @@ extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const floa
         DenseGemm g = {};
         g.A = hs; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = 2 * N; g.N = D; g.K = F;
         g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
-        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)2 * N * D;
+        g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)2 * N * D; g.gate = mode;
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(gated_finish_kernel, dim3((2 * N + 3) / 4), dim3(256), 0, stream, x, (const float*)sae_in, (const float*)kpart, S,
                            (int64_t)2 * N * D, (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
                            (const float*)(wsb + ws.norm), out->sae_out, dYs, (float*)(wsb + ws.loss_part), (float*)(gb + gw.auxpart), N, D,
-                           2.0f / (ng * (float)D), 2.0f / ng);
+                           2.0f / (ng * (float)D), 2.0f / ng, mode);
         PV_LAUNCH_CHECK("gated_finish_kernel");
-        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / (ng * (float)D), 1, -1, stream);
-        sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / ng, 6, -1, stream);
-        hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
-        // G4: gW_dec = [f; relu(gate)]^T @ [dY; dVia] (K = 2N) + the decoder-norm factor of the L1 term
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / (ng * (float)D), 1, -1, stream, mode, 1u);
+        sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / ng, 6, -1, stream, mode, 1u);
+        hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, mode);
+        // G4: gW_dec = [f; relu(gate)]^T @ [dY; dVia] (K = 2N); the decoder-norm factor of the L1 term is added behind both forms
         DenseGemm g4 = {};
         g4.A = hs; g4.lda = F; g4.B = dYs; g4.ldb = D; g4.M = F; g4.N = D; g4.K = 2 * N; g4.k_chunk = 2 * N;
-        g4.out = st->gW_dec; g4.ldo = D;
+        g4.out = st->gW_dec; g4.ldo = D; g4.gate = mode;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(gated_l1_rows_kernel, dim3((F + 3) / 4), dim3(256), 0, stream, st->gW_dec, (const float*)st->W_dec,
-                           (const float*)pgsum, l1_coefficient / ng, F, D);
         // G3a: dM = (dY @ W_dec^T) [f > 0] over f; column sums = gb_mag, of dM * f = the raw term of gr_mag
         DenseGemm g3 = {};
         g3.A = dYs; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
-        g3.out = hs; g3.ldo = F; g3.colpart = colpart; g3.colpart2 = colpart2; g3.add = 0.f;
+        g3.out = hs; g3.ldo = F; g3.colpart = colpart; g3.colpart2 = colpart2; g3.add = 0.f; g3.gate = mode;
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_mag,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, mode);
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart2, rblk, F, sdmf,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, mode);
         // G3b: dG = (dVia @ W_dec^T + l1 / N) [gate > 0] over relu(gate); column sums = gb_gate
         g3.A = dYs + (size_t)N * D; g3.out = hs + (size_t)N * F; g3.colpart2 = nullptr; g3.add = l1_coefficient / ng;
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_gate,
-                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr);
+                           (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, mode);
         // gr_mag; colsum(dP) parked in gb_enc for the bias-gradient kernels below
         hipLaunchKernelGGL(gated_vec_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)sdmf, (const float*)t.gb_mag,
-                           (const float*)t.gb_gate, (const float*)t.b_mag, (const float*)t.r_mag, t.gr_mag, st->gb_enc, F);
+                           (const float*)t.gb_gate, (const float*)t.b_mag, (const float*)t.r_mag, t.gr_mag, st->gb_enc, F, mode);
         // dP = dM e^r + dG, then G5: gW_enc^T = dP^T @ sae_in
         hipLaunchKernelGGL(gated_dp_kernel, dim3((unsigned)(((int64_t)N * F / 4 + 255) / 256)), dim3(256), 0, stream, hs,
-                           (const float*)t.r_mag, (int64_t)N, F);
+                           (const float*)t.r_mag, (int64_t)N, F, mode);
         PV_LAUNCH_CHECK("gated elementwise kernels");
         DenseGemm g5 = {};
         g5.A = hs; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
-        g5.out = st->gW_enc; g5.ldo = D;
+        g5.out = st->gW_enc; g5.ldo = D; g5.gate = mode;
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
-        // gb_dec = colsum(dY) + 2 colsum(dVia) - W_enc colsum(dP): b_dec sits in the decoder twice and in sae_in, which is also
-        // the auxiliary loss's target
-        rc = sae_gbdec(d, st, dYs, N, wsb, ws, stream);                   // colsum(dY) - W_enc gb_enc (= colsum(dP) for now)
-        if (rc) return rc;
-        rc = sae_colsum(dYs + (size_t)N * D, N, D, (float*)(gb + gw.tmpd), 2.0f, (float*)(gb + gw.cspart), stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(gated_axpy_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, st->gb_dec, (const float*)(gb + gw.tmpd), D);
-        PV_LAUNCH_CHECK("gated_axpy_kernel");
-        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)F * 4, stream));      // b_enc takes no part in a gated SAE
     }
+    // behind either form: dYs = [dY; dVia], pgsum = colsum(relu(gate_pre)), colsum(dP) in gb_enc, gW_dec without the L1 term
+    hipLaunchKernelGGL(gated_l1_rows_kernel, dim3((F + 3) / 4), dim3(256), 0, stream, st->gW_dec, (const float*)st->W_dec,
+                       (const float*)pgsum, l1_coefficient / ng, F, D);
+    // gb_dec = colsum(dY) + 2 colsum(dVia) - W_enc colsum(dP): b_dec sits in the decoder twice and in sae_in, which is also
+    // the auxiliary loss's target
+    rc = sae_gbdec(d, st, dYs, N, wsb, ws, stream);                   // colsum(dY) - W_enc gb_enc (= colsum(dP) for now)
+    if (rc) return rc;
+    rc = sae_colsum(dYs + (size_t)N * D, N, D, (float*)(gb + gw.tmpd), 2.0f, (float*)(gb + gw.cspart), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gated_axpy_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, st->gb_dec, (const float*)(gb + gw.tmpd), D);
+    PV_LAUNCH_CHECK("gated_axpy_kernel");
+    PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)F * 4, stream));      // b_enc takes no part in a gated SAE
     return PV_OK;
+}
+
+extern "C" int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean, int32_t n_global,
+                                 int32_t flags, float l1_coefficient, pv_sae_out* out, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+    return gated_step_impl(plan, st, x, N, batch_mean, n_global, flags, l1_coefficient, nullptr, out, workspace, workspace_bytes, stream_);
+}
+
+extern "C" size_t pv_sae_gated_sparse_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap) {
+    if (!plan || n_tokens < 1 || cap < 4 || cap > PV_SAE_RELU_CAP_MAX || cap % 4) return 0;
+    return gated_sparse_carve(plan->d, n_tokens, cap).total;
+}
+
+extern "C" int pv_sae_gated_step_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                                        int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp,
+                                        pv_sae_out* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    PV_REQUIRE(sp, "pv_sae_gated_step_sparse: pv_sae_relu_sparse is required (pv_sae_gated_step is the dense form)");
+    return gated_step_impl(plan, st, x, N, batch_mean, n_global, flags, l1_coefficient, sp, out, workspace, workspace_bytes, stream_);
 }

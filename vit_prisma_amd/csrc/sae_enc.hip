@@ -846,14 +846,24 @@ __global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__
 
 // One workgroup per token: candidates -> exact values -> the positive ones, ranked by (value desc, feature asc) -> idx / val /
 // wpos [cap] (holes: val 0, wpos ~0), tok_cnt, the token's sum of activations (the L1 term).
-template <int V4>
+// GATED (pv_sae_gated_step_sparse): b_enc = b_gate, the list = the features whose GATE is open (gate_pre = sae_in W_enc + b_gate > 0,
+// sae.py:703-706), ranked by gate_pre.  The token's rows are written twice, n_tok rows apart -- the step's backward walks
+// [feature_acts; relu(gate_pre)] as 2 n_tok tokens, like the dense form stacks them: rows [0, n_tok) hold feature_acts = relu(p e^r_mag +
+// b_mag) of the same pairs (0 where the magnitude path is shut: such a pair still carries the gate path's gradient), rows
+// [n_tok, 2 n_tok) relu(gate_pre); idx is the same in both, wpos of the second copy is the first's (the step adds the feature's count).
+// l0part = the token's count of feature_acts > 0.
+template <int V4, bool GATED = false>
 __global__ __launch_bounds__(256) void relu_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ thr, int32_t* __restrict__ idx_out,
     float* __restrict__ val_out, uint32_t* __restrict__ tok_cnt, float* __restrict__ l1part, uint32_t* __restrict__ feat_cnt,
-    uint32_t* __restrict__ wpos, uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots) {
+    uint32_t* __restrict__ wpos, uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots,
+    const float* __restrict__ r_mag = nullptr, const float* __restrict__ b_mag = nullptr, float* __restrict__ l0part = nullptr) {
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ float rval[PV_SAE_CAND_CAP];
+    __shared__ float rmag[GATED ? PV_SAE_CAND_CAP : 1];
+    __shared__ uint32_t sh_l0;
+    const int64_t half = GATED ? (int64_t)gridDim.x * cap : 0;       // (the second copy of the token's rows)
     __shared__ uint32_t tcnt[256];
     __shared__ float sval[256];                              // the kept values in rank order (cap <= 256)
     __shared__ float red[4];
@@ -935,7 +945,10 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
             const uint32_t c = c0 + 4 * lane;
             const float av = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
             const int jv = lane == 0 ? jj[0] : (lane == 1 ? jj[1] : (lane == 2 ? jj[2] : jj[3]));
-            if (c < nr) rval[c] = av + b_enc[jv];
+            if (c < nr) {
+                rval[c] = av + b_enc[jv];
+                if constexpr (GATED) rmag[c] = fmaxf(av * expf(r_mag[jv]) + b_mag[jv], 0.f);      // (as DG_EPI_GENC writes it)
+            }
         }
     }
     __syncthreads();
@@ -954,16 +967,26 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
     const uint32_t m = sh_m;
     bad = bad || sh_bad != 0u || m > (uint32_t)cap;
     if (bad) {                                                 // (uniform) this token cannot be held: the whole step goes dense
-        if (tid == 0) { atomicOr(mode, 1u); tok_cnt[row] = 0u; l1part[row] = 0.f; }
+        if (tid == 0) {
+            atomicOr(mode, 1u); tok_cnt[row] = 0u; l1part[row] = 0.f;
+            if constexpr (GATED) l0part[row] = 0.f;
+        }
         for (int s = tid; s < cap; s += 256) {
             idx_out[row * cap + s] = 0;
             val_out[row * cap + s] = 0.f;
             wpos[row * cap + s] = 0xffffffffu;
+            if constexpr (GATED) {
+                idx_out[half + row * cap + s] = 0;
+                val_out[half + row * cap + s] = 0.f;
+                wpos[half + row * cap + s] = 0xffffffffu;
+            }
         }
         return;
     }
     sval[tid] = 0.f;
+    if (tid == 0) sh_l0 = 0u;
     __syncthreads();
+    uint32_t myl0 = 0;
     for (uint32_t c = tid; c < nr; c += 256) {
         const float vc = rval[c];
         if (!(vc > 0.f)) continue;
@@ -973,16 +996,32 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
             const float vo = rval[o];
             rank += (vo > vc) || (vo == vc && cidx[o] < ic);
         }
+        const uint32_t wp = atomicAdd(&feat_cnt[ic], 1u);
         idx_out[row * cap + rank] = ic;
-        val_out[row * cap + rank] = vc;
-        wpos[row * cap + rank] = atomicAdd(&feat_cnt[ic], 1u);
+        wpos[row * cap + rank] = wp;
+        if constexpr (GATED) {
+            const float f = rmag[c];
+            val_out[row * cap + rank] = f;
+            idx_out[half + row * cap + rank] = ic;
+            val_out[half + row * cap + rank] = vc;
+            wpos[half + row * cap + rank] = wp;
+            myl0 += f > 0.f ? 1u : 0u;
+        } else {
+            val_out[row * cap + rank] = vc;
+        }
         sval[rank] = vc;
     }
     for (int s = (int)m + tid; s < cap; s += 256) {           // the rest of the row: holes
         idx_out[row * cap + s] = 0;
         val_out[row * cap + s] = 0.f;
         wpos[row * cap + s] = 0xffffffffu;
+        if constexpr (GATED) {
+            idx_out[half + row * cap + s] = 0;
+            val_out[half + row * cap + s] = 0.f;
+            wpos[half + row * cap + s] = 0xffffffffu;
+        }
     }
+    if (GATED && myl0) atomicAdd(&sh_l0, myl0);
     __syncthreads();
     // the token's L1 term, summed in rank order (the candidates arrive in whatever order the filter's LDS atomics drew)
     const float lsum = wave_sum(sval[tid]);
@@ -991,6 +1030,7 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
     if (tid == 0) {
         tok_cnt[row] = m;
         l1part[row] = (red[0] + red[1]) + (red[2] + red[3]);
+        if constexpr (GATED) l0part[row] = (float)sh_l0;
     }
 }
 
@@ -1066,7 +1106,10 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
 
 int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
                     float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
-                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, float* l0part) {
+    // l0part != NULL: the gated form (see relu_select_kernel) -- the bias is b_gate, idx / val / wpos hold 2 N rows
+    const bool gated = l0part != nullptr;
+    const float* bias = gated ? (const float*)st->gt.b_gate : (const float*)st->b_enc;
     PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
     PV_REQUIRE(cap >= 4 && cap <= PV_SAE_RELU_CAP_MAX && cap % 4 == 0, "cap");
     float* wmax = (float*)(wsb + ws.wmax);
@@ -1078,15 +1121,21 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
     EncParams p = {};
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
     p.B = st->W_enc16T; p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes;
-    p.bias = st->b_enc; p.bias_stride = 1; p.out = nullptr; p.thr = (const float*)(wsb + ws.thr);
+    p.bias = bias; p.bias_stride = 1; p.out = nullptr; p.thr = (const float*)(wsb + ws.thr);
     p.cnt = cand_cnt; p.cand = (int2*)cand; p.slots = PV_SAE_RELU_SLOTS; p.mode = mode;
     int rc = launch_enc_gemm(1, p, stream);
     if (rc) return rc;
     const int ntn = d.d_sae / 256;
 #define CALL(D)                                                                                                                 \
-    hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                    \
-                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)cand_cnt, (const int2*)cand,           \
-                       (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
+    if (gated)                                                                                                                  \
+        hipLaunchKernelGGL((relu_select_kernel<D, true>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),          \
+                           (const float*)st->W_encT, bias, (const uint32_t*)cand_cnt, (const int2*)cand,                           \
+                           (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn,        \
+                           PV_SAE_RELU_SLOTS, (const float*)st->gt.r_mag, (const float*)st->gt.b_mag, l0part);                     \
+    else                                                                                                                        \
+        hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                \
+                           (const float*)st->W_encT, bias, (const uint32_t*)cand_cnt, (const int2*)cand,                           \
+                           (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
 #undef CALL
     PV_LAUNCH_CHECK("relu_select_kernel");

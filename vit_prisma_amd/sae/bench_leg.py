@@ -200,26 +200,41 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
     return res
 
 
-def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3) -> dict:
+def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3, only: Optional[str] = None) -> dict:
     """Step-only times of the other coders of the reference on their fused HIP steps, through ``VisionSAETrainer.train_step`` at
     the bench shape (768 -> 24576, 4096 tokens, single process): a top-k Transcoder with the skip connection (sae/transcoder.py)
-    and a Gated SAE with the ReLU magnitude path (sae.py:648-792)."""
+    and a Gated SAE with the ReLU magnitude path (sae.py:648-792) -- as a training run from the synthetic init (every gate half open:
+    the step's dense form) and with b_gate shifted so that a token opens about 64 gates, lr 0 (a trained gated SAE's regime: the sparse
+    form, pv_sae_gated_step_sparse; which form ran is decided on the GPU and counted)."""
     from .config import VisionModelSAERunnerConfig
     from .trainer import VisionSAETrainer
     out = {}
     for name, over in (("transcoder_topk_skip", dict(activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, is_transcoder=True,
                                                      transcoder_with_skip_connection=True, d_out=D_IN, out_hook_point_layer=6)),
-                       ("gated_relu", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated", l1_coefficient=8e-5))):
+                       ("gated_relu", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated", l1_coefficient=8e-5)),
+                       ("gated_relu_l0_64", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated",
+                                                 l1_coefficient=8e-5))):
+        if only is not None and name != only:
+            continue
+        target_l0 = 64.0 if name == "gated_relu_l0_64" else None
         cfg = VisionModelSAERunnerConfig(
             hook_point_layer=6, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
             normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
-            train_batch_size=N_TOKENS, lr=1e-3, max_grad_norm=1.0, _device=str(dev), log_to_wandb=False, lr_scheduler_name="constant",
-            n_checkpoints=0, **over)
+            train_batch_size=N_TOKENS, lr=0.0 if target_l0 else 1e-3, max_grad_norm=1.0, _device=str(dev), log_to_wandb=False,
+            lr_scheduler_name="constant", n_checkpoints=0, **over)
         tr = VisionSAETrainer(cfg, model=None, dataset=None).use_native(True)
         sae = tr.sparse_coder
         with torch.no_grad():
             for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
                 getattr(sae, n).copy_(torch.from_numpy(v))
+            if target_l0:
+                xb = torch.from_numpy(synth_sae_batch(512, D_IN, seed=0)).to(dev)
+                xh = (xb - xb.mean(-1, keepdim=True)) / (xb.std(-1, keepdim=True) + 1e-5)
+                h = (xh - sae.b_dec) @ sae.W_enc + sae.b_gate
+                sae.b_gate -= torch.quantile(h.flatten()[::97].float(), 1.0 - target_l0 / D_SAE)
+                del xb, xh, h
+        gated = over.get("architecture") == "gated"
+        n_dense = torch.zeros(1, dtype=torch.int32, device=dev)
         st = list(tr.initialize_training_variables())
         pair = cfg.is_transcoder
         xs = [torch.from_numpy(synth_sae_batch(N_TOKENS, D_IN, seed=i)).to(dev) for i in range(4)]
@@ -237,9 +252,12 @@ def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3) -> dict
                               n_training_tokens=n_done[0] * N_TOKENS)
             last[0], st[0], st[1], st[2] = r[0], r[4], r[5], r[6]
             n_done[0] += 1
+            if gated and getattr(tr._engine, "_gated_ws", None) is not None:
+                n_dense.add_(tr._engine._gated_ws[:4].view(torch.int32))      # (the step's mode word: a device word added to a device counter)
 
         for i in range(warmup):
             step(xs[i % 4])
+        n_dense.zero_()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
@@ -250,6 +268,12 @@ def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3) -> dict
         out[name] = {"value": round(N_TOKENS * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                      "steps": steps, "warmup": warmup, "final_loss": float(last[0]),
                      "config": {"workload": f"{name}: 768 -> 24576, {N_TOKENS} tokens per step, Adam, clip 1.0, fused HIP step"}}
+        if gated:
+            eng = tr._engine
+            out[name].update({"l0": float(eng.scalars[2].item()), "dense_steps": int(n_dense.item()),
+                              "sparse_steps": steps - int(n_dense.item()), "per_token_capacity": int(eng.relu_cap)})
+            out[name]["config"]["regime"] = (f"b_gate shifted to ~{target_l0:g} open gates per token, lr 0 (state held)" if target_l0 else
+                                             f"training run from the synthetic init, steps {warmup + 1}..{warmup + steps} timed")
         del tr, sae, xs
         torch.cuda.empty_cache()
     return out

@@ -410,10 +410,14 @@ class NativeSAE:
         self._grad_sparse = False
 
     def gated_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
-                   n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False) -> None:
-        """One train step of a gated SAE (pv_sae_gated_step): set_decoder_norm_to_unit_norm, forward, backward, statistics;
+                   n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
+                   cap: Optional[int] = None, sparse: bool = True) -> None:
+        """One train step of a gated SAE: set_decoder_norm_to_unit_norm, forward, backward, statistics;
         gradients in ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, -, auxiliary loss.  batch_mean / n_global:
-        as in ``step`` (tokens sharded over ranks; the caller all-reduces ``flat_g``)."""
+        as in ``step`` (tokens sharded over ranks; the caller all-reduces ``flat_g``).  sparse (default; pv_sae_gated_step_sparse):
+        every token's OPEN gates as a list of at most ``cap`` pairs and the k-sparse kernels behind them, the dense GEMMs
+        (pv_sae_gated_step) when a token of the batch holds more -- decided on the GPU (``gated_mode``: 0 sparse, 1 dense), same
+        results either way; sparse=False: the dense GEMMs unconditionally."""
         assert self.gated
         x = self._check_x(x)
         self._ensure_shadows()                                    # (as in step / dense_step)
@@ -422,13 +426,34 @@ class NativeSAE:
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
         bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
-        N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
-                                           int(n_global if n_global is not None else n), int(bool(update_stats)) | 2,
-                                           float(l1_coefficient), C.byref(out), self.workspace.data_ptr(), self.workspace.numel(),
-                                           self._stream()), "pv_sae_gated_step")
+        flags = int(bool(update_stats)) | 2
+        ng = int(n_global if n_global is not None else n)
+        if sparse:
+            cap = int(cap if cap is not None else self.relu_cap)
+            key = (self.max_tokens, cap)
+            if getattr(self, "_gated_key", None) != key:
+                need = self.lib.pv_sae_gated_sparse_workspace_bytes(self._plan, self.max_tokens, cap)
+                if not need:
+                    raise ValueError(f"gated_step: cap must be a multiple of 4 in [4, 256], got {cap}")
+                self._gated_ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
+                self._gated_key = key
+            sp = N.SaeReluSparse(cap=cap, reserved=0, workspace=self._gated_ws.data_ptr(), workspace_bytes=self._gated_ws.numel())
+            N.check(self.lib.pv_sae_gated_step_sparse(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                                      ng, flags, float(l1_coefficient), C.byref(sp), C.byref(out),
+                                                      self.workspace.data_ptr(), self.workspace.numel(), self._stream()),
+                    "pv_sae_gated_step_sparse")
+        else:
+            N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                               ng, flags, float(l1_coefficient), C.byref(out), self.workspace.data_ptr(),
+                                               self.workspace.numel(), self._stream()), "pv_sae_gated_step")
         self._inv_norm_key = None
         self._grad_fresh = False
         self._grad_sparse = False
+
+    @property
+    def gated_mode(self) -> int:
+        """0: the last ``gated_step(sparse=True)`` ran sparse; 1: it ran on the dense GEMMs (a device word: this read synchronises)."""
+        return int(self._gated_ws[:4].view(torch.int32)[0].item())
 
     def _no_pending_sparse(self, what: str) -> None:
         if getattr(self, "_grad_sparse", False) and self._grad_fresh:
