@@ -735,13 +735,16 @@ struct BwdAcc {
 
 // accumulate the pairs [q0, q1) (all of ONE feature when STOP_AT_LONG is false).  With STOP_AT_LONG the run is a chunk of
 // whole lists: a finished feature's rows are stored, and the walk ends at the first long list (the last list of a chunk).
-template <int V4, bool STOP_AT_LONG>
+// DUAL (the gated step, sae_gated_sparse): a pair carries a SECOND decoder term -- gW_dec[j] = sum_p a_p dY[n_p] + b_p dYb[n_p] (b =
+// val_b: relu(gate_pre), dYb: the gradient of the reconstruction through the gate) -- gathered and accumulated alongside the first.
+template <int V4, bool STOP_AT_LONG, bool DUAL = false>
 __device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t q1, const uint32_t* __restrict__ offs,
                                          const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx,
                                          const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
                                          const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT,
                                          float* __restrict__ gb_enc, float* __restrict__ rowsq, int d, int k, int lane,
-                                         const int (&col)[V4], const bool (&ok)[V4]) {
+                                         const int (&col)[V4], const bool (&ok)[V4], const float* __restrict__ val_b = nullptr,
+                                         const float* __restrict__ dYb = nullptr) {
     int cur = -1;
     auto store_rows = [&](int j) {
         acc.store(j, gW_dec, gW_encT, gb_enc, rowsq, d, lane, col, ok);
@@ -751,25 +754,29 @@ __device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t 
     for (uint32_t base = q0; base < q1 && !stop; base += 64) {
         const int cnt = (int)min(64u, q1 - base);
         int my_n = 0, my_j = 0;
-        float my_a = 0.f, my_g = 0.f;
+        float my_a = 0.f, my_g = 0.f, my_b = 0.f;
         if (lane < cnt) {
             const int32_t p = pairs[base + lane];
             my_n = p / k;
             my_j = idx[p];
             my_a = val[p];
             my_g = dh[p];
+            if constexpr (DUAL) my_b = val_b[p];
         }
-        float4 dy0[V4], si0[V4], dy1[V4], si1[V4];
-        auto gather = [&](float4 (&dy)[V4], float4 (&si)[V4], int t) {
+        constexpr int VB = DUAL ? V4 : 1;
+        float4 dy0[V4], si0[V4], dy1[V4], si1[V4], db0[VB], db1[VB];
+        auto gather = [&](float4 (&dy)[V4], float4 (&si)[V4], float4 (&db)[VB], int t) {
             const int n = __shfl(my_n, t, 64);
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 dy[i] = ld4(dY + (int64_t)n * d + col[i], ok[i]);
                 si[i] = ld4(sae_in + (int64_t)n * d + col[i], ok[i]);
+                if constexpr (DUAL) db[i] = ld4(dYb + (int64_t)n * d + col[i], ok[i]);
             }
         };
-        auto accumulate = [&](const float4 (&dy)[V4], const float4 (&si)[V4], int t) {
+        auto accumulate = [&](const float4 (&dy)[V4], const float4 (&si)[V4], const float4 (&db)[VB], int t) {
             const float a = __shfl(my_a, t, 64), g = __shfl(my_g, t, 64);
+            const float b = DUAL ? __shfl(my_b, t, 64) : 0.f;
             if constexpr (STOP_AT_LONG) {
                 const int j = __shfl(my_j, t, 64);
                 if (j != cur) {
@@ -783,17 +790,20 @@ __device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t 
             for (int i = 0; i < V4; ++i) {
                 acc.gd[i].x += a * dy[i].x; acc.gd[i].y += a * dy[i].y; acc.gd[i].z += a * dy[i].z; acc.gd[i].w += a * dy[i].w;
                 acc.ge[i].x += g * si[i].x; acc.ge[i].y += g * si[i].y; acc.ge[i].z += g * si[i].z; acc.ge[i].w += g * si[i].w;
+                if constexpr (DUAL) {
+                    acc.gd[i].x += b * db[i].x; acc.gd[i].y += b * db[i].y; acc.gd[i].z += b * db[i].z; acc.gd[i].w += b * db[i].w;
+                }
             }
             acc.gb += g;
         };
-        gather(dy0, si0, 0);
-        if (cnt > 1) gather(dy1, si1, 1);
+        gather(dy0, si0, db0, 0);
+        if (cnt > 1) gather(dy1, si1, db1, 1);
         for (int t = 0; t < cnt && !stop; t += 2) {
-            accumulate(dy0, si0, t);
-            if (t + 2 < cnt) gather(dy0, si0, t + 2);
+            accumulate(dy0, si0, db0, t);
+            if (t + 2 < cnt) gather(dy0, si0, db0, t + 2);
             if (t + 1 < cnt && !stop) {
-                accumulate(dy1, si1, t + 1);
-                if (t + 3 < cnt) gather(dy1, si1, t + 3);
+                accumulate(dy1, si1, db1, t + 1);
+                if (t + 3 < cnt) gather(dy1, si1, db1, t + 3);
             }
         }
     }
@@ -802,12 +812,13 @@ __device__ __forceinline__ void bwd_walk(BwdAcc<V4>& acc, uint32_t q0, uint32_t 
     }
 }
 
-template <int V4>
+template <int V4, bool DUAL = false>
 __global__ __launch_bounds__(256) void sae_backward_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ chunk_start, const int32_t* __restrict__ pairs,
     const int32_t* __restrict__ idx, const float* __restrict__ val, const float* __restrict__ dh, const float* __restrict__ dY,
     const float* __restrict__ sae_in, float* __restrict__ gW_dec, float* __restrict__ gW_encT, float* __restrict__ gb_enc,
-    float* __restrict__ rowsq, int d, int k, int n_chunks, const uint32_t* __restrict__ gate = nullptr) {
+    float* __restrict__ rowsq, int d, int k, int n_chunks, const uint32_t* __restrict__ gate = nullptr,
+    const float* __restrict__ val_b = nullptr, const float* __restrict__ dYb = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= n_chunks) return;
@@ -823,7 +834,8 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
     }
     BwdAcc<V4> acc;
     acc.clear();
-    bwd_walk<V4, true>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, rowsq, d, k, lane, col, ok);
+    bwd_walk<V4, true, DUAL>(acc, q0, q1, offs, pairs, idx, val, dh, dY, sae_in, gW_dec, gW_encT, gb_enc, rowsq, d, k, lane, col, ok, val_b,
+                             dYb);
 }
 
 // long lists, stage 0 (token-range form): sort every long list by token and cut it at the BWD_RANGES token-range boundaries.
@@ -891,12 +903,13 @@ __global__ __launch_bounds__(256) void sae_long_sort_kernel(int32_t* __restrict_
 // long lists, stage 1: one wave per segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb).  Segments are BWD_SEG-pair
 // cuts (ranged == 0) or the BWD_RANGES token ranges of a sorted list (ranged == 1: segment 8 e + r goes to a workgroup with
 // blockIdx % 8 == r, i.e. to XCD r)
-template <int V4>
+template <int V4, bool DUAL = false>
 __global__ __launch_bounds__(512) void sae_backward_seg_kernel(
     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ seg_range, const uint32_t* __restrict__ n_long,
     const int32_t* __restrict__ pairs, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const float* __restrict__ dh, const float* __restrict__ dY, const float* __restrict__ sae_in, float* __restrict__ seg_rows,
-    float* __restrict__ seg_b, int d, int k, int max_segs, int ranged, const uint32_t* __restrict__ gate = nullptr) {
+    float* __restrict__ seg_b, int d, int k, int max_segs, int ranged, const uint32_t* __restrict__ gate = nullptr,
+    const float* __restrict__ val_b = nullptr, const float* __restrict__ dYb = nullptr) {
     if (gate && *gate != 0u) return;                               // (uniform over the grid: no barrier is skipped by a part of a workgroup)
     constexpr int NW = 8;                                          // waves per workgroup (token-range form: 512 threads)
     __shared__ __attribute__((aligned(16))) float part[NW * 2 * 256 * V4];      // [wave][gd | ge][256 V4] (token-range form)
@@ -915,8 +928,8 @@ __global__ __launch_bounds__(512) void sae_backward_seg_kernel(
         for (uint32_t sg = blockIdx.x * nw + wv; sg < nseg; sg += gridDim.x * nw) {
             BwdAcc<V4> acc;
             acc.clear();
-            bwd_walk<V4, false>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
-                                nullptr, nullptr, d, k, lane, col, ok);
+            bwd_walk<V4, false, DUAL>(acc, seg_range[2 * sg], seg_range[2 * sg + 1], offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr,
+                                      nullptr, nullptr, d, k, lane, col, ok, val_b, dYb);
             float* o = seg_rows + (int64_t)sg * 2 * d;
 #pragma unroll
             for (int i = 0; i < V4; ++i)
@@ -940,7 +953,8 @@ __global__ __launch_bounds__(512) void sae_backward_seg_kernel(
         const uint32_t w0 = min(q0 + wv * per, q1), w1 = min(w0 + per, q1);
         BwdAcc<V4> acc;
         acc.clear();
-        bwd_walk<V4, false>(acc, w0, w1, offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr, nullptr, nullptr, d, k, lane, col, ok);
+        bwd_walk<V4, false, DUAL>(acc, w0, w1, offs, pairs, idx, val, dh, dY, sae_in, nullptr, nullptr, nullptr, nullptr, d, k, lane, col, ok,
+                                  val_b, dYb);
         __syncthreads();                                          // (the previous segment's reads of part)
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
@@ -1524,12 +1538,11 @@ SaeWs sae_carve(const pv_sae_desc& d) {
 }
 
 // The buffers of the sparse ReLU + L1 step that depend on its per-token capacity (pv_sae_relu_step; caller-owned workspace)
-// (copies = 2: the gated step's lists, every pair held twice -- see sae_gated_sparse)
-ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap, int copies) {
+ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap) {
     ReluWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
-    const size_t N = (size_t)n_tokens, P = N * (size_t)cap * (size_t)copies, ntn = (size_t)(d.d_sae + 255) / 256;
+    const size_t N = (size_t)n_tokens, P = N * (size_t)cap, ntn = (size_t)(d.d_sae + 255) / 256;
     w.mode = take(256);
     w.idx = take(P * 4);
     w.val = take(P * 4);
@@ -1829,18 +1842,18 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 // The backward of a k-sparse step behind its decode kernel: the CSR by feature (counts and within-list positions came out of the
 // selection), then the three backward kernels -- every row of gW_dec / gW_enc^T / gb_enc written exactly once.  N tokens of k slots;
 // dY / sae_in hold N rows, dh N k entries.  loss_part (optional): the N per-token loss terms, scalars[0] = scalars[1] = loss_scale * sum.
-// cnt_in: the per-feature pair counts when they are not the selection's (ws.cnt).  cs_here: also the 16-row partial column sums of dY.
+// cs_here: also the 16-row partial column sums of dY.  val_b / dYb: the second decoder term of a pair (bwd_walk<DUAL>: the gated step).
 int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
                      const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
                      const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
-                     const uint32_t* gate, hipStream_t stream, const uint32_t* cnt_in) {
+                     const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
     const dim3 block(256);
     {
         // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
-        const uint32_t* cnt = cnt_in ? cnt_in : (const uint32_t*)(wsb + ws.cnt);
+        const uint32_t* cnt = (const uint32_t*)(wsb + ws.cnt);
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
         uint32_t* chunk_start = tb.chunk_start;
         int32_t* pairs = tb.pairs;
@@ -1884,13 +1897,23 @@ int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const in
     if (!sparse)                                                                                                       \
         hipLaunchKernelGGL((sae_zero_empty_kernel<D>), dim3((d.d_sae + 3) / 4), block, 0, stream, (const uint32_t*)offs, st->gW_dec, \
                            st->gW_enc, st->gb_enc, rowsq, d.d_sae, d.d_in, gate);                                         \
-    hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
-                       (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh, \
-                       (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks, gate); \
-    hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
-                       (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx, \
-                       topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b, \
-                       d.d_in, k, max_segs, ranged, gate);                                                                       \
+    if (val_b) {                                                                                                       \
+        hipLaunchKernelGGL((sae_backward_kernel<D, true>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
+                           (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, \
+                           st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks, gate, val_b, dYb);           \
+        hipLaunchKernelGGL((sae_backward_seg_kernel<D, true>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, \
+                           (const uint32_t*)offs, (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx, \
+                           topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b,          \
+                           d.d_in, k, max_segs, ranged, gate, val_b, dYb);                                                \
+    } else {                                                                                                           \
+        hipLaunchKernelGGL((sae_backward_kernel<D>), gridf, block, 0, stream, (const uint32_t*)offs, (const uint32_t*)chunk_start, \
+                           (const int32_t*)pairs, topk_idx, topk_val, (const float*)dh,                                  \
+                           (const float*)dY, (const float*)sae_in, st->gW_dec, st->gW_enc, st->gb_enc, rowsq, d.d_in, k, max_chunks, gate); \
+        hipLaunchKernelGGL((sae_backward_seg_kernel<D>), dim3(ranged ? 2048 : 1024), dim3(ranged ? 512 : 256), 0, stream, (const uint32_t*)offs, \
+                           (const uint32_t*)seg_range, (const uint32_t*)n_long, (const int32_t*)pairs, topk_idx,         \
+                           topk_val, (const float*)dh, (const float*)dY, (const float*)sae_in, seg_rows, seg_b,          \
+                           d.d_in, k, max_segs, ranged, gate);                                                           \
+    }                                                                                                                  \
     hipLaunchKernelGGL((sae_backward_long_kernel<D>), dim3(256), block, 0, stream, (const int32_t*)long_list,           \
                        (const uint32_t*)n_long, (const float*)seg_rows, (const float*)seg_b, st->gW_dec, st->gW_enc,   \
                        st->gb_enc, rowsq, d.d_in, max_segs, gate)
@@ -1929,7 +1952,7 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         PV_LAUNCH_CHECK("sae_decode_kernel");
         const bool cs_here = bias_grads && !tc;
         rc = sae_csr_backward(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
-                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)d.d_in), cs_here, gate, stream, nullptr);
+                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)d.d_in), cs_here, gate, stream);
         if (rc) return rc;
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)
@@ -1949,60 +1972,140 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
 // The gated step in sparse form (pv_sae_gated_step_sparse; the dense form and the mathematics: pv_sae_gated_step, sae_dense.hip).
 // A gated SAE's forward is sparse in the OPEN GATES: feature_acts, relu(gate_pre) and every gradient behind them vanish where
 // gate_pre <= 0 (sae.py:703-716, :773-792).  The selection (relu_select_kernel<GATED>) leaves, per token, the list of its open gates
-// with both values per pair; from there the step is the k-sparse machinery run on 2 N "tokens", exactly as the dense form stacks
-// [feature_acts; relu(gate_pre)] into one 2N-row operand:
-//     rows [0, N):   val = feature_acts,    dY = d mse / d reconstruction,        dh = dP = dM e^r + dG,  sae_in = the encoder input
-//     rows [N, 2N):  val = relu(gate_pre),  dY = d aux / d (reconstruction via the gate),  dh = 0,        sae_in = 0
-// so that sae_csr_backward's  gW_dec[j] = sum val dY,  gW_enc^T[j] = sum dh sae_in,  gb_enc[j] = sum dh  are the gated step's
-// gW_dec (both decoder products), gW_enc^T and colsum(dP) (parked in gb_enc for gb_dec, as the dense form does).
+// with both values per pair {f = feature_acts, g = relu(gate_pre)}; from there the step is the k-sparse machinery with TWO decoder
+// terms per pair:
+//     decode (ONE gather of W_dec[j] per pair):  reconstruction = sum f W_dec[j] (+ LN-out, mse, dY, dM = (dY . W_dec[j]) [f > 0]),
+//                                                via the gate   = sum g W_dec[j] (aux loss against sae_in, dVia, dG = dVia . W_dec[j] + l1 / N)
+//     backward (bwd_walk<DUAL>):  gW_dec[j] = sum f dY[n] + g dVia[n],  gW_enc^T[j] = sum dP sae_in[n],  gb_enc[j] = sum dP = colsum(dP)
+//     with dP = dM e^r + dG (parked in gb_enc for gb_dec, as the dense form does)
 // ------------------------------------------------------------------------------------------------
 namespace {
-// encoder input as 2N rows (the second N zero) + the constant LN-out terms of the pass through the gate (no LN-out there: mu 0, std 1,
-// loss normaliser 1)
-__global__ __launch_bounds__(256) void gated_stage_kernel(const float* __restrict__ sae_in, float* __restrict__ sae_in2, int64_t n4,
-                                                          float* __restrict__ mu0, float* __restrict__ one, int n_tok,
-                                                          const uint32_t* __restrict__ gate) {
+template <int V4>
+__global__ __launch_bounds__(256) void gated_decode_kernel(
+    const float* __restrict__ x, const float* __restrict__ sae_in, const float* __restrict__ W_dec, const float* __restrict__ b_dec,
+    const int32_t* __restrict__ idx, const float* __restrict__ valf, const float* __restrict__ valg, const float* __restrict__ mu,
+    const float* __restrict__ sd, const float* __restrict__ norm, float* __restrict__ sae_out, float* __restrict__ dY,
+    float* __restrict__ dVia, float* __restrict__ dM, float* __restrict__ dG, float* __restrict__ mse_part, float* __restrict__ aux_part,
+    int n_tok, int d, int k, float grad_scale /* 2 / (N d_in) */, float aux_scale /* 2 / N */, float dh_add /* l1 / N */,
+    const uint32_t* __restrict__ tok_cnt, const uint32_t* __restrict__ gate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
     if (*gate != 0u) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_tok) { mu0[i] = 0.f; one[i] = 1.f; }
-    if (i >= 2 * n4) return;
-    const float4 v = i < n4 ? reinterpret_cast<const float4*>(sae_in)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(sae_in2)[i] = v;
+    bool ok[V4];
+    int col[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+    }
+    float4 af[V4], ag[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) { af[i] = make_float4(0.f, 0.f, 0.f, 0.f); ag[i] = af[i]; }
+    const int32_t* ir = idx + (int64_t)n * k;
+    const float* fr = valf + (int64_t)n * k;
+    const float* gr = valg + (int64_t)n * k;
+    const int k_walk = min(k, (int)((tok_cnt[n] + 3u) & ~3u));       // (slots beyond it are holes: g = 0)
+    for (int s = 0; s < k_walk; s += 4) {
+        float a[4], b[4];
+        float4 w[4][V4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ju = ir[s + u];
+            a[u] = fr[s + u];
+            b[u] = gr[s + u];
+            const float* wr = W_dec + (int64_t)ju * d;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i] && b[u] != 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                       // (slot order: fixed)
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                af[i].x += a[u] * w[u][i].x; af[i].y += a[u] * w[u][i].y; af[i].z += a[u] * w[u][i].z; af[i].w += a[u] * w[u][i].w;
+                ag[i].x += b[u] * w[u][i].x; ag[i].y += b[u] * w[u][i].y; ag[i].z += b[u] * w[u][i].z; ag[i].w += b[u] * w[u][i].w;
+            }
+    }
+    const float m = mu[n], sdv = sd[n], nf = norm[n];
+    float lf = 0.f, lg = 0.f;
+    float4 gf[V4], gg[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        gf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gg[i] = gf[i];
+        if (ok[i]) {
+            const float4 bd = *reinterpret_cast<const float4*>(b_dec + col[i]);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * d + col[i]);
+            const float4 sv = *reinterpret_cast<const float4*>(sae_in + (int64_t)n * d + col[i]);
+            float4 o, e;
+            o.x = (af[i].x + bd.x) * sdv + m; o.y = (af[i].y + bd.y) * sdv + m;          // as sae_decode_kernel / gated_finish_kernel
+            o.z = (af[i].z + bd.z) * sdv + m; o.w = (af[i].w + bd.w) * sdv + m;
+            e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
+            if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + col[i]) = o;
+            lf += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;
+            gf[i].x = grad_scale * e.x / nf * sdv; gf[i].y = grad_scale * e.y / nf * sdv;
+            gf[i].z = grad_scale * e.z / nf * sdv; gf[i].w = grad_scale * e.w / nf * sdv;
+            *reinterpret_cast<float4*>(dY + (int64_t)n * d + col[i]) = gf[i];
+            e.x = ag[i].x + bd.x - sv.x; e.y = ag[i].y + bd.y - sv.y; e.z = ag[i].z + bd.z - sv.z; e.w = ag[i].w + bd.w - sv.w;
+            lg += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;                          // sae.py:786-792
+            gg[i].x = aux_scale * e.x; gg[i].y = aux_scale * e.y; gg[i].z = aux_scale * e.z; gg[i].w = aux_scale * e.w;
+            *reinterpret_cast<float4*>(dVia + (int64_t)n * d + col[i]) = gg[i];
+        }
+    }
+    lf = wave_sum(lf);
+    lg = wave_sum(lg);
+    if (lane == 0) { mse_part[n] = lf; aux_part[n] = lg; }
+    for (int s = 0; s < k_walk; s += 4) {
+        float df[4], dg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ju = ir[s + u];
+            const bool live = gr[s + u] > 0.f;                    // (wave-uniform)
+            const float* wr = W_dec + (int64_t)ju * d;
+            float tf = 0.f, tg = 0.f;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                const float4 wv = ld4(wr + col[i], ok[i] && live);
+                tf += dot4(gf[i], wv);
+                tg += dot4(gg[i], wv);
+            }
+            df[u] = tf;
+            dg[u] = tg;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                df[u] += __shfl_xor(df[u], o, 64);
+                dg[u] += __shfl_xor(dg[u], o, 64);
+            }
+        if (lane < 4) {
+            const float sf = lane == 0 ? df[0] : (lane == 1 ? df[1] : (lane == 2 ? df[2] : df[3]));
+            const float sg = lane == 0 ? dg[0] : (lane == 1 ? dg[1] : (lane == 2 ? dg[2] : dg[3]));
+            dM[(int64_t)n * k + s + lane] = fr[s + lane] > 0.f ? sf : 0.f;                    // (dY W_dec^T) [f > 0]
+            dG[(int64_t)n * k + s + lane] = gr[s + lane] > 0.f ? sg + dh_add : 0.f;           // (dVia W_dec^T + l1 / N) [gate_pre > 0]
+        }
+    }
 }
 
-// threads [0, n_half): dh of the pair's two copies, the second copy's position in its feature's list (behind all first copies);
-// threads [n_half, n_half + F): the doubled counts (ALWAYS: the CSR kernels behind read them in either mode)
-__global__ __launch_bounds__(256) void gated_pairs_kernel(const int32_t* __restrict__ idx, uint32_t* __restrict__ wpos,
-                                                          const uint32_t* __restrict__ cnt_g, uint32_t* __restrict__ cnt2,
+// dP = dM e^r + dG per pair (sae.py:708-712 backwards); holes (never written by the decode kernel) -> 0
+__global__ __launch_bounds__(256) void gated_pairs_kernel(const int32_t* __restrict__ idx, const uint32_t* __restrict__ wpos,
                                                           const float* __restrict__ dM, const float* __restrict__ dG,
-                                                          const float* __restrict__ r_mag, float* __restrict__ dh2, int n_half, int F,
+                                                          const float* __restrict__ r_mag, float* __restrict__ dP, int n_pairs,
                                                           const uint32_t* __restrict__ gate) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_half) {
-        const int j = i - n_half;
-        if (j < F) cnt2[j] = 2u * cnt_g[j];
-        return;
-    }
-    if (*gate != 0u) return;
-    const uint32_t w = wpos[i];
-    float g = 0.f;
-    if (w != 0xffffffffu) {                                     // (a hole's dM / dG were never written)
-        const int j = idx[i];
-        g = dM[i] * expf(r_mag[j]) + dG[i];                    // dP = dM e^r + dG (sae.py:708-712 backwards)
-        wpos[n_half + i] = w + cnt_g[j];
-    }
-    dh2[i] = g;
-    dh2[n_half + i] = 0.f;
+    if (i >= n_pairs || *gate != 0u) return;
+    dP[i] = wpos[i] != 0xffffffffu ? dM[i] * expf(r_mag[idx[i]]) + dG[i] : 0.f;
 }
 
-// per feature, over the first copies of its list (ascending token order): gb_gate = sum dG, gb_mag = sum dM, gr_mag = sum dM (mag_pre
-// - b_mag) = sum dM f - b_mag gb_mag, pgsum = sum relu(gate_pre) (the decoder-norm factor of the L1 term), the firing count of
-// feature_acts + the statistics (train_sae.py:356-361).  One wave per feature.
+// per feature, over its list (ascending token order): gb_gate = sum dG, gb_mag = sum dM, gr_mag = sum dM (mag_pre - b_mag) = sum dM f -
+// b_mag gb_mag, pgsum = sum relu(gate_pre) (the decoder-norm factor of the L1 term), the firing count of feature_acts + the
+// statistics (train_sae.py:356-361).  One wave per feature.
 __global__ __launch_bounds__(256) void gated_feat_kernel(const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs,
-                                                         const float* __restrict__ val2, const float* __restrict__ dM,
-                                                         const float* __restrict__ dG, const float* __restrict__ b_mag, int n_half, int F,
-                                                         float* __restrict__ gb_gate, float* __restrict__ gb_mag,
-                                                         float* __restrict__ gr_mag, float* __restrict__ pgsum,
+                                                         const float* __restrict__ valf, const float* __restrict__ valg,
+                                                         const float* __restrict__ dM, const float* __restrict__ dG,
+                                                         const float* __restrict__ b_mag, int F, float* __restrict__ gb_gate,
+                                                         float* __restrict__ gb_mag, float* __restrict__ gr_mag, float* __restrict__ pgsum,
                                                          float* __restrict__ fire_count, float* __restrict__ act_freq,
                                                          float* __restrict__ n_since_fired, int update_stats,
                                                          const uint32_t* __restrict__ gate) {
@@ -2014,12 +2117,11 @@ __global__ __launch_bounds__(256) void gated_feat_kernel(const uint32_t* __restr
     float sg = 0.f, sm = 0.f, smf = 0.f, sp = 0.f, fired = 0.f;
     for (uint32_t q = beg + lane; q < end; q += 64) {
         const int p = pairs[q];
-        if (p >= n_half) continue;
-        const float f = val2[p], m = dM[p];
+        const float f = valf[p], m = dM[p];
         sg += dG[p];
         sm += m;
         smf += m * f;
-        sp += val2[n_half + p];
+        sp += valg[p];
         fired += f > 0.f ? 1.f : 0.f;
     }
     sg = wave_sum(sg); sm = wave_sum(sm); smf = wave_sum(smf); sp = wave_sum(sp); fired = wave_sum(fired);
@@ -2061,22 +2163,19 @@ __global__ __launch_bounds__(256) void gated_sparse_scalars_kernel(const float* 
 
 GatedSparseWs gated_sparse_carve(const pv_sae_desc& d, int n_tokens, int cap) {
     GatedSparseWs w;
-    w.rw = relu_carve(d, n_tokens, cap, 2);
+    w.rw = relu_carve(d, n_tokens, cap);
     size_t off = w.rw.total;
     auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
     const size_t N = (size_t)n_tokens, P = N * (size_t)cap;
+    w.valg = take(P * 4);
     w.dM = take(P * 4);
     w.dG = take(P * 4);
-    w.cnt2 = take((size_t)d.d_sae * 4);
-    w.mu0 = take(N * 4);
-    w.one = take(N * 4);
     w.l0part = take(N * 4);
-    w.sae_in2 = take(2 * N * (size_t)d.d_in * 4);
     w.total = off + 256;
     return w;
 }
 
-// dYs: [2N, d_in] (rows as above; the dense form's layout), auxpart: [N], pgsum: [d_sae] -- regions of the gated scratch the two
+// dYs: [2N, d_in] = [dY; dVia] (the dense form's layout), auxpart: [N], pgsum: [d_sae] -- regions of the gated scratch the two
 // forms share, so that everything behind them (the decoder-norm term, gb_dec) runs once.  Leaves colsum(dP) in st->gb_enc.
 int sae_gated_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int cap, float l1_coefficient,
                      int update_stats, unsigned char* rwb, const GatedSparseWs& gs, pv_sae_out* out, unsigned char* wsb, const SaeWs& ws,
@@ -2084,65 +2183,53 @@ int sae_gated_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N,
     const pv_sae_desc& d = plan->d;
     const pv_sae_gated& t = st->gt;
     const ReluWs& rw = gs.rw;
-    const int D = d.d_in, F = d.d_sae, n_half = N * cap;
+    const int D = d.d_in, F = d.d_sae, n_pairs = N * cap;
     const float ng = (float)n_global;
     uint32_t* mode = (uint32_t*)(rwb + rw.mode);
-    int32_t* idx2 = (int32_t*)(rwb + rw.idx);
-    float* val2 = (float*)(rwb + rw.val);
-    uint32_t* wpos2 = (uint32_t*)(rwb + rw.wpos);
+    int32_t* idx = (int32_t*)(rwb + rw.idx);
+    float* valf = (float*)(rwb + rw.val);
+    float* valg = (float*)(rwb + gs.valg);
+    uint32_t* wpos = (uint32_t*)(rwb + rw.wpos);
     uint32_t* tok_cnt = (uint32_t*)(rwb + rw.tok_cnt);
     float* l1part = (float*)(rwb + rw.l1part);
     float* l0part = (float*)(rwb + gs.l0part);
     float* dM = (float*)(rwb + gs.dM);
     float* dG = (float*)(rwb + gs.dG);
-    float* dh2 = (float*)(rwb + rw.dh);
-    uint32_t* cnt2 = (uint32_t*)(rwb + gs.cnt2);
-    uint32_t* cnt_g = (uint32_t*)(wsb + ws.cnt);
-    float* sae_in2 = (float*)(rwb + gs.sae_in2);
+    float* dP = (float*)(rwb + rw.dh);
     const float* sae_in = (const float*)(wsb + ws.sae_in);
+    float* dVia = dYs + (size_t)N * D;
     int rc;
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F) * 2.0);
-        rc = sae_encode_relu(d, st, N, cap, idx2, val2, tok_cnt, l1part, (uint32_t*)(rwb + rw.cand_cnt), rwb + rw.cand, cnt_g, wpos2, mode,
-                             (const float*)out->scalars, wsb, ws, stream, l0part);
+        rc = sae_encode_relu(d, st, N, cap, idx, valf, tok_cnt, l1part, (uint32_t*)(rwb + rw.cand_cnt), rwb + rw.cand,
+                             (uint32_t*)(wsb + ws.cnt), wpos, mode, (const float*)out->scalars, wsb, ws, stream, l0part, valg);
         if (rc) return rc;
     }
-    ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * n_half * (double)D * 2.0, 0.0);
-    const int64_t n4 = (int64_t)N * D / 4;
-    hipLaunchKernelGGL(gated_stage_kernel, dim3((unsigned)((2 * n4 + 255) / 256)), dim3(256), 0, stream, sae_in, sae_in2, n4,
-                       (float*)(rwb + gs.mu0), (float*)(rwb + gs.one), N, (const uint32_t*)mode);
-    PV_LAUNCH_CHECK("gated_stage_kernel");
+    ProfScope prof(PV_PROF_SAE_BWD, stream, 6.0 * n_pairs * (double)D * 2.0, 0.0);
     const dim3 grid((N + 3) / 4), block(256);
-    // the reconstruction (feature_acts; LN-out, mse, dY, dM) and the reconstruction through the gate (relu(gate_pre) against sae_in:
-    // sae.py:786-792; dG carries the L1 term's l1 / N as the ReLU step's dh does)
 #define CALL(V)                                                                                                                   \
-    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec,           \
-                       (const int32_t*)idx2, (const float*)val2, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),           \
-                       (const float*)(wsb + ws.norm), out->sae_out, dYs, dM, (float*)(wsb + ws.loss_part), N, D, cap,                \
-                       2.0f / (ng * (float)D), 1, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f,           \
-                       (const uint32_t*)tok_cnt, (const uint32_t*)mode);                                                              \
-    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, sae_in, (const float*)st->W_dec, (const float*)st->b_dec,      \
-                       (const int32_t*)idx2, (const float*)(val2 + n_half), (const float*)(rwb + gs.mu0), (const float*)(rwb + gs.one), \
-                       (const float*)(rwb + gs.one), (float*)nullptr, dYs + (size_t)N * D, dG, auxpart, N, D, cap, 2.0f / ng, 1,      \
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, l1_coefficient / ng,                      \
+    hipLaunchKernelGGL((gated_decode_kernel<V>), grid, block, 0, stream, x, sae_in, (const float*)st->W_dec, (const float*)st->b_dec, \
+                       (const int32_t*)idx, (const float*)valf, (const float*)valg, (const float*)(wsb + ws.mu),                    \
+                       (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dYs, dVia, dM, dG,                 \
+                       (float*)(wsb + ws.loss_part), auxpart, N, D, cap, 2.0f / (ng * (float)D), 2.0f / ng, l1_coefficient / ng,   \
                        (const uint32_t*)tok_cnt, (const uint32_t*)mode)
     V4_DISPATCH(D, CALL);
 #undef CALL
-    PV_LAUNCH_CHECK("sae_decode_kernel (gated)");
-    hipLaunchKernelGGL(gated_pairs_kernel, dim3((n_half + F + 255) / 256), block, 0, stream, (const int32_t*)idx2, wpos2,
-                       (const uint32_t*)cnt_g, cnt2, (const float*)dM, (const float*)dG, (const float*)t.r_mag, dh2, n_half, F,
-                       (const uint32_t*)mode);
+    PV_LAUNCH_CHECK("gated_decode_kernel");
+    hipLaunchKernelGGL(gated_pairs_kernel, dim3((n_pairs + 255) / 256), block, 0, stream, (const int32_t*)idx, (const uint32_t*)wpos,
+                       (const float*)dM, (const float*)dG, (const float*)t.r_mag, dP, n_pairs, (const uint32_t*)mode);
     PV_LAUNCH_CHECK("gated_pairs_kernel");
     SaeTail tb;
-    tb.dh = dh2; tb.chunk_start = (uint32_t*)(rwb + rw.cursor); tb.wpos = wpos2; tb.seg_range = (uint32_t*)(rwb + rw.seg_range);
+    tb.dh = dP; tb.chunk_start = (uint32_t*)(rwb + rw.cursor); tb.wpos = wpos; tb.seg_range = (uint32_t*)(rwb + rw.seg_range);
     tb.seg_rows = (float*)(rwb + rw.seg_rows); tb.seg_b = (float*)(rwb + rw.seg_b); tb.pairs = (int32_t*)(rwb + rw.pairs);
     tb.max_segs = rw.max_segs;
-    rc = sae_csr_backward(plan, st, 2 * N, cap, idx2, val2, dh2, dYs, sae_in2, out->scalars, nullptr, 0, false, tb, wsb, ws, nullptr, 0.f,
-                          false, mode, stream, cnt2);
+    rc = sae_csr_backward(plan, st, N, cap, idx, valf, dP, dYs, sae_in, out->scalars, nullptr, 0, false, tb, wsb, ws, nullptr, 0.f,
+                          false, mode, stream, valg, dVia);
     if (rc) return rc;
     hipLaunchKernelGGL(gated_feat_kernel, dim3((F + 3) / 4), block, 0, stream, (const uint32_t*)(wsb + ws.offs), (const int32_t*)tb.pairs,
-                       (const float*)val2, (const float*)dM, (const float*)dG, (const float*)t.b_mag, n_half, F, t.gb_gate, t.gb_mag,
-                       t.gr_mag, pgsum, out->fire_count, st->act_freq_scores, st->n_fwd_since_fired, update_stats, (const uint32_t*)mode);
+                       (const float*)valf, (const float*)valg, (const float*)dM, (const float*)dG, (const float*)t.b_mag, F, t.gb_gate,
+                       t.gb_mag, t.gr_mag, pgsum, out->fire_count, st->act_freq_scores, st->n_fwd_since_fired, update_stats,
+                       (const uint32_t*)mode);
     hipLaunchKernelGGL(gated_sparse_scalars_kernel, dim3(1), block, 0, stream, (const float*)(wsb + ws.loss_part), (const float*)auxpart,
                        (const float*)l1part, (const float*)l0part, N, 1.0f / (ng * (float)D), 1.0f / ng, l1_coefficient / ng,
                        1.0f / (float)N, out->scalars, (const uint32_t*)mode);

@@ -73,20 +73,21 @@ struct ReluWs {
     size_t total, mode, idx, val, tok_cnt, l1part, cand_cnt, cand, dh, cursor, wpos, seg_range, seg_rows, seg_b, pairs;
     int max_segs;
 };
-ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap, int copies = 1);
+ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap);
 // sae_enc.hip: the positive entries of relu(sae_in W_enc + b_enc) per token (see the definition); raises *mode when a token cannot be held
 int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
                     float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
-                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, float* l0part = nullptr);
+                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, float* l0part = nullptr,
+                    float* valg = nullptr);
 // sae.hip: the backward of a k-sparse step behind its decode kernel (see the definition)
 int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
                      const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
                      const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
-                     const uint32_t* gate, hipStream_t stream, const uint32_t* cnt_in);
+                     const uint32_t* gate, hipStream_t stream, const float* val_b = nullptr, const float* dYb = nullptr);
 // sae.hip: the gated step in sparse form (pv_sae_gated_step_sparse; see the definition)
 struct GatedSparseWs {
     ReluWs rw;
-    size_t total, dM, dG, cnt2, mu0, one, l0part, sae_in2;
+    size_t total, valg, dM, dG, l0part;
 };
 GatedSparseWs gated_sparse_carve(const pv_sae_desc& d, int n_tokens, int cap);
 int sae_gated_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, int n_global, int cap, float l1_coefficient,

@@ -25,6 +25,7 @@
 // its two row-major layouts without a transposed copy -- K-contiguous rows ([rows][K]: one 16-byte LDS read = four k-steps) or
 // row-contiguous k-slices ([K][rows]: four 4-byte LDS reads, lanes on consecutive rows).  f^T, dH^T, dY and sae_in of G4 / G5
 // are therefore the buffers as they lie, read "the other way".
+#include <algorithm>
 #include "sae.hpp"
 #include <cstring>
 
@@ -1155,15 +1156,15 @@ __global__ void gated_loss_kernel(float* __restrict__ scalars, const uint32_t* _
 // dP = dM e^r + dG, in place over dM (rows [0, N) of hs; dG = rows [N, 2N))
 __global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, const float* __restrict__ r_mag, int64_t n_rows, int F,
                                                        const uint32_t* __restrict__ gate) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (gate && *gate != 1u) return;
-    if (i >= n_rows * F) return;
-    const int c = (int)(i % F);
-    float4 a = *reinterpret_cast<const float4*>(hs + i);
-    const float4 g = *reinterpret_cast<const float4*>(hs + n_rows * F + i);
-    const float4 r = *reinterpret_cast<const float4*>(r_mag + c);
-    a.x = a.x * expf(r.x) + g.x; a.y = a.y * expf(r.y) + g.y; a.z = a.z * expf(r.z) + g.z; a.w = a.w * expf(r.w) + g.w;
-    *reinterpret_cast<float4*>(hs + i) = a;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n_rows * F; i += (int64_t)gridDim.x * 1024) {
+        const int c = (int)(i % F);
+        float4 a = *reinterpret_cast<const float4*>(hs + i);
+        const float4 g = *reinterpret_cast<const float4*>(hs + n_rows * F + i);
+        const float4 r = *reinterpret_cast<const float4*>(r_mag + c);
+        a.x = a.x * expf(r.x) + g.x; a.y = a.y * expf(r.y) + g.y; a.z = a.z * expf(r.z) + g.z; a.w = a.w * expf(r.w) + g.w;
+        *reinterpret_cast<float4*>(hs + i) = a;
+    }
 }
 
 // per feature: gr_mag = sum_n dM (mag_pre - b_mag) = sum_n dM f - b_mag gb_mag (dM != 0 only where f = mag_pre > 0);
@@ -1328,7 +1329,8 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         hipLaunchKernelGGL(gated_vec_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)sdmf, (const float*)t.gb_mag,
                            (const float*)t.gb_gate, (const float*)t.b_mag, (const float*)t.r_mag, t.gr_mag, st->gb_enc, F, mode);
         // dP = dM e^r + dG, then G5: gW_enc^T = dP^T @ sae_in
-        hipLaunchKernelGGL(gated_dp_kernel, dim3((unsigned)(((int64_t)N * F / 4 + 255) / 256)), dim3(256), 0, stream, hs,
+        // (a bounded grid walking the rows: in the sparse form's mode the launch is empty, and ~100k empty workgroups are 20 us)
+        hipLaunchKernelGGL(gated_dp_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)N * F / 4 + 255) / 256, 8192)), dim3(256), 0, stream, hs,
                            (const float*)t.r_mag, (int64_t)N, F, mode);
         PV_LAUNCH_CHECK("gated elementwise kernels");
         DenseGemm g5 = {};

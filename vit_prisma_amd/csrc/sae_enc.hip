@@ -847,23 +847,21 @@ __global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__
 // One workgroup per token: candidates -> exact values -> the positive ones, ranked by (value desc, feature asc) -> idx / val /
 // wpos [cap] (holes: val 0, wpos ~0), tok_cnt, the token's sum of activations (the L1 term).
 // GATED (pv_sae_gated_step_sparse): b_enc = b_gate, the list = the features whose GATE is open (gate_pre = sae_in W_enc + b_gate > 0,
-// sae.py:703-706), ranked by gate_pre.  The token's rows are written twice, n_tok rows apart -- the step's backward walks
-// [feature_acts; relu(gate_pre)] as 2 n_tok tokens, like the dense form stacks them: rows [0, n_tok) hold feature_acts = relu(p e^r_mag +
-// b_mag) of the same pairs (0 where the magnitude path is shut: such a pair still carries the gate path's gradient), rows
-// [n_tok, 2 n_tok) relu(gate_pre); idx is the same in both, wpos of the second copy is the first's (the step adds the feature's count).
-// l0part = the token's count of feature_acts > 0.
+// sae.py:703-706), ranked by gate_pre.  A pair carries two values: val_out = feature_acts = relu(p e^r_mag + b_mag) (0 where the
+// magnitude path is shut: such a pair still carries the gate path's gradient), valg_out = relu(gate_pre).  l0part = the token's count of
+// feature_acts > 0.
 template <int V4, bool GATED = false>
 __global__ __launch_bounds__(256) void relu_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ thr, int32_t* __restrict__ idx_out,
     float* __restrict__ val_out, uint32_t* __restrict__ tok_cnt, float* __restrict__ l1part, uint32_t* __restrict__ feat_cnt,
     uint32_t* __restrict__ wpos, uint32_t* __restrict__ mode, int d, int cap, int ntn, int slots,
-    const float* __restrict__ r_mag = nullptr, const float* __restrict__ b_mag = nullptr, float* __restrict__ l0part = nullptr) {
+    const float* __restrict__ r_mag = nullptr, const float* __restrict__ b_mag = nullptr, float* __restrict__ l0part = nullptr,
+    float* __restrict__ valg_out = nullptr) {
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ float rval[PV_SAE_CAND_CAP];
     __shared__ float rmag[GATED ? PV_SAE_CAND_CAP : 1];
     __shared__ uint32_t sh_l0;
-    const int64_t half = GATED ? (int64_t)gridDim.x * cap : 0;       // (the second copy of the token's rows)
     __shared__ uint32_t tcnt[256];
     __shared__ float sval[256];                              // the kept values in rank order (cap <= 256)
     __shared__ float red[4];
@@ -975,11 +973,7 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
             idx_out[row * cap + s] = 0;
             val_out[row * cap + s] = 0.f;
             wpos[row * cap + s] = 0xffffffffu;
-            if constexpr (GATED) {
-                idx_out[half + row * cap + s] = 0;
-                val_out[half + row * cap + s] = 0.f;
-                wpos[half + row * cap + s] = 0xffffffffu;
-            }
+            if constexpr (GATED) valg_out[row * cap + s] = 0.f;
         }
         return;
     }
@@ -1002,9 +996,7 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
         if constexpr (GATED) {
             const float f = rmag[c];
             val_out[row * cap + rank] = f;
-            idx_out[half + row * cap + rank] = ic;
-            val_out[half + row * cap + rank] = vc;
-            wpos[half + row * cap + rank] = wp;
+            valg_out[row * cap + rank] = vc;
             myl0 += f > 0.f ? 1u : 0u;
         } else {
             val_out[row * cap + rank] = vc;
@@ -1015,11 +1007,7 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
         idx_out[row * cap + s] = 0;
         val_out[row * cap + s] = 0.f;
         wpos[row * cap + s] = 0xffffffffu;
-        if constexpr (GATED) {
-            idx_out[half + row * cap + s] = 0;
-            val_out[half + row * cap + s] = 0.f;
-            wpos[half + row * cap + s] = 0xffffffffu;
-        }
+        if constexpr (GATED) valg_out[row * cap + s] = 0.f;
     }
     if (GATED && myl0) atomicAdd(&sh_l0, myl0);
     __syncthreads();
@@ -1106,8 +1094,8 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
 
 int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap, int32_t* idx, float* val, uint32_t* tok_cnt,
                     float* l1part, uint32_t* cand_cnt, void* cand, uint32_t* feat_cnt, uint32_t* wpos, uint32_t* mode,
-                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, float* l0part) {
-    // l0part != NULL: the gated form (see relu_select_kernel) -- the bias is b_gate, idx / val / wpos hold 2 N rows
+                    const float* prev_scalars, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, float* l0part, float* valg) {
+    // l0part != NULL: the gated form (see relu_select_kernel) -- the bias is b_gate, val = feature_acts, valg = relu(gate_pre)
     const bool gated = l0part != nullptr;
     const float* bias = gated ? (const float*)st->gt.b_gate : (const float*)st->b_enc;
     PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
@@ -1131,7 +1119,7 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
         hipLaunchKernelGGL((relu_select_kernel<D, true>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),          \
                            (const float*)st->W_encT, bias, (const uint32_t*)cand_cnt, (const int2*)cand,                           \
                            (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn,        \
-                           PV_SAE_RELU_SLOTS, (const float*)st->gt.r_mag, (const float*)st->gt.b_mag, l0part);                     \
+                           PV_SAE_RELU_SLOTS, (const float*)st->gt.r_mag, (const float*)st->gt.b_mag, l0part, valg);               \
     else                                                                                                                        \
         hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                \
                            (const float*)st->W_encT, bias, (const uint32_t*)cand_cnt, (const int2*)cand,                           \
