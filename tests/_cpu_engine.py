@@ -284,3 +284,66 @@ class OracleGatedEngine(OracleEngine):
         O.adam_step(P, g, m, v, lr, self.adam_step)
         self.params["W_enc"].copy_(self.W_encT.t())
 
+
+
+class OracleTranscoderEngine(OracleEngine):
+    """The twin of a NativeSAE built with ``b_dec_out`` / ``W_skip`` (pv_sae_state.tc) on its top-k step: the oracle's transcoder form
+    (target activation, the decoder's own bias, the skip matrix)."""
+    transcoder = True
+
+    def __init__(self, sae, k: int, max_tokens: int):
+        super().__init__(sae, k, max_tokens)
+        self.extra = [n for n in ("b_dec_out", "W_skip") if getattr(sae, n, None) is not None]
+        for n in self.extra:
+            self.params[n] = getattr(sae, n).data
+        nW = self.d_in * self.d_sae
+        base = 2 * nW + self.d_sae + self.d_in
+        sizes = {"b_dec_out": self.d_in, "W_skip": self.d_in * self.d_in}
+        self.n_flat = base + sum(sizes[n] for n in self.extra)
+        self.flat_g, self.flat_m, self.flat_v = (torch.zeros(self.n_flat) for _ in range(3))
+
+        def views(flat):
+            v = dict(W_encT=flat[:nW].view(self.d_sae, self.d_in), W_dec=flat[nW:2 * nW].view(self.d_sae, self.d_in),
+                     b_enc=flat[2 * nW:2 * nW + self.d_sae], b_dec=flat[2 * nW + self.d_sae:base])
+            off = base
+            for n in self.extra:
+                v[n] = flat[off:off + sizes[n]].view(self.params[n].shape)
+                off += sizes[n]
+            return v
+
+        self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
+
+    def step(self, x, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=False, sparse_grads=False,
+             target=None):
+        assert target is not None
+        if renorm_decoder:
+            self.renorm_decoder()
+        P, xn, yn = self._P(), x.numpy(), target.numpy()
+        bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
+        fw = O.sae_forward(P, xn, self.k, batch_mean=bm, n_global=n_global, target=yn)
+        g = O.sae_backward(P, xn, fw, n_global=n_global)
+        self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
+        for n in ["W_dec", "b_enc", "b_dec"] + self.extra:
+            self._g[n].copy_(torch.from_numpy(g[n]))
+        self.fire_count.copy_(torch.from_numpy((fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)))
+        self.scalars[0], self.scalars[1], self.scalars[2] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"])
+        if update_stats:
+            self.act_freq_scores += self.fire_count
+            self.n_fwd_since_fired += 1
+            self.n_fwd_since_fired[self.fire_count > 0] = 0
+
+    def apply(self, lr, max_grad_norm, j_lo=0, j_hi=None):
+        assert j_lo == 0 and j_hi in (None, self.d_sae)
+        self.adam_step += 1
+        total = float(self.scalars[3]) ** 0.5
+        coef = min(max_grad_norm / (total + 1e-6), 1.0) if max_grad_norm else 1.0
+        names = ["W_encT", "W_dec", "b_enc", "b_dec"] + self.extra
+        W = {"W_encT": self.W_encT, **{n: self.params[n] for n in names[1:]}}
+        P = {n: W[n].numpy() for n in names}
+        g = {n: (self._g[n] * coef).numpy().copy() for n in names}
+        m = {n: self._m[n].numpy() for n in names}
+        v = {n: self._v[n].numpy() for n in names}
+        par = (g["W_dec"] * P["W_dec"]).sum(axis=1, keepdims=True)
+        g["W_dec"] -= par * P["W_dec"]
+        O.adam_step(P, g, m, v, lr, self.adam_step)
+        self.params["W_enc"].copy_(self.W_encT.t())

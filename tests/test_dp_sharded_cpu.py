@@ -259,3 +259,88 @@ def test_gated_data_parallel_step_equals_single_process_oracle():
             assert rel_fro(out[n], P[n]) < 2e-5, (rank, n)
         assert np.array_equal(out["b_enc"], init["b_enc"])
         assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
+
+
+# ---- top-k Transcoder, data parallel: VisionSAETrainer._native_dp_step's transcoder branch (the TARGET's global mean, one all-reduce
+# of the whole flat gradient buffer -- b_dec_out and W_skip ride in it -- replicated optimizer)
+def _tc_init():
+    init = dict(synth_sae_state(D_IN, D_SAE, 0))
+    rs = np.random.RandomState(5)
+    init["b_dec_out"] = (rs.standard_normal(D_IN) * 0.05).astype(np.float32)
+    init["W_skip"] = (rs.standard_normal((D_IN, D_IN)) / np.sqrt(D_IN) * 0.3).astype(np.float32)
+    return init
+
+
+def _tc_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from vit_prisma_amd.sae import Transcoder, VisionModelSAERunnerConfig, VisionSAETrainer
+    from _cpu_engine import OracleTranscoderEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN, activation_fn_str="topk",
+        activation_fn_kwargs={"k": K}, normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N, lr=1e-3,
+        max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0, seed=7 + rank,
+        is_transcoder=True, transcoder_with_skip_connection=True, d_out=D_IN, out_hook_point_layer=1)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None)
+    sae = tr.sparse_coder
+    assert type(sae) is Transcoder
+    if rank == 0:
+        with torch.no_grad():
+            for n, v in _tc_init().items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+    tr._native_kind = lambda *a, **k: "topk"
+
+    def get_engine(s, n_tokens):
+        if tr._engine is None:
+            for p in s.parameters():
+                dist.broadcast(p.data, src=0)
+            tr._engine = OracleTranscoderEngine(s, K, n_tokens)
+        return tr._engine
+
+    tr._get_engine = get_engine
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    losses = []
+    h = N // world
+    for t in range(STEPS):
+        pair = torch.stack([torch.from_numpy(synth_sae_batch(N, D_IN, seed=t)), torch.from_numpy(synth_sae_batch(N, D_IN, seed=100 + t))],
+                           dim=1)[rank * h:(rank + 1) * h].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=pair, n_training_steps=t, n_training_tokens=t * N)
+        losses.append((float(loss), float(mse), float(l0)))
+        assert tr.last_step_native and l1 is None
+    out = {n: p.detach().numpy().copy() for n, p in sae.named_parameters()}
+    q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy(), frac))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_topk_transcoder_data_parallel_step_equals_single_process_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = {k: v.copy() for k, v in _tc_init().items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    want = [O.train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), K, lr=1e-3, step=t + 1, target=synth_sae_batch(N, D_IN, seed=100 + t))
+            for t in range(STEPS)]
+    for rank, out, losses, act, since, frac in got:
+        for t, (loss, mse, l0) in enumerate(losses):
+            assert abs(loss - want[t]["loss"]) <= 1e-5 * want[t]["loss"] and abs(mse - want[t]["mse_loss"]) <= 1e-5 * want[t]["mse_loss"]
+            assert abs(l0 - want[t]["l0"]) <= 1e-6 * want[t]["l0"]
+        for n in P:
+            assert rel_fro(out[n], P[n]) < 2e-5, (rank, n)
+            assert np.array_equal(out[n], got[0][1][n]), (rank, n)          # replicas stay identical
+        assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
+        assert frac == N * STEPS

@@ -264,6 +264,14 @@ def test_native_data_parallel_world2_equals_single_process_oracle():
     assert leg_tps > 0 and e2e_tps > 0
 
 
+def _tc_init(d_in, d_sae):
+    init = dict(synth_sae_state(d_in, d_sae, 0))
+    rs = np.random.RandomState(5)
+    init["b_dec_out"] = (rs.standard_normal(d_in) * 0.05).astype(np.float32)
+    init["W_skip"] = (rs.standard_normal((d_in, d_in)) / np.sqrt(d_in) * 0.3).astype(np.float32)
+    return init
+
+
 def _rccl_world1_worker(port, q, mode):
     """ONE rank in a process group on the nccl backend (= RCCL on ROCm): the trainer is told to take its multi-rank code paths
     (force_distributed_paths), so every collective of the 8-GPU job -- the in-place reduce_scatter_tensor of the gradient rows,
@@ -278,14 +286,22 @@ def _rccl_world1_worker(port, q, mode):
     dev = torch.device("cuda:0")
     d_in, d_sae, k, N = 768, 6144, 32, 1024
     relu = mode == "relu_dp"
+    tc = mode == "topk_tc_dp"
     cfg = VisionModelSAERunnerConfig(
         hook_point_layer=1, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in,
         activation_fn_str="relu" if relu else "topk", activation_fn_kwargs={} if relu else {"k": k}, l1_coefficient=3e-3,
         normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda",
-        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0)
-    sae = StandardSparseAutoencoder(cfg)
+        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
+        **(dict(is_transcoder=True, transcoder_with_skip_connection=True, d_out=d_in, out_hook_point_layer=1) if tc else {}))
+    if tc:
+        from vit_prisma_amd.sae import Transcoder
+        sae = Transcoder(cfg)
+        init = _tc_init(d_in, d_sae)
+    else:
+        sae = StandardSparseAutoencoder(cfg)
+        init = synth_sae_state(d_in, d_sae, 0)
     with torch.no_grad():
-        for n, v in synth_sae_state(d_in, d_sae, 0).items():
+        for n, v in init.items():
             getattr(sae, n).copy_(torch.from_numpy(v))
     tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True).force_distributed_paths(True)
     tr.use_feature_parallel(mode == "topk_tp")
@@ -293,22 +309,24 @@ def _rccl_world1_worker(port, q, mode):
     out = []
     for t in range(3):
         x = torch.from_numpy(synth_sae_batch(N, d_in, seed=10 + t)).to(dev)[:, None, :].contiguous()
+        if tc:
+            x = torch.cat([x, torch.from_numpy(synth_sae_batch(N, d_in, seed=60 + t)).to(dev)[:, None, :]], dim=1).contiguous()
         loss, mse, l1, l0, act, since, frac = tr.train_step(
             sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
             n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t, n_training_tokens=t * N)
         assert tr.last_step_native
         out.append((float(loss), float(l0)))
     took = {"topk_dp": tr._engine is not None and tr._fp is None and not tr._engine.lazy_w_enc,
-            "topk_tp": tr._fp is not None, "relu_dp": tr._engine is not None}[mode]
+            "topk_tp": tr._fp is not None, "relu_dp": tr._engine is not None,
+            "topk_tc_dp": tr._engine is not None and tr._engine.transcoder and tr._fp is None}[mode]
     tr.sync_parameters()
-    q.put((out, {n: getattr(sae, n).detach().cpu().numpy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}, act.cpu().numpy(), took,
-           dist.get_backend()))
+    q.put((out, {n: getattr(sae, n).detach().cpu().numpy() for n in init}, act.cpu().numpy(), took, dist.get_backend()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["topk_dp", "topk_tp", "relu_dp"])
+@pytest.mark.parametrize("mode", ["topk_dp", "topk_tp", "relu_dp", "topk_tc_dp"])
 def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
     """the trainer's data-parallel step (sharded optimizer), its feature-parallel step and the dense step's
     data-parallel form, each through torch.distributed on the NCCL backend (RCCL) with a world of one rank, against the
@@ -326,12 +344,13 @@ def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
     assert p.exitcode == 0 and took and backend == "nccl"
     d_in, d_sae, k, N = 768, 6144, 32, 1024
     relu = mode == "relu_dp"
-    P = {kk: v.copy() for kk, v in synth_sae_state(d_in, d_sae, 0).items()}
+    tc = mode == "topk_tc_dp"                    # (a top-k Transcoder with the skip connection: the token-sharded step's transcoder branch)
+    P = {kk: v.copy() for kk, v in (_tc_init(d_in, d_sae) if tc else synth_sae_state(d_in, d_sae, 0)).items()}
     opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
     stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
     for t in range(3):
         ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=10 + t), None if relu else k, lr=1e-3, step=t + 1,
-                           l1_coefficient=3e-3 if relu else 0.0)
+                           l1_coefficient=3e-3 if relu else 0.0, target=synth_sae_batch(N, d_in, seed=60 + t) if tc else None)
         assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
     # (relu_dp runs from the synthetic init, where half of all pre-activations are positive: a few of the 6.3 M per step lie within fp32
     # summation noise of zero and take the other side of the ReLU than numpy's; Adam turns those entries into lr-sized differences --
@@ -1273,7 +1292,7 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
 
 
-@pytest.mark.parametrize("kind", ["gated", "relu_transcoder"])
+@pytest.mark.parametrize("kind", ["gated", "relu_transcoder", "topk_transcoder"])
 def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
     """The data-parallel form of the gated step and of the ReLU transcoder step (batch_mean / n_global: tokens sharded over ranks,
     gradients summed by the caller): two half batches with the GLOBAL mean and token count give gradients and losses that add up
@@ -1288,7 +1307,7 @@ def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
     else:
         kw["b_dec_out"] = torch.from_numpy((rs.standard_normal(d_in) * 0.05).astype(np.float32)).cuda()
         kw["W_skip"] = torch.from_numpy((rs.standard_normal((d_in, d_in)) / np.sqrt(d_in) * 0.3).astype(np.float32)).cuda()
-    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 1, True, n, **kw)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], 16 if kind == "topk_transcoder" else 1, True, n, **kw)
     x = torch.from_numpy(synth_sae_batch(n, d_in, seed=0)).cuda()
     y = torch.from_numpy(synth_sae_batch(n, d_in, seed=50)).cuda()
     ref = y if kind != "gated" else x
@@ -1296,6 +1315,8 @@ def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
     def run(xs, ys, **kk):
         if kind == "gated":
             eng.gated_step(xs, l1c, update_stats=False, **kk)
+        elif kind == "topk_transcoder":
+            eng.step(xs, update_stats=False, renorm_decoder=True, target=ys, **kk)
         else:
             eng.dense_step(xs, l1c, update_stats=False, target=ys, **kk)
         torch.cuda.synchronize()

@@ -197,9 +197,9 @@ class VisionSAETrainer:
         cfg = sae.cfg
         from .variants import Transcoder
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
-        # no ghost gradients; with a process group on the dense (ReLU) step only
+        # no ghost gradients; with a process group the tokens are sharded and the optimizer replicated (one all-reduce of the flat
+        # gradient buffer: _native_dense_step for ReLU, _native_dp_step's transcoder branch for top-k)
         is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in)
-                 and (not self._mr or cfg.activation_fn_str == "relu")             # (multi-rank: on the dense step only)
                  and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own dense step (pv_sae_gated_step)
@@ -386,7 +386,7 @@ class VisionSAETrainer:
         kind = self._native_kind(sae, x)
         if kind in ("relu", "gated"):
             return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired, gated=kind == "gated")
-        if self._use_tp(sae):
+        if self._use_tp(sae) and not self.is_transcoder:        # (the feature-parallel step serves the plain SAE)
             return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         self._dp_flush()                                        # parameters of the previous step must have landed
         eng = self._get_engine(sae, x.shape[0])
@@ -514,11 +514,34 @@ class VisionSAETrainer:
         import torch.distributed as dist
         W = self.world
         n_global = x.shape[0] * W
+        d_in, d_sae = eng.d_in, eng.d_sae
+        if eng.transcoder:
+            # a top-k Transcoder (b_dec_out, W_skip beside the four tensors the row shards know): tokens sharded, the mean of the
+            # TARGET all-reduced (its loss normaliser, transcoder.py:78), ONE all-reduce of the whole flat gradient buffer and a
+            # replicated optimizer, as the dense step's multi-rank form
+            bm = self._target.float().sum(dim=0)
+            dist.all_reduce(bm)
+            eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True, target=self._target)
+            if self._small is None or self._small.numel() != d_sae + 3:
+                self._small = torch.empty(d_sae + 3, dtype=torch.float32, device=x.device)
+            small = self._small
+            small[:d_sae].copy_(eng.fire_count)
+            small[d_sae:].copy_(eng.scalars[:3])
+            dist.all_reduce(eng.flat_g)
+            dist.all_reduce(small)                              # fire counts | loss, mse, l0 in one bucket
+            fire = small[:d_sae]
+            eng.scalars[:3].copy_(small[d_sae:])
+            eng.scalars[2] /= W
+            n_since_fired += 1
+            n_since_fired[fire > 0] = 0
+            act_freq_scores += fire
+            eng.grad_sqnorm()
+            eng.apply(lr, self.cfg.max_grad_norm)
+            return
         bm = x.float().sum(dim=0)
         dist.all_reduce(bm)                                     # global batch mean (sae.py:145)
         eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
         shard = self._shard(eng.d_sae)
-        d_in, d_sae = eng.d_in, eng.d_sae
         if self._small is None or self._small.numel() != d_in + d_sae + 3:
             self._small = torch.empty(d_in + d_sae + 3, dtype=torch.float32, device=x.device)
         small = self._small
