@@ -425,7 +425,7 @@ def main():
     peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
     gemm_tf = gemm["flops"] / max(gemm["ms"], 1e-9) / 1e9
     roofline = {
-        "kernel": "gemm_kernel_v7 family (bf16 MFMA GEMM, 320x256 tile per CU, fused bias / activation / residual / tap-store epilogues; + the patch-embed and head GEMMs)",
+        "kernel": "gemm_kernel_v8 / v7 family (bf16 MFMA GEMM, 320x256 tile, fused bias / activation / residual / tap-store epilogues; v8 = the persistent form, one workgroup per CU walking its tiles, where a launch has more tiles than CUs; + the patch-embed and head GEMMs)",
         "bound": "mfma", "achieved": round(gemm_tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
         "frac": round(gemm_tf / peak_tf, 4),
         "launches": gemm["launches"], "avg_launch_us": round(gemm["ms"] * 1e3 / max(gemm["launches"], 1), 2),

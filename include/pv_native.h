@@ -302,7 +302,9 @@ typedef struct pv_sae_desc {
  *   - loss, normaliser and `batch_mean` are the TARGET's (`target` [n_tokens, d_in], set before every step; :78);
  *   - the clip norm covers the two extra tensors, pv_sae_apply runs plain Adam on them with the same clip coefficient
  *     (PV_SAE_SPARSE_GRADS works as for the plain step).
- * pv_sae_step: single process only; pv_sae_dense_step also with tokens sharded over ranks (batch_mean = the target's global mean); the feature-parallel entry points refuse a transcoder state.  d_out == d_in. */
+ * pv_sae_step and pv_sae_dense_step: also with tokens sharded over ranks (batch_mean = the TARGET's global mean, n_global = the global
+ * token count; the caller all-reduces the flat gradient buffer); the feature-parallel entry points refuse a transcoder state.
+ * d_out == d_in. */
 typedef struct pv_sae_transcoder {
     float *b_dec_out, *gb_dec_out, *mb_dec_out, *vb_dec_out;   /* [d_in]                                              */
     float *W_skip, *gW_skip, *mW_skip, *vW_skip;               /* [d_in, d_in] (row o = output coordinate) or all NULL */

@@ -2281,7 +2281,8 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     // transcoder (pv_sae_state.tc): the loss is taken against tc.target, the decoder adds b_dec_out and the skip term
     const bool tc = sae_is_tc(st);
     if (tc) {
-        PV_REQUIRE(n_global == N, "transcoder on the top-k step: single process");
+        // (token-sharded form: batch_mean = the TARGET's global mean -- the x-side normaliser sae_prep derives from it is overwritten by
+        // sae_tc_target_norm below, as in the dense step)
         const int rq = sae_tc_require(d, st, N);
         if (rq) return rq;
     }
