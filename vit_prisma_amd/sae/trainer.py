@@ -193,7 +193,8 @@ class VisionSAETrainer:
     # ---- native engine ----------------------------------------------------------------------------
     def _native_kind(self, sae, x: torch.Tensor) -> Optional[str]:
         """Which fused HIP step serves this SAE: "topk" (k-sparse step, sae.hip), "relu" (dense ReLU + L1 step,
-        sae_dense.hip), "gated" (the gated SAE's dense step, sae_dense.hip) or None (PyTorch path: gated / ghost gradients on top-k / other activations / CPU)."""
+        sae_dense.hip), "gated" (the gated SAE's step: sparse where the batch allows it, sae.hip / sae_dense.hip) or None (PyTorch path: the top-k
+        gated form / other activations / d_out != d_in / CPU)."""
         cfg = sae.cfg
         from .variants import Transcoder
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
@@ -202,7 +203,8 @@ class VisionSAETrainer:
         is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in)
                  and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
         from .variants import GatedSparseAutoencoder
-        # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own dense step (pv_sae_gated_step)
+        # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own step (pv_sae_gated_step_sparse: the open gates
+        # as per-token lists where the batch allows it, the dense GEMMs of pv_sae_gated_step otherwise -- decided on the GPU)
         is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.activation_fn_str == "relu"
                     and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0)
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
@@ -418,8 +420,8 @@ class VisionSAETrainer:
         return sc[0], sc[1], None, sc[2]
 
     def _native_dense_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired, gated: bool = False):
-        """ReLU + L1 (sae.py:617-626; also a ReLU Transcoder) on the dense fused step (pv_sae_dense_step), or a Gated SAE on
-        pv_sae_gated_step.  Multi-rank: tokens sharded, ONE all-reduce of the flat gradient buffer and a replicated optimizer (the
+        """ReLU + L1 (sae.py:617-626; also a ReLU Transcoder) on pv_sae_relu_step / pv_sae_dense_step, or a Gated SAE on
+        pv_sae_gated_step_sparse.  Multi-rank: tokens sharded, ONE all-reduce of the flat gradient buffer and a replicated optimizer (the
         step is 6-11 ms of fp32 GEMMs: the 151 MB are not what bounds it), statistics and losses over the global batch like every
         other path."""
         self._dp_flush()
