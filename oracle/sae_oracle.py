@@ -219,10 +219,12 @@ def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dic
 
 # ---- Gated SAE (sae/sae.py:648-792), ReLU activation ----------------------------------------------------------------------
 def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coefficient: float = 0.0,
-                  batch_mean: Optional[Array] = None, n_global: Optional[int] = None) -> Dict[str, Array]:
-    """GatedSparseAutoencoder.forward (:730-771) with activation_fn_str = "relu": gate path (sae_in @ W_enc + b_gate) > 0 (:703-706),
-    magnitude path with shared weights sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712), L1 on relu(gate pre-activation)
-    weighted by the decoder row norms (:780-784), auxiliary reconstruction of sae_in through the gate (:786-792)."""
+                  batch_mean: Optional[Array] = None, n_global: Optional[int] = None, k: Optional[int] = None) -> Dict[str, Array]:
+    """GatedSparseAutoencoder.forward (:730-771): gate path (sae_in @ W_enc + b_gate) > 0 (:703-706), magnitude path with shared weights
+    sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712), auxiliary reconstruction of sae_in through the gate (:786-792).
+    k = None: activation_fn_str = "relu" -- magnitudes relu(mag_pre), gate activations relu(gate_pre), L1 on them weighted by the
+    decoder row norms (:780-784).  k given: activation_fn_str = "topk" -- BOTH go through TopK (:795-810; magnitudes :714, gate
+    activations :773-778) and there is no L1 term (:741-745)."""
     dt = x.dtype.type
     N, d = x.shape
     if layer_norm:
@@ -233,31 +235,44 @@ def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coe
     gate_pre = S @ P["W_enc"] + P["b_gate"]
     active = gate_pre > 0
     mag_pre = S @ (P["W_enc"] * np.exp(P["r_mag"])) + P["b_mag"]
-    feats = np.where(active, np.maximum(mag_pre, dt(0)), dt(0))
+    if k is None:
+        mags = np.maximum(mag_pre, dt(0))
+        pg = np.maximum(gate_pre, dt(0))                               # _compute_gate_activation :773-778
+    else:
+        mags, pg = np.zeros_like(mag_pre), np.zeros_like(gate_pre)
+        idx, vals = topk_mask(mag_pre, k)
+        np.put_along_axis(mags, idx, vals, axis=-1)
+        idx, vals = topk_mask(gate_pre, k)
+        np.put_along_axis(pg, idx, vals, axis=-1)
+    feats = np.where(active, mags, dt(0))
     pre_out = feats @ P["W_dec"] + P["b_dec"]
     sae_out = pre_out * std + mu if layer_norm else pre_out
     bm = x.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)      # (data-parallel form: the GLOBAL batch's)
     ng = N if n_global is None else n_global
     nf = np.sqrt(((x - bm) ** 2).sum(axis=-1, keepdims=True))
     mse = ((sae_out - x) ** 2 / nf).sum() / dt(ng * d)
-    pg = np.maximum(gate_pre, dt(0))                                   # _compute_gate_activation :773-778
     wn = np.linalg.norm(P["W_dec"], axis=1)
-    l1 = dt(l1_coefficient) * ((pg * wn).sum(axis=-1).sum() / dt(ng))
+    l1 = dt(l1_coefficient) * ((pg * wn).sum(axis=-1).sum() / dt(ng)) if k is None else dt(0)
     via = pg @ P["W_dec"] + P["b_dec"]
     aux = ((via - S) ** 2).sum(axis=-1).sum() / dt(ng)
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()
     return dict(sae_in=S, gate_pre=gate_pre, mag_pre=mag_pre, feature_acts=feats, pg=pg, via=via, sae_out=sae_out, mu=mu, std=std,
-                norm_factor=nf, wn=wn, n_global=ng, loss=dt(mse + l1 + aux), mse_loss=dt(mse), l1_loss=dt(l1), aux_loss=dt(aux), l0=l0)
+                norm_factor=nf, wn=wn, n_global=ng, loss=dt(mse + l1 + aux), mse_loss=dt(mse), l1_loss=dt(l1), aux_loss=dt(aux), l0=l0,
+                topk=k is not None)
 
 
 def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True, l1_coefficient: float = 0.0,
                    gates: Optional[Tuple[Array, Array]] = None) -> Dict[str, Array]:
     """loss.backward() of the gated forward.  b_enc takes no part in it (its .grad stays None in the reference: no entry here).
-    gates = (feature_acts > 0, gate_pre > 0) to use instead of the oracle's own (tests: entries within summation noise of zero)."""
+    gates = (feature_acts > 0, gate_pre > 0) to use instead of the oracle's own (tests: entries within summation noise of zero).
+    Top-k form (fw["topk"]): the gradient reaches the kept entries only (TopK's scatter + its ReLU), and there is no L1 term."""
     dt = x.dtype.type
     N, d = x.shape
     S, feats, pg = fw["sae_in"], fw["feature_acts"], fw["pg"]
-    on_f, on_g = (feats > 0, fw["gate_pre"] > 0) if gates is None else gates
+    topk = bool(fw.get("topk", False))
+    if topk:
+        l1_coefficient = 0.0
+    on_f, on_g = (feats > 0, (pg > 0) if topk else (fw["gate_pre"] > 0)) if gates is None else gates
     N = fw["n_global"]                                                 # (every mean is over the global batch)
     d_out = dt(2.0) * (fw["sae_out"] - x) / fw["norm_factor"] / dt(N * d)
     dY = d_out * fw["std"] if layer_norm else d_out
@@ -278,18 +293,19 @@ def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_no
 
 
 def gated_train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, lr: float, step: int,
-                     max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0) -> Dict[str, float]:
+                     max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
+                     k: Optional[int] = None) -> Dict[str, float]:
     """VisionSAETrainer.train_step (sae/train_sae.py:278-411) on a GatedSparseAutoencoder.  P, opt hold every parameter but b_enc
-    (untouched by the optimizer: no gradient)."""
+    (untouched by the optimizer: no gradient).  k: the top-k form (see gated_forward)."""
     renorm_decoder(P)
-    fw = gated_forward(P, x, layer_norm, l1_coefficient)
+    fw = gated_forward(P, x, layer_norm, l1_coefficient, k=k)
     fired = (fw["feature_acts"] > 0).sum(axis=0)
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0
     stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
     g = gated_backward(P, x, fw, layer_norm, l1_coefficient)
-    Pg = {k: P[k] for k in g}
+    Pg = {k_: P[k_] for k_ in g}
     total = clip_and_project(Pg, g, max_grad_norm)
-    adam_step(Pg, g, {k: opt["m"][k] for k in g}, {k: opt["v"][k] for k in g}, lr, step)
+    adam_step(Pg, g, {k_: opt["m"][k_] for k_ in g}, {k_: opt["v"][k_] for k_ in g}, lr, step)
     return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l1_loss=float(fw["l1_loss"]), aux_loss=float(fw["aux_loss"]),
                 l0=float(fw["l0"]), grad_norm=total)

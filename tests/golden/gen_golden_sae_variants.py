@@ -1,6 +1,6 @@
 """Golden fixtures for the other sparse coders by EXECUTING THE REFERENCE (build container only):
 the reference's StandardSparseAutoencoder with ReLU + L1 (+ ghost gradients) and with top-k + ghost gradients, GatedSparseAutoencoder
-and Transcoder are
+(ReLU and top-k forms) and Transcoder are
 run through its own VisionSAETrainer.train_step (/root/reference/src/vit_prisma/sae/train_sae.py:278-411) for 3 steps at
 d_in = 64, d_sae = 512, N = 256.
 
@@ -35,6 +35,7 @@ VARIANTS = {
     "topk_ghost": dict(activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=True, dead_feature_window=1),
     "gated": dict(architecture="gated", activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3,
                   use_ghost_grads=False),
+    "gated_topk": dict(architecture="gated", activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=False),
     "transcoder": dict(is_transcoder=True, transcoder_with_skip_connection=True, d_out=64, out_hook_point_layer=6,
                        activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=False),
 }

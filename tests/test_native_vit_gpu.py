@@ -733,6 +733,10 @@ def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning)
         d = _digests(model, (77, 300))
         ref = ref or d
         assert d == ref, (tile, loop)
+    for persist in (0, 1):                         # the persistent form (gemm_kernel_v8) wherever it applies / nowhere; default: where tiles > CUs
+        tuning("reset")
+        tuning("gemm_persist", persist)
+        assert _digests(model, (77, 300)) == ref, ("gemm_persist", persist)
     tuning("reset")
     x = torch.randn(300, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(300)).bfloat16()
     with torch.no_grad():
@@ -740,6 +744,48 @@ def test_bf16_results_do_not_depend_on_the_gemm_kernel_or_the_batch_size(tuning)
         _, one = model.run_with_cache(x[123:124])
     for k in big.keys():
         assert torch.equal(big[k][123], one[k][0]), k
+
+
+@pytest.mark.parametrize("epi,M,N_,K", [("bias", 25600, 2304, 768), ("act", 25600 - 37, 1000, 1024), ("resid", 8000 + 13, 1024, 256),
+                                       ("resid", 25600, 768, 3072), ("act", 4 * 577, 4096, 1024), ("bias", 300, 768, 768)])
+def test_persistent_gemm_is_bit_identical_to_the_one_tile_per_workgroup_form(epi, M, N_, K, tuning):
+    """gemm_kernel_v8 (one workgroup per CU walking its tiles, the K slabs of consecutive tiles as one stream: DESIGN.md 3.6) against
+    gemm_kernel_v7 through pv_gemm_epilogue on the forward's shapes, ragged ones and a launch smaller than the chip, for the three
+    epilogue families (second output included): same MFMA order, same k order of every fp32 sum -> the same bits; and against a
+    torch fp32 product of the same bf16 operands within bf16 rounding of the result (2^-8 relative to the row's largest entry)."""
+    from vit_prisma_amd import _native as N
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(M + N_ + K)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    B = (torch.randn(N_, K, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N_, device="cuda", generator=g).bfloat16()
+    res = torch.randn(M, N_, device="cuda", generator=g).bfloat16() if epi == "resid" else None
+    outs = []
+    for persist in (0, 1):
+        tuning("reset")
+        tuning("gemm_persist", persist)
+        o0 = torch.zeros(M, N_, device="cuda", dtype=torch.bfloat16)
+        o1 = torch.zeros_like(o0) if epi != "bias" else None
+        N.check(L.pv_gemm_epilogue(1, {"bias": 0, "resid": 2, "act": 3}[epi], 0, A.data_ptr(), K, B.data_ptr(), K, bias.data_ptr(),
+                                   res.data_ptr() if res is not None else None, N_, o0.data_ptr(), o1.data_ptr() if o1 is not None else None,
+                                   N_, M, N_, K, st), "pv_gemm_epilogue")
+        torch.cuda.synchronize()
+        outs.append((o0, o1))
+    for a, b in zip(*outs):
+        if a is not None:
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    rows = slice(0, min(M, 512))
+    pre = A[rows].float() @ B.float().T + bias.float()
+
+    def close(got, want):
+        return float(((got.float() - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max()) < 2.0 ** -7
+
+    assert close(outs[1][0][rows], pre)               # out0: the product + bias (hook_attn_out / hook_mlp_out / mlp.hook_pre; epi 0: the output)
+    if epi == "resid":
+        assert close(outs[1][1][rows], pre + res[rows].float())            # out1: the residual stream
+    if epi == "act":
+        assert close(outs[1][1][rows], torch.nn.functional.gelu(outs[1][0][rows].float()))     # out1 = act(round_T(acc + bias)), PV_ACT_GELU
 
 
 def test_plain_forward_is_native_and_the_autograd_fallback_warns_once():

@@ -156,25 +156,27 @@ def test_transcoder_three_steps_vs_reference_fixture():
         assert rel_fro(P[n], g[f"transcoder_s2_param_{n}"]) < 1e-5, n
 
 
-def test_gated_three_steps_vs_reference_fixture():
-    """The gated form of the oracle (ReLU) against the reference's own GatedSparseAutoencoder through its own train_step
-    (gated of tests/golden/sae_variants_steps.npz): loss / mse / l1 / l0 / auxiliary loss, statistics, parameters after step 3
-    (b_enc, which the gated forward never uses, must come out untouched)."""
+@pytest.mark.parametrize("variant,k", [("gated", None), ("gated_topk", 8)])
+def test_gated_three_steps_vs_reference_fixture(variant, k):
+    """The gated form of the oracle (ReLU; top-k: TopK on the magnitudes AND on the gate activations, no L1 term, sae.py:741-745,
+    773-778) against the reference's own GatedSparseAutoencoder through its own train_step (gated / gated_topk of
+    tests/golden/sae_variants_steps.npz): loss / mse / l1 / l0 / auxiliary loss, statistics, parameters after step 3 (b_enc, which the
+    gated forward never uses, must come out untouched)."""
     g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
     d_in, d_sae, N, l1c = 64, 512, 256, 2e-3
-    names = [str(k) for k in g["gated_keys"]]
+    names = [str(k_) for k_ in g[f"{variant}_keys"]]
     assert names == ["W_enc", "b_gate", "r_mag", "b_mag", "W_dec", "b_enc", "b_dec"]
-    P = {n: g[f"gated_init_{n}"].copy() for n in names if n != "b_enc"}
-    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
-    stats = {"n_fwd_since_fired": g["gated_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    P = {n: g[f"{variant}_init_{n}"].copy() for n in names if n != "b_enc"}
+    opt = {"m": {k_: np.zeros_like(v) for k_, v in P.items()}, "v": {k_: np.zeros_like(v) for k_, v in P.items()}}
+    stats = {"n_fwd_since_fired": g[f"{variant}_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
     for t in range(3):
-        out = O.gated_train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), lr=1e-3, step=t + 1, l1_coefficient=l1c)
-        loss, mse, l1, l0, _, aux = g[f"gated_s{t}_scalars"]
+        out = O.gated_train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), lr=1e-3, step=t + 1, l1_coefficient=l1c, k=k)
+        loss, mse, l1, l0, _, aux = g[f"{variant}_s{t}_scalars"]
         for got, want in ((out["loss"], loss), (out["mse_loss"], mse), (out["l1_loss"], l1), (out["aux_loss"], aux)):
-            assert abs(got - want) <= 1e-5 * abs(want), (t, out, g[f"gated_s{t}_scalars"])
+            assert abs(got - want) <= 1e-5 * abs(want), (t, out, g[f"{variant}_s{t}_scalars"])
         assert abs(out["l0"] - l0) <= 1e-6 * l0
-        assert np.array_equal(stats["act_freq_scores"], g[f"gated_s{t}_act_freq"])
-        assert np.array_equal(stats["n_fwd_since_fired"], g[f"gated_s{t}_n_since"])
+        assert np.array_equal(stats["act_freq_scores"], g[f"{variant}_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"{variant}_s{t}_n_since"])
     for n in P:
-        assert rel_fro(P[n], g[f"gated_s2_param_{n}"]) < 1e-5, n
-    assert np.array_equal(g["gated_s2_param_b_enc"], g["gated_init_b_enc"])
+        assert rel_fro(P[n], g[f"{variant}_s2_param_{n}"]) < 1e-5, n
+    assert np.array_equal(g[f"{variant}_s2_param_b_enc"], g[f"{variant}_init_b_enc"])
