@@ -45,7 +45,7 @@ extern "C" {
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
  * gemm_persist / gemm_stagger tuning keys). */
-#define PV_ABI_VERSION 18
+#define PV_ABI_VERSION 19
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -534,6 +534,19 @@ int pv_sae_gated_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32
  * [feature_acts; relu(gate_pre)] stacked as 2 n_tokens rows -- the dense form's stacking.  A batch some token of which cannot be held
  * raises the device-side mode word (sp->workspace, as pv_sae_relu_step) and the dense GEMMs run instead; exact fp32 values either
  * way.  sp->workspace: pv_sae_gated_sparse_workspace_bytes.  Needs the encoder shadows (W_enc16T, enc_colsq) current, else dense. */
+/* The TOP-K form of the gated SAE (activation_fn_str = "topk" on a GatedSparseAutoencoder: TopK on the magnitudes AND on the gate
+ * activations, no L1 term -- sae.py:699-716, 741-745, 773-778): two k-sparse lists per token (k = the plan's k).  The magnitude
+ * path's top-k runs on the filtered encoder against a per-step scaled copy of the encoder shadows (W_encT e^r_mag), the gate path's
+ * on the shadows with b_gate as the bias; each kept magnitude's gate is evaluated exactly; one decode per list, ONE CSR + sparse
+ * backward over the two lists stacked as 2 n_tokens rows.  The PLAN must be created for 2 x n_tokens (max_tokens >= 2 n_tokens:
+ * its k-dependent buffers hold both lists) and out->topk_idx / topk_val hold 2 n_tokens x k entries: rows [0, n_tokens) = the
+ * magnitude list (feature_acts), rows [n_tokens, 2 n_tokens) = the gate list (relu'd gate activations).  flags, scalars (4 = 0),
+ * batch_mean / n_global and the follow-up calls as pv_sae_gated_step; scratch: pv_sae_gated_topk_scratch_bytes (gt.scratch is not
+ * used). */
+size_t pv_sae_gated_topk_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens);
+int pv_sae_gated_topk_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
+                           int32_t n_global, int32_t flags, pv_sae_out* out, void* workspace, size_t workspace_bytes, void* scratch,
+                           size_t scratch_bytes, void* stream);
 size_t pv_sae_gated_sparse_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t cap);
 int pv_sae_gated_step_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,
                              int32_t n_global, int32_t flags, float l1_coefficient, const pv_sae_relu_sparse* sp, pv_sae_out* out,

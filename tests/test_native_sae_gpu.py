@@ -1292,6 +1292,69 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
 
 
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("d_in,d_sae,k,n,ln", [(64, 512, 8, 256, True), (136, 1056, 16, 300, False), (768, 8192, 32, 1024, True),
+                                               (768, 24576, 32, 4096, True), (1024, 16384, 64, 512, True)])
+def test_gated_topk_step_vs_oracle(d_in, d_sae, k, n, ln):
+    """pv_sae_gated_topk_step + grad_sqnorm + apply against the oracle's top-k gated form (pinned to the reference's own run,
+    tests/test_oracle_sae_vs_golden.py): losses, l0, the two k-sparse lists, every gradient tensor, the clip norm, parameters and
+    statistics after the optimizer step; the exact-encoder shapes (d_sae < 2048, ragged) and the filtered ones."""
+    P, opt, stats, T = fresh(d_in, d_sae)
+    rs = np.random.RandomState(9)
+    for name, scale in (("b_gate", 0.05), ("r_mag", 0.2), ("b_mag", 0.05)):
+        P[name] = (rs.standard_normal(d_sae) * scale).astype(np.float32)
+        opt["m"][name], opt["v"][name] = np.zeros_like(P[name]), np.zeros_like(P[name])
+        T[name] = torch.from_numpy(P[name].copy()).cuda()
+    b_enc0 = P.pop("b_enc")
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, ln, n, gated={m: T[m] for m in ("b_gate", "r_mag", "b_mag")},
+                    gated_topk=True)
+    for t in range(2):
+        x = synth_sae_batch(n, d_in, seed=t)
+        Pc = {kk: v.copy() for kk, v in P.items()}
+        O.renorm_decoder(Pc)
+        fw = O.gated_forward(Pc, x, layer_norm=ln, k=k)
+        # a kept magnitude whose gate pre-activation lies within fp32 summation noise of zero may fall on either side of the
+        # Heaviside step (a whole decoder row of difference): such tokens -- picked by the oracle alone -- are replaced by a safe one
+        # (likewise a k-th / (k+1)-th entry of either path that close to each other: the two top-k selections may differ by that pair)
+        idx_m = np.argsort(-fw["mag_pre"], axis=1, kind="stable")[:, :k]
+        risky = np.abs(np.take_along_axis(fw["gate_pre"], idx_m, axis=1)).min(axis=1) < 1e-5 * np.abs(fw["gate_pre"]).max()
+        for pre in (fw["mag_pre"], fw["gate_pre"]):
+            top = -np.partition(-pre, k, axis=1)[:, :k + 1]
+            risky |= (top[:, :k].min(axis=1) - top[:, k]) < 1e-5 * np.abs(pre).max()
+        if risky.any():
+            x[risky] = x[np.flatnonzero(~risky)[0]]
+            fw = O.gated_forward(Pc, x, layer_norm=ln, k=k)
+        gr = O.gated_backward(Pc, x, fw, layer_norm=ln)
+        before = stats["act_freq_scores"].copy()
+        ref = O.gated_train_step(P, opt, stats, x, lr=1e-3, step=t + 1, layer_norm=ln, k=k)
+        eng.gated_topk_step(torch.from_numpy(x).cuda(), want_out=True)
+        eng.grad_sqnorm()
+        torch.cuda.synchronize()
+        sc = eng.scalars.cpu().numpy()
+        for slot, key in ((0, "loss"), (1, "mse_loss"), (6, "aux_loss"), (2, "l0")):
+            assert abs(sc[slot] - ref[key]) <= TOL * abs(ref[key]), (key, sc, ref)
+        assert sc[4] == 0.0 and ref["l1_loss"] == 0.0
+        # the two lists: rows [0, n) = feature_acts at the magnitude path's top-k, rows [n, 2n) = the gate activations
+        got_idx, got_val = eng.topk_idx.cpu().numpy(), eng.topk_val.cpu().numpy()
+        dense_f, dense_g = np.zeros((n, d_sae), np.float32), np.zeros((n, d_sae), np.float32)
+        np.put_along_axis(dense_f, got_idx[:n], got_val[:n], axis=1)
+        np.put_along_axis(dense_g, got_idx[n:2 * n], got_val[n:2 * n], axis=1)
+        assert rel_fro(dense_f, fw["feature_acts"]) < TOL and rel_fro(dense_g, fw["pg"]) < TOL
+        assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
+        for name in gr:
+            assert rel_fro((eng.grad_W_enc() if name == "W_enc" else eng.g[name]).cpu().numpy(), gr[name]) < TOL, name
+        assert float(eng.g["b_enc"].abs().max()) == 0.0
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr)
+        fire_ref = stats["act_freq_scores"] - before
+        assert np.array_equal(eng.fire_count.cpu().numpy(), fire_ref)
+        eng.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name in P:
+            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < TOL, name
+        assert np.array_equal(eng.params["b_enc"].cpu().numpy(), b_enc0)
+        assert np.array_equal(eng.act_freq_scores.cpu().numpy(), stats["act_freq_scores"])
+
+
 @pytest.mark.parametrize("kind", ["gated", "relu_transcoder", "topk_transcoder"])
 def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
     """The data-parallel form of the gated step and of the ReLU transcoder step (batch_mean / n_global: tokens sharded over ranks,
@@ -1334,15 +1397,18 @@ def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
     assert torch.equal(f0 + f1, fire_all)
 
 
-def test_gated_trainer_runs_natively_and_matches_the_reference_fixture():
-    """architecture = "gated" (ReLU) through VisionSAETrainer.train_step on the HIP step, against what the REFERENCE's own
-    GatedSparseAutoencoder produced through its own train_step (tests/golden/sae_variants_steps.npz)."""
+@pytest.mark.parametrize("variant", ["gated", "gated_topk"])
+def test_gated_trainer_runs_natively_and_matches_the_reference_fixture(variant):
+    """architecture = "gated" (ReLU, and the top-k form: TopK on the magnitudes and on the gate activations, k = 8) through
+    VisionSAETrainer.train_step on the HIP step, against what the REFERENCE's own GatedSparseAutoencoder produced through its own
+    train_step (tests/golden/sae_variants_steps.npz)."""
     from vit_prisma_amd.sae import GatedSparseAutoencoder
     g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
     d_in, exp, N = 64, 8, 256
     cfg = VisionModelSAERunnerConfig(
-        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp, activation_fn_str="relu",
-        activation_fn_kwargs={}, normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp,
+        activation_fn_str="relu" if variant == "gated" else "topk", activation_fn_kwargs={} if variant == "gated" else {"k": 8},
+        normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
         train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda", _dtype="float32", log_to_wandb=False, use_ghost_grads=False,
         feature_sampling_window=1000, dead_feature_window=5000, lr_scheduler_name="constant", n_checkpoints=0, verbose=False,
         l1_coefficient=2e-3, architecture="gated")
@@ -1351,7 +1417,7 @@ def test_gated_trainer_runs_natively_and_matches_the_reference_fixture():
     assert type(model) is GatedSparseAutoencoder
     with torch.no_grad():
         for n, p in model.named_parameters():
-            p.copy_(torch.from_numpy(g[f"gated_init_{n}"]).cuda())
+            p.copy_(torch.from_numpy(g[f"{variant}_init_{n}"]).cuda())
     act, since, frac, opt, sched = tr.initialize_training_variables()
     for t in range(3):
         x = torch.from_numpy(synth_sae_batch(N, d_in, seed=t)).cuda()[:, None, :]
@@ -1359,12 +1425,12 @@ def test_gated_trainer_runs_natively_and_matches_the_reference_fixture():
             sparse_autoencoder=model, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
             n_frac_active_tokens=frac, layer_acts=x, n_training_steps=t, n_training_tokens=t * N)
         assert tr.last_step_native
-        want = g[f"gated_s{t}_scalars"]
+        want = g[f"{variant}_s{t}_scalars"]
         for got, w in ((loss, want[0]), (mse, want[1]), (l1, want[2]), (l0, want[3]), (tr._engine.scalars[6], want[5])):
             assert abs(float(got) - w) <= TOL * abs(w), (t, float(got), w)
-        assert np.array_equal(act.cpu().numpy(), g[f"gated_s{t}_act_freq"]) and np.array_equal(since.cpu().numpy(), g[f"gated_s{t}_n_since"])
+        assert np.array_equal(act.cpu().numpy(), g[f"{variant}_s{t}_act_freq"]) and np.array_equal(since.cpu().numpy(), g[f"{variant}_s{t}_n_since"])
     for n, p in model.named_parameters():
-        assert rel_fro(p.detach().cpu().numpy(), g[f"gated_s2_param_{n}"]) < TOL, n
+        assert rel_fro(p.detach().cpu().numpy(), g[f"{variant}_s2_param_{n}"]) < TOL, n
 
 
 def test_store_harvest_prefetch_on_a_side_stream_serves_the_same_batches():

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -103,7 +103,7 @@ EXPORTS = [
     "pv_sae_step", "pv_sae_grad_sqnorm", "pv_sae_grad_sqnorm_step", "pv_sae_grad_sqnorm_rows", "pv_sae_apply", "pv_sae_encode_topk",
     "pv_sae_sync_shadows", "pv_sae_encoder_is_filtered", "pv_debug_sae_ws_offset", "pv_sae_forward",
     "pv_sae_tp_partial", "pv_sae_tp_finish", "pv_sae_tp_merge", "pv_sae_tp_bucket_pack", "pv_sae_tp_bucket_unpack",
-    "pv_sae_dense_step", "pv_sae_topk_ghost", "pv_sae_relu_step", "pv_sae_relu_workspace_bytes", "pv_debug_sae_relu_offset", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes", "pv_sae_gated_scratch_bytes", "pv_sae_gated_step", "pv_sae_gated_sparse_workspace_bytes", "pv_sae_gated_step_sparse",
+    "pv_sae_dense_step", "pv_sae_topk_ghost", "pv_sae_relu_step", "pv_sae_relu_workspace_bytes", "pv_debug_sae_relu_offset", "pv_sae_ghost_workspace_bytes", "pv_sae_transcoder_scratch_bytes", "pv_sae_gated_scratch_bytes", "pv_sae_gated_step", "pv_sae_gated_sparse_workspace_bytes", "pv_sae_gated_step_sparse", "pv_sae_gated_topk_scratch_bytes", "pv_sae_gated_topk_step",
     "pv_debug_gemm_trace_arm", "pv_debug_gemm_trace_read", "pv_debug_set_tuning", "pv_debug_get_tuning",
     "pv_clip_preprocess",
 ]
@@ -182,6 +182,9 @@ def lib() -> C.CDLL:
         L.pv_sae_gated_scratch_bytes.argtypes = [vp, i32]
         L.pv_sae_gated_scratch_bytes.restype = sz
         L.pv_sae_gated_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeOut), vp, sz, vp]
+        L.pv_sae_gated_topk_scratch_bytes.argtypes = [vp, i32]
+        L.pv_sae_gated_topk_scratch_bytes.restype = sz
+        L.pv_sae_gated_topk_step.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.POINTER(SaeOut), vp, sz, vp, sz, vp]
         L.pv_sae_gated_sparse_workspace_bytes.argtypes = [vp, i32, i32]
         L.pv_sae_gated_sparse_workspace_bytes.restype = sz
         L.pv_sae_gated_step_sparse.argtypes = [vp, C.POINTER(SaeState), vp, i32, vp, i32, i32, C.c_float, C.POINTER(SaeReluSparse),

@@ -1760,15 +1760,19 @@ void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, in
 }
 
 // want_csr: also count the kept pairs per feature (ws.cnt) and record their positions (ws.wpos) for the backward
+// cnt_over / wpos_over: other destinations for those two (the top-k gated step encodes twice); skip_prep: sae_prep has already run on x
 static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const float* x, int N, const float* batch_mean,
-                           int32_t* topk_idx, float* topk_val, bool want_csr, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                           int32_t* topk_idx, float* topk_val, bool want_csr, unsigned char* wsb, const SaeWs& ws, hipStream_t stream,
+                           uint32_t* cnt_over = nullptr, uint32_t* wpos_over = nullptr, bool skip_prep = false) {
     const pv_sae_desc& d = plan->d;
-    uint32_t* feat_cnt = want_csr ? (uint32_t*)(wsb + ws.cnt) : nullptr;
-    uint32_t* wpos = want_csr ? (uint32_t*)(wsb + ws.wpos) : nullptr;
+    uint32_t* feat_cnt = want_csr ? (cnt_over ? cnt_over : (uint32_t*)(wsb + ws.cnt)) : nullptr;
+    uint32_t* wpos = want_csr ? (wpos_over ? wpos_over : (uint32_t*)(wsb + ws.wpos)) : nullptr;
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
-    int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream);
-    if (rcp) return rcp;
+    if (!skip_prep) {
+        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream);
+        if (rcp) return rcp;
+    }
     // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
     ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
                    ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
@@ -1846,14 +1850,14 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
                      const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
                      const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
-                     const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb) {
+                     const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb, const uint32_t* cnt_in) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
     const dim3 block(256);
     {
         // CSR by feature: counts and within-list positions came out of the top-k selection; scan + atomic-free scatter
-        const uint32_t* cnt = (const uint32_t*)(wsb + ws.cnt);
+        const uint32_t* cnt = cnt_in ? cnt_in : (const uint32_t*)(wsb + ws.cnt);       // (cnt_in: counts that are not the selection's own)
         uint32_t* offs = (uint32_t*)(wsb + ws.offs);
         uint32_t* chunk_start = tb.chunk_start;
         int32_t* pairs = tb.pairs;
@@ -2234,6 +2238,320 @@ int sae_gated_sparse(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N,
                        (const float*)l1part, (const float*)l0part, N, 1.0f / (ng * (float)D), 1.0f / ng, l1_coefficient / ng,
                        1.0f / (float)N, out->scalars, (const uint32_t*)mode);
     PV_LAUNCH_CHECK("gated sparse kernels");
+    return PV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The TOP-K form of the gated SAE (activation_fn_str = "topk" on a GatedSparseAutoencoder, sae.py:699-716, 741-745, 773-778):
+//     feature_acts = [gate_pre > 0] TopK(mag_pre),   mag_pre  = sae_in (W_enc e^r_mag) + b_mag
+//     pi_gate_act  = TopK(gate_pre),                 gate_pre = sae_in W_enc + b_gate
+//     loss = mse(feature_acts W_dec + b_dec) + aux(pi_gate_act W_dec + b_dec against sae_in);  no L1 term
+// Two k-sparse lists per token, so the step is the k-sparse machinery twice over:
+//   * the magnitude path's top-k runs on the SAME filtered encoder against a scaled copy of the encoder shadows (W_magT[j] = W_encT[j]
+//     e^r_j in fp32 and fp16, its column norms: one pass per step, gated_scale_rows_kernel), the gate path's on the shadows themselves
+//     with b_gate as the bias;
+//   * the gate of every kept magnitude is evaluated EXACTLY (gated_topk_mask_kernel: the fp32 dot product of the exact re-scoring);
+//   * decode once per list (sae_decode_kernel: the second against sae_in with constant LN-out terms), then ONE CSR + sparse backward
+//     over the two lists stacked as 2N "tokens" of k slots -- rows [0, N): {f, dY, dh = dM e^r}, rows [N, 2N): {g, dVia, dh = dG},
+//     sae_in repeated -- so that gW_dec, gW_enc^T and colsum(dP) (parked in gb_enc) come out of the unmodified backward kernels;
+//   * per-feature sums over the CSR lists: gb_mag, gr_mag, gb_gate, firing statistics.
+// The plan must be created for 2 x the tokens of a step (its k-dependent buffers hold both lists).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GatedTopkWs {
+    size_t total, wmagT, wmag16, colsq, cnt_m, cnt2, dM, mu0, one, l0part, auxpart, tmpd, cspart;
+};
+GatedTopkWs gated_topk_carve(const pv_sae_desc& d, int n_tokens) {
+    GatedTopkWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (size_t)pv_align_up((int64_t)bytes, 256); return o; };
+    const size_t F = d.d_sae, D = d.d_in, N = n_tokens;
+    w.wmagT = take(F * D * 4);
+    w.wmag16 = take(F * D * 2);
+    w.colsq = take(F * 4);
+    w.cnt_m = take(F * 4);
+    w.cnt2 = take(F * 4);
+    w.dM = take(N * (size_t)d.k * 4);
+    w.mu0 = take(N * 4);
+    w.one = take(N * 4);
+    w.l0part = take(N * 4);
+    w.auxpart = take(N * 4);
+    w.tmpd = take(D * 4);
+    w.cspart = take((N / 16 + 2) * D * 4);
+    w.total = off + 256;
+    return w;
+}
+
+// W_magT[j] = W_encT[j] e^r_j (fp32 + fp16) and its squared column norm (INFINITY outside the fp16 range, as adam_wenct_kernel);
+// one wave per feature
+__global__ __launch_bounds__(256) void gated_scale_rows_kernel(const float* __restrict__ WT, const float* __restrict__ r_mag,
+                                                               float* __restrict__ MT, _Float16* __restrict__ M16T,
+                                                               float* __restrict__ colsq, int F, int d) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= F) return;
+    const float e = expf(r_mag[j]);
+    float sq = 0.f;
+    bool big = false;
+    for (int c = 4 * lane; c < d; c += 256) {
+        float4 w = *reinterpret_cast<const float4*>(WT + (int64_t)j * d + c);
+        w.x *= e; w.y *= e; w.z *= e; w.w *= e;
+        *reinterpret_cast<float4*>(MT + (int64_t)j * d + c) = w;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hv = {(_Float16)w.x, (_Float16)w.y, (_Float16)w.z, (_Float16)w.w};
+        *reinterpret_cast<h4*>(M16T + (int64_t)j * d + c) = hv;
+        sq += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+        big = big || !(fabsf(w.x) <= 6.0e4f) || !(fabsf(w.y) <= 6.0e4f) || !(fabsf(w.z) <= 6.0e4f) || !(fabsf(w.w) <= 6.0e4f);
+    }
+    sq = wave_sum(sq);
+    const bool any_big = __any(big);
+    if (lane == 0) colsq[j] = any_big ? INFINITY : sq;
+}
+
+// a wave per token: the gate of each kept magnitude, exactly (gate_pre = sae_in . W_encT[j] + b_gate[j] in the summation order of the
+// exact re-scoring), feature_acts = [gate_pre > 0] relu(top-k magnitude) written over the magnitude; the token's count of f > 0 (l0);
+// the constant LN-out terms of the pass through the gate
+template <int V4>
+__global__ __launch_bounds__(256) void gated_topk_mask_kernel(const float* __restrict__ sae_in, const float* __restrict__ W_encT,
+                                                              const float* __restrict__ b_gate, const int32_t* __restrict__ idx,
+                                                              float* __restrict__ val, float* __restrict__ l0part,
+                                                              float* __restrict__ mu0, float* __restrict__ one, int n_tok, int d, int k) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    bool ok[V4];
+    int col[V4];
+    float4 xr[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        col[i] = 4 * lane + 256 * i;
+        ok[i] = col[i] < d;
+        xr[i] = ld4(sae_in + (int64_t)n * d + col[i], ok[i]);
+    }
+    float cnt = 0.f;
+    for (int s = 0; s < k; s += 4) {
+        float acc[4];
+        int jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int su = min(s + u, k - 1);
+            jj[u] = idx[(int64_t)n * k + su];
+            const float* w = W_encT + (int64_t)jj[u] * d;
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                if (ok[i]) {
+                    const float4 wv = *reinterpret_cast<const float4*>(w + col[i]);
+                    a = fmaf(xr[i].x, wv.x, a); a = fmaf(xr[i].y, wv.y, a); a = fmaf(xr[i].z, wv.z, a); a = fmaf(xr[i].w, wv.w, a);
+                }
+            }
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
+        if (lane < 4 && s + lane < k) {
+            const float av = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+            const int jv = lane == 0 ? jj[0] : (lane == 1 ? jj[1] : (lane == 2 ? jj[2] : jj[3]));
+            const float m = val[(int64_t)n * k + s + lane];
+            const float f = (av + b_gate[jv] > 0.f && m > 0.f) ? m : 0.f;
+            val[(int64_t)n * k + s + lane] = f;
+            cnt += f > 0.f ? 1.f : 0.f;
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0) { l0part[n] = cnt; mu0[n] = 0.f; one[n] = 1.f; }
+}
+
+// threads [0, n_half): dh of the two stacked lists (dM e^r | dG is already in place), the second list's positions behind the first's;
+// threads [n_half, n_half + F): the summed counts
+__global__ __launch_bounds__(256) void gated_topk_pairs_kernel(const int32_t* __restrict__ idx, uint32_t* __restrict__ wpos,
+                                                               const uint32_t* __restrict__ cnt_m, const uint32_t* __restrict__ cnt_g,
+                                                               uint32_t* __restrict__ cnt2, const float* __restrict__ dM,
+                                                               const float* __restrict__ r_mag, float* __restrict__ dh2, int n_half, int F) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_half) {
+        const int j = i - n_half;
+        if (j < F) cnt2[j] = cnt_m[j] + cnt_g[j];
+        return;
+    }
+    dh2[i] = dM[i] * expf(r_mag[idx[i]]);                       // d mag_pre / d p = e^r (sae.py:708-712 backwards)
+    const uint32_t w = wpos[n_half + i];
+    if (w != 0xffffffffu) wpos[n_half + i] = w + cnt_m[idx[n_half + i]];
+}
+
+// per feature over its (token-ordered) list: pairs of the first list -> gb_mag = sum dM, gr_mag = sum dM (mag_pre - b_mag) (dM != 0
+// only where f = mag_pre > 0), the firing count of feature_acts; pairs of the second -> gb_gate = sum dG.  One wave per feature.
+__global__ __launch_bounds__(256) void gated_topk_feat_kernel(const uint32_t* __restrict__ offs, const int32_t* __restrict__ pairs,
+                                                              const float* __restrict__ val2, const float* __restrict__ dM,
+                                                              const float* __restrict__ dh2, const float* __restrict__ b_mag, int n_half,
+                                                              int F, float* __restrict__ gb_gate, float* __restrict__ gb_mag,
+                                                              float* __restrict__ gr_mag, float* __restrict__ fire_count,
+                                                              float* __restrict__ act_freq, float* __restrict__ n_since_fired,
+                                                              int update_stats) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= F) return;
+    const uint32_t beg = offs[j], end = offs[j + 1];
+    float sg = 0.f, sm = 0.f, smf = 0.f, fired = 0.f;
+    for (uint32_t q = beg + lane; q < end; q += 64) {
+        const int p = pairs[q];
+        if (p < n_half) {
+            const float f = val2[p], m = dM[p];
+            sm += m;
+            smf += m * f;
+            fired += f > 0.f ? 1.f : 0.f;
+        } else {
+            sg += dh2[p];
+        }
+    }
+    sg = wave_sum(sg); sm = wave_sum(sm); smf = wave_sum(smf); fired = wave_sum(fired);
+    if (lane != 0) return;
+    gb_gate[j] = sg;
+    gb_mag[j] = sm;
+    gr_mag[j] = smf - b_mag[j] * sm;
+    if (fire_count) fire_count[j] = fired;
+    if (update_stats) {
+        act_freq[j] += fired;
+        n_since_fired[j] = fired > 0.f ? 0.f : n_since_fired[j] + 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void gated_topk_scalars_kernel(const float* __restrict__ mse_part, const float* __restrict__ aux_part,
+                                                                 const float* __restrict__ l0part, int n_tok, float s_mse, float s_aux,
+                                                                 float s_l0, float* __restrict__ scalars) {
+    __shared__ float red[3][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f, e = 0.f;
+    for (int i = threadIdx.x; i < n_tok; i += 256) { a += mse_part[i]; b += aux_part[i]; e += l0part[i]; }
+    a = wave_sum(a); b = wave_sum(b); e = wave_sum(e);
+    if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mse = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * s_mse;
+        const float aux = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * s_aux;
+        scalars[1] = mse; scalars[6] = aux; scalars[4] = 0.f;               // (no L1 term in the top-k form, sae.py:741-745)
+        scalars[2] = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * s_l0;
+        scalars[0] = mse + aux;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+}  // namespace
+
+extern "C" size_t pv_sae_gated_topk_scratch_bytes(const pv_sae_plan* plan, int32_t n_tokens) {
+    if (!plan || n_tokens < 1) return 0;
+    return gated_topk_carve(plan->d, n_tokens).total;
+}
+
+extern "C" int pv_sae_gated_topk_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, const float* batch_mean,
+                                      int32_t n_global, int32_t flags, pv_sae_out* out, void* workspace, size_t workspace_bytes,
+                                      void* scratch, size_t scratch_bytes, void* stream_) {
+    const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
+    PV_REQUIRE(plan && st && x && out && workspace && scratch && out->scalars && out->topk_idx && out->topk_val, "null argument");
+    PV_REQUIRE(sae_is_gated(st) && !sae_is_tc(st), "pv_sae_gated_topk_step needs a gated state (pv_sae_state.gt) and no transcoder");
+    const pv_sae_gated& t = st->gt;
+    PV_REQUIRE(t.r_mag && t.b_mag && t.gb_gate && t.gr_mag && t.gb_mag, "gated state");
+    PV_REQUIRE(st->W_dec && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec && st->W_encT, "state");
+    PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
+    PV_REQUIRE(flags & PV_SAE_RENORM_DECODER, "pv_sae_gated_topk_step: PV_SAE_RENORM_DECODER is required (train_sae.py:307 is part of the step)");
+    const pv_sae_desc& d = plan->d;
+    PV_REQUIRE(N >= 1 && 2 * (int64_t)N <= d.max_tokens, "the plan must be created for 2 x the step's tokens (both k-sparse lists)");
+    PV_REQUIRE(n_global >= N, "n_global must be >= n_tokens");
+    const SaeWs ws = sae_carve(d);
+    PV_REQUIRE(workspace_bytes >= ws.total && ((uintptr_t)workspace & 255) == 0, "workspace too small / misaligned");
+    const GatedTopkWs gw = gated_topk_carve(d, N);
+    PV_REQUIRE(scratch_bytes >= gw.total && ((uintptr_t)scratch & 255) == 0, "scratch too small / misaligned (pv_sae_gated_topk_scratch_bytes)");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned char* wsb = (unsigned char*)workspace;
+    unsigned char* gb = (unsigned char*)scratch;
+    plan->live_offs = nullptr;
+    plan->renorm_pending = false;
+    const int F = d.d_sae, D = d.d_in, k = d.k, n_half = N * k;
+    const float ng = (float)n_global;
+    int rc = pv_sae_renorm_decoder(plan, st, stream_);
+    if (rc) return rc;
+    int32_t* idx2 = out->topk_idx;
+    float* val2 = out->topk_val;
+    uint32_t* wpos2 = (uint32_t*)(wsb + ws.wpos);
+    uint32_t* cnt_g = (uint32_t*)(wsb + ws.cnt);
+    uint32_t* cnt_m = (uint32_t*)(gb + gw.cnt_m);
+    uint32_t* cnt2 = (uint32_t*)(gb + gw.cnt2);
+    float* dM = (float*)(gb + gw.dM);
+    float* dh2 = (float*)(wsb + ws.dh);
+    float* dY2 = (float*)(wsb + ws.dY);
+    float* sae_in = (float*)(wsb + ws.sae_in);
+    float* auxpart = (float*)(gb + gw.auxpart);
+    float* l0part = (float*)(gb + gw.l0part);
+    const dim3 block(256);
+    // the magnitude path's operands + its top-k (list 1)
+    const bool shadows = st->W_enc16T && st->enc_colsq;
+    hipLaunchKernelGGL(gated_scale_rows_kernel, dim3((F + 3) / 4), block, 0, stream, (const float*)st->W_encT, (const float*)t.r_mag,
+                       (float*)(gb + gw.wmagT), (_Float16*)(gb + gw.wmag16), (float*)(gb + gw.colsq), F, D);
+    PV_LAUNCH_CHECK("gated_scale_rows_kernel");
+    pv_sae_state sm = *st;
+    sm.W_encT = (float*)(gb + gw.wmagT);
+    sm.W_enc16T = shadows ? (uint16_t*)(gb + gw.wmag16) : nullptr;
+    sm.enc_colsq = shadows ? (float*)(gb + gw.colsq) : nullptr;
+    sm.b_enc = t.b_mag;
+    rc = sae_encode_topk(plan, &sm, x, N, batch_mean, idx2, val2, true, wsb, ws, stream, cnt_m, wpos2);
+    if (rc) return rc;
+#define CALL(V)                                                                                                                   \
+    hipLaunchKernelGGL((gated_topk_mask_kernel<V>), dim3((N + 3) / 4), block, 0, stream, (const float*)sae_in, (const float*)st->W_encT, \
+                       (const float*)t.b_gate, (const int32_t*)idx2, val2, l0part, (float*)(gb + gw.mu0), (float*)(gb + gw.one), N, D, k)
+    V4_DISPATCH(D, CALL);
+#undef CALL
+    PV_LAUNCH_CHECK("gated_topk_mask_kernel");
+    // the gate path's top-k (list 2)
+    pv_sae_state sg = *st;
+    sg.b_enc = t.b_gate;
+    rc = sae_encode_topk(plan, &sg, x, N, batch_mean, idx2 + n_half, val2 + n_half, true, wsb, ws, stream, cnt_g, wpos2 + n_half, true);
+    if (rc) return rc;
+    PV_HIP_CHECK(hipMemcpyAsync(sae_in + (size_t)N * D, sae_in, (size_t)N * D * 4, hipMemcpyDeviceToDevice, stream));
+    {
+        ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * n_half * (double)D * 2.0, 0.0);
+        const dim3 grid((N + 3) / 4);
+#define CALL(V)                                                                                                                   \
+    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec,           \
+                       (const int32_t*)idx2, (const float*)val2, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),           \
+                       (const float*)(wsb + ws.norm), out->sae_out, dY2, dM, (float*)(wsb + ws.loss_part), N, D, k,                  \
+                       2.0f / (ng * (float)D), 1, (const float*)nullptr);                                                             \
+    hipLaunchKernelGGL((sae_decode_kernel<V>), grid, block, 0, stream, (const float*)sae_in, (const float*)st->W_dec,                  \
+                       (const float*)st->b_dec, (const int32_t*)(idx2 + n_half), (const float*)(val2 + n_half),                       \
+                       (const float*)(gb + gw.mu0), (const float*)(gb + gw.one), (const float*)(gb + gw.one), (float*)nullptr,        \
+                       dY2 + (size_t)N * D, dh2 + n_half, auxpart, N, D, k, 2.0f / ng, 1, (const float*)nullptr)
+        V4_DISPATCH(D, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel (top-k gated)");
+        hipLaunchKernelGGL(gated_topk_pairs_kernel, dim3((n_half + F + 255) / 256), block, 0, stream, (const int32_t*)idx2, wpos2,
+                           (const uint32_t*)cnt_m, (const uint32_t*)cnt_g, cnt2, (const float*)dM, (const float*)t.r_mag, dh2, n_half, F);
+        PV_LAUNCH_CHECK("gated_topk_pairs_kernel");
+        SaeTail tb;
+        tb.dh = dh2; tb.chunk_start = (uint32_t*)(wsb + ws.cursor); tb.wpos = wpos2; tb.seg_range = (uint32_t*)(wsb + ws.seg_range);
+        tb.seg_rows = (float*)(wsb + ws.seg_rows); tb.seg_b = (float*)(wsb + ws.seg_b); tb.pairs = (int32_t*)(wsb + ws.pairs);
+        tb.max_segs = (int)sae_max_segs((size_t)2 * n_half);
+        rc = sae_csr_backward(plan, st, 2 * N, k, idx2, val2, dh2, dY2, sae_in, out->scalars, nullptr, 0, false, tb, wsb, ws, nullptr, 0.f,
+                              false, nullptr, stream, nullptr, nullptr, cnt2);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gated_topk_feat_kernel, dim3((F + 3) / 4), block, 0, stream, (const uint32_t*)(wsb + ws.offs),
+                           (const int32_t*)tb.pairs, (const float*)val2, (const float*)dM, (const float*)dh2, (const float*)t.b_mag, n_half,
+                           F, t.gb_gate, t.gb_mag, t.gr_mag, out->fire_count, st->act_freq_scores, st->n_fwd_since_fired, update_stats);
+        hipLaunchKernelGGL(gated_topk_scalars_kernel, dim3(1), block, 0, stream, (const float*)(wsb + ws.loss_part), (const float*)auxpart,
+                           (const float*)l0part, N, 1.0f / (ng * (float)D), 1.0f / ng, 1.0f / (float)N, out->scalars);
+        PV_LAUNCH_CHECK("top-k gated kernels");
+        // gb_dec = colsum(dY) + 2 colsum(dVia) - W_enc colsum(dP) (as pv_sae_gated_step); b_enc takes no part
+        rc = sae_gbdec(d, st, dY2, N, wsb, ws, stream);
+        if (rc) return rc;
+        rc = sae_colsum(dY2 + (size_t)N * D, N, D, (float*)(gb + gw.tmpd), 2.0f, (float*)(gb + gw.cspart), stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(axpy_kernel, dim3((D + 255) / 256), block, 0, stream, st->gb_dec, (const float*)(gb + gw.tmpd), D);
+        PV_LAUNCH_CHECK("axpy_kernel");
+        PV_HIP_CHECK(hipMemsetAsync(st->gb_enc, 0, (size_t)F * 4, stream));
+    }
     return PV_OK;
 }
 

@@ -83,7 +83,8 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
 int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
                      const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
                      const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
-                     const uint32_t* gate, hipStream_t stream, const float* val_b = nullptr, const float* dYb = nullptr);
+                     const uint32_t* gate, hipStream_t stream, const float* val_b = nullptr, const float* dYb = nullptr,
+                     const uint32_t* cnt_in = nullptr);
 // sae.hip: the gated step in sparse form (pv_sae_gated_step_sparse; see the definition)
 struct GatedSparseWs {
     ReluWs rw;

@@ -205,7 +205,8 @@ def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3, only: O
     the bench shape (768 -> 24576, 4096 tokens, single process): a top-k Transcoder with the skip connection (sae/transcoder.py)
     and a Gated SAE with the ReLU magnitude path (sae.py:648-792) -- as a training run from the synthetic init (every gate half open:
     the step's dense form) and with b_gate shifted so that a token opens about 64 gates, lr 0 (a trained gated SAE's regime: the sparse
-    form, pv_sae_gated_step_sparse; which form ran is decided on the GPU and counted)."""
+    form, pv_sae_gated_step_sparse; which form ran is decided on the GPU and counted) -- and a Gated SAE in its top-k form
+    (pv_sae_gated_topk_step)."""
     from .config import VisionModelSAERunnerConfig
     from .trainer import VisionSAETrainer
     out = {}
@@ -213,7 +214,8 @@ def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3, only: O
                                                      transcoder_with_skip_connection=True, d_out=D_IN, out_hook_point_layer=6)),
                        ("gated_relu", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated", l1_coefficient=8e-5)),
                        ("gated_relu_l0_64", dict(activation_fn_str="relu", activation_fn_kwargs={}, architecture="gated",
-                                                 l1_coefficient=8e-5))):
+                                                 l1_coefficient=8e-5)),
+                       ("gated_topk", dict(activation_fn_str="topk", activation_fn_kwargs={"k": TOPK}, architecture="gated"))):
         if only is not None and name != only:
             continue
         target_l0 = 64.0 if name == "gated_relu_l0_64" else None
@@ -268,7 +270,11 @@ def sae_variants_leg(dev: torch.device, steps: int = 8, warmup: int = 3, only: O
         out[name] = {"value": round(N_TOKENS * steps / elapsed, 1), "unit": "tokens/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
                      "steps": steps, "warmup": warmup, "final_loss": float(last[0]),
                      "config": {"workload": f"{name}: 768 -> 24576, {N_TOKENS} tokens per step, Adam, clip 1.0, fused HIP step"}}
-        if gated:
+        if gated and name == "gated_topk":
+            out[name].update({"l0": float(tr._engine.scalars[2].item())})
+            out[name]["config"]["regime"] = (f"top-k form (TopK k = {TOPK} on the magnitudes and on the gate activations): two k-sparse lists per "
+                                             f"token, training run from the synthetic init, steps {warmup + 1}..{warmup + steps} timed")
+        elif gated:
             eng = tr._engine
             out[name].update({"l0": float(eng.scalars[2].item()), "dense_steps": int(n_dense.item()),
                               "sparse_steps": steps - int(n_dense.item()), "per_token_capacity": int(eng.relu_cap)})

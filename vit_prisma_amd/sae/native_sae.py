@@ -28,14 +28,17 @@ class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
                  layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False,
                  b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None,
-                 gated: Optional[Dict[str, torch.Tensor]] = None):
+                 gated: Optional[Dict[str, torch.Tensor]] = None, gated_topk: bool = False):
         """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``.
         b_dec_out [d_in] (+ W_skip [d_in, d_in]): a Transcoder (sae/transcoder.py; pv_sae_transcoder) -- ``step`` /
         ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input.
         gated = {b_gate, r_mag, b_mag} [d_sae] each: a GatedSparseAutoencoder (sae.py:648-792; pv_sae_gated) -- ``gated_step`` is
-        its train step (``b_enc`` is kept but plays no part)."""
+        its train step (``b_enc`` is kept but plays no part); gated_topk: its top-k form (activation_fn_str = "topk": TopK on the
+        magnitudes and on the gate activations, k of each per token) -- ``gated_topk_step`` is the train step then, and the plan is
+        created for twice the tokens (its k-dependent buffers hold both lists)."""
         self.transcoder = b_dec_out is not None
         self.gated = gated is not None
+        self.gated_topk = bool(gated_topk) and self.gated
         assert not (self.gated and (self.transcoder or inference)), "gated: training engine, no transcoder"
         assert W_skip is None or self.transcoder, "W_skip belongs to a transcoder (pass b_dec_out)"
         assert not (self.transcoder and inference), "the inference entry points do not serve a transcoder"
@@ -60,7 +63,7 @@ class NativeSAE:
             self._src.update(gated)
         self.params = {n: t.detach() for n, t in self._src.items()}
         desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
-                         max_tokens=self.max_tokens, ln_eps=ln_eps)
+                         max_tokens=self.max_tokens * (2 if self.gated_topk else 1), ln_eps=ln_eps)
         self._plan = C.c_void_p()
         N.check(self.lib.pv_sae_plan_create(C.byref(desc), C.byref(self._plan)), "pv_sae_plan_create")
         self.filtered_encoder = bool(self.lib.pv_sae_encoder_is_filtered(self._plan))
@@ -117,8 +120,9 @@ class NativeSAE:
         self.fire_count = torch.zeros(self.d_sae, **f32)
         self.scalars = torch.zeros(8, **f32)
         self.sq_partial = torch.zeros(1024, **f32)
-        self.topk_idx = torch.zeros(self.max_tokens, self.k, dtype=torch.int32, device=dev)
-        self.topk_val = torch.zeros(self.max_tokens, self.k, **f32)
+        rows = self.max_tokens * (2 if self.gated_topk else 1)             # (top-k gated: the magnitude list, then the gate list)
+        self.topk_idx = torch.zeros(rows, self.k, dtype=torch.int32, device=dev)
+        self.topk_val = torch.zeros(rows, self.k, **f32)
         self.sae_out = torch.zeros(self.max_tokens, self.d_in, **f32)
         self.workspace = torch.empty(self.lib.pv_sae_workspace_bytes(self._plan), dtype=torch.uint8, device=dev)
         self._tc_scratch = None
@@ -127,7 +131,11 @@ class NativeSAE:
             self._tc_scratch = torch.empty(self.lib.pv_sae_transcoder_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8,
                                            device=dev)
         self._gt_scratch = None
-        if self.gated:
+        self._gk_scratch = None
+        if self.gated_topk:
+            self._gk_scratch = torch.empty(self.lib.pv_sae_gated_topk_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8,
+                                           device=dev)
+        elif self.gated:
             self._gt_scratch = torch.empty(self.lib.pv_sae_gated_scratch_bytes(self._plan, self.max_tokens), dtype=torch.uint8, device=dev)
         self.adam_step = 0
         self.relu_cap = 256                                        # per-token capacity of relu_step's sparse form
@@ -178,7 +186,8 @@ class NativeSAE:
             kw["g" + short] = g[name].data_ptr()
             kw["m" + short] = m[name].data_ptr()
             kw["v" + short] = v[name].data_ptr()
-        return N.SaeGated(scratch=self._gt_scratch.data_ptr(), scratch_bytes=self._gt_scratch.numel(), **kw)
+        sc = self._gt_scratch
+        return N.SaeGated(scratch=sc.data_ptr() if sc is not None else None, scratch_bytes=sc.numel() if sc is not None else 0, **kw)
 
     def _tc_state(self) -> N.SaeTranscoder:
         if not self.transcoder:
@@ -446,6 +455,26 @@ class NativeSAE:
             N.check(self.lib.pv_sae_gated_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                                ng, flags, float(l1_coefficient), C.byref(out), self.workspace.data_ptr(),
                                                self.workspace.numel(), self._stream()), "pv_sae_gated_step")
+        self._inv_norm_key = None
+        self._grad_fresh = False
+        self._grad_sparse = False
+
+    def gated_topk_step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
+                        update_stats: bool = True, want_out: bool = False) -> None:
+        """One train step of a gated SAE in its top-k form (pv_sae_gated_topk_step): contract as ``gated_step`` (scalars[4] = 0: no L1
+        term).  ``topk_idx / topk_val`` rows [0, n) = the magnitude list (feature_acts), rows [n, 2 n) = the gate list."""
+        assert self.gated_topk
+        x = self._check_x(x)
+        self._ensure_shadows()
+        n = x.shape[0]
+        st = self._state()
+        out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=self.topk_idx.data_ptr(),
+                       topk_val=self.topk_val.data_ptr(), scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
+        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        N.check(self.lib.pv_sae_gated_topk_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
+                                                int(n_global if n_global is not None else n), int(bool(update_stats)) | 2, C.byref(out),
+                                                self.workspace.data_ptr(), self.workspace.numel(), self._gk_scratch.data_ptr(),
+                                                self._gk_scratch.numel(), self._stream()), "pv_sae_gated_topk_step")
         self._inv_norm_key = None
         self._grad_fresh = False
         self._grad_sparse = False

@@ -205,8 +205,10 @@ class VisionSAETrainer:
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own step (pv_sae_gated_step_sparse: the open gates
         # as per-token lists where the batch allows it, the dense GEMMs of pv_sae_gated_step otherwise -- decided on the GPU)
-        is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.activation_fn_str == "relu"
-                    and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0)
+        # ... and the top-k form (TopK on the magnitudes and on the gate activations) its own k-sparse step (pv_sae_gated_topk_step)
+        is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
+                    and (cfg.activation_fn_str == "relu"
+                         or (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64)))
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
@@ -242,8 +244,6 @@ class VisionSAETrainer:
             why.append(f"k = {cfg.activation_fn_kwargs.get('k')} (supported: 1..64)")
         if cfg.activation_fn_str not in ("topk", "relu"):
             why.append(f"activation {cfg.activation_fn_str!r}")
-        if getattr(cfg, "architecture", "standard") == "gated" and cfg.activation_fn_str != "relu":
-            why.append("the top-k form of the gated SAE")
         if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
             why.append("a transcoder with d_out != d_in")
         if cfg.normalize_activations not in ("layer_norm", "none", None):
@@ -278,7 +278,8 @@ class VisionSAETrainer:
                             layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world),
                             **{n: P_[n] for n in tc_names},
-                            **({"gated": {n: P_[n] for n in ("b_gate", "r_mag", "b_mag")}} if "b_gate" in P_ else {}))
+                            **({"gated": {n: P_[n] for n in ("b_gate", "r_mag", "b_mag")},
+                                "gated_topk": sae.cfg.activation_fn_str == "topk"} if "b_gate" in P_ else {}))
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
@@ -432,7 +433,9 @@ class VisionSAETrainer:
         target = self._target if eng.transcoder else None
 
         def run(**kw):
-            if gated:
+            if gated and getattr(eng, "gated_topk", False):
+                eng.gated_topk_step(x, **kw)
+            elif gated:
                 eng.gated_step(x, l1, **kw)
             elif kw.get("dead_mask") is not None:                 # ghost gradients: exp(hidden_pre) of the dead columns is a dense quantity
                 eng.dense_step(x, l1, renorm_decoder=True, target=target, **kw)
