@@ -249,12 +249,19 @@ class OracleGatedEngine(OracleEngine):
 
         self._g, self._m, self._v = views(self.flat_g), views(self.flat_m), views(self.flat_v)
 
-    def gated_step(self, x, l1_coefficient, batch_mean=None, n_global=None, update_stats=True, want_out=False):
+    gated_topk = False                                            # (set by the test: the top-k form, NativeSAE(gated_topk=True))
+
+    def gated_topk_step(self, x, batch_mean=None, n_global=None, update_stats=True, want_out=False):
+        assert self.gated_topk
+        return self.gated_step(x, 0.0, batch_mean=batch_mean, n_global=n_global, update_stats=update_stats, want_out=want_out, k=self.k)
+
+    def gated_step(self, x, l1_coefficient, batch_mean=None, n_global=None, update_stats=True, want_out=False, cap=None, sparse=True,
+                   k=None):
         self.renorm_decoder()
         P = {n: t.numpy() for n, t in self.params.items() if n != "b_enc"}
         xn = x.numpy()
         bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
-        fw = O.gated_forward(P, xn, l1_coefficient=l1_coefficient, batch_mean=bm, n_global=n_global)
+        fw = O.gated_forward(P, xn, l1_coefficient=l1_coefficient, batch_mean=bm, n_global=n_global, k=k)
         g = O.gated_backward(P, xn, fw, l1_coefficient=l1_coefficient)
         self.flat_g.zero_()
         self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))

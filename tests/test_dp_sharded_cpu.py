@@ -184,7 +184,7 @@ def test_relu_l1_data_parallel_step_equals_single_process_oracle(world):
 
 
 # ---- Gated SAE, data parallel: the same orchestration around pv_sae_gated_step (batch_mean / n_global)
-def _gated_worker(rank, world, port, q, init):
+def _gated_worker(rank, world, port, q, init, topk=False):
     import torch.distributed as dist
     from vit_prisma_amd.sae import GatedSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
     from _cpu_engine import OracleGatedEngine
@@ -193,8 +193,9 @@ def _gated_worker(rank, world, port, q, init):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)
     cfg = VisionModelSAERunnerConfig(
-        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN, activation_fn_str="relu",
-        activation_fn_kwargs={}, l1_coefficient=L1C, architecture="gated", normalize_activations="layer_norm", b_dec_init_method="mean",
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
+        activation_fn_str="topk" if topk else "relu", activation_fn_kwargs={"k": K} if topk else {}, l1_coefficient=L1C,
+        architecture="gated", normalize_activations="layer_norm", b_dec_init_method="mean",
         train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cpu", log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
         seed=7 + rank)
     tr = VisionSAETrainer(cfg, model=None, dataset=None)
@@ -211,6 +212,7 @@ def _gated_worker(rank, world, port, q, init):
             for p in s.parameters():
                 dist.broadcast(p.data, src=0)
             tr._engine = OracleGatedEngine(s, n_tokens)
+            tr._engine.gated_topk, tr._engine.k = topk, K
         return tr._engine
 
     tr._get_engine = get_engine
@@ -230,7 +232,10 @@ def _gated_worker(rank, world, port, q, init):
     dist.destroy_process_group()
 
 
-def test_gated_data_parallel_step_equals_single_process_oracle():
+@pytest.mark.parametrize("topk", [False, True])
+def test_gated_data_parallel_step_equals_single_process_oracle(topk):
+    """(topk: the top-k form of the gated SAE -- TopK on the magnitudes and on the gate activations, no L1 term -- through the same
+    token-sharded orchestration)"""
     world = 2
     rs = np.random.RandomState(9)
     init = dict(synth_sae_state(D_IN, D_SAE, 0))
@@ -239,7 +244,7 @@ def test_gated_data_parallel_step_equals_single_process_oracle():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gated_worker, args=(r, world, port, q, init)) for r in range(world)]
+    procs = [ctx.Process(target=_gated_worker, args=(r, world, port, q, init, topk)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -249,7 +254,8 @@ def test_gated_data_parallel_step_equals_single_process_oracle():
     P = {k: v.copy() for k, v in init.items() if k != "b_enc"}
     opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
     stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
-    want = [O.gated_train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), lr=1e-3, step=t + 1, l1_coefficient=L1C) for t in range(STEPS)]
+    want = [O.gated_train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), lr=1e-3, step=t + 1, l1_coefficient=L1C, k=K if topk else None)
+            for t in range(STEPS)]
     for rank, out, losses, act, since in got:
         for t, (loss, mse, l1, l0, aux) in enumerate(losses):
             for gotv, key in ((loss, "loss"), (mse, "mse_loss"), (l1, "l1_loss"), (aux, "aux_loss")):
