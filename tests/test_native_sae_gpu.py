@@ -34,7 +34,8 @@ def fresh(d_in, d_sae):
 # (768, 49152): the x64 CLIP-B/32 SAEs of the reference's docs/sae_table.md (d_sae > 32768: two blocks of the CSR scan, 192
 # candidate tiles, 3072 sampled values per token); (512, 65536): the plan's upper bound
 @pytest.mark.parametrize("d_in,d_sae,k,n", [(64, 512, 8, 256), (96, 1024, 16, 300), (768, 24576, 32, 4096),
-                                            (768, 49152, 32, 1024), (768, 49152, 64, 512), (512, 65536, 32, 300)])
+                                            (768, 49152, 32, 1024), (768, 49152, 64, 512), (512, 65536, 32, 300),
+                                            (1280, 20480, 32, 1024), (1156, 4624, 16, 300)])       # (d_in up to 1280: ViT-H/14's width; ragged beyond 1024)
 def test_native_step_vs_oracle(d_in, d_sae, k, n):
     P, opt, stats, T = fresh(d_in, d_sae)
     eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
@@ -379,7 +380,7 @@ def _both_paths(eng, x, tuning, loop=-1):
 
 @pytest.mark.parametrize("loop", [-1, 0])
 @pytest.mark.parametrize("d_in,d_sae,k,n", [(128, 8192, 16, 600), (768, 24576, 32, 1100), (96, 4096, 64, 257), (104, 4096, 16, 300),
-                                            (768, 49152, 32, 700), (768, 3072, 32, 900), (128, 2048, 8, 300)])
+                                            (768, 49152, 32, 700), (768, 3072, 32, 900), (128, 2048, 8, 300), (1280, 20480, 32, 500)])
 def test_filtered_encoder_equals_exact_path(d_in, d_sae, k, n, loop, tuning):
     _, _, _, T = fresh(d_in, d_sae)
     T["b_enc"].mul_(20.0)                                                  # biases that matter
@@ -787,7 +788,8 @@ def ghost_tolerances(floor):
 @pytest.mark.parametrize("d_in,d_sae,n,ln,ghost", [(64, 512, 256, True, False), (136, 1056, 300, False, False), (768, 8192, 1024, True, False),
                                                    (64, 512, 256, True, True), (136, 1056, 300, False, True), (768, 8192, 1024, True, True),
                                                    (768, 24576, 4096, True, False), (768, 24576, 4096, True, True),
-                                                   (768, 49152, 1024, True, False), (768, 49152, 1024, True, True)])
+                                                   (768, 49152, 1024, True, False), (768, 49152, 1024, True, True),
+                                                   (1280, 10240, 512, True, True)])
 def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
     """pv_sae_dense_step + grad_sqnorm + apply against the ReLU + L1 form of the oracle (pinned to the reference fixtures by
     tests/test_oracle_sae_vs_golden.py): losses, l0, every gradient tensor, parameters, statistics; ragged shapes (partial
@@ -1080,7 +1082,8 @@ def fresh_transcoder(d_in, d_sae, skip):
                                                     (768, 8192, None, 1024, True, True),
                                                     # the benchmarked shape (768 -> 24576, 4096 tokens) and the published x64 width, both steps
                                                     (768, 24576, 32, 4096, True, True), (768, 24576, None, 4096, True, True),
-                                                    (768, 49152, 32, 1024, True, True), (768, 49152, None, 1024, True, False)])
+                                                    (768, 49152, 32, 1024, True, True), (768, 49152, None, 1024, True, False),
+                                                    (1280, 10240, 32, 512, True, True)])
 def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
     """A Transcoder (target activation, b_dec_out, optional W_skip) on the top-k step (k given) and on the dense ReLU + L1 step
     (k = None) against the oracle's transcoder form (pinned to the reference's own Transcoder run by
@@ -1209,7 +1212,8 @@ def _shut_gates(P, x, ln, open_max):
     # a batch whose gates are mostly shut runs SPARSE (pv_sae_gated_step_sparse; "fallback": the same batch with a capacity it cannot
     # be held in -- the mode word sends it to the dense GEMMs; "forced": sparse=False)
     (768, 8192, 1024, True, "sparse"), (256, 2048, 300, False, "sparse"), (768, 24576, 4096, True, "sparse"),
-    (1024, 16384, 512, True, "sparse"), (768, 8192, 1024, True, "fallback"), (768, 8192, 1024, True, "forced")])
+    (1024, 16384, 512, True, "sparse"), (1280, 10240, 512, True, "sparse"), (768, 8192, 1024, True, "fallback"),
+    (768, 8192, 1024, True, "forced")])
 def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
     """pv_sae_gated_step(_sparse) + grad_sqnorm + apply against the oracle's gated form (pinned to the reference's own
     GatedSparseAutoencoder run by tests/test_oracle_sae_vs_golden.py): the four losses, l0, every gradient tensor, the clip norm,
@@ -1294,7 +1298,7 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
 
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("d_in,d_sae,k,n,ln", [(64, 512, 8, 256, True), (136, 1056, 16, 300, False), (768, 8192, 32, 1024, True),
-                                               (768, 24576, 32, 4096, True), (1024, 16384, 64, 512, True)])
+                                               (768, 24576, 32, 4096, True), (1024, 16384, 64, 512, True), (1280, 10240, 32, 512, True)])
 def test_gated_topk_step_vs_oracle(d_in, d_sae, k, n, ln):
     """pv_sae_gated_topk_step + grad_sqnorm + apply against the oracle's top-k gated form (pinned to the reference's own run,
     tests/test_oracle_sae_vs_golden.py): losses, l0, the two k-sparse lists, every gradient tensor, the clip norm, parameters and
@@ -1584,7 +1588,8 @@ def _shift_b_enc_for_l0(P, x, ln, want_l0):
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("d_in,d_sae,n,ln,l0,tc", [(64, 2048, 256, True, 12, False), (136, 2304, 300, False, 20, False),
                                                     (768, 8192, 1024, True, 24, False), (768, 8192, 1024, True, 24, True),
-                                                    (768, 24576, 4096, True, 32, False), (768, 49152, 1024, True, 60, False)])
+                                                    (768, 24576, 4096, True, 32, False), (768, 49152, 1024, True, 60, False),
+                                                    (1280, 20480, 512, True, 40, False)])
 def test_relu_step_sparse_vs_oracle(d_in, d_sae, n, ln, l0, tc):
     """relu_step in its sparse form against the ReLU + L1 oracle: the step must report mode 0, keep exactly the oracle's positive
     entries (sets equal up to entries within fp32 summation noise of zero) with the exact fp32 values, and give the losses,

@@ -1089,17 +1089,17 @@ __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restr
 constexpr int GBD_ROWS = 96;
 __global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
                                                                 float* __restrict__ partial, int d_sae, int d) {
-    __shared__ float red[3][1024];                       // waves 1..3 -> wave 0, up to 1024 columns
+    __shared__ float red[3][1280];                       // waves 1..3 -> wave 0, up to 1280 columns (d_in <= 256 * 5)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j0 = blockIdx.x * GBD_ROWS, j1 = min(j0 + GBD_ROWS, d_sae);
-    float4 acc[4];
+    float4 acc[5];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 5; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = j0 + wv; j < j1; j += 4) {
         const float g = gb_enc[j];
         if (g == 0.f) continue;                          // (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             const int c = 4 * lane + 256 * i;
             if (c < d) {
                 const float4 w = *reinterpret_cast<const float4*>(W_encT + (int64_t)j * d + c);
@@ -1109,12 +1109,12 @@ __global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __r
     }
     if (wv > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&red[wv - 1][4 * lane + 256 * i]) = acc[i];
+        for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(&red[wv - 1][4 * lane + 256 * i]) = acc[i];
     }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             const int c = 4 * lane + 256 * i;
             if (c < d) {
                 float4 t = acc[i];
@@ -1564,7 +1564,7 @@ ReluWs relu_carve(const pv_sae_desc& d, int n_tokens, int cap) {
 
 extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_plan) {
     PV_REQUIRE(desc && out_plan, "null argument");
-    PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 16 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1024");
+    PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 20 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1280 (ViT-H/14)");
     PV_REQUIRE(desc->d_sae >= desc->k && desc->d_sae % 4 == 0 && desc->d_sae <= 256 * 256, "d_sae must be a multiple of 4, <= 65536");
     PV_REQUIRE(desc->k >= 1 && desc->k <= MAXK, "k must be in [1, 64]");
     PV_REQUIRE(desc->max_tokens >= 1, "max_tokens");
@@ -1593,14 +1593,16 @@ extern "C" size_t pv_debug_sae_ws_offset(const pv_sae_plan* plan, const char* na
     do {                                    \
         if ((d_in) <= 64 * 4) { CALL(4); }  \
         else if ((d_in) <= 64 * 12) { CALL(12); } \
-        else { CALL(16); }                  \
+        else if ((d_in) <= 64 * 16) { CALL(16); } \
+        else { CALL(20); }                  \
     } while (0)
 // kernels whose lanes own 16-byte column groups: d_in <= 256 * V4
 #define V4_DISPATCH(d_in, CALL)             \
     do {                                    \
         if ((d_in) <= 256) { CALL(1); }     \
         else if ((d_in) <= 768) { CALL(3); } \
-        else { CALL(4); }                   \
+        else if ((d_in) <= 1024) { CALL(4); } \
+        else { CALL(5); }                   \
     } while (0)
 
 extern "C" int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream_) {

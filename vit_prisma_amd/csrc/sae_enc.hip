@@ -23,7 +23,8 @@
 //   |x.w - fl16(x).fl16(w)| <= (2u + u^2) sum|x_i w_i| + 2^-25 (sum|x_i| + sum|w_i|)      (operand rounding, subnormals)
 //   fp32 accumulation of exact products on the matrix core, and the fp32 re-scoring it is compared with:
 //                           <= 4 K 2^-24 sum|x_i w_i| + K 2^-24 sum|x_i w_i|
-//   => B_n = ||x_n||_2 (C1 Wmax + C2) + C2 Wmax,  C1 = 1.25e-3 >= 2^-10 (1 + 2^-12) + 5 K 2^-24 (K <= 1024),
+//   => B_n = ||x_n||_2 (C1 Wmax + C2) + C2 Wmax,  C1 = max(1.25e-3, 2^-10 (1 + 2^-12) + 5 K 2^-24) (enc_c1(K): 1.25e-3 up to K = 916,
+//      1.36e-3 at K = 1280),
 //      C2 = 2^-25 sqrt(K),  Wmax = max_j ||W_enc[:, j]||_2 (maintained by the Adam kernel as enc_colsq).
 // Rows with |x| beyond the fp16 range get B = inf (-> fallback); a weight beyond it makes its column norm inf (-> every
 // row falls back): slow, never wrong.
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
 // ---------------------------------------------------------------------------------------------------
 // thr: q-th largest of a token's sampled values, band and threshold.  One wave per token.
 // ---------------------------------------------------------------------------------------------------
-constexpr float ENC_C1 = 1.25e-3f;
+__device__ __forceinline__ float enc_c1(int K) { return fmaxf(1.25e-3f, 9.7680092e-4f + 5.0f * 5.9604645e-8f * (float)K); }
 
 template <int VPL>                                            // sampled values per lane: ns <= 64 VPL
 __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ 
     if (lane == 0) {
         const float wmx = sqrtf(*wmax_sq);
         const float c2 = 2.98023224e-8f * sqrtf((float)d_in);
-        const float B = xnorm[n] * (ENC_C1 * wmx + c2) + c2 * wmx + 4.8e-7f * fabsf(m);
+        const float B = xnorm[n] * (enc_c1(d_in) * wmx + c2) + c2 * wmx + 4.8e-7f * fabsf(m);
         sq_out[n] = m;
         band[n] = 2.0f * B;
         thr[n] = m - 2.0f * B;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(256) void sae_fb_hidden_kernel(const float* __restr
                                                             const float* __restrict__ b_enc, const int32_t* __restrict__ fb_list,
                                                             const uint32_t* __restrict__ fb_count, float* __restrict__ hidden,
                                                             int d, int d_sae) {
-    __shared__ float xs[1024];
+    __shared__ float xs[1280];
     const uint32_t nfb = *fb_count;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int jper = (d_sae + gridDim.y - 1) / gridDim.y;
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256) void relu_thr_kernel(const float* __restrict__
     if (n >= n_tok) return;
     const float wmx = sqrtf(*wmax_sq);
     const float c2 = 2.98023224e-8f * sqrtf((float)d_in);
-    const float B = xnorm[n] * (ENC_C1 * wmx + c2) + c2 * wmx;
+    const float B = xnorm[n] * (enc_c1(d_in) * wmx + c2) + c2 * wmx;
     thr[n] = (B == B) ? -B : -INFINITY;                        // (a NaN bound lets everything through: the slots overflow -> dense)
 }
 
@@ -1080,7 +1081,7 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
                        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
                        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
                        topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots)
-    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
+    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else if (d.d_in <= 1024) { CALL(4); } else { CALL(5); }
 #undef CALL
     PV_LAUNCH_CHECK("sae_select_kernel");
     // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)
@@ -1124,7 +1125,7 @@ int sae_encode_relu(const pv_sae_desc& d, const pv_sae_state* st, int N, int cap
         hipLaunchKernelGGL((relu_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                \
                            (const float*)st->W_encT, bias, (const uint32_t*)cand_cnt, (const int2*)cand,                           \
                            (const float*)(wsb + ws.thr), idx, val, tok_cnt, l1part, feat_cnt, wpos, mode, d.d_in, cap, ntn, PV_SAE_RELU_SLOTS)
-    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else { CALL(4); }
+    if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else if (d.d_in <= 1024) { CALL(4); } else { CALL(5); }
 #undef CALL
     PV_LAUNCH_CHECK("relu_select_kernel");
     return PV_OK;

@@ -212,7 +212,7 @@ class VisionSAETrainer:
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
-                  and cfg.d_in % 4 == 0 and cfg.d_in <= 1024 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
+                  and cfg.d_in % 4 == 0 and cfg.d_in <= 1280 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                   and self._native_pref is not False)
         if not common:
             return None
@@ -236,8 +236,8 @@ class VisionSAETrainer:
         why = []
         if cfg.dtype != torch.float32:
             why.append(f"dtype {cfg.dtype} (the fused steps keep fp32 master weights)")
-        if cfg.d_in > 1024 or cfg.d_in % 4:
-            why.append(f"d_in = {cfg.d_in} (supported: multiples of 4 up to 1024; ViT-H/14's 1280 is not)")
+        if cfg.d_in > 1280 or cfg.d_in % 4:
+            why.append(f"d_in = {cfg.d_in} (supported: multiples of 4 up to 1280 = ViT-H/14)")
         if cfg.d_sae > 65536 or cfg.d_sae % 4:
             why.append(f"d_sae = {cfg.d_sae} (supported: multiples of 4 up to 65536)")
         if cfg.activation_fn_str == "topk" and not 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64:
