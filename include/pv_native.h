@@ -45,7 +45,7 @@ extern "C" {
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
  * gemm_persist / gemm_stagger tuning keys). */
-#define PV_ABI_VERSION 19
+#define PV_ABI_VERSION 20
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -457,13 +457,22 @@ int pv_sae_tp_bucket_unpack(pv_sae_plan* plan, const float* bucket, float* scala
  * (pv_sae_ghost_workspace_bytes).  The step then adds the ghost residual loss (scalars[5]; the reference adds it even when
  * no feature is dead) and its gradient: exp(hidden_pre) of the dead columns leaves the encoder GEMM's epilogue, three small
  * GEMMs over the dead columns do the rest, the result joins dH in the G3 epilogue and gW_dec by a row scatter-add.
- * Single process only (n_global == n_tokens).  NULL = no ghost gradients. */
+ * NULL = no ghost gradients.
+ * Tokens sharded over ranks (n_global > n_tokens): the ghost term normalises by the residual's column mean and rescales by the mse
+ * loss OF THE WHOLE BATCH (sae.py:156, :172), so the caller provides both -- err_colmean [d_in] = mean over the global batch of
+ * (sae_out - target) and mse_global (device scalar) -- from a forward of the same batch (pv_sae_topk_ghost: the pv_sae_step before it;
+ * pv_sae_dense_step: a pass without ghost gradients) and an all-reduce; n_global (pv_sae_topk_ghost; the dense step takes its own
+ * argument) = the global token count.  All three zero / NULL: single process. */
 typedef struct pv_sae_ghost {
     int32_t n_dead;
     const int32_t* dead_idx;
     const int32_t* dead_slot;
     void* workspace;
     size_t workspace_bytes;
+    const float* err_colmean;
+    const float* mse_global;
+    int32_t n_global;
+    int32_t reserved;
 } pv_sae_ghost;
 size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t n_tokens, int32_t n_dead);
 int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens, const float* batch_mean,

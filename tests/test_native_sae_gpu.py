@@ -286,13 +286,14 @@ def _rccl_world1_worker(port, q, mode):
     dist.init_process_group("nccl", rank=0, world_size=1)
     dev = torch.device("cuda:0")
     d_in, d_sae, k, N = 768, 6144, 32, 1024
-    relu = mode == "relu_dp"
+    relu = mode in ("relu_dp", "relu_ghost_dp")
     tc = mode == "topk_tc_dp"
+    ghost = mode.endswith("ghost_dp")
     cfg = VisionModelSAERunnerConfig(
         hook_point_layer=1, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in,
         activation_fn_str="relu" if relu else "topk", activation_fn_kwargs={} if relu else {"k": k}, l1_coefficient=3e-3,
         normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda",
-        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0,
+        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0, use_ghost_grads=ghost, dead_feature_window=1 if ghost else 5000,
         **(dict(is_transcoder=True, transcoder_with_skip_connection=True, d_out=d_in, out_hook_point_layer=1) if tc else {}))
     if tc:
         from vit_prisma_amd.sae import Transcoder
@@ -304,9 +305,29 @@ def _rccl_world1_worker(port, q, mode):
     with torch.no_grad():
         for n, v in init.items():
             getattr(sae, n).copy_(torch.from_numpy(v))
+    import copy
+    single = None
+    if mode == "topk_ghost_dp":
+        # the same three steps on the single-process path first: the top-k ghost term's gradient is ill-conditioned in fp32 where the
+        # ghost reconstruction meets the residual (r = mse / (mg + 1e-6) with mg -> 0), so after three Adam steps the PARAMETERS are
+        # compared with the single-process engine's and the losses with the oracle's
+        sae1 = copy.deepcopy(sae)
+        tr1 = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae1).use_native(True)
+        a1, s1, f1, o1, sc1 = tr1.initialize_training_variables()
+        s1[::3] = 5.0
+        for t in range(3):
+            x = torch.from_numpy(synth_sae_batch(N, d_in, seed=10 + t)).to(dev)[:, None, :].contiguous()
+            _, _, _, _, a1, s1, f1 = tr1.train_step(sparse_autoencoder=sae1, optimizer=o1, scheduler=sc1, act_freq_scores=a1,
+                                                    n_forward_passes_since_fired=s1, n_frac_active_tokens=f1, layer_acts=x,
+                                                    n_training_steps=t, n_training_tokens=t * N)
+        tr1.sync_parameters()
+        single = {n: getattr(sae1, n).detach().cpu().numpy() for n in init}
+        single["act_freq"] = a1.cpu().numpy()
     tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_native(True).force_distributed_paths(True)
     tr.use_feature_parallel(mode == "topk_tp")
     act, since, frac, opt, sched = tr.initialize_training_variables()
+    if ghost:
+        since[::3] = 5.0                          # a third of the features count as dead (window 1): the ghost term is live
     out = []
     for t in range(3):
         x = torch.from_numpy(synth_sae_batch(N, d_in, seed=10 + t)).to(dev)[:, None, :].contiguous()
@@ -319,15 +340,16 @@ def _rccl_world1_worker(port, q, mode):
         out.append((float(loss), float(l0)))
     took = {"topk_dp": tr._engine is not None and tr._fp is None and not tr._engine.lazy_w_enc,
             "topk_tp": tr._fp is not None, "relu_dp": tr._engine is not None,
-            "topk_tc_dp": tr._engine is not None and tr._engine.transcoder and tr._fp is None}[mode]
+            "topk_tc_dp": tr._engine is not None and tr._engine.transcoder and tr._fp is None,
+            "topk_ghost_dp": tr._engine is not None and tr._fp is None, "relu_ghost_dp": tr._engine is not None}[mode]
     tr.sync_parameters()
-    q.put((out, {n: getattr(sae, n).detach().cpu().numpy() for n in init}, act.cpu().numpy(), took, dist.get_backend()))
+    q.put((out, {n: getattr(sae, n).detach().cpu().numpy() for n in init}, act.cpu().numpy(), took, dist.get_backend(), single))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["topk_dp", "topk_tp", "relu_dp", "topk_tc_dp"])
+@pytest.mark.parametrize("mode", ["topk_dp", "topk_tp", "relu_dp", "topk_tc_dp", "topk_ghost_dp", "relu_ghost_dp"])
 def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
     """the trainer's data-parallel step (sharded optimizer), its feature-parallel step and the dense step's
     data-parallel form, each through torch.distributed on the NCCL backend (RCCL) with a world of one rank, against the
@@ -340,26 +362,34 @@ def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_worker, args=(port, q, mode))
     p.start()
-    out, params, act, took, backend = _queue_get_or_fail(q, [p], 600)
+    out, params, act, took, backend, single = _queue_get_or_fail(q, [p], 600)
     p.join(timeout=120)
     assert p.exitcode == 0 and took and backend == "nccl"
     d_in, d_sae, k, N = 768, 6144, 32, 1024
-    relu = mode == "relu_dp"
+    relu = mode in ("relu_dp", "relu_ghost_dp")
+    ghost = mode.endswith("ghost_dp")            # (use_ghost_grads with a process group: the global residual mean / mse exchange)
     tc = mode == "topk_tc_dp"                    # (a top-k Transcoder with the skip connection: the token-sharded step's transcoder branch)
     P = {kk: v.copy() for kk, v in (_tc_init(d_in, d_sae) if tc else synth_sae_state(d_in, d_sae, 0)).items()}
     opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
     stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    if ghost:
+        stats["n_fwd_since_fired"][::3] = 5.0
     for t in range(3):
         ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=10 + t), None if relu else k, lr=1e-3, step=t + 1,
-                           l1_coefficient=3e-3 if relu else 0.0, target=synth_sae_batch(N, d_in, seed=60 + t) if tc else None)
+                           l1_coefficient=3e-3 if relu else 0.0, target=synth_sae_batch(N, d_in, seed=60 + t) if tc else None,
+                           dead_feature_window=1 if ghost else None)
         assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
     # (relu_dp runs from the synthetic init, where half of all pre-activations are positive: a few of the 6.3 M per step lie within fp32
     # summation noise of zero and take the other side of the ReLU than numpy's; Adam turns those entries into lr-sized differences --
     # measured 1.8e-4 on W_enc after three steps with every loss within 1e-4)
     ptol = 5e-4 if relu else TOL
     for n in P:
-        assert rel_fro(params[n], P[n]) < ptol, n
-    assert np.abs(act - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
+        if single is not None:                   # (topk_ghost_dp: against the single-process engine, see the worker)
+            assert rel_fro(params[n], single[n]) < 1e-3, n
+        else:
+            assert rel_fro(params[n], P[n]) < ptol, n
+    want_act = single["act_freq"] if single is not None else stats["act_freq_scores"]
+    assert np.abs(act - want_act).sum() <= TOL * want_act.sum()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1399,6 +1429,45 @@ def test_variant_steps_on_token_shards_sum_to_the_whole_batch(kind):
         assert abs(float(sc0[slot] + sc1[slot]) - float(sc_all[slot])) <= TOL * abs(float(sc_all[slot])), slot
     assert abs(float(sc0[2] + sc1[2]) / 2 - float(sc_all[2])) <= TOL * float(sc_all[2])
     assert torch.equal(f0 + f1, fire_all)
+
+
+@pytest.mark.parametrize("kind", ["relu", "topk"])
+def test_ghost_gradient_steps_on_token_shards_sum_to_the_whole_batch(kind):
+    """Ghost gradients with the tokens sharded over ranks (pv_sae_ghost.err_colmean / mse_global / n_global): the ghost term normalises
+    by the residual's column mean and rescales by the mse loss of the WHOLE batch (sae.py:156, :172), so two half batches that are
+    given both give gradients and losses that add up to the whole batch's -- on the dense ReLU + L1 step and on the top-k step +
+    pv_sae_topk_ghost (one engine, the halves one after the other; statistics off; a third of the features dead)."""
+    d_in, d_sae, n, l1c, k = 136, 1056, 512, 3e-3, 16
+    P, opt, stats, T = fresh(d_in, d_sae)
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n)
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=0)).cuda()
+    dead = torch.zeros(d_sae, dtype=torch.bool, device="cuda")
+    dead[::3] = True
+
+    def run(xs, ghost_global=None, **kk):
+        if kind == "relu":
+            eng.dense_step(xs, l1c, update_stats=False, want_out=True, dead_mask=dead, ghost_global=ghost_global, **kk)
+        else:
+            eng.renorm_decoder()
+            eng.step(xs, update_stats=False, renorm_decoder=False, want_out=True, **kk)
+            eng.topk_ghost(xs, dead, ghost_global=ghost_global)
+        torch.cuda.synchronize()
+        return eng.flat_g.clone(), eng.scalars.clone(), eng.sae_out[:xs.shape[0]].clone()
+
+    g_all, sc_all, out_all = run(x)
+    assert float(sc_all[5]) > 0
+    glob = ((out_all - x).mean(dim=0), sc_all[1:2].clone(), n)
+    bm = x.mean(dim=0)
+    h = n // 2
+    g0, sc0, _ = run(x[:h].contiguous(), ghost_global=glob, batch_mean=bm, n_global=n)
+    g1, sc1, _ = run(x[h:].contiguous(), ghost_global=glob, batch_mean=bm, n_global=n)
+    assert rel_fro((g0 + g1).cpu().numpy(), g_all.cpu().numpy()) < TOL
+    for slot in (0, 1, 5) + ((4,) if kind == "relu" else ()):
+        assert abs(float(sc0[slot] + sc1[slot]) - float(sc_all[slot])) <= TOL * abs(float(sc_all[slot])), slot
+    # and without the global quantities a sharded call is refused rather than silently wrong
+    from vit_prisma_amd._native import NativeError
+    with pytest.raises(NativeError):
+        eng.dense_step(x[:h].contiguous(), l1c, update_stats=False, dead_mask=dead, batch_mean=bm, n_global=n)
 
 
 @pytest.mark.parametrize("variant", ["gated", "gated_topk"])

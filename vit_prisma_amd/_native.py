@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -79,7 +79,8 @@ class SaeState(C.Structure):
 
 class SaeGhost(C.Structure):
     _fields_ = [("n_dead", C.c_int32), ("dead_idx", C.c_void_p), ("dead_slot", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("err_colmean", C.c_void_p), ("mse_global", C.c_void_p), ("n_global", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class SaeReluSparse(C.Structure):

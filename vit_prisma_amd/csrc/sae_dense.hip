@@ -432,9 +432,11 @@ __global__ __launch_bounds__(256) void ghost_scatter_add_rows_kernel(float* __re
 //   mg = (G - res)^2 / den;  r = mse_loss / (mg + 1e-6)  (detached);  ghost loss = mean(r mg)
 //   d ghost / d G0 = s r 2 (G - res) / (den N d)
 __global__ __launch_bounds__(256) void ghost_rows_kernel(const float* __restrict__ err, const float* __restrict__ G0,
-                                                         const float* __restrict__ colmean_err, const float* __restrict__ scalars,
+                                                         const float* __restrict__ colmean_err, const float* __restrict__ mse_ptr,
                                                          float* __restrict__ dG0, float* __restrict__ part, int n_tok, int d,
                                                          float inv_count) {
+    // colmean_err / mse_ptr / inv_count: over the GLOBAL batch (tokens sharded over ranks: pv_sae_ghost.err_colmean / mse_global /
+    // n_global), this call's own batch otherwise
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void ghost_rows_kernel(const float* __restrict
     r2 = wave_sum(r2); g2 = wave_sum(g2); c2 = wave_sum(c2);
     const float s = sqrtf(r2) / (1e-6f + 2.0f * sqrtf(g2));
     const float den = sqrtf(c2);
-    const float mse = scalars[1];
+    const float mse = *mse_ptr;
     float acc = 0.f;
     for (int i = lane; i < d; i += 64) {
         const float res = -e[i], diff = g0[i] * s - res;
@@ -689,13 +691,18 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
             } else {
                 PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
             }
-            rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
-            if (rc) return rc;
-            hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0,
-                               (const float*)(gwb + gw.colmean), (const float*)out->scalars, dg0, (float*)(gwb + gw.part), N, D,
-                               1.0f / ((float)N * (float)D));
+            const float* colmean = ghost->err_colmean;
+            if (!colmean) {
+                rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
+                if (rc) return rc;
+                colmean = (const float*)(gwb + gw.colmean);
+            }
+            const float inv_cnt = 1.0f / ((float)n_global * (float)D);
+            hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0, colmean,
+                               ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + 1), dg0, (float*)(gwb + gw.part), N, D,
+                               inv_cnt);
             PV_LAUNCH_CHECK("ghost_rows_kernel");
-            sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, 1.0f / ((float)N * (float)D), 5, -1, stream);
+            sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, inv_cnt, 5, -1, stream);
             if (nd > 0) {
                 DenseGemm gb = {};
                 gb.A = dg0; gb.lda = D; gb.B = wdd; gb.ldb = D; gb.M = N; gb.N = gw.n_pad; gb.K = D; gb.k_chunk = D;
@@ -827,7 +834,8 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     GhostWs gw = {};
     const int nd = ghost ? ghost->n_dead : 0;
     if (ghost) {
-        PV_REQUIRE(n_global == N, "ghost gradients: single process only");
+        PV_REQUIRE(n_global == N || (ghost->err_colmean && ghost->mse_global),
+                   "ghost gradients with tokens sharded over ranks need pv_sae_ghost.err_colmean and mse_global (the global batch's)");
         PV_REQUIRE(nd >= 0 && nd <= d.d_sae && ghost->workspace && (nd == 0 || (ghost->dead_idx && ghost->dead_slot)), "pv_sae_ghost");
         gw = ghost_carve(d, N, nd);
         PV_REQUIRE(ghost->workspace_bytes >= gw.total && ((uintptr_t)ghost->workspace & 255) == 0, "ghost workspace too small / misaligned");
@@ -1031,13 +1039,20 @@ extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const floa
     } else {
         PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
     }
-    rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0,
-                       (const float*)(gwb + gw.colmean), (const float*)out->scalars, dg0, (float*)(gwb + gw.part), N, D,
-                       1.0f / ((float)N * (float)D));
+    const float* colmean = ghost->err_colmean;
+    if (!colmean) {
+        rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
+        if (rc) return rc;
+        colmean = (const float*)(gwb + gw.colmean);
+    }
+    const int ng = ghost->n_global > 0 ? ghost->n_global : N;
+    PV_REQUIRE(ng >= N && (ng == N || (ghost->err_colmean && ghost->mse_global)),
+               "pv_sae_ghost.n_global > n_tokens needs err_colmean and mse_global (the global batch's)");
+    const float inv_cnt = 1.0f / ((float)ng * (float)D);
+    hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0, colmean,
+                       ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + 1), dg0, (float*)(gwb + gw.part), N, D, inv_cnt);
     PV_LAUNCH_CHECK("ghost_rows_kernel");
-    sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, 1.0f / ((float)N * (float)D), 5, -1, stream);
+    sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, inv_cnt, 5, -1, stream);
     hipLaunchKernelGGL(topk_ghost_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
     if (nd > 0) {
         // dHd = (dG0 @ W_dec[dead]^T) * E: what reaches hidden_pre of the dead features, for every token

@@ -300,12 +300,13 @@ class NativeSAE:
     def dense_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
                    renorm_decoder: bool = True, dead_mask: Optional[torch.Tensor] = None,
-                   target: Optional[torch.Tensor] = None) -> None:
+                   target: Optional[torch.Tensor] = None, ghost_global=None) -> None:
         """The ReLU + L1 step (pv_sae_dense_step): forward + backward + statistics on dense fp32 MFMA GEMMs with fused
         epilogues; gradients are written into ``flat_g`` (complete); scalars = loss, mse_loss, l0, -, l1_loss, ghost loss.  The
         engine's ``k`` plays no role.  dead_mask [d_sae] bool (use_ghost_grads: ``n_forward_passes_since_fired >
         dead_feature_window`` BEFORE this step, train_sae.py:330-332): adds the ghost residual loss and its gradient
-        (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs).  target: as in ``step``."""
+        (sae.py:151-179); costs one device read-back (the number of dead features sizes three small GEMMs).  target: as in ``step``.
+        ghost_global: as in ``_ghost_struct`` (required for ghost gradients with n_global > the tokens of this call)."""
         x = self._check_x(x)
         self._set_target(x, target)
         self._ensure_shadows()                                    # (the encoder is read as W_encT: an outside edit of W_enc must reach it)
@@ -314,7 +315,7 @@ class NativeSAE:
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
         bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
-        ghost = self._ghost_struct(dead_mask, n) if dead_mask is not None else None
+        ghost = self._ghost_struct(dead_mask, n, ghost_global) if dead_mask is not None else None
         N.check(self.lib.pv_sae_dense_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                            int(n_global if n_global is not None else n),
                                            int(bool(update_stats)) | (2 if renorm_decoder else 0), float(l1_coefficient),
@@ -385,8 +386,10 @@ class NativeSAE:
         return (self._relu_region(b"idx", torch.int32, (n, cap)), self._relu_region(b"val", torch.float32, (n, cap)),
                 self._relu_region(b"tok_cnt", torch.int32, (n,)))
 
-    def _ghost_struct(self, dead_mask: torch.Tensor, n: int) -> "N.SaeGhost":
-        """pv_sae_ghost for the features ``dead_mask`` marks (one device read-back: their number sizes three small GEMMs)."""
+    def _ghost_struct(self, dead_mask: torch.Tensor, n: int, ghost_global=None) -> "N.SaeGhost":
+        """pv_sae_ghost for the features ``dead_mask`` marks (one device read-back: their number sizes three small GEMMs).
+        ghost_global = (err_colmean [d_in], mse [1], n_global): the residual's column mean and the mse loss of the GLOBAL batch when
+        the tokens are sharded over ranks (sae.py:156, :172 take them over the whole batch)."""
         idx = torch.nonzero(dead_mask.to(self.device), as_tuple=False).flatten().to(torch.int32)     # (synchronises: n_dead is a launch size)
         nd = int(idx.numel())
         slot = torch.full((self.d_sae,), -1, dtype=torch.int32, device=self.device)
@@ -397,14 +400,22 @@ class NativeSAE:
         if gws is None or gws.numel() < need:
             self._ghost_ws = gws = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._ghost_keep = (idx, slot)                            # (alive until the kernels have run)
+        extra = {}
+        if ghost_global is not None:
+            cm, mse, ng = ghost_global
+            cm, mse = cm.to(torch.float32).contiguous(), mse.to(torch.float32).contiguous().view(-1)
+            assert cm.numel() == self.d_in and mse.numel() == 1 and cm.is_cuda and mse.is_cuda
+            self._ghost_keep += (cm, mse)
+            extra = dict(err_colmean=cm.data_ptr(), mse_global=mse.data_ptr(), n_global=int(ng))
         return N.SaeGhost(n_dead=nd, dead_idx=idx.data_ptr() if nd else None, dead_slot=slot.data_ptr(),
-                          workspace=gws.data_ptr(), workspace_bytes=gws.numel())
+                          workspace=gws.data_ptr(), workspace_bytes=gws.numel(), **extra)
 
-    def topk_ghost(self, x: torch.Tensor, dead_mask: torch.Tensor) -> None:
+    def topk_ghost(self, x: torch.Tensor, dead_mask: torch.Tensor, ghost_global=None) -> None:
         """Ghost gradients of a top-k SAE (pv_sae_topk_ghost; sae.py:151-179 with train_sae.py:330-346), added to what the
         preceding ``step(x, renorm_decoder=False, sparse_grads=False, want_out=True)`` left (the decoder renormalised by
         ``renorm_decoder()`` before it): scalars[5] = ghost residual loss, scalars[0] = mse + ghost, the dead features' gradient rows
         and gb_dec updated.  dead_mask [d_sae] bool = ``n_forward_passes_since_fired > dead_feature_window`` BEFORE that step.
+        ghost_global: as in ``_ghost_struct`` (tokens sharded over ranks: the preceding step ran with batch_mean / n_global).
         Follow with ``grad_sqnorm()`` (the full pass) and ``apply``."""
         x = self._check_x(x)
         n = x.shape[0]
@@ -412,7 +423,7 @@ class NativeSAE:
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr(), topk_idx=None, topk_val=None, scalars=self.scalars.data_ptr(),
                        fire_count=self.fire_count.data_ptr())
-        ghost = self._ghost_struct(dead_mask, n)
+        ghost = self._ghost_struct(dead_mask, n, ghost_global)
         N.check(self.lib.pv_sae_topk_ghost(self._plan, C.byref(st), x.data_ptr(), n, C.byref(ghost), C.byref(out),
                                            self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_topk_ghost")
         self._grad_fresh = False                                  # (the per-feature norm terms of the step no longer describe the buffers)

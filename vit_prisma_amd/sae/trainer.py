@@ -219,11 +219,10 @@ class VisionSAETrainer:
         if is_gated:
             return "gated"
         if (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
-                # ghost gradients on top-k (pv_sae_topk_ghost): single process, plain SAE, d_in a multiple of 8
-                and (not cfg.use_ghost_grads or (not self._mr and not is_tc and cfg.d_in % 8 == 0))):
+                # ghost gradients on top-k (pv_sae_topk_ghost): plain SAE, d_in a multiple of 8
+                and (not cfg.use_ghost_grads or (not is_tc and cfg.d_in % 8 == 0))):
             return "topk"
-        if (cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
-                and not (cfg.use_ghost_grads and self._mr)):                 # (ghost gradients natively: single process)
+        if cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0:
             return "relu"
         return None
 
@@ -248,8 +247,6 @@ class VisionSAETrainer:
             why.append("a transcoder with d_out != d_in")
         if cfg.normalize_activations not in ("layer_norm", "none", None):
             why.append(f"normalize_activations = {cfg.normalize_activations!r}")
-        if cfg.use_ghost_grads and self._mr:
-            why.append("ghost gradients with more than one rank")
         return "; ".join(why) or "a parameter is not a contiguous fp32 CUDA tensor"
 
     def _get_engine(self, sae, n_tokens: int):
@@ -389,7 +386,8 @@ class VisionSAETrainer:
         kind = self._native_kind(sae, x)
         if kind in ("relu", "gated"):
             return self._native_dense_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired, gated=kind == "gated")
-        if self._use_tp(sae) and not self.is_transcoder:        # (the feature-parallel step serves the plain SAE)
+        ghost_mr = bool(sae.cfg.use_ghost_grads) and sae.training
+        if self._use_tp(sae) and not self.is_transcoder and not ghost_mr:      # (the feature-parallel step serves the plain SAE, no ghost term)
             return self._native_tp_step(sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired)
         self._dp_flush()                                        # parameters of the previous step must have landed
         eng = self._get_engine(sae, x.shape[0])
@@ -455,7 +453,18 @@ class VisionSAETrainer:
             n_global = x.shape[0] * W
             bm = (target if target is not None else x).float().sum(dim=0)
             dist.all_reduce(bm)                                 # global batch mean of what the loss is taken against (sae.py:145)
-            run(batch_mean=bm / n_global, n_global=n_global, update_stats=False)
+            if sae.cfg.use_ghost_grads and sae.training and not gated and not eng.transcoder:
+                # ghost gradients (sae.py:151-179) need the residual's column mean and the mse loss of the WHOLE batch before the ghost
+                # term is formed: a pass without it gives this rank's share of both (one small all-reduce), the step proper follows
+                dead = n_since_fired > sae.cfg.dead_feature_window
+                eng.dense_step(x, l1, batch_mean=bm / n_global, n_global=n_global, update_stats=False, want_out=True, renorm_decoder=True)
+                gl = torch.cat([(eng.sae_out[:x.shape[0]] - x).sum(dim=0), eng.scalars[1:2]])
+                dist.all_reduce(gl)
+                d_in_ = eng.d_in
+                eng.dense_step(x, l1, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True,
+                               dead_mask=dead, ghost_global=(gl[:d_in_] / n_global, gl[d_in_:], n_global))
+            else:
+                run(batch_mean=bm / n_global, n_global=n_global, update_stats=False)
             d_sae = eng.d_sae
             if self._small is None or self._small.numel() != d_sae + 7:
                 self._small = torch.empty(d_sae + 7, dtype=torch.float32, device=x.device)
@@ -545,7 +554,18 @@ class VisionSAETrainer:
             return
         bm = x.float().sum(dim=0)
         dist.all_reduce(bm)                                     # global batch mean (sae.py:145)
-        eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
+        if sae.cfg.use_ghost_grads and sae.training:
+            # top-k + ghost gradients (sae.py:151-179): the ghost term normalises by the residual's column mean and rescales by the mse
+            # loss of the WHOLE batch -- one more small all-reduce between the step and pv_sae_topk_ghost; the decoder renormalised in
+            # place (the ghost term reads W_dec as it lies), complete gradient buffers as every multi-rank step has them
+            dead = n_since_fired > sae.cfg.dead_feature_window
+            eng.renorm_decoder()
+            eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=False, want_out=True)
+            gl = torch.cat([(eng.sae_out[:x.shape[0]] - x).sum(dim=0), eng.scalars[1:2]])
+            dist.all_reduce(gl)
+            eng.topk_ghost(x, dead, ghost_global=(gl[:d_in] / n_global, gl[d_in:], n_global))
+        else:
+            eng.step(x, batch_mean=bm / n_global, n_global=n_global, update_stats=False, renorm_decoder=True)
         shard = self._shard(eng.d_sae)
         if self._small is None or self._small.numel() != d_in + d_sae + 3:
             self._small = torch.empty(d_in + d_sae + 3, dtype=torch.float32, device=x.device)
