@@ -46,7 +46,7 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
 
 def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
                 n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None,
-                target: Optional[Array] = None) -> Dict[str, Array]:
+                target: Optional[Array] = None, ghost_global: Optional[Tuple[Array, float]] = None) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
     :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
     (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
@@ -55,6 +55,9 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     batch and the global token count; default = this batch (single process, the reference).
     dead_mask [d_sae] bool (use_ghost_grads, training): adds _compute_ghost_residual_loss (sae/sae.py:151-179) -- also when
     no feature is dead (ghost_out is then zero and the term is a constant: the reference adds it all the same).
+    ghost_global = (mean over the GLOBAL batch of the residual x - sae_out [d_in], the global batch's mse loss): the data-parallel form
+    of the ghost term, whose two batch-wide quantities (:156, :172) are then the whole batch's, not this shard's; its mean runs over
+    n_global tokens.
     target [N, d_in] (Transcoder.forward, sae/transcoder.py:66-116): the activation to reconstruct; P then holds the decoder's
     own bias ``b_dec_out`` (decode, :54-64; ``b_dec`` only centres the encoder input, :35-37) and optionally ``W_skip``
     [d_in, d_in] (``sae_out += x @ W_skip.mT`` on the RAW input, before LN-out, :73-76); loss and normaliser against it
@@ -97,7 +100,7 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     gh = None
     if dead_mask is not None:                                          # sae/sae.py:151-179
         res = x - sae_out
-        rc = res - res.mean(axis=0, keepdims=True)
+        rc = res - (res.mean(axis=0, keepdims=True) if ghost_global is None else np.asarray(ghost_global[0], x.dtype).reshape(1, -1))
         l2 = np.sqrt((res ** 2).sum(axis=-1))
         E = np.exp(hidden_pre[:, dead_mask])
         G0 = E @ P["W_dec"][dead_mask]
@@ -105,9 +108,9 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         G = G0 * s[:, None]
         den = np.sqrt((rc ** 2).sum(axis=-1, keepdims=True))                   # (detached)
         mg = (G - res) ** 2 / den
-        r = dt(mse) / (mg + dt(1e-6))                                          # (detached)
-        ghost = (r * mg).mean(dtype=np.float64)
-        gh = dict(E=E, s=s, G=G, res=res, den=den, r=r, mask=dead_mask, loss=dt(ghost))
+        r = dt(mse if ghost_global is None else ghost_global[1]) / (mg + dt(1e-6))      # (detached)
+        ghost = (r * mg).sum(dtype=np.float64) / (ng * x.shape[1])
+        gh = dict(E=E, s=s, G=G, res=res, den=den, r=r, mask=dead_mask, loss=dt(ghost), ng=ng)
         loss = loss + dt(ghost)
     return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
                 mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0,
@@ -135,7 +138,7 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     d_hidden = np.where(feats > 0 if gate is None else gate, d_feats, dt(0))     # topk scatter + ReLU gates
     gh = fw.get("ghost")
     if gh is not None and gh["mask"].any():                           # gradient of the ghost residual loss: through ghost_out only
-        dG0 = gh["r"] * dt(2) * (gh["G"] - gh["res"]) / gh["den"] / dt(N * d) * gh["s"][:, None]
+        dG0 = gh["r"] * dt(2) * (gh["G"] - gh["res"]) / gh["den"] / dt(gh.get("ng", N) * d) * gh["s"][:, None]
         g["W_dec"][gh["mask"]] += gh["E"].T @ dG0
         d_hidden[:, gh["mask"]] += (dG0 @ P["W_dec"][gh["mask"]].T) * gh["E"]
     g["W_enc"] = fw["sae_in"].T @ d_hidden

@@ -34,6 +34,8 @@ class OracleEngine:
         self.adam_step = 0
         self.filtered_encoder = False
         self.lazy_w_enc = False
+        self.sae_out = torch.zeros(max_tokens, self.d_in)
+        self._last = None                                         # (batch_mean, n_global) of the last top-k step, for topk_ghost
 
     def materialize_w_enc(self):                                  # (NativeSAE.lazy_w_enc: this twin keeps W_enc current)
         pass
@@ -60,20 +62,41 @@ class OracleEngine:
         fire = (fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)
         self.fire_count.copy_(torch.from_numpy(fire))
         self.scalars[0], self.scalars[1], self.scalars[2] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"])
+        self.sae_out[:x.shape[0]].copy_(torch.from_numpy(fw["sae_out"]))
+        self._last = (bm, n_global)
         if update_stats:
             self.act_freq_scores += self.fire_count
             self.n_fwd_since_fired += 1
             self.n_fwd_since_fired[self.fire_count > 0] = 0
 
+    @staticmethod
+    def _ghost_global(gg):
+        """NativeSAE's ghost_global = (mean of sae_out - x over the global batch, its mse loss, n_global) -> the oracle's form"""
+        return None if gg is None else (-gg[0].numpy().astype(np.float32), float(gg[1].reshape(-1)[0]))
+
+    def topk_ghost(self, x, dead_mask, ghost_global=None):
+        """The twin of NativeSAE.topk_ghost (pv_sae_topk_ghost): the step's gradients with the ghost term's added."""
+        P, xn = self._P(), x.numpy()
+        bm, ng = self._last
+        fw = O.sae_forward(P, xn, self.k, batch_mean=bm, n_global=ng, dead_mask=dead_mask.numpy().astype(bool),
+                           ghost_global=self._ghost_global(ghost_global))
+        g = O.sae_backward(P, xn, fw, n_global=ng)
+        self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
+        for n in ("W_dec", "b_enc", "b_dec"):
+            self._g[n].copy_(torch.from_numpy(g[n]))
+        self.scalars[0], self.scalars[5] = float(fw["loss"]), float(fw["ghost_loss"])
+
     def dense_step(self, x, l1_coefficient, batch_mean=None, n_global=None, update_stats=True, want_out=False, renorm_decoder=True,
-                   dead_mask=None, target=None):
-        """The twin of NativeSAE.dense_step (pv_sae_dense_step): the ReLU + L1 form of the oracle."""
-        assert dead_mask is None and target is None
+                   dead_mask=None, target=None, ghost_global=None):
+        """The twin of NativeSAE.dense_step (pv_sae_dense_step): the ReLU + L1 form of the oracle (+ ghost gradients)."""
+        assert target is None
         if renorm_decoder:
             self.renorm_decoder()
         P, xn = self._P(), x.numpy()
         bm = None if batch_mean is None else batch_mean.numpy().astype(np.float32)
-        fw = O.sae_forward(P, xn, None, batch_mean=bm, n_global=n_global, l1_coefficient=l1_coefficient)
+        fw = O.sae_forward(P, xn, None, batch_mean=bm, n_global=n_global, l1_coefficient=l1_coefficient,
+                           dead_mask=None if dead_mask is None else dead_mask.numpy().astype(bool),
+                           ghost_global=self._ghost_global(ghost_global))
         g = O.sae_backward(P, xn, fw, n_global=n_global, l1_coefficient=l1_coefficient)
         self._g["W_encT"].copy_(torch.from_numpy(g["W_enc"].T.copy()))
         for n in ("W_dec", "b_enc", "b_dec"):
@@ -81,6 +104,8 @@ class OracleEngine:
         self.fire_count.copy_(torch.from_numpy((fw["feature_acts"] > 0).sum(axis=0).astype(np.float32)))
         self.scalars[0], self.scalars[1], self.scalars[2] = float(fw["loss"]), float(fw["mse_loss"]), float(fw["l0"])
         self.scalars[4] = float(fw["l1_loss"])
+        self.scalars[5] = 0.0 if fw["ghost_loss"] is None else float(fw["ghost_loss"])
+        self.sae_out[:x.shape[0]].copy_(torch.from_numpy(fw["sae_out"]))
         if update_stats:
             self.act_freq_scores += self.fire_count
             self.n_fwd_since_fired += 1

@@ -350,3 +350,83 @@ def test_topk_transcoder_data_parallel_step_equals_single_process_oracle():
             assert np.array_equal(out[n], got[0][1][n]), (rank, n)          # replicas stay identical
         assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
         assert frac == N * STEPS
+
+
+# ---- ghost gradients with a process group (use_ghost_grads; sae.py:151-179): the ghost term's two batch-wide quantities -- the residual's
+# column mean (:156) and the mse loss (:172) -- are exchanged between the step and the ghost term (top-k) / after a pass without it
+# (dense ReLU step): VisionSAETrainer._native_dp_step / _native_dense_step at world 2 against the single-process oracle
+def _ghost_worker(rank, world, port, q, relu):
+    import torch.distributed as dist
+    from vit_prisma_amd.sae import StandardSparseAutoencoder, VisionModelSAERunnerConfig, VisionSAETrainer
+    from _cpu_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=1, layer_subtype="hook_resid_post", d_in=D_IN, expansion_factor=D_SAE // D_IN,
+        activation_fn_str="relu" if relu else "topk", activation_fn_kwargs={} if relu else {"k": K}, l1_coefficient=L1C,
+        normalize_activations="layer_norm", b_dec_init_method="mean", train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cpu",
+        log_to_wandb=False, lr_scheduler_name="constant", n_checkpoints=0, seed=7 + rank, use_ghost_grads=True, dead_feature_window=1)
+    sae = StandardSparseAutoencoder(cfg)
+    if rank == 0:
+        with torch.no_grad():
+            for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
+                getattr(sae, n).copy_(torch.from_numpy(v))
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_feature_parallel(False)
+    tr._native_kind = lambda *a, **k: "relu" if relu else "topk"
+
+    def get_engine(s, n_tokens):
+        if tr._engine is None:
+            for p in s.parameters():
+                dist.broadcast(p.data, src=0)
+            tr._engine = OracleEngine(s, K, n_tokens)
+        return tr._engine
+
+    tr._get_engine = get_engine
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    since[::3] = 5.0                                              # a third of the features count as dead (window 1)
+    losses = []
+    for t in range(STEPS):
+        x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
+        xs = x[rank * (N // world):(rank + 1) * (N // world)][:, None, :].contiguous()
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=sae, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
+        losses.append((float(loss), float(mse), float(l0)))
+        assert tr.last_step_native
+    tr.sync_parameters()
+    out = {n: getattr(sae, n).detach().numpy().copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_ghost_gradients_data_parallel_equal_single_process_oracle(relu):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ghost_worker, args=(r, world, port, q, relu)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = {k: v.copy() for k, v in synth_sae_state(D_IN, D_SAE, 0).items()}
+    opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(D_SAE, np.float32), "act_freq_scores": np.zeros(D_SAE, np.float32)}
+    stats["n_fwd_since_fired"][::3] = 5.0
+    want = [O.train_step(P, opt, stats, synth_sae_batch(N, D_IN, seed=t), None if relu else K, lr=1e-3, step=t + 1,
+                         l1_coefficient=L1C if relu else 0.0, dead_feature_window=1) for t in range(STEPS)]
+    assert all(w["ghost_loss"] is not None and w["ghost_loss"] > 0 for w in want)
+    for rank, out, losses, act, since in got:
+        for t, (loss, mse, l0) in enumerate(losses):
+            assert abs(loss - want[t]["loss"]) <= 1e-5 * want[t]["loss"] and abs(mse - want[t]["mse_loss"]) <= 1e-5 * want[t]["mse_loss"], (t, loss, want[t])
+            assert abs(l0 - want[t]["l0"]) <= 1e-6 * want[t]["l0"]
+        for n in P:
+            assert rel_fro(out[n], P[n]) < 1e-4, (rank, n, rel_fro(out[n], P[n]))
+            assert np.array_equal(out[n], got[0][1][n]), (rank, n)          # replicas stay identical
+        assert np.array_equal(act, stats["act_freq_scores"]) and np.array_equal(since, stats["n_fwd_since_fired"])
