@@ -286,7 +286,7 @@ int pv_debug_get_tuning(const char* key, int32_t* value);
 /* ------------------------------------------------------------------------------------------ */
 
 typedef struct pv_sae_desc {
-    int32_t d_in, d_sae, k;          /* sae/config.py: d_in (<= 1280, % 4), d_sae = d_in*expansion_factor (<= 65536), topk k (<= 64) */
+    int32_t d_in, d_sae, k;          /* sae/config.py: d_in (<= 1280, % 4), d_sae = d_in*expansion_factor (<= 65536), topk k (<= 256; the fp16-filtered encoder up to 64, the exact fp32 encoder beyond) */
     int32_t normalize_layer_norm;    /* normalize_activations == "layer_norm", sae.py:78-93         */
     int32_t max_tokens;              /* largest N a step will be called with                        */
     float ln_eps;                    /* 1e-5, sae.py:80                                             */

@@ -1566,7 +1566,8 @@ extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_pla
     PV_REQUIRE(desc && out_plan, "null argument");
     PV_REQUIRE(desc->d_in > 1 && desc->d_in <= 64 * 20 && desc->d_in % 4 == 0, "d_in must be a multiple of 4, <= 1280 (ViT-H/14)");
     PV_REQUIRE(desc->d_sae >= desc->k && desc->d_sae % 4 == 0 && desc->d_sae <= 256 * 256, "d_sae must be a multiple of 4, <= 65536");
-    PV_REQUIRE(desc->k >= 1 && desc->k <= MAXK, "k must be in [1, 64]");
+    // (k <= 64: the filtered encoder; beyond it, up to 256, the exact fp32 encoder + the streaming top-k serve the plan -- pv_sae_fast_ok)
+    PV_REQUIRE(desc->k >= 1 && desc->k <= 256, "k must be in [1, 256]");
     PV_REQUIRE(desc->max_tokens >= 1, "max_tokens");
     pv_sae_plan* p = new pv_sae_plan();
     p->d = *desc;

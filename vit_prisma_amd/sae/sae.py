@@ -370,7 +370,7 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         if self.dtype != torch.float32 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.parameters()):
             return "parameters are not contiguous fp32 CUDA tensors"
         k = cfg.activation_fn_kwargs.get("k", 0)
-        if not (cfg.d_in % 4 == 0 and cfg.d_in <= 1280 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536 and 1 <= k <= 64):
+        if not (cfg.d_in % 4 == 0 and cfg.d_in <= 1280 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536 and 1 <= k <= 256):
             return "shape outside the native plan's limits"
         if self.is_caching or any(hp.fwd_hooks or hp.bwd_hooks for hp in (self.hook_sae_in, self.hook_hidden_pre, self.hook_hidden_post, self.hook_sae_out)):
             return "hooks on the SAE's own hook points"

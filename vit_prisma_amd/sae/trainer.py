@@ -134,7 +134,7 @@ class VisionSAETrainer:
             # hard error.
             d_sae, k = int(sae.cfg.d_sae), int((sae.cfg.activation_fn_kwargs or {}).get("k", 1))
             shard = d_sae // self.world
-            return d_sae % self.world == 0 and self.world <= 8 and shard >= k and shard % 4 == 0
+            return d_sae % self.world == 0 and self.world <= 8 and shard >= k and shard % 4 == 0 and k <= 64      # (pv_sae_tp_merge ranks <= 8 x 64)
         return True
 
     # ---- bookkeeping ------------------------------------------------------------------------------
@@ -208,7 +208,7 @@ class VisionSAETrainer:
         # ... and the top-k form (TopK on the magnitudes and on the gate activations) its own k-sparse step (pv_sae_gated_topk_step)
         is_gated = (isinstance(sae, GatedSparseAutoencoder) and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0
                     and (cfg.activation_fn_str == "relu"
-                         or (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64)))
+                         or (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256)))
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
                   and cfg.normalize_activations in ("layer_norm", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
@@ -218,7 +218,7 @@ class VisionSAETrainer:
             return None
         if is_gated:
             return "gated"
-        if (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64
+        if (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256
                 # ghost gradients on top-k (pv_sae_topk_ghost): plain SAE, d_in a multiple of 8
                 and (not cfg.use_ghost_grads or (not is_tc and cfg.d_in % 8 == 0))):
             return "topk"
@@ -239,8 +239,8 @@ class VisionSAETrainer:
             why.append(f"d_in = {cfg.d_in} (supported: multiples of 4 up to 1280 = ViT-H/14)")
         if cfg.d_sae > 65536 or cfg.d_sae % 4:
             why.append(f"d_sae = {cfg.d_sae} (supported: multiples of 4 up to 65536)")
-        if cfg.activation_fn_str == "topk" and not 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 64:
-            why.append(f"k = {cfg.activation_fn_kwargs.get('k')} (supported: 1..64)")
+        if cfg.activation_fn_str == "topk" and not 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256:
+            why.append(f"k = {cfg.activation_fn_kwargs.get('k')} (supported: 1..256)")
         if cfg.activation_fn_str not in ("topk", "relu"):
             why.append(f"activation {cfg.activation_fn_str!r}")
         if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
