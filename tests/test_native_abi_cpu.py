@@ -45,5 +45,10 @@ def test_plan_queries_and_error_reporting_without_gpu():
     assert lib.pv_sae_plan_create(C.byref(sdesc), C.byref(splan)) == 0
     assert lib.pv_sae_workspace_bytes(splan) > 4096 * 24576 * 4
     lib.pv_sae_plan_destroy(splan)
-    sdesc.k = 100
+    sdesc.k = 100                                  # (beyond the filtered encoder's 64: the exact encoder serves the plan)
+    assert lib.pv_sae_plan_create(C.byref(sdesc), C.byref(splan)) == 0 and lib.pv_sae_encoder_is_filtered(splan) == 0
+    lib.pv_sae_plan_destroy(splan)
+    sdesc.k = 300
+    assert lib.pv_sae_plan_create(C.byref(sdesc), C.byref(splan)) == 1
+    sdesc.k, sdesc.d_in = 32, 1284
     assert lib.pv_sae_plan_create(C.byref(sdesc), C.byref(splan)) == 1
