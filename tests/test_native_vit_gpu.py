@@ -788,6 +788,41 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_per_workgroup_form(epi
         assert close(outs[1][1][rows], torch.nn.functional.gelu(outs[1][0][rows].float()))     # out1 = act(round_T(acc + bias)), PV_ACT_GELU
 
 
+def test_repeated_calls_reuse_the_host_side_plan_and_stay_exact():
+    """The host side of a repeated call is cached (tap layout per (names, batch, segment), the ctypes tap array per slab, the parameter
+    slots of the weight-change check): calls with different name filters, batch sizes and stop layers interleaved, entries of an
+    earlier call still held (so the arena hands out another slab), and an in-place weight edit in between must give exactly what a
+    fresh model gives; keys and order as always."""
+    model, arch, _ = build("clip-vit-b32", torch.bfloat16)
+    fresh, _, _ = build("clip-vit-b32", torch.bfloat16)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xa = torch.randn(5, 3, 224, 224, device="cuda", generator=g).bfloat16()
+    xb = torch.randn(9, 3, 224, 224, device="cuda", generator=g).bfloat16()
+    calls = [(xa, {}), (xb, {}), (xa, {"names_filter": lambda n: n.endswith("hook_resid_post")}), (xa, {}),
+             (xb, {"names_filter": ["blocks.3.attn.hook_pattern", "blocks.0.hook_resid_pre"], "stop_at_layer": 5}), (xa, {}), (xb, {})]
+    held = []
+    with torch.no_grad():
+        for rnd in range(2):
+            for x, kw in calls:
+                out, cache = model.run_with_cache(x, **kw)
+                assert model.last_run_native
+                nv = fresh._native
+                if nv is not None:                                  # a fresh engine state for the comparison: no caches
+                    nv._layouts.clear(); nv._tap_arrays.clear(); nv._param_slots = None
+                want_out, want = fresh.run_with_cache(x, **kw)
+                assert list(cache.keys()) == list(want.keys())
+                assert torch.equal(out, want_out)
+                for k in want.keys():
+                    assert torch.equal(cache[k], want[k]), k
+                held.append(cache)                                  # (keeps the slab busy: the next call gets another one)
+                if len(held) > 3:
+                    held.pop(0)
+            # an in-place edit of a weight must reach the next call of BOTH models' engines (version counter of the parameter)
+            for m in (model, fresh):
+                m.blocks[2].mlp.b_out.mul_(1.5)
+    assert len(model._native._layouts) >= 4 and len(model._native._tap_arrays) >= 4
+
+
 def test_plain_forward_is_native_and_the_autograd_fallback_warns_once():
     model, arch, sd = build("tiny", torch.float32)
     model.use_native(None)                                             # auto mode
