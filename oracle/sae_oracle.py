@@ -90,7 +90,8 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     bm = y.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
     nf = np.sqrt(((y - bm) ** 2).sum(axis=-1, keepdims=True))          # :145-147
     ng = N if n_global is None else n_global
-    mse = ((sae_out - y) ** 2 / nf).sum() / dt(ng * d)                 # :146-148 (mean over N*d)
+    mse = ((sae_out - y) ** 2 / nf).sum() / dt(ng * y.shape[1])        # :146-148 (mean over N x the width of what is reconstructed:
+    #                                                                     d_in, or a transcoder's d_out -- transcoder.py:12, 78)
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()            # train_sae.py:364
     l1 = None
     loss = mse
@@ -127,7 +128,7 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     N, d = x.shape
     ng = N if n_global is None else n_global
     tc = fw.get("target") is not None
-    d_out = dt(2.0) * (fw["sae_out"] - (fw["target"] if tc else x)) / fw["norm_factor"] / dt(ng * d)
+    d_out = dt(2.0) * (fw["sae_out"] - (fw["target"] if tc else x)) / fw["norm_factor"] / dt(ng * (fw["target"].shape[1] if tc else d))
     d_pre = d_out * fw["std"] if layer_norm else d_out
     feats = fw["feature_acts"]
     g = {}

@@ -36,6 +36,8 @@ VARIANTS = {
     "gated": dict(architecture="gated", activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3,
                   use_ghost_grads=False),
     "gated_topk": dict(architecture="gated", activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=False),
+    "transcoder_dout": dict(is_transcoder=True, transcoder_with_skip_connection=False, d_out=40, out_hook_point_layer=6,
+                            activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=False),
     "transcoder": dict(is_transcoder=True, transcoder_with_skip_connection=True, d_out=64, out_hook_point_layer=6,
                        activation_fn_str="topk", activation_fn_kwargs={"k": 8}, use_ghost_grads=False),
 }
@@ -66,6 +68,17 @@ def init_params(model, seed):
     return out
 
 
+class _PairActs:
+    """layer_acts[:, 0, :] -> x, layer_acts[:, 1, :] -> y for tensors of different widths (what train_step indexes)."""
+
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+        self.shape = x.shape
+
+    def __getitem__(self, idx):
+        return (self.x, self.y)[idx[1]]
+
+
 def run(variant, over):
     Cfg, SAE, Trainer = ref_trainer_classes()
     from vit_prisma.sae.sae import GatedSparseAutoencoder
@@ -90,7 +103,12 @@ def run(variant, over):
     blob[f"{variant}_since0"] = since.clone().numpy()
     for t in range(3):
         x = torch.from_numpy(synth_sae_batch(N, D_IN, seed=t))
-        if tr.is_transcoder:
+        if tr.is_transcoder and over.get("d_out", D_IN) != D_IN:
+            # a target of another width than the input (the first d_out columns of a batch of the usual kind): train_step only reads
+            # layer_acts[:, 0] and [:, 1] (train_sae.py:299-301), a two-entry container per token serves
+            y = torch.from_numpy(synth_sae_batch(N, D_IN, seed=100 + t)[:, :over["d_out"]].copy())
+            layer_acts = _PairActs(x, y)
+        elif tr.is_transcoder:
             y = torch.from_numpy(synth_sae_batch(N, D_IN, seed=100 + t))
             layer_acts = torch.stack([x, y], dim=1)
         else:

@@ -133,27 +133,31 @@ def test_topk_ghost_three_steps_vs_reference_fixture():
         assert rel_fro(P[n], g[f"topk_ghost_s2_param_{n}"]) < (1e-3 if n == "W_enc" else 2e-4), (n, rel_fro(P[n], g[f"topk_ghost_s2_param_{n}"]))   # (W_dec's dead rows: the same effect, 8e-5)
 
 
-def test_transcoder_three_steps_vs_reference_fixture():
-    """The Transcoder form of the oracle (target given, b_dec_out, W_skip; top-k, k = 8) against the reference's own Transcoder
-    through its own train_step (transcoder of tests/golden/sae_variants_steps.npz)."""
+@pytest.mark.parametrize("variant,d_out", [("transcoder", 64), ("transcoder_dout", 40)])
+def test_transcoder_three_steps_vs_reference_fixture(variant, d_out):
+    """The Transcoder form of the oracle (target given, b_dec_out; top-k, k = 8) against the reference's own Transcoder through its own
+    train_step: with the skip matrix at d_out = d_in (transcoder of tests/golden/sae_variants_steps.npz) and WITHOUT it at d_out = 40
+    != d_in = 64 (transcoder_dout: the reference's skip term only type-checks at equal widths, transcoder.py:10, 73-76; the loss is the
+    mean over N x d_out)."""
     g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
     d_in, d_sae, N = 64, 512, 256
-    names = [str(k) for k in g["transcoder_keys"]]
-    assert sorted(names) == ["W_dec", "W_enc", "W_skip", "b_dec", "b_dec_out", "b_enc"]
-    P = {n: g[f"transcoder_init_{n}"].copy() for n in names}
+    names = [str(k) for k in g[f"{variant}_keys"]]
+    assert sorted(names) == ["W_dec", "W_enc"] + (["W_skip"] if d_out == d_in else []) + ["b_dec", "b_dec_out", "b_enc"]
+    P = {n: g[f"{variant}_init_{n}"].copy() for n in names}
+    assert P["W_dec"].shape == (d_sae, d_out)
     opt = {"m": {k: np.zeros_like(v) for k, v in P.items()}, "v": {k: np.zeros_like(v) for k, v in P.items()}}
-    stats = {"n_fwd_since_fired": g["transcoder_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    stats = {"n_fwd_since_fired": g[f"{variant}_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
     for t in range(3):
         out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), 8, lr=1e-3, step=t + 1,
-                           target=synth_sae_batch(N, d_in, seed=100 + t))
-        loss, mse, l1, l0 = g[f"transcoder_s{t}_scalars"][:4]
+                           target=synth_sae_batch(N, d_in, seed=100 + t)[:, :d_out].copy())
+        loss, mse, l1, l0 = g[f"{variant}_s{t}_scalars"][:4]
         assert np.isnan(l1) and out["l1_loss"] is None
         assert abs(out["loss"] - loss) <= 1e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
         assert abs(out["l0"] - l0) <= 1e-6 * l0
-        assert np.array_equal(stats["act_freq_scores"], g[f"transcoder_s{t}_act_freq"])
-        assert np.array_equal(stats["n_fwd_since_fired"], g[f"transcoder_s{t}_n_since"])
+        assert np.array_equal(stats["act_freq_scores"], g[f"{variant}_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"{variant}_s{t}_n_since"])
     for n in P:
-        assert rel_fro(P[n], g[f"transcoder_s2_param_{n}"]) < 1e-5, n
+        assert rel_fro(P[n], g[f"{variant}_s2_param_{n}"]) < 1e-5, n
 
 
 @pytest.mark.parametrize("variant,k", [("gated", None), ("gated_topk", 8)])
