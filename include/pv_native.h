@@ -45,7 +45,7 @@ extern "C" {
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
  * gemm_persist / gemm_stagger tuning keys). */
-#define PV_ABI_VERSION 20
+#define PV_ABI_VERSION 21
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -304,13 +304,19 @@ typedef struct pv_sae_desc {
  *     (PV_SAE_SPARSE_GRADS works as for the plain step).
  * pv_sae_step and pv_sae_dense_step: also with tokens sharded over ranks (batch_mean = the TARGET's global mean, n_global = the global
  * token count; the caller all-reduces the flat gradient buffer); the feature-parallel entry points refuse a transcoder state.
- * d_out == d_in. */
+ * d_out != d_in: see d_in_true / d_out_true below. */
 typedef struct pv_sae_transcoder {
     float *b_dec_out, *gb_dec_out, *mb_dec_out, *vb_dec_out;   /* [d_in]                                              */
     float *W_skip, *gW_skip, *mW_skip, *vW_skip;               /* [d_in, d_in] (row o = output coordinate) or all NULL */
     const float* target;                                       /* [n_tokens, d_in] of the coming step                  */
     void* scratch;                                             /* pv_sae_transcoder_scratch_bytes (only with W_skip)   */
     size_t scratch_bytes;
+    /* d_out != d_in (skip-less transcoders between hook points of different width): the plan's d_in is max(d_in, d_out) and EVERY
+     * row of width d_in above is padded to it with zeros -- W_enc rows / b_dec / x beyond d_in_true, W_dec columns / b_dec_out beyond
+     * d_out_true (they stay exact zeros: their gradients are) -- d_in_true / d_out_true = the real widths (0 = the plan's d_in).  LN-in
+     * runs over d_in_true columns, the loss is the mean over n_tokens x d_out_true, and the step WRITES the padding columns of `target`
+     * (the token's LN mean: what the zero-padded decoder reconstructs there). */
+    int32_t d_in_true, d_out_true;
 } pv_sae_transcoder;
 
 /* Gated SAE (GatedSparseAutoencoder, sae.py:648-792, activation_fn_str = "relu"): gate path (sae_in @ W_enc + b_gate) > 0,

@@ -1198,6 +1198,132 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
 
 
+class _PairActs:
+    """layer_acts[:, 0, :] -> x, layer_acts[:, 1, :] -> target for tensors of different widths: what train_step indexes
+    (train_sae.py:299-301; the reference's own store concatenates the two buffers and therefore only serves equal widths)."""
+
+    def __init__(self, x, y):
+        self.x, self.y, self.shape = x, y, x.shape
+
+    def __getitem__(self, idx):
+        return (self.x, self.y)[idx[1]]
+
+
+@pytest.mark.parametrize("d_in,d_out,d_sae,k,n,ln", [(64, 40, 512, 8, 256, True), (768, 1024, 8192, 32, 1024, True),
+                                                      (1024, 768, 8192, 32, 1024, True), (136, 72, 1056, None, 300, False),
+                                                      (768, 1024, 8192, None, 512, True), (1024, 768, 24576, 32, 2048, True)])
+def test_transcoder_of_unequal_widths_vs_oracle(d_in, d_out, d_sae, k, n, ln):
+    """A skip-less Transcoder between hook points of DIFFERENT width (transcoder.py:12: W_dec [d_sae, d_out]; the loss is the mean over
+    N x d_out) on the top-k step (k) and on the ReLU + L1 step (k = None): every row padded to D = max(d_in, d_out)
+    (pv_sae_transcoder.d_in_true / d_out_true) against the oracle on the real widths (pinned to the reference's own run at 64 -> 40 by
+    tests/test_oracle_sae_vs_golden.py) -- losses, l0, every gradient and parameter on the real entries, and the padding exactly zero
+    before and after the optimizer step."""
+    l1c = 3e-3
+    D = max(d_in, d_out)
+    rs = np.random.RandomState(5)
+    sd = synth_sae_state(d_in, d_sae, 0)
+    P = {"W_enc": sd["W_enc"].copy(), "b_enc": sd["b_enc"].copy(), "b_dec": sd["b_dec"].copy(),
+         "b_dec_out": (rs.standard_normal(d_out) * 0.05).astype(np.float32)}
+    wd = rs.uniform(-1.0, 1.0, size=(d_sae, d_out)).astype(np.float32)
+    P["W_dec"] = wd / np.linalg.norm(wd, axis=1, keepdims=True)
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
+
+    def pad(a, shape, sl):
+        buf = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        buf[sl].copy_(torch.from_numpy(a))
+        return buf
+
+    real = {"W_enc": (slice(0, d_in),), "b_dec": (slice(0, d_in),), "W_dec": (slice(None), slice(0, d_out)), "b_dec_out": (slice(0, d_out),),
+            "b_enc": (slice(None),)}
+    T = {"W_enc": pad(P["W_enc"], (D, d_sae), real["W_enc"]), "b_dec": pad(P["b_dec"], (D,), real["b_dec"]),
+         "W_dec": pad(P["W_dec"], (d_sae, D), real["W_dec"]), "b_dec_out": pad(P["b_dec_out"], (D,), real["b_dec_out"]),
+         "b_enc": torch.from_numpy(P["b_enc"].copy()).cuda()}
+    eng = NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k or 1, ln, n, b_dec_out=T["b_dec_out"], tc_widths=(d_in, d_out))
+
+    def padding_is_zero(get):
+        for name, sl in real.items():
+            full = get(name)
+            mask = torch.ones_like(full, dtype=torch.bool)
+            mask[sl] = False
+            assert float(full[mask].abs().sum()) == 0.0 if mask.any() else True, name
+
+    for t in range(2):
+        x = synth_sae_batch(n, d_in, seed=10 + t)
+        y = synth_sae_batch(n, max(d_out, d_in), seed=50 + t)[:, :d_out].copy() if d_out <= d_in else \
+            np.concatenate([synth_sae_batch(n, d_in, seed=50 + t), synth_sae_batch(n, d_in, seed=70 + t)], axis=1)[:, :d_out].copy()
+        Pc = {kk: v.copy() for kk, v in P.items()}
+        O.renorm_decoder(Pc)
+        fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
+        if k is not None:
+            top = -np.partition(-fw["hidden_pre"], k, axis=1)[:, :k + 1]
+            risky = (top[:, :k].min(axis=1) - top[:, k]) < 1e-5 * np.abs(fw["hidden_pre"]).max()
+            if risky.any():
+                safe = np.flatnonzero(~risky)[0]
+                x[risky], y[risky] = x[safe], y[safe]
+                fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
+        gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
+        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        if k is None:
+            eng.dense_step(xg, l1c, want_out=True, target=yg)
+        else:
+            eng.step(xg, want_out=True, renorm_decoder=True, target=yg)
+        eng.grad_sqnorm()
+        torch.cuda.synchronize()
+        sc = eng.scalars.cpu().numpy()
+        assert abs(sc[0] - ref["loss"]) <= TOL * ref["loss"] and abs(sc[1] - ref["mse_loss"]) <= TOL * ref["mse_loss"], (sc, ref)
+        assert abs(sc[2] - ref["l0"]) <= TOL * ref["l0"]
+        assert rel_fro(eng.sae_out[:n, :d_out].cpu().numpy(), fw["sae_out"]) < TOL
+        grads = {"W_enc": eng.grad_W_enc(), **{m: eng.g[m] for m in ("W_dec", "b_enc", "b_dec", "b_dec_out")}}
+        gtol = TOL if k is not None else 5e-4          # (ReLU gates within fp32 summation noise of zero: see the dense tests)
+        for name, sl in real.items():
+            assert rel_fro(grads[name][sl].cpu().numpy(), gr[name]) < gtol, name
+        padding_is_zero(lambda name: grads[name])
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= gtol * grad_norm_of(gr)
+        eng.apply(1e-3, 1.0)
+        torch.cuda.synchronize()
+        for name, sl in real.items():
+            assert rel_fro(eng.params[name][sl].cpu().numpy(), P[name]) < gtol, name
+        padding_is_zero(lambda name: eng.params[name])
+
+
+def test_transcoder_of_unequal_widths_through_the_trainer_matches_the_reference_fixture():
+    """is_transcoder with d_out = 40 != d_in = 64 (top-k, k = 8, no skip connection) through VisionSAETrainer.train_step on the fused
+    HIP step -- the module's parameters become views of the engine's padded storage -- against what the REFERENCE's own Transcoder
+    produced through its own train_step (transcoder_dout of tests/golden/sae_variants_steps.npz)."""
+    from vit_prisma_amd.sae import Transcoder
+    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
+    d_in, d_out, exp, N = 64, 40, 8, 256
+    cfg = VisionModelSAERunnerConfig(
+        hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=exp, activation_fn_str="topk",
+        activation_fn_kwargs={"k": 8}, normalize_activations="layer_norm", initialization_method="independent", b_dec_init_method="mean",
+        train_batch_size=N, lr=1e-3, max_grad_norm=1.0, _device="cuda", _dtype="float32", log_to_wandb=False, use_ghost_grads=False,
+        feature_sampling_window=1000, dead_feature_window=5000, lr_scheduler_name="constant", n_checkpoints=0, verbose=False,
+        is_transcoder=True, transcoder_with_skip_connection=False, d_out=d_out, out_hook_point_layer=6)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None).use_native(True)
+    model = tr.sparse_coder
+    assert type(model) is Transcoder and tuple(model.W_dec.shape) == (d_in * exp, d_out)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"transcoder_dout_init_{n}"]).cuda())
+    act, since, frac, opt, sched = tr.initialize_training_variables()
+    for t in range(3):
+        pair = _PairActs(torch.from_numpy(synth_sae_batch(N, d_in, seed=t)).cuda(),
+                         torch.from_numpy(synth_sae_batch(N, d_in, seed=100 + t)[:, :d_out].copy()).cuda())
+        loss, mse, l1, l0, act, since, frac = tr.train_step(
+            sparse_autoencoder=model, optimizer=opt, scheduler=sched, act_freq_scores=act, n_forward_passes_since_fired=since,
+            n_frac_active_tokens=frac, layer_acts=pair, n_training_steps=t, n_training_tokens=t * N)
+        assert tr.last_step_native and l1 is None
+        want = g[f"transcoder_dout_s{t}_scalars"]
+        for got, w in ((loss, want[0]), (mse, want[1]), (l0, want[3])):
+            assert abs(float(got) - w) <= TOL * abs(w), (t, float(got), w)
+        assert np.array_equal(act.cpu().numpy(), g[f"transcoder_dout_s{t}_act_freq"])
+    for n, p in model.named_parameters():
+        assert tuple(p.shape) == g[f"transcoder_dout_s2_param_{n}"].shape
+        assert rel_fro(p.detach().cpu().numpy(), g[f"transcoder_dout_s2_param_{n}"]) < TOL, n
+
+
 def test_transcoder_trainer_runs_natively_and_matches_the_reference_fixture():
     """is_transcoder (top-k, k = 8, with the skip connection) through VisionSAETrainer.train_step on the fused HIP step, against
     what the REFERENCE's own Transcoder produced through its own train_step (tests/golden/sae_variants_steps.npz)."""

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -61,7 +61,8 @@ class SaeDesc(C.Structure):
 class SaeTranscoder(C.Structure):
     """pv_sae_transcoder: all NULL = a plain autoencoder."""
     _fields_ = [(n, C.c_void_p) for n in ("b_dec_out", "gb_dec_out", "mb_dec_out", "vb_dec_out", "W_skip", "gW_skip", "mW_skip",
-                                           "vW_skip", "target", "scratch")] + [("scratch_bytes", C.c_size_t)]
+                                           "vW_skip", "target", "scratch")] + [("scratch_bytes", C.c_size_t),
+                                                                                  ("d_in_true", C.c_int32), ("d_out_true", C.c_int32)]
 
 
 class SaeGated(C.Structure):

@@ -86,31 +86,34 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
                                                        const float* __restrict__ batch_mean, float* __restrict__ sae_in,
                                                        _Float16* __restrict__ x16, float* __restrict__ xnorm_out,
                                                        float* __restrict__ mu_out, float* __restrict__ std_out,
-                                                       float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps) {
+                                                       float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps,
+                                                       int d_true) {
+    // d_true < d (a transcoder whose input is narrower than its output, pv_sae_transcoder.d_in_true: rows are padded to the common
+    // width d): the statistics run over the d_true real columns, the padding of sae_in / x16 is written as exact zeros
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     const float* xr = x + (int64_t)n * d;
     float s = 0.f, cn = 0.f;
-    for (int i = lane; i < d; i += 64) {
+    for (int i = lane; i < d_true; i += 64) {
         const float v = xr[i];
         s += v;
         const float c = v - batch_mean[i];
         cn += c * c;
     }
-    const float mu = use_ln ? wave_sum(s) / (float)d : 0.f;
+    const float mu = use_ln ? wave_sum(s) / (float)d_true : 0.f;
     cn = wave_sum(cn);
     float sq = 0.f;
-    for (int i = lane; i < d; i += 64) {
+    for (int i = lane; i < d_true; i += 64) {
         const float c = xr[i] - mu;
         sq += c * c;
     }
     // torch.std: unbiased (divide by d - 1)
-    const float sd = use_ln ? sqrtf(wave_sum(sq) / (float)(d - 1)) : 1.f;
+    const float sd = use_ln ? sqrtf(wave_sum(sq) / (float)(d_true - 1)) : 1.f;
     float s2 = 0.f, amax = 0.f;
     for (int i = lane; i < d; i += 64) {
         const float xh = use_ln ? (xr[i] - mu) / (sd + eps) : xr[i];
-        const float si = xh - b_dec[i];
+        const float si = i < d_true ? xh - b_dec[i] : 0.f;
         sae_in[(int64_t)n * d + i] = si;
         if (x16) x16[(int64_t)n * d + i] = (_Float16)si;       // operand of the filter GEMM (sae_enc.hip)
         s2 += si * si;
@@ -1643,18 +1646,24 @@ extern "C" int pv_sae_sync_shadows(pv_sae_plan* plan, pv_sae_state* st, int32_t 
 
 // ---- transcoder (pv_sae_state.tc; sae/transcoder.py:6-116) ----------------------------------------------------------------
 // loss normaliser of the target: ||y_n - mean_n(y)||_2 (sae.py:145-147 as called by transcoder.py:78).  One wave per token.
-__global__ __launch_bounds__(256) void sae_target_norm_kernel(const float* __restrict__ y, const float* __restrict__ batch_mean,
-                                                              float* __restrict__ norm_out, int n_tok, int d) {
+// d_true < d (a transcoder whose output is narrower than its input, pv_sae_transcoder.d_out_true: rows padded to the common width d):
+// the norm runs over the real columns, and the padding of the target row is set to the token's LN mean -- exactly what the decoder
+// (zero padded columns of W_dec / b_dec_out) reconstructs there after LN-out, so that the padding's error, loss and gradient are exact
+// zeros
+__global__ __launch_bounds__(256) void sae_target_norm_kernel(float* __restrict__ y, const float* __restrict__ batch_mean,
+                                                              float* __restrict__ norm_out, int n_tok, int d, int d_true,
+                                                              const float* __restrict__ mu) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     float cn = 0.f;
-    for (int i = lane; i < d; i += 64) {
+    for (int i = lane; i < d_true; i += 64) {
         const float c = y[(int64_t)n * d + i] - batch_mean[i];
         cn += c * c;
     }
     cn = wave_sum(cn);
     if (lane == 0) norm_out[n] = sqrtf(cn);
+    for (int i = d_true + lane; i < d; i += 64) y[(int64_t)n * d + i] = mu[n];
 }
 
 int sae_tc_require(const pv_sae_desc& d, const pv_sae_state* st, int N) {
@@ -1662,6 +1671,11 @@ int sae_tc_require(const pv_sae_desc& d, const pv_sae_state* st, int N) {
     PV_REQUIRE(t.b_dec_out && t.gb_dec_out && t.target, "transcoder state: b_dec_out, gb_dec_out and target are required");
     const bool any_skip = t.W_skip || t.gW_skip;
     PV_REQUIRE(!any_skip || (t.W_skip && t.gW_skip), "transcoder state: W_skip and gW_skip come together");
+    PV_REQUIRE(t.d_in_true >= 0 && t.d_in_true <= d.d_in && t.d_out_true >= 0 && t.d_out_true <= d.d_in &&
+                   (t.d_in_true == 0 || t.d_in_true == d.d_in || t.d_out_true == 0 || t.d_out_true == d.d_in),
+               "transcoder widths: d_in_true / d_out_true are 0 (= the plan's d_in) or the real widths of rows padded to max(d_in, d_out)");
+    PV_REQUIRE(!t.W_skip || ((t.d_in_true == 0 || t.d_in_true == d.d_in) && (t.d_out_true == 0 || t.d_out_true == d.d_in)),
+               "the skip connection needs d_out == d_in (transcoder.py:10, 73-76)");
     if (t.W_skip) {
         PV_REQUIRE(d.d_in % 8 == 0, "the skip connection's GEMMs need d_in to be a multiple of 8");
         PV_REQUIRE(t.scratch && ((uintptr_t)t.scratch & 255) == 0 &&
@@ -1689,8 +1703,8 @@ int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float
         hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
-    hipLaunchKernelGGL(sae_target_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, y, (const float*)bmean,
-                       (float*)(wsb + ws.norm), N, d.d_in);
+    hipLaunchKernelGGL(sae_target_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, const_cast<float*>(y), (const float*)bmean,
+                       (float*)(wsb + ws.norm), N, d.d_in, sae_loss_width(d, st), (const float*)(wsb + ws.mu));
     PV_LAUNCH_CHECK("sae_target_norm_kernel");
     return PV_OK;
 }
@@ -1699,7 +1713,7 @@ int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float
 // batch mean (given, or computed from x) -> ws.batch_mean; LN-in, sae_in, loss normaliser (+ the fp16 copy / row norms the
 // filtered encoder wants) -> ws.sae_in, ws.mu, ws.sd, ws.norm (ws.x16, ws.xnorm)
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true) {
     float* bmean = (float*)(wsb + ws.batch_mean);
     if (batch_mean) {
         PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
@@ -1712,7 +1726,7 @@ int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const flo
     hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, (const float*)bmean,
                        (float*)(wsb + ws.sae_in), want_filter_inputs ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
                        want_filter_inputs ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
-                       (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps);
+                       (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps, d_true > 0 ? d_true : d.d_in);
     PV_LAUNCH_CHECK("sae_prep_kernel");
     return PV_OK;
 }
@@ -1773,7 +1787,7 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
     if (!skip_prep) {
-        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream);
+        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st));
         if (rcp) return rcp;
     }
     // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
@@ -1947,7 +1961,7 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
     float* sae_in = (float*)(wsb + ws.sae_in);
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
-        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));      // (a transcoder: the mean is over N x d_out)
         const dim3 grid((N + 3) / 4), block(256);
 #define CALL(D)                                                                                                      \
     hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
@@ -1959,7 +1973,7 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         PV_LAUNCH_CHECK("sae_decode_kernel");
         const bool cs_here = bias_grads && !tc;
         rc = sae_csr_backward(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
-                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)d.d_in), cs_here, gate, stream);
+                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), cs_here, gate, stream);
         if (rc) return rc;
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)

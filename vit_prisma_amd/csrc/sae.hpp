@@ -105,7 +105,7 @@ int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t s
 
 // sae.hip, shared with sae_dense.hip: see the definitions
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true = 0);
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
               hipStream_t stream, bool have_colsum = false);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream,
@@ -113,6 +113,14 @@ void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, in
 int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);
 // transcoder (pv_sae_state.tc, sae/transcoder.py): helpers shared by the top-k step (sae.hip) and the dense step (sae_dense.hip)
 static inline bool sae_is_tc(const pv_sae_state* st) { return st->tc.b_dec_out != nullptr; }
+// a transcoder between hook points of different width (pv_sae_transcoder.d_in_true / d_out_true): every row is padded to the plan's
+// d_in = max(d_in, d_out); what the loss is a mean over, and what LN-in's statistics run over
+static inline int sae_loss_width(const pv_sae_desc& d, const pv_sae_state* st) {
+    return (st && sae_is_tc(st) && st->tc.d_out_true > 0) ? st->tc.d_out_true : d.d_in;
+}
+static inline int sae_in_width(const pv_sae_desc& d, const pv_sae_state* st) {
+    return (st && sae_is_tc(st) && st->tc.d_in_true > 0) ? st->tc.d_in_true : d.d_in;
+}
 constexpr int PV_SAE_SKIP_SPLITK = 8;        // token splits of gW_skip = dY^T x (36 output tiles at d_in = 768 otherwise)
 int sae_tc_require(const pv_sae_desc& d, const pv_sae_state* st, int N);                                  // sae.hip: field checks
 // sae.hip: the loss normaliser of the TARGET (sae.py:145-147 on y) -> ws.norm; batch_mean = mean_n(target) or NULL (computed here)

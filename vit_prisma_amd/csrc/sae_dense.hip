@@ -602,7 +602,7 @@ int dense_prepare(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, co
         int rc = pv_sae_renorm_decoder(plan, st, stream_);
         if (rc) return rc;
     }
-    int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, want_filter_inputs, wsb, ws, stream);
+    int rc = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, want_filter_inputs, wsb, ws, stream, sae_in_width(d, st));
     if (rc) return rc;
     *skip = nullptr;
     if (sae_is_tc(st)) {
@@ -665,13 +665,14 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)N * D; g.gate = gate;
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
-        const float grad_scale = 2.0f / ((float)n_global * (float)D);
+        const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));
         hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, tc ? st->tc.target : x, (const float*)kpart, S,
                            (int64_t)N * D, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, (const float*)(wsb + ws.mu),
                            (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
                            grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate);
         PV_LAUNCH_CHECK("dense_finish_kernel");
-        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)D), 1, -1, stream, gate, 1u);
+        sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), 1, -1,
+                       stream, gate, 1u);
         if (ghost) {
             // ghost forward: G0 = exp(hidden_pre[:, dead]) @ W_dec[dead]; loss and d loss / d G0 per token; then the part of
             // d loss / d hidden_pre that reaches the dead columns, dHd = (dG0 @ W_dec[dead]^T) * exp(hidden_pre[:, dead])

@@ -28,17 +28,24 @@ class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
                  layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False,
                  b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None,
-                 gated: Optional[Dict[str, torch.Tensor]] = None, gated_topk: bool = False):
+                 gated: Optional[Dict[str, torch.Tensor]] = None, gated_topk: bool = False,
+                 tc_widths: Optional[Tuple[int, int]] = None):
         """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``.
         b_dec_out [d_in] (+ W_skip [d_in, d_in]): a Transcoder (sae/transcoder.py; pv_sae_transcoder) -- ``step`` /
         ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input.
         gated = {b_gate, r_mag, b_mag} [d_sae] each: a GatedSparseAutoencoder (sae.py:648-792; pv_sae_gated) -- ``gated_step`` is
         its train step (``b_enc`` is kept but plays no part); gated_topk: its top-k form (activation_fn_str = "topk": TopK on the
         magnitudes and on the gate activations, k of each per token) -- ``gated_topk_step`` is the train step then, and the plan is
-        created for twice the tokens (its k-dependent buffers hold both lists)."""
+        created for twice the tokens (its k-dependent buffers hold both lists).
+        tc_widths = (d_in, d_out) of a skip-less Transcoder between hook points of DIFFERENT width: every tensor given here is padded
+        with zeros to D = max(d_in, d_out) (W_enc [D, d_sae], W_dec [d_sae, D], b_dec / b_dec_out [D]; pv_sae_transcoder.d_in_true /
+        d_out_true); ``step`` / ``dense_step`` / ``relu_step`` take x [N, d_in] and target [N, d_out] and pad them into engine-owned
+        buffers, the padding of the parameters stays exactly zero (its gradients are)."""
         self.transcoder = b_dec_out is not None
         self.gated = gated is not None
         self.gated_topk = bool(gated_topk) and self.gated
+        self.tc_widths = tuple(int(v) for v in tc_widths) if tc_widths is not None else None
+        assert self.tc_widths is None or (self.transcoder and W_skip is None), "tc_widths: a transcoder without the skip connection"
         assert not (self.gated and (self.transcoder or inference)), "gated: training engine, no transcoder"
         assert W_skip is None or self.transcoder, "W_skip belongs to a transcoder (pass b_dec_out)"
         assert not (self.transcoder and inference), "the inference entry points do not serve a transcoder"
@@ -201,7 +208,8 @@ class NativeSAE:
             W_skip=P["W_skip"].data_ptr() if skip else None, gW_skip=g["W_skip"].data_ptr() if skip else None,
             mW_skip=m["W_skip"].data_ptr() if skip else None, vW_skip=v["W_skip"].data_ptr() if skip else None,
             target=self._target.data_ptr() if self._target is not None else None,
-            scratch=sc.data_ptr() if sc is not None else None, scratch_bytes=sc.numel() if sc is not None else 0)
+            scratch=sc.data_ptr() if sc is not None else None, scratch_bytes=sc.numel() if sc is not None else 0,
+            d_in_true=self.tc_widths[0] if self.tc_widths else 0, d_out_true=self.tc_widths[1] if self.tc_widths else 0)
 
     def _set_target(self, x: torch.Tensor, target: Optional[torch.Tensor]) -> None:
         if not self.transcoder:
@@ -210,6 +218,16 @@ class NativeSAE:
         if target is None:
             raise ValueError("transcoder step: the target activation is required")
         t = target.to(torch.float32).contiguous()
+        if self.tc_widths is not None:
+            # rows padded to the common width (the step writes the padding columns itself: pv_sae_transcoder.d_out_true)
+            if tuple(t.shape) != (x.shape[0], self.tc_widths[1]) or t.device != self.device:
+                raise ValueError(f"target {tuple(t.shape)} on {t.device}: expected [{x.shape[0]}, {self.tc_widths[1]}] on {self.device}")
+            if getattr(self, "_y_pad", None) is None:
+                self._y_pad = torch.zeros(self.max_tokens, self.d_in, dtype=torch.float32, device=self.device)
+            buf = self._y_pad[:x.shape[0]]
+            buf[:, :self.tc_widths[1]].copy_(t)
+            self._target = buf
+            return
         if tuple(t.shape) != tuple(x.shape) or t.device != self.device:
             raise ValueError(f"target {tuple(t.shape)} on {t.device} does not match the input {tuple(x.shape)} on {self.device}")
         self._target = t
@@ -221,6 +239,14 @@ class NativeSAE:
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
+        if self.tc_widths is not None and x.ndim == 2 and x.shape[1] == self.tc_widths[0] and self.tc_widths[0] < self.d_in:
+            if x.shape[0] > self.max_tokens or x.device != self.device:
+                raise ValueError(f"expected [N<={self.max_tokens}, {self.tc_widths[0]}] on {self.device}, got {tuple(x.shape)} on {x.device}")
+            if getattr(self, "_x_pad", None) is None:
+                self._x_pad = torch.zeros(self.max_tokens, self.d_in, dtype=torch.float32, device=self.device)
+            buf = self._x_pad[:x.shape[0]]
+            buf[:, :self.tc_widths[0]].copy_(x)                     # (the padding columns stay zero)
+            return buf
         if x.ndim != 2 or x.shape[1] != self.d_in or x.shape[0] > self.max_tokens or x.device != self.device:
             raise ValueError(f"expected [N<={self.max_tokens}, {self.d_in}] on {self.device}, got {tuple(x.shape)} on {x.device}")
         return x

@@ -200,8 +200,12 @@ class VisionSAETrainer:
         # a Transcoder (sae/transcoder.py) of equal input and output width runs on the same two steps (pv_sae_transcoder):
         # no ghost gradients; with a process group the tokens are sharded and the optimizer replicated (one all-reduce of the flat
         # gradient buffer: _native_dense_step for ReLU, _native_dp_step's transcoder branch for top-k)
-        is_tc = (isinstance(sae, Transcoder) and int(getattr(cfg, "d_out", cfg.d_in)) == int(cfg.d_in)
-                 and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None)
+        # ... and one between hook points of DIFFERENT width (no skip connection: the reference's needs d_out == d_in) on the same steps with
+        # every row padded to the wider of the two (single process; pv_sae_transcoder.d_in_true / d_out_true)
+        d_out = int(getattr(cfg, "d_out", cfg.d_in))
+        is_tc = (isinstance(sae, Transcoder) and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None
+                 and (d_out == int(cfg.d_in) or (sae._parameters.get("W_skip") is None and not self._mr and d_out % 8 == 0
+                                                 and d_out <= 1280 and cfg.d_in % 8 == 0)))
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own step (pv_sae_gated_step_sparse: the open gates
         # as per-token lists where the batch allows it, the dense GEMMs of pv_sae_gated_step otherwise -- decided on the GPU)
@@ -244,7 +248,7 @@ class VisionSAETrainer:
         if cfg.activation_fn_str not in ("topk", "relu"):
             why.append(f"activation {cfg.activation_fn_str!r}")
         if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
-            why.append("a transcoder with d_out != d_in")
+            why.append("a transcoder with d_out != d_in and more than one rank / widths that are not multiples of 8 / d_out > 1280")
         if cfg.normalize_activations not in ("layer_norm", "none", None):
             why.append(f"normalize_activations = {cfg.normalize_activations!r}")
         return "; ".join(why) or "a parameter is not a contiguous fp32 CUDA tensor"
@@ -269,12 +273,29 @@ class VisionSAETrainer:
             old = eng
             if old is not None:
                 old.materialize_w_enc()                          # (the new engine derives its shadows from the parameter)
-            P_ = sae._parameters
+            P_ = dict(sae._parameters)
+            tcw = None
+            if self.is_transcoder and int(getattr(sae.cfg, "d_out", sae.cfg.d_in)) != int(sae.cfg.d_in):
+                # rows padded to D = max(d_in, d_out): the engine owns the padded storage, the module's parameters become views of it
+                # (W_enc / b_dec: leading rows; W_dec / b_dec_out: leading columns), so both sides see every update
+                d_i, d_o = int(sae.cfg.d_in), int(sae.cfg.d_out)
+                D = max(d_i, d_o)
+                with torch.no_grad():
+                    def padded(p, shape, sl):
+                        buf = torch.zeros(shape, dtype=torch.float32, device=p.device)
+                        buf[sl].copy_(p.data)
+                        p.data = buf[sl]
+                        return buf
+                    P_["W_enc"] = padded(P_["W_enc"], (D, sae.cfg.d_sae), (slice(0, d_i),))
+                    P_["b_dec"] = padded(P_["b_dec"], (D,), (slice(0, d_i),))
+                    P_["W_dec"] = padded(P_["W_dec"], (sae.cfg.d_sae, D), (slice(None), slice(0, d_o)))
+                    P_["b_dec_out"] = padded(P_["b_dec_out"], (D,), (slice(0, d_o),))
+                tcw = (d_i, d_o)
             eng = NativeSAE(P_["W_enc"], P_["W_dec"], P_["b_enc"], P_["b_dec"],
                             k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
                             layer_norm=sae.cfg.normalize_activations == "layer_norm",
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world),
-                            **{n: P_[n] for n in tc_names},
+                            **{n: P_[n] for n in tc_names}, **({"tc_widths": tcw} if tcw else {}),
                             **({"gated": {n: P_[n] for n in ("b_gate", "r_mag", "b_mag")},
                                 "gated_topk": sae.cfg.activation_fn_str == "topk"} if "b_gate" in P_ else {}))
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
