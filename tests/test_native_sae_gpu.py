@@ -1288,6 +1288,46 @@ def test_transcoder_of_unequal_widths_vs_oracle(d_in, d_out, d_sae, k, n, ln):
         padding_is_zero(lambda name: eng.params[name])
 
 
+@pytest.mark.parametrize("k", [8, None])
+def test_unequal_width_transcoder_steps_on_token_shards_sum_to_the_whole_batch(k):
+    """The token-sharded form (batch_mean = the TARGET's global mean over its d_out real columns, n_global) of the padded transcoder
+    steps: two half batches add up to the whole batch's gradients and losses (top-k step and ReLU + L1 step)."""
+    d_in, d_out, d_sae, n, l1c = 72, 136, 2048, 512, 3e-3
+    D = max(d_in, d_out)
+    rs = np.random.RandomState(3)
+    sd = synth_sae_state(d_in, d_sae, 0)
+
+    def pad(a, shape, sl):
+        buf = torch.zeros(shape, dtype=torch.float32, device="cuda")
+        buf[sl].copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        return buf
+
+    wd = rs.uniform(-1.0, 1.0, size=(d_sae, d_out)).astype(np.float32)
+    eng = NativeSAE(pad(sd["W_enc"], (D, d_sae), (slice(0, d_in),)), pad(wd / np.linalg.norm(wd, axis=1, keepdims=True), (d_sae, D), (slice(None), slice(0, d_out))),
+                    torch.from_numpy(sd["b_enc"].copy()).cuda(), pad(sd["b_dec"], (D,), (slice(0, d_in),)), k or 1, True, n,
+                    b_dec_out=pad((rs.standard_normal(d_out) * 0.05).astype(np.float32), (D,), (slice(0, d_out),)), tc_widths=(d_in, d_out))
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=0)).cuda()
+    y = torch.from_numpy(synth_sae_batch(n, d_out, seed=50)).cuda()
+
+    def run(xs, ys, **kk):
+        if k is None:
+            eng.dense_step(xs, l1c, update_stats=False, target=ys, **kk)
+        else:
+            eng.step(xs, update_stats=False, renorm_decoder=True, target=ys, **kk)
+        torch.cuda.synchronize()
+        return eng.flat_g.clone(), eng.scalars.clone(), eng.fire_count.clone()
+
+    g_all, sc_all, fire_all = run(x, y)
+    bm = y.mean(dim=0)                                            # [d_out]: padded by the engine
+    h = n // 2
+    g0, sc0, f0 = run(x[:h].contiguous(), y[:h].contiguous(), batch_mean=bm, n_global=n)
+    g1, sc1, f1 = run(x[h:].contiguous(), y[h:].contiguous(), batch_mean=bm, n_global=n)
+    assert rel_fro((g0 + g1).cpu().numpy(), g_all.cpu().numpy()) < TOL
+    for slot in (0, 1) + ((4,) if k is None else ()):
+        assert abs(float(sc0[slot] + sc1[slot]) - float(sc_all[slot])) <= TOL * abs(float(sc_all[slot])), slot
+    assert torch.equal(f0 + f1, fire_all)
+
+
 def test_transcoder_of_unequal_widths_through_the_trainer_matches_the_reference_fixture():
     """is_transcoder with d_out = 40 != d_in = 64 (top-k, k = 8, no skip connection) through VisionSAETrainer.train_step on the fused
     HIP step -- the module's parameters become views of the engine's padded storage -- against what the REFERENCE's own Transcoder

@@ -235,6 +235,18 @@ class NativeSAE:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _bm(self, batch_mean: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """The caller's global batch mean as the kernels read it: d_in floats (a transcoder of unequal widths: the TARGET's mean,
+        d_out floats, padded to the common width)."""
+        if batch_mean is None:
+            return None
+        bm = batch_mean.to(torch.float32).contiguous().view(-1)
+        if self.tc_widths is not None and bm.numel() == self.tc_widths[1] and bm.numel() < self.d_in:
+            bm = torch.nn.functional.pad(bm, (0, self.d_in - bm.numel()))
+        if bm.numel() != self.d_in:
+            raise ValueError(f"batch_mean has {bm.numel()} entries, expected {self.d_in}")
+        return bm
+
     def _check_x(self, x: torch.Tensor) -> torch.Tensor:
         if x.dtype != torch.float32:
             x = x.float()
@@ -314,7 +326,7 @@ class NativeSAE:
                        fire_count=self.fire_count.data_ptr())
         bm = None
         if batch_mean is not None:
-            bm = batch_mean.to(torch.float32).contiguous()
+            bm = self._bm(batch_mean)
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                      int(n_global if n_global is not None else n),
                                      int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0) |
@@ -340,7 +352,7 @@ class NativeSAE:
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
-        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        bm = self._bm(batch_mean)
         ghost = self._ghost_struct(dead_mask, n, ghost_global) if dead_mask is not None else None
         N.check(self.lib.pv_sae_dense_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                            int(n_global if n_global is not None else n),
@@ -378,7 +390,7 @@ class NativeSAE:
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
-        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        bm = self._bm(batch_mean)
         sp = N.SaeReluSparse(cap=cap, reserved=0, workspace=self._relu_ws.data_ptr(), workspace_bytes=self._relu_ws.numel())
         self._relu_last = (n, cap)
         inv_valid = renorm_decoder and self._inv_norm_key is not None and self._inv_norm_key == self._w_dec_key()
@@ -471,7 +483,7 @@ class NativeSAE:
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=None, topk_val=None,
                        scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
-        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        bm = self._bm(batch_mean)
         flags = int(bool(update_stats)) | 2
         ng = int(n_global if n_global is not None else n)
         if sparse:
@@ -507,7 +519,7 @@ class NativeSAE:
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr() if want_out else None, topk_idx=self.topk_idx.data_ptr(),
                        topk_val=self.topk_val.data_ptr(), scalars=self.scalars.data_ptr(), fire_count=self.fire_count.data_ptr())
-        bm = batch_mean.to(torch.float32).contiguous() if batch_mean is not None else None
+        bm = self._bm(batch_mean)
         N.check(self.lib.pv_sae_gated_topk_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                                 int(n_global if n_global is not None else n), int(bool(update_stats)) | 2, C.byref(out),
                                                 self.workspace.data_ptr(), self.workspace.numel(), self._gk_scratch.data_ptr(),

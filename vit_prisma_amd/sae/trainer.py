@@ -201,11 +201,11 @@ class VisionSAETrainer:
         # no ghost gradients; with a process group the tokens are sharded and the optimizer replicated (one all-reduce of the flat
         # gradient buffer: _native_dense_step for ReLU, _native_dp_step's transcoder branch for top-k)
         # ... and one between hook points of DIFFERENT width (no skip connection: the reference's needs d_out == d_in) on the same steps with
-        # every row padded to the wider of the two (single process; pv_sae_transcoder.d_in_true / d_out_true)
+        # every row padded to the wider of the two (pv_sae_transcoder.d_in_true / d_out_true)
         d_out = int(getattr(cfg, "d_out", cfg.d_in))
         is_tc = (isinstance(sae, Transcoder) and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None
-                 and (d_out == int(cfg.d_in) or (sae._parameters.get("W_skip") is None and not self._mr and d_out % 8 == 0
-                                                 and d_out <= 1280 and cfg.d_in % 8 == 0)))
+                 and (d_out == int(cfg.d_in) or (sae._parameters.get("W_skip") is None and d_out % 8 == 0 and d_out <= 1280
+                                                 and cfg.d_in % 8 == 0)))
         from .variants import GatedSparseAutoencoder
         # a GatedSparseAutoencoder (sae.py:648-792) with the ReLU magnitude path has its own step (pv_sae_gated_step_sparse: the open gates
         # as per-token lists where the batch allows it, the dense GEMMs of pv_sae_gated_step otherwise -- decided on the GPU)
@@ -248,7 +248,7 @@ class VisionSAETrainer:
         if cfg.activation_fn_str not in ("topk", "relu"):
             why.append(f"activation {cfg.activation_fn_str!r}")
         if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
-            why.append("a transcoder with d_out != d_in and more than one rank / widths that are not multiples of 8 / d_out > 1280")
+            why.append("a transcoder with d_out != d_in and the skip connection / widths that are not multiples of 8 / d_out > 1280")
         if cfg.normalize_activations not in ("layer_norm", "none", None):
             why.append(f"normalize_activations = {cfg.normalize_activations!r}")
         return "; ".join(why) or "a parameter is not a contiguous fp32 CUDA tensor"
