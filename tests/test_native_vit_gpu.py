@@ -1130,6 +1130,15 @@ def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
             assert cache_h[k].shape == cache_t[k].shape and rel_fro(cache_h[k].cpu().numpy(), cache_t[k].cpu().numpy()) < FP32_TOL, k
 
 
+@pytest.mark.parametrize("tag", ["all", "attn_in", "result_mlp", "split"])
+def test_hooks_on_flag_gated_points_vs_reference_fixture(tag):
+    """Forward hooks that EDIT attn.hook_result / hook_mlp_in / hook_attn_in / hook_q_input / hook_v_input (+ an ordinary point beside
+    them) against the REFERENCE's own hooked runs (tests/golden/vit_tiny_flag_hooks.npz): the hooked block runs on its own module,
+    the others on the HIP plan (vit.py:_run_blocks_mixed) -- output, key order and every cache tensor."""
+    from test_flag_hooks_vs_reference_cpu import check_case
+    check_case(tag, "cuda", FP32_TOL, expect_native=True)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_flag_gated_hook_points_at_b32_size_vs_reference_fixture(dtype):
     """The four flags at CLIP ViT-B/32 size (286 cache entries per forward, bs = 2): fp32 against the reference's own run,
