@@ -1010,21 +1010,36 @@ def test_hooked_sae_vit_splices_run_on_the_plan_vs_reference_fixture():
     check("only_b")
     model.reset_saes()
     assert torch.equal(check("reset"), out0)
-    # a splice on block 0's entry: that block on its own module, the rest on the plan -- the same numbers as the PyTorch path
+    # a splice on block 0's entry: that block on its own module, the rest on the plan -- against the REFERENCE's own run of that splice
+    # (tests/golden/sae_vit_tiny_edges.npz), and the same numbers as the PyTorch path
+    E = np.load(os.path.join(GOLDEN, "sae_vit_tiny_edges.npz"))
     e = make_sae(0, "hook_resid_pre", "relu", {}, 5)
     model.add_sae(e)
-    with torch.no_grad():
-        out_n, c_n = model.run_with_cache(x)
-        assert model.last_run_native
-        model.use_native(False)
-        out_t, c_t = model.run_with_cache(x)
-        model.use_native(True)
-    assert list(c_n.keys()) == list(c_t.keys()) and rel_fro(out_n.cpu().numpy(), out_t.cpu().numpy()) < FP32_TOL
-    for k in c_t.keys():
-        assert rel_fro(c_n[k].cpu().numpy(), c_t[k].cpu().numpy()) < FP32_TOL, k
+
+    def check_edge(tag):
+        with torch.no_grad():
+            out_n, c_n = model.run_with_cache(x)
+            assert model.last_run_native
+            model.use_native(False)
+            out_t, c_t = model.run_with_cache(x)
+            model.use_native(True)
+        assert list(c_n.keys()) == list(c_t.keys()) == [str(k) for k in E[f"{tag}::__keys__"]]
+        assert rel_fro(out_n.cpu().numpy(), E[f"{tag}::__out__"]) < FP32_TOL and rel_fro(out_t.cpu().numpy(), E[f"{tag}::__out__"]) < FP32_TOL
+        for k in c_t.keys():
+            assert rel_fro(c_n[k].cpu().numpy(), E[f"{tag}::{k}"]) < FP32_TOL, k
+
+    check_edge("entry0")
     model.reset_saes()
-    # on the embedding stage: that stage on the model's own modules, the blocks on the plan
+    # cfg.hook_point = ... does NOT move an SAE: the reference's setter stores a value its getter never reads (sae/config.py:428-436);
+    # the fixture's "embed" case is the reference after that assignment -- the same splice as before
     e.cfg.hook_point = "hook_embed"
+    assert e.cfg.hook_point == "blocks.0.hook_resid_pre"
+    model.add_sae(e)
+    check_edge("embed")
+    model.reset_saes()
+    # on the embedding stage (reachable with a config CLASS whose hook point is something else: not through the reference's config):
+    # that stage on the model's own modules, the blocks on the plan
+    e.cfg.__class__ = type("EmbedStageCfg", (type(e.cfg),), {"hook_point": "hook_embed"})
     model.add_sae(e)
     with torch.no_grad():
         out_n, c_n = model.run_with_cache(x)

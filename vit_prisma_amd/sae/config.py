@@ -120,8 +120,9 @@ class VisionModelSAERunnerConfig:
 
     @property
     def hook_point(self) -> str:
-        custom = getattr(self, "_custom_hook_point", None)
-        return custom if custom else f"blocks.{self.hook_point_layer}.{self.layer_subtype}"
+        # (as the reference: the setter below stores a value the getter never reads -- config.py:428-436 -- so assigning cfg.hook_point
+        # does NOT move an SAE; pinned by tests/golden/sae_vit_tiny_edges.npz, where the reference was asked for "hook_embed")
+        return f"blocks.{self.hook_point_layer}.{self.layer_subtype}"
 
     @hook_point.setter
     def hook_point(self, value) -> None:
