@@ -183,3 +183,39 @@ def test_offline_loader_configs_carry_the_reference_registry_overrides():
             assert getattr(cfg, k) == v, (name, k, getattr(cfg, k), v)
     a, b = load_config("openai/clip-vit-base-patch32", device="cpu"), load_config("open-clip:laion/CLIP-ViT-B-32-DataComp.XL-s13B-b90K", device="cpu")
     assert (a.eps, a.normalize_output) == (1e-6, False) and (b.eps, b.normalize_output) == (1e-5, True)
+
+
+def test_sae_runner_config_contract_vs_reference_fixture():
+    """VisionModelSAERunnerConfig against the reference's own class (tests/golden/sae_config_contract.json, generated by instantiating the
+    reference's config: gen_golden_sae_config_contract.py): for six keyword sets every dataclass field after __post_init__, every
+    property (device, dtype, hook_point, out_hook_point, tokens_per_buffer, total_training_*) and what assigning through the setters
+    leaves behind -- e.g. ``cfg.hook_point = ...`` changes nothing (sae/config.py:428-436).  The one deliberate superset: _dtype =
+    "bfloat16" resolves here and raises KeyError in the reference (its dtype table has no bf16 entry)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_sae_config_contract import contract
+    from vit_prisma_amd.sae import VisionModelSAERunnerConfig
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sae_config_contract.json")) as f:
+        G = json.load(f)
+    mine = contract(VisionModelSAERunnerConfig)
+    assert sorted(mine) == sorted(G)
+    for tag in G:
+        for sect in ("fields", "props", "after_setters"):
+            assert sorted(mine[tag][sect]) == sorted(G[tag][sect]), (tag, sect)
+            for k, want in G[tag][sect].items():
+                if tag == "gated_bf16" and k == "dtype" and sect == "props":
+                    assert want == "raises KeyError" and mine[tag][sect][k] == "torch.bfloat16"
+                    continue
+                assert mine[tag][sect][k] == want, (tag, sect, k, mine[tag][sect][k], want)
+
+
+def test_hooked_vit_config_contract_vs_reference_fixture():
+    """HookedViTConfig against the reference's own class (tests/golden/vit_config_contract.json: every one of its 89 dataclass fields after
+    __post_init__ for the defaults, the two target architectures and the tiny test architecture; gen_golden_vit_config_contract.py)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_vit_config_contract import contract
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vit_config_contract.json")) as f:
+        G = json.load(f)
+    mine = contract(HookedViTConfig)
+    assert mine == G
