@@ -219,3 +219,34 @@ def test_hooked_vit_config_contract_vs_reference_fixture():
         G = json.load(f)
     mine = contract(HookedViTConfig)
     assert mine == G
+
+
+def test_fold_value_biases_vs_reference_fixture():
+    """HookedViT.fold_value_biases / load_and_process_state_dict (base_vit.py:498-532, base_transformer.py:35-104; the reference's loader
+    applies the folding BY DEFAULT) against the reference's own run on the tiny model (tests/golden/vit_tiny_fold_value_biases.npz): the
+    b_O / b_V it leaves, and the output / cache of the folded model -- hook_v changes, the output does not."""
+    from vit_prisma_amd.synth import ARCHS, synth_images, synth_vit_state
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vit_tiny_fold_value_biases.npz"))
+    arch = ARCHS["tiny"]
+    model = HookedViT(HookedViTConfig(**arch, dtype=torch.float32, device="cpu")).eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth_vit_state(arch, 0).items()}
+    plain = HookedViT(HookedViTConfig(**arch, dtype=torch.float32, device="cpu")).eval()
+    plain.load_state_dict(sd, strict=True)
+    model.load_and_process_state_dict(dict(sd), fold_ln=False, center_writing_weights=False, fold_value_biases=True)
+    for k in G.files:
+        if k.startswith("param::"):
+            got = model.state_dict()[k.split("::", 1)[1]].numpy()
+            assert np.allclose(got, G[k], rtol=1e-6, atol=1e-7), k
+    assert float(model.blocks[0].attn.b_V.abs().max()) == 0.0
+    x = torch.from_numpy(synth_images(arch, 2, 1))
+    with torch.no_grad():
+        out, cache = model.run_with_cache(x)
+        out_plain, cache_plain = plain.run_with_cache(x)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))      # noqa: E731
+    assert rel(out.numpy(), G["out"]) < 1e-5 and rel(out.numpy(), out_plain.numpy()) < 1e-5
+    for k in G.files:
+        if k.startswith("cache::"):
+            assert rel(cache[k.split("::", 1)[1]].numpy(), G[k]) < 1e-5, k
+    assert rel(cache["blocks.0.attn.hook_v"].numpy(), cache_plain["blocks.0.attn.hook_v"].numpy()) > 1e-3      # (the folding is visible in the cache)
+    with pytest.raises(NotImplementedError):
+        model.load_and_process_state_dict(dict(sd))                  # (the reference's own defaults: fold_ln = True)

@@ -7,7 +7,8 @@ per-name overrides of the reference registry (``NAME_OVERRIDES``) -- what ``load
 (``local_path=...``: a ``.safetensors`` / ``.pt`` / ``.bin`` file, converted by ``weights.py`` exactly as the reference's converters do) --
 or none (``pretrained=False``: the reference's initialisation).  Everything else about the signature is the reference's; the options
 that rewrite weights (``fold_ln``, ``center_writing_weights``, ``refactor_factored_attn_matrices``) are not implemented and raise
-when set (``fold_value_biases`` only matters together with ``fold_ln``).
+when set; ``fold_value_biases`` (on by default, as in the reference: b_O absorbs the value biases, model_loader.py:286, 352-358 ->
+base_vit.py:498-532) IS applied to loaded weights -- ``attn.hook_v`` / ``hook_z`` of a loaded model are those of the folded weights.
 """
 from __future__ import annotations
 
@@ -76,7 +77,7 @@ def load_hooked_model(model_name: str, model_class: Optional[Type] = None, model
         if local_path is None:
             raise FileNotFoundError(f"pretrained=True needs local_path=<checkpoint file> for {model_name!r}: this build cannot download "
                                     "weights (no network); pass pretrained=False for the reference's random initialisation")
-        load_clip_vision_weights(model, local_path)
+        load_clip_vision_weights(model, local_path, fold_value_biases=bool(fold_value_biases))
     model = model.to(dtype)
     if move_to_device:
         model = model.to(device)

@@ -1095,6 +1095,33 @@ class HookedViT(HookedRootModule):
             ordered[n] = t[0] if remove_batch_dim else t
         return out, ordered
 
+    # ------------------------------------------------------------------------------ state-dict processing of the loader
+    def fold_value_biases(self, state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """b_O <- b_O + sum_head b_V[head] @ W_O[head], b_V <- 0 (models/base_vit.py:498-532): attention rows sum to one, so the value
+        biases only ever add a constant to the layer's output.  The reference's ``load_hooked_model`` applies it BY DEFAULT
+        (model_loader.py:286, 352-358): ``attn.hook_v`` / ``hook_z`` of a model loaded that way are those of the folded weights."""
+        for layer in range(self.cfg.n_layers):
+            b_V = state_dict[f"blocks.{layer}.attn.b_V"]                       # [n_heads, d_head]
+            W_O = state_dict[f"blocks.{layer}.attn.W_O"]                       # [n_heads, d_head, d_model]
+            state_dict[f"blocks.{layer}.attn.b_O"] = state_dict[f"blocks.{layer}.attn.b_O"] + (b_V[:, :, None] * W_O).sum([0, 1])
+            state_dict[f"blocks.{layer}.attn.b_V"] = torch.zeros_like(b_V)
+        return state_dict
+
+    def load_and_process_state_dict(self, state_dict: Dict[str, torch.Tensor], fold_ln: Optional[bool] = True,
+                                    center_writing_weights: Optional[bool] = True, fold_value_biases: Optional[bool] = True,
+                                    refactor_factored_attn_matrices: Optional[bool] = False):
+        """models/base_transformer.py:35-104 (signature and defaults the reference's): missing keys are filled from the model, the
+        requested processing is applied, the result loaded non-strictly.  Of the four steps only ``fold_value_biases`` -- the one the
+        reference's loader switches on by default -- is built here; asking for another raises."""
+        if fold_ln or center_writing_weights or refactor_factored_attn_matrices:
+            raise NotImplementedError("fold_ln / center_writing_weights / refactor_factored_attn_matrices are not implemented in this build "
+                                      "(pass them as False: load_hooked_model's defaults)")
+        own = self.state_dict()
+        state_dict = {**{k: v for k, v in own.items() if k not in state_dict}, **state_dict}      # fill_missing_keys
+        if fold_value_biases:
+            state_dict = self.fold_value_biases(dict(state_dict))
+        self.load_state_dict(state_dict, strict=False)
+
     # ------------------------------------------------------------------------------ flag setters
     def set_use_attn_result(self, use_attn_result: bool):
         self.cfg.use_attn_result = use_attn_result

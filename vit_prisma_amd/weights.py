@@ -98,9 +98,10 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return {k[len("module."):] if k.startswith("module.") else k: v for k, v in blob.items()}
 
 
-def load_clip_vision_weights(model, path: str, source: Optional[str] = None):
+def load_clip_vision_weights(model, path: str, source: Optional[str] = None, fold_value_biases: bool = False):
     """Load a local open_clip or HuggingFace CLIP checkpoint into a ``HookedViT`` built for the matching architecture
-    (``source``: "open_clip" | "hf"; default: detected from the key names).  Returns the model."""
+    (``source``: "open_clip" | "hf"; default: detected from the key names).  fold_value_biases: as the reference's loader does by
+    default (``HookedViT.fold_value_biases``).  Returns the model."""
     sd = read_checkpoint(path)
     if source is None:
         source = "open_clip" if "visual.conv1.weight" in sd else ("hf" if "vision_model.embeddings.class_embedding" in sd else None)
@@ -111,5 +112,8 @@ def load_clip_vision_weights(model, path: str, source: Optional[str] = None):
     else:
         raise ValueError("unrecognised checkpoint layout (expected open_clip 'visual.*' or HuggingFace 'vision_model.*' keys)")
     dtype = next(model.parameters()).dtype
-    model.load_state_dict({k: v.to(dtype) for k, v in new.items()}, strict=True)
+    new = {k: v.to(dtype) for k, v in new.items()}
+    if fold_value_biases:
+        new = model.fold_value_biases(new)
+    model.load_state_dict(new, strict=True)
     return model
