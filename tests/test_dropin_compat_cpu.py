@@ -250,3 +250,25 @@ def test_fold_value_biases_vs_reference_fixture():
     assert rel(cache["blocks.0.attn.hook_v"].numpy(), cache_plain["blocks.0.attn.hook_v"].numpy()) > 1e-3      # (the folding is visible in the cache)
     with pytest.raises(NotImplementedError):
         model.load_and_process_state_dict(dict(sd))                  # (the reference's own defaults: fold_ln = True)
+
+
+def test_construction_helpers_of_the_reference_surface(tmp_path):
+    """HookedViT.from_local (a reference-trainer checkpoint: {"model_state_dict": ...}, base_vit.py:652-668), from_pretrained (the legacy
+    entry point forwarding to load_hooked_model, base_transformer.py:320-364 -- offline: a local checkpoint or pretrained=False),
+    move_model_modules_to_device."""
+    from vit_prisma_amd.synth import ARCHS, synth_vit_state
+    arch = ARCHS["tiny"]
+    cfg = HookedViTConfig(**arch, dtype=torch.float32, device="cpu")
+    src = HookedViT(cfg).eval()
+    src.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vit_state(arch, 0).items()}, strict=True)
+    path = os.path.join(tmp_path, "ckpt.pt")
+    torch.save({"model_state_dict": src.state_dict(), "epoch": 3}, path)
+    model = HookedViT.from_local(cfg, path)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), src.state_dict().values()))
+    with pytest.raises(Exception, match="no file was found"):
+        HookedViT.from_local(cfg, os.path.join(tmp_path, "missing.pt"))
+    assert model.move_model_modules_to_device() is model
+    rnd = HookedViT.from_pretrained("openai/clip-vit-base-patch32", fold_ln=False, center_writing_weights=False, device="cpu", pretrained=False)
+    assert type(rnd) is HookedViT and rnd.cfg.n_layers == 12 and rnd.cfg.eps == 1e-6
+    with pytest.raises(NotImplementedError):
+        HookedViT.from_pretrained("openai/clip-vit-base-patch32", device="cpu", pretrained=False)      # (the legacy defaults fold LayerNorm)

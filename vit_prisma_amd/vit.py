@@ -1095,6 +1095,44 @@ class HookedViT(HookedRootModule):
             ordered[n] = t[0] if remove_batch_dim else t
         return out, ordered
 
+    # ------------------------------------------------------------------------------ construction helpers of the reference
+    @classmethod
+    def from_local(cls, model_config, checkpoint_path: str):
+        """models/base_vit.py:652-668: a model from one of the reference trainer's own checkpoints ({"model_state_dict": ...})."""
+        import os
+        model = cls(model_config)
+        if not os.path.exists(checkpoint_path):
+            raise Exception(f"Attempting to load a Prisma ViT but no file was found at {checkpoint_path}")
+        checkpoint = torch.load(checkpoint_path, map_location=torch.device(model_config.device), weights_only=False)
+        model.load_state_dict(checkpoint["model_state_dict"])
+        return model
+
+    @classmethod
+    def from_pretrained(cls, model_name: str, is_timm: bool = True, is_clip: bool = False, fold_ln: Optional[bool] = True,
+                        center_writing_weights: Optional[bool] = True, refactor_factored_attn_matrices: Optional[bool] = False,
+                        checkpoint_index: Optional[int] = None, checkpoint_value: Optional[int] = None, hf_model=None,
+                        device=None, n_devices: Optional[int] = 1, move_to_device: Optional[bool] = True,
+                        fold_value_biases: Optional[bool] = True, default_prepend_bos: Optional[bool] = True,
+                        default_padding_side="right", dtype="float32", use_attn_result: Optional[bool] = False, model_type=None,
+                        **from_pretrained_kwargs):
+        """models/base_transformer.py:320-364 (the legacy entry point: it forwards to ``load_hooked_model``, as here).  This build has
+        no network: pass ``local_path=<checkpoint>`` (or ``pretrained=False``); the weight-rewriting options other than
+        ``fold_value_biases`` are not built and must be switched off (the reference's legacy defaults have them on)."""
+        from .model_loader import load_hooked_model
+        return load_hooked_model(model_name, model_class=cls, model_type=model_type, device=device or "cuda", dtype=dtype,
+                                 fold_ln=bool(fold_ln), center_writing_weights=bool(center_writing_weights),
+                                 fold_value_biases=bool(fold_value_biases),
+                                 refactor_factored_attn_matrices=bool(refactor_factored_attn_matrices),
+                                 move_to_device=bool(move_to_device), use_attn_result=bool(use_attn_result), **from_pretrained_kwargs)
+
+    def mps(self):
+        return self.to("mps")
+
+    def move_model_modules_to_device(self):
+        """models/base_vit.py:637-650 with n_devices = 1 (the only placement the forward supports): everything on
+        cfg.device."""
+        return self.to(self.cfg.device)
+
     # ------------------------------------------------------------------------------ state-dict processing of the loader
     def fold_value_biases(self, state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """b_O <- b_O + sum_head b_V[head] @ W_O[head], b_V <- 0 (models/base_vit.py:498-532): attention rows sum to one, so the value
