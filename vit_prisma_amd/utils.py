@@ -14,16 +14,17 @@ import torch
 SliceInput = Optional[Union[int, Tuple[int, ...], List[int], torch.Tensor, np.ndarray]]
 
 
-def to_numpy(x) -> np.ndarray:
-    if isinstance(x, np.ndarray):
-        return x
-    if isinstance(x, (list, tuple)):
-        return np.array(x)
-    if isinstance(x, (torch.Tensor, torch.nn.Parameter)):
-        return x.detach().cpu().numpy()
-    if isinstance(x, (int, float, bool, str)):
-        return np.array(x)
-    raise ValueError(f"Input to to_numpy has invalid type: {type(x)}")
+def to_numpy(tensor) -> np.ndarray:
+    """utils/prisma_utils.py:304-318 (parameter name the reference's: callers pass ``tensor=``)."""
+    if isinstance(tensor, np.ndarray):
+        return tensor
+    if isinstance(tensor, (list, tuple)):
+        return np.array(tensor)
+    if isinstance(tensor, (torch.Tensor, torch.nn.Parameter)):
+        return tensor.detach().cpu().numpy()
+    if isinstance(tensor, (int, float, bool, str)):
+        return np.array(tensor)
+    raise ValueError(f"Input to to_numpy has invalid type: {type(tensor)}")
 
 
 class Slice:
