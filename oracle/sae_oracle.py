@@ -46,7 +46,8 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
 
 def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
                 n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None,
-                target: Optional[Array] = None, ghost_global: Optional[Tuple[Array, float]] = None) -> Dict[str, Array]:
+                target: Optional[Array] = None, ghost_global: Optional[Tuple[Array, float]] = None,
+                idx: Optional[Array] = None) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
     :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
     (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
@@ -61,7 +62,9 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     target [N, d_in] (Transcoder.forward, sae/transcoder.py:66-116): the activation to reconstruct; P then holds the decoder's
     own bias ``b_dec_out`` (decode, :54-64; ``b_dec`` only centres the encoder input, :35-37) and optionally ``W_skip``
     [d_in, d_in] (``sae_out += x @ W_skip.mT`` on the RAW input, before LN-out, :73-76); loss and normaliser against it
-    (:78; batch_mean is then the target's)."""
+    (:78; batch_mean is then the target's).
+    idx [N, k] (tests only: the fp32-vs-float64 noise floors): the selection to keep instead of hidden_pre's own top-k -- the same
+    computation carried in another precision must not move to another set where two pre-activations tie within its noise."""
     dt = x.dtype.type
     N, d = x.shape
     if layer_norm:
@@ -74,7 +77,10 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         feats = np.maximum(hidden_pre, dt(0))                          # :576 with torch.nn.ReLU
         idx = vals = None
     else:
-        idx, vals = topk_mask(hidden_pre, k)                           # :576
+        if idx is None:
+            idx, vals = topk_mask(hidden_pre, k)                       # :576
+        else:
+            vals = np.maximum(np.take_along_axis(hidden_pre, idx, axis=-1), dt(0))
         feats = np.zeros_like(hidden_pre)
         np.put_along_axis(feats, idx, vals, axis=-1)
     if target is None:
@@ -203,17 +209,19 @@ def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, 
 
 def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: Optional[int], lr: float,
                step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
-               dead_feature_window: Optional[int] = None, target: Optional[Array] = None) -> Dict[str, float]:
+               dead_feature_window: Optional[int] = None, target: Optional[Array] = None, gate: Optional[Array] = None) -> Dict[str, float]:
     """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
-    firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count)."""
+    firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count).
+    gate (tests of the ReLU steps, see sae_backward): the step as it continues when the ReLU gates [N, d_sae] of the entries within
+    fp32 summation noise of zero fall as given -- the backward and the firing statistics under these gates."""
     renorm_decoder(P)                                                   # :306-307
     dead = None if dead_feature_window is None else stats["n_fwd_since_fired"] > dead_feature_window      # :330-332 (use_ghost_grads)
     fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead, target=target)
-    fired = (fw["feature_acts"] > 0).sum(axis=0)                        # :356-361
+    fired = ((fw["feature_acts"] > 0) if gate is None else gate).sum(axis=0)      # :356-361
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0
     stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
-    g = sae_backward(P, x, fw, layer_norm, l1_coefficient=l1_coefficient)
+    g = sae_backward(P, x, fw, layer_norm, l1_coefficient=l1_coefficient, gate=gate)
     total = clip_and_project(P, g, max_grad_norm)
     adam_step(P, g, opt["m"], opt["v"], lr, step)
     return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), grad_norm=total,

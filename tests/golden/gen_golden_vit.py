@@ -12,6 +12,10 @@ Writes (all small enough to commit):
     vit_b32_bf16_budget.json     per-key rel-Frobenius error of the reference's OWN bf16 path
                                  (cfg.dtype=bf16, .to(bf16)) against its fp32 path, bs=4: the error
                                  budget the bf16 HIP mode is held to (hard part 1)
+    vit_b32_outliers_bf16_budget.json   (round 6, ``outliers``) the same two things on synth_vit_state(outliers=True) -- a residual
+                                 stream with massive-activation channels (|x| ~ 100 beside an rms of ~1.2: where bf16 is actually
+                                 stressed): fingerprints of the reference's fp32 run (bs=4, all 214 keys), its bf16-vs-fp32 budget
+                                 on those 4 images and on images SUB512 of the bs=512 batch
 """
 from __future__ import annotations
 
@@ -219,3 +223,37 @@ if __name__ == "__main__":
         dump_bf16_budget_sub512()
     if "l14bf16" in what2:
         dump_l14_bf16_budget()
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: the massive-activation state (VERDICT r5 "next" item 4a)
+# ---------------------------------------------------------------------------------------------
+def dump_outliers():
+    """The reference in fp32 and in its own bf16 on synth_vit_state(clip-vit-b32, 0, outliers=True): (1) bs=4, seed 1: fingerprints of
+    all 214 fp32 cache tensors + the per-key bf16 budget; (2) images SUB512 of synth_images(b32, 512, seed=1): the budget at the
+    bench batch.  SURVEY.md section 7 hard part 1: the bf16 bar must hold where the residual stream carries outlier channels."""
+    arch = ARCHS["clip-vit-b32"]
+    m32, _ = build_reference_model("clip-vit-b32", dtype=torch.float32, outliers=True)
+    m16, _ = build_reference_model("clip-vit-b32", dtype=torch.bfloat16, outliers=True)
+    imgs = synth_images(arch, 4, seed=1)
+    o32, c32 = run_ref(m32, imgs)
+    o16, c16 = run_ref(m16, imgs)
+    res = {"arch": "clip-vit-b32", "outliers": True, "batch": 4, "seed": 1, "fp32": fp_cache(o32, c32.cache_dict)}
+    res["budget"] = _budget(c32.cache_dict, c16.cache_dict)
+    res["budget"]["__out__"] = _budget({"o": o32}, {"o": o16})["o"]
+    big = synth_images(arch, 512, seed=1)[SUB512]
+    p32, d32 = run_ref(m32, big)
+    p16, d16 = run_ref(m16, big)
+    res["sub512"] = {"images": SUB512, "batch": 512, "seed": 1, "budget": _budget(d32.cache_dict, d16.cache_dict)}
+    res["sub512"]["budget"]["__out__"] = _budget({"o": p32}, {"o": p16})["o"]
+    r = c32.cache_dict["blocks.6.hook_resid_post"]
+    res["resid6_absmax_over_rms"] = float(r.abs().max() / r.pow(2).mean().sqrt())
+    with open(os.path.join(HERE, "vit_b32_outliers_bf16_budget.json"), "w") as f:
+        json.dump(res, f)
+    rel = sorted(v["rel_fro"] for v in res["budget"].values())
+    print("outliers: bf16 budget rel_fro min/median/max", rel[0], rel[len(rel) // 2], rel[-1], "| resid6 absmax/rms", res["resid6_absmax_over_rms"])
+
+
+if __name__ == "__main__":
+    if "outliers" in sys.argv[1:]:
+        dump_outliers()

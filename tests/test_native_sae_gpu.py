@@ -22,6 +22,23 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def fw_scalars(fw):
+    """The scalars O.train_step returns, read off a forward on the renormed copy (the step itself is taken later, once the kernel's
+    ReLU gates are known: see ``gate`` of O.train_step)."""
+    opt = lambda key: None if fw.get(key) is None else float(fw[key])
+    return dict(loss=float(fw["loss"]), mse_loss=float(fw["mse_loss"]), l0=float(fw["l0"]), l1_loss=opt("l1_loss"), ghost_loss=opt("ghost_loss"))
+
+
+def truncated(reason):
+    """A comparison that cannot go on entry for entry (a near-tie fell differently in two correct fp32 computations) ends HERE, visibly:
+    the parametrization is reported as xfailed, not passed, and named in gpurun_out/truncated_tests.txt (profiles/r06_truncated_tests.txt
+    is that file from the round's GPU run).  Round 5 ended such runs with a bare ``return``."""
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "truncated_tests.txt"), "a") as f:
+        f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?')}: {reason}\n")
+    pytest.xfail(reason)
+
+
 def fresh(d_in, d_sae):
     sd = synth_sae_state(d_in, d_sae, 0)
     P = {k: v.copy() for k, v in sd.items()}
@@ -382,18 +399,28 @@ def test_multi_rank_steps_on_rccl_world1_equal_the_oracle(mode):
     stats = {"n_fwd_since_fired": np.zeros(d_sae, np.float32), "act_freq_scores": np.zeros(d_sae, np.float32)}
     if ghost:
         stats["n_fwd_since_fired"][::3] = 5.0
-    for t in range(3):
-        ref = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=10 + t), None if relu else k, lr=1e-3, step=t + 1,
-                           l1_coefficient=3e-3 if relu else 0.0, target=synth_sae_batch(N, d_in, seed=60 + t) if tc else None,
-                           dead_feature_window=1 if ghost else None)
-        assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
+    # the same three steps carried in float64 beside the fp32 ones: how far two correct computations of this run end up apart
     # (relu_dp runs from the synthetic init, where half of all pre-activations are positive: a few of the 6.3 M per step lie within fp32
-    # summation noise of zero and take the other side of the ReLU than numpy's; Adam turns those entries into lr-sized differences --
-    # measured 1.8e-4 on W_enc after three steps with every loss within 1e-4)
-    ptol = 5e-4 if relu else TOL
+    # summation noise of zero and take the other side of the ReLU; the top-k ghost term's gradient is ill-conditioned in fp32 where the
+    # ghost reconstruction meets the residual; Adam turns such entries into lr-sized differences -- measured 1.8e-4 on W_enc after three
+    # relu_dp steps with every loss within 1e-4).  The parameters are held to 6 x that distance (as ghost_tolerances) where it exceeds
+    # 1e-4; round 5 had the constants 5e-4 / 1e-3 here.
+    noisy = relu or single is not None
+    if noisy:
+        P64 = {kk: v.astype(np.float64) for kk, v in P.items()}
+        opt64 = {w: {kk: v.astype(np.float64) for kk, v in opt[w].items()} for w in ("m", "v")}
+        stats64 = {kk: v.copy() for kk, v in stats.items()}
+    for t in range(3):
+        x, y = synth_sae_batch(N, d_in, seed=10 + t), synth_sae_batch(N, d_in, seed=60 + t) if tc else None
+        kw = dict(lr=1e-3, step=t + 1, l1_coefficient=3e-3 if relu else 0.0, dead_feature_window=1 if ghost else None)
+        ref = O.train_step(P, opt, stats, x, None if relu else k, target=y, **kw)
+        if noisy:
+            O.train_step(P64, opt64, stats64, x.astype(np.float64), None if relu else k, target=None if y is None else y.astype(np.float64), **kw)
+        assert abs(out[t][0] - ref["loss"]) <= TOL * abs(ref["loss"]) and abs(out[t][1] - ref["l0"]) <= TOL * ref["l0"], (t, out[t], ref)
     for n in P:
+        ptol = max(TOL, 6.0 * rel_fro(P[n], P64[n])) if noisy else TOL
         if single is not None:                   # (topk_ghost_dp: against the single-process engine, see the worker)
-            assert rel_fro(params[n], single[n]) < 1e-3, n
+            assert rel_fro(params[n], single[n]) < ptol, n
         else:
             assert rel_fro(params[n], P[n]) < ptol, n
     want_act = single["act_freq"] if single is not None else stats["act_freq_scores"]
@@ -790,35 +817,62 @@ def test_feature_parallel_simulated_world_equals_single_process_oracle(world, d_
 # ---------------------------------------------------------------------------------------------------
 # (the last four: the shape bench.py times this step at -- 768 -> 24576, 4096 tokens -- and the x64 SAEs every published CLIP-B/32 SAE of
 # the reference is, docs/sae_table.md:12-36 -- 768 -> 49152)
-def fp32_noise_floor(Pc, x, k, ln, dead, l1c=0.0, gate=None):
+def fp32_noise_floor(Pc, x, k, ln, dead, l1c=0.0, gate=None, opt=None, lr=1e-3, step=1):
     """How far is the fp32 ORACLE itself from the same computation carried in float64?  Per gradient tensor, the rel-Frobenius distance
-    between the oracle's fp32 gradients and its float64 ones (same gates / same top-k sets).  The ghost term puts exp(hidden_pre) of the
-    dead columns into the gradients, which turns the ABSOLUTE fp32 summation noise of hidden_pre into a RELATIVE error of those
-    entries: two correct fp32 implementations differ by this much, whatever their summation orders.  The ghost tests hold the kernels
-    to a multiple of this floor per tensor (ghost_tolerances) instead of a constant argued in a comment (round-4 review).  None when float64 picks another top-k set (a tie within fp32 noise)."""
+    between the oracle's fp32 gradients and its float64 ones (same ReLU gates / the same top-k sets: the float64 run keeps the fp32
+    run's selection).  The ghost term puts exp(hidden_pre) of the dead columns into the gradients, which turns the ABSOLUTE fp32
+    summation noise of hidden_pre into a RELATIVE error of those entries: two correct fp32 implementations differ by this much,
+    whatever their summation orders.  The ghost tests hold the kernels to a multiple of this floor per tensor (ghost_tolerances)
+    instead of a constant argued in a comment (round-4 review).
+    opt given: also "param:<name>" -- the same distance between the PARAMETERS after clip + projection + Adam on the two gradient
+    sets (Adam's g / (sqrt(v) + eps) turns a noise-sized gradient entry into an lr-sized step in either direction): the bound the
+    post-step parameters are held to (round 5 used a constant 1e-3 there)."""
     P64 = {kk: v.astype(np.float64) for kk, v in Pc.items()}
     x64 = x.astype(np.float64)
     fw32 = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead)
-    fw64 = O.sae_forward(P64, x64, k, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead)
-    if k is not None and not np.array_equal(np.sort(fw32["idx"], axis=1), np.sort(fw64["idx"], axis=1)):
-        return None
+    fw64 = O.sae_forward(P64, x64, k, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead, idx=fw32["idx"])
     g = gate if gate is not None else (None if k is not None else fw32["feature_acts"] > 0)
     kw = {} if k is not None else dict(l1_coefficient=l1c, gate=g)
     gr32 = O.sae_backward(Pc, x, fw32, layer_norm=ln, **kw)
     gr64 = O.sae_backward(P64, x64, fw64, layer_norm=ln, **kw)
-    return {name: rel_fro(gr32[name], gr64[name]) for name in gr32}
+    floor = {name: rel_fro(gr32[name], gr64[name]) for name in gr32}
+    if opt is not None:
+        after = []
+        for gr in (gr32, gr64):
+            P2 = {kk: v.copy() for kk, v in Pc.items()}
+            g2 = {kk: np.asarray(v, np.float32).copy() for kk, v in gr.items()}
+            m2, v2 = ({kk: v.copy() for kk, v in opt[which].items()} for which in ("m", "v"))
+            O.clip_and_project(P2, g2, 1.0)
+            O.adam_step(P2, g2, m2, v2, lr, step)
+            after.append(P2)
+        for name in Pc:
+            floor["param:" + name] = rel_fro(after[0][name], after[1][name])
+    return floor
+
+
+def run_param_floor(P0, since0, batches, k, **kw):
+    """name -> rel-Frobenius distance between the parameters the ORACLE ends at when it carries len(batches) train steps in fp32 and in
+    float64 (from the same fp32 start): what two correct computations of this run are apart.  Parameter bounds of multi-step
+    comparisons are 6 x this (as ghost_tolerances) where that exceeds 1e-4; round 5 had the constant 1e-3 there."""
+    ends = []
+    for dt in (np.float32, np.float64):
+        P = {n: np.asarray(v, dt).copy() for n, v in P0.items()}
+        opt = {w: {n: np.zeros_like(v) for n, v in P.items()} for w in ("m", "v")}
+        stats = {"n_fwd_since_fired": np.asarray(since0, np.float32).copy(), "act_freq_scores": np.zeros(len(since0), np.float32)}
+        for t, x in enumerate(batches):
+            O.train_step(P, opt, stats, np.asarray(x, dt), k, step=t + 1, **kw)
+        ends.append(P)
+    return {n: rel_fro(ends[0][n], ends[1][n]) for n in P0}
 
 
 def ghost_tolerances(floor):
-    """name -> min(5e-4, max(TOL, 6 x floor[name])) (and "max": the largest of them); None when no floor could be taken (the caller keeps the old
-    constant).  6 x: numpy's matmul sums in blocks, the MFMA chain of the kernels sums the K = d_in (768) products of an entry in k order --
-    measured on the GPU, the kernels sit at 1.2 ... 3.5 x the oracle's own floor (3.5 x: gW_dec at 768 -> 49152).  The bound so derived is
-    2e-4 ... 5e-4 depending on the shape (5e-4 only without LayerNorm, where |hidden_pre| reaches ~50) and never looser than the constant
-    it replaces."""
-    if floor is None:
-        return None
-    tol = {name: min(5e-4, max(TOL, 6.0 * v)) for name, v in floor.items()}
-    tol["max"] = max(tol.values())
+    """name -> max(TOL, 6 x floor[name]) (and "max": the largest over the gradient tensors).  6 x: numpy's matmul sums in blocks, the
+    MFMA chain of the kernels sums the K = d_in (768) products of an entry in k order -- measured on the GPU, the kernels sit at
+    1.2 ... 3.5 x the oracle's own floor (3.5 x: gW_dec at 768 -> 49152).  The bound so derived is 2e-4 ... 5e-4 depending on the shape
+    (the loose end only without LayerNorm, where |hidden_pre| reaches ~50); no constant beside it (round 5 capped it at 5e-4 and kept
+    5e-4 / 1e-3 as fallbacks)."""
+    tol = {name: max(TOL, 6.0 * v) for name, v in floor.items()}
+    tol["max"] = max(v for name, v in tol.items() if not name.startswith("param:"))
     return tol
 
 
@@ -837,8 +891,8 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
     # ghost: exp(hidden_pre) turns the ABSOLUTE fp32 summation noise of hidden_pre into a RELATIVE error of the ghost
     # activations (d exp(h) / exp(h) = dh): without LayerNorm |hidden_pre| reaches ~50 here and the dead rows of gW_dec carry
     # ~1e-4 of it (the reference run on a GPU would differ from its CPU run by as much); after one such step the two
-    # parameter sets are ~1e-4 apart and later steps are not comparable gate for gate: one step, 5e-4 on the gradients
-    gtol = 5e-4 if ghost else TOL
+    # parameter sets are ~1e-4 apart and later steps are not comparable gate for gate: one step, every bound derived from the
+    # oracle's own fp32-vs-float64 distance on this batch (fp32_noise_floor)
     P, opt, stats, T = fresh(d_in, d_sae)
     if ghost:
         stats["n_fwd_since_fired"][::5] = 10.0
@@ -852,8 +906,7 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
         fw = O.sae_forward(Pc, x, None, layer_norm=ln, l1_coefficient=l1c, dead_mask=dead)
         gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
         before = stats["act_freq_scores"].copy()
-        ref = O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c,
-                           dead_feature_window=window if ghost else None)
+        ref = fw_scalars(fw)
         eng.dense_step(torch.from_numpy(x).cuda(), l1c, want_out=True,
                        dead_mask=(eng.n_fwd_since_fired > window) if ghost else None)
         eng.grad_sqnorm()
@@ -878,20 +931,21 @@ def test_relu_l1_dense_step_vs_oracle(d_in, d_sae, n, ln, ghost):
         if differs.any():
             gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c, gate=gate)
         # ghost: per-tensor bounds DERIVED from the oracle's own fp32-vs-float64 distance on this very batch (fp32_noise_floor)
-        gt = ghost_tolerances(fp32_noise_floor(Pc, x, None, ln, dead, l1c, gate if differs.any() else None)) if ghost else None
-        tol_of = (lambda name: gt[name]) if gt else (lambda name: gtol)
-        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= (gt["max"] if gt else gtol) * grad_norm_of(gr)
+        gt = ghost_tolerances(fp32_noise_floor(Pc, x, None, ln, dead, l1c, gate if differs.any() else None, opt=opt, step=t + 1)) if ghost else None
+        tol_of = (lambda name: gt[name]) if gt else (lambda name: TOL)
+        assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= (gt["max"] if gt else TOL) * grad_norm_of(gr)
         assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < tol_of("W_enc")
         for name in ("W_dec", "b_enc", "b_dec"):
             assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < tol_of(name), name
-        if differs.any():
-            return                   # (the oracle's own step continued under its own gates: later steps are not comparable)
+        # the oracle's step continues under the KERNEL's gates where they differ (round 5 stopped the comparison here)
+        O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c,
+                     dead_feature_window=window if ghost else None, gate=gate if differs.any() else None)
         fire_ref = stats["act_freq_scores"] - before
         assert np.abs(eng.fire_count.cpu().numpy() - fire_ref).sum() <= TOL * fire_ref.sum()
         eng.apply(1e-3, 1.0)
         torch.cuda.synchronize()
         for name in P:
-            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < gtol, name
+            assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < tol_of("param:" + name), name
         assert np.abs(eng.act_freq_scores.cpu().numpy() - stats["act_freq_scores"]).sum() <= TOL * stats["act_freq_scores"].sum()
         assert np.abs(eng.n_fwd_since_fired.cpu().numpy() - stats["n_fwd_since_fired"]).sum() <= 2
 
@@ -938,8 +992,8 @@ def test_dense_steps_see_an_outside_edit_of_w_enc(kind):
 def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
     """Ghost gradients on the top-k step (pv_sae_step + pv_sae_topk_ghost; sae.py:151-179 behind TopK :795-810) against the oracle's
     top-k + ghost form (pinned to the reference's own topk_ghost run by tests/test_oracle_sae_vs_golden.py): every fifth feature counts
-    as dead; losses (mse, ghost, total), l0, the reconstruction, every gradient tensor, the clip norm.  One step, gradients at 5e-4
-    where the dead rows are concerned: exp(hidden_pre) turns the absolute fp32 summation noise of hidden_pre into a relative error
+    as dead; losses (mse, ghost, total), l0, the reconstruction, every gradient tensor, the clip norm.  One step, gradients and post-step
+    parameters held to bounds derived from the oracle's own fp32-vs-float64 distance where the dead rows are concerned: exp(hidden_pre) turns the absolute fp32 summation noise of hidden_pre into a relative error
     of the ghost activations (see test_relu_l1_dense_step_vs_oracle)."""
     window = 3
     P, opt, stats, T = fresh(d_in, d_sae)
@@ -953,6 +1007,7 @@ def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
     fw = O.sae_forward(Pc, x, k, layer_norm=ln, dead_mask=dead)
     gr = O.sae_backward(Pc, x, fw, layer_norm=ln)
     before = stats["act_freq_scores"].copy()
+    gt = ghost_tolerances(fp32_noise_floor(Pc, x, k, ln, dead, opt=opt))      # derived per-tensor bounds, gradients and post-step parameters
     ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=1, layer_norm=ln, dead_feature_window=window)
     xg = torch.from_numpy(x).cuda()
     dead_g = eng.n_fwd_since_fired > window                          # (before the step's statistics, train_sae.py:330-332)
@@ -966,10 +1021,8 @@ def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
     assert abs(sc[5] - ref["ghost_loss"]) <= TOL * ref["ghost_loss"] and abs(sc[2] - ref["l0"]) < 1e-4, (sc, ref)
     assert np.array_equal(np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1), np.sort(fw["idx"], axis=1))
     assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
-    gtol = 5e-4
-    gt = ghost_tolerances(fp32_noise_floor(Pc, x, k, ln, dead))          # derived per-tensor bounds (None: float64 broke a top-k tie differently)
-    tol_of = (lambda name: gt[name]) if gt else (lambda name: gtol)
-    assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= (gt["max"] if gt else gtol) * grad_norm_of(gr)
+    tol_of = lambda name: gt[name]
+    assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= gt["max"] * grad_norm_of(gr)
     assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < tol_of("W_enc")
     for name in ("W_dec", "b_enc", "b_dec"):
         assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < tol_of(name), name
@@ -980,14 +1033,16 @@ def test_topk_ghost_step_vs_oracle(d_in, d_sae, k, n, ln):
     eng.apply(1e-3, 1.0)
     torch.cuda.synchronize()
     for name in P:
-        # (Adam's g / (|g| + 1e-8) on the dead features' ~1e-9 gradient entries: see the ReLU ghost test)
-        assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < 1e-3, name
+        # (Adam's g / (|g| + 1e-8) on the dead features' ~1e-9 gradient entries: the bound is the oracle's own fp32-vs-float64 distance
+        # of the post-step parameters, see fp32_noise_floor)
+        assert rel_fro(eng.params[name].cpu().numpy(), P[name]) < tol_of("param:" + name), name
 
 
 def test_topk_ghost_trainer_runs_natively_and_matches_the_reference_fixture():
     """activation_fn_str = "topk" with use_ghost_grads through VisionSAETrainer.train_step on the HIP path, against what the REFERENCE's
     own classes produced through its own train_step (topk_ghost of tests/golden/sae_variants_steps.npz): three steps, losses and the
-    ghost loss at 1e-4, statistics (a handful of entries may differ after a ghost step, as for the ReLU form), parameters at 1e-3."""
+    ghost loss at 1e-4, statistics (a handful of entries may differ after a ghost step, as for the ReLU form), parameters at 6 x the
+    oracle's own fp32-vs-float64 distance over the three steps (run_param_floor)."""
     g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
     d_in, exp, N = 64, 8, 256
     cfg = VisionModelSAERunnerConfig(
@@ -1014,8 +1069,10 @@ def test_topk_ghost_trainer_runs_natively_and_matches_the_reference_fixture():
         af = g[f"topk_ghost_s{t}_act_freq"]
         assert np.abs(act.cpu().numpy() - af).sum() <= 1e-3 * af.sum()
         assert (since.cpu().numpy() != g[f"topk_ghost_s{t}_n_since"]).sum() <= 2
+    floor = run_param_floor({n: g[f"topk_ghost_init_{n}"] for n, _ in model.named_parameters()}, g["topk_ghost_since0"],
+                            [synth_sae_batch(N, d_in, seed=t) for t in range(3)], 8, lr=1e-3, dead_feature_window=1)
     for n, p in model.named_parameters():
-        assert rel_fro(p.detach().cpu().numpy(), g[f"topk_ghost_s2_param_{n}"]) < 1e-3, n
+        assert rel_fro(p.detach().cpu().numpy(), g[f"topk_ghost_s2_param_{n}"]) < max(TOL, 6.0 * floor[n]), n
 
 
 def grad_norm_of(g):
@@ -1065,8 +1122,11 @@ def test_relu_variants_trainer_runs_natively_and_matches_the_reference_fixture(v
     # ghost: the dead features' only gradient is the ghost term -- entries of ~1e-9, where fp32 summation-order noise is an
     # ABSOLUTE error Adam's g / (|g| + 1e-8) turns into lr-sized differences on a few elements (measured 3.4e-4 on W_enc after
     # three steps; losses, the north-star quantity, stay within 1e-4 at every step above)
+    floor = run_param_floor({n: g[f"{variant}_init_{n}"] for n, _ in model.named_parameters()}, g[f"{variant}_since0"],
+                            [synth_sae_batch(N, d_in, seed=t) for t in range(3)], None, lr=1e-3, l1_coefficient=2e-3,
+                            dead_feature_window=1 if ghost else None) if ghost else None
     for n, p in model.named_parameters():
-        assert rel_fro(p.detach().cpu().numpy(), g[f"{variant}_s2_param_{n}"]) < (1e-3 if ghost else TOL), n
+        assert rel_fro(p.detach().cpu().numpy(), g[f"{variant}_s2_param_{n}"]) < (max(TOL, 6.0 * floor[n]) if ghost else TOL), n
 
 
 def test_step_is_bit_reproducible_from_run_to_run():
@@ -1138,9 +1198,19 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
         Pc = {kk: v.copy() for kk, v in P.items()}
         O.renorm_decoder(Pc)
         fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
+        if k is not None:
+            # a token whose k-th and (k+1)-th pre-activations lie within fp32 summation noise of each other may keep either one
+            # (measured: 1 token of 1024 at 768 -> 8192 in step 2, tools/tc_diag.py): picked by the oracle alone, replaced by a
+            # safe token (as test_native_step_vs_oracle does), so that the comparison runs to the end of the step
+            top = -np.partition(-fw["hidden_pre"], k, axis=1)[:, :k + 1]
+            risky = (top[:, :k].min(axis=1) - top[:, k]) < 1e-5 * np.abs(fw["hidden_pre"]).max()
+            if risky.any():
+                safe = np.flatnonzero(~risky)[0]
+                x[risky], y[risky] = x[safe], y[safe]
+                fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
         gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
         before = stats["act_freq_scores"].copy()
-        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        ref = fw_scalars(fw)
         xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
         if k is None:
             eng.dense_step(xg, l1c, want_out=True, target=yg)
@@ -1161,11 +1231,7 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
             # (measured: 1 token of 1024 at 768 -> 8192 in step 2, tools/tc_diag.py).  Such tokens must be near-ties in the
             # oracle's own numbers; the comparison of everything behind the selection ends there.
             same = (np.sort(eng.topk_idx[:n].cpu().numpy(), axis=1) == np.sort(fw["idx"], axis=1)).all(axis=1)
-            if not same.all():
-                assert t > 0 and (~same).sum() <= 2
-                hs = -np.sort(-fw["hidden_pre"][~same], axis=1)
-                assert np.all((hs[:, k - 1] - hs[:, k]) <= 2e-6 * np.abs(fw["hidden_pre"]).max())
-                return
+            assert same.all(), ("top-k sets differ on tokens the oracle does not call near-ties", np.flatnonzero(~same))
         assert rel_fro(eng.sae_out[:n].cpu().numpy(), fw["sae_out"]) < TOL
         if k is None:
             assert abs(sc[4] - ref["l1_loss"]) <= TOL * ref["l1_loss"]
@@ -1187,8 +1253,9 @@ def test_transcoder_steps_vs_oracle(d_in, d_sae, k, n, ln, skip):
         else:
             for name in ("b_dec", "b_dec_out") + (("W_skip",) if skip else ()):
                 assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
-        if differs.any():
-            return
+        # (the oracle's step continues under the KERNEL's ReLU gates where they differ; round 5 stopped the comparison here)
+        O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y,
+                     gate=gate if differs.any() else None)
         fire_ref = stats["act_freq_scores"] - before
         assert np.abs(eng.fire_count.cpu().numpy() - fire_ref).sum() <= TOL * fire_ref.sum()
         eng.apply(1e-3, 1.0)
@@ -1263,7 +1330,7 @@ def test_transcoder_of_unequal_widths_vs_oracle(d_in, d_out, d_sae, k, n, ln):
                 x[risky], y[risky] = x[safe], y[safe]
                 fw = O.sae_forward(Pc, x, k, layer_norm=ln, l1_coefficient=l1c, target=y)
         gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c)
-        ref = O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        ref = fw_scalars(fw)
         xg, yg = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
         if k is None:
             eng.dense_step(xg, l1c, want_out=True, target=yg)
@@ -1276,7 +1343,19 @@ def test_transcoder_of_unequal_widths_vs_oracle(d_in, d_out, d_sae, k, n, ln):
         assert abs(sc[2] - ref["l0"]) <= TOL * ref["l0"]
         assert rel_fro(eng.sae_out[:n, :d_out].cpu().numpy(), fw["sae_out"]) < TOL
         grads = {"W_enc": eng.grad_W_enc(), **{m: eng.g[m] for m in ("W_dec", "b_enc", "b_dec", "b_dec_out")}}
-        gtol = TOL if k is not None else 5e-4          # (ReLU gates within fp32 summation noise of zero: see the dense tests)
+        gate = None
+        if k is None:
+            # ReLU gates within fp32 summation noise of zero may fall on either side: the kernel's gates are read back, must differ from the
+            # oracle's only on such entries, and gradients + the rest of the step are compared under them (round 5: a constant 5e-4)
+            off = eng.lib.pv_debug_sae_ws_offset(eng._plan, b"hidden")
+            dH = eng.workspace[off:off + n * d_sae * 4].view(torch.float32).view(n, d_sae).cpu().numpy()
+            differs = (dH != 0) != (fw["feature_acts"] > 0)
+            assert differs.sum() <= 1e-5 * differs.size and np.all(np.abs(fw["hidden_pre"][differs]) < 1e-5 * np.abs(fw["hidden_pre"]).max())
+            if differs.any():
+                gate = dH != 0
+                gr = O.sae_backward(Pc, x, fw, layer_norm=ln, l1_coefficient=l1c, gate=gate)
+        O.train_step(P, opt, stats, x, k, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y, gate=gate)
+        gtol = TOL
         for name, sl in real.items():
             assert rel_fro(grads[name][sl].cpu().numpy(), gr[name]) < gtol, name
         padding_is_zero(lambda name: grads[name])
@@ -1475,7 +1554,7 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
             # (at most a handful of the n * d_sae gates: 4 up to 8 M of them, 2e-7 of them beyond -- 7 of 100 M at 768 -> 24576 x 4096)
             assert off.sum() <= max(4, int(2e-7 * n * d_sae)) and np.all(np.abs(fw["gate_pre"][off]).min(axis=1) < 2e-6 * np.abs(fw["gate_pre"]).max()), (off.sum(), tok_err.max())
             assert rel_fro(got_out, fw["sae_out"]) < 1e-3
-            return
+            truncated(f"gated step {t}: {int(off.sum())} token(s) opened another gate within fp32 noise of zero; losses compared, tensors to 1e-3")
         assert rel_fro(got_out, fw["sae_out"]) < TOL
         # the two ReLU gates of the backward as the kernel took them (dP = dM e^r + dG is what the scratch holds at the end, so they
         # are read off the gradients they shape): entries within summation noise of zero may fall on either side -- compare under
@@ -1487,7 +1566,7 @@ def test_gated_step_vs_oracle(d_in, d_sae, n, ln, form):
                 assert rel_fro((eng.grad_W_enc() if name == "W_enc" else eng.g[name]).cpu().numpy(), gr[name]) < 1e-3, name
             small = np.minimum(np.abs(fw["gate_pre"]), np.where(fw["gate_pre"] > 0, np.abs(fw["mag_pre"]), np.inf)).min()
             assert small < 1e-5 * np.abs(fw["gate_pre"]).max(), (bad, small)
-            return
+            truncated(f"gated step {t}: a backward ReLU gate within fp32 noise of zero fell differently ({bad}); every gradient compared to 1e-3")
         assert float(eng.g["b_enc"].abs().max()) == 0.0
         assert abs(np.sqrt(sc[3]) - grad_norm_of(gr)) <= TOL * grad_norm_of(gr)
         fire_ref = stats["act_freq_scores"] - before
@@ -1850,7 +1929,7 @@ def test_relu_step_sparse_vs_oracle(d_in, d_sae, n, ln, l0, tc):
         O.renorm_decoder(Pc)
         fw = O.sae_forward(Pc, x, None, layer_norm=ln, l1_coefficient=l1c, target=y)
         before = stats["act_freq_scores"].copy()
-        ref = O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y)
+        ref = fw_scalars(fw)
         eng.relu_step(torch.from_numpy(x).cuda(), l1c, want_out=True, target=torch.from_numpy(y).cuda() if tc else None)
         eng.grad_sqnorm()
         torch.cuda.synchronize()
@@ -1876,8 +1955,9 @@ def test_relu_step_sparse_vs_oracle(d_in, d_sae, n, ln, l0, tc):
         assert rel_fro(eng.grad_W_enc().cpu().numpy(), gr["W_enc"]) < TOL
         for name in [m for m in gr if m != "W_enc"]:
             assert rel_fro(eng.g[name].cpu().numpy(), gr[name]) < TOL, name
-        if differs.any():
-            return
+        # (the oracle's step continues under the KERNEL's lists where an entry within noise of zero fell differently)
+        O.train_step(P, opt, stats, x, None, lr=1e-3, step=t + 1, layer_norm=ln, l1_coefficient=l1c, target=y,
+                     gate=gate if differs.any() else None)
         fire_ref = stats["act_freq_scores"] - before
         assert np.array_equal(eng.fire_count.cpu().numpy(), fire_ref)
         eng.apply(1e-3, 1.0)
