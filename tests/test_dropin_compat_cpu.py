@@ -248,8 +248,12 @@ def test_fold_value_biases_vs_reference_fixture():
         if k.startswith("cache::"):
             assert rel(cache[k.split("::", 1)[1]].numpy(), G[k]) < 1e-5, k
     assert rel(cache["blocks.0.attn.hook_v"].numpy(), cache_plain["blocks.0.attn.hook_v"].numpy()) > 1e-3      # (the folding is visible in the cache)
+    # the reference's own defaults (fold_ln = center_writing_weights = True): accepted, the two unbuilt rewrites skipped with a warning
+    again = HookedViT(HookedViTConfig(**arch, dtype=torch.float32, device="cpu")).eval()
+    again.load_and_process_state_dict(dict(sd))
+    assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), model.state_dict().values()))
     with pytest.raises(NotImplementedError):
-        model.load_and_process_state_dict(dict(sd))                  # (the reference's own defaults: fold_ln = True)
+        model.load_and_process_state_dict(dict(sd), refactor_factored_attn_matrices=True)
 
 
 def test_construction_helpers_of_the_reference_surface(tmp_path):
@@ -270,5 +274,7 @@ def test_construction_helpers_of_the_reference_surface(tmp_path):
     assert model.move_model_modules_to_device() is model
     rnd = HookedViT.from_pretrained("openai/clip-vit-base-patch32", fold_ln=False, center_writing_weights=False, device="cpu", pretrained=False)
     assert type(rnd) is HookedViT and rnd.cfg.n_layers == 12 and rnd.cfg.eps == 1e-6
+    legacy = HookedViT.from_pretrained("openai/clip-vit-base-patch32", device="cpu", pretrained=False)      # (the reference's own defaults work)
+    assert type(legacy) is HookedViT and legacy.cfg.n_layers == 12
     with pytest.raises(NotImplementedError):
-        HookedViT.from_pretrained("openai/clip-vit-base-patch32", device="cpu", pretrained=False)      # (the legacy defaults fold LayerNorm)
+        HookedViT.from_pretrained("openai/clip-vit-base-patch32", device="cpu", pretrained=False, refactor_factored_attn_matrices=True)

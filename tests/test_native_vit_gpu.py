@@ -147,6 +147,52 @@ def test_bf16_b32_within_reference_bf16_budget(tile, tuning):
     assert rel_fro(out.float().cpu().numpy(), o_ref) <= budget["__out__"]["rel_fro"] * BF16_SLACK
 
 
+def test_fp32_b32_outliers_vs_oracle_and_golden():
+    """VERDICT r5 item 4a, fp32 form: all 214 keys on the massive-activation state (synth_vit_state(outliers=True): residual channels
+    at |x| ~ 100 beside an rms of ~1.2) against the oracle at 1e-4 and against the REFERENCE's own fp32 run, fingerprinted
+    (tests/golden/vit_b32_outliers_bf16_budget.json)."""
+    with open(os.path.join(GOLDEN, "vit_b32_outliers_bf16_budget.json")) as f:
+        G = json.load(f)
+    model, arch, sd = build("clip-vit-b32", torch.float32, outliers=True)
+    imgs = synth_images(arch, G["batch"], G["seed"])
+    o_ref, c_ref = vit_forward(sd, arch, imgs)
+    out, cache = run(model, imgs, torch.float32)
+    want = G["fp32"]
+    assert list(cache.keys()) == want["keys"] == list(c_ref.keys()) and len(cache) == 214
+    for k, ref in c_ref.items():
+        got = cache[k].cpu().numpy()
+        assert rel_fro(got, ref) < FP32_TOL, k
+        fp = fingerprint(got)
+        assert abs(fp["l2"] - want["cache"][k]["l2"]) <= FP32_TOL * want["cache"][k]["l2"], k
+        vw = np.array(want["cache"][k]["vals"])
+        assert np.max(np.abs(np.array(fp["vals"]) - vw)) <= 1e-3 * max(np.max(np.abs(vw)), want["cache"][k]["l2"] / np.sqrt(got.size)), k
+    assert rel_fro(out.cpu().numpy(), o_ref) < FP32_TOL
+
+
+def test_bf16_b32_outliers_within_reference_bf16_budget():
+    """VERDICT r5 item 4a, bf16 form -- the bar "error vs the fp32 oracle <= 1.0 x the reference's OWN bf16 error, key by key" where bf16
+    is actually stressed: on the massive-activation state (ulp(100) = 0.5 in bf16 beside values of ~1), all 214 keys on the 4-image
+    batch, then images 0-7 / 504-511 of the bs = 512 bench batch with the kernels the library picks at that size."""
+    with open(os.path.join(GOLDEN, "vit_b32_outliers_bf16_budget.json")) as f:
+        G = json.load(f)
+    model, arch, sd = build("clip-vit-b32", torch.bfloat16, outliers=True)
+    imgs = synth_images(arch, G["batch"], G["seed"])
+    o_ref, c_ref = vit_forward(sd, arch, imgs)
+    out, cache = run(model, imgs, torch.bfloat16)
+    assert list(cache.keys()) == list(c_ref.keys()) and len(cache) == 214
+    _held_to_budget(cache, c_ref, G["budget"], slice(None), "outliers bs=4", SCALE_SLACK_SMALL)
+    assert rel_fro(out.float().cpu().numpy(), o_ref) <= G["budget"]["__out__"]["rel_fro"] * BF16_SLACK
+    del cache
+    S = G["sub512"]
+    sub = S["images"]
+    big = synth_images(arch, S["batch"], S["seed"])
+    o_ref, c_ref = vit_forward(sd, arch, big[sub])
+    out, cache = run(model, big, torch.bfloat16)
+    assert len(cache) == 214
+    _held_to_budget(cache, c_ref, S["budget"], sub, "outliers bs=512")
+    assert rel_fro(out[sub].float().cpu().numpy(), o_ref) <= S["budget"]["__out__"]["rel_fro"] * BF16_SLACK
+
+
 def test_filters_stop_remove_batch_and_cpu_device():
     model, arch, sd = build("clip-vit-b32", torch.float32)
     imgs = synth_images(arch, 4, 1)

@@ -94,3 +94,18 @@ def test_oracle_matches_reference_l14_patterns():
     _check_fp("out", out, want["out"])
     assert G["all_keys"] == hook_names_in_order(arch)
     assert len(G["all_keys"]) == 418                        # 6 + 17*24 + 4
+
+
+def test_oracle_matches_reference_on_the_massive_activation_state():
+    """Round 6: the oracle against the reference's own fp32 run on synth_vit_state(outliers=True) -- a residual
+    stream with channels at |x| ~ 100 beside an rms of ~1.2 (tests/golden/vit_b32_outliers_bf16_budget.json) -- all 214 keys."""
+    with open(os.path.join(GOLDEN, "vit_b32_outliers_bf16_budget.json")) as f:
+        G = json.load(f)
+    assert G["outliers"] and G["resid6_absmax_over_rms"] > 15.0
+    arch = ARCHS["clip-vit-b32"]
+    out, cache = vit_forward(synth_vit_state(arch, 0, outliers=True), arch, synth_images(arch, G["batch"], G["seed"]))
+    want = G["fp32"]
+    assert list(cache.keys()) == want["keys"] and len(want["keys"]) == 214
+    for k in want["keys"]:
+        _check_fp(k, cache[k], want["cache"][k])
+    _check_fp("out", out, want["out"])

@@ -18,6 +18,8 @@
 //   costs one HBM store, nothing is re-read).
 //   blockIdx -> tile mapping is XCD-aware: consecutive tiles along N (which share the A rows)
 //   are placed on the same XCD so the A slab is served from that XCD's L2.
+#include <atomic>
+
 #include "gemm.hpp"
 
 #include <hip/hip_ext.h>
@@ -1454,6 +1456,26 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v8(const GemmParams p, con
     __builtin_amdgcn_s_waitcnt(0x0F70);     // the dead prefetches behind the last tile must land before the LDS is handed on
 }
 
+// CUs a launch may count on: the launch's own budget (a plan's pipeline on CU-masked streams), else the tuning override, else the
+// current device's count (cached per device id; rounded down to a multiple of the XCD count: bid and bid + grid on one XCD)
+inline int pv_gemm_cus(const GemmParams& p) {
+    int n = p.cus > 0 ? p.cus : g_pv_tuning.gemm_cus;
+    if (n <= 0) {
+        static std::atomic<int> per_dev[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        n = per_dev[dev].load(std::memory_order_relaxed);
+        if (n == 0) {
+            hipDeviceProp_t prop;
+            n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+            if (n <= 0) n = 256;
+            per_dev[dev].store(n, std::memory_order_relaxed);
+        }
+    }
+    n -= n % 8;
+    return n <= 0 ? 8 : n;
+}
+
 template <typename T, int MB>
 int launch_v7(const GemmParams& p, hipStream_t stream) {
     const int ntm = (p.M + 64 * MB - 1) / (64 * MB), ntn = (p.N + 255) / 256;
@@ -1473,15 +1495,7 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
             loop_sel = (kbytes % 128 == 0 && g_pv_tuning.gemm_loop != 1) ? 2 : 1;
         // persistent form (v8): the full-line loop's shapes with an even slab count, when the launch has more tiles than CUs
         // (gemm_persist: -1 auto, 0 never, 1 wherever legal)
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-            if (n_cu <= 0) n_cu = 256;
-            n_cu -= n_cu % 8;                                   // (a multiple of the XCD count: bid and bid + grid on one XCD)
-            if (n_cu <= 0) n_cu = 8;
-        }
+        const int n_cu = pv_gemm_cus(p);
         const int ntiles = ntm * ntn;
         const bool persist = loop_sel == 2 && (kbytes / 128) % 2 == 0 && g_pv_tuning.gemm_persist != 0 &&
                              (g_pv_tuning.gemm_persist > 0 || ntiles > n_cu);
@@ -1528,12 +1542,12 @@ int launch_v7(const GemmParams& p, hipStream_t stream) {
 inline int pick_v7(const GemmParams& p) {
     if (g_pv_tuning.gemm_tile >= 0) return g_pv_tuning.gemm_tile;           // 0 = v4, 4 / 5 = v7<MB>
     auto rounds = [](int64_t tiles, int64_t slots) { return (double)((tiles + slots - 1) / slots); };
-    const int64_t M = p.M, N = p.N;
+    const int64_t M = p.M, N = p.N, cus = pv_gemm_cus(p);
     // (the round times predate the full-line loop, which makes the v7 tiles about 10 % faster; scaling them moved only the
     // 512 x 512 head GEMM from 16 small tiles to 4 large ones -- slower -- so the measured constants stay)
-    const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 768) * 25.0;
-    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), 256) * 26.5;
-    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), 256) * 32.0;
+    const double c4 = rounds(((M + 127) / 128) * ((N + 127) / 128), 3 * cus) * 25.0;
+    const double c74 = rounds(((M + 255) / 256) * ((N + 255) / 256), cus) * 26.5;
+    const double c75 = rounds(((M + 319) / 320) * ((N + 255) / 256), cus) * 32.0;
     if (c4 <= c74 && c4 <= c75) return 0;
     return c75 <= c74 ? 5 : 4;
 }

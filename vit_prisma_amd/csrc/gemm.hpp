@@ -34,6 +34,7 @@ struct GemmParams {
     int32_t vec_out;         // set by the launcher: 16-byte vector epilogue legal
     uint64_t* trace;         // debug: per-workgroup {t_start, t_loop_end, t_end, hw_id} (100 MHz wall clock) or NULL
     int32_t dbg;             // ablation switches for kernel tuning (PV_GEMM_DBG): 1 = no DMA in the loop, 2 = no epilogue
+    int32_t cus;             // CUs this launch may count on (a plan's pipeline launches on CU-masked streams): 0 = the device's
 };
 
 // dtype: PV_DTYPE_*.  Returns PV_OK / error code (pv_last_error has the message).

@@ -168,7 +168,7 @@ class NativeViT:
             return None  # dropout is the identity in eval mode; training mode is checked by the caller
         return None
 
-    def _collect(self, model) -> Tuple[N.VitWeights, list, tuple]:
+    def _collect(self, model) -> Tuple[N.VitWeights, list]:
         cfg = self.cfg
         keep: List[torch.Tensor] = []
 
@@ -201,8 +201,31 @@ class NativeViT:
             ln_final_w=P(model.ln_final.w), ln_final_b=P(model.ln_final.b),
             W_H=P(model.head.W_H) if has_head else None, b_H=P(model.head.b_H) if has_head else None,
             layers=C.cast(L, C.POINTER(N.VitLayerWeights)))
-        key = tuple((p.data_ptr(), p._version) for p in model.parameters())
-        return W, [keep, L], key
+        return W, [keep, L]
+
+    def _plan_slots(self, model) -> list:
+        """(module, parameter name) of exactly the parameters the plan borrows (what ``_collect`` reads) -- the one list both the
+        change detection and the key stored after a repack are built from (round-5 advisor: the stored key came from
+        ``model.parameters()``, a different walk -- tied parameters de-duplicated, spliced modules included -- so after one real
+        repack the two could never match again and every forward repacked the whole shadow)."""
+        cfg = self.cfg
+        slots = []
+        for blk in model.blocks:
+            slots += [(blk.ln1, "w"), (blk.ln1, "b"), (blk.ln2, "w"), (blk.ln2, "b")]
+            slots += [(blk.attn, n) for n in ("W_Q", "W_K", "W_V", "b_Q", "b_K", "b_V", "W_O", "b_O")]
+            slots += [(blk.mlp, n) for n in ("W_in", "b_in", "W_out", "b_out")]
+        if cfg.use_cls_token:
+            slots.append((model, "cls_token"))
+        slots += [(model.embed.proj, "weight"), (model.embed.proj, "bias"), (model.pos_embed, "W_pos"), (model.ln_final, "w"), (model.ln_final, "b")]
+        if cfg.layer_norm_pre:
+            slots += [(model.ln_pre, "w"), (model.ln_pre, "b")]
+        if cfg.return_type != "pre_logits":
+            slots += [(model.head, "W_H"), (model.head, "b_H")]
+        return slots
+
+    @staticmethod
+    def _slots_key(slots) -> tuple:
+        return tuple((p.data_ptr(), p._version) for p in (m._parameters.get(n) for m, n in slots) if p is not None)
 
     def sync_weights(self, model, force: bool = False) -> None:
         """(Re)pack the MFMA-layout weight shadow when parameters changed (data_ptr / _version of
@@ -210,15 +233,17 @@ class NativeViT:
         to the version counter; ``HookedViT.invalidate_native_weights()`` forces a repack)."""
         if self._frozen and not force and self._weights_key is not None:
             return
-        # (every call pays this check: walk the (module, name) slots found once instead of model.parameters() -- 0.5 ms of module-tree
-        # traversal per call, which is what a small-batch forward costs on the GPU; a Parameter object replaced in its slot is seen)
+        # (every call pays this check: walk the (module, name) slots of the parameters the plan borrows, found once, instead of
+        # model.parameters() -- 0.5 ms of module-tree traversal per call, which is what a small-batch forward costs on the GPU; a
+        # Parameter object replaced in its slot is seen; a block object replaced in model.blocks is seen by the identity of the list)
         slots = self._param_slots
-        if slots is None or slots[0] is not model:
-            slots = self._param_slots = (model, [(m, n) for m in model.modules() for n, p in m._parameters.items() if p is not None])
-        key = tuple((p.data_ptr(), p._version) for p in (m._parameters[n] for m, n in slots[1]))
+        blocks = tuple(model.blocks)
+        if slots is None or slots[0] is not model or slots[2] != blocks:
+            slots = self._param_slots = (model, self._plan_slots(model), blocks)
+        key = self._slots_key(slots[1])
         if not force and key == self._weights_key:
             return
-        W, keep, key = self._collect(model)
+        W, keep = self._collect(model)
         nbytes = self.lib.pv_vit_shadow_bytes(self._plan)
         if self._shadow is None or self._shadow.numel() < nbytes:
             self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

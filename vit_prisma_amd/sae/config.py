@@ -1,9 +1,10 @@
 """VisionModelSAERunnerConfig -- field-compatible with the reference's runner config
 (/root/reference/src/vit_prisma/sae/config.py:287-663): same field names and defaults, same derived
 properties, same JSON ``save_config`` / ``load_config`` round trip, so existing SAE configs (python or
-JSON) drop in unchanged.  Two reference quirks are NOT reproduced because they are plain bugs:
-``num_patch`` needs ``math`` (never imported there, config.py:489-491) and the ``hook_point`` setter is
-ignored by the getter (:428-436) -- here a custom hook point set through the setter is honoured.
+JSON) drop in unchanged.  One reference quirk is NOT reproduced because it is a plain bug: ``num_patch`` needs
+``math`` (never imported there, config.py:489-491).  One IS reproduced because the reference's own runs depend on it:
+the ``hook_point`` setter is ignored by the getter (:428-436) -- assigning ``cfg.hook_point`` does not move an SAE
+(pinned by tests/golden/sae_vit_tiny_edges.npz); the setter warns once that the value is not read.
 """
 from __future__ import annotations
 
@@ -126,6 +127,11 @@ class VisionModelSAERunnerConfig:
 
     @hook_point.setter
     def hook_point(self, value) -> None:
+        if value != self.hook_point and not getattr(VisionModelSAERunnerConfig, "_warned_hook_point", False):
+            VisionModelSAERunnerConfig._warned_hook_point = True
+            logging.getLogger(__name__).warning(
+                "cfg.hook_point = %r is stored but never read (as in the reference, sae/config.py:428-436): the hook point stays "
+                "blocks.{hook_point_layer}.{layer_subtype} = %r; set hook_point_layer / layer_subtype instead", value, self.hook_point)
         self._custom_hook_point = value
 
     @property
