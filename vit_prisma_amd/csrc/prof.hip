@@ -142,6 +142,7 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "gemm_persist")) return &g_pv_tuning.gemm_persist;
     if (!strcmp(key, "gemm_stagger")) return &g_pv_tuning.gemm_stagger;
     if (!strcmp(key, "gemm_cus")) return &g_pv_tuning.gemm_cus;
+    if (!strcmp(key, "dense_fp32")) return &g_pv_tuning.dense_fp32;
     return nullptr;
 }
 }  // namespace
@@ -168,7 +169,7 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
         const PvTuning& t = g_pv_tuning;
         *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct ||
                   t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.enc_rounds != d.enc_rounds || t.gemm_dbg != d.gemm_dbg ||
-                  t.gemm_loop != d.gemm_loop || t.gemm_persist != d.gemm_persist || t.gemm_stagger != d.gemm_stagger || t.gemm_cus != d.gemm_cus) ? 1 : 0;
+                  t.gemm_loop != d.gemm_loop || t.gemm_persist != d.gemm_persist || t.gemm_stagger != d.gemm_stagger || t.gemm_cus != d.gemm_cus || t.dense_fp32 != d.dense_fp32) ? 1 : 0;
         return PV_OK;
     }
     const int* f = tuning_field(key);

@@ -179,6 +179,8 @@ struct PvTuning {
     int gemm_persist = -1;   // persistent form of the full-line kernel (one workgroup per CU walks its tiles, the K slabs of consecutive tiles one
                              // stream): -1 auto = where the launch has more tiles than CUs, 0 = never, 1 = wherever it is legal
     int gemm_stagger = 0;    // A/B knob of the persistent form: start delay step between workgroups (units of 127 x 64 clocks), 0 = none
+    int dense_fp32 = 0;      // 1: the dense SAE steps (ReLU + L1, gated) on the exact fp32 matrix instruction (round 5's form) instead of the
+                             // split-fp16 one (three fp16 products per fp32 product, fp32 accumulation): the A/B of sae_dense.hip
     int gemm_cus = 0;        // CUs a GEMM launch may count on (grid of the persistent form, rounds of the tile model): 0 = the device's; set by
                              // probes that run forwards on CU-masked streams (tools/cu_mask_forward_probe.py); a plan with a pipeline passes its own
 };

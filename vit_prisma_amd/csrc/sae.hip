@@ -1535,6 +1535,7 @@ SaeWs sae_carve(const pv_sae_desc& d) {
         w.dense_colpart = take(rblk * (size_t)d.d_sae * 4);
         w.dense_rowpart = take(rblk * cblk * 4);
         w.dense_kpart = take((size_t)PV_SAE_DENSE_SPLITK * N * (size_t)d.d_in * 4);
+        w.dense_amax = take((size_t)PV_SAE_AMAX_TENSORS * 256 * 4);
     }
     w.total = off + 256;
     return w;

@@ -67,7 +67,15 @@ struct DenseGemm {
     // pv_sae_relu_step: the step's mode word (device).  Non-NULL: the kernel runs only when *gate == 1 (the sparse attempt could not
     // hold the batch); NULL: always.
     const uint32_t* gate;
+    // split-fp16 form (SPLIT kernels, round 6): DG_AMAX_SLOTS words each -- the bit patterns of partial maxima of |A| and |B| (any entry
+    // may be 0); the largest gives the operand's power-of-two scale.  amax_out (ENC / GENC / DH epilogues, or NULL): the same for the
+    // tensor this launch writes to `out` (atomicMax on bit patterns of non-negative floats: order-independent, so run-to-run identical)
+    const uint32_t* a_max;
+    const uint32_t* b_max;
+    uint32_t* amax_out;
 };
+
+constexpr int DG_AMAX_SLOTS = 256;
 
 // 16 bytes from global memory, or zeros (a plain branch: `ok ? *p : zero` makes hipcc select between two ADDRESSES and park the
 // staging registers in scratch)
@@ -77,7 +85,42 @@ __device__ __forceinline__ uint4 ld16_or_zero(const float* ptr, bool ok) {
     return v;
 }
 
-template <bool A_KM, bool B_KN, int EPI>
+// ---- the split-fp16 K loop (round 6) ------------------------------------------------------------------------------------------
+// The fp32 matrix instruction runs at 1/16 of the fp16 one.  An fp32 value x scaled by a power of two s splits EXACTLY into
+// s x = hi + lo + r with hi = fp16(s x), lo = fp16(s x - hi) and |r| <= 2^-20 |s x| (both conversions round toward zero:
+// v_cvt_pkrtz_f16_f32, one instruction per pair), so a . b = (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) up to 2^-19 relative per
+// product: three fp16 products with fp32 accumulation instead of one fp32 product -- the same tiles and epilogues at 16 / 3 of the
+// matrix rate.  s = 2^(13 - floor(log2 max|.|)) per TENSOR (DenseGemm.a_max / b_max: the producers track the maxima), so the largest
+// entry lands in [2^13, 2^14) and every entry within 2^-14 of it keeps 21+ bits (smaller ones lose relative, not absolute,
+// accuracy: their lo part goes denormal at 2^-24 of the scaled range).  Conversion happens in the staging pass the fp32 kernel has
+// anyway (global -> registers -> LDS); the LDS image of an operand is two planes (hi, lo) of [128 rows][32 k] halves -- 64-byte rows,
+// 16-byte chunk c of row r at c ^ ((r >> 2) & 3): conflict-free ds_read_b128 fragments, the filter GEMM's image -- whichever of
+// its two row-major layouts the fp32 matrix lies in: K-contiguous rows are converted four k at a time, row-contiguous k-slices are
+// transposed on the way (a lane loads the same four rows at four consecutive k and writes four 8-byte row pieces).
+typedef _Float16 dg_f16x8 __attribute__((ext_vector_type(8)));
+constexpr int DG_SPL_PLANE = 128 * 64;          // one operand plane of a stage
+constexpr int DG_SPL_STAGE = 4 * DG_SPL_PLANE;  // A hi, A lo, B hi, B lo
+
+// power-of-two scale of an operand from its tracked maximum (bit pattern of max|.|): the largest entry lands in [2^13, 2^14)
+__device__ __forceinline__ void dg_scale_of(uint32_t max_bits, float& s, float& inv) {
+    int e = (int)((max_bits >> 23) & 0xffu);
+    e = e < 24 ? 24 : (e > 250 ? 250 : e);      // (zeros / denormal maxima: any scale is exact on them)
+    s = __uint_as_float((uint32_t)(267 - e) << 23);
+    inv = __uint_as_float((uint32_t)(e - 13) << 23);
+}
+
+// hi / lo halves of four scaled floats, packed as (k0 k1), (k2 k3)
+__device__ __forceinline__ void dg_split4(float x0, float x1, float x2, float x3, float s, uint2& hi, uint2& lo) {
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    x0 *= s; x1 *= s; x2 *= s; x3 *= s;
+    const h2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    const h2 l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
+    const h2 l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+    hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+    lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+}
+
+template <bool A_KM, bool B_KN, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (p.gate && *p.gate != 1u) return;                   // (uniform over the grid)
@@ -95,39 +138,6 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     const int k_begin = blockIdx.y * p.k_chunk, k_end = min(p.K, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + DG_KSLAB - 1) / DG_KSLAB;
 
-    uint4 ra[4], rb[4];
-    auto load_slab = [&](int kt) {
-        const int kb = k_begin + kt * DG_KSLAB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (A_KM) {                      // chunk c -> k row c >> 5, 4-float group c & 31 of the 128 rows
-                const int k = kb + (c >> 5), mm = m0 + (c & 31) * 4;
-                ra[i] = ld16_or_zero(p.A + (int64_t)k * p.lda + mm, k < k_end && mm < p.M);
-            } else {                                   // chunk c -> row c >> 3, 4-float k group c & 7
-                const int mm = m0 + (c >> 3), k = kb + (c & 7) * 4;
-                ra[i] = ld16_or_zero(p.A + (int64_t)mm * p.lda + k, mm < p.M && k < k_end);
-            }
-            if constexpr (B_KN) {
-                const int k = kb + (c >> 5), nn = n0 + (c & 31) * 4;
-                rb[i] = ld16_or_zero(p.B + (int64_t)k * p.ldb + nn, k < k_end && nn < p.N);
-            } else {
-                const int nn = n0 + (c >> 3), k = kb + (c & 7) * 4;
-                rb[i] = ld16_or_zero(p.B + (int64_t)nn * p.ldb + k, nn < p.N && k < k_end);
-            }
-        }
-    };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;
-            if constexpr (A_KM) *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = ra[i];
-            else *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = ra[i];
-            if constexpr (B_KN) *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = rb[i];
-            else *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = rb[i];
-        }
-    };
-
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -137,52 +147,201 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int l31 = lane & 31, half = lane >> 5;
-    if (nk > 0) {
-        load_slab(0);
-        store_slab(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_slab(kt + 1);
-        const unsigned char* Ab = As + buf * DG_TILE;
-        const unsigned char* Bb = Bs + buf * DG_TILE;
+    float inv_a = 1.0f, inv_b = 1.0f;                      // SPLIT: the two inverse operand scales (applied in the epilogue)
+    if constexpr (SPLIT) {
+        // ---- operand scales: the largest of the tracked partial maxima (one slot per thread)
+        float sa, sb;
+        {
+            uint32_t ma = p.a_max[tid], mb = p.b_max[tid];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // MFMA step (j, e) consumes k = 8 j + 4 half + e of the slab on BOTH operands
-            float af[2][4], bf[2][4];
+            for (int o = 32; o > 0; o >>= 1) {
+                ma = max(ma, (uint32_t)__shfl_xor((int)ma, o, 64));
+                mb = max(mb, (uint32_t)__shfl_xor((int)mb, o, 64));
+            }
+            uint32_t* red = reinterpret_cast<uint32_t*>(smem);
+            if (lane == 0) { red[wave] = ma; red[4 + wave] = mb; }
+            __syncthreads();
+            ma = max(max(red[0], red[1]), max(red[2], red[3]));
+            mb = max(max(red[4], red[5]), max(red[6], red[7]));
+            __syncthreads();
+            dg_scale_of(ma, sa, inv_a);
+            dg_scale_of(mb, sb, inv_b);
+        }
+        uint4 ra[4], rb[4];
+        const int rgl = lane & 7, kql = lane >> 3;             // row-contiguous sources: rows wave * 32 + 4 rgl .. + 3 at k = 4 kql + i
+        auto load_slab = [&](int kt) {
+            const int kb = k_begin + kt * DG_KSLAB;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i;
                 if constexpr (A_KM) {
-                    const float* ak = reinterpret_cast<const float*>(Ab + (8 * j + 4 * half) * DG_KROW) + wm * 64 + mi * 32 + l31;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[mi][e] = ak[e * (DG_KROW / 4)];
+                    const int k = kb + 4 * kql + i, mm = m0 + wave * 32 + 4 * rgl;
+                    ra[i] = ld16_or_zero(p.A + (int64_t)k * p.lda + mm, k < k_end && mm < p.M);
                 } else {
-                    const float4 a = *reinterpret_cast<const float4*>(Ab + (wm * 64 + mi * 32 + l31) * DG_ROWB + half * 16 + j * 32);
-                    af[mi][0] = a.x; af[mi][1] = a.y; af[mi][2] = a.z; af[mi][3] = a.w;
+                    const int mm = m0 + (c >> 3), k = kb + (c & 7) * 4;
+                    ra[i] = ld16_or_zero(p.A + (int64_t)mm * p.lda + k, mm < p.M && k < k_end);
                 }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
                 if constexpr (B_KN) {
-                    const float* bk = reinterpret_cast<const float*>(Bb + (8 * j + 4 * half) * DG_KROW) + wn * 64 + ni * 32 + l31;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bf[ni][e] = bk[e * (DG_KROW / 4)];
+                    const int k = kb + 4 * kql + i, nn = n0 + wave * 32 + 4 * rgl;
+                    rb[i] = ld16_or_zero(p.B + (int64_t)k * p.ldb + nn, k < k_end && nn < p.N);
                 } else {
-                    const float4 b = *reinterpret_cast<const float4*>(Bb + (wn * 64 + ni * 32 + l31) * DG_ROWB + half * 16 + j * 32);
-                    bf[ni][0] = b.x; bf[ni][1] = b.y; bf[ni][2] = b.z; bf[ni][3] = b.w;
+                    const int nn = n0 + (c >> 3), k = kb + (c & 7) * 4;
+                    rb[i] = ld16_or_zero(p.B + (int64_t)nn * p.ldb + k, nn < p.N && k < k_end);
                 }
             }
+        };
+        auto put = [&](unsigned char* plane_hi, int row, int kgrp, float x0, float x1, float x2, float x3, float sc) {
+            uint2 hi, lo;
+            dg_split4(x0, x1, x2, x3, sc, hi, lo);
+            const int off = row * 64 + ((((kgrp >> 1) ^ (row >> 2)) & 3) << 4) + (kgrp & 1) * 8;
+            *reinterpret_cast<uint2*>(plane_hi + off) = hi;
+            *reinterpret_cast<uint2*>(plane_hi + DG_SPL_PLANE + off) = lo;
+        };
+        auto store_operand = [&](unsigned char* plane_hi, const uint4 (&r)[4], bool km, float sc) {
+            if (km) {
+                const int row = wave * 32 + 4 * rgl;
+                put(plane_hi, row + 0, kql, __uint_as_float(r[0].x), __uint_as_float(r[1].x), __uint_as_float(r[2].x), __uint_as_float(r[3].x), sc);
+                put(plane_hi, row + 1, kql, __uint_as_float(r[0].y), __uint_as_float(r[1].y), __uint_as_float(r[2].y), __uint_as_float(r[3].y), sc);
+                put(plane_hi, row + 2, kql, __uint_as_float(r[0].z), __uint_as_float(r[1].z), __uint_as_float(r[2].z), __uint_as_float(r[3].z), sc);
+                put(plane_hi, row + 3, kql, __uint_as_float(r[0].w), __uint_as_float(r[1].w), __uint_as_float(r[2].w), __uint_as_float(r[3].w), sc);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < 4; ++i) {
+                    const int c = tid + 256 * i;
+                    put(plane_hi, c >> 3, c & 7, __uint_as_float(r[i].x), __uint_as_float(r[i].y), __uint_as_float(r[i].z), __uint_as_float(r[i].w), sc);
+                }
+            }
+        };
+        auto store_slab = [&](int buf) {
+            store_operand(smem + buf * DG_SPL_STAGE, ra, A_KM, sa);
+            store_operand(smem + buf * DG_SPL_STAGE + 2 * DG_SPL_PLANE, rb, B_KN, sb);
+        };
+        if (nk > 0) {
+            load_slab(0);
+            store_slab(0);
+        }
+        __syncthreads();
+        const int sw = (l31 >> 2) & 3;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_slab(kt + 1);
+            const unsigned char* Ab = smem + buf * DG_SPL_STAGE;
+            const unsigned char* Bb = Ab + 2 * DG_SPL_PLANE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((ks * 2 + half) ^ sw) << 4;
+                dg_f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const unsigned char* a = Ab + (wm * 64 + mi * 32 + l31) * 64 + co;
+                    ah[mi] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(a));
+                    al[mi] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(a + DG_SPL_PLANE));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const unsigned char* b = Bb + (wn * 64 + ni * 32 + l31) * 64 + co;
+                    bh[ni] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(b));
+                    bl[ni] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(b + DG_SPL_PLANE));
+                }
+                // (the two cross terms first: they are 2^-11 of the main term)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (kt + 1 < nk) store_slab(buf ^ 1);
+            __syncthreads();
         }
-        if (kt + 1 < nk) store_slab(buf ^ 1);
+    } else {
+        uint4 ra[4], rb[4];
+        auto load_slab = [&](int kt) {
+            const int kb = k_begin + kt * DG_KSLAB;
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i;
+                if constexpr (A_KM) {                      // chunk c -> k row c >> 5, 4-float group c & 31 of the 128 rows
+                    const int k = kb + (c >> 5), mm = m0 + (c & 31) * 4;
+                    ra[i] = ld16_or_zero(p.A + (int64_t)k * p.lda + mm, k < k_end && mm < p.M);
+                } else {                                   // chunk c -> row c >> 3, 4-float k group c & 7
+                    const int mm = m0 + (c >> 3), k = kb + (c & 7) * 4;
+                    ra[i] = ld16_or_zero(p.A + (int64_t)mm * p.lda + k, mm < p.M && k < k_end);
+                }
+                if constexpr (B_KN) {
+                    const int k = kb + (c >> 5), nn = n0 + (c & 31) * 4;
+                    rb[i] = ld16_or_zero(p.B + (int64_t)k * p.ldb + nn, k < k_end && nn < p.N);
+                } else {
+                    const int nn = n0 + (c >> 3), k = kb + (c & 7) * 4;
+                    rb[i] = ld16_or_zero(p.B + (int64_t)nn * p.ldb + k, nn < p.N && k < k_end);
+                }
+            }
+        };
+        auto store_slab = [&](int buf) {
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + 256 * i;
+                if constexpr (A_KM) *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = ra[i];
+                else *reinterpret_cast<uint4*>(As + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = ra[i];
+                if constexpr (B_KN) *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 5) * DG_KROW + (c & 31) * 16) = rb[i];
+                else *reinterpret_cast<uint4*>(Bs + buf * DG_TILE + (c >> 3) * DG_ROWB + (c & 7) * 16) = rb[i];
+            }
+        };
+
+        if (nk > 0) {
+            load_slab(0);
+            store_slab(0);
+        }
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_slab(kt + 1);
+            const unsigned char* Ab = As + buf * DG_TILE;
+            const unsigned char* Bb = Bs + buf * DG_TILE;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // MFMA step (j, e) consumes k = 8 j + 4 half + e of the slab on BOTH operands
+                float af[2][4], bf[2][4];
+    #pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    if constexpr (A_KM) {
+                        const float* ak = reinterpret_cast<const float*>(Ab + (8 * j + 4 * half) * DG_KROW) + wm * 64 + mi * 32 + l31;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) af[mi][e] = ak[e * (DG_KROW / 4)];
+                    } else {
+                        const float4 a = *reinterpret_cast<const float4*>(Ab + (wm * 64 + mi * 32 + l31) * DG_ROWB + half * 16 + j * 32);
+                        af[mi][0] = a.x; af[mi][1] = a.y; af[mi][2] = a.z; af[mi][3] = a.w;
+                    }
+                }
+    #pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (B_KN) {
+                        const float* bk = reinterpret_cast<const float*>(Bb + (8 * j + 4 * half) * DG_KROW) + wn * 64 + ni * 32 + l31;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) bf[ni][e] = bk[e * (DG_KROW / 4)];
+                    } else {
+                        const float4 b = *reinterpret_cast<const float4*>(Bb + (wn * 64 + ni * 32 + l31) * DG_ROWB + half * 16 + j * 32);
+                        bf[ni][0] = b.x; bf[ni][1] = b.y; bf[ni][2] = b.z; bf[ni][3] = b.w;
+                    }
+                }
+    #pragma unroll
+                for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+    #pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
+            }
+            if (kt + 1 < nk) store_slab(buf ^ 1);
+            __syncthreads();
+        }
+
     }
 
     // ---- epilogue: accumulators -> per-wave LDS block (the operand buffers are free: barrier above) -> a lane owns 8
@@ -195,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                Cs[row * DG_CS_LD + ni * 32 + l31] = acc[mi][ni][e];
+                Cs[row * DG_CS_LD + ni * 32 + l31] = SPLIT ? acc[mi][ni][e] * inv_a * inv_b : acc[mi][ni][e];
             }
     __builtin_amdgcn_wave_barrier();                      // (wave-private block; a wave's LDS operations execute in order)
     const int cc = (lane & 7) * 8;
@@ -232,6 +391,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         }
     }
     float* outz = p.out + (int64_t)blockIdx.y * p.out_zstride;
+    float vmax = 0.f;
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + (lane >> 3);
@@ -247,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int sl = dslot[i];
-                        if (sl >= 0) p.dead_act[(int64_t)gm * p.ldd + sl] = __expf(v[i] + b8[i]);
+                        if (sl >= 0) p.dead_act[(int64_t)gm * p.ldd + sl] = expf(v[i] + b8[i]);       // (the accurate exp: the ghost gradients cancel down to ~1e-9, where the fast exp's 1e-6 is visible)
                     }
                 }
 #pragma unroll
@@ -268,6 +428,10 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                     csum2[i] += g8[i];
                     rsum += g8[i];
                 }
+                if (p.amax_out) {                                      // (out2 shares out's maximum: the two are ONE operand [2N][F] of the GEMMs behind)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) vmax = fmaxf(vmax, g8[i]);
+                }
                 store8(p.out2 + (int64_t)gm * p.ldo + gn, g8);
             } else if constexpr (EPI == DG_EPI_DH) {
                 float f8[8];
@@ -281,15 +445,23 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                 }
             } else if constexpr (EPI == DG_EPI_EXPB) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __expf(v[i] + b8[i]);       // exp(hidden_pre) of the dead features (sae.py:163), as DG_EPI_ENC writes it
+                for (int i = 0; i < 8; ++i) v[i] = expf(v[i] + b8[i]);         // exp(hidden_pre) of the dead features (sae.py:163), as DG_EPI_ENC writes it
             } else if constexpr (EPI == DG_EPI_MUL) {
                 float m8[8];
                 load8(p.mul + (int64_t)gm * p.ldo + gn, m8);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] *= m8[i];
             }
+            if (p.amax_out) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vmax = fmaxf(vmax, fabsf(v[i]));
+            }
             store8(o, v);
         }
+    }
+    if (p.amax_out) {                                      // max |out| of this wave's block -> one of the DG_AMAX_SLOTS partial maxima
+        vmax = wave_max(vmax);
+        if (lane == 0) atomicMax(p.amax_out + ((blockIdx.x * 4 + wave) & (DG_AMAX_SLOTS - 1)), __float_as_uint(vmax));
     }
     if constexpr (EPI == DG_EPI_ENC || EPI == DG_EPI_DH || EPI == DG_EPI_GENC) {
         // the wave's 64 rows of each column: lanes with equal (lane & 7) hold the same 8 columns
@@ -318,11 +490,11 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     }
 }
 
-template <bool A_KM, bool B_KN, int EPI>
-int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
+template <bool A_KM, bool B_KN, int EPI, bool SPLIT>
+int launch_dense_gemm_form(const DenseGemm& p, int splits, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gemm_kernel<A_KM, B_KN, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_gemm_kernel<A_KM, B_KN, EPI, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS);
         if (e != hipSuccess) {
             pv_set_error(std::string("hipFuncSetAttribute(dense_gemm_kernel): ") + hipGetErrorString(e));
@@ -331,9 +503,40 @@ int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
         attr_done = true;
     }
     const int ntm = (p.M + DG_BM - 1) / DG_BM, ntn = (p.N + DG_BN - 1) / DG_BN;
-    hipLaunchKernelGGL((dense_gemm_kernel<A_KM, B_KN, EPI>), dim3(ntm * ntn, splits), dim3(256), DG_LDS, stream, p);
+    hipLaunchKernelGGL((dense_gemm_kernel<A_KM, B_KN, EPI, SPLIT>), dim3(ntm * ntn, splits), dim3(256), DG_LDS, stream, p);
     PV_LAUNCH_CHECK("dense_gemm_kernel");
     return PV_OK;
+}
+
+// the split-fp16 form when the launch carries both operand maxima (and the tuning key dense_fp32 is off), else the exact fp32 form
+template <bool A_KM, bool B_KN, int EPI>
+int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
+    if constexpr (EPI == DG_EPI_STORE || EPI == DG_EPI_ENC || EPI == DG_EPI_DH || EPI == DG_EPI_GENC) {
+        if (p.a_max && p.b_max && !g_pv_tuning.dense_fp32) return launch_dense_gemm_form<A_KM, B_KN, EPI, true>(p, splits, stream);
+    }
+    return launch_dense_gemm_form<A_KM, B_KN, EPI, false>(p, splits, stream);
+}
+
+// ---- operand maxima of the split-fp16 form ---------------------------------------------------------------------------------------
+// slots[b % DG_AMAX_SLOTS] = max(slots[...], max |x| over workgroup b's grid-stride share): bit patterns of non-negative floats order
+// like the floats, and a maximum does not depend on the order it is taken in
+__global__ __launch_bounds__(256) void dense_absmax_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ slots,
+                                                           const uint32_t* __restrict__ gate) {
+    if (gate && *gate != 1u) return;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DG_AMAX_SLOTS - 1)), __float_as_uint(m));
+}
+
+// max |x| of a contiguous fp32 tensor of n elements (n % 4 == 0) into its slot array (zeroed by the caller at the head of the step)
+void dense_absmax(const float* x, int64_t n, uint32_t* slots, const uint32_t* gate, hipStream_t stream) {
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::min<int64_t>(2048, (n4 + 255) / 256);
+    hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, stream, x, n4, slots, gate);
 }
 
 // column partials [nblk][d] -> out[j] (+ firing statistics, + per-workgroup totals for l0)
@@ -633,6 +836,19 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
     const int rblk = (N + 63) / 64, cblk = (F + 63) / 64;
     const int nb_f = (F + 255) / 256;
     float* blk_tot = (float*)(wsb + ws.sqpart);            // 1024 floats of scratch (nb_f <= 256)
+    // operand maxima of the split-fp16 GEMMs (see dense_gemm_kernel): sae_in, W_enc^T, f, W_dec, dY, dH.  The three that exist before
+    // the first GEMM are taken here, dY behind the finish kernel, f and dH by the epilogues that write them.
+    uint32_t* amax = (uint32_t*)(wsb + ws.dense_amax);
+    enum { AM_X = 0, AM_WENC = 1, AM_F = 2, AM_WDEC = 3, AM_DY = 4, AM_DH = 5 };
+    auto am = [&](int t) { return amax + t * DG_AMAX_SLOTS; };
+    const bool split = !g_pv_tuning.dense_fp32 && (D % 4) == 0 && (F % 4) == 0 && (N % 4) == 0;
+    if (split) {
+        PV_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)PV_SAE_AMAX_TENSORS * DG_AMAX_SLOTS * 4, stream));
+        dense_absmax(sae_in, (int64_t)N * D, am(AM_X), gate, stream);
+        dense_absmax((const float*)st->W_encT, (int64_t)F * D, am(AM_WENC), gate, stream);
+        dense_absmax((const float*)st->W_dec, (int64_t)F * D, am(AM_WDEC), gate, stream);
+        PV_LAUNCH_CHECK("dense_absmax_kernel");
+    }
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + (double)N * F) * 4.0);
         // G1: f = relu(sae_in @ W_enc + b_enc)
@@ -641,6 +857,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         // own layout may be materialised lazily)
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart; g.gate = gate;
+        if (split) { g.a_max = am(AM_X); g.b_max = am(AM_WENC); g.amax_out = am(AM_F); }
         if (nd > 0) {
             PV_HIP_CHECK(hipMemsetAsync(gwb + gw.dead_act, 0, (size_t)N * gw.n_pad * 4, stream));       // (padding columns stay zero)
             g.dead_slot = ghost->dead_slot; g.dead_act = (float*)(gwb + gw.dead_act); g.ldd = gw.n_pad;
@@ -663,6 +880,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g.A = f; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = N; g.N = D; g.K = F;
         g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
         g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)N * D; g.gate = gate;
+        if (split) { g.a_max = am(AM_F); g.b_max = am(AM_WDEC); }
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
         const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));
@@ -671,6 +889,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
                            (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
                            grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate);
         PV_LAUNCH_CHECK("dense_finish_kernel");
+        if (split) dense_absmax(dY, (int64_t)N * D, am(AM_DY), gate, stream);
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), 1, -1,
                        stream, gate, 1u);
         if (ghost) {
@@ -717,6 +936,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         DenseGemm g4 = {};
         g4.A = f; g4.lda = F; g4.B = dY; g4.ldb = D; g4.M = F; g4.N = D; g4.K = N; g4.k_chunk = N;
         g4.out = st->gW_dec; g4.ldo = D; g4.gate = gate;
+        if (split) { g4.a_max = am(AM_F); g4.b_max = am(AM_DY); }
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
         if (nd > 0) {                                                 // gW_dec[dead] += exp(hidden_pre[:, dead])^T @ dG0
@@ -733,6 +953,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         DenseGemm g3 = {};
         g3.A = dY; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
         g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global; g3.gate = gate;
+        if (split) { g3.a_max = am(AM_DY); g3.b_max = am(AM_WDEC); g3.amax_out = am(AM_DH); }
         if (nd > 0) { g3.dead_slot = ghost->dead_slot; g3.dead_act = (float*)(gwb + gw.dhd); g3.ldd = gw.n_pad; }      // + the ghost term
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
@@ -743,6 +964,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         DenseGemm g5 = {};
         g5.A = f; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
         g5.out = st->gW_enc; g5.ldo = D; g5.gate = gate;
+        if (split) { g5.a_max = am(AM_DH); g5.b_max = am(AM_X); }
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
         if (bias_grads) {                                     // (false: pv_sae_relu_step runs them once behind both of its forms)
@@ -1170,16 +1392,23 @@ __global__ void gated_loss_kernel(float* __restrict__ scalars, const uint32_t* _
 }
 
 // dP = dM e^r + dG, in place over dM (rows [0, N) of hs; dG = rows [N, 2N))
+// amax (or NULL): partial maxima of |dP| (DG_AMAX_SLOTS words, see DenseGemm.a_max)
 __global__ __launch_bounds__(256) void gated_dp_kernel(float* __restrict__ hs, const float* __restrict__ r_mag, int64_t n_rows, int F,
-                                                       const uint32_t* __restrict__ gate) {
+                                                       const uint32_t* __restrict__ gate, uint32_t* __restrict__ amax) {
     if (gate && *gate != 1u) return;
+    float m = 0.f;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n_rows * F; i += (int64_t)gridDim.x * 1024) {
         const int c = (int)(i % F);
         float4 a = *reinterpret_cast<const float4*>(hs + i);
         const float4 g = *reinterpret_cast<const float4*>(hs + n_rows * F + i);
         const float4 r = *reinterpret_cast<const float4*>(r_mag + c);
         a.x = a.x * expf(r.x) + g.x; a.y = a.y * expf(r.y) + g.y; a.z = a.z * expf(r.z) + g.z; a.w = a.w * expf(r.w) + g.w;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
         *reinterpret_cast<float4*>(hs + i) = a;
+    }
+    if (amax) {
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DG_AMAX_SLOTS - 1)), __float_as_uint(m));
     }
 }
 
@@ -1276,12 +1505,25 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     float* sdmf = (float*)(gb + gw.vec1);
     const int rblk = (N + 63) / 64, cblk = (F + 63) / 64, nb_f = (F + 255) / 256;
     float* blk_tot = (float*)(wsb + ws.sqpart);
+    // operand maxima of the split-fp16 GEMMs (see dense_gemm_kernel): sae_in, W_enc^T, hs = [f; relu(gate)], W_dec, dYs = [dY; dVia],
+    // dM, dG, dP
+    uint32_t* amax = (uint32_t*)(wsb + ws.dense_amax);
+    enum { AM_X = 0, AM_WENC = 1, AM_HS = 2, AM_WDEC = 3, AM_DY = 4, AM_DM = 5, AM_DG = 6, AM_DP = 7 };
+    auto am = [&](int t) { return amax + t * DG_AMAX_SLOTS; };
+    const bool split = !g_pv_tuning.dense_fp32 && (D % 4) == 0 && (F % 4) == 0 && (N % 4) == 0;
     if (sparse) {
         rc = sae_gated_sparse(plan, st, x, N, n_global, sp->cap, l1_coefficient, update_stats, rwb, gs, out, wsb, ws, dYs,
                               (float*)(gb + gw.auxpart), pgsum, stream);
         if (rc) return rc;
     } else if (mode) {
         hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, stream, (uint32_t*)(rwb + gs.rw.mode), 1u);
+    }
+    if (split) {
+        PV_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)PV_SAE_AMAX_TENSORS * DG_AMAX_SLOTS * 4, stream));
+        dense_absmax(sae_in, (int64_t)N * D, am(AM_X), mode, stream);
+        dense_absmax((const float*)st->W_encT, (int64_t)F * D, am(AM_WENC), mode, stream);
+        dense_absmax((const float*)st->W_dec, (int64_t)F * D, am(AM_WDEC), mode, stream);
+        PV_LAUNCH_CHECK("dense_absmax_kernel");
     }
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + 2.0 * N * F) * 4.0);
@@ -1290,6 +1532,7 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = hs; g.ldo = F; g.out2 = hs + (size_t)N * F; g.bias = t.b_gate; g.bias2 = t.b_mag; g.cscale = t.r_mag;
         g.colpart = colpart; g.colpart2 = colpart2; g.rowpart = rowpart; g.gate = mode;
+        if (split) { g.a_max = am(AM_X); g.b_max = am(AM_WENC); g.amax_out = am(AM_HS); }
         rc = launch_dense_gemm<false, false, DG_EPI_GENC>(g, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
@@ -1309,6 +1552,7 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         g.A = hs; g.lda = F; g.B = st->W_dec; g.ldb = D; g.M = 2 * N; g.N = D; g.K = F;
         g.k_chunk = ((F + S - 1) / S + DG_KSLAB - 1) / DG_KSLAB * DG_KSLAB;
         g.out = kpart; g.ldo = D; g.out_zstride = (int64_t)2 * N * D; g.gate = mode;
+        if (split) { g.a_max = am(AM_HS); g.b_max = am(AM_WDEC); }
         rc = launch_dense_gemm<false, true, DG_EPI_STORE>(g, S, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(gated_finish_kernel, dim3((2 * N + 3) / 4), dim3(256), 0, stream, x, (const float*)sae_in, (const float*)kpart, S,
@@ -1316,6 +1560,7 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            (const float*)(wsb + ws.norm), out->sae_out, dYs, (float*)(wsb + ws.loss_part), (float*)(gb + gw.auxpart), N, D,
                            2.0f / (ng * (float)D), 2.0f / ng, mode);
         PV_LAUNCH_CHECK("gated_finish_kernel");
+        if (split) dense_absmax(dYs, (int64_t)2 * N * D, am(AM_DY), mode, stream);
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / (ng * (float)D), 1, -1, stream, mode, 1u);
         sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / ng, 6, -1, stream, mode, 1u);
         hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, mode);
@@ -1323,12 +1568,14 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         DenseGemm g4 = {};
         g4.A = hs; g4.lda = F; g4.B = dYs; g4.ldb = D; g4.M = F; g4.N = D; g4.K = 2 * N; g4.k_chunk = 2 * N;
         g4.out = st->gW_dec; g4.ldo = D; g4.gate = mode;
+        if (split) { g4.a_max = am(AM_HS); g4.b_max = am(AM_DY); }
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g4, 1, stream);
         if (rc) return rc;
         // G3a: dM = (dY @ W_dec^T) [f > 0] over f; column sums = gb_mag, of dM * f = the raw term of gr_mag
         DenseGemm g3 = {};
         g3.A = dYs; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
         g3.out = hs; g3.ldo = F; g3.colpart = colpart; g3.colpart2 = colpart2; g3.add = 0.f; g3.gate = mode;
+        if (split) { g3.a_max = am(AM_DY); g3.b_max = am(AM_WDEC); g3.amax_out = am(AM_DM); }
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_mag,
@@ -1337,6 +1584,7 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, mode);
         // G3b: dG = (dVia @ W_dec^T + l1 / N) [gate > 0] over relu(gate); column sums = gb_gate
         g3.A = dYs + (size_t)N * D; g3.out = hs + (size_t)N * F; g3.colpart2 = nullptr; g3.add = l1_coefficient / ng;
+        if (split) g3.amax_out = am(AM_DG);
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, t.gb_gate,
@@ -1347,11 +1595,12 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         // dP = dM e^r + dG, then G5: gW_enc^T = dP^T @ sae_in
         // (a bounded grid walking the rows: in the sparse form's mode the launch is empty, and ~100k empty workgroups are 20 us)
         hipLaunchKernelGGL(gated_dp_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)N * F / 4 + 255) / 256, 8192)), dim3(256), 0, stream, hs,
-                           (const float*)t.r_mag, (int64_t)N, F, mode);
+                           (const float*)t.r_mag, (int64_t)N, F, mode, split ? am(AM_DP) : (uint32_t*)nullptr);
         PV_LAUNCH_CHECK("gated elementwise kernels");
         DenseGemm g5 = {};
         g5.A = hs; g5.lda = F; g5.B = sae_in; g5.ldb = D; g5.M = F; g5.N = D; g5.K = N; g5.k_chunk = N;
         g5.out = st->gW_enc; g5.ldo = D; g5.gate = mode;
+        if (split) { g5.a_max = am(AM_DP); g5.b_max = am(AM_X); }
         rc = launch_dense_gemm<true, true, DG_EPI_STORE>(g5, 1, stream);
         if (rc) return rc;
     }
