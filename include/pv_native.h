@@ -44,8 +44,9 @@ extern "C" {
 
 /* ABI version; bumped on any struct / signature / flag change (10: PV_SAE_SPARSE_GRADS, pv_sae_tp_partial / pv_sae_tp_finish;
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
- * gemm_persist / gemm_stagger tuning keys). */
-#define PV_ABI_VERSION 21
+ * gemm_persist / gemm_stagger tuning keys; 22: pv_sae_desc.activation / lp_norm,
+ * normalize_layer_norm = 2 (constant_norm_rescale), the split-fp16 dense GEMMs and their tuning key dense_fp32, gemm_cus). */
+#define PV_ABI_VERSION 22
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -287,10 +288,16 @@ int pv_debug_get_tuning(const char* key, int32_t* value);
 
 typedef struct pv_sae_desc {
     int32_t d_in, d_sae, k;          /* sae/config.py: d_in (<= 1280, % 4), d_sae = d_in*expansion_factor (<= 65536), topk k (<= 256; the fp16-filtered encoder up to 64, the exact fp32 encoder beyond) */
-    int32_t normalize_layer_norm;    /* normalize_activations == "layer_norm", sae.py:78-93         */
+    int32_t normalize_layer_norm;    /* cfg.normalize_activations: 0 none, 1 "layer_norm" (sae.py:74-90), 2 "constant_norm_rescale" (sae.py:60-72) */
     int32_t max_tokens;              /* largest N a step will be called with                        */
     float ln_eps;                    /* 1e-5, sae.py:80                                             */
+    int32_t activation;              /* the dense ReLU + L1 step (pv_sae_dense_step / pv_sae_relu_step): PV_SAE_ACT_RELU, or PV_SAE_ACT_TANH_RELU =
+                                      * tanh(relu(.)), cfg.activation_fn_str = "tanh-relu" (sae.py:823-830; always on the dense GEMMs) */
+    float lp_norm;                   /* the same step: p of the sparsity term l1_coefficient * mean_n ||f_n||_p (sae.py:617); 0 or 1 = the
+                                      * 1-norm (the sparse form of pv_sae_relu_step serves that one only), otherwise p > 1 */
 } pv_sae_desc;
+#define PV_SAE_ACT_RELU 0
+#define PV_SAE_ACT_TANH_RELU 1
 
 /* Transcoder (sae/transcoder.py:6-116; train_sae.py:299-301 hands train_step the pair (input, target)): the coder encodes
  * one activation and reconstructs ANOTHER of the same width.  b_dec_out != NULL switches pv_sae_step / pv_sae_dense_step /

@@ -44,10 +44,20 @@ def topk_mask(hidden_pre: Array, k: int) -> Tuple[Array, Array]:
     return idx, vals
 
 
+def norm_mode(layer_norm) -> str:
+    """cfg.normalize_activations as the oracle's functions take it: a bool (round 1-5 callers: layer_norm on / off) or the config string."""
+    if layer_norm is True or layer_norm == "layer_norm":
+        return "layer_norm"
+    if layer_norm in (False, None, "none"):
+        return "none"
+    assert layer_norm == "constant_norm_rescale", layer_norm
+    return layer_norm
+
+
 def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: bool = True, batch_mean: Optional[Array] = None,
                 n_global: Optional[int] = None, l1_coefficient: float = 0.0, dead_mask: Optional[Array] = None,
                 target: Optional[Array] = None, ghost_global: Optional[Tuple[Array, float]] = None,
-                idx: Optional[Array] = None) -> Dict[str, Array]:
+                idx: Optional[Array] = None, act: str = "relu", lp_norm: float = 1.0) -> Dict[str, Array]:
     """StandardSparseAutoencoder.forward, sae/sae.py:597-645 (encode :557-581, decode :583-595, loss
     :144-149; for topk l1_loss is None and loss == mse_loss, :617-626).  k = None: activation_fn_str = "relu"
     (get_activation_fn :813-830) with the L1 sparsity term l1_coefficient * mean_n ||f_n||_1 (:617-626, lp_norm = 1).
@@ -63,18 +73,30 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     own bias ``b_dec_out`` (decode, :54-64; ``b_dec`` only centres the encoder input, :35-37) and optionally ``W_skip``
     [d_in, d_in] (``sae_out += x @ W_skip.mT`` on the RAW input, before LN-out, :73-76); loss and normaliser against it
     (:78; batch_mean is then the target's).
+    layer_norm: True / "layer_norm" (:74-90), False / None / "none", or "constant_norm_rescale" (:60-72: x * sqrt(d_in) / ||x|| on the way in,
+    / the same coefficient on the way out).  act (k = None): "relu" or "tanh-relu" = tanh(relu(.)) (get_activation_fn :823-830).
+    lp_norm (k = None): the sparsity term is l1_coefficient * mean_n ||f_n||_p (:617, ``feature_acts.norm(p=self.lp_norm, dim=1)``).
     idx [N, k] (tests only: the fp32-vs-float64 noise floors): the selection to keep instead of hidden_pre's own top-k -- the same
     computation carried in another precision must not move to another set where two pre-activations tie within its noise."""
     dt = x.dtype.type
     N, d = x.shape
-    if layer_norm:
+    mode = norm_mode(layer_norm)
+    coeff = None
+    if mode == "layer_norm":
         xh, mu, std = ln_in(x)
+    elif mode == "constant_norm_rescale":                              # :60-72
+        coeff = dt(d ** 0.5) / np.sqrt((x ** 2).sum(axis=-1, keepdims=True))
+        xh, mu, std = x * coeff, np.zeros((N, 1), x.dtype), dt(1) / coeff
     else:
         xh, mu, std = x, np.zeros((N, 1), x.dtype), np.ones((N, 1), x.dtype)
     sae_in = xh - P["b_dec"]                                           # :563-565
     hidden_pre = sae_in @ P["W_enc"] + P["b_enc"]                      # :567-574
     if k is None:
         feats = np.maximum(hidden_pre, dt(0))                          # :576 with torch.nn.ReLU
+        if act == "tanh-relu":
+            feats = np.tanh(feats)                                     # :823-830
+        else:
+            assert act == "relu", act
         idx = vals = None
     else:
         if idx is None:
@@ -87,12 +109,16 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         pre_out = feats @ P["W_dec"] + P["b_dec"]                      # :584-591
         y = x
     else:
-        assert dead_mask is None, "ghost gradients of a transcoder are not restated here"
         pre_out = feats @ P["W_dec"] + P["b_dec_out"]                  # transcoder.py:54-64
         if P.get("W_skip") is not None:
             pre_out = pre_out + x @ P["W_skip"].T                      # transcoder.py:73-74
         y = target
-    sae_out = pre_out * std + mu if layer_norm else pre_out            # :89-90 (no eps on the way out)
+    if mode == "layer_norm":
+        sae_out = pre_out * std + mu                                   # :89-90 (no eps on the way out)
+    elif mode == "constant_norm_rescale":
+        sae_out = pre_out / coeff                                      # :68-70
+    else:
+        sae_out = pre_out
     bm = y.mean(axis=0, keepdims=True) if batch_mean is None else batch_mean.reshape(1, -1)
     nf = np.sqrt(((y - bm) ** 2).sum(axis=-1, keepdims=True))          # :145-147
     ng = N if n_global is None else n_global
@@ -101,11 +127,22 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
     l0 = (feats > 0).sum(axis=-1).astype(np.float64).mean()            # train_sae.py:364
     l1 = None
     loss = mse
-    if k is None:                                                      # :617-626: sparsity = ||f||_1 per token, mean over the batch
-        l1 = dt(l1_coefficient) * (np.abs(feats).sum(axis=-1).sum() / dt(ng))
+    lp_S = None
+    if k is None:                                                      # :617-626: sparsity = ||f||_p per token, mean over the batch
+        if lp_norm == 1:
+            l1 = dt(l1_coefficient) * (np.abs(feats).sum(axis=-1).sum() / dt(ng))
+        else:
+            lp_S = (np.abs(feats) ** dt(lp_norm)).sum(axis=-1, keepdims=True)
+            l1 = dt(l1_coefficient) * ((lp_S ** dt(1.0 / lp_norm)).sum() / dt(ng))
         loss = mse + l1
     gh = None
     if dead_mask is not None:                                          # sae/sae.py:151-179
+        # (a Transcoder hands the ghost term its INPUT x, not the target, transcoder.py:82-86: the residual is x - sae_out and the rescaling
+        # mse is _compute_mse_loss(x, sae_out), normalised by x's own centred norms -- as the reference computes it, d_out = d_in)
+        ghost_mse = mse
+        if target is not None and ghost_global is None:
+            nfx = np.sqrt(((x - x.mean(axis=0, keepdims=True)) ** 2).sum(axis=-1, keepdims=True))
+            ghost_mse = ((sae_out - x) ** 2 / nfx).sum() / dt(ng * d)
         res = x - sae_out
         rc = res - (res.mean(axis=0, keepdims=True) if ghost_global is None else np.asarray(ghost_global[0], x.dtype).reshape(1, -1))
         l2 = np.sqrt((res ** 2).sum(axis=-1))
@@ -115,13 +152,13 @@ def sae_forward(P: Dict[str, Array], x: Array, k: Optional[int], layer_norm: boo
         G = G0 * s[:, None]
         den = np.sqrt((rc ** 2).sum(axis=-1, keepdims=True))                   # (detached)
         mg = (G - res) ** 2 / den
-        r = dt(mse if ghost_global is None else ghost_global[1]) / (mg + dt(1e-6))      # (detached)
+        r = dt(ghost_mse if ghost_global is None else ghost_global[1]) / (mg + dt(1e-6))      # (detached)
         ghost = (r * mg).sum(dtype=np.float64) / (ng * x.shape[1])
         gh = dict(E=E, s=s, G=G, res=res, den=den, r=r, mask=dead_mask, loss=dt(ghost), ng=ng)
         loss = loss + dt(ghost)
     return dict(sae_in=sae_in, hidden_pre=hidden_pre, idx=idx, vals=vals, feature_acts=feats, sae_out=sae_out,
                 mu=mu, std=std, norm_factor=nf, loss=dt(loss), mse_loss=dt(mse), l1_loss=None if l1 is None else dt(l1), l0=l0,
-                ghost=gh, ghost_loss=None if gh is None else gh["loss"], target=target)
+                ghost=gh, ghost_loss=None if gh is None else gh["loss"], target=target, act=act, lp_norm=lp_norm, lp_S=lp_S, norm_mode=mode)
 
 
 def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm: bool = True,
@@ -135,13 +172,21 @@ def sae_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_norm
     ng = N if n_global is None else n_global
     tc = fw.get("target") is not None
     d_out = dt(2.0) * (fw["sae_out"] - (fw["target"] if tc else x)) / fw["norm_factor"] / dt(ng * (fw["target"].shape[1] if tc else d))
-    d_pre = d_out * fw["std"] if layer_norm else d_out
+    d_pre = d_out * fw["std"] if norm_mode(layer_norm) != "none" else d_out      # (constant_norm_rescale: std holds 1 / coefficient)
     feats = fw["feature_acts"]
     g = {}
     g["W_dec"] = feats.T @ d_pre
     d_feats = d_pre @ P["W_dec"].T
     if fw.get("l1_loss") is not None:
-        d_feats = d_feats + dt(l1_coefficient) / dt(ng)
+        if fw.get("lp_S") is None:
+            d_feats = d_feats + dt(l1_coefficient) / dt(ng)
+        else:                                                          # d ||f||_p / d f = ||f||_p^(1 - p) f^(p - 1)  (f >= 0; 0 where f = 0 as torch's)
+            lp = dt(fw["lp_norm"])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.where(fw["lp_S"] > 0, fw["lp_S"] ** dt(1.0 / fw["lp_norm"] - 1.0), dt(0))
+                d_feats = d_feats + dt(l1_coefficient) / dt(ng) * t * np.where(feats > 0, feats ** (lp - dt(1)), dt(0))
+    if fw.get("act") == "tanh-relu":
+        d_feats = d_feats * (dt(1) - feats * feats)                    # d tanh(relu(h)) / d h = 1 - f^2 where h > 0
     d_hidden = np.where(feats > 0 if gate is None else gate, d_feats, dt(0))     # topk scatter + ReLU gates
     gh = fw.get("ghost")
     if gh is not None and gh["mask"].any():                           # gradient of the ghost residual loss: through ghost_out only
@@ -209,14 +254,15 @@ def lr_lambda_cosine_warmup(step: int, warm_up_steps: int, training_steps: int, 
 
 def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, k: Optional[int], lr: float,
                step: int, max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
-               dead_feature_window: Optional[int] = None, target: Optional[Array] = None, gate: Optional[Array] = None) -> Dict[str, float]:
+               dead_feature_window: Optional[int] = None, target: Optional[Array] = None, gate: Optional[Array] = None,
+               act: str = "relu", lp_norm: float = 1.0) -> Dict[str, float]:
     """VisionSAETrainer.train_step, sae/train_sae.py:278-411, in its order: renorm decoder -> forward ->
     firing statistics -> backward -> clip -> project -> Adam.  ``step`` is 1-based (Adam's step count).
     gate (tests of the ReLU steps, see sae_backward): the step as it continues when the ReLU gates [N, d_sae] of the entries within
     fp32 summation noise of zero fall as given -- the backward and the firing statistics under these gates."""
     renorm_decoder(P)                                                   # :306-307
     dead = None if dead_feature_window is None else stats["n_fwd_since_fired"] > dead_feature_window      # :330-332 (use_ghost_grads)
-    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead, target=target)
+    fw = sae_forward(P, x, k, layer_norm, l1_coefficient=l1_coefficient, dead_mask=dead, target=target, act=act, lp_norm=lp_norm)
     fired = ((fw["feature_acts"] > 0) if gate is None else gate).sum(axis=0)      # :356-361
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0

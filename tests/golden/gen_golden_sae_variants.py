@@ -98,7 +98,7 @@ def run(variant, over):
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: 1.0)
     act, since, frac = torch.zeros(cfg.d_sae), torch.zeros(cfg.d_sae), 0
-    if variant in ("relu_ghost", "topk_ghost"):
+    if over.get("use_ghost_grads"):            # (relu_ghost, topk_ghost; round 6: the two transcoder ghost variants of gen_golden_sae_tail.py)
         since[::3] = 5.0                       # a third of the features count as dead (window 1): ghost grads are live
     blob[f"{variant}_since0"] = since.clone().numpy()
     for t in range(3):

@@ -184,3 +184,61 @@ def test_gated_three_steps_vs_reference_fixture(variant, k):
     for n in P:
         assert rel_fro(P[n], g[f"{variant}_s2_param_{n}"]) < 1e-5, n
     assert np.array_equal(g[f"{variant}_s2_param_b_enc"], g[f"{variant}_init_b_enc"])
+
+
+TAIL = {"relu_constnorm": dict(k=None, layer_norm="constant_norm_rescale", l1_coefficient=2e-3),
+        "topk_constnorm": dict(k=8, layer_norm="constant_norm_rescale"),
+        "tanh_relu": dict(k=None, l1_coefficient=2e-3, act="tanh-relu"),
+        "relu_lp2": dict(k=None, l1_coefficient=2e-3, lp_norm=2.0)}
+
+
+@pytest.mark.parametrize("variant", sorted(TAIL))
+def test_tail_variants_three_steps_vs_reference_fixture(variant):
+    """Round 6, SURVEY.md 8(f) row 3's tail: normalize_activations = "constant_norm_rescale" (sae.py:60-72; ReLU + L1 and top-k), the
+    "tanh-relu" activation (:823-830) and lp_norm = 2 (:617) in the oracle against what the reference's own StandardSparseAutoencoder
+    produced through its own train_step (tests/golden/gen_golden_sae_tail.py): scalars, statistics, parameters after step 3."""
+    g = np.load(os.path.join(GOLDEN, "sae_tail_steps.npz"))
+    kw = dict(TAIL[variant])
+    k = kw.pop("k")
+    d_in, d_sae, N = 64, 512, 256
+    P = {n: g[f"{variant}_init_{n}"].copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": g[f"{variant}_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), k, lr=1e-3, step=t + 1, **kw)
+        loss, mse, l1, l0 = g[f"{variant}_s{t}_scalars"][:4]
+        assert abs(out["loss"] - loss) <= 1e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        if k is None:
+            assert abs(out["l1_loss"] - l1) <= 1e-5 * abs(l1), (t, out, l1)
+        assert abs(out["l0"] - l0) <= 1e-6 * l0
+        assert np.array_equal(stats["act_freq_scores"], g[f"{variant}_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"{variant}_s{t}_n_since"])
+    for n in P:
+        assert rel_fro(P[n], g[f"{variant}_s2_param_{n}"]) < 1e-5, n
+
+
+@pytest.mark.parametrize("variant,k", [("tc_topk_ghost", 8), ("tc_relu_ghost", None)])
+def test_transcoder_ghost_three_steps_vs_reference_fixture(variant, k):
+    """Round 6: ghost gradients on a Transcoder -- the ghost term sees the INPUT activation (residual x - sae_out, rescaled by
+    _compute_mse_loss(x, sae_out): transcoder.py:82-86 + sae.py:151-179) while the loss reconstructs the target -- in the oracle against
+    the reference's own Transcoder through its own train_step (tests/golden/sae_tail_steps.npz): top-k with the skip connection, ReLU + L1
+    without; a third of the features dead from the start."""
+    g = np.load(os.path.join(GOLDEN, "sae_tail_steps.npz"))
+    d_in, d_sae, N = 64, 512, 256
+    names = [str(n) for n in g[f"{variant}_keys"]]
+    P = {n: g[f"{variant}_init_{n}"].copy() for n in names}
+    opt = {"m": {kk: np.zeros_like(v) for kk, v in P.items()}, "v": {kk: np.zeros_like(v) for kk, v in P.items()}}
+    stats = {"n_fwd_since_fired": g[f"{variant}_since0"].astype(np.float32).copy(), "act_freq_scores": np.zeros(d_sae, np.float32)}
+    assert (stats["n_fwd_since_fired"] > 1).sum() > 100
+    for t in range(3):
+        out = O.train_step(P, opt, stats, synth_sae_batch(N, d_in, seed=t), k, lr=1e-3, step=t + 1, dead_feature_window=1,
+                           l1_coefficient=0.0 if k else 2e-3, target=synth_sae_batch(N, d_in, seed=100 + t))
+        loss, mse, l1, l0, ghost = g[f"{variant}_s{t}_scalars"][:5]
+        assert abs(out["loss"] - loss) <= 2e-5 * abs(loss) and abs(out["mse_loss"] - mse) <= 1e-5 * abs(mse), (t, out, loss, mse)
+        assert abs(out["ghost_loss"] - ghost) <= 2e-5 * abs(ghost), (t, out, ghost)
+        assert abs(out["l0"] - l0) <= 1e-6 * l0
+        assert np.array_equal(stats["act_freq_scores"], g[f"{variant}_s{t}_act_freq"])
+        assert np.array_equal(stats["n_fwd_since_fired"], g[f"{variant}_s{t}_n_since"])
+    for n in P:
+        # (a dead feature's only gradient is the ghost term: ~1e-9 entries Adam turns into lr-sized steps either way -- see the top-k ghost test)
+        assert rel_fro(P[n], g[f"{variant}_s2_param_{n}"]) < (1e-3 if n == "W_enc" else 2e-4), (n, rel_fro(P[n], g[f"{variant}_s2_param_{n}"]))

@@ -35,10 +35,19 @@ def make_cfg(**over):
     return VisionModelSAERunnerConfig(**kw)
 
 
-@pytest.mark.parametrize("variant", list(VARIANTS))
+# round 6: the tail of 8(f) row 3 (tests/golden/gen_golden_sae_tail.py -> sae_tail_steps.npz)
+TAIL = {
+    "relu_constnorm": dict(activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3, normalize_activations="constant_norm_rescale"),
+    "topk_constnorm": dict(activation_fn_str="topk", activation_fn_kwargs={"k": 8}, normalize_activations="constant_norm_rescale"),
+    "tanh_relu": dict(activation_fn_str="tanh-relu", activation_fn_kwargs={}, l1_coefficient=2e-3),
+    "relu_lp2": dict(activation_fn_str="relu", activation_fn_kwargs={}, l1_coefficient=2e-3, lp_norm=2),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS) + list(TAIL))
 def test_variant_three_steps_match_the_reference(variant):
-    g = np.load(os.path.join(GOLDEN, "sae_variants_steps.npz"))
-    cfg = make_cfg(**VARIANTS[variant])
+    g = np.load(os.path.join(GOLDEN, "sae_tail_steps.npz" if variant in TAIL else "sae_variants_steps.npz"))
+    cfg = make_cfg(**{**VARIANTS, **TAIL}[variant])
     tr = VisionSAETrainer(cfg, model=None, dataset=None)          # the trainer picks the class (train_sae.py:72-81)
     model = tr.sparse_coder
     want_cls = {"gated": GatedSparseAutoencoder, "transcoder": Transcoder}.get(variant, StandardSparseAutoencoder)

@@ -11,7 +11,7 @@ from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PV_NATIVE_LIB") or os.path.join(HERE, "libpvnative.so")     # (override: kernel A/B builds)
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 PV_DTYPE_F32, PV_DTYPE_BF16 = 0, 1
 PV_ACT = {"gelu": 0, "quick_gelu": 1, "relu": 2}
@@ -55,7 +55,8 @@ class Tap(C.Structure):
 
 class SaeDesc(C.Structure):
     _fields_ = [("d_in", C.c_int32), ("d_sae", C.c_int32), ("k", C.c_int32),
-                ("normalize_layer_norm", C.c_int32), ("max_tokens", C.c_int32), ("ln_eps", C.c_float)]
+                ("normalize_layer_norm", C.c_int32), ("max_tokens", C.c_int32), ("ln_eps", C.c_float),
+                ("activation", C.c_int32), ("lp_norm", C.c_float)]
 
 
 class SaeTranscoder(C.Structure):

@@ -101,18 +101,22 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
         const float c = v - batch_mean[i];
         cn += c * c;
     }
-    const float mu = use_ln ? wave_sum(s) / (float)d_true : 0.f;
+    // use_ln: 0 none, 1 "layer_norm" (sae.py:74-90), 2 "constant_norm_rescale" (sae.py:60-72: x * c on the way in with
+    // c = sqrt(d_in) / ||x||, / c on the way out -- the step's other kernels only know "out = pre * sd + mu": mu = 0, sd = 1 / c)
+    const float mu = use_ln == 1 ? wave_sum(s) / (float)d_true : 0.f;
     cn = wave_sum(cn);
     float sq = 0.f;
     for (int i = lane; i < d_true; i += 64) {
         const float c = xr[i] - mu;
         sq += c * c;
     }
+    sq = wave_sum(sq);
     // torch.std: unbiased (divide by d - 1)
-    const float sd = use_ln ? sqrtf(wave_sum(sq) / (float)(d_true - 1)) : 1.f;
+    const float coeff = use_ln == 2 ? sqrtf((float)d_true) / sqrtf(sq) : 1.f;
+    const float sd = use_ln == 1 ? sqrtf(sq / (float)(d_true - 1)) : (use_ln == 2 ? 1.f / coeff : 1.f);
     float s2 = 0.f, amax = 0.f;
     for (int i = lane; i < d; i += 64) {
-        const float xh = use_ln ? (xr[i] - mu) / (sd + eps) : xr[i];
+        const float xh = use_ln == 1 ? (xr[i] - mu) / (sd + eps) : (use_ln == 2 ? xr[i] * coeff : xr[i]);
         const float si = i < d_true ? xh - b_dec[i] : 0.f;
         sae_in[(int64_t)n * d + i] = si;
         if (x16) x16[(int64_t)n * d + i] = (_Float16)si;       // operand of the filter GEMM (sae_enc.hip)
@@ -1536,6 +1540,10 @@ SaeWs sae_carve(const pv_sae_desc& d) {
         w.dense_rowpart = take(rblk * cblk * 4);
         w.dense_kpart = take((size_t)PV_SAE_DENSE_SPLITK * N * (size_t)d.d_in * 4);
         w.dense_amax = take((size_t)PV_SAE_AMAX_TENSORS * 256 * 4);
+        const bool lp = d.lp_norm != 0.f && d.lp_norm != 1.f;
+        w.dense_lp_part = take(lp ? N * cblk * 4 : 0);
+        w.dense_lp_tok = take(lp ? N * 4 : 0);
+        w.dense_lp_loss = take(lp ? N * 4 : 0);
     }
     w.total = off + 256;
     return w;
@@ -1573,6 +1581,9 @@ extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_pla
     // (k <= 64: the filtered encoder; beyond it, up to 256, the exact fp32 encoder + the streaming top-k serve the plan -- pv_sae_fast_ok)
     PV_REQUIRE(desc->k >= 1 && desc->k <= 256, "k must be in [1, 256]");
     PV_REQUIRE(desc->max_tokens >= 1, "max_tokens");
+    PV_REQUIRE(desc->normalize_layer_norm >= 0 && desc->normalize_layer_norm <= 2, "normalize_layer_norm: 0 none, 1 layer_norm, 2 constant_norm_rescale");
+    PV_REQUIRE(desc->activation == PV_SAE_ACT_RELU || desc->activation == PV_SAE_ACT_TANH_RELU, "activation: PV_SAE_ACT_RELU or PV_SAE_ACT_TANH_RELU");
+    PV_REQUIRE(desc->lp_norm == 0.f || desc->lp_norm >= 1.f, "lp_norm: 0 / 1 (the 1-norm) or p > 1 (p < 1 has no finite gradient at zero activations)");
     pv_sae_plan* p = new pv_sae_plan();
     p->d = *desc;
     *out_plan = p;

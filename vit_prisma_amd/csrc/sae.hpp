@@ -20,6 +20,7 @@ struct SaeWs {
     size_t total;
     size_t dense_colpart, dense_rowpart, dense_kpart;     // sae_dense.hip: column partials [N/64][d_sae], per-wave sums, split-K partials
     size_t dense_amax;                                    // sae_dense.hip: PV_SAE_AMAX_TENSORS x 256 partial maxima (operand scales of the split-fp16 GEMMs)
+    size_t dense_lp_part, dense_lp_tok, dense_lp_loss;    // sae_dense.hip, lp_norm > 1: [N][d_sae / 64] sums of f^p, [N] gradient factors, [N] norms
     size_t hidden, sae_in, dY, mu, sd, norm, dh, loss_part, cnt, offs, cursor, wpos, long_list, n_long, seg_range, seg_rows, seg_b, pairs, colpart, colsum, batch_mean, sqpart, rowsq;
     // fast encoder (sae_enc.hip)
     size_t x16, xnorm, sample, thr, sq, band, cand_cnt, cand, fb_list, fb_count, wmax;
@@ -134,6 +135,10 @@ int sae_tc_bias_grads(const pv_sae_desc& d, const pv_sae_state* st, const float*
 // W_skip); gW_skip = dY^T x
 int sae_tc_skip_forward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, int N, const float** skip, hipStream_t stream);
 int sae_tc_skip_backward(const pv_sae_desc& d, const pv_sae_state* st, const float* x, const float* dY, int N, hipStream_t stream);
+// the plain ReLU + L1 form (what the sparse form of pv_sae_relu_step serves): ReLU activation, the 1-norm as the sparsity term
+static inline bool sae_plain_relu(const pv_sae_desc& d) {
+    return d.activation == PV_SAE_ACT_RELU && (d.lp_norm == 0.f || d.lp_norm == 1.f);
+}
 static inline bool sae_is_gated(const pv_sae_state* st) { return st->gt.b_gate != nullptr; }
 constexpr int PV_SAE_AMAX_TENSORS = 16;      // slot arrays of operand maxima a dense step may track (SaeWs.dense_amax)
 constexpr int PV_SAE_DENSE_SPLITK = 4;       // K splits of the dense decoder GEMM (M = tokens, N = d_in: too few tiles otherwise)

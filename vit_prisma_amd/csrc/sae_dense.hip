@@ -73,6 +73,11 @@ struct DenseGemm {
     const uint32_t* a_max;
     const uint32_t* b_max;
     uint32_t* amax_out;
+    // round 6: the tail of SURVEY.md 8(f) row 3 on the ENC / DH epilogues
+    int act;                                  // PV_SAE_ACT_TANH_RELU: f = tanh(relu(.)) (sae.py:823-830); DH: x (1 - f^2)
+    float lp;                                 // p of the sparsity term ||f_n||_p (sae.py:617); 0 / 1: the 1-norm
+    float* lp_part;                           // ENC, lp > 1: [M][ceil(N / 64)] sums of f^p over the row's 64 columns of a wave
+    const float* lp_tok;                      // DH, lp > 1: [M] l1 / N_global * ||f_n||_p^(1 - p), the per-token factor of d ||f_n||_p / d f
 };
 
 constexpr int DG_AMAX_SLOTS = 256;
@@ -87,9 +92,9 @@ __device__ __forceinline__ uint4 ld16_or_zero(const float* ptr, bool ok) {
 
 // ---- the split-fp16 K loop (round 6) ------------------------------------------------------------------------------------------
 // The fp32 matrix instruction runs at 1/16 of the fp16 one.  An fp32 value x scaled by a power of two s splits EXACTLY into
-// s x = hi + lo + r with hi = fp16(s x), lo = fp16(s x - hi) and |r| <= 2^-20 |s x| (both conversions round toward zero:
-// v_cvt_pkrtz_f16_f32, one instruction per pair), so a . b = (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) up to 2^-19 relative per
-// product: three fp16 products with fp32 accumulation instead of one fp32 product -- the same tiles and epilogues at 16 / 3 of the
+// s x = hi + lo + r with hi = fp16(s x), lo = fp16(s x - hi) and |r| <= 2^-23 |s x| (both conversions round to nearest:
+// v_cvt_pk_f16_f32, one instruction per pair), so a . b = (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) up to 2^-22 relative per
+// product (the dropped a_lo b_lo term): three fp16 products with fp32 accumulation instead of one fp32 product -- the same tiles and epilogues at 16 / 3 of the
 // matrix rate.  s = 2^(13 - floor(log2 max|.|)) per TENSOR (DenseGemm.a_max / b_max: the producers track the maxima), so the largest
 // entry lands in [2^13, 2^14) and every entry within 2^-14 of it keeps 21+ bits (smaller ones lose relative, not absolute,
 // accuracy: their lo part goes denormal at 2^-24 of the scaled range).  Conversion happens in the staging pass the fp32 kernel has
@@ -110,12 +115,16 @@ __device__ __forceinline__ void dg_scale_of(uint32_t max_bits, float& s, float& 
 }
 
 // hi / lo halves of four scaled floats, packed as (k0 k1), (k2 k3)
+// (round to nearest even both times: gfx950's v_cvt_pk_f16_f32, one instruction per pair like the round-toward-zero v_cvt_pkrtz of
+// older parts -- |r| <= 2^-23 |s x| instead of 2^-20, and unbiased: measured on the gated step, the RTZ form opened 9 "other" gates
+// per 8 M where the fp32 kernels open <= 4)
 __device__ __forceinline__ void dg_split4(float x0, float x1, float x2, float x3, float s, uint2& hi, uint2& lo) {
-    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-    x0 *= s; x1 *= s; x2 *= s; x3 *= s;
-    const h2 h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-    const h2 l01 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h01[0], x1 - (float)h01[1]);
-    const h2 l23 = __builtin_amdgcn_cvt_pkrtz(x2 - (float)h23[0], x3 - (float)h23[1]);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 a = {x0 * s, x1 * s}, b = {x2 * s, x3 * s};
+    const h2 h01 = __builtin_convertvector(a, h2), h23 = __builtin_convertvector(b, h2);
+    const h2 l01 = __builtin_convertvector(a - __builtin_convertvector(h01, f2), h2);
+    const h2 l23 = __builtin_convertvector(b - __builtin_convertvector(h23, f2), h2);
     hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
     lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
 }
@@ -410,11 +419,20 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                         if (sl >= 0) p.dead_act[(int64_t)gm * p.ldd + sl] = expf(v[i] + b8[i]);       // (the accurate exp: the ghost gradients cancel down to ~1e-9, where the fast exp's 1e-6 is visible)
                     }
                 }
+                float psum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = fmaxf(v[i] + b8[i], 0.f);                   // hidden_pre + b_enc -> ReLU (sae.py:567-577)
+                    if (p.act == PV_SAE_ACT_TANH_RELU) v[i] = tanhf(v[i]);      // "tanh-relu" (sae.py:823-830)
                     csum[i] += v[i] > 0.f ? 1.f : 0.f;                // firing counts (train_sae.py:356-364)
                     rsum += v[i];                                     // ||f||_1 (sae.py:617)
+                    if (p.lp_part) psum += v[i] > 0.f ? powf(v[i], p.lp) : 0.f;
+                }
+                if (p.lp_part) {                                       // sum of f^p over this row's 64 columns (the 8 lanes that share the row)
+                    psum += __shfl_xor(psum, 1, 64);
+                    psum += __shfl_xor(psum, 2, 64);
+                    psum += __shfl_xor(psum, 4, 64);
+                    if ((lane & 7) == 0) p.lp_part[(int64_t)gm * ((p.N + 63) / 64) + tile_n * 2 + wn] = psum;
                 }
             } else if constexpr (EPI == DG_EPI_GENC) {
                 float g8[8];
@@ -436,9 +454,14 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
             } else if constexpr (EPI == DG_EPI_DH) {
                 float f8[8];
                 load8(o, f8);                                          // the stored activation: the ReLU gate of the backward
+                const float lpt = p.lp_tok ? p.lp_tok[gm] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    v[i] = f8[i] > 0.f ? v[i] + p.add : 0.f;           // d loss / d hidden_pre = (dF + l1 / N) [f > 0]
+                    // d loss / d hidden_pre = (dF + l1 / N) [f > 0]; lp > 1: the sparsity term's l1 / N ||f_n||_p^(1 - p) f^(p - 1)
+                    // instead of the constant; tanh-relu: x d tanh = 1 - f^2
+                    float g = v[i] + (p.lp_tok ? lpt * powf(f8[i], p.lp - 1.f) : p.add);
+                    if (p.act == PV_SAE_ACT_TANH_RELU) g *= 1.f - f8[i] * f8[i];
+                    v[i] = f8[i] > 0.f ? g : 0.f;
                     if (p.dead_slot && dslot[i] >= 0) v[i] += p.dead_act[(int64_t)gm * p.ldd + dslot[i]];    // + the ghost term (not gated)
                     csum[i] += v[i];                                  // gb_enc
                     csum2[i] += v[i] * f8[i];
@@ -573,8 +596,10 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            float* __restrict__ sae_out, float* __restrict__ dY,
                                                            float* __restrict__ loss_partial, int n_tok, int d, float grad_scale,
                                                            float* __restrict__ err_out, const float* __restrict__ addend,
-                                                           const uint32_t* __restrict__ gate = nullptr) {
-    // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term or nullptr
+                                                           const uint32_t* __restrict__ gate = nullptr,
+                                                           const float* __restrict__ ghost_x = nullptr) {
+    // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term or nullptr; ghost_x (a transcoder with
+    // ghost gradients): the INPUT activation -- err_out is then sae_out - input, what the ghost term is computed on (transcoder.py:82-86)
     if (gate && *gate != 1u) return;
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -597,7 +622,14 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
         o.x = (a.x + bd.x) * sdv + m; o.y = (a.y + bd.y) * sdv + m; o.z = (a.z + bd.z) * sdv + m; o.w = (a.w + bd.w) * sdv + m;
         e.x = o.x - xv.x; e.y = o.y - xv.y; e.z = o.z - xv.z; e.w = o.w - xv.w;
         if (sae_out) *reinterpret_cast<float4*>(sae_out + (int64_t)n * d + c) = o;
-        if (err_out) *reinterpret_cast<float4*>(err_out + (int64_t)n * d + c) = e;
+        if (err_out) {
+            float4 eg = e;
+            if (ghost_x) {
+                const float4 gx = *reinterpret_cast<const float4*>(ghost_x + (int64_t)n * d + c);
+                eg.x = o.x - gx.x; eg.y = o.y - gx.y; eg.z = o.z - gx.z; eg.w = o.w - gx.w;
+            }
+            *reinterpret_cast<float4*>(err_out + (int64_t)n * d + c) = eg;
+        }
         lsum += (e.x * e.x) / nf + (e.y * e.y) / nf + (e.z * e.z) / nf + (e.w * e.w) / nf;
         g.x = grad_scale * e.x / nf * sdv; g.y = grad_scale * e.y / nf * sdv;
         g.z = grad_scale * e.z / nf * sdv; g.w = grad_scale * e.w / nf * sdv;
@@ -605,6 +637,24 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
     }
     lsum = wave_sum(lsum);
     if (lane == 0) loss_partial[n] = lsum;
+}
+
+// lp_norm > 1 (sae.py:617): per token S = sum_j f^p from the ENC epilogue's partials -> ||f_n||_p = S^(1/p) (the loss term) and
+// l1 / N_global * S^(1/p - 1), the per-token factor of d ||f_n||_p / d f_j = S^(1/p - 1) f_j^(p - 1).  One wave per token, fixed order.
+__global__ __launch_bounds__(256) void dense_lp_finish_kernel(const float* __restrict__ part, int ncb, float p, float l1_over_n,
+                                                              float* __restrict__ lp_tok, float* __restrict__ lp_loss, int n_tok,
+                                                              const uint32_t* __restrict__ gate) {
+    if (gate && *gate != 1u) return;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    float s = 0.f;
+    for (int c = lane; c < ncb; c += 64) s += part[(int64_t)n * ncb + c];
+    s = wave_sum(s);
+    if (lane == 0) {
+        lp_loss[n] = s > 0.f ? powf(s, 1.f / p) : 0.f;
+        lp_tok[n] = s > 0.f ? l1_over_n * powf(s, 1.f / p - 1.f) : 0.f;
+    }
 }
 
 // scalars[0] = mse + l1 (+ ghost) (sae.py:628), one thread
@@ -630,6 +680,22 @@ __global__ __launch_bounds__(256) void ghost_scatter_add_rows_kernel(float* __re
     float* dst = gW_dec + (int64_t)dead_idx[s] * d;
     for (int c = threadIdx.x; c < d; c += 256) dst[c] += add[(int64_t)s * d + c];
 }
+// A Transcoder's ghost term rescales by _compute_mse_loss(INPUT, sae_out) (transcoder.py:82-86, sae.py:144-149, 170-173): per token
+// sum_i err_i^2 / ||x_n - mean_batch(x)||, err = sae_out - x.  One wave per token.
+__global__ __launch_bounds__(256) void tc_ghost_mse_kernel(const float* __restrict__ x, const float* __restrict__ err,
+                                                           const float* __restrict__ xmean, float* __restrict__ part, int n_tok, int d) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_tok) return;
+    float c2 = 0.f, e2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float c = x[(int64_t)n * d + i] - xmean[i], e = err[(int64_t)n * d + i];
+        c2 += c * c; e2 += e * e;
+    }
+    c2 = wave_sum(c2); e2 = wave_sum(e2);
+    if (lane == 0) part[n] = e2 / sqrtf(c2);
+}
+
 // One wave per token.  res = x - sae_out = -err; G0 = exp(hidden_pre[:, dead]) @ W_dec[dead]:
 //   s = ||res|| / (1e-6 + 2 ||G0||)  (detached);  G = s G0;  den = || res - mean_batch(res) ||  (detached)
 //   mg = (G - res)^2 / den;  r = mse_loss / (mg + 1e-6)  (detached);  ghost loss = mean(r mg)
@@ -778,6 +844,18 @@ extern "C" size_t pv_sae_ghost_workspace_bytes(const pv_sae_plan* plan, int32_t 
 
 namespace {
 // validation shared by pv_sae_dense_step and pv_sae_relu_step
+// scalars[7] = _compute_mse_loss(INPUT, sae_out) of a transcoder's ghost term (err = sae_out - x); scratch: the ghost workspace's
+// colmean / colpart / part (re-used afterwards for the residual's own column mean)
+int tc_ghost_mse(const float* x, const float* err, int N, int D, unsigned char* gwb, const GhostWs& gw, float* scalars, hipStream_t stream) {
+    int rc = sae_colsum(x, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tc_ghost_mse_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, err, (const float*)(gwb + gw.colmean),
+                       (float*)(gwb + gw.part), N, D);
+    PV_LAUNCH_CHECK("tc_ghost_mse_kernel");
+    sae_reduce_sum((const float*)(gwb + gw.part), scalars, N, 1.0f / ((float)N * (float)D), 7, -1, stream);
+    return PV_OK;
+}
+
 int dense_require(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t N, int32_t n_global, int update_stats, pv_sae_out* out,
                   void* workspace) {
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
@@ -842,6 +920,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
     enum { AM_X = 0, AM_WENC = 1, AM_F = 2, AM_WDEC = 3, AM_DY = 4, AM_DH = 5 };
     auto am = [&](int t) { return amax + t * DG_AMAX_SLOTS; };
     const bool split = !g_pv_tuning.dense_fp32 && (D % 4) == 0 && (F % 4) == 0 && (N % 4) == 0;
+    const bool lp_on = d.lp_norm != 0.f && d.lp_norm != 1.f;      // the sparsity term is ||f_n||_p, p > 1 (sae.py:617)
     if (split) {
         PV_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)PV_SAE_AMAX_TENSORS * DG_AMAX_SLOTS * 4, stream));
         dense_absmax(sae_in, (int64_t)N * D, am(AM_X), gate, stream);
@@ -858,6 +937,8 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g.A = sae_in; g.lda = D; g.B = st->W_encT; g.ldb = D; g.M = N; g.N = F; g.K = D; g.k_chunk = D;
         g.out = f; g.ldo = F; g.bias = st->b_enc; g.colpart = colpart; g.rowpart = rowpart; g.gate = gate;
         if (split) { g.a_max = am(AM_X); g.b_max = am(AM_WENC); g.amax_out = am(AM_F); }
+        g.act = d.activation; g.lp = d.lp_norm;
+        if (lp_on) g.lp_part = (float*)(wsb + ws.dense_lp_part);
         if (nd > 0) {
             PV_HIP_CHECK(hipMemsetAsync(gwb + gw.dead_act, 0, (size_t)N * gw.n_pad * 4, stream));       // (padding columns stay zero)
             g.dead_slot = ghost->dead_slot; g.dead_act = (float*)(gwb + gw.dead_act); g.ldd = gw.n_pad;
@@ -870,7 +951,16 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
                            st->n_fwd_since_fired, update_stats, blk_tot, gate);
         PV_LAUNCH_CHECK("dense_colreduce_kernel");
         sae_reduce_sum(blk_tot, out->scalars, nb_f, 1.0f / (float)N, 2, -1, stream, gate, 1u);                       // l0 (train_sae.py:364)
-        sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)n_global, 4, -1, stream, gate, 1u);  // l1_loss (sae.py:617-626)
+        if (lp_on) {
+            // l1_loss = l1 * mean_n ||f_n||_p (sae.py:617-626 with lp_norm = p)
+            hipLaunchKernelGGL(dense_lp_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.dense_lp_part), cblk,
+                               d.lp_norm, l1_coefficient / (float)n_global, (float*)(wsb + ws.dense_lp_tok), (float*)(wsb + ws.dense_lp_loss),
+                               N, gate);
+            PV_LAUNCH_CHECK("dense_lp_finish_kernel");
+            sae_reduce_sum((const float*)(wsb + ws.dense_lp_loss), out->scalars, N, l1_coefficient / (float)n_global, 4, -1, stream, gate, 1u);
+        } else {
+            sae_reduce_sum(rowpart, out->scalars, rblk * cblk, l1_coefficient / (float)n_global, 4, -1, stream, gate, 1u);  // l1_loss (sae.py:617-626)
+        }
     }
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 8.0 * N * (double)D * F, 0.0);
@@ -887,7 +977,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, tc ? st->tc.target : x, (const float*)kpart, S,
                            (int64_t)N * D, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, (const float*)(wsb + ws.mu),
                            (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
-                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate);
+                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate, (ghost && tc) ? x : (const float*)nullptr);
         PV_LAUNCH_CHECK("dense_finish_kernel");
         if (split) dense_absmax(dY, (int64_t)N * D, am(AM_DY), gate, stream);
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), 1, -1,
@@ -911,6 +1001,11 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
             } else {
                 PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
             }
+            if (tc) {
+                // a transcoder's ghost term rescales by the mse of (INPUT, sae_out), not by the step's mse against the target
+                rc = tc_ghost_mse(x, err, N, D, gwb, gw, out->scalars, stream);
+                if (rc) return rc;
+            }
             const float* colmean = ghost->err_colmean;
             if (!colmean) {
                 rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
@@ -919,7 +1014,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
             }
             const float inv_cnt = 1.0f / ((float)n_global * (float)D);
             hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0, colmean,
-                               ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + 1), dg0, (float*)(gwb + gw.part), N, D,
+                               ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + (tc ? 7 : 1)), dg0, (float*)(gwb + gw.part), N, D,
                                inv_cnt);
             PV_LAUNCH_CHECK("ghost_rows_kernel");
             sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, inv_cnt, 5, -1, stream);
@@ -954,6 +1049,8 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g3.A = dY; g3.lda = D; g3.B = st->W_dec; g3.ldb = D; g3.M = N; g3.N = F; g3.K = D; g3.k_chunk = D;
         g3.out = f; g3.ldo = F; g3.colpart = colpart; g3.add = l1_coefficient / (float)n_global; g3.gate = gate;
         if (split) { g3.a_max = am(AM_DY); g3.b_max = am(AM_WDEC); g3.amax_out = am(AM_DH); }
+        g3.act = d.activation; g3.lp = d.lp_norm;
+        if (lp_on) g3.lp_tok = (const float*)(wsb + ws.dense_lp_tok);
         if (nd > 0) { g3.dead_slot = ghost->dead_slot; g3.dead_act = (float*)(gwb + gw.dhd); g3.ldd = gw.n_pad; }      // + the ghost term
         rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
         if (rc) return rc;
@@ -1068,7 +1165,9 @@ extern "C" int pv_sae_dense_step(pv_sae_plan* plan, pv_sae_state* st, const floa
     PV_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace alignment");
     unsigned char* wsb = (unsigned char*)workspace;
     if (sae_is_tc(st)) {
-        PV_REQUIRE(!ghost, "transcoder: no ghost gradients");
+        // ghost gradients on a transcoder (round 6; transcoder.py:82-86): equal widths (the ghost residual is INPUT - sae_out), one process
+        PV_REQUIRE(!ghost || (st->tc.d_in_true <= 0 && st->tc.d_out_true <= 0 && n_global == N),
+                   "transcoder + ghost gradients: d_out == d_in and the whole batch in one process");
         const int rq = sae_tc_require(d, st, N);
         if (rq) return rq;
     }
@@ -1118,7 +1217,7 @@ extern "C" int pv_sae_relu_step(pv_sae_plan* plan, pv_sae_state* st, const float
         const int rq = sae_tc_require(d, st, N);
         if (rq) return rq;
     }
-    const bool sparse = sp && pv_sae_relu_sparse_ok(d) && st->W_enc16T && st->enc_colsq;
+    const bool sparse = sp && pv_sae_relu_sparse_ok(d) && sae_plain_relu(d) && st->W_enc16T && st->enc_colsq;      // (tanh-relu / lp_norm > 1: dense)
     // PV_SAE_SPARSE_GRADS (single-process training): a step that ran sparse leaves the rows of features no token kept unwritten, as
     // pv_sae_step does; a step that ran dense marks every feature live.  Either way pv_sae_grad_sqnorm_step / pv_sae_apply follow.
     const bool sparse_grads = (flags & PV_SAE_SPARSE_GRADS) != 0;
@@ -1214,7 +1313,11 @@ extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const floa
     PV_REQUIRE(plan && st && x && ghost && out && workspace, "null argument");
     PV_REQUIRE(out->sae_out && out->scalars, "pv_sae_out: sae_out (as pv_sae_step wrote it) and scalars are required");
     PV_REQUIRE(st->W_dec && st->W_encT && st->b_enc && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
-    PV_REQUIRE(!sae_is_tc(st) && !sae_is_gated(st), "top-k ghost gradients: plain SAE only");
+    PV_REQUIRE(!sae_is_gated(st), "top-k ghost gradients: not for a gated SAE");
+    const bool tc = sae_is_tc(st);
+    // a Transcoder (round 6): x = the INPUT activation -- the ghost residual is input - sae_out (transcoder.py:82-86); equal widths, one process
+    PV_REQUIRE(!tc || (st->tc.d_in_true <= 0 && st->tc.d_out_true <= 0 && ghost->n_global <= N && !ghost->mse_global),
+               "transcoder + ghost gradients: d_out == d_in and the whole batch in one process");
     PV_REQUIRE(!plan->renorm_pending, "top-k ghost gradients need the decoder renormalised IN PLACE before the step (pv_sae_renorm_decoder), "
                                       "not deferred (PV_SAE_RENORM_DECODER)");
     const pv_sae_desc& d = plan->d;
@@ -1262,6 +1365,10 @@ extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const floa
     } else {
         PV_HIP_CHECK(hipMemsetAsync(g0, 0, (size_t)N * D * 4, stream));
     }
+    if (tc) {
+        rc = tc_ghost_mse(x, err, N, D, gwb, gw, out->scalars, stream);
+        if (rc) return rc;
+    }
     const float* colmean = ghost->err_colmean;
     if (!colmean) {
         rc = sae_colsum(err, N, D, (float*)(gwb + gw.colmean), 1.0f / (float)N, (float*)(gwb + gw.colpart), stream);
@@ -1273,7 +1380,7 @@ extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const floa
                "pv_sae_ghost.n_global > n_tokens needs err_colmean and mse_global (the global batch's)");
     const float inv_cnt = 1.0f / ((float)ng * (float)D);
     hipLaunchKernelGGL(ghost_rows_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)err, (const float*)g0, colmean,
-                       ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + 1), dg0, (float*)(gwb + gw.part), N, D, inv_cnt);
+                       ghost->mse_global ? ghost->mse_global : (const float*)(out->scalars + (tc ? 7 : 1)), dg0, (float*)(gwb + gw.part), N, D, inv_cnt);
     PV_LAUNCH_CHECK("ghost_rows_kernel");
     sae_reduce_sum((const float*)(gwb + gw.part), out->scalars, N, inv_cnt, 5, -1, stream);
     hipLaunchKernelGGL(topk_ghost_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars);
@@ -1302,7 +1409,7 @@ extern "C" int pv_sae_topk_ghost(pv_sae_plan* plan, pv_sae_state* st, const floa
         hipLaunchKernelGGL(ghost_scatter_add_vec_kernel, dim3((nd + 255) / 256), dim3(256), 0, stream, st->gb_enc, ghost->dead_idx, nd,
                            (const float*)(gwb + gw.vec_b));
         PV_LAUNCH_CHECK("ghost scatter kernels");
-        rc = sae_gbdec(d, st, dY, N, wsb, ws, stream);
+        rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream);
         if (rc) return rc;
     }
     plan->live_offs = nullptr;

@@ -24,12 +24,24 @@ import torch
 from .. import _native as N
 
 
+def norm_mode_code(mode) -> int:
+    """pv_sae_desc.normalize_layer_norm of cfg.normalize_activations (or of the bool the round 1-5 callers pass): 0 none, 1 "layer_norm"
+    (sae.py:74-90), 2 "constant_norm_rescale" (sae.py:60-72)."""
+    if mode is True or mode == "layer_norm" or mode == 1:
+        return 1
+    if mode == "constant_norm_rescale" or mode == 2:
+        return 2
+    if mode in (False, None, "none", 0):
+        return 0
+    raise ValueError(f"normalize_activations = {mode!r}")
+
+
 class NativeSAE:
     def __init__(self, W_enc: torch.Tensor, W_dec: torch.Tensor, b_enc: torch.Tensor, b_dec: torch.Tensor, k: int,
                  layer_norm: bool, max_tokens: int, ln_eps: float = 1e-5, inference: bool = False,
                  b_dec_out: Optional[torch.Tensor] = None, W_skip: Optional[torch.Tensor] = None,
                  gated: Optional[Dict[str, torch.Tensor]] = None, gated_topk: bool = False,
-                 tc_widths: Optional[Tuple[int, int]] = None):
+                 tc_widths: Optional[Tuple[int, int]] = None, activation: str = "relu", lp_norm: float = 1.0):
         """inference=True: no gradient / Adam buffers (453 MB at 768 -> 24576): only ``encode_topk`` / ``forward``.
         b_dec_out [d_in] (+ W_skip [d_in, d_in]): a Transcoder (sae/transcoder.py; pv_sae_transcoder) -- ``step`` /
         ``dense_step`` then take the target activation, ``b_dec`` only centres the encoder input.
@@ -40,7 +52,10 @@ class NativeSAE:
         tc_widths = (d_in, d_out) of a skip-less Transcoder between hook points of DIFFERENT width: every tensor given here is padded
         with zeros to D = max(d_in, d_out) (W_enc [D, d_sae], W_dec [d_sae, D], b_dec / b_dec_out [D]; pv_sae_transcoder.d_in_true /
         d_out_true); ``step`` / ``dense_step`` / ``relu_step`` take x [N, d_in] and target [N, d_out] and pad them into engine-owned
-        buffers, the padding of the parameters stays exactly zero (its gradients are)."""
+        buffers, the padding of the parameters stays exactly zero (its gradients are).
+        layer_norm: cfg.normalize_activations ("layer_norm" / "constant_norm_rescale" / "none") or a bool (layer norm on / off).
+        activation / lp_norm (the dense ReLU + L1 step only): "relu" or "tanh-relu" (sae.py:823-830), p of the sparsity term ||f_n||_p
+        (sae.py:617; 1 or p > 1) -- anything but ("relu", 1) keeps ``relu_step`` on the dense GEMMs."""
         self.transcoder = b_dec_out is not None
         self.gated = gated is not None
         self.gated_topk = bool(gated_topk) and self.gated
@@ -69,8 +84,9 @@ class NativeSAE:
             assert sorted(gated) == ["b_gate", "b_mag", "r_mag"] and all(tuple(t.shape) == (self.d_sae,) for t in gated.values())
             self._src.update(gated)
         self.params = {n: t.detach() for n, t in self._src.items()}
-        desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=int(layer_norm),
-                         max_tokens=self.max_tokens * (2 if self.gated_topk else 1), ln_eps=ln_eps)
+        desc = N.SaeDesc(d_in=self.d_in, d_sae=self.d_sae, k=self.k, normalize_layer_norm=norm_mode_code(layer_norm),
+                         max_tokens=self.max_tokens * (2 if self.gated_topk else 1), ln_eps=ln_eps,
+                         activation={"relu": 0, "topk": 0, "tanh-relu": 1}[activation], lp_norm=float(lp_norm))
         self._plan = C.c_void_p()
         N.check(self.lib.pv_sae_plan_create(C.byref(desc), C.byref(self._plan)), "pv_sae_plan_create")
         self.filtered_encoder = bool(self.lib.pv_sae_encoder_is_filtered(self._plan))
@@ -457,7 +473,7 @@ class NativeSAE:
         Follow with ``grad_sqnorm()`` (the full pass) and ``apply``."""
         x = self._check_x(x)
         n = x.shape[0]
-        assert not self.transcoder and not self.gated
+        assert not self.gated and not (self.transcoder and (self.tc_widths is not None or ghost_global is not None))
         st = self._state()
         out = N.SaeOut(sae_out=self.sae_out.data_ptr(), topk_idx=None, topk_val=None, scalars=self.scalars.data_ptr(),
                        fire_count=self.fire_count.data_ptr())

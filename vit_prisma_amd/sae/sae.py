@@ -365,7 +365,7 @@ class StandardSparseAutoencoder(SparseAutoencoder):
             return "hidden_pre [N, d_sae] is never materialised by the native encoder"
         if cfg.activation_fn_str != "topk" or not isinstance(self.activation_fn, TopK) or not isinstance(self.activation_fn.postact_fn, nn.ReLU):
             return f"activation {cfg.activation_fn_str!r} (the native encoder is the top-k one)"
-        if cfg.normalize_activations not in ("layer_norm", "none", None):
+        if cfg.normalize_activations not in ("layer_norm", "constant_norm_rescale", "none", None):
             return f"normalize_activations={cfg.normalize_activations!r}"
         if self.dtype != torch.float32 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.parameters()):
             return "parameters are not contiguous fp32 CUDA tensors"
@@ -382,7 +382,7 @@ class StandardSparseAutoencoder(SparseAutoencoder):
         stale = eng is not None and any(eng.params[n].data_ptr() != getattr(self, n).data_ptr() for n in ("W_enc", "W_dec", "b_enc", "b_dec"))
         if eng is None or stale or eng.max_tokens < n_tokens:
             eng = NativeSAE(self.W_enc, self.W_dec, self.b_enc, self.b_dec, k=self.cfg.activation_fn_kwargs["k"],
-                            layer_norm=self.cfg.normalize_activations == "layer_norm", max_tokens=max(n_tokens, 4096), inference=True)
+                            layer_norm=self.cfg.normalize_activations, max_tokens=max(n_tokens, 4096), inference=True)
             object.__setattr__(self, "_engine", eng)          # (not a submodule / parameter)
         return eng
 

@@ -203,7 +203,9 @@ class VisionSAETrainer:
         # ... and one between hook points of DIFFERENT width (no skip connection: the reference's needs d_out == d_in) on the same steps with
         # every row padded to the wider of the two (pv_sae_transcoder.d_in_true / d_out_true)
         d_out = int(getattr(cfg, "d_out", cfg.d_in))
-        is_tc = (isinstance(sae, Transcoder) and not cfg.use_ghost_grads and getattr(self, "_target", None) is not None
+        # ghost gradients on a transcoder (round 6; transcoder.py:82-86: the ghost term sees the INPUT activation): equal widths, one process
+        tc_ghost_ok = not cfg.use_ghost_grads or (d_out == int(cfg.d_in) and not self._mr and cfg.d_in % 8 == 0)
+        is_tc = (isinstance(sae, Transcoder) and tc_ghost_ok and getattr(self, "_target", None) is not None
                  and (d_out == int(cfg.d_in) or (sae._parameters.get("W_skip") is None and d_out % 8 == 0 and d_out <= 1280
                                                  and cfg.d_in % 8 == 0)))
         from .variants import GatedSparseAutoencoder
@@ -214,7 +216,7 @@ class VisionSAETrainer:
                     and (cfg.activation_fn_str == "relu"
                          or (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256)))
         common = (x.is_cuda and (isinstance(sae, StandardSparseAutoencoder) or is_tc or is_gated) and cfg.dtype == torch.float32
-                  and cfg.normalize_activations in ("layer_norm", "none", None)
+                  and cfg.normalize_activations in ("layer_norm", "constant_norm_rescale", "none", None)
                   and all(p.is_cuda and p.dtype == torch.float32 for p in sae._parameters.values() if p is not None)   # (not .parameters(): no sync of lazily kept layouts)
                   and cfg.d_in % 4 == 0 and cfg.d_in <= 1280 and cfg.d_sae % 4 == 0 and cfg.d_sae <= 65536
                   and self._native_pref is not False)
@@ -224,9 +226,12 @@ class VisionSAETrainer:
             return "gated"
         if (cfg.activation_fn_str == "topk" and 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256
                 # ghost gradients on top-k (pv_sae_topk_ghost): plain SAE, d_in a multiple of 8
-                and (not cfg.use_ghost_grads or (not is_tc and cfg.d_in % 8 == 0))):
+                and (not cfg.use_ghost_grads or cfg.d_in % 8 == 0)):
             return "topk"
-        if cfg.activation_fn_str == "relu" and getattr(sae, "lp_norm", 1) == 1 and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0:
+        # ReLU + L1; since round 6 also "tanh-relu" (sae.py:823-830) and lp_norm > 1 in the sparsity term (sae.py:617) -- both on the dense
+        # GEMMs' epilogues (the sparse form of the step serves the plain one)
+        if (cfg.activation_fn_str in ("relu", "tanh-relu") and float(getattr(sae, "lp_norm", 1)) >= 1.0
+                and cfg.d_in % 8 == 0 and cfg.d_sae % 8 == 0):
             return "relu"
         return None
 
@@ -245,11 +250,15 @@ class VisionSAETrainer:
             why.append(f"d_sae = {cfg.d_sae} (supported: multiples of 4 up to 65536)")
         if cfg.activation_fn_str == "topk" and not 1 <= cfg.activation_fn_kwargs.get("k", 0) <= 256:
             why.append(f"k = {cfg.activation_fn_kwargs.get('k')} (supported: 1..256)")
-        if cfg.activation_fn_str not in ("topk", "relu"):
+        if getattr(cfg, "is_transcoder", False) and cfg.use_ghost_grads and (self._mr or int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in)):
+            why.append("ghost gradients on a transcoder with tokens sharded over ranks / d_out != d_in")
+        if cfg.activation_fn_str not in ("topk", "relu", "tanh-relu"):
             why.append(f"activation {cfg.activation_fn_str!r}")
+        if float(getattr(sae, "lp_norm", 1)) < 1.0:
+            why.append(f"lp_norm = {sae.lp_norm} (p < 1 has no finite gradient at zero activations: supported p >= 1)")
         if getattr(cfg, "is_transcoder", False) and int(getattr(cfg, "d_out", cfg.d_in)) != int(cfg.d_in):
             why.append("a transcoder with d_out != d_in and the skip connection / widths that are not multiples of 8 / d_out > 1280")
-        if cfg.normalize_activations not in ("layer_norm", "none", None):
+        if cfg.normalize_activations not in ("layer_norm", "constant_norm_rescale", "none", None):
             why.append(f"normalize_activations = {cfg.normalize_activations!r}")
         return "; ".join(why) or "a parameter is not a contiguous fp32 CUDA tensor"
 
@@ -293,11 +302,13 @@ class VisionSAETrainer:
                 tcw = (d_i, d_o)
             eng = NativeSAE(P_["W_enc"], P_["W_dec"], P_["b_enc"], P_["b_dec"],
                             k=sae.cfg.activation_fn_kwargs.get("k", 1),        # (the dense ReLU + L1 step has no k)
-                            layer_norm=sae.cfg.normalize_activations == "layer_norm",
+                            layer_norm=sae.cfg.normalize_activations,
                             max_tokens=max(n_tokens, self.cfg.train_batch_size // self.world),
                             **{n: P_[n] for n in tc_names}, **({"tc_widths": tcw} if tcw else {}),
                             **({"gated": {n: P_[n] for n in ("b_gate", "r_mag", "b_mag")},
-                                "gated_topk": sae.cfg.activation_fn_str == "topk"} if "b_gate" in P_ else {}))
+                                "gated_topk": sae.cfg.activation_fn_str == "topk"} if "b_gate" in P_ else
+                               {"activation": sae.cfg.activation_fn_str,
+                                "lp_norm": float(getattr(sae, "lp_norm", 1)) if sae.cfg.activation_fn_str != "topk" else 1.0}))
             if old is not None and old.n_flat == eng.n_flat:             # keep the optimizer state across a re-bind
                 eng.flat_m.copy_(old.flat_m)
                 eng.flat_v.copy_(old.flat_v)
@@ -415,13 +426,14 @@ class VisionSAETrainer:
         # statistics tensors are the caller's: the kernels update them in place
         eng.act_freq_scores = act_freq_scores
         eng.n_fwd_since_fired = n_since_fired
-        ghost = bool(sae.cfg.use_ghost_grads) and sae.training and not eng.transcoder
+        ghost = bool(sae.cfg.use_ghost_grads) and sae.training
         if not self._mr and ghost:
             # top-k + ghost gradients (sae.py:151-179; the mask of train_sae.py:330-332 is taken BEFORE this step's statistics): the
             # k-sparse step with complete gradient buffers over a decoder renormalised in place, then the ghost term's additions
             dead = n_since_fired > sae.cfg.dead_feature_window
             eng.renorm_decoder()
-            eng.step(x, update_stats=True, renorm_decoder=False, sparse_grads=False, want_out=True)
+            eng.step(x, update_stats=True, renorm_decoder=False, sparse_grads=False, want_out=True,
+                     target=self._target if eng.transcoder else None)
             eng.topk_ghost(x, dead)
             eng.grad_sqnorm()
             eng.apply(lr, self.cfg.max_grad_norm)
@@ -520,7 +532,7 @@ class VisionSAETrainer:
     def _make_shard_engine(self, sae, max_tokens: int):
         """Engine over one rank's feature shard (tests substitute the CPU twin)."""
         from .native_sae import NativeSAE
-        k, ln = sae.cfg.activation_fn_kwargs["k"], sae.cfg.normalize_activations == "layer_norm"
+        k, ln = sae.cfg.activation_fn_kwargs["k"], sae.cfg.normalize_activations
         return lambda We, Wd, be, bd: NativeSAE(We, Wd, be, bd, k=k, layer_norm=ln, max_tokens=max_tokens)
 
     def _native_tp_step(self, sae, optimizer, scheduler, x, lr, act_freq_scores, n_since_fired):
