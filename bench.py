@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sae", action="store_true")
     ap.add_argument("--no-l14", action="store_true", help="skip the L/14@336 pattern-only leg")
+    ap.add_argument("--l14-batch", type=int, default=128, help="images per GPU of the L/14@336 leg (128 = BASELINE config 5; a rehearsal of "
+                                                                 "many ranks on ONE GPU passes less: 32.7 GB of pattern taps per rank at 128)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allow-overrides", action="store_true", help="A/B runs only: measure with PV_* env / tuning overrides (recorded)")
     ap.add_argument("--sae-parallel", default="feature", choices=["data", "feature"],
@@ -568,7 +570,7 @@ def main():
                 sae["cpu_baseline"]["numpy_oracle"] = sae_cpu_baseline(6.0)
     if not a.no_l14:
         torch.cuda.empty_cache()
-        l14 = leg("l14_336_pattern", lambda: l14_pattern_leg(dev, dist))
+        l14 = leg("l14_336_pattern", lambda: l14_pattern_leg(dev, dist, batch=a.l14_batch))
         if rank == 0:
             line["l14_336_pattern"] = l14
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -588,6 +590,26 @@ def main():
                 out.extend(leg_errors(v, f"{path}.{k}" if path else k))
         return out
 
+    # the headline numbers of the secondary legs once more, short and LAST (a consumer that keeps only the head or only the tail of this
+    # long line still sees them: round 5's driver record lost the step-only SAE number inside the end-to-end leg's text)
+    def pick(obj, *path):
+        for k in path:
+            obj = obj.get(k) if isinstance(obj, dict) else None
+        return obj
+
+    sae_obj = line.get("sae")
+    if isinstance(sae_obj, dict):
+        summary = {
+            "sae_step_only_tokens_per_s": pick(sae_obj, "value"), "sae_step_only_ms": pick(sae_obj, "ms_per_step"),
+            "sae_step_roofline_frac": pick(sae_obj, "roofline", "frac"), "sae_step_hbm_GB": pick(sae_obj, "roofline", "traffic"),
+            "sae_end_to_end_tokens_per_s": pick(sae_obj, "end_to_end", "value"),
+            "sae_relu_l1_published_l0_ms": pick(sae_obj, "relu_l1", "published_l0", "ms_per_step"),
+            "sae_relu_l1_sparse_ms": pick(sae_obj, "relu_l1", "ms_per_step"),
+            "sae_gated_relu_ms": pick(sae_obj, "variants", "gated_relu", "ms_per_step"),
+            "sae_weak_scaling_tokens_per_s": pick(sae_obj, "weak_scaling_data_parallel", "value"),
+            "l14_336_images_per_s": pick(line, "l14_336_pattern", "value"),
+        }
+        line["summary"] = {k: v for k, v in summary.items() if v is not None}
     errs = leg_errors(line)
     line["ok"] = not errs                          # a failed secondary leg is recorded and flagged here (the main line stays valid)
     if errs:

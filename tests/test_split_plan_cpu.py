@@ -369,8 +369,14 @@ def test_flag_gated_points_are_derived_from_the_plan(flags):
                 for k_ in w_cache.keys():
                     a, b = g_cache[k_], w_cache[k_]
                     assert a.shape == b.shape and a.dtype == b.dtype and torch.allclose(a, b, atol=1e-5), (k_, kw)
-    # a hook ON a flag-gated point (or on ln1 under per-head block inputs) changes that block's forward: the block runs on its own
-    # module, the blocks around it stay on the plan
+    # a hook ON a flag-gated point (or on ln1 under per-head block inputs) changes that block's forward.  Round 6: the block stays on
+    # the plan all the same -- attn.hook_result / hook_mlp_in are served at the block's positions 6 / 7, hooks on the per-head inputs
+    # run only the block's head (inputs, ln1, q / k / v projections) on the module's code and enter the plan at PV_STAGE_QKV.  No block
+    # may be sent to its PyTorch module here:
+    def no_torch_block(*a, **k):
+        raise AssertionError("a block hooked on a flag-gated point was sent to its PyTorch module")
+
+    model._torch_block_stage = no_torch_block
     def head_edit(t, hook):
         t = t.clone()
         t[:, :, 1] = t[:, :, 1] * 0.5
@@ -405,6 +411,12 @@ def test_flag_gated_points_are_derived_from_the_plan(flags):
                 finally:
                     model._native_reason = real_reason
                 assert model.last_run_native, hooks
+                # every block's MLP output stage (9 -> the block's end) ran on the backend: no block left the plan
+                n_run = model.cfg.n_layers if kw.get("stop_at_layer") is None else len(range(model.cfg.n_layers)[:kw["stop_at_layer"]])
+                done = set()
+                for fb, es, nb, xs, _ in model._backend.calls:
+                    done.update(range(fb, nb))                     # (a segment that exits inside block nb does not finish it)
+                assert done >= set(range(n_run)), (hooks, kw, model._backend.calls)
                 assert list(g_cache.keys()) == list(w_cache.keys()), (hooks, kw)
                 assert torch.allclose(g_out, w_out, atol=1e-5), (hooks, kw)
                 for k_ in w_cache.keys():

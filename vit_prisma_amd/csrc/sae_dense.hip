@@ -39,7 +39,8 @@ constexpr int DG_TILE = DG_BM * DG_ROWB;      // 18432 >= 32 * 528
 constexpr int DG_CS_LD = 68;                  // fp32 staging row of the epilogue (floats)
 constexpr int DG_LDS = 4 * DG_TILE;           // As[2] + Bs[2] = 73728 >= 4 waves x 64 x 68 x 4
 
-enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3, DG_EPI_GENC = 4, DG_EPI_EXPB = 5 };   // EXPB: out = exp(acc + bias)
+enum { DG_EPI_STORE = 0, DG_EPI_ENC = 1, DG_EPI_DH = 2, DG_EPI_MUL = 3, DG_EPI_GENC = 4, DG_EPI_EXPB = 5,      // EXPB: out = exp(acc + bias)
+       DG_EPI_ENC_T = 6, DG_EPI_DH_T = 7 };   // ENC / DH with the tail of SURVEY.md 8(f) row 3 compiled in: tanh-relu, lp_norm > 1 (DenseGemm.act / lp)
 
 struct DenseGemm {
     const float* A; int64_t lda;              // A_KM ? [K][lda] (M contiguous) : [M][lda] (K contiguous)
@@ -92,9 +93,9 @@ __device__ __forceinline__ uint4 ld16_or_zero(const float* ptr, bool ok) {
 
 // ---- the split-fp16 K loop (round 6) ------------------------------------------------------------------------------------------
 // The fp32 matrix instruction runs at 1/16 of the fp16 one.  An fp32 value x scaled by a power of two s splits EXACTLY into
-// s x = hi + lo + r with hi = fp16(s x), lo = fp16(s x - hi) and |r| <= 2^-23 |s x| (both conversions round to nearest:
-// v_cvt_pk_f16_f32, one instruction per pair), so a . b = (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) up to 2^-22 relative per
-// product (the dropped a_lo b_lo term): three fp16 products with fp32 accumulation instead of one fp32 product -- the same tiles and epilogues at 16 / 3 of the
+// s x = hi + lo + r with hi = fp16(s x), lo = fp16(s x - hi) and |r| <= 2^-20 |s x| (both conversions round toward zero:
+// v_cvt_pkrtz_f16_f32, one instruction per pair), so a . b = (a_hi b_hi + a_hi b_lo + a_lo b_hi) / (s_a s_b) up to 2^-19 relative per
+// product: three fp16 products with fp32 accumulation instead of one fp32 product -- the same tiles and epilogues at 16 / 3 of the
 // matrix rate.  s = 2^(13 - floor(log2 max|.|)) per TENSOR (DenseGemm.a_max / b_max: the producers track the maxima), so the largest
 // entry lands in [2^13, 2^14) and every entry within 2^-14 of it keeps 21+ bits (smaller ones lose relative, not absolute,
 // accuracy: their lo part goes denormal at 2^-24 of the scaled range).  Conversion happens in the staging pass the fp32 kernel has
@@ -115,22 +116,36 @@ __device__ __forceinline__ void dg_scale_of(uint32_t max_bits, float& s, float& 
 }
 
 // hi / lo halves of four scaled floats, packed as (k0 k1), (k2 k3)
-// (round to nearest even both times: gfx950's v_cvt_pk_f16_f32, one instruction per pair like the round-toward-zero v_cvt_pkrtz of
-// older parts -- |r| <= 2^-23 |s x| instead of 2^-20, and unbiased: measured on the gated step, the RTZ form opened 9 "other" gates
-// per 8 M where the fp32 kernels open <= 4)
+// (both conversions round toward zero, v_cvt_pkrtz_f16_f32: one full-rate instruction per pair.  The round-to-nearest pair
+// conversion of gfx950, v_cvt_pk_f16_f32 (-DPV_SPLIT_RNE), is 8 x more accurate per element and was measured 2.1 ms per step slower
+// -- 6.02 against 3.90 ms for the ReLU + L1 step, profiles/r06_dense_split_fp16_ab.txt -- while the product's error is already below
+// that of an fp32 accumulation either way: a numpy emulation over K = 768 gives 3.4e-7 of the largest entry for this form, 6e-8 for
+// round-to-nearest, 6.2e-7 for numpy's own fp32 matmul.)
 __device__ __forceinline__ void dg_split4(float x0, float x1, float x2, float x3, float s, uint2& hi, uint2& lo) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 a = {x0 * s, x1 * s}, b = {x2 * s, x3 * s};
+#ifndef PV_SPLIT_RNE
+    typedef __fp16 hz2 __attribute__((ext_vector_type(2)));
+    const hz2 z01 = __builtin_amdgcn_cvt_pkrtz(a[0], a[1]), z23 = __builtin_amdgcn_cvt_pkrtz(b[0], b[1]);
+    const hz2 y01 = __builtin_amdgcn_cvt_pkrtz(a[0] - (float)z01[0], a[1] - (float)z01[1]);
+    const hz2 y23 = __builtin_amdgcn_cvt_pkrtz(b[0] - (float)z23[0], b[1] - (float)z23[1]);
+    const h2 h01 = __builtin_bit_cast(h2, z01), h23 = __builtin_bit_cast(h2, z23), l01 = __builtin_bit_cast(h2, y01), l23 = __builtin_bit_cast(h2, y23);
+#else
     const h2 h01 = __builtin_convertvector(a, h2), h23 = __builtin_convertvector(b, h2);
     const h2 l01 = __builtin_convertvector(a - __builtin_convertvector(h01, f2), h2);
     const h2 l23 = __builtin_convertvector(b - __builtin_convertvector(h23, f2), h2);
+#endif
     hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
     lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
 }
 
-template <bool A_KM, bool B_KN, int EPI, bool SPLIT = false>
+template <bool A_KM, bool B_KN, int EPI_, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
+    // (the tail variants are their own instantiations: tanhf / powf inlined into the plain ENC / DH epilogues cost the split-fp16 step
+    // 2.2 ms of 3.8 although never executed there)
+    constexpr bool TAIL = EPI_ == DG_EPI_ENC_T || EPI_ == DG_EPI_DH_T;
+    constexpr int EPI = EPI_ == DG_EPI_ENC_T ? DG_EPI_ENC : (EPI_ == DG_EPI_DH_T ? DG_EPI_DH : EPI_);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (p.gate && *p.gate != 1u) return;                   // (uniform over the grid)
     unsigned char* As = smem;
@@ -423,16 +438,22 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     v[i] = fmaxf(v[i] + b8[i], 0.f);                   // hidden_pre + b_enc -> ReLU (sae.py:567-577)
-                    if (p.act == PV_SAE_ACT_TANH_RELU) v[i] = tanhf(v[i]);      // "tanh-relu" (sae.py:823-830)
+                    if constexpr (TAIL) {
+                        if (p.act == PV_SAE_ACT_TANH_RELU) v[i] = tanhf(v[i]);      // "tanh-relu" (sae.py:823-830)
+                    }
                     csum[i] += v[i] > 0.f ? 1.f : 0.f;                // firing counts (train_sae.py:356-364)
                     rsum += v[i];                                     // ||f||_1 (sae.py:617)
-                    if (p.lp_part) psum += v[i] > 0.f ? powf(v[i], p.lp) : 0.f;
+                    if constexpr (TAIL) {
+                        if (p.lp_part) psum += v[i] > 0.f ? powf(v[i], p.lp) : 0.f;
+                    }
                 }
-                if (p.lp_part) {                                       // sum of f^p over this row's 64 columns (the 8 lanes that share the row)
-                    psum += __shfl_xor(psum, 1, 64);
-                    psum += __shfl_xor(psum, 2, 64);
-                    psum += __shfl_xor(psum, 4, 64);
-                    if ((lane & 7) == 0) p.lp_part[(int64_t)gm * ((p.N + 63) / 64) + tile_n * 2 + wn] = psum;
+                if constexpr (TAIL) {
+                    if (p.lp_part) {                                   // sum of f^p over this row's 64 columns (the 8 lanes that share the row)
+                        psum += __shfl_xor(psum, 1, 64);
+                        psum += __shfl_xor(psum, 2, 64);
+                        psum += __shfl_xor(psum, 4, 64);
+                        if ((lane & 7) == 0) p.lp_part[(int64_t)gm * ((p.N + 63) / 64) + tile_n * 2 + wn] = psum;
+                    }
                 }
             } else if constexpr (EPI == DG_EPI_GENC) {
                 float g8[8];
@@ -454,13 +475,17 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
             } else if constexpr (EPI == DG_EPI_DH) {
                 float f8[8];
                 load8(o, f8);                                          // the stored activation: the ReLU gate of the backward
-                const float lpt = p.lp_tok ? p.lp_tok[gm] : 0.f;
+                float lpt = 0.f;
+                if constexpr (TAIL) lpt = p.lp_tok ? p.lp_tok[gm] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    // d loss / d hidden_pre = (dF + l1 / N) [f > 0]; lp > 1: the sparsity term's l1 / N ||f_n||_p^(1 - p) f^(p - 1)
-                    // instead of the constant; tanh-relu: x d tanh = 1 - f^2
-                    float g = v[i] + (p.lp_tok ? lpt * powf(f8[i], p.lp - 1.f) : p.add);
-                    if (p.act == PV_SAE_ACT_TANH_RELU) g *= 1.f - f8[i] * f8[i];
+                    // d loss / d hidden_pre = (dF + l1 / N) [f > 0]; TAIL, lp > 1: the sparsity term's l1 / N ||f_n||_p^(1 - p) f^(p - 1)
+                    // instead of the constant; TAIL, tanh-relu: x d tanh = 1 - f^2
+                    float g = v[i] + p.add;
+                    if constexpr (TAIL) {
+                        if (p.lp_tok) g = v[i] + lpt * powf(f8[i], p.lp - 1.f);
+                        if (p.act == PV_SAE_ACT_TANH_RELU) g *= 1.f - f8[i] * f8[i];
+                    }
                     v[i] = f8[i] > 0.f ? g : 0.f;
                     if (p.dead_slot && dslot[i] >= 0) v[i] += p.dead_act[(int64_t)gm * p.ldd + dslot[i]];    // + the ghost term (not gated)
                     csum[i] += v[i];                                  // gb_enc
@@ -534,7 +559,7 @@ int launch_dense_gemm_form(const DenseGemm& p, int splits, hipStream_t stream) {
 // the split-fp16 form when the launch carries both operand maxima (and the tuning key dense_fp32 is off), else the exact fp32 form
 template <bool A_KM, bool B_KN, int EPI>
 int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
-    if constexpr (EPI == DG_EPI_STORE || EPI == DG_EPI_ENC || EPI == DG_EPI_DH || EPI == DG_EPI_GENC) {
+    if constexpr (EPI == DG_EPI_STORE || EPI == DG_EPI_ENC || EPI == DG_EPI_DH || EPI == DG_EPI_GENC || EPI == DG_EPI_ENC_T || EPI == DG_EPI_DH_T) {
         if (p.a_max && p.b_max && !g_pv_tuning.dense_fp32) return launch_dense_gemm_form<A_KM, B_KN, EPI, true>(p, splits, stream);
     }
     return launch_dense_gemm_form<A_KM, B_KN, EPI, false>(p, splits, stream);
@@ -943,7 +968,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
             PV_HIP_CHECK(hipMemsetAsync(gwb + gw.dead_act, 0, (size_t)N * gw.n_pad * 4, stream));       // (padding columns stay zero)
             g.dead_slot = ghost->dead_slot; g.dead_act = (float*)(gwb + gw.dead_act); g.ldd = gw.n_pad;
         }
-        rc = launch_dense_gemm<false, false, DG_EPI_ENC>(g, 1, stream);
+        rc = sae_plain_relu(d) ? launch_dense_gemm<false, false, DG_EPI_ENC>(g, 1, stream) : launch_dense_gemm<false, false, DG_EPI_ENC_T>(g, 1, stream);
         if (rc) return rc;
         // firing counts, statistics, l0, l1
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F,
@@ -1052,7 +1077,7 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         g3.act = d.activation; g3.lp = d.lp_norm;
         if (lp_on) g3.lp_tok = (const float*)(wsb + ws.dense_lp_tok);
         if (nd > 0) { g3.dead_slot = ghost->dead_slot; g3.dead_act = (float*)(gwb + gw.dhd); g3.ldd = gw.n_pad; }      // + the ghost term
-        rc = launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream);
+        rc = sae_plain_relu(d) ? launch_dense_gemm<false, false, DG_EPI_DH>(g3, 1, stream) : launch_dense_gemm<false, false, DG_EPI_DH_T>(g3, 1, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dense_colreduce_kernel, dim3(nb_f), dim3(256), 0, stream, (const float*)colpart, rblk, F, st->gb_enc,
                            (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, gate);

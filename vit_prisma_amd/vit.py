@@ -492,6 +492,14 @@ class HookedViT(HookedRootModule):
     # inputs carry a head dimension, a module spliced on one of its LayerNorm points or on block 0's entry.  Every HookPoint of such a
     # block fires inside its module's forward; the blocks around it stay on the HIP plan.
     _TORCH_POS = -2
+    # round 6: hooks ON flag-gated points no longer send the block to PyTorch.  attn.hook_result and hook_mlp_in are kinds of their own
+    # at the block's positions 6 / 7 ("result": z against W_O per head in one einsum, the hook, the head sum folded back -- attention.py:
+    # 155-183; "mlpin": the hook on a copy of resid_mid, ln2 of what it returns as the module computes it -- transformer_block.py:125-129);
+    # hooks on the per-head block inputs (hook_attn_in, hook_q_input / k / v, or ln1 while the inputs carry a head dimension) put the
+    # block under _HEAD_POS: ITS head -- per-head inputs, per-head ln1, per-head q / k / v projections -- runs on the module's own code
+    # (_head_glue: that is where those HookPoints live), everything behind q / k / v (attention core, O-projection, LayerNorm 2, the
+    # MLP: 3/4 of the block's FLOP) stays on the HIP plan, entered at PV_STAGE_QKV.
+    _HEAD_POS = -3
     _FLAG_RE = re.compile(r"blocks\.(\d+)\.(hook_attn_in|hook_q_input|hook_k_input|hook_v_input|attn\.hook_result|hook_mlp_in)$")
     _EMBED_NAMES = ("hook_embed", "hook_pos_embed", "hook_full_embed", "ln_pre.hook_scale", "ln_pre.hook_normalized", "hook_ln_pre")
     _FINAL_NAMES = ("ln_final.hook_scale", "ln_final.hook_normalized", "hook_ln_final", "hook_post_head_pre_normalize")
@@ -582,13 +590,19 @@ class HookedViT(HookedRootModule):
                 flag = {"hook_attn_in": "use_attn_in", "attn.hook_result": "use_attn_result", "hook_mlp_in": "use_hook_mlp_in"}.get(
                     f.group(2), "use_split_qkv_input")
                 if getattr(self.cfg, flag):                       # (with its flag off the point is never called: the hook cannot fire)
-                    out.setdefault(self._TORCH_POS, {})[int(f.group(1))] = True
+                    l_ = int(f.group(1))
+                    if f.group(2) == "attn.hook_result":
+                        out.setdefault(self._NPOS * l_ + 6, {})["result"] = hp
+                    elif f.group(2) == "hook_mlp_in":
+                        out.setdefault(self._NPOS * l_ + 7, {})["mlpin"] = hp
+                    else:
+                        out.setdefault(self._HEAD_POS, {})[l_] = True
                 continue
             kind, off = self._KIND_POS[m.group(2)]
             if kind.startswith("ln") and self.cfg.normalization_type not in ("LN", "LNPre"):
                 return None
             if kind.startswith("ln1") and (self.cfg.use_attn_in or self.cfg.use_split_qkv_input):
-                out.setdefault(self._TORCH_POS, {})[int(m.group(1))] = True     # (ln1's HookPoints carry a head dimension there)
+                out.setdefault(self._HEAD_POS, {})[int(m.group(1))] = True      # (ln1's HookPoints carry a head dimension there: _head_glue)
                 continue
             pos = self._NPOS * int(m.group(1)) + off
             if pos == 0:
@@ -758,11 +772,17 @@ class HookedViT(HookedRootModule):
         run_head = stop_at_layer is None
         n_blocks = cfg.n_layers if run_head else resolve_n_blocks(cfg.n_layers, stop_at_layer)
         names = [n for n in hook_order(cfg, n_blocks, run_head) if keep(n)]
-        on_plan = [n for n in names if self._FLAG_RE.fullmatch(n) is None]      # (flag-gated points exist in torch blocks only)
         bh = dict(self._boundary_hooks() or {})
+        # (flag-gated points are no taps of the plan: a HOOKED attn.hook_result / hook_mlp_in is produced -- and recorded -- where its
+        # hook is served, the per-head block inputs by _head_glue; the unhooked ones are derived by the caller)
+        served = {f"blocks.{q // self._NPOS}." + ("attn.hook_result" if k_ == "result" else "hook_mlp_in")
+                  for q, kinds in bh.items() if q >= 0 for k_ in kinds if k_ in ("result", "mlpin")}
+        on_plan = [n for n in names if self._FLAG_RE.fullmatch(n) is None or n in served]
         embed_hooked = bh.pop(self._EMBED_POS, None) is not None
         final_hooked = (bh.pop(self._FINAL_POS, None) is not None) and run_head
-        tblocks = sorted(l for l in (bh.pop(self._TORCH_POS, None) or {}) if l < n_blocks)
+        hblocks = set(l for l in (bh.pop(self._HEAD_POS, None) or {}) if l < n_blocks)
+        tblocks = sorted(set(l for l in (bh.pop(self._TORCH_POS, None) or {}) if l < n_blocks) | hblocks)
+        hblocks -= set(l for l in (self._boundary_hooks() or {}).get(self._TORCH_POS, {}))      # (a block that needs its module anyway)
         if not embed_hooked and not final_hooked and not tblocks:
             return self._run_native_segments(x, None, on_plan, n_blocks, run_head, bh, device, remove_batch_dim)
         # hooks on the embedding / final stage, blocks that need their own module: those on PyTorch (their hooks fire as usual),
@@ -778,7 +798,7 @@ class HookedViT(HookedRootModule):
                  and not (embed_hooked and (n in self._EMBED_NAMES or n == "blocks.0.hook_resid_pre"))]
         head_on_plan = run_head and not final_hooked
         if tblocks:
-            out = self._run_blocks_mixed(x, start, inner, n_blocks, head_on_plan, bh, tblocks, cache, wanted)
+            out = self._run_blocks_mixed(x, start, inner, n_blocks, head_on_plan, bh, tblocks, cache, wanted, hblocks)
         elif n_blocks > 0 or head_on_plan or start is None:
             out, c = self._run_native_segments(x, start, inner, n_blocks, head_on_plan, bh, None, False)
             cache.update(c)
@@ -797,12 +817,14 @@ class HookedViT(HookedRootModule):
             ordered[n] = t[0] if remove_batch_dim else t
         return out, ordered
 
-    def _run_blocks_mixed(self, x, start, names, n_blocks: int, run_head: bool, bh, tblocks, cache, wanted):
+    def _run_blocks_mixed(self, x, start, names, n_blocks: int, run_head: bool, bh, tblocks, cache, wanted, hblocks=frozenset()):
         """Blocks 0 .. n_blocks - 1 (+ the head) where the blocks of `tblocks` run on their own PyTorch module (every HookPoint of
         such a block fires inside it: transformer_block.py:80-138) and the runs of blocks between them on the HIP plan, resumed from
-        / stopped at the residual stream.  Fills `cache`, returns the output."""
+        / stopped at the residual stream.  Blocks of `hblocks` (a subset: hooks on their per-head inputs) run only their HEAD on the
+        module's code (_head_glue); the plan is entered behind their q, k, v.  Fills `cache`, returns the output."""
         NP = self._NPOS
         resid, b = start, 0
+        entry, acts = 0, ()                                      # the next plan run enters block b at this stage with these activations
         for L in list(tblocks) + [None]:
             stop = n_blocks if L is None else L
             head_here = L is None and run_head
@@ -811,13 +833,13 @@ class HookedViT(HookedRootModule):
                 # (the next block's hook_resid_pre fires inside that block's module); at its start hook_resid_pre of block b by hand
                 sub = {}
                 for q, kinds in bh.items():
-                    if NP * b < q < NP * stop:
+                    if NP * b + entry < q < NP * stop:           # (entry > 0: what lies before fired inside _head_glue)
                         sub[q] = kinds
                     elif q == NP * stop and stop > b:
                         k_ = kinds if L is None else {k: v for k, v in kinds.items() if k in ("mlp", "post")}
                         if k_:
                             sub[q] = k_
-                if resid is not None and b > 0 and stop > b:
+                if resid is not None and b > 0 and stop > b and not entry:
                     pre = bh.get(NP * b, {}).get("pre")
                     if pre is not None:
                         resid = pre(resid)
@@ -829,16 +851,80 @@ class HookedViT(HookedRootModule):
                         return b <= int(n.split(".", 2)[1]) < stop
                     return (n in self._FINAL_NAMES and head_here) or (n not in self._FINAL_NAMES and b == 0 and resid is None)
 
-                seg_names = [n for n in names if mine(n) and not (resid is not None and n == f"blocks.{b}.hook_resid_pre")]
+                seg_names = [n for n in names if mine(n) and not (resid is not None and n == f"blocks.{b}.hook_resid_pre")
+                             and not (entry and n.startswith(f"blocks.{b}.") and self._stage_of(n) < NP * b + entry)]
                 resid, c = self._run_native_segments(x, resid, seg_names, stop, head_here, sub, None, False,
-                                                     first_block=b)
+                                                     first_block=b, entry_stage=entry, entry_acts=acts)
                 cache.update(c)
+                entry, acts = 0, ()
             if L is None:
                 break
+            if L in hblocks:
+                # the block's head on its own code (hooks on the per-head inputs / per-head ln1 fire there), the rest on the plan
+                resid, acts, rec = self._head_glue(L, resid, wanted)
+                cache.update(rec)
+                b, entry = L, 2                                  # PV_STAGE_QKV: q, k, v given, resid = the stream they add to
+                continue
             resid, rec = self._torch_block_stage(L, resid, wanted)
             cache.update(rec)
             b = L + 1
         return resid
+
+    def _head_glue(self, l: int, resid: torch.Tensor, wanted):
+        """Block l up to its q, k, v on the module's own code (transformer_block.py:80-109, attention.py:186-244): hook_resid_pre, the
+        per-head inputs with their flag-gated HookPoints, ln1 per input, the per-head projections with hook_q / hook_k / hook_v.
+        -> (resid_pre, (q, k, v), {name: cached tensor}); the plan resumes at PV_STAGE_QKV."""
+        cfg, blk = self.cfg, self.blocks[l]
+        rec: Dict[str, torch.Tensor] = {}
+        pre = f"blocks.{l}."
+        which = [pre + r for r in ("hook_resid_pre", "hook_attn_in", "hook_q_input", "hook_k_input", "hook_v_input", "ln1.hook_scale",
+                                   "ln1.hook_normalized", "attn.hook_q", "attn.hook_k", "attn.hook_v")]
+        handles = self._recording_hooks(which, wanted, rec)
+        try:
+            resid_pre = blk.hook_resid_pre(resid)
+            attn_in = resid_pre
+            if cfg.use_attn_in or cfg.use_split_qkv_input:
+                attn_in = resid_pre.unsqueeze(2).expand(-1, -1, cfg.n_heads, -1)
+            if cfg.use_attn_in:
+                attn_in = blk.hook_attn_in(attn_in.clone())
+            if cfg.use_split_qkv_input:
+                q_in, k_in, v_in = blk.hook_q_input(attn_in.clone()), blk.hook_k_input(attn_in.clone()), blk.hook_v_input(attn_in.clone())
+            else:
+                q_in = k_in = v_in = attn_in
+            q, k, v = blk.attn.calculate_qkv_matrices(blk.ln1(q_in), blk.ln1(k_in), blk.ln1(v_in))
+        finally:
+            for h in handles:
+                h.remove()
+        return resid_pre.contiguous(), (q.contiguous(), k.contiguous(), v.contiguous()), rec
+
+    def _stage_of(self, name: str) -> int:
+        """The stage (position scale: _NPOS per block) that produces a HookPoint's tensor; -1: embedding stage, _NPOS * n_layers: final."""
+        NP = self._NPOS
+        if name.startswith("blocks."):
+            _, l, rest = name.split(".", 2)
+            if rest == "hook_resid_pre" or rest.startswith("ln1.") or rest in ("hook_attn_in", "hook_q_input", "hook_k_input", "hook_v_input"):
+                st = 0
+            elif rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
+                st = 1
+            elif rest == "attn.hook_attn_scores":
+                st = 2
+            elif rest == "attn.hook_pattern":
+                st = 3
+            elif rest == "attn.hook_z":
+                st = 4
+            elif rest in ("hook_attn_out", "hook_resid_mid", "attn.hook_result"):
+                st = 5
+            elif rest.startswith("ln2.") or rest == "hook_mlp_in":
+                st = 6
+            elif rest == "mlp.hook_pre":
+                st = 7
+            elif rest.startswith("mlp."):
+                st = 8
+            else:
+                st = 9
+            return NP * int(l) + st
+        return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
+            else NP * self.cfg.n_layers
 
     def _torch_block_stage(self, l: int, resid: torch.Tensor, wanted):
         """Block l on its own module (transformer_block.py:80-138): (its output, {name: cached tensor} of its HookPoints)."""
@@ -907,16 +993,17 @@ class HookedViT(HookedRootModule):
         return x, rec
 
     def _run_native_segments(self, x: torch.Tensor, start_resid: Optional[torch.Tensor], names, n_blocks: int, run_head: bool, bh,
-                             device, remove_batch_dim: bool, first_block: int = 0):
+                             device, remove_batch_dim: bool, first_block: int = 0, entry_stage: int = 0, entry_acts=()):
         """The blocks (+ the head) on the HIP plan, split at the hooked positions of `bh`; start_resid: resume at block
-        `first_block` from this residual stream instead of starting from the pixels (what lies before ran elsewhere)."""
+        `first_block` from this residual stream instead of starting from the pixels (what lies before ran elsewhere); entry_stage /
+        entry_acts: ... at that position INSIDE block first_block with the stage's activations (2 = q, k, v given: _head_glue)."""
         cfg = self.cfg
         nv = self._get_native(x.device)
         NP = self._NPOS
         end_pos = NP * n_blocks
         # a hook at the very end fires only if its point is produced: "pre" of block n_blocks is not
         bounds = sorted(q for q in bh if q < end_pos or (q == end_pos and ("post" in bh[q] or "mlp" in bh[q])))
-        if not bounds:
+        if not bounds and not entry_stage:
             tap_dst = getattr(self, "_tap_dst", None)             # (the activation store's own buffer slice, sae/store.py)
             if start_resid is not None:
                 return nv.forward(self, None, names, n_blocks, run_head, cache_device=device, remove_batch_dim=remove_batch_dim,
@@ -930,33 +1017,7 @@ class HookedViT(HookedRootModule):
         cache: Dict[str, torch.Tensor] = {}
         ST_QKV, ST_O, ST_MLP = 1, 5, 9                          # stages of q / k / v, the O-projection, the MLP output
 
-        def pos_of(name: str) -> int:
-            """the stage that produces `name` (-1: embedding stage, NP * n_layers: final stage)"""
-            if name.startswith("blocks."):
-                _, l, rest = name.split(".", 2)
-                if rest == "hook_resid_pre" or rest.startswith("ln1."):
-                    st = 0
-                elif rest in ("attn.hook_q", "attn.hook_k", "attn.hook_v"):
-                    st = ST_QKV
-                elif rest == "attn.hook_attn_scores":
-                    st = 2
-                elif rest == "attn.hook_pattern":
-                    st = 3
-                elif rest.startswith("attn."):
-                    st = 4
-                elif rest in ("hook_attn_out", "hook_resid_mid"):
-                    st = ST_O
-                elif rest.startswith("ln2."):
-                    st = 6
-                elif rest == "mlp.hook_pre":
-                    st = 7
-                elif rest.startswith("mlp."):
-                    st = 8
-                else:
-                    st = ST_MLP
-                return NP * int(l) + st
-            return -1 if name in ("hook_embed", "hook_pos_embed", "hook_full_embed", "hook_ln_pre") or name.startswith("ln_pre.") \
-                else NP * cfg.n_layers
+        pos_of = self._stage_of                                 # the stage that produces a name (-1: embedding stage, NP * n_layers: final stage)
 
         def renormalize(ln_mod: nn.Module, x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
             """hook_normalized's tensor from an edited hook_scale, as the module computes it (layer_norm.py:88-93, :38-45)"""
@@ -965,16 +1026,17 @@ class HookedViT(HookedRootModule):
             out = xc / scale
             return out * ln_mod.w + ln_mod.b if isinstance(ln_mod, LayerNorm) else out
 
-        p0, resid, acts, out = NP * first_block, start_resid, (), None
+        p0, resid, acts, out = NP * first_block + entry_stage, start_resid, tuple(entry_acts), None
         from_pixels = start_resid is None
-        assert first_block == 0 or not from_pixels
+        assert (first_block == 0 and not entry_stage) or not from_pixels
         for q in bounds + [None]:
             last = q is None
             p1 = end_pos if last else q
             b1, s1 = divmod(p1, NP)                             # the segment ends at position s1 of block b1
             blk = b1 if s1 else b1 - 1                          # the block its last stage lies in
             seg = [n for n in names if (p0 == 0 or pos_of(n) >= p0) and pos_of(n) < (NP * cfg.n_layers + 1 if last else p1)
-                   and not ((p0 > 0 or not from_pixels) and p0 % NP == 0 and n == f"blocks.{p0 // NP}.hook_resid_pre")]     # (the resumed tensor: set by hand)
+                   and not ((p0 > 0 or not from_pixels) and p0 % NP == 0 and n == f"blocks.{p0 // NP}.hook_resid_pre")      # (the resumed tensor: set by hand)
+                   and self._FLAG_RE.fullmatch(n) is None]          # (a served flag-gated point is no tap: produced below)
             hooks = {} if last else bh[q]
             c: Dict[str, torch.Tensor] = {}
             seg_in = resid
@@ -1005,8 +1067,10 @@ class HookedViT(HookedRootModule):
                         forced = [f"blocks.{b1}.attn.hook_z"] + pre_f
                     elif s1 == 6:
                         forced = [mid_name]
-                        if "attn" in hooks:
+                        if "attn" in hooks or "result" in hooks:
                             forced += [f"blocks.{b1}.hook_attn_out"] + pre_f
+                        if "result" in hooks and p0 <= NP * b1 + 4:      # z is produced inside this segment (else: carried from a hook on z)
+                            forced += [f"blocks.{b1}.attn.hook_z"]
                     elif s1 == 7:
                         forced = [f"blocks.{b1}.ln2.hook_scale", f"blocks.{b1}.ln2.hook_normalized"] + mid_f
                     elif s1 == 8:
@@ -1030,6 +1094,18 @@ class HookedViT(HookedRootModule):
                 resid = c.get(carried, seg_in)
                 s_name, n_name = f"blocks.{b1}.{which}.hook_scale", f"blocks.{b1}.{which}.hook_normalized"
                 scale, norm = c[s_name], c[n_name]
+                if s1 == 7 and "mlpin" in hooks:
+                    # use_hook_mlp_in (transformer_block.py:125-129): the hook sees a COPY of resid_mid, the MLP half continues from
+                    # what it returns, the residual stream it adds to stays resid_mid; ln2 of the edited tensor as the module computes it
+                    m_name = f"blocks.{b1}.hook_mlp_in"
+                    mlp_in = hooks["mlpin"](resid.clone())
+                    if m_name in wanted:
+                        cache[m_name] = mlp_in
+                    ln_mod = self.blocks[b1].ln2
+                    xc = mlp_in.to(torch.float32) if cfg.dtype not in (torch.float32, torch.float64) else mlp_in
+                    xc = xc - xc.mean(-1, keepdim=True)
+                    scale = (xc.pow(2).mean(-1, keepdim=True) + ln_mod.eps).sqrt()
+                    norm = renormalize(ln_mod, mlp_in, scale)
                 if which + "s" in hooks:
                     scale = hooks[which + "s"](scale)
                     norm = renormalize(getattr(self.blocks[b1], which), resid, scale)
@@ -1066,9 +1142,20 @@ class HookedViT(HookedRootModule):
                 # after block b1's attention half: hook_attn_out rebuilds resid_mid = resid_pre + attn_out with the
                 # kernel's rounding (transformer_block.py:117-124), then hook_resid_mid
                 resid = c[f"blocks.{b1}.hook_resid_mid"]
-                if "attn" in hooks:
+                if "attn" in hooks or "result" in hooks:
                     a_name = f"blocks.{b1}.hook_attn_out"
-                    attn_out = hooks["attn"](c[a_name])
+                    attn_out = c[a_name]
+                    if "result" in hooks:
+                        # use_attn_result (attention.py:155-183): z against W_O per head, the hook on the per-head results, their sum
+                        # + b_O is what the block adds -- one batched product and a reduction folded back into the stream
+                        z_name, r_name = f"blocks.{b1}.attn.hook_z", f"blocks.{b1}.attn.hook_result"
+                        attn = self.blocks[b1].attn
+                        result = hooks["result"](torch.einsum("bqhe,hed->bqhd", c[z_name] if z_name in c else prev_acts[0], attn.W_O))
+                        if r_name in wanted:
+                            cache[r_name] = result
+                        attn_out = result.sum(dim=2) + attn.b_O
+                    if "attn" in hooks:
+                        attn_out = hooks["attn"](attn_out)
                     if a_name in wanted:
                         cache[a_name] = attn_out
                     pre = c.get(f"blocks.{b1}.hook_resid_pre", seg_in)
