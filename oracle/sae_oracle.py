@@ -277,12 +277,15 @@ def train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dic
 
 # ---- Gated SAE (sae/sae.py:648-792), ReLU activation ----------------------------------------------------------------------
 def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coefficient: float = 0.0,
-                  batch_mean: Optional[Array] = None, n_global: Optional[int] = None, k: Optional[int] = None) -> Dict[str, Array]:
+                  batch_mean: Optional[Array] = None, n_global: Optional[int] = None, k: Optional[int] = None,
+                  active: Optional[Array] = None) -> Dict[str, Array]:
     """GatedSparseAutoencoder.forward (:730-771): gate path (sae_in @ W_enc + b_gate) > 0 (:703-706), magnitude path with shared weights
     sae_in @ (W_enc * exp(r_mag)) + b_mag (:708-712), auxiliary reconstruction of sae_in through the gate (:786-792).
     k = None: activation_fn_str = "relu" -- magnitudes relu(mag_pre), gate activations relu(gate_pre), L1 on them weighted by the
     decoder row norms (:780-784).  k given: activation_fn_str = "topk" -- BOTH go through TopK (:795-810; magnitudes :714, gate
-    activations :773-778) and there is no L1 term (:741-745)."""
+    activations :773-778) and there is no L1 term (:741-745).
+    active [N, d_sae] bool (tests of the dense gated step): the Heaviside gates to use instead of ``gate_pre > 0`` -- feature_acts is
+    discontinuous in the sign of gate_pre, and an entry within fp32 summation noise of zero may fall on either side."""
     dt = x.dtype.type
     N, d = x.shape
     if layer_norm:
@@ -291,7 +294,7 @@ def gated_forward(P: Dict[str, Array], x: Array, layer_norm: bool = True, l1_coe
         xh, mu, std = x, np.zeros((N, 1), x.dtype), np.ones((N, 1), x.dtype)
     S = xh - P["b_dec"]
     gate_pre = S @ P["W_enc"] + P["b_gate"]
-    active = gate_pre > 0
+    active = gate_pre > 0 if active is None else active
     mag_pre = S @ (P["W_enc"] * np.exp(P["r_mag"])) + P["b_mag"]
     if k is None:
         mags = np.maximum(mag_pre, dt(0))
@@ -352,16 +355,17 @@ def gated_backward(P: Dict[str, Array], x: Array, fw: Dict[str, Array], layer_no
 
 def gated_train_step(P: Dict[str, Array], opt: Dict[str, Dict[str, Array]], stats: Dict[str, Array], x: Array, lr: float, step: int,
                      max_grad_norm: Optional[float] = 1.0, layer_norm: bool = True, l1_coefficient: float = 0.0,
-                     k: Optional[int] = None) -> Dict[str, float]:
+                     k: Optional[int] = None, active: Optional[Array] = None) -> Dict[str, float]:
     """VisionSAETrainer.train_step (sae/train_sae.py:278-411) on a GatedSparseAutoencoder.  P, opt hold every parameter but b_enc
-    (untouched by the optimizer: no gradient).  k: the top-k form (see gated_forward)."""
+    (untouched by the optimizer: no gradient).  k: the top-k form (see gated_forward).  active: the step as it continues when the
+    Heaviside gates within fp32 noise of zero fall as given (see gated_forward; the backward's gate ReLU follows them)."""
     renorm_decoder(P)
-    fw = gated_forward(P, x, layer_norm, l1_coefficient, k=k)
+    fw = gated_forward(P, x, layer_norm, l1_coefficient, k=k, active=active)
     fired = (fw["feature_acts"] > 0).sum(axis=0)
     stats["n_fwd_since_fired"] += 1
     stats["n_fwd_since_fired"][fired > 0] = 0
     stats["act_freq_scores"] += fired.astype(stats["act_freq_scores"].dtype)
-    g = gated_backward(P, x, fw, layer_norm, l1_coefficient)
+    g = gated_backward(P, x, fw, layer_norm, l1_coefficient, gates=None if active is None else (fw["feature_acts"] > 0, active))
     Pg = {k_: P[k_] for k_ in g}
     total = clip_and_project(Pg, g, max_grad_norm)
     adam_step(Pg, g, {k_: opt["m"][k_] for k_ in g}, {k_: opt["v"][k_] for k_ in g}, lr, step)

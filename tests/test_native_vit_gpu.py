@@ -1199,10 +1199,12 @@ def test_flag_gated_hook_points_on_the_plan_vs_reference_fixture(tag, flags):
 @pytest.mark.parametrize("tag", ["all", "attn_in", "result_mlp", "split"])
 def test_hooks_on_flag_gated_points_vs_reference_fixture(tag):
     """Forward hooks that EDIT attn.hook_result / hook_mlp_in / hook_attn_in / hook_q_input / hook_v_input (+ an ordinary point beside
-    them) against the REFERENCE's own hooked runs (tests/golden/vit_tiny_flag_hooks.npz): the hooked block runs on its own module,
-    the others on the HIP plan (vit.py:_run_blocks_mixed) -- output, key order and every cache tensor."""
+    them) against the REFERENCE's own hooked runs (tests/golden/vit_tiny_flag_hooks.npz) -- output, key order and every cache tensor --
+    with EVERY block on the HIP plan (round 6, VERDICT r5 item 7: attn.hook_result / hook_mlp_in are served at the block's positions 6 / 7
+    -- one einsum + the head sum, ln2 of the edited input -- and hooks on the per-head inputs run only the block's head on the module's
+    code before the plan is entered at PV_STAGE_QKV; round 5 sent such a block to its PyTorch module)."""
     from test_flag_hooks_vs_reference_cpu import check_case
-    check_case(tag, "cuda", FP32_TOL, expect_native=True)
+    check_case(tag, "cuda", FP32_TOL, expect_native=True, blocks_on_plan=True)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -216,7 +216,11 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         };
         auto put = [&](unsigned char* plane_hi, int row, int kgrp, float x0, float x1, float x2, float x3, float sc) {
             uint2 hi, lo;
+#ifndef PV_DG_NOCVT
             dg_split4(x0, x1, x2, x3, sc, hi, lo);
+#else
+            hi = make_uint2(__float_as_uint(x0), __float_as_uint(x1)); lo = make_uint2(__float_as_uint(x2), __float_as_uint(x3));
+#endif
             const int off = row * 64 + ((((kgrp >> 1) ^ (row >> 2)) & 3) << 4) + (kgrp & 1) * 8;
             *reinterpret_cast<uint2*>(plane_hi + off) = hi;
             *reinterpret_cast<uint2*>(plane_hi + DG_SPL_PLANE + off) = lo;
@@ -248,7 +252,9 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         const int sw = (l31 >> 2) & 3;
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
+#ifndef PV_DG_NOLOAD                                   // (timing ablations of tools/build_variant.sh builds: results are wrong with any of them)
             if (kt + 1 < nk) load_slab(kt + 1);
+#endif
             const unsigned char* Ab = smem + buf * DG_SPL_STAGE;
             const unsigned char* Bb = Ab + 2 * DG_SPL_PLANE;
 #pragma unroll
@@ -267,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                     bh[ni] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(b));
                     bl[ni] = __builtin_bit_cast(dg_f16x8, *reinterpret_cast<const uint4*>(b + DG_SPL_PLANE));
                 }
+#ifndef PV_DG_NOMFMA
                 // (the two cross terms first: they are 2^-11 of the main term)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
@@ -280,6 +287,9 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+#else
+                acc[0][0][0] += (float)ah[0][0] + (float)al[1][1] + (float)bh[0][2] + (float)bl[1][3] + (float)ah[1][4] + (float)al[0][5] + (float)bh[1][6] + (float)bl[0][7];
+#endif
             }
             if (kt + 1 < nk) store_slab(buf ^ 1);
             __syncthreads();

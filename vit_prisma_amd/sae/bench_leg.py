@@ -23,6 +23,7 @@ from .native_sae import NativeSAE
 D_IN, D_SAE, TOPK, N_TOKENS = 768, 24576, 32, 4096
 PEAK_HBM_GBS = 8000.0
 PEAK_F32_TFLOPS = 157.3
+PEAK_F16_TFLOPS = 2500.0                     # dense fp16 / bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
 def _pmc_step_traffic() -> dict:
@@ -139,10 +140,20 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
         # dense steps: five fp32 MFMA GEMMs of 2 N d_in d_sae FLOP each (sae_dense.hip), bound by the fp32 matrix peak; sparse steps:
         # the top-k step's traffic (1.4 GB of algorithmic HBM bytes), bound by HBM
         if dense_steps == steps:
+            # since round 6 the five GEMMs run on the fp16 matrix pipe as three fp16 products per fp32 product (split-fp16, sae_dense.hip):
+            # the roof is the dense fp16 MFMA peak over the 30 N d_in d_sae fp16 FLOP issued; the algorithmic (fp32-equivalent) rate
+            # and its fraction of the fp32 matrix peak -- the roof of round 5's form -- stand beside it
             flops = 10.0 * n_local * D_IN * D_SAE
             tf = flops / (ms_step * 1e-3) / 1e12
-            roof = {"kernel": "whole step vs 10 N d_in d_sae FLOP (five dense fp32 GEMMs)", "bound": "mfma", "achieved": round(tf, 1),
-                    "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_TFLOPS, 4)}
+            split = N.get_tuning("dense_fp32") == 0
+            if split:
+                roof = {"kernel": "whole step vs 30 N d_in d_sae fp16 FLOP (five dense GEMMs, three fp16 products per fp32 product, fp32 accumulation)",
+                        "bound": "mfma", "achieved": round(3.0 * tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(3.0 * tf / PEAK_F16_TFLOPS, 4), "algorithmic_TFLOPs_fp32_equivalent": round(tf, 1),
+                        "frac_of_fp32_matrix_peak": round(tf / PEAK_F32_TFLOPS, 4)}
+            else:
+                roof = {"kernel": "whole step vs 10 N d_in d_sae FLOP (five dense fp32 GEMMs)", "bound": "mfma", "achieved": round(tf, 1),
+                        "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_TFLOPS, 4)}
         elif dense_steps == 0:
             gbs = 1.4e9 / (ms_step * 1e-3) / 1e9
             roof = {"kernel": "whole step vs the 1.4 GB of algorithmic HBM bytes of a k-sparse step (SURVEY.md 8d)", "bound": "hbm",
@@ -159,7 +170,8 @@ def sae_bench_leg(dev: torch.device, dist=None, steps: int = 20, warmup: int = 5
                                   f"training run from the synthetic init, steps {warmup + 1}..{warmup + steps} timed (the first ~5 steps of "
                                   "this run are dense: half of all features fire; the L1 term then collapses L0 to a few features)"),
                        "arithmetic": "sparse steps: fp16 MFMA filter at the threshold -B_n + exact fp32 re-scoring, k-sparse kernels; dense "
-                                     "steps: exact fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32); exact fp32 values either way",
+                                     "steps: split-fp16 MFMA GEMMs (hi / lo fp16 halves of each fp32 operand, three v_mfma_f32_32x32x16_f16 "
+                                     "products, fp32 accumulation: within 8e-7 of a float64 run, profiles/r06_dense_split_err.json)",
                        "per_token_capacity": int(getattr(eng, "relu_cap", 0))},
             "final_loss": loss, "l0": float(eng.scalars[2].item()), "sparse_steps": sparse_steps, "dense_steps": dense_steps,
             "roofline": roof,
