@@ -216,10 +216,17 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
         };
         auto put = [&](unsigned char* plane_hi, int row, int kgrp, float x0, float x1, float x2, float x3, float sc) {
             uint2 hi, lo;
-#ifndef PV_DG_NOCVT
-            dg_split4(x0, x1, x2, x3, sc, hi, lo);
-#else
+#if defined(PV_DG_NOCVT)
             hi = make_uint2(__float_as_uint(x0), __float_as_uint(x1)); lo = make_uint2(__float_as_uint(x2), __float_as_uint(x3));
+#elif defined(PV_DG_HALFCVT)                           // (timing ablation: the hi halves only -- 2^-11 products, the step stays dense)
+            {
+                typedef __fp16 hz2 __attribute__((ext_vector_type(2)));
+                const hz2 z01 = __builtin_amdgcn_cvt_pkrtz(x0 * sc, x1 * sc), z23 = __builtin_amdgcn_cvt_pkrtz(x2 * sc, x3 * sc);
+                hi = make_uint2(__builtin_bit_cast(uint32_t, z01), __builtin_bit_cast(uint32_t, z23));
+                lo = make_uint2(0u, 0u);
+            }
+#else
+            dg_split4(x0, x1, x2, x3, sc, hi, lo);
 #endif
             const int off = row * 64 + ((((kgrp >> 1) ^ (row >> 2)) & 3) << 4) + (kgrp & 1) * 8;
             *reinterpret_cast<uint2*>(plane_hi + off) = hi;

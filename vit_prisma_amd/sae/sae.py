@@ -212,7 +212,10 @@ class SparseAutoencoder(HookedRootModule, ABC):
         folder = os.path.dirname(path)
         if folder:
             os.makedirs(folder, exist_ok=True)
-        blob = {"cfg": self.cfg, "state_dict": self.state_dict()}
+        # (a tensor that is a VIEW of larger storage -- the parameters of a transcoder of unequal widths are views of the engine's padded
+        # buffers, trainer.py:_get_engine -- would be pickled with its whole storage and come back non-contiguous: saved as its own copy)
+        blob = {"cfg": self.cfg, "state_dict": {k: (v if v.is_contiguous() and v.untyped_storage().nbytes() == v.numel() * v.element_size()
+                                                    else v.contiguous().clone()) for k, v in self.state_dict().items()}}
         if path.endswith(".pt"):
             torch.save(blob, path)
         elif path.endswith(".pkl.gz"):

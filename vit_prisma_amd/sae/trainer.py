@@ -278,7 +278,12 @@ class VisionSAETrainer:
                 # batch, a re-bound parameter) is a per-rank event and must not contain a collective.
                 import torch.distributed as dist
                 for p in sae.parameters():
-                    dist.broadcast(p.data, src=0)
+                    if p.data.is_contiguous():
+                        dist.broadcast(p.data, src=0)
+                    else:                                        # (a view of an earlier engine's padded storage: unequal-width transcoder)
+                        tmp = p.data.contiguous()
+                        dist.broadcast(tmp, src=0)
+                        p.data.copy_(tmp)
             old = eng
             if old is not None:
                 old.materialize_w_enc()                          # (the new engine derives its shadows from the parameter)
