@@ -212,9 +212,12 @@ def test_boundary_hook_classification_for_the_split_native_plan(model, x):
                        ("blocks.0.hook_q_input", "use_split_qkv_input")):
         with model.hooks(fwd_hooks=[(name, ident)]):
             assert model._boundary_hooks() == {}, name                  # flag off: the point is never called, the hook cannot fire
-            setattr(model.cfg, flag, True)                              # flag on: that block runs on its own module
-            try:
-                assert model._boundary_hooks() == {model._TORCH_POS: {int(name.split(".")[1]): True}}, name
+            setattr(model.cfg, flag, True)                              # flag on (round 6): served ON the plan -- hook_mlp_in / hook_result as kinds
+            try:                                                        # of their own at the block's positions 7 / 6, the per-head inputs by _head_glue
+                l, hp = int(name.split(".")[1]), model.hook_dict[name]
+                want = {"use_hook_mlp_in": {model._NPOS * l + 7: {"mlpin": hp}}, "use_attn_result": {model._NPOS * l + 6: {"result": hp}},
+                        "use_split_qkv_input": {model._HEAD_POS: {l: True}}}[flag]
+                assert model._boundary_hooks() == want, name
             finally:
                 setattr(model.cfg, flag, False)
     with model.hooks(bwd_hooks=[("blocks.0.hook_resid_post", ident)]):
