@@ -583,25 +583,29 @@ int launch_dense_gemm(const DenseGemm& p, int splits, hipStream_t stream) {
 }
 
 // ---- operand maxima of the split-fp16 form ---------------------------------------------------------------------------------------
-// slots[b % DG_AMAX_SLOTS] = max(slots[...], max |x| over workgroup b's grid-stride share): bit patterns of non-negative floats order
-// like the floats, and a maximum does not depend on the order it is taken in
-__global__ __launch_bounds__(256) void dense_absmax_kernel(const float* __restrict__ x, int64_t n4, uint32_t* __restrict__ slots,
-                                                           const uint32_t* __restrict__ gate) {
+// operand maxima: bit patterns of non-negative floats order like the floats, and a maximum does not depend on the order it is taken in
+// the three operands that exist before the first GEMM of a dense step -- sae_in, W_enc^T, W_dec -- in ONE launch (blockIdx.y = tensor):
+// slot arrays t * DG_AMAX_SLOTS of `slots`, zeroed by the caller at the head of the step
+struct AbsmaxArgs { const float* x[3]; int64_t n4[3]; int slot[3]; };
+__global__ __launch_bounds__(256) void dense_absmax3_kernel(const AbsmaxArgs a, uint32_t* __restrict__ slots, const uint32_t* __restrict__ gate) {
     if (gate && *gate != 1u) return;
+    const int t = blockIdx.y;
+    const float* __restrict__ x = a.x[t];
+    const int64_t n4 = a.n4[t];
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DG_AMAX_SLOTS - 1)), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(slots + a.slot[t] * DG_AMAX_SLOTS + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DG_AMAX_SLOTS - 1)), __float_as_uint(m));
 }
-
-// max |x| of a contiguous fp32 tensor of n elements (n % 4 == 0) into its slot array (zeroed by the caller at the head of the step)
-void dense_absmax(const float* x, int64_t n, uint32_t* slots, const uint32_t* gate, hipStream_t stream) {
-    const int64_t n4 = n / 4;
-    const int grid = (int)std::min<int64_t>(2048, (n4 + 255) / 256);
-    hipLaunchKernelGGL(dense_absmax_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, stream, x, n4, slots, gate);
+void dense_absmax3(const float* x0, int64_t n0, int s0, const float* x1, int64_t n1, int s1, const float* x2, int64_t n2, int s2, uint32_t* slots,
+                   const uint32_t* gate, hipStream_t stream) {
+    AbsmaxArgs a;
+    a.x[0] = x0; a.x[1] = x1; a.x[2] = x2; a.n4[0] = n0 / 4; a.n4[1] = n1 / 4; a.n4[2] = n2 / 4; a.slot[0] = s0; a.slot[1] = s1; a.slot[2] = s2;
+    hipLaunchKernelGGL(dense_absmax3_kernel, dim3(1024, 3), dim3(256), 0, stream, a, slots, gate);
 }
 
 // column partials [nblk][d] -> out[j] (+ firing statistics, + per-workgroup totals for l0)
@@ -639,7 +643,8 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            float* __restrict__ loss_partial, int n_tok, int d, float grad_scale,
                                                            float* __restrict__ err_out, const float* __restrict__ addend,
                                                            const uint32_t* __restrict__ gate = nullptr,
-                                                           const float* __restrict__ ghost_x = nullptr) {
+                                                           const float* __restrict__ ghost_x = nullptr, uint32_t* __restrict__ amax = nullptr) {
+    // amax (or NULL): partial maxima of |dY| (DG_AMAX_SLOTS words, see DenseGemm.a_max)
     // transcoder (pv_sae_state.tc): x = the TARGET, b_dec = b_dec_out, addend = the skip term or nullptr; ghost_x (a transcoder with
     // ghost gradients): the INPUT activation -- err_out is then sae_out - input, what the ghost term is computed on (transcoder.py:82-86)
     if (gate && *gate != 1u) return;
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     const float m = mu[n], sdv = sd[n], nf = norm[n];
-    float lsum = 0.f;
+    float lsum = 0.f, gmax = 0.f;
     for (int c = 4 * lane; c < d; c += 256) {
         float4 a = *reinterpret_cast<const float4*>(kpart + (int64_t)n * d + c);
         for (int z = 1; z < splits; ++z) {
@@ -676,9 +681,14 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
         g.x = grad_scale * e.x / nf * sdv; g.y = grad_scale * e.y / nf * sdv;
         g.z = grad_scale * e.z / nf * sdv; g.w = grad_scale * e.w / nf * sdv;
         *reinterpret_cast<float4*>(dY + (int64_t)n * d + c) = g;
+        gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
     }
     lsum = wave_sum(lsum);
     if (lane == 0) loss_partial[n] = lsum;
+    if (amax) {
+        gmax = wave_max(gmax);
+        if (lane == 0) atomicMax(amax + (n & (DG_AMAX_SLOTS - 1)), __float_as_uint(gmax));
+    }
 }
 
 // lp_norm > 1 (sae.py:617): per token S = sum_j f^p from the ENC epilogue's partials -> ||f_n||_p = S^(1/p) (the loss term) and
@@ -965,10 +975,9 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
     const bool lp_on = d.lp_norm != 0.f && d.lp_norm != 1.f;      // the sparsity term is ||f_n||_p, p > 1 (sae.py:617)
     if (split) {
         PV_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)PV_SAE_AMAX_TENSORS * DG_AMAX_SLOTS * 4, stream));
-        dense_absmax(sae_in, (int64_t)N * D, am(AM_X), gate, stream);
-        dense_absmax((const float*)st->W_encT, (int64_t)F * D, am(AM_WENC), gate, stream);
-        dense_absmax((const float*)st->W_dec, (int64_t)F * D, am(AM_WDEC), gate, stream);
-        PV_LAUNCH_CHECK("dense_absmax_kernel");
+        dense_absmax3(sae_in, (int64_t)N * D, AM_X, (const float*)st->W_encT, (int64_t)F * D, AM_WENC, (const float*)st->W_dec, (int64_t)F * D, AM_WDEC,
+                      amax, gate, stream);
+        PV_LAUNCH_CHECK("dense_absmax3_kernel");
     }
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + (double)N * F) * 4.0);
@@ -1019,9 +1028,9 @@ int dense_step_body(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t
         hipLaunchKernelGGL(dense_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, tc ? st->tc.target : x, (const float*)kpart, S,
                            (int64_t)N * D, tc ? (const float*)st->tc.b_dec_out : (const float*)st->b_dec, (const float*)(wsb + ws.mu),
                            (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), out->sae_out, dY, (float*)(wsb + ws.loss_part), N, D,
-                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate, (ghost && tc) ? x : (const float*)nullptr);
+                           grad_scale, ghost ? (float*)(gwb + gw.err) : (float*)nullptr, skip, gate, (ghost && tc) ? x : (const float*)nullptr,
+                           split ? am(AM_DY) : (uint32_t*)nullptr);
         PV_LAUNCH_CHECK("dense_finish_kernel");
-        if (split) dense_absmax(dY, (int64_t)N * D, am(AM_DY), gate, stream);
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), 1, -1,
                        stream, gate, 1u);
         if (ghost) {
@@ -1496,11 +1505,13 @@ __global__ __launch_bounds__(256) void gated_finish_kernel(const float* __restri
                                                            float* __restrict__ sae_out, float* __restrict__ dYs,
                                                            float* __restrict__ loss_partial, float* __restrict__ aux_partial, int n_tok,
                                                            int d, float grad_scale, float aux_scale /* 2 / N */,
-                                                           const uint32_t* __restrict__ gate) {
+                                                           const uint32_t* __restrict__ gate, uint32_t* __restrict__ amax = nullptr) {
+    // amax (or NULL): partial maxima of |dYs| (DG_AMAX_SLOTS words, see DenseGemm.a_max)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (gate && *gate != 1u) return;                           // (gate: as in DenseGemm)
     if (r >= 2 * n_tok) return;
+    float gmax = 0.f;
     const bool second = r >= n_tok;
     const int n = second ? r - n_tok : r;
     const float m = mu[n], sdv = sd[n], nf = norm[n];
@@ -1529,9 +1540,14 @@ __global__ __launch_bounds__(256) void gated_finish_kernel(const float* __restri
             g.x = aux_scale * e.x; g.y = aux_scale * e.y; g.z = aux_scale * e.z; g.w = aux_scale * e.w;
         }
         *reinterpret_cast<float4*>(dYs + (int64_t)r * d + c) = g;
+        gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
     }
     lsum = wave_sum(lsum);
     if (lane == 0) (second ? aux_partial : loss_partial)[n] = lsum;
+    if (amax) {
+        gmax = wave_max(gmax);
+        if (lane == 0) atomicMax(amax + (r & (DG_AMAX_SLOTS - 1)), __float_as_uint(gmax));
+    }
 }
 
 // scalars[0] = mse + l1 + aux (sae.py:748), one thread
@@ -1669,10 +1685,9 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     }
     if (split) {
         PV_HIP_CHECK(hipMemsetAsync(amax, 0, (size_t)PV_SAE_AMAX_TENSORS * DG_AMAX_SLOTS * 4, stream));
-        dense_absmax(sae_in, (int64_t)N * D, am(AM_X), mode, stream);
-        dense_absmax((const float*)st->W_encT, (int64_t)F * D, am(AM_WENC), mode, stream);
-        dense_absmax((const float*)st->W_dec, (int64_t)F * D, am(AM_WDEC), mode, stream);
-        PV_LAUNCH_CHECK("dense_absmax_kernel");
+        dense_absmax3(sae_in, (int64_t)N * D, AM_X, (const float*)st->W_encT, (int64_t)F * D, AM_WENC, (const float*)st->W_dec, (int64_t)F * D, AM_WDEC,
+                      amax, mode, stream);
+        PV_LAUNCH_CHECK("dense_absmax3_kernel");
     }
     {
         ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)D * F, ((double)N * D + (double)D * F + 2.0 * N * F) * 4.0);
@@ -1707,9 +1722,8 @@ static int gated_step_impl(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
         hipLaunchKernelGGL(gated_finish_kernel, dim3((2 * N + 3) / 4), dim3(256), 0, stream, x, (const float*)sae_in, (const float*)kpart, S,
                            (int64_t)2 * N * D, (const float*)st->b_dec, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),
                            (const float*)(wsb + ws.norm), out->sae_out, dYs, (float*)(wsb + ws.loss_part), (float*)(gb + gw.auxpart), N, D,
-                           2.0f / (ng * (float)D), 2.0f / ng, mode);
+                           2.0f / (ng * (float)D), 2.0f / ng, mode, split ? am(AM_DY) : (uint32_t*)nullptr);
         PV_LAUNCH_CHECK("gated_finish_kernel");
-        if (split) dense_absmax(dYs, (int64_t)2 * N * D, am(AM_DY), mode, stream);
         sae_reduce_sum((const float*)(wsb + ws.loss_part), out->scalars, N, 1.0f / (ng * (float)D), 1, -1, stream, mode, 1u);
         sae_reduce_sum((const float*)(gb + gw.auxpart), out->scalars, N, 1.0f / ng, 6, -1, stream, mode, 1u);
         hipLaunchKernelGGL(gated_loss_kernel, dim3(1), dim3(1), 0, stream, out->scalars, mode);
