@@ -640,10 +640,10 @@ def test_filtered_encoder_exact_fallback_on_ties_range_and_outside_edits(tuning)
 # ---------------------------------------------------------------------------------------------------
 # module-level inference on the HIP kernels (the SAE inside a ViT hook)
 # ---------------------------------------------------------------------------------------------------
-def _module(d_in, d_sae, k, return_out_only=False):
+def _module(d_in, d_sae, k, return_out_only=False, normalize_activations="layer_norm"):
     cfg = VisionModelSAERunnerConfig(
         hook_point_layer=6, layer_subtype="hook_resid_post", d_in=d_in, expansion_factor=d_sae // d_in, activation_fn_str="topk",
-        activation_fn_kwargs={"k": k}, normalize_activations="layer_norm", _device="cuda", log_to_wandb=False)
+        activation_fn_kwargs={"k": k}, normalize_activations=normalize_activations, _device="cuda", log_to_wandb=False)
     cfg.return_out_only = return_out_only
     sae = StandardSparseAutoencoder(cfg)
     with torch.no_grad():
@@ -652,8 +652,10 @@ def _module(d_in, d_sae, k, return_out_only=False):
     return sae.eval()
 
 
-def test_module_forward_and_encode_run_natively_and_equal_the_torch_path():
-    sae = _module(768, 24576, 32)
+@pytest.mark.parametrize("norm", ["layer_norm", "constant_norm_rescale", "none"])
+def test_module_forward_and_encode_run_natively_and_equal_the_torch_path(norm):
+    """(round 6: also under normalize_activations = "constant_norm_rescale" -- sae.py:60-72, the prep kernel's third mode -- and none)"""
+    sae = _module(768, 24576, 32, normalize_activations=norm)
     x = torch.from_numpy(synth_sae_batch(300, 768, seed=4)).cuda().view(6, 50, 768)      # [batch, tokens, d_in] like a hook sees it
     with torch.no_grad():
         got = sae(x)
