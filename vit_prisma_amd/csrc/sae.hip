@@ -94,12 +94,17 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     const float* xr = x + (int64_t)n * d;
+    // batch_mean == NULL: the loss normaliser is left to a later kernel (sae_thr_kernel of the two-stream pre-pass, SaePre)
     float s = 0.f, cn = 0.f;
-    for (int i = lane; i < d_true; i += 64) {
-        const float v = xr[i];
-        s += v;
-        const float c = v - batch_mean[i];
-        cn += c * c;
+    if (batch_mean) {
+        for (int i = lane; i < d_true; i += 64) {
+            const float v = xr[i];
+            s += v;
+            const float c = v - batch_mean[i];
+            cn += c * c;
+        }
+    } else {
+        for (int i = lane; i < d_true; i += 64) s += xr[i];
     }
     // use_ln: 0 none, 1 "layer_norm" (sae.py:74-90), 2 "constant_norm_rescale" (sae.py:60-72: x * c on the way in with
     // c = sqrt(d_in) / ||x||, / c on the way out -- the step's other kernels only know "out = pre * sd + mu": mu = 0, sd = 1 / c)
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
     if (lane == 0) {
         mu_out[n] = mu;
         std_out[n] = sd;
-        norm_out[n] = sqrtf(cn);
+        if (batch_mean) norm_out[n] = sqrtf(cn);
         // ||sae_in||_2 for the filter's error bound; a row outside the fp16 range (or NaN) is sent to the exact path
         if (xnorm_out) xnorm_out[n] = (amax <= 6.0e4f) ? sqrtf(s2) : INFINITY;
     }
@@ -1106,11 +1111,11 @@ __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restr
 // over its GBD_ROWS features, skipping the features no token kept (gb_enc = 0: half of them on the bench batch), so the
 // pass reads the fired rows of W_encT once, coalesced, instead of all of W_enc.
 constexpr int GBD_ROWS = 96;
-__global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
-                                                                float* __restrict__ partial, int d_sae, int d) {
+__device__ __forceinline__ void gbdec_partial_body(int bid, const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
+                                                   float* __restrict__ partial, int d_sae, int d) {
     __shared__ float red[3][1280];                       // waves 1..3 -> wave 0, up to 1280 columns (d_in <= 256 * 5)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j0 = blockIdx.x * GBD_ROWS, j1 = min(j0 + GBD_ROWS, d_sae);
+    const int j0 = bid * GBD_ROWS, j1 = min(j0 + GBD_ROWS, d_sae);
     float4 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1141,10 +1146,48 @@ __global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __r
                     const float4 o = *reinterpret_cast<const float4*>(&red[w][c]);
                     t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
                 }
-                *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * d + c) = t;
+                *reinterpret_cast<float4*>(partial + (int64_t)bid * d + c) = t;
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
+                                                                float* __restrict__ partial, int d_sae, int d) {
+    gbdec_partial_body(blockIdx.x, W_encT, gb_enc, partial, d_sae, d);
+}
+// The step's loss from the decode kernel's per-token terms: scalars[0] = scalars[1] = loss_scale * sum, in the order of the 1024-thread
+// reduction that rides in csr_scan_kernel's workgroup (thread t of 1024 takes terms t, t + 1024, ...; 16 wave sums; added in wave
+// order) -- here by 256 threads that each play four of those threads, so that the two homes of the reduction agree to the bit.
+__device__ __forceinline__ void loss_reduce_body(const float* __restrict__ loss_part, int n_loss, float loss_scale, float* __restrict__ scalars) {
+    __shared__ float lsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t = 0.f;
+        for (int i = tid + 256 * q; i < n_loss; i += 1024) t += loss_part[i];
+        t = wave_sum(t);
+        if (lane == 0) lsum[wv + 4 * q] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += lsum[w];               // fixed order
+        scalars[0] = t * loss_scale;
+        scalars[1] = t * loss_scale;
+    }
+}
+// What stands between the sparse backward and the column sum that finishes gb_dec, as ONE launch (the two-stream form of pv_sae_step,
+// whose CSR build no longer waits for the decode kernel and so cannot carry the decode kernel's reductions): blocks [0, ngb) = the
+// encoder-path partial rows (gbdec_partial_body), [ngb, ngb + nblk) = the 16-row partial column sums of dY, the last one = the loss.
+__global__ __launch_bounds__(256) void sae_gbdec_tail_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
+                                                             float* __restrict__ colpart, int d_sae, int d, int ngb,
+                                                             const float* __restrict__ dY, int n_tok, int nblk,
+                                                             const float* __restrict__ loss_part, float loss_scale,
+                                                             float* __restrict__ scalars) {
+    const int b = blockIdx.x;
+    if (b < ngb) gbdec_partial_body(b, W_encT, gb_enc, colpart + (int64_t)nblk * d, d_sae, d);
+    else if (b < ngb + nblk) colsum_partial_body(b - ngb, dY, colpart, n_tok, d);
+    else loss_reduce_body(loss_part, n_tok, loss_scale, scalars);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1601,7 +1644,45 @@ extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_pla
     *out_plan = p;
     return PV_OK;
 }
-extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) { delete plan; }
+extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) {
+    if (!plan) return;
+    if (plan->side) {
+        (void)hipStreamSynchronize(plan->side);
+        for (int i = 0; i < 2; ++i) {
+            if (plan->ev_fork[i]) (void)hipEventDestroy(plan->ev_fork[i]);
+            if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
+        }
+        (void)hipStreamDestroy(plan->side);
+    }
+    delete plan;
+}
+
+int sae_side_fork(pv_sae_plan* plan, hipStream_t main, int i, hipStream_t* side) {
+    *side = nullptr;
+    if (!g_pv_tuning.sae_side || g_pv_tuning.sae_side == 3 - i) return PV_OK;      // (2 / 3: fork 0 / fork 1 only -- the A/B of each)
+    int dev = 0;
+    PV_HIP_CHECK(hipGetDevice(&dev));
+    if (!plan->side) {
+        PV_HIP_CHECK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
+        for (int e = 0; e < 2; ++e) {
+            // (no system-scope fence at these events: both streams are on this device, and the fence's L2 write-back + invalidate is
+            // paid by every kernel behind it)
+            PV_HIP_CHECK(hipEventCreateWithFlags(&plan->ev_fork[e], hipEventDisableTiming | hipEventDisableSystemFence));
+            PV_HIP_CHECK(hipEventCreateWithFlags(&plan->ev_join[e], hipEventDisableTiming | hipEventDisableSystemFence));
+        }
+        plan->side_dev = dev;
+    }
+    PV_REQUIRE(plan->side_dev == dev, "pv_sae_step: this plan's side stream belongs to another device (one plan per device)");
+    PV_HIP_CHECK(hipEventRecord(plan->ev_fork[i], main));
+    PV_HIP_CHECK(hipStreamWaitEvent(plan->side, plan->ev_fork[i], 0));
+    *side = plan->side;
+    return PV_OK;
+}
+int sae_side_join(pv_sae_plan* plan, hipStream_t main, int i) {
+    PV_HIP_CHECK(hipEventRecord(plan->ev_join[i], plan->side));
+    PV_HIP_CHECK(hipStreamWaitEvent(main, plan->ev_join[i], 0));
+    return PV_OK;
+}
 extern "C" size_t pv_sae_workspace_bytes(const pv_sae_plan* plan) { return plan ? sae_carve(plan->d).total : 0; }
 extern "C" int pv_sae_encoder_is_filtered(const pv_sae_plan* plan) { return plan && pv_sae_fast_ok(plan->d) ? 1 : 0; }
 // debug / tests: byte offset of a named region of the workspace ("fb_count": uint32 number of tokens of the last encode that
@@ -1737,17 +1818,18 @@ int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float
 // batch mean (given, or computed from x) -> ws.batch_mean; LN-in, sae_in, loss normaliser (+ the fp16 copy / row norms the
 // filtered encoder wants) -> ws.sae_in, ws.mu, ws.sd, ws.norm (ws.x16, ws.xnorm)
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true) {
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true, hipStream_t mean_stream) {
     float* bmean = (float*)(wsb + ws.batch_mean);
+    hipStream_t ms = mean_stream ? mean_stream : stream;
     if (batch_mean) {
-        PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
+        PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, ms));
     } else {
         const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, ms, x, (float*)(wsb + ws.colpart), N, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, ms,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
-    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, (const float*)bmean,
+    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, mean_stream ? (const float*)nullptr : (const float*)bmean,
                        (float*)(wsb + ws.sae_in), want_filter_inputs ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
                        want_filter_inputs ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
                        (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps, d_true > 0 ? d_true : d.d_in);
@@ -1764,6 +1846,19 @@ int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int
     if (!have_colsum) hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
     hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
                        colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                       nblk + ngb, d.d_in, 1.0f);
+    PV_LAUNCH_CHECK("sae bias-grad kernels");
+    return PV_OK;
+}
+
+// sae_gbdec with the decode kernel's two reductions in its first launch (sae_gbdec_tail_kernel)
+static int sae_gbdec_tail(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
+                          const float* loss_part, float loss_scale, float* scalars, hipStream_t stream) {
+    const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+    float* colpart = (float*)(wsb + ws.colpart);
+    hipLaunchKernelGGL(sae_gbdec_tail_kernel, dim3(ngb + nblk + 1), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                       colpart, d.d_sae, d.d_in, ngb, dY, N, nblk, loss_part, loss_scale, scalars);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
                        nblk + ngb, d.d_in, 1.0f);
     PV_LAUNCH_CHECK("sae bias-grad kernels");
@@ -1810,15 +1905,21 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     uint32_t* wpos = want_csr ? (wpos_over ? wpos_over : (uint32_t*)(wsb + ws.wpos)) : nullptr;
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
+    // the training step's pre-pass on two streams: batch mean + weight bound (three launch-bound kernels) beside prep + the sample GEMM
+    SaePre pre = {plan, nullptr, x, sae_in_width(d, st)};
+    if (fast && want_csr && !skip_prep && !cnt_over) {
+        int rcf = sae_side_fork(plan, stream, 0, &pre.side);
+        if (rcf) return rcf;
+    }
     if (!skip_prep) {
-        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st));
+        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st), pre.side);
         if (rcp) return rcp;
     }
     // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
     ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
                    ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
                        (fast ? 0.0 : (double)N * d.d_sae * 8.0));
-    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, feat_cnt, wpos, wsb, ws, stream);
+    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, feat_cnt, wpos, wsb, ws, stream, pre.side ? &pre : nullptr);
     {
         // exact path: hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574) on the fp32 MFMA, W_enc in its own [d_in][d_sae] layout
         GemmParams g = {};
@@ -1888,10 +1989,13 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 // selection), then the three backward kernels -- every row of gW_dec / gW_enc^T / gb_enc written exactly once.  N tokens of k slots;
 // dY / sae_in hold N rows, dh N k entries.  loss_part (optional): the N per-token loss terms, scalars[0] = scalars[1] = loss_scale * sum.
 // cs_here: also the 16-row partial column sums of dY.  val_b / dYb: the second decoder term of a pair (bwd_walk<DUAL>: the gated step).
-int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
-                     const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
-                     const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
-                     const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb, const uint32_t* cnt_in) {
+// The two halves of sae_csr_backward.  sae_csr_build: the CSR by feature -- scan, chunk cuts / long lists / statistics / pair scatter, the
+// two list sorts; it reads the selection's output only (counts, positions, indices), so with loss_part == NULL and cs_here false it
+// does not wait for the decode kernel and may run beside it (pv_sae_step's side stream).  sae_csr_grads: the backward kernels.
+static int sae_csr_build(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* dY, float* scalars,
+                         float* fire_count, int update_stats, bool sparse, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws,
+                         const float* loss_part, float loss_scale, bool cs_here, const uint32_t* gate, hipStream_t stream,
+                         const uint32_t* cnt_in) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
@@ -1908,8 +2012,6 @@ int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const in
         float* rowsq = (float*)(wsb + ws.rowsq);
         const int max_segs = tb.max_segs;
         uint32_t* seg_range = tb.seg_range;
-        float* seg_rows = tb.seg_rows;
-        float* seg_b = tb.seg_b;
         // (the scan's workgroup also reduces the loss: loss = mse_loss = sum / (N_global * d_in), sae.py:148; topk: loss == mse_loss,
         // :620-626 -- scalars[0] = scalars[1])
         hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, offs, n_long, d.d_sae,
@@ -1932,6 +2034,29 @@ int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const in
             if (rc) return rc;
         }
         PV_LAUNCH_CHECK("csr kernels");
+    }
+    return PV_OK;
+}
+
+static int sae_csr_grads(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
+                         const float* dY, const float* sae_in, bool sparse, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws,
+                         const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb) {
+    const pv_sae_desc& d = plan->d;
+    const int n_pairs = N * k;
+    const dim3 block(256);
+    {
+        uint32_t* offs = (uint32_t*)(wsb + ws.offs);
+        uint32_t* chunk_start = tb.chunk_start;
+        int32_t* pairs = tb.pairs;
+        int32_t* long_list = (int32_t*)(wsb + ws.long_list);
+        uint32_t* n_long = (uint32_t*)(wsb + ws.n_long);
+        const int max_chunks = (n_pairs + BWD_CH - 1) / BWD_CH;
+        float* rowsq = (float*)(wsb + ws.rowsq);
+        const int max_segs = tb.max_segs;
+        uint32_t* seg_range = tb.seg_range;
+        float* seg_rows = tb.seg_rows;
+        float* seg_b = tb.seg_b;
+        const int ranged = sae_long_ranged(N) ? 1 : 0;
         const dim3 gridf((max_chunks + 3) / 4);
         // every gradient row is stored exactly once: by the zero kernel (features no token kept), the short-list kernel or
         // the long-list combine.  PV_SAE_SPARSE_GRADS: the rows of features no token kept are not touched at all -- pv_sae_apply
@@ -1969,6 +2094,16 @@ int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const in
     return PV_OK;
 }
 
+int sae_csr_backward(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* topk_val, const float* dh,
+                     const float* dY, const float* sae_in, float* scalars, float* fire_count, int update_stats, bool sparse,
+                     const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* loss_part, float loss_scale, bool cs_here,
+                     const uint32_t* gate, hipStream_t stream, const float* val_b, const float* dYb, const uint32_t* cnt_in) {
+    int rc = sae_csr_build(plan, st, N, k, topk_idx, dY, scalars, fire_count, update_stats, sparse, tb, wsb, ws, loss_part, loss_scale,
+                           cs_here, gate, stream, cnt_in);
+    if (rc) return rc;
+    return sae_csr_grads(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, sparse, tb, wsb, ws, gate, stream, val_b, dYb);
+}
+
 // Everything of the k-sparse step behind the selection: decode + LN-out + loss + dY + dh, the CSR by feature, the sparse backward,
 // the bias gradients.  Shared by pv_sae_step (k = the plan's k) and by the sparse form of the ReLU + L1 step (pv_sae_relu_step:
 // k = the per-token capacity, tok_cnt / dh_add / gate as described at sae_decode_kernel; the k-dependent buffers come in through tb).
@@ -1986,7 +2121,20 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
     {
         ProfScope prof(PV_PROF_SAE_BWD, stream, 4.0 * n_pairs * (double)d.d_in * 2.0, 0.0);
         const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));      // (a transcoder: the mean is over N x d_out)
+        const float loss_scale = 1.0f / ((float)n_global * (float)sae_loss_width(d, st));
         const dim3 grid((N + 3) / 4), block(256);
+        // pv_sae_step on an autoencoder: the CSR build (four launch-bound kernels that read the selection's output only) runs on the
+        // plan's side stream beside the decode kernel; the decode kernel's two reductions move to the bias gradients' first launch
+        hipStream_t side = nullptr;
+        if (bias_grads && !tc && !gate && !tok_cnt) {
+            rc = sae_side_fork(plan, stream, 1, &side);
+            if (rc) return rc;
+        }
+        if (side) {
+            rc = sae_csr_build(plan, st, N, k, topk_idx, dY, scalars, fire_count, update_stats, sparse, tb, wsb, ws, nullptr, 0.f, false,
+                               gate, side, nullptr);
+            if (rc) return rc;
+        }
 #define CALL(D)                                                                                                      \
     hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
                        topk_idx, topk_val, (const float*)(wsb + ws.mu),      \
@@ -1995,9 +2143,16 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
+        if (side) {
+            rc = sae_side_join(plan, stream, 1);
+            if (rc) return rc;
+            rc = sae_csr_grads(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, sparse, tb, wsb, ws, gate, stream, nullptr, nullptr);
+            if (rc) return rc;
+            return sae_gbdec_tail(d, st, dY, N, wsb, ws, (const float*)(wsb + ws.loss_part), loss_scale, scalars, stream);
+        }
         const bool cs_here = bias_grads && !tc;
         rc = sae_csr_backward(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
-                              (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)sae_loss_width(d, st)), cs_here, gate, stream);
+                              (const float*)(wsb + ws.loss_part), loss_scale, cs_here, gate, stream);
         if (rc) return rc;
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)

@@ -14,6 +14,22 @@ struct pv_sae_plan {
     pv_sae_desc d;
     bool renorm_pending = false;     // the last pv_sae_step deferred set_decoder_norm_to_unit_norm to pv_sae_apply
     const uint32_t* live_offs = nullptr;   // PV_SAE_SPARSE_GRADS: feature offsets of the last pv_sae_step (in ITS workspace), else null
+    // pv_sae_step's side stream (created on first use, on the device of that call): the launches of a step that depend on nothing the
+    // main chain is about to produce run beside it -- the batch mean + the weight bound beside prep + the sample GEMM, the CSR build
+    // beside the decode kernel -- forked and joined by events, so that the caller's stream sees one ordered step (sae_side_fork / _join)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    int side_dev = -1;
+};
+// sae.hip: *side = the plan's side stream, waiting for everything queued on `main` so far (fork i of a step: 0 the pre-pass, 1 the CSR
+// build); nullptr when the side stream is off (tuning key sae_side = 0).  sae_side_join: `main` waits for what was queued on the side stream.
+int sae_side_fork(pv_sae_plan* plan, hipStream_t main, int i, hipStream_t* side);
+int sae_side_join(pv_sae_plan* plan, hipStream_t main, int i);
+// the pre-pass of the filtered top-k on two streams (sae_encode_topk -> sae_encode_fast): the weight bound (sae_wmax_kernel) goes to
+// `side`, `main` waits for `join` in front of the threshold kernel, which then takes the loss normaliser ||x_n - mean||_2 (sae.py:145-147)
+// that sae_prep left out (the batch mean is computed on the side stream)
+struct SaePre {
+    pv_sae_plan* plan; hipStream_t side; const float* x; int d_true;
 };
 
 struct SaeWs {
@@ -53,7 +69,7 @@ static inline bool pv_sae_fast_ok(const pv_sae_desc& d) {
 // feat_cnt / wpos (both or neither; feat_cnt is zeroed here): per-feature pair counts and each kept pair's position in
 // its feature's list, for the backward's CSR.
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
-                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream);
+                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, const SaePre* pre = nullptr);
 
 // sae.hip: exact streaming / radix top-k of rows of `hidden`; row_list == nullptr: rows 0..n_rows-1 (one workgroup each),
 // else the rows row_list[0 .. *n_list) are walked by `slots` workgroups.
@@ -106,8 +122,9 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
 int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t stream);
 
 // sae.hip, shared with sae_dense.hip: see the definitions
+// mean_stream: the batch mean (ws.batch_mean) is produced on THAT stream and the prep kernel leaves ws.norm to a later kernel (SaePre)
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true = 0);
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true = 0, hipStream_t mean_stream = nullptr);
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
               hipStream_t stream, bool have_colsum = false);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream,

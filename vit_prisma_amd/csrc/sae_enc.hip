@@ -521,10 +521,23 @@ __device__ __forceinline__ float enc_c1(int K) { return fmaxf(1.25e-3f, 9.768009
 template <int VPL>                                            // sampled values per lane: ns <= 64 VPL
 __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
                                                       const float* __restrict__ wmax_sq, int qsel, int d_in, float* __restrict__ thr,
-                                                      float* __restrict__ sq_out, float* __restrict__ band, int n_tok) {
+                                                      float* __restrict__ sq_out, float* __restrict__ band, int n_tok,
+                                                      const float* __restrict__ x, const float* __restrict__ batch_mean,
+                                                      float* __restrict__ norm_out, int d_true) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
+    if (x) {
+        // (two-stream pre-pass, SaePre) the loss normaliser ||x_n - mean_batch(x)||_2 that sae_prep_kernel left out: its loop, its order
+        const float* xr = x + (int64_t)n * d_in;
+        float cn = 0.f;
+        for (int i = lane; i < d_true; i += 64) {
+            const float c = xr[i] - batch_mean[i];
+            cn += c * c;
+        }
+        cn = wave_sum(cn);
+        if (lane == 0) norm_out[n] = sqrtf(cn);
+    }
     const float* s = sample + (int64_t)n * ns;
     float v[VPL];
 #pragma unroll
@@ -1048,13 +1061,14 @@ int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
 }  // namespace
 
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
-                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream) {
+                    uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, const SaePre* pre) {
     PV_REQUIRE(st->W_encT && st->W_enc16T && st->enc_colsq, "encoder shadows (W_encT, W_enc16T, enc_colsq) are required");
     const int S = PV_SAE_SAMPLE_STRIDE, ns = d.d_sae / S, q = pv_sae_sample_q(d.k);
     float* wmax = (float*)(wsb + ws.wmax);
     uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
     int32_t* fb_list = (int32_t*)(wsb + ws.fb_list);
-    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count, feat_cnt);
+    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, pre ? pre->side : stream, (const float*)st->enc_colsq, d.d_sae, wmax,
+                       fb_count, feat_cnt);
     EncParams p = {};
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
     // pass 0: every S-th feature
@@ -1062,10 +1076,15 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     p.bias = st->b_enc; p.bias_stride = S; p.out = (float*)(wsb + ws.sample); p.ldo = ns;
     int rc = launch_enc_gemm(0, p, stream);
     if (rc) return rc;
+    if (pre) {                                                 // the side stream's batch mean and weight bound are due here
+        rc = sae_side_join(pre->plan, stream, 0);
+        if (rc) return rc;
+    }
 #define THR(V)                                                                                                                \
     hipLaunchKernelGGL((sae_thr_kernel<V>), dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,         \
                        (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq), \
-                       (float*)(wsb + ws.band), N)
+                       (float*)(wsb + ws.band), N, pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean),          \
+                       (float*)(wsb + ws.norm), pre ? pre->d_true : 0)
     if (ns <= 1024) { THR(16); } else if (ns <= 2048) { THR(32); } else { THR(64); }        // d_sae <= 65536: ns <= 4096
 #undef THR
     PV_LAUNCH_CHECK("sae_thr_kernel");
