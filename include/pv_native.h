@@ -46,7 +46,7 @@ extern "C" {
  * 11: pv_sae_tp_merge / pv_sae_tp_bucket_*, pv_build_id, the dense ReLU + L1 step pv_sae_dense_*; 17: pv_gemm_epilogue, the
  * gemm_persist / gemm_stagger tuning keys; 22: pv_sae_desc.activation / lp_norm,
  * normalize_layer_norm = 2 (constant_norm_rescale), the split-fp16 dense GEMMs and their tuning key dense_fp32, gemm_cus). */
-#define PV_ABI_VERSION 22
+#define PV_ABI_VERSION 23
 int pv_abi_version(void);
 /* Hash of the sources this binary was built from (sha256 over the .hip / .hpp files of vit_prisma_amd/csrc and this header, names and
  * contents, sorted; first 32 hex digits): the prebuilt library travels next to the sources, and the Python binding refuses
@@ -411,6 +411,9 @@ int pv_sae_renorm_decoder(pv_sae_plan* plan, pv_sae_state* st, void* stream);
 #define PV_SAE_INV_NORM_VALID 4
 #define PV_SAE_SPARSE_GRADS 8
 #define PV_SAE_TP_ENC_TERM_ONLY 16   /* pv_sae_tp_finish: st->gb_dec = -W_enc[:, shard] gb_enc[shard] only (without colsum(dY)) */
+#define PV_SAE_FUSED_SQNORM 32       /* pv_sae_step (autoencoder states): the step's last launch also leaves scalars[3] = the gradient's sum of
+                                        squares -- pv_sae_grad_sqnorm_step's terms, added block-wise (a fixed order of its own, so the
+                                        last bits may differ from that call's); the caller then goes straight to pv_sae_apply */
 int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, int32_t n_tokens,
                 const float* batch_mean, int32_t n_global, int32_t flags, pv_sae_out* out,
                 void* workspace, size_t workspace_bytes, void* stream);

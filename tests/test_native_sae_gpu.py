@@ -1387,6 +1387,55 @@ def test_step_is_bit_reproducible_from_run_to_run():
         assert torch.equal(a.W_encT, b.W_encT) and torch.equal(a.flat_m, b.flat_m) and torch.equal(a.flat_v, b.flat_v)
 
 
+@pytest.mark.parametrize("d_in,d_sae,k,n,sparse", [(768, 24576, 32, 4096, True), (768, 24576, 32, 4096, False), (256, 4096, 16, 1000, True),
+                                                   (1024, 8192, 64, 777, True)])
+def test_folded_launches_equal_the_single_launches_bitwise(d_in, d_sae, k, n, sparse):
+    """Round 6 folded the step's launch-bound kernels into their neighbours -- batch-mean partials and the weight bound into the prep
+    launch, the mean's second stage into the threshold launch, the loss normaliser into an idle wave of the select kernel, the CSR
+    scan into the decode launch, the loss into the post + fill launch, the two list sorts into one launch, the clip norm into the last
+    column sum (PV_SAE_FUSED_SQNORM), the bias vectors' Adam into the encoder's -- each in the arithmetic ORDER of the launch it
+    replaces.  So the folded step (tuning key sae_fold = 1, the default) and the step of single launches (sae_fold = 0; the clip
+    norm's block-wise sum from a launch of its own) agree BIT FOR BIT: reconstruction, scalars (loss, mse, l0, clip norm), the selected sets, every
+    gradient, parameters and moments after the optimizer step, firing statistics -- three steps in a row, ragged token counts too."""
+    from vit_prisma_amd import _native as NV
+    engines = []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        engines.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n))
+    try:
+        for t in range(3):
+            x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+            for fold, e in enumerate(engines):
+                NV.set_tuning("sae_fold", fold)
+                e.step(x, want_out=True, renorm_decoder=True, sparse_grads=sparse, fused_sqnorm=True)
+                e.grad_sqnorm(from_step=True)                   # (nothing to do: the step left the clip norm)
+            torch.cuda.synchronize()
+            a, b = engines
+            assert a._sq_fused and b._sq_fused
+            # the block-wise clip norm against pv_sae_grad_sqnorm_step's (the same terms in another order: fp32 summation noise apart)
+            fused_sq = float(b.scalars[3])
+            b._sq_fused = False
+            b.grad_sqnorm(from_step=True)
+            torch.cuda.synchronize()
+            assert abs(float(b.scalars[3]) - fused_sq) <= 2e-6 * fused_sq, (float(b.scalars[3]), fused_sq)
+            b.scalars[3] = fused_sq
+            assert torch.equal(a.sae_out, b.sae_out)
+            assert torch.equal(a.scalars[:4], b.scalars[:4]), (a.scalars.tolist(), b.scalars.tolist())
+            assert torch.equal(torch.sort(a.topk_idx[:n], dim=1).values, torch.sort(b.topk_idx[:n], dim=1).values)
+            assert torch.equal(a.fire_count, b.fire_count) and torch.equal(a.act_freq_scores, b.act_freq_scores)
+            if not sparse:
+                assert torch.equal(a.flat_g, b.flat_g), float((a.flat_g - b.flat_g).abs().max())
+            for fold, e in enumerate(engines):
+                NV.set_tuning("sae_fold", fold)
+                e.apply(1e-3, 1.0)
+            torch.cuda.synchronize()
+            for name in ("W_dec", "b_enc", "b_dec"):
+                assert torch.equal(a.params[name], b.params[name]), name
+            assert torch.equal(a.W_encT, b.W_encT) and torch.equal(a.flat_m, b.flat_m) and torch.equal(a.flat_v, b.flat_v)
+    finally:
+        NV.set_tuning("reset")
+
+
 # ---------------------------------------------------------------------------------------------------
 # Transcoder (SURVEY.md 8f row 3; sae/transcoder.py; pv_sae_transcoder) on the two fused steps
 # ---------------------------------------------------------------------------------------------------

@@ -170,7 +170,8 @@ struct PvTuning {
     int attn_direct = 0;     // 1: the one-wave-per-head attention kernel loads its Q / K fragments straight from global (no whole-row staging)
     int prof_markers = 0;    // 1: time v7 launches with hipEventRecord markers instead of dispatch-packet events
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
-    int sae_side = 1;        // 0: pv_sae_step keeps every launch on the caller's stream (no side stream: the A/B of pv_sae_plan.side)
+    int sae_fold = 1;        // 0: pv_sae_step launches its small kernels one by one (the A/B of the fused pre-pass, SaePre, the scan as a role of
+                             // the decode launch, ScanRole, the merged list sorts and the Adam pair's tail roles)
     int enc_rounds = 0;      // 1: the SAE filter GEMM compacts its hits in a round per 32-row block whatever the shape (A/B of the one-round epilogue)
     int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds
     int gemm_loop = -1;      // K loop of the one-workgroup-per-CU kernels (ViT GEMMs, SAE filter GEMM): -1 auto = the full-line form (128-byte

@@ -61,11 +61,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 // stage 2: out[c] = scale * sum_blk partial[blk][c]; 64 columns per workgroup, 16 partial streams per column (the
 // 256 partial rows of a 4096-token batch are 16 loads per thread instead of a 64-deep serial chain)
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            int nblk, int d, float scale) {
+// (returns out[c] on the threads that wrote one -- part 0, c < d -- and 0 elsewhere)
+__device__ __forceinline__ float colsum_final_body(int bid, const float* __restrict__ partial, float* __restrict__ out,
+                                                   int nblk, int d, float scale) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = bid * 64 + lane;
     float s = 0.f;
     if (c < d)
         for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
@@ -76,25 +77,31 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += red[q][lane];        // fixed order
         out[c] = t * scale;
+        return t * scale;
     }
+    return 0.f;
+}
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int nblk, int d, float scale) {
+    (void)colsum_final_body(blockIdx.x, partial, out, nblk, d, scale);
 }
 
 // ------------------------------------------------------------------------------------------------
 // prep: LN-in (sae.py:78-87), sae_in (sae.py:563-565), loss normaliser (sae.py:145-147)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
-                                                       const float* __restrict__ batch_mean, float* __restrict__ sae_in,
-                                                       _Float16* __restrict__ x16, float* __restrict__ xnorm_out,
-                                                       float* __restrict__ mu_out, float* __restrict__ std_out,
-                                                       float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps,
-                                                       int d_true) {
+__device__ __forceinline__ void sae_prep_body(int bid, const float* __restrict__ x, const float* __restrict__ b_dec,
+                                              const float* __restrict__ batch_mean, float* __restrict__ sae_in,
+                                              _Float16* __restrict__ x16, float* __restrict__ xnorm_out,
+                                              float* __restrict__ mu_out, float* __restrict__ std_out,
+                                              float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps,
+                                              int d_true) {
     // d_true < d (a transcoder whose input is narrower than its output, pv_sae_transcoder.d_in_true: rows are padded to the common
     // width d): the statistics run over the d_true real columns, the padding of sae_in / x16 is written as exact zeros
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = bid * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     const float* xr = x + (int64_t)n * d;
-    // batch_mean == NULL: the loss normaliser is left to a later kernel (sae_thr_kernel of the two-stream pre-pass, SaePre)
+    // batch_mean == NULL: the loss normaliser is left to a later kernel (the select kernel of the fused pre-pass, SaePre)
     float s = 0.f, cn = 0.f;
     if (batch_mean) {
         for (int i = lane; i < d_true; i += 64) {
@@ -136,6 +143,51 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
         if (batch_mean) norm_out[n] = sqrtf(cn);
         // ||sae_in||_2 for the filter's error bound; a row outside the fp16 range (or NaN) is sent to the exact path
         if (xnorm_out) xnorm_out[n] = (amax <= 6.0e4f) ? sqrtf(s2) : INFINITY;
+    }
+}
+__global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
+                                                       const float* __restrict__ batch_mean, float* __restrict__ sae_in,
+                                                       _Float16* __restrict__ x16, float* __restrict__ xnorm_out,
+                                                       float* __restrict__ mu_out, float* __restrict__ std_out,
+                                                       float* __restrict__ norm_out, int n_tok, int d, int use_ln, float eps,
+                                                       int d_true) {
+    sae_prep_body(blockIdx.x, x, b_dec, batch_mean, sae_in, x16, xnorm_out, mu_out, std_out, norm_out, n_tok, d, use_ln, eps, d_true);
+}
+// The first launch of the fused pre-pass (SaePre): workgroups [0, nb_prep) = prep without the loss normaliser, [nb_prep, nb_prep + nblk)
+// = the 16-row partial column sums of x (the batch mean's first stage; nblk = 0 when the caller supplied the mean), the last one = the
+// weight bound max_j ||W_enc[:, j]||^2 of the filter's error band + the zeroing of the per-feature pair counters and the fallback
+// count (sae_wmax_kernel of sae_enc.hip on 256 threads; a maximum does not care about the order)
+__global__ __launch_bounds__(256) void sae_prep_roles_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
+                                                             float* __restrict__ sae_in, _Float16* __restrict__ x16,
+                                                             float* __restrict__ xnorm_out, float* __restrict__ mu_out,
+                                                             float* __restrict__ std_out, int n_tok, int d, int use_ln, float eps,
+                                                             int d_true, int nb_prep, float* __restrict__ colpart, int nblk,
+                                                             const float* __restrict__ colsq, int d_sae, float* __restrict__ wmax_out,
+                                                             uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt) {
+    const int b = blockIdx.x;
+    if (b < nb_prep) {
+        sae_prep_body(b, x, b_dec, nullptr, sae_in, x16, xnorm_out, mu_out, std_out, nullptr, n_tok, d, use_ln, eps, d_true);
+    } else if (b < nb_prep + nblk) {
+        colsum_partial_body(b - nb_prep, x, colpart, n_tok, d);
+    } else {
+        __shared__ float red[4];
+        if (feat_cnt)
+            for (int j = threadIdx.x; j < d_sae; j += 256) feat_cnt[j] = 0u;
+        float m = 0.f;
+        for (int j0 = threadIdx.x; j0 < d_sae; j0 += 8 * 256) {     // 8 independent loads in flight per thread
+            float c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = j0 + u * 256 < d_sae ? colsq[j0 + u * 256] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = (c[u] == c[u]) ? fmaxf(m, c[u]) : INFINITY;      // a NaN column norm poisons the bound (-> exact fallback)
+        }
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *wmax_out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            *fb_count = 0u;
+        }
     }
 }
 
@@ -355,6 +407,68 @@ __device__ __forceinline__ void st4_stream(float* p, const float4& v) {
 #endif
 }
 
+// The exclusive scan of csr_scan_kernel as ONE 256-thread workgroup without its LDS staging (a role of the decode launch, see
+// sae_decode_kernel: the scan reads the selection's counts only, so it does not have to wait for the decode kernel -- it runs inside it):
+// every thread owns a contiguous run of counts, sums it with 16-byte loads, the runs are scanned by shuffles, the offsets are written
+// in a second walk over the (cached) counts.  Integer arithmetic: the offsets are csr_scan_kernel's.  Also its other duties: the
+// total (offs[d_sae], scalars[2] = l0) and the zeroing of the long-list counters.  The loss reduction that rides in csr_scan_kernel's
+// workgroup cannot come along (it needs the decode kernel's output): loss_reduce_body, a role of csr_post_fill_kernel.
+struct ScanRole {
+    const uint32_t* cnt; uint32_t* offs; uint32_t* n_long; int d_sae; float* scalars; float inv_tokens;
+};
+__device__ __forceinline__ void scan_body_256(const ScanRole& r) {
+    __shared__ uint32_t sc_wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (((r.d_sae + 255) / 256) + 3) & ~3;
+    const int lo = min(tid * per, r.d_sae), hi = min(lo + per, r.d_sae);
+    const bool quads = (r.d_sae & 3) == 0;                   // (then lo and hi are multiples of four)
+    uint32_t s = 0;
+    {
+        int i = lo;
+        if (quads)
+            for (; i + 4 <= hi; i += 4) {
+                const uint4 c = *reinterpret_cast<const uint4*>(r.cnt + i);
+                s += c.x + c.y + c.z + c.w;
+            }
+        for (; i < hi; ++i) s += r.cnt[i];
+    }
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += a;
+    }
+    if (lane == 63) sc_wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        base += w < wv ? sc_wsum[w] : 0u;
+        total += sc_wsum[w];
+    }
+    uint32_t run = base + inc - s;                           // exclusive prefix of this thread's run
+    {
+        int i = lo;
+        if (quads)
+            for (; i + 4 <= hi; i += 4) {
+                const uint4 c = *reinterpret_cast<const uint4*>(r.cnt + i);
+                uint4 o;
+                o.x = run; o.y = run + c.x; o.z = o.y + c.y; o.w = o.z + c.z;
+                run = o.w + c.w;
+                *reinterpret_cast<uint4*>(r.offs + i) = o;
+            }
+        for (; i < hi; ++i) {
+            const uint32_t c = r.cnt[i];
+            r.offs[i] = run;
+            run += c;
+        }
+    }
+    if (tid == 255) {
+        r.offs[r.d_sae] = total;
+        if (r.scalars) r.scalars[2] = (float)total * r.inv_tokens;      // l0 = mean_n #(val > 0), train_sae.py:364
+    }
+    if (tid == 0) { r.n_long[0] = 0u; r.n_long[1] = 0u; r.n_long[2] = 0u; }      // counters of csr_post_kernel; the ticket of colsum_final_sq_kernel
+}
+
 // MODE 0: the whole thing.  The feature-parallel step cuts it at the reconstruction: MODE 1 = this rank's PARTIAL
 // reconstruction sum_s val_s W_dec[idx_s] only (written to sae_out, no b_dec, no LN-out); MODE 2 = everything behind it, the
 // reconstruction summed over the ranks coming in through pre_sum.
@@ -366,7 +480,12 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     float* __restrict__ dY, float* __restrict__ dh, float* __restrict__ loss_partial, int n_tok, int d, int k,
     float grad_scale /* 2 / (N_global * d_in) */, int want_grad, const float* __restrict__ inv_norm,
     const float* __restrict__ pre_sum = nullptr, const float* __restrict__ addend = nullptr, float dh_add = 0.f,
-    const uint32_t* __restrict__ tok_cnt = nullptr, const uint32_t* __restrict__ gate = nullptr) {
+    const uint32_t* __restrict__ tok_cnt = nullptr, const uint32_t* __restrict__ gate = nullptr, const ScanRole scan = ScanRole{}) {
+    // scan.cnt != NULL: the launch carries one more workgroup than the tokens need, and that one runs the CSR scan (scan_body_256)
+    if (MODE == 0 && scan.cnt && blockIdx.x == gridDim.x - 1) {
+        scan_body_256(scan);
+        return;
+    }
     // the sparse form of the ReLU + L1 step (pv_sae_relu_step): k = the per-token capacity, tok_cnt[n] = the pairs token n holds
     // (front-packed; the rest of the row are holes), dh_add = l1_coefficient / N_global (the L1 term's gradient on every kept
     // activation, sae.py:617-626), gate: the step's mode word -- nonzero = the step runs on the dense GEMMs, leave at once
@@ -502,6 +621,27 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
     }
 }
 
+// The step's loss from the decode kernel's per-token terms: scalars[0] = scalars[1] = loss_scale * sum, in the order of the 1024-thread
+// reduction that rides in csr_scan_kernel's workgroup (thread t of 1024 takes terms t, t + 1024, ...; 16 wave sums; added in wave
+// order) -- here by 256 threads that each play four of those threads, so that the two homes of the reduction agree to the bit.
+__device__ __forceinline__ void loss_reduce_body(const float* __restrict__ loss_part, int n_loss, float loss_scale, float* __restrict__ scalars) {
+    __shared__ float lsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t = 0.f;
+        for (int i = tid + 256 * q; i < n_loss; i += 1024) t += loss_part[i];
+        t = wave_sum(t);
+        if (lane == 0) lsum[wv + 4 * q] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += lsum[w];               // fixed order
+        scalars[0] = t * loss_scale;
+        scalars[1] = t * loss_scale;
+    }
+}
 // ------------------------------------------------------------------------------------------------
 // CSR by feature of the active (token, slot) pairs
 // ------------------------------------------------------------------------------------------------
@@ -589,7 +729,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const uint32_t* __restri
         offs[d_sae] = carry;
         if (scalars) scalars[2] = (float)carry * inv_tokens;            // l0 = mean_n #(val > 0), train_sae.py:364
     }
-    if (tid == 0) { n_long[0] = 0u; n_long[1] = 0u; }                 // counters of csr_post_kernel
+    if (tid == 0) { n_long[0] = 0u; n_long[1] = 0u; n_long[2] = 0u; }   // counters of csr_post_kernel; the ticket of colsum_final_sq_kernel
 }
 
 // Per feature (one thread each), after the scan:
@@ -674,18 +814,23 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict
 // The three passes behind the scan that depend on nothing but it and the decode kernel, as ONE launch (they were three): blocks
 // [0, nb_post) = csr_post, [nb_post, nb_post + nb_fill) = csr_fill, the rest (cs_x != NULL) = the 16-row partial column sums of dY
 // that the bias gradients start from.
+// nb_cs (the column-sum workgroups; 0: none) + one more workgroup when loss_part != NULL: the step's loss (loss_reduce_body: the scan ran as a
+// role of the decode launch and could not take it)
 __global__ __launch_bounds__(256) void csr_post_fill_kernel(const CsrPostArgs a, int nb_post, const int32_t* __restrict__ idx,
                                                             const uint32_t* __restrict__ wpos, int32_t* __restrict__ pairs, int n_pairs,
                                                             int nb_fill, const float* __restrict__ cs_x, float* __restrict__ cs_partial,
-                                                            int cs_rows, int cs_d) {
+                                                            int cs_rows, int cs_d, int nb_cs, const float* __restrict__ loss_part = nullptr,
+                                                            int n_loss = 0, float loss_scale = 0.f, float* __restrict__ scalars = nullptr) {
     const int b = blockIdx.x;
     if (b < nb_post)
         csr_post_body(b, nb_post, a.offs, a.chunk_start, a.max_chunks, a.long_list, a.n_long, a.seg_range, a.max_segs, a.act_freq,
                       a.n_since_fired, a.fire_count, a.d_sae, a.update_stats, a.gb_enc_sparse, a.rowsq_sparse, a.ranged, a.gate);
     else if (b < nb_post + nb_fill)
         csr_fill_body(b - nb_post, idx, wpos, a.offs, pairs, n_pairs);
-    else
+    else if (b < nb_post + nb_fill + nb_cs)
         colsum_partial_body(b - nb_post - nb_fill, cs_x, cs_partial, cs_rows, cs_d);
+    else
+        loss_reduce_body(loss_part, n_loss, loss_scale, scalars);
 }
 
 // The position of a pair inside its feature's list was drawn by an integer atomic in the selection kernel: the SET of a list is
@@ -693,9 +838,9 @@ __global__ __launch_bounds__(256) void csr_post_fill_kernel(const CsrPostArgs a,
 // only up to fp32 summation order.  Short lists (<= BWD_LMAX = 64 pairs: one wave holds a whole list) are put into ascending pair
 // order here (a pair id is token * k + slot and a feature holds a token at most once: token order) with a 64-lane bitonic network;
 // the long lists get the same from sae_long_sort_kernel.  With both, every gradient is bit-reproducible.
-__global__ __launch_bounds__(256) void csr_sort_short_kernel(const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int d_sae) {
+__device__ __forceinline__ void csr_sort_short_body(int bid, const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int d_sae) {
     const int lane = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = bid * 4 + (threadIdx.x >> 6);
     if (f >= d_sae) return;
     const uint32_t o = offs[f];
     const int c = (int)(offs[f + 1] - o);
@@ -710,6 +855,9 @@ __global__ __launch_bounds__(256) void csr_sort_short_kernel(const uint32_t* __r
             v = (lower == up) ? min(v, other) : max(v, other);
         }
     if (lane < c) pairs[o + lane] = v;
+}
+__global__ __launch_bounds__(256) void csr_sort_short_kernel(const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs, int d_sae) {
+    csr_sort_short_body(blockIdx.x, offs, pairs, d_sae);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -868,17 +1016,18 @@ __global__ __launch_bounds__(256) void sae_backward_kernel(
 // the segment kernel gives range r to the workgroups of XCD r (3 MB of rows per L2).  A feature's pairs are DISTINCT tokens,
 // so the sort is a scatter into a token-indexed LDS array + a compaction -- which also makes the summation order of these
 // lists independent of the order the select kernel's atomics drew their positions in.  One workgroup per long feature.
-__global__ __launch_bounds__(256) void sae_long_sort_kernel(int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
-                                                            const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs,
-                                                            uint32_t* __restrict__ seg_range, int k, int n_tok, int max_segs) {
-    extern __shared__ int32_t slot[];                      // [n_tok] token -> pair (or -1)
+// bid / nblocks: this workgroup's index among the nblocks that sort long lists (a launch of its own, or the leading block range of csr_sort_kernel)
+__device__ __forceinline__ void sae_long_sort_body(int bid, int nblocks, int32_t* __restrict__ slot, int32_t* __restrict__ long_list,
+                                                   uint32_t* __restrict__ n_long, const uint32_t* __restrict__ offs,
+                                                   int32_t* __restrict__ pairs, uint32_t* __restrict__ seg_range, int k, int n_tok,
+                                                   int max_segs) {
     __shared__ uint32_t wsum[4], bnd[BWD_RANGES + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t nl = n_long[0];
-    if (blockIdx.x == 0 && tid == 0) n_long[1] = min(nl * BWD_RANGES, (uint32_t)max_segs);
+    if (bid == 0 && tid == 0) n_long[1] = min(nl * BWD_RANGES, (uint32_t)max_segs);
     const int chunk = (n_tok + 255) / 256;
     const int rs = (n_tok + BWD_RANGES - 1) / BWD_RANGES;
-    for (uint32_t e = blockIdx.x; e < nl; e += gridDim.x) {
+    for (uint32_t e = bid; e < nl; e += nblocks) {
         const int j = long_list[3 * e];
         const uint32_t beg = offs[j], c = offs[j + 1] - beg;
         __syncthreads();
@@ -922,6 +1071,21 @@ __global__ __launch_bounds__(256) void sae_long_sort_kernel(int32_t* __restrict_
             long_list[3 * e + 2] = BWD_RANGES;
         }
     }
+}
+__global__ __launch_bounds__(256) void sae_long_sort_kernel(int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                            const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs,
+                                                            uint32_t* __restrict__ seg_range, int k, int n_tok, int max_segs) {
+    extern __shared__ int32_t slot[];                      // [n_tok] token -> pair (or -1)
+    sae_long_sort_body(blockIdx.x, gridDim.x, slot, long_list, n_long, offs, pairs, seg_range, k, n_tok, max_segs);
+}
+// Both list sorts as ONE launch (they touch disjoint lists): workgroups [0, nb_long) = the long lists (first: they are the longer jobs),
+// the rest = the short lists, four features per workgroup.  The launch carries the long sort's LDS (4 bytes per token).
+__global__ __launch_bounds__(256) void csr_sort_kernel(int nb_long, int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long,
+                                                       const uint32_t* __restrict__ offs, int32_t* __restrict__ pairs,
+                                                       uint32_t* __restrict__ seg_range, int k, int n_tok, int max_segs, int d_sae) {
+    extern __shared__ int32_t slot[];
+    if ((int)blockIdx.x < nb_long) sae_long_sort_body(blockIdx.x, nb_long, slot, long_list, n_long, offs, pairs, seg_range, k, n_tok, max_segs);
+    else csr_sort_short_body(blockIdx.x - nb_long, offs, pairs, d_sae);
 }
 
 // long lists, stage 1: one wave per segment -> partial rows in scratch  [segment][gd | ge][d] (+ gb).  Segments are BWD_SEG-pair
@@ -1106,6 +1270,62 @@ __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restr
     }
 }
 
+// The step's last launch with the clip norm in it (PV_SAE_FUSED_SQNORM).  Workgroup b of the nb that finish gb_dec (64 columns each)
+// also takes block b of the clip norm: the squares of its own 64 columns + the b-th of nb slices of the backward's per-feature terms
+// (rowsq) -> sqpart[b]; the workgroup that finishes LAST (a ticket from an agent-scope acq_rel counter; the partials travel as
+// agent-scope atomics, so no cache of another XCD can hold a stale one) adds the nb partials in block order -> scalars[3] and re-arms
+// the counter.  The sum is a fixed function of the inputs: which workgroup comes last does not enter it.  sq_block_terms is that
+// block's arithmetic, shared with the one-workgroup form (sqnorm_blocks_kernel: the same bits from a launch of its own).
+__device__ __forceinline__ float sq_block_terms(int b, int nb, float g, const float* __restrict__ rowsq, int d_sae, float* red16) {
+    // g: this thread's column of block b (threads of wave 0; 0 elsewhere)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slice = (d_sae + nb - 1) / nb, lo = b * slice, hi = min(lo + slice, d_sae);
+    float sr = 0.f;
+    for (int j = lo + (int)threadIdx.x; j < hi; j += 1024) sr += rowsq[j];
+    sr = wave_sum(sr);
+    const float gg = wave_sum(g * g);                        // (only wave 0's matters)
+    __syncthreads();
+    if (lane == 0) red16[wv] = sr;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; ++w) t += red16[w];          // fixed order
+        t += gg;
+    }
+    return t;                                                // (thread 0)
+}
+__global__ __launch_bounds__(1024) void colsum_final_sq_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int d,
+                                                               const float* __restrict__ rowsq, int d_sae, float* __restrict__ sqpart,
+                                                               uint32_t* __restrict__ ticket, float* __restrict__ scalars) {
+    __shared__ float red16[16];
+    const int b = blockIdx.x, nb = gridDim.x;
+    const float g = colsum_final_body(b, partial, out, nblk, d, 1.0f);
+    const float t = sq_block_terms(b, nb, g, rowsq, d_sae, red16);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&sqpart[b], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine == (uint32_t)nb - 1u) {
+            float total = 0.f;
+            for (int i = 0; i < nb; ++i) total += __hip_atomic_load(&sqpart[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            scalars[3] = total;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// the same sum from a launch of its own (gb_dec finished by the launch before): one workgroup walks the blocks
+__global__ __launch_bounds__(1024) void sqnorm_blocks_kernel(const float* __restrict__ gb_dec, int d, const float* __restrict__ rowsq,
+                                                             int d_sae, float* __restrict__ scalars) {
+    __shared__ float red16[16];
+    const int nb = (d + 63) / 64;
+    float total = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        const int c = b * 64 + (int)threadIdx.x;
+        const float g = (threadIdx.x < 64 && c < d) ? gb_dec[c] : 0.f;
+        total += sq_block_terms(b, nb, g, rowsq, d_sae, red16);
+    }
+    if (threadIdx.x == 0) scalars[3] = total;
+}
+
 // gb_dec = colsum(dY) - W_enc gb_enc (the encoder-input path of b_dec: sae_in = x - b_dec).  The second term as partial rows
 // for colsum_final_kernel, stacked under the dY partials with the sign folded in: workgroup c sums -gb_enc[j] * W_encT[j][:]
 // over its GBD_ROWS features, skipping the features no token kept (gb_enc = 0: half of them on the bench batch), so the
@@ -1155,40 +1375,6 @@ __global__ __launch_bounds__(256) void sae_gbdec_partial_kernel(const float* __r
                                                                 float* __restrict__ partial, int d_sae, int d) {
     gbdec_partial_body(blockIdx.x, W_encT, gb_enc, partial, d_sae, d);
 }
-// The step's loss from the decode kernel's per-token terms: scalars[0] = scalars[1] = loss_scale * sum, in the order of the 1024-thread
-// reduction that rides in csr_scan_kernel's workgroup (thread t of 1024 takes terms t, t + 1024, ...; 16 wave sums; added in wave
-// order) -- here by 256 threads that each play four of those threads, so that the two homes of the reduction agree to the bit.
-__device__ __forceinline__ void loss_reduce_body(const float* __restrict__ loss_part, int n_loss, float loss_scale, float* __restrict__ scalars) {
-    __shared__ float lsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float t = 0.f;
-        for (int i = tid + 256 * q; i < n_loss; i += 1024) t += loss_part[i];
-        t = wave_sum(t);
-        if (lane == 0) lsum[wv + 4 * q] = t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += lsum[w];               // fixed order
-        scalars[0] = t * loss_scale;
-        scalars[1] = t * loss_scale;
-    }
-}
-// What stands between the sparse backward and the column sum that finishes gb_dec, as ONE launch (the two-stream form of pv_sae_step,
-// whose CSR build no longer waits for the decode kernel and so cannot carry the decode kernel's reductions): blocks [0, ngb) = the
-// encoder-path partial rows (gbdec_partial_body), [ngb, ngb + nblk) = the 16-row partial column sums of dY, the last one = the loss.
-__global__ __launch_bounds__(256) void sae_gbdec_tail_kernel(const float* __restrict__ W_encT, const float* __restrict__ gb_enc,
-                                                             float* __restrict__ colpart, int d_sae, int d, int ngb,
-                                                             const float* __restrict__ dY, int n_tok, int nblk,
-                                                             const float* __restrict__ loss_part, float loss_scale,
-                                                             float* __restrict__ scalars) {
-    const int b = blockIdx.x;
-    if (b < ngb) gbdec_partial_body(b, W_encT, gb_enc, colpart + (int64_t)nblk * d, d_sae, d);
-    else if (b < ngb + nblk) colsum_partial_body(b - ngb, dY, colpart, n_tok, d);
-    else loss_reduce_body(loss_part, n_tok, loss_scale, scalars);
-}
 
 // ------------------------------------------------------------------------------------------------
 // gradient square-norm (two stage, deterministic)
@@ -1224,6 +1410,29 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
     v = v * c.b2 + (1.f - c.b2) * g * g;                    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
     const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
     return w - (c.lr / c.bc1) * (m / denom);
+}
+
+// two vectors in one launch (b_enc's feature range and b_dec): blocks [0, nb0) take the first
+struct AdamVec2 {
+    float* W0; const float* G0; float* M0; float* V0; int lo0, hi0, nb0;
+    float* W1; const float* G1; float* M1; float* V1; int hi1;
+};
+__device__ __forceinline__ void adam_vec2_body(int bid, const AdamVec2& a, const float* __restrict__ scalars, const AdamC& c) {
+    const bool first = bid < a.nb0;
+    const int i = first ? a.lo0 + bid * 256 + threadIdx.x : (bid - a.nb0) * 256 + threadIdx.x;
+    if (i >= (first ? a.hi0 : a.hi1)) return;
+    float* W = first ? a.W0 : a.W1;
+    const float* G = first ? a.G0 : a.G1;
+    float* M = first ? a.M0 : a.M1;
+    float* V = first ? a.V0 : a.V1;
+    const float coef = clip_coef(scalars, c.max_norm);
+    float m = M[i], v = V[i];
+    W[i] = adam_update(W[i], G[i] * coef, m, v, c);
+    M[i] = m;
+    V[i] = v;
+}
+__global__ __launch_bounds__(256) void adam_vec2_kernel(const AdamVec2 a, const float* __restrict__ scalars, AdamC c) {
+    adam_vec2_body(blockIdx.x, a, scalars, c);
 }
 
 template <int V4>   // W_dec rows [j_lo, j_hi): one wave per row (16 bytes per lane and load), with the parallel-gradient projection
@@ -1289,7 +1498,12 @@ template <int V4>
 __global__ __launch_bounds__(256) void adam_wenct_kernel(float* __restrict__ WT, _Float16* __restrict__ W16T, float* __restrict__ colsq,
                                                          const float* __restrict__ GT, float* __restrict__ MT, float* __restrict__ VT,
                                                          const float* __restrict__ scalars, AdamC c, int j_lo, int j_hi, int d,
-                                                         const uint32_t* __restrict__ live_offs) {
+                                                         const uint32_t* __restrict__ live_offs, int nb_rows, const AdamVec2 v2) {
+    // workgroups beyond nb_rows (v2.nb0 + the blocks of b_dec of them): the two bias vectors' Adam (adam_vec2_body) -- it was a launch
+    if ((int)blockIdx.x >= nb_rows) {
+        adam_vec2_body(blockIdx.x - nb_rows, v2, scalars, c);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int j = j_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= j_hi) return;
@@ -1456,25 +1670,6 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float* __restrict__ W, co
     V[i] = v;
 }
 
-// two vectors in one launch (b_enc's feature range and b_dec): blocks [0, nb0) take the first
-__global__ __launch_bounds__(256) void adam_vec2_kernel(float* __restrict__ W0, const float* __restrict__ G0, float* __restrict__ M0,
-                                                        float* __restrict__ V0, int lo0, int hi0, int nb0, float* __restrict__ W1,
-                                                        const float* __restrict__ G1, float* __restrict__ M1, float* __restrict__ V1,
-                                                        int hi1, const float* __restrict__ scalars, AdamC c) {
-    const bool first = (int)blockIdx.x < nb0;
-    const int i = first ? lo0 + blockIdx.x * 256 + threadIdx.x : ((int)blockIdx.x - nb0) * 256 + threadIdx.x;
-    if (i >= (first ? hi0 : hi1)) return;
-    float* W = first ? W0 : W1;
-    const float* G = first ? G0 : G1;
-    float* M = first ? M0 : M1;
-    float* V = first ? V0 : V1;
-    const float coef = clip_coef(scalars, c.max_norm);
-    float m = M[i], v = V[i];
-    W[i] = adam_update(W[i], G[i] * coef, m, v, c);
-    M[i] = m;
-    V[i] = v;
-}
-
 // 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm): a wave takes four rows, all loads in flight
 __global__ __launch_bounds__(256) void dec_inv_norm_kernel(const float* __restrict__ W, float* __restrict__ inv, int rows, int d) {
     const int lane = threadIdx.x & 63;
@@ -1531,6 +1726,20 @@ int launch_long_sort(int32_t* long_list, uint32_t* n_long, const uint32_t* offs,
     hipLaunchKernelGGL(sae_long_sort_kernel, dim3(512), dim3(256), (size_t)N * 4, stream, long_list, n_long, offs, pairs, seg_range, k, N,
                        max_segs);
     PV_LAUNCH_CHECK("sae_long_sort_kernel");
+    return PV_OK;
+}
+int launch_csr_sort(int32_t* long_list, uint32_t* n_long, const uint32_t* offs, int32_t* pairs, uint32_t* seg_range, int k, int N,
+                    int max_segs, int d_sae, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        PV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&csr_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         150 * 1024));
+        attr_done = true;
+    }
+    const int nb_long = 512;
+    hipLaunchKernelGGL(csr_sort_kernel, dim3(nb_long + (d_sae + 3) / 4), dim3(256), (size_t)N * 4, stream, nb_long, long_list, n_long, offs,
+                       pairs, seg_range, k, N, max_segs, d_sae);
+    PV_LAUNCH_CHECK("csr_sort_kernel");
     return PV_OK;
 }
 
@@ -1644,45 +1853,7 @@ extern "C" int pv_sae_plan_create(const pv_sae_desc* desc, pv_sae_plan** out_pla
     *out_plan = p;
     return PV_OK;
 }
-extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) {
-    if (!plan) return;
-    if (plan->side) {
-        (void)hipStreamSynchronize(plan->side);
-        for (int i = 0; i < 2; ++i) {
-            if (plan->ev_fork[i]) (void)hipEventDestroy(plan->ev_fork[i]);
-            if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
-        }
-        (void)hipStreamDestroy(plan->side);
-    }
-    delete plan;
-}
-
-int sae_side_fork(pv_sae_plan* plan, hipStream_t main, int i, hipStream_t* side) {
-    *side = nullptr;
-    if (!g_pv_tuning.sae_side || g_pv_tuning.sae_side == 3 - i) return PV_OK;      // (2 / 3: fork 0 / fork 1 only -- the A/B of each)
-    int dev = 0;
-    PV_HIP_CHECK(hipGetDevice(&dev));
-    if (!plan->side) {
-        PV_HIP_CHECK(hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking));
-        for (int e = 0; e < 2; ++e) {
-            // (no system-scope fence at these events: both streams are on this device, and the fence's L2 write-back + invalidate is
-            // paid by every kernel behind it)
-            PV_HIP_CHECK(hipEventCreateWithFlags(&plan->ev_fork[e], hipEventDisableTiming | hipEventDisableSystemFence));
-            PV_HIP_CHECK(hipEventCreateWithFlags(&plan->ev_join[e], hipEventDisableTiming | hipEventDisableSystemFence));
-        }
-        plan->side_dev = dev;
-    }
-    PV_REQUIRE(plan->side_dev == dev, "pv_sae_step: this plan's side stream belongs to another device (one plan per device)");
-    PV_HIP_CHECK(hipEventRecord(plan->ev_fork[i], main));
-    PV_HIP_CHECK(hipStreamWaitEvent(plan->side, plan->ev_fork[i], 0));
-    *side = plan->side;
-    return PV_OK;
-}
-int sae_side_join(pv_sae_plan* plan, hipStream_t main, int i) {
-    PV_HIP_CHECK(hipEventRecord(plan->ev_join[i], plan->side));
-    PV_HIP_CHECK(hipStreamWaitEvent(main, plan->ev_join[i], 0));
-    return PV_OK;
-}
+extern "C" void pv_sae_plan_destroy(pv_sae_plan* plan) { delete plan; }
 extern "C" size_t pv_sae_workspace_bytes(const pv_sae_plan* plan) { return plan ? sae_carve(plan->d).total : 0; }
 extern "C" int pv_sae_encoder_is_filtered(const pv_sae_plan* plan) { return plan && pv_sae_fast_ok(plan->d) ? 1 : 0; }
 // debug / tests: byte offset of a named region of the workspace ("fb_count": uint32 number of tokens of the last encode that
@@ -1818,18 +1989,26 @@ int sae_tc_target_norm(const pv_sae_desc& d, const pv_sae_state* st, const float
 // batch mean (given, or computed from x) -> ws.batch_mean; LN-in, sae_in, loss normaliser (+ the fp16 copy / row norms the
 // filtered encoder wants) -> ws.sae_in, ws.mu, ws.sd, ws.norm (ws.x16, ws.xnorm)
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true, hipStream_t mean_stream) {
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true, SaePre* pre, const pv_sae_state* st, uint32_t* feat_cnt) {
     float* bmean = (float*)(wsb + ws.batch_mean);
-    hipStream_t ms = mean_stream ? mean_stream : stream;
-    if (batch_mean) {
-        PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, ms));
-    } else {
-        const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, ms, x, (float*)(wsb + ws.colpart), N, d.d_in);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, ms,
+    const int nblk = (N + CS_ROWS - 1) / CS_ROWS;
+    if (batch_mean) PV_HIP_CHECK(hipMemcpyAsync(bmean, batch_mean, (size_t)d.d_in * 4, hipMemcpyDeviceToDevice, stream));
+    if (pre) {                                                   // the fused pre-pass (SaePre): one launch, the mean and the normaliser come later
+        pre->x = x; pre->d_true = d_true > 0 ? d_true : d.d_in; pre->have_mean = batch_mean != nullptr;
+        const int nb_prep = (N + 3) / 4, nb_cs = batch_mean ? 0 : nblk;
+        hipLaunchKernelGGL(sae_prep_roles_kernel, dim3(nb_prep + nb_cs + 1), dim3(256), 0, stream, x, b_dec, (float*)(wsb + ws.sae_in),
+                           (_Float16*)(wsb + ws.x16), (float*)(wsb + ws.xnorm), (float*)(wsb + ws.mu), (float*)(wsb + ws.sd), N, d.d_in,
+                           d.normalize_layer_norm, d.ln_eps, pre->d_true, nb_prep, (float*)(wsb + ws.colpart), nb_cs,
+                           (const float*)st->enc_colsq, d.d_sae, (float*)(wsb + ws.wmax), (uint32_t*)(wsb + ws.fb_count), feat_cnt);
+        PV_LAUNCH_CHECK("sae_prep_roles_kernel");
+        return PV_OK;
+    }
+    if (!batch_mean) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, x, (float*)(wsb + ws.colpart), N, d.d_in);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
                            (const float*)(wsb + ws.colpart), bmean, nblk, d.d_in, 1.0f / (float)N);
     }
-    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, mean_stream ? (const float*)nullptr : (const float*)bmean,
+    hipLaunchKernelGGL(sae_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, b_dec, (const float*)bmean,
                        (float*)(wsb + ws.sae_in), want_filter_inputs ? (_Float16*)(wsb + ws.x16) : (_Float16*)nullptr,
                        want_filter_inputs ? (float*)(wsb + ws.xnorm) : (float*)nullptr, (float*)(wsb + ws.mu), (float*)(wsb + ws.sd),
                        (float*)(wsb + ws.norm), N, d.d_in, d.normalize_layer_norm, d.ln_eps, d_true > 0 ? d_true : d.d_in);
@@ -1840,27 +2019,19 @@ int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const flo
 // gb_dec = colsum(dY) - W_enc @ gb_enc (the encoder-input path of b_dec): both terms as partial rows of one column sum
 // have_colsum: the partial column sums of dY are in ws.colpart already (csr_post_fill_kernel)
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
-              hipStream_t stream, bool have_colsum) {
+              hipStream_t stream, bool have_colsum, float* sq_scalars) {
     const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
     float* colpart = (float*)(wsb + ws.colpart);
     if (!have_colsum) hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, stream, dY, colpart, N, d.d_in);
     hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
                        colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
-                       nblk + ngb, d.d_in, 1.0f);
-    PV_LAUNCH_CHECK("sae bias-grad kernels");
-    return PV_OK;
-}
-
-// sae_gbdec with the decode kernel's two reductions in its first launch (sae_gbdec_tail_kernel)
-static int sae_gbdec_tail(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
-                          const float* loss_part, float loss_scale, float* scalars, hipStream_t stream) {
-    const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
-    float* colpart = (float*)(wsb + ws.colpart);
-    hipLaunchKernelGGL(sae_gbdec_tail_kernel, dim3(ngb + nblk + 1), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
-                       colpart, d.d_sae, d.d_in, ngb, dY, N, nblk, loss_part, loss_scale, scalars);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
-                       nblk + ngb, d.d_in, 1.0f);
+    if (sq_scalars)                 // PV_SAE_FUSED_SQNORM: the clip norm out of the same launch (the ticket word: n_long[2], zeroed by the scan)
+        hipLaunchKernelGGL(colsum_final_sq_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                           nblk + ngb, d.d_in, (const float*)(wsb + ws.rowsq), d.d_sae, (float*)(wsb + ws.sqpart),
+                           (uint32_t*)(wsb + ws.n_long) + 2, sq_scalars);
+    else
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                           nblk + ngb, d.d_in, 1.0f);
     PV_LAUNCH_CHECK("sae bias-grad kernels");
     return PV_OK;
 }
@@ -1905,21 +2076,19 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     uint32_t* wpos = want_csr ? (wpos_over ? wpos_over : (uint32_t*)(wsb + ws.wpos)) : nullptr;
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
-    // the training step's pre-pass on two streams: batch mean + weight bound (three launch-bound kernels) beside prep + the sample GEMM
-    SaePre pre = {plan, nullptr, x, sae_in_width(d, st)};
-    if (fast && want_csr && !skip_prep && !cnt_over) {
-        int rcf = sae_side_fork(plan, stream, 0, &pre.side);
-        if (rcf) return rcf;
-    }
+    // the training step's pre-pass in fused launches (SaePre)
+    SaePre pre = {x, 0, false};
+    const bool fused = fast && want_csr && !skip_prep && !cnt_over && g_pv_tuning.sae_fold;
     if (!skip_prep) {
-        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st), pre.side);
+        int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st), fused ? &pre : nullptr,
+                           st, feat_cnt);
         if (rcp) return rcp;
     }
     // algorithmic work of the encoder: 2 N d_in d_sae FLOP; bytes = operands once (x, W_enc as fp16) + the k results
     ProfScope prof(PV_PROF_SAE_ENC, stream, 2.0 * N * (double)d.d_in * d.d_sae,
                    ((double)N * d.d_in + (double)d.d_in * d.d_sae) * (fast ? 2.0 : 4.0) + (double)N * d.k * 8.0 +
                        (fast ? 0.0 : (double)N * d.d_sae * 8.0));
-    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, feat_cnt, wpos, wsb, ws, stream, pre.side ? &pre : nullptr);
+    if (fast) return sae_encode_fast(d, st, N, topk_idx, topk_val, feat_cnt, wpos, wsb, ws, stream, fused ? &pre : nullptr);
     {
         // exact path: hidden_pre = sae_in @ W_enc + b_enc (sae.py:567-574) on the fp32 MFMA, W_enc in its own [d_in][d_sae] layout
         GemmParams g = {};
@@ -1991,11 +2160,13 @@ extern "C" int pv_sae_forward(pv_sae_plan* plan, const pv_sae_state* st, const f
 // cs_here: also the 16-row partial column sums of dY.  val_b / dYb: the second decoder term of a pair (bwd_walk<DUAL>: the gated step).
 // The two halves of sae_csr_backward.  sae_csr_build: the CSR by feature -- scan, chunk cuts / long lists / statistics / pair scatter, the
 // two list sorts; it reads the selection's output only (counts, positions, indices), so with loss_part == NULL and cs_here false it
-// does not wait for the decode kernel and may run beside it (pv_sae_step's side stream).  sae_csr_grads: the backward kernels.
+// does not wait for the decode kernel.  sae_csr_grads: the backward kernels.
 static int sae_csr_build(pv_sae_plan* plan, pv_sae_state* st, int N, int k, const int32_t* topk_idx, const float* dY, float* scalars,
                          float* fire_count, int update_stats, bool sparse, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws,
                          const float* loss_part, float loss_scale, bool cs_here, const uint32_t* gate, hipStream_t stream,
-                         const uint32_t* cnt_in) {
+                         const uint32_t* cnt_in, bool folded = false) {
+    // folded (pv_sae_step): the scan has run as a role of the decode launch (ScanRole); the loss rides in the post + fill launch, the two
+    // list sorts are one launch -- two launches here instead of four
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
@@ -2014,8 +2185,9 @@ static int sae_csr_build(pv_sae_plan* plan, pv_sae_state* st, int N, int k, cons
         uint32_t* seg_range = tb.seg_range;
         // (the scan's workgroup also reduces the loss: loss = mse_loss = sum / (N_global * d_in), sae.py:148; topk: loss == mse_loss,
         // :620-626 -- scalars[0] = scalars[1])
-        hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, offs, n_long, d.d_sae,
-                           scalars, 1.0f / (float)N, loss_part, loss_part ? N : 0, loss_scale);
+        if (!folded)
+            hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, stream, cnt, offs, n_long, d.d_sae,
+                               scalars, 1.0f / (float)N, loss_part, loss_part ? N : 0, loss_scale);
         // chunk cuts / long lists / statistics, the scatter of the pairs and (autoencoder) the partial column sums of dY: one launch
         {
             CsrPostArgs pa;
@@ -2024,11 +2196,18 @@ static int sae_csr_build(pv_sae_plan* plan, pv_sae_state* st, int N, int k, cons
             pa.fire_count = fire_count; pa.d_sae = d.d_sae; pa.update_stats = update_stats; pa.gb_enc_sparse = sparse ? st->gb_enc : nullptr;
             pa.rowsq_sparse = sparse ? rowsq : nullptr; pa.ranged = sae_long_ranged(N) ? 1 : 0; pa.gate = gate;
             const int nb_post = (d.d_sae + 255) / 256, nb_fill = (n_pairs + 255) / 256, nb_cs = cs_here ? (N + CS_ROWS - 1) / CS_ROWS : 0;
-            hipLaunchKernelGGL(csr_post_fill_kernel, dim3(nb_post + nb_fill + nb_cs), block, 0, stream, pa, nb_post, topk_idx,
-                               (const uint32_t*)tb.wpos, pairs, n_pairs, nb_fill, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in);
+            const int nb_loss = (folded && loss_part) ? 1 : 0;
+            hipLaunchKernelGGL(csr_post_fill_kernel, dim3(nb_post + nb_fill + nb_cs + nb_loss), block, 0, stream, pa, nb_post, topk_idx,
+                               (const uint32_t*)tb.wpos, pairs, n_pairs, nb_fill, (const float*)dY, (float*)(wsb + ws.colpart), N, d.d_in,
+                               nb_cs, nb_loss ? loss_part : (const float*)nullptr, N, loss_scale, scalars);
+        }
+        const int ranged = sae_long_ranged(N) ? 1 : 0;
+        if (folded && ranged) {
+            rc = launch_csr_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, d.d_sae, stream);
+            if (rc) return rc;
+            return PV_OK;
         }
         hipLaunchKernelGGL(csr_sort_short_kernel, dim3((d.d_sae + 3) / 4), dim3(256), 0, stream, (const uint32_t*)offs, pairs, d.d_sae);
-        const int ranged = sae_long_ranged(N) ? 1 : 0;
         if (ranged) {
             rc = launch_long_sort(long_list, n_long, (const uint32_t*)offs, pairs, seg_range, k, N, max_segs, stream);
             if (rc) return rc;
@@ -2111,7 +2290,7 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
                     const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
                     const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
                     const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
-                    bool bias_grads) {
+                    bool bias_grads, float* sq_scalars) {
     const pv_sae_desc& d = plan->d;
     const int n_pairs = N * k;
     int rc = PV_OK;
@@ -2123,41 +2302,32 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));      // (a transcoder: the mean is over N x d_out)
         const float loss_scale = 1.0f / ((float)n_global * (float)sae_loss_width(d, st));
         const dim3 grid((N + 3) / 4), block(256);
-        // pv_sae_step on an autoencoder: the CSR build (four launch-bound kernels that read the selection's output only) runs on the
-        // plan's side stream beside the decode kernel; the decode kernel's two reductions move to the bias gradients' first launch
-        hipStream_t side = nullptr;
-        if (bias_grads && !tc && !gate && !tok_cnt) {
-            rc = sae_side_fork(plan, stream, 1, &side);
-            if (rc) return rc;
+        // pv_sae_step: the CSR scan reads the selection's counts only -- it runs as one more workgroup of the decode launch (ScanRole)
+        const bool folded = bias_grads && !gate && !tok_cnt && g_pv_tuning.sae_fold != 0;
+        ScanRole scan = {};
+        if (folded) {
+            scan.cnt = (const uint32_t*)(wsb + ws.cnt); scan.offs = (uint32_t*)(wsb + ws.offs); scan.n_long = (uint32_t*)(wsb + ws.n_long);
+            scan.d_sae = d.d_sae; scan.scalars = scalars; scan.inv_tokens = 1.0f / (float)N;
         }
-        if (side) {
-            rc = sae_csr_build(plan, st, N, k, topk_idx, dY, scalars, fire_count, update_stats, sparse, tb, wsb, ws, nullptr, 0.f, false,
-                               gate, side, nullptr);
-            if (rc) return rc;
-        }
+        const dim3 grid_dec((N + 3) / 4 + (folded ? 1 : 0));
 #define CALL(D)                                                                                                      \
-    hipLaunchKernelGGL((sae_decode_kernel<D>), grid, block, 0, stream, y, (const float*)st->W_dec, bdo,              \
+    hipLaunchKernelGGL((sae_decode_kernel<D>), grid_dec, block, 0, stream, y, (const float*)st->W_dec, bdo,          \
                        topk_idx, topk_val, (const float*)(wsb + ws.mu),      \
                        (const float*)(wsb + ws.sd), (const float*)(wsb + ws.norm), sae_out, dY, dh,             \
-                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip, dh_add, tok_cnt, gate)
+                       (float*)(wsb + ws.loss_part), N, d.d_in, k, grad_scale, 1, inv_norm, (const float*)nullptr, skip, dh_add, tok_cnt, gate, scan)
         V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         PV_LAUNCH_CHECK("sae_decode_kernel");
-        if (side) {
-            rc = sae_side_join(plan, stream, 1);
-            if (rc) return rc;
-            rc = sae_csr_grads(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, sparse, tb, wsb, ws, gate, stream, nullptr, nullptr);
-            if (rc) return rc;
-            return sae_gbdec_tail(d, st, dY, N, wsb, ws, (const float*)(wsb + ws.loss_part), loss_scale, scalars, stream);
-        }
         const bool cs_here = bias_grads && !tc;
-        rc = sae_csr_backward(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
-                              (const float*)(wsb + ws.loss_part), loss_scale, cs_here, gate, stream);
+        rc = sae_csr_build(plan, st, N, k, topk_idx, dY, scalars, fire_count, update_stats, sparse, tb, wsb, ws,
+                           (const float*)(wsb + ws.loss_part), loss_scale, cs_here, gate, stream, nullptr, folded);
+        if (rc) return rc;
+        rc = sae_csr_grads(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, sparse, tb, wsb, ws, gate, stream, nullptr, nullptr);
         if (rc) return rc;
         // gb_dec = colsum(dY) - W_enc @ gb_enc: both terms as partial rows of one column sum
         // (bias_grads false: pv_sae_relu_step runs them once, behind whichever of its two forms produced dY and gb_enc)
         if (bias_grads) {
-            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream, cs_here);
+            rc = tc ? sae_tc_bias_grads(d, st, dY, N, wsb, ws, stream) : sae_gbdec(d, st, dY, N, wsb, ws, stream, cs_here, sq_scalars);
             if (rc) return rc;
             if (tc) {
                 rc = sae_tc_skip_backward(d, st, x, dY, N, stream);
@@ -2764,8 +2934,11 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     const int update_stats = (flags & PV_SAE_UPDATE_STATS) ? 1 : 0;
     const bool renorm = (flags & PV_SAE_RENORM_DECODER) != 0;
     const bool sparse = (flags & PV_SAE_SPARSE_GRADS) != 0;
+    const bool fused_sq = (flags & PV_SAE_FUSED_SQNORM) != 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
+    PV_REQUIRE(!fused_sq || st->tc.b_dec_out == nullptr,
+               "PV_SAE_FUSED_SQNORM: autoencoder states (a transcoder's clip norm has more terms: pv_sae_grad_sqnorm_step)");
     PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
     PV_REQUIRE(st->W_encT, "pv_sae_step needs the transposed encoder copy (pv_sae_state.W_encT, see pv_sae_sync_shadows)");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");
@@ -2817,8 +2990,14 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     tb.seg_range = (uint32_t*)(wsb + ws.seg_range); tb.seg_rows = (float*)(wsb + ws.seg_rows); tb.seg_b = (float*)(wsb + ws.seg_b);
     tb.pairs = (int32_t*)(wsb + ws.pairs); tb.max_segs = (int)sae_max_segs((size_t)n_pairs);
     rc = sae_sparse_tail(plan, st, x, N, n_global, k, out->topk_idx, out->topk_val, out->sae_out, out->scalars, out->fire_count,
-                         update_stats, sparse, inv_norm, tb, wsb, ws, y, bdo, skip, tc, 0.0f, nullptr, nullptr, stream);
+                         update_stats, sparse, inv_norm, tb, wsb, ws, y, bdo, skip, tc, 0.0f, nullptr, nullptr, stream, true,
+                         (fused_sq && g_pv_tuning.sae_fold) ? out->scalars : (float*)nullptr);
     if (rc) return rc;
+    if (fused_sq && !g_pv_tuning.sae_fold) {                          // (the A/B of the folds: the same sum as a launch of its own)
+        hipLaunchKernelGGL(sqnorm_blocks_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->gb_dec, d.d_in,
+                           (const float*)(wsb + ws.rowsq), d.d_sae, out->scalars);
+        PV_LAUNCH_CHECK("sqnorm_blocks_kernel");
+    }
     return PV_OK;
 }
 
@@ -3143,6 +3322,10 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
     // algorithmic bytes: 7 x 4 per parameter (w, g, m, v read; w, m, v written) + the two extra copies of W_enc (fp32 + fp16)
     ProfScope prof(PV_PROF_SAE_APPLY, stream, 0.0, 7.0 * 4.0 * (2.0 * d.d_in * (double)nj + nj + d.d_in) + 6.0 * d.d_in * (double)nj);
     const dim3 block(256);
+    AdamVec2 v2;
+    v2.W0 = st->b_enc; v2.G0 = (const float*)st->gb_enc; v2.M0 = st->mb_enc; v2.V0 = st->vb_enc; v2.lo0 = j_lo; v2.hi0 = j_hi;
+    v2.nb0 = (nj + 255) / 256; v2.W1 = st->b_dec; v2.G1 = (const float*)st->gb_dec; v2.M1 = st->mb_dec; v2.V1 = st->vb_dec; v2.hi1 = d.d_in;
+    bool vec2_done = false;
     if (nj > 0) {
         const float* inv_norm = plan->renorm_pending ? (const float*)st->dec_inv_norm : nullptr;
 #define CALL(D) hipLaunchKernelGGL((adam_wdec_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_dec, (const float*)st->gW_dec, st->mW_dec, st->vW_dec, scalars, c, j_lo, j_hi, d.d_in, inv_norm, st->dec_inv_norm, plan->live_offs)
@@ -3153,17 +3336,16 @@ extern "C" int pv_sae_apply(pv_sae_plan* plan, pv_sae_state* st, const float* sc
                                st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, d.d_in, d.d_sae, j_lo, j_hi,
                                plan->live_offs);
         } else {                                                  // lazy parameter layout: everything stays in the transposed domain
-#define CALL(D) hipLaunchKernelGGL((adam_wenct_kernel<D>), dim3((nj + 3) / 4), block, 0, stream, st->W_encT, (_Float16*)st->W_enc16T, st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, j_lo, j_hi, d.d_in, plan->live_offs)
+            // (the two bias vectors ride at the end of this launch)
+            vec2_done = g_pv_tuning.sae_fold != 0;
+            const int nb_rows = (nj + 3) / 4, nb_v2 = vec2_done ? v2.nb0 + (d.d_in + 255) / 256 : 0;
+#define CALL(D) hipLaunchKernelGGL((adam_wenct_kernel<D>), dim3(nb_rows + nb_v2), block, 0, stream, st->W_encT, (_Float16*)st->W_enc16T, st->enc_colsq, (const float*)st->gW_enc, st->mW_enc, st->vW_enc, scalars, c, j_lo, j_hi, d.d_in, plan->live_offs, nb_rows, v2)
             V4_DISPATCH(d.d_in, CALL);
 #undef CALL
         }
     }
-    {   // b_enc's feature range and b_dec: one launch
-        const int nb0 = (nj + 255) / 256;
-        hipLaunchKernelGGL(adam_vec2_kernel, dim3(nb0 + (d.d_in + 255) / 256), block, 0, stream, st->b_enc, (const float*)st->gb_enc,
-                           st->mb_enc, st->vb_enc, j_lo, j_hi, nb0, st->b_dec, (const float*)st->gb_dec, st->mb_dec, st->vb_dec, d.d_in,
-                           scalars, c);
-    }
+    if (!vec2_done)     // b_enc's feature range and b_dec: one launch
+        hipLaunchKernelGGL(adam_vec2_kernel, dim3(v2.nb0 + (d.d_in + 255) / 256), block, 0, stream, v2, scalars, c);
     if (sae_is_tc(st)) {                                               // transcoder: plain Adam on the decoder's own bias and the skip matrix
         const pv_sae_transcoder& t = st->tc;
         PV_REQUIRE(t.gb_dec_out && t.mb_dec_out && t.vb_dec_out && (!t.W_skip || (t.gW_skip && t.mW_skip && t.vW_skip)), "transcoder Adam state");

@@ -14,22 +14,14 @@ struct pv_sae_plan {
     pv_sae_desc d;
     bool renorm_pending = false;     // the last pv_sae_step deferred set_decoder_norm_to_unit_norm to pv_sae_apply
     const uint32_t* live_offs = nullptr;   // PV_SAE_SPARSE_GRADS: feature offsets of the last pv_sae_step (in ITS workspace), else null
-    // pv_sae_step's side stream (created on first use, on the device of that call): the launches of a step that depend on nothing the
-    // main chain is about to produce run beside it -- the batch mean + the weight bound beside prep + the sample GEMM, the CSR build
-    // beside the decode kernel -- forked and joined by events, so that the caller's stream sees one ordered step (sae_side_fork / _join)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
-    int side_dev = -1;
 };
-// sae.hip: *side = the plan's side stream, waiting for everything queued on `main` so far (fork i of a step: 0 the pre-pass, 1 the CSR
-// build); nullptr when the side stream is off (tuning key sae_side = 0).  sae_side_join: `main` waits for what was queued on the side stream.
-int sae_side_fork(pv_sae_plan* plan, hipStream_t main, int i, hipStream_t* side);
-int sae_side_join(pv_sae_plan* plan, hipStream_t main, int i);
-// the pre-pass of the filtered top-k on two streams (sae_encode_topk -> sae_encode_fast): the weight bound (sae_wmax_kernel) goes to
-// `side`, `main` waits for `join` in front of the threshold kernel, which then takes the loss normaliser ||x_n - mean||_2 (sae.py:145-147)
-// that sae_prep left out (the batch mean is computed on the side stream)
+
+// The pre-pass of the filtered top-k step (pv_sae_step) in three launches instead of six: the prep launch also carries the 16-row partial
+// column sums of x (the batch mean) and the weight bound's workgroup (sae_prep_roles_kernel), the column sums are finished by a few
+// extra workgroups of the threshold launch, and the loss normaliser ||x_n - mean||_2 (sae.py:145-147) -- which needs that mean -- is
+// taken by an idle wave of the select kernel instead of by prep.  have_mean: the caller supplied the batch mean (no column sums).
 struct SaePre {
-    pv_sae_plan* plan; hipStream_t side; const float* x; int d_true;
+    const float* x; int d_true; bool have_mean;
 };
 
 struct SaeWs {
@@ -43,6 +35,32 @@ struct SaeWs {
     int sq_blocks;
 };
 SaeWs sae_carve(const pv_sae_desc& d);
+
+// out[c] = scale * sum_blk partial[blk][c] for the 64 columns of workgroup `bid`, on 256 threads in the summation order of the 1024-thread
+// colsum_final_kernel (sae.hip: 16 partial streams per column, then their sum in stream order) -- each thread plays four of its threads
+#ifdef __HIPCC__
+__device__ __forceinline__ void colsum_final_body_256(int bid, const float* __restrict__ partial, float* __restrict__ out, int nblk, int d,
+                                                      float scale) {
+    __shared__ float cf_red[16][64];
+    const int lane = threadIdx.x & 63, p4 = threadIdx.x >> 6;
+    const int c = bid * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int part = p4 + 4 * q;
+        float s = 0.f;
+        if (c < d)
+            for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
+        cf_red[part][lane] = s;
+    }
+    __syncthreads();
+    if (p4 == 0 && c < d) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += cf_red[q][lane];        // fixed order
+        out[c] = t * scale;
+    }
+}
+#endif
 
 // number of sampled values per token that bound the k-th largest from below (order statistic taken in pass 0)
 static inline int pv_sae_sample_q(int k) { return k * 3 / 8 > 8 ? k * 3 / 8 : 8; }
@@ -117,16 +135,18 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
                     const float* topk_val, float* sae_out, float* scalars, float* fire_count, int update_stats, bool sparse,
                     const float* inv_norm, const SaeTail& tb, unsigned char* wsb, const SaeWs& ws, const float* y, const float* bdo,
                     const float* skip, bool tc, float dh_add, const uint32_t* tok_cnt, const uint32_t* gate, hipStream_t stream,
-                    bool bias_grads = true);
+                    bool bias_grads = true, float* sq_scalars = nullptr);
 // sae.hip: dec_inv_norm[j] = 1 / ||W_dec[j]|| (the read-only half of set_decoder_norm_to_unit_norm)
 int sae_dec_inv_norm(const pv_sae_desc& d, const pv_sae_state* st, hipStream_t stream);
 
 // sae.hip, shared with sae_dense.hip: see the definitions
-// mean_stream: the batch mean (ws.batch_mean) is produced on THAT stream and the prep kernel leaves ws.norm to a later kernel (SaePre)
+// pre (with st): the fused pre-pass of the filtered top-k step, see SaePre -- ws.norm and the finished batch mean are left to later launches
 int sae_prep(const pv_sae_desc& d, const float* x, const float* b_dec, const float* batch_mean, int N, bool want_filter_inputs,
-             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true = 0, hipStream_t mean_stream = nullptr);
+             unsigned char* wsb, const SaeWs& ws, hipStream_t stream, int d_true = 0, SaePre* pre = nullptr,
+             const pv_sae_state* st = nullptr, uint32_t* feat_cnt = nullptr);
+// sq_scalars: also leave sq_scalars[3] = the gradient's sum of squares (PV_SAE_FUSED_SQNORM)
 int sae_gbdec(const pv_sae_desc& d, const pv_sae_state* st, const float* dY, int N, unsigned char* wsb, const SaeWs& ws,
-              hipStream_t stream, bool have_colsum = false);
+              hipStream_t stream, bool have_colsum = false, float* sq_scalars = nullptr);
 void sae_reduce_sum(const float* v, float* out, int n, float scale, int slot, int slot2, hipStream_t stream,
                     const uint32_t* gate = nullptr, uint32_t want = 0u);
 int sae_colsum(const float* x, int rows, int d, float* out, float scale, float* partial, hipStream_t stream);

@@ -522,22 +522,16 @@ template <int VPL>                                            // sampled values 
 __global__ __launch_bounds__(256) void sae_thr_kernel(const float* __restrict__ sample, int ns, const float* __restrict__ xnorm,
                                                       const float* __restrict__ wmax_sq, int qsel, int d_in, float* __restrict__ thr,
                                                       float* __restrict__ sq_out, float* __restrict__ band, int n_tok,
-                                                      const float* __restrict__ x, const float* __restrict__ batch_mean,
-                                                      float* __restrict__ norm_out, int d_true) {
+                                                      int nb_thr, const float* __restrict__ cs_partial, float* __restrict__ cs_out,
+                                                      int cs_nblk, float cs_scale) {
+    // workgroups beyond nb_thr (the fused pre-pass, SaePre): the batch mean's second stage -- 64 columns each
+    if ((int)blockIdx.x >= nb_thr) {
+        colsum_final_body_256(blockIdx.x - nb_thr, cs_partial, cs_out, cs_nblk, d_in, cs_scale);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
-    if (x) {
-        // (two-stream pre-pass, SaePre) the loss normaliser ||x_n - mean_batch(x)||_2 that sae_prep_kernel left out: its loop, its order
-        const float* xr = x + (int64_t)n * d_in;
-        float cn = 0.f;
-        for (int i = lane; i < d_true; i += 64) {
-            const float c = xr[i] - batch_mean[i];
-            cn += c * c;
-        }
-        cn = wave_sum(cn);
-        if (lane == 0) norm_out[n] = sqrtf(cn);
-    }
     const float* s = sample + (int64_t)n * ns;
     float v[VPL];
 #pragma unroll
@@ -607,7 +601,9 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
-    uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn, int slots) {
+    uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn, int slots,
+    const float* __restrict__ xn = nullptr, const float* __restrict__ batch_mean = nullptr, float* __restrict__ norm_out = nullptr,
+    int d_true = 0) {
     __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
@@ -616,6 +612,20 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     __shared__ uint32_t sh_t, sh_nr, sh_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
+    // (the fused pre-pass, SaePre) the loss normaliser ||x_n - mean_batch(x)||_2 that prep left out because the mean was not there yet:
+    // sae_prep_kernel's loop in its order, on the wave that has nothing to do while the candidate lists are gathered.  The loads leave
+    // here; they are used behind the candidate pass (the first barrier of the kernel would otherwise wait for this wave's HBM trip)
+    float nx[4 * V4], nb[4 * V4];
+    const bool norm_wave = xn != nullptr && wave == 3;
+    if (norm_wave) {
+        const float* xr = xn + row * d;
+#pragma unroll
+        for (int u = 0; u < 4 * V4; ++u) {
+            const int i = lane + 64 * u;
+            nx[u] = i < d_true ? xr[i] : 0.f;
+            nb[u] = i < d_true ? batch_mean[i] : 0.f;
+        }
+    }
     // gather the token's candidates: ntn (<= 256: d_sae <= 65536) per-tile lists of <= slots entries
     uint32_t myc = 0;
     if (tid < ntn) myc = tile_cnt[row * ntn + tid];
@@ -734,6 +744,16 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     __syncthreads();
     const uint32_t nr = sh_nr;
     bad = bad || nr > (uint32_t)PV_SAE_RESCORE_MAX;
+    if (norm_wave) {
+        float cn = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4 * V4; ++u) {                     // (terms beyond d_true are exact zeros: they do not move the sum)
+            const float c = nx[u] - nb[u];
+            cn += c * c;
+        }
+        cn = wave_sum(cn);
+        if (lane == 0) norm_out[row] = sqrtf(cn);
+    }
     if (bad) {                                                 // (uniform over the workgroup)
         if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
         return;
@@ -1067,8 +1087,8 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     float* wmax = (float*)(wsb + ws.wmax);
     uint32_t* fb_count = (uint32_t*)(wsb + ws.fb_count);
     int32_t* fb_list = (int32_t*)(wsb + ws.fb_list);
-    hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, pre ? pre->side : stream, (const float*)st->enc_colsq, d.d_sae, wmax,
-                       fb_count, feat_cnt);
+    if (!pre)                                                  // (the fused pre-pass: a workgroup of the prep launch did this)
+        hipLaunchKernelGGL(sae_wmax_kernel, dim3(1), dim3(1024), 0, stream, (const float*)st->enc_colsq, d.d_sae, wmax, fb_count, feat_cnt);
     EncParams p = {};
     p.A = wsb + ws.x16; p.M = N; p.K = d.d_in; p.lda = d.d_in;
     // pass 0: every S-th feature
@@ -1076,15 +1096,12 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     p.bias = st->b_enc; p.bias_stride = S; p.out = (float*)(wsb + ws.sample); p.ldo = ns;
     int rc = launch_enc_gemm(0, p, stream);
     if (rc) return rc;
-    if (pre) {                                                 // the side stream's batch mean and weight bound are due here
-        rc = sae_side_join(pre->plan, stream, 0);
-        if (rc) return rc;
-    }
+    const int nb_thr = (N + 3) / 4, nb_cf = (pre && !pre->have_mean) ? (d.d_in + 63) / 64 : 0;
 #define THR(V)                                                                                                                \
-    hipLaunchKernelGGL((sae_thr_kernel<V>), dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,         \
+    hipLaunchKernelGGL((sae_thr_kernel<V>), dim3(nb_thr + nb_cf), dim3(256), 0, stream, (const float*)(wsb + ws.sample), ns,      \
                        (const float*)(wsb + ws.xnorm), (const float*)wmax, q, d.d_in, (float*)(wsb + ws.thr), (float*)(wsb + ws.sq), \
-                       (float*)(wsb + ws.band), N, pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean),          \
-                       (float*)(wsb + ws.norm), pre ? pre->d_true : 0)
+                       (float*)(wsb + ws.band), N, nb_thr, (const float*)(wsb + ws.colpart), (float*)(wsb + ws.batch_mean),          \
+                       (N + 15) / 16, 1.0f / (float)N)
     if (ns <= 1024) { THR(16); } else if (ns <= 2048) { THR(32); } else { THR(64); }        // d_sae <= 65536: ns <= 4096
 #undef THR
     PV_LAUNCH_CHECK("sae_thr_kernel");
@@ -1099,7 +1116,9 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
                        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
                        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
-                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots)
+                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots,                              \
+                       pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean), (float*)(wsb + ws.norm),   \
+                       pre ? pre->d_true : 0)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else if (d.d_in <= 1024) { CALL(4); } else { CALL(5); }
 #undef CALL
     PV_LAUNCH_CHECK("sae_select_kernel");

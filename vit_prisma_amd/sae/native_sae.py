@@ -166,6 +166,7 @@ class NativeSAE:
         self._shadow_key: Optional[Tuple[int, int]] = None
         self._inv_norm_key: Optional[Tuple[int, int]] = None     # W_dec as the last full-range apply left it (dec_inv_norm is current)
         self._grad_fresh = False                                   # gradient buffers exactly as the last step wrote them
+        self._sq_fused = False
         # lazy_w_enc: ``apply`` keeps the encoder in W_encT (+ fp16 shadow) only and leaves the parameter's own [d_in, d_sae]
         # layout stale (its transposed write is 75 MB per step at 768 -> 24576); ``materialize_w_enc()`` rewrites it.  The
         # kernels never read that layout.  Off by default: whoever turns it on (VisionSAETrainer, single process) also makes
@@ -323,13 +324,15 @@ class NativeSAE:
 
     def step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
              update_stats: bool = True, want_out: bool = False, renorm_decoder: bool = False,
-             sparse_grads: bool = False, target: Optional[torch.Tensor] = None) -> None:
+             sparse_grads: bool = False, target: Optional[torch.Tensor] = None, fused_sqnorm: bool = False) -> None:
         """forward + backward + statistics; gradients are written into ``flat_g``; scalars[0..2] =
         loss, mse_loss, l0 (device).  renorm_decoder: set_decoder_norm_to_unit_norm as part of the step (the rewrite of
         W_dec is fused into the following ``apply``) instead of a separate ``renorm_decoder()`` pass.  sparse_grads
         (PV_SAE_SPARSE_GRADS, single process): the gradient rows of features that kept no token are left unwritten and
         ``apply`` takes them as zero -- ``flat_g`` is then NOT a complete gradient and only ``grad_sqnorm(from_step=True)``
-        and ``apply`` may follow.  target (transcoder engines): the activation to reconstruct; batch_mean is then ITS mean."""
+        and ``apply`` may follow.  target (transcoder engines): the activation to reconstruct; batch_mean is then ITS mean.
+        fused_sqnorm (PV_SAE_FUSED_SQNORM; ignored on transcoders, whose clip norm has more terms): the step's last launch also
+        leaves scalars[3], the clip norm's sum of squares -- a following ``grad_sqnorm(from_step=True)`` then has nothing to do."""
         x = self._check_x(x)
         self._set_target(x, target)
         self._ensure_shadows()
@@ -343,13 +346,15 @@ class NativeSAE:
         bm = None
         if batch_mean is not None:
             bm = self._bm(batch_mean)
+        fuse = bool(fused_sqnorm) and not self.transcoder
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                      int(n_global if n_global is not None else n),
                                      int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0) |
-                                     (8 if sparse_grads else 0), C.byref(out),
+                                     (8 if sparse_grads else 0) | (32 if fuse else 0), C.byref(out),
                                      self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_step")
         self._grad_fresh = True
         self._grad_sparse = bool(sparse_grads)
+        self._sq_fused = fuse
 
     def dense_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
                    n_global: Optional[int] = None, update_stats: bool = True, want_out: bool = False,
@@ -378,6 +383,7 @@ class NativeSAE:
                 "pv_sae_dense_step")
         self._inv_norm_key = None
         self._grad_fresh = False
+        self._sq_fused = False
         self._grad_sparse = False
 
     def relu_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
@@ -418,6 +424,7 @@ class NativeSAE:
                 "pv_sae_relu_step")
         self._inv_norm_key = None
         self._grad_fresh = bool(sparse_grads)                     # (the per-feature clip-norm terms exist in that form only)
+        self._sq_fused = False
         self._grad_sparse = bool(sparse_grads)
 
     def _relu_region(self, name: bytes, dtype: torch.dtype, shape) -> torch.Tensor:
@@ -481,6 +488,7 @@ class NativeSAE:
         N.check(self.lib.pv_sae_topk_ghost(self._plan, C.byref(st), x.data_ptr(), n, C.byref(ghost), C.byref(out),
                                            self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_topk_ghost")
         self._grad_fresh = False                                  # (the per-feature norm terms of the step no longer describe the buffers)
+        self._sq_fused = False
         self._grad_sparse = False
 
     def gated_step(self, x: torch.Tensor, l1_coefficient: float, batch_mean: Optional[torch.Tensor] = None,
@@ -522,6 +530,7 @@ class NativeSAE:
                                                self.workspace.numel(), self._stream()), "pv_sae_gated_step")
         self._inv_norm_key = None
         self._grad_fresh = False
+        self._sq_fused = False
         self._grad_sparse = False
 
     def gated_topk_step(self, x: torch.Tensor, batch_mean: Optional[torch.Tensor] = None, n_global: Optional[int] = None,
@@ -542,6 +551,7 @@ class NativeSAE:
                                                 self._gk_scratch.numel(), self._stream()), "pv_sae_gated_topk_step")
         self._inv_norm_key = None
         self._grad_fresh = False
+        self._sq_fused = False
         self._grad_sparse = False
 
     @property
@@ -559,6 +569,8 @@ class NativeSAE:
         kernels of the last ``step`` left behind instead of re-reading the 151 MB -- only while the gradient buffers are
         exactly what that step wrote (no all-reduce, no edit through ``g``); otherwise the full pass runs."""
         if from_step and self._grad_fresh:
+            if getattr(self, "_sq_fused", False):                 # (the step's last launch left scalars[3]: PV_SAE_FUSED_SQNORM)
+                return
             st = self._state()
             N.check(self.lib.pv_sae_grad_sqnorm_step(self._plan, C.byref(st), self.workspace.data_ptr(), self.scalars.data_ptr(),
                                                      self._stream()), "pv_sae_grad_sqnorm_step")
@@ -583,6 +595,7 @@ class NativeSAE:
                                       float(max_grad_norm) if max_grad_norm else -1.0, float(lr), self.adam_step,
                                       int(j_lo), int(self.d_sae if j_hi is None else j_hi), self._stream()), "pv_sae_apply")
         self._grad_fresh = False
+        self._sq_fused = False
         full = j_lo == 0 and (j_hi is None or j_hi == self.d_sae)
         self._inv_norm_key = self._w_dec_key() if full else None
         if self.lazy_w_enc:
@@ -650,6 +663,7 @@ class NativeSAE:
                                           int(bool(update_stats)) | (16 if enc_term_only else 0), C.byref(out),
                                           self.workspace.data_ptr(), self.workspace.numel(), self._stream()), "pv_sae_tp_finish")
         self._grad_fresh = False            # (grad_sqnorm(from_step=True) is about pv_sae_step; use grad_sqnorm_rows here)
+        self._sq_fused = False
         self._grad_sparse = False
 
     # the feature-parallel step's glue (sae/feature_parallel.py): exchange buffers the kernels write in place

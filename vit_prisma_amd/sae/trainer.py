@@ -445,7 +445,8 @@ class VisionSAETrainer:
         elif not self._mr:
             # set_decoder_norm_to_unit_norm is part of the step; one process = nobody but the step's own apply reads the
             # gradient buffers, so the rows of features that kept no token are neither zeroed nor read (PV_SAE_SPARSE_GRADS)
-            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True, target=self._target if eng.transcoder else None)
+            eng.step(x, update_stats=True, renorm_decoder=True, sparse_grads=True, target=self._target if eng.transcoder else None,
+                     fused_sqnorm=True)
             eng.grad_sqnorm(from_step=True)                     # clip_grad_norm_ (the gradient is as the step wrote it)
             eng.apply(lr, self.cfg.max_grad_norm)
         else:
