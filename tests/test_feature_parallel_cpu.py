@@ -127,7 +127,7 @@ def test_simulated_world_equals_the_process_group_step():
         assert rel_fro(got[n].numpy(), P[n]) < 1e-5, n
 
 
-def _trainer_worker(rank, world, port, q):
+def _trainer_worker(rank, world, port, q, drop=False):
     """The same step through VisionSAETrainer.train_step (use_feature_parallel): tokens harvested per rank, statistics,
     sync_parameters() gathering the shards back into the module."""
     import torch.distributed as dist
@@ -146,7 +146,7 @@ def _trainer_worker(rank, world, port, q):
         with torch.no_grad():
             for n, v in synth_sae_state(D_IN, D_SAE, 0).items():
                 getattr(sae, n).copy_(torch.from_numpy(v))
-    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_feature_parallel(True)
+    tr = VisionSAETrainer(cfg, model=None, dataset=None, sparse_coder=sae).use_feature_parallel(True, drop_replicas=drop)
     tr._native_ok = lambda *a, **k: True
     tr._make_shard_engine = lambda s, max_tokens: (lambda We, Wd, be, bd: OracleShardEngine(We, Wd, be, bd, K, max_tokens))
     act, since, frac, opt, sched = tr.initialize_training_variables()
@@ -159,19 +159,27 @@ def _trainer_worker(rank, world, port, q):
             n_frac_active_tokens=frac, layer_acts=xs, n_training_steps=t, n_training_tokens=t * N)
         losses.append((float(loss), float(l0)))
         assert tr.last_step_native
-    tr.sync_parameters()
+        # drop_replicas: the module's matrices are released while the shards train ...
+        assert (sae.W_enc.numel() == 0 and sae.W_dec.numel() == 0) if drop else sae.W_enc.shape == (D_IN, D_SAE)
+        if drop and t == 0:
+            tr.sync_parameters()                                # ... come back complete on request ...
+            assert sae.W_enc.shape == (D_IN, D_SAE) and sae.W_dec.shape == (D_SAE, D_IN)
+    tr.sync_parameters()                                        # ... (and are released again by the step after)
     out = {n: getattr(sae, n).detach().numpy().copy() for n in ("W_enc", "W_dec", "b_enc", "b_dec")}
     q.put((rank, out, losses, act.numpy().copy(), since.numpy().copy(), frac))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_trainer_feature_parallel_world2_equals_single_process_oracle():
+@pytest.mark.parametrize("drop", [False, True])
+def test_trainer_feature_parallel_world2_equals_single_process_oracle(drop):
+    """drop: use_feature_parallel(True, drop_replicas=True) -- the full-size W_enc / W_dec of the module are released on every rank
+    while the shards train and come back, complete and equal to the single-process run's, on sync_parameters()."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, drop)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])

@@ -112,7 +112,7 @@ class VisionSAETrainer:
         self._native_pref = flag
         return self
 
-    def use_feature_parallel(self, flag: Optional[bool] = True) -> "VisionSAETrainer":
+    def use_feature_parallel(self, flag: Optional[bool] = True, drop_replicas: bool = False) -> "VisionSAETrainer":
         """How multi-rank native top-k steps are sharded.  True: by FEATURE (sae/feature_parallel.py: every rank keeps
         d_sae / world features and their optimizer state for good, sees the whole token batch, and only token-sized
         collectives cross the links); False: by token, with the optimizer sharded by feature (reduce-scatter of the gradient
@@ -120,8 +120,12 @@ class VisionSAETrainer:
         parallel whenever d_sae is divisible by the world size -- by the measured per-rank phase times it is the faster of
         the two at every world size for the reference's 4096-token batch.  In the feature-parallel mode
         the module's own parameters are refreshed only by ``sync_parameters()`` (``checkpoint`` and the end of ``run`` call
-        it).  New functionality (the reference is single-process)."""
+        it).  drop_replicas: while the shards train, the module's two matrices (W_enc, W_dec: 2 x d_in x d_sae floats that no
+        kernel reads in this mode) are released on every rank -- ``sae.W_enc`` / ``sae.W_dec`` are EMPTY between
+        ``sync_parameters()`` calls, which allocate and fill them again (and the next step releases them again).  New
+        functionality (the reference is single-process)."""
         self._feature_parallel = None if flag is None else bool(flag)
+        self._fp_drop = bool(drop_replicas)
         return self
 
     def _use_tp(self, sae) -> bool:
@@ -351,7 +355,10 @@ class VisionSAETrainer:
             P = self._fp.gather_parameters()
             with torch.no_grad():
                 for n in ("W_enc", "W_dec", "b_enc", "b_dec"):
-                    getattr(self.sparse_coder, n).copy_(P[n])       # (not through .data: the version counter must move)
+                    p = getattr(self.sparse_coder, n)
+                    if p.shape != P[n].shape:                       # (released by drop_replicas: a fresh allocation)
+                        p.data = torch.empty_like(P[n])
+                    p.copy_(P[n])                                   # (not through .data: the version counter must move)
             eng = getattr(self.sparse_coder, "_engine", None)       # the module's own inference engine re-derives its shadows
             if eng is not None:
                 eng.invalidate()
@@ -554,6 +561,11 @@ class VisionSAETrainer:
                                           sae.cfg.activation_fn_kwargs["k"], self._make_shard_engine(sae, n_global),
                                           dist=dist, rank=self.rank, world=self.world)
         fp = self._fp
+        if getattr(self, "_fp_drop", False):                    # the shards are the truth from here on: release the replicas
+            for n in ("W_enc", "W_dec"):
+                p = getattr(sae, n)
+                if p.numel():
+                    p.data = torch.empty(0, dtype=p.dtype, device=p.device)
         loss, l0 = fp.step(fp.gather_tokens(x), lr, self.cfg.max_grad_norm)
         self._fp_dirty = True
         n_since_fired += 1                                      # train_sae.py:356-361 on the global batch
