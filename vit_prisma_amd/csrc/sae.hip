@@ -2302,8 +2302,10 @@ int sae_sparse_tail(pv_sae_plan* plan, pv_sae_state* st, const float* x, int N, 
         const float grad_scale = 2.0f / ((float)n_global * (float)sae_loss_width(d, st));      // (a transcoder: the mean is over N x d_out)
         const float loss_scale = 1.0f / ((float)n_global * (float)sae_loss_width(d, st));
         const dim3 grid((N + 3) / 4), block(256);
-        // pv_sae_step: the CSR scan reads the selection's counts only -- it runs as one more workgroup of the decode launch (ScanRole)
-        const bool folded = bias_grads && !gate && !tok_cnt && g_pv_tuning.sae_fold != 0;
+        // the CSR scan reads the selection's counts only -- it runs as one more workgroup of the decode launch (ScanRole).  (The sparse
+        // form of the ReLU step on a batch that turns out dense: the scan walks counts nobody will use and writes scalars the dense
+        // form overwrites -- as the scan's own launch did)
+        const bool folded = g_pv_tuning.sae_fold != 0;
         ScanRole scan = {};
         if (folded) {
             scan.cnt = (const uint32_t*)(wsb + ws.cnt); scan.offs = (uint32_t*)(wsb + ws.offs); scan.n_long = (uint32_t*)(wsb + ws.n_long);
