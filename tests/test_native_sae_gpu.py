@@ -1436,6 +1436,33 @@ def test_folded_launches_equal_the_single_launches_bitwise(d_in, d_sae, k, n, sp
         NV.set_tuning("reset")
 
 
+def test_sample_pass_on_128_row_tiles_equals_256_row_tiles_bitwise():
+    """The sample GEMM of the filtered encoder (every 16th feature: 4096 x 1536 outputs at the bench shape) runs on 128 x 256 tiles where
+    256 x 256 ones would occupy 96 of 256 CUs.  An output element's K order does not depend on the tile it sits in, so the thresholds,
+    the candidate lists and everything behind them are those of the 256-row form (tuning key enc_tm256 = 1) to the bit."""
+    from vit_prisma_amd import _native as NV
+    d_in, d_sae, k, n = 768, 24576, 32, 4000                    # (ragged last M tile)
+    engines = []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        engines.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, True, n))
+    try:
+        for t in range(2):
+            x = torch.from_numpy(synth_sae_batch(n, d_in, seed=t)).cuda()
+            for big, e in enumerate(engines):
+                NV.set_tuning("enc_tm256", big)
+                e.step(x, want_out=True, renorm_decoder=True, fused_sqnorm=True)
+                e.apply(1e-3, 1.0)
+            torch.cuda.synchronize()
+            a, b = engines
+            ws = NV  # noqa: F841
+            assert torch.equal(a.sae_out, b.sae_out) and torch.equal(a.scalars[:4], b.scalars[:4])
+            assert torch.equal(torch.sort(a.topk_idx[:n], dim=1).values, torch.sort(b.topk_idx[:n], dim=1).values)
+            assert torch.equal(a.W_encT, b.W_encT) and torch.equal(a.params["W_dec"], b.params["W_dec"])
+    finally:
+        NV.set_tuning("reset")
+
+
 # ---------------------------------------------------------------------------------------------------
 # Transcoder (SURVEY.md 8f row 3; sae/transcoder.py; pv_sae_transcoder) on the two fused steps
 # ---------------------------------------------------------------------------------------------------

@@ -172,6 +172,7 @@ struct PvTuning {
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
     int sae_fold = 1;        // 0: pv_sae_step launches its small kernels one by one (the A/B of the fused pre-pass, SaePre, the scan as a role of
                              // the decode launch, ScanRole, the merged list sorts and the Adam pair's tail roles)
+    int enc_tm256 = 0;       // 1: the SAE sample pass keeps 256-row tiles where 128-row ones would fill more of the chip (A/B of sae_enc_gemm_kernel's MB_)
     int enc_rounds = 0;      // 1: the SAE filter GEMM compacts its hits in a round per 32-row block whatever the shape (A/B of the one-round epilogue)
     int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds
     int gemm_loop = -1;      // K loop of the one-workgroup-per-CU kernels (ViT GEMMs, SAE filter GEMM): -1 auto = the full-line form (128-byte

@@ -28,6 +28,8 @@
 //      C2 = 2^-25 sqrt(K),  Wmax = max_j ||W_enc[:, j]||_2 (maintained by the Adam kernel as enc_colsq).
 // Rows with |x| beyond the fp16 range get B = inf (-> fallback); a weight beyond it makes its column norm inf (-> every
 // row falls back): slow, never wrong.
+#include <atomic>
+
 #include "sae.hpp"
 
 namespace {
@@ -65,9 +67,12 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 // 4-slot LDS ring three slabs ahead, counted vmcnt across a raw s_barrier) on fp16 operands, with an epilogue that
 // stores nothing but the hits.  MODE 0: plain fp32 store of acc + bias (the sample of pass 0).
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, int LP = 0, bool ONE = false>
+// MB_: 32-row blocks per wave along M -- 4 (256 x 256 tiles) everywhere but the sample pass at the bench shape, whose 4096 x 1536 output
+// is 96 such tiles on 256 CUs: 2 (128 x 256 tiles, the full-line loop only) makes it 192 half-sized ones, still one round
+template <int MODE, int LP = 0, bool ONE = false, int MB_ = 4>
 __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p) {
-    constexpr int MB = 4, TM = 64 * MB, TN = 256;
+    constexpr int MB = MB_, TM = 64 * MB, TN = 256;
+    static_assert(MB == 4 || (MB == 2 && LP == 2 && MODE == 0), "the 128-row tile exists in the full-line form of the sample pass only");
     constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, SLOT = A_BYTES + B_BYTES;
     // LP == 2 (full-line K slabs): two slots of 128-byte rows in ring0 / ring1, ring2 / ring3 shrink to stubs
     __shared__ __attribute__((aligned(16))) unsigned char ring0[LP == 2 ? 2 * SLOT : SLOT];
@@ -333,7 +338,9 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                     fb[(h + 1) & 1][1] = h < 3 ? rdB2(CUR, h < 3 ? h + 1 : 0, 1) : rdB2(NXT, 0, 1);           \
                 }                                                                                             \
                 if (h == 3) issue_piece2((KT) + 2, CUR, mi);                                                  \
-                if (h == 0) issue_piece2((KT) + 1, NXT, MB + mi);                                             \
+                if (h == 0) {                                                                                 \
+                    _Pragma("unroll") for (int jb = mi; jb < 4; jb += MB) issue_piece2((KT) + 1, NXT, MB + jb); \
+                }                                                                                             \
                 __builtin_amdgcn_sched_barrier(0);                                                            \
             }                                                                                                 \
         }
@@ -1056,9 +1063,30 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
     }
 }
 
+// CUs of the current device (cached per device id)
+static int enc_cus() {
+    static std::atomic<int> per_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = per_dev[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        if (n <= 0) n = 256;
+        per_dev[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
     const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
     const dim3 grid(ntm * ntn), block(512);
+    if (mode == 0 && g_pv_tuning.gemm_loop == -1 && p.K % 64 == 0 && ntm * ntn <= enc_cus() / 2 && !g_pv_tuning.enc_tm256) {
+        // the sample pass where 256-row tiles leave most of the chip idle: 128-row tiles (see the kernel's MB_)
+        hipLaunchKernelGGL((sae_enc_gemm_kernel<0, 2, false, 2>), dim3(((p.M + 127) / 128) * ntn), block, 0, stream, p);
+        PV_LAUNCH_CHECK("sae_enc_gemm_kernel");
+        return PV_OK;
+    }
     // K loop as in gemm.hip's launcher: 2 = full-line form (whole 128-byte slabs of fp16: K % 64 == 0), 1 = pipelined 64-byte
     // slabs (K % 32 == 0), 0 = barrier-then-fetch
     int lp = 0;
