@@ -30,6 +30,7 @@ python $R/tools/pmc_traffic.py $O/pmc_relu_fetch $O/pmc_relu_write $O/pmc_traffi
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -o p -- python $R/bench.py --no-sae --no-l14 --no-cpu-baseline --steps 2 --warmup 1 > $O/pmc_mfma.log 2>&1
 python $R/tools/pmc_mfma.py $O/pmc_mfma $O/pmc_mfma.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -- python bench.py --no-sae --no-l14 --no-cpu-baseline --steps 2 --warmup 1" > $O/pmc_mfma.txt 2>&1
 echo "pmc done $(( $(date +%s) - T0 ))s"
+STEPS=40 REPS=3 timeout 300 python $R/tools/sae_fold_ab.py > $O/sae_fold_ab.txt 2>&1
 timeout 200 python $R/tools/dense_split_err.py > $O/dense_split_err.json 2> $O/dense_split_err.err
 timeout 300 python $R/tools/tp_shard_times.py > $O/tp_shard_times.json 2> $O/tp_shard_times.err
 for n in vit sae relu reludense gateddense gated l14; do cp $O/prof_$n/${n}_kernel_stats.csv $O/${n}_kernel_stats.csv 2>/dev/null; done

@@ -8,6 +8,20 @@ import torch
 from vit_prisma_amd import _native as N
 from vit_prisma_amd.sae.bench_leg import sae_bench_leg
 
+from vit_prisma_amd.sae.native_sae import NativeSAE
+
+_step = NativeSAE.step
+FOLD = [1]
+
+
+def step_ab(self, *a, **kw):
+    # the leg of single launches takes its clip norm from pv_sae_grad_sqnorm_step, as the step did before the folds
+    if not FOLD[0]:
+        kw["fused_sqnorm"] = False
+    return _step(self, *a, **kw)
+
+
+NativeSAE.step = step_ab
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 rows = []
@@ -16,6 +30,7 @@ for rep in range(int(os.environ.get("REPS", "3"))):
     for side in MODES:
         N.set_tuning("reset")
         N.set_tuning("sae_fold", side)
+        FOLD[0] = side
         r = sae_bench_leg(dev, dist=None, steps=int(os.environ.get("STEPS", "40")), warmup=5)
         rows.append({"sae_fold": side, "ms_per_step": r["ms_per_step"], "final_loss": r.get("final_loss"), "l0": r.get("l0")})
         print(rows[-1], flush=True)

@@ -200,7 +200,7 @@ __device__ __forceinline__ uint32_t f2ord(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-constexpr int TOPK_CAP = 1024;   // candidate list capacity of the fast path
+constexpr int TOPK_CAP = PV_TOPK_CAP;   // candidate list capacity of the fast path
 
 // Per-row exact top-k, streaming (no per-thread value cache -> ~40 VGPRs, full occupancy):
 //   pass 1  each thread streams its share of the row keeping only its maximum
@@ -238,129 +238,9 @@ __global__ __launch_bounds__(256) void sae_topk_kernel(const float* __restrict__
 __device__ void sae_topk_row(const float* __restrict__ hidden, int32_t* __restrict__ idx_out, float* __restrict__ val_out,
                              int d_sae, int k, int64_t row, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh_T0, sh_ncand, sh_prefix, sh_k, sh_wcnt[4];
     __shared__ uint32_t cand_key[TOPK_CAP];
     __shared__ int32_t cand_idx[TOPK_CAP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* h = hidden + row * d_sae;
-    const int nvec = d_sae >> 2;                     // d_sae % 4 == 0 (checked at plan creation)
-
-    uint32_t lmax = 0;
-    for (int v = tid; v < nvec; v += 256) {
-        const float4 x = *reinterpret_cast<const float4*>(h + 4 * v);
-        lmax = max(max(lmax, f2ord(x.x)), max(f2ord(x.y), max(f2ord(x.z), f2ord(x.w))));
-    }
-    hist[tid] = lmax;
-    if (tid == 0) { sh_T0 = 0u; sh_ncand = 0u; }
-    __syncthreads();
-    if (k <= 256) {
-        uint32_t rank = 0;
-        for (int u = 0; u < 256; ++u) {
-            const uint32_t o = hist[u];               // same address for all lanes: LDS broadcast
-            rank += (o > lmax) || (o == lmax && u < tid);
-        }
-        if (rank == (uint32_t)(k - 1)) sh_T0 = lmax;
-    }
-    __syncthreads();
-    const uint32_t T0 = sh_T0;
-    for (int v = tid; v < nvec; v += 256) {
-        const float4 x = *reinterpret_cast<const float4*>(h + 4 * v);
-        const uint32_t kx[4] = {f2ord(x.x), f2ord(x.y), f2ord(x.z), f2ord(x.w)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (kx[e] >= T0) {
-                const uint32_t pos = atomicAdd(&sh_ncand, 1u);
-                if (pos < TOPK_CAP) { cand_key[pos] = kx[e]; cand_idx[pos] = 4 * v + e; }
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t ncand = sh_ncand;
-    if (ncand <= TOPK_CAP) {
-        for (uint32_t c = tid; c < ncand; c += 256) {
-            const uint32_t kc = cand_key[c];
-            const int32_t ic = cand_idx[c];
-            uint32_t rank = 0;
-            for (uint32_t o = 0; o < ncand; ++o) {
-                const uint32_t ko = cand_key[o];
-                rank += (ko > kc) || (ko == kc && cand_idx[o] < ic);
-            }
-            if (rank < (uint32_t)k) {
-                const float v = fmaxf(h[ic], 0.f);                // postact_fn = ReLU (sae.py:806)
-                idx_out[row * k + rank] = ic;
-                val_out[row * k + rank] = v;
-                if (feat_cnt) wpos[row * k + rank] = v > 0.f ? atomicAdd(&feat_cnt[ic], 1u) : 0xffffffffu;
-            }
-        }
-        return;
-    }
-    // ---------------------------------------------------- fallback: radix select, re-streaming the row
-    uint32_t prefix = 0, kk = (uint32_t)k;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        __syncthreads();
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        for (int c = tid; c < d_sae; c += 256) {
-            const uint32_t key = f2ord(h[c]);
-            if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = 0;
-            int dsel = 0;
-            for (int dgt = 255; dgt >= 0; --dgt) {
-                if (acc + hist[dgt] >= kk) { dsel = dgt; break; }
-                acc += hist[dgt];
-            }
-            sh_prefix = prefix | ((uint32_t)dsel << shift);
-            sh_k = kk - acc;
-        }
-        __syncthreads();
-        prefix = sh_prefix;
-        kk = sh_k;
-    }
-    // prefix = k-th largest key; take everything above it and the first kk (lowest column) ties
-    uint32_t ngt = 0, neq = 0;
-    for (int c = tid; c < d_sae; c += 256) {
-        const uint32_t key = f2ord(h[c]);
-        ngt += key > prefix;
-        neq += key == prefix;
-    }
-    auto block_scan = [&](uint32_t cnt, uint32_t& total) -> uint32_t {
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t a = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += a;
-        }
-        __syncthreads();
-        if (lane == 63) sh_wcnt[wave] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        total = 0;
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) base += sh_wcnt[w];
-            total += sh_wcnt[w];
-        }
-        return base + inc - cnt;
-    };
-    uint32_t tot_gt, tot_eq;
-    uint32_t pos_gt = block_scan(ngt, tot_gt);
-    uint32_t pos_eq = block_scan(neq, tot_eq);
-    for (int c = tid; c < d_sae; c += 256) {
-        const uint32_t key = f2ord(h[c]);
-        int slot = -1;
-        if (key > prefix) slot = (int)pos_gt++;
-        else if (key == prefix) { if (pos_eq < kk) slot = (int)(tot_gt + pos_eq); pos_eq++; }
-        if (slot >= 0 && slot < k) {
-            const float v = fmaxf(h[c], 0.f);
-            idx_out[row * k + slot] = c;
-            val_out[row * k + slot] = v;
-            if (feat_cnt) wpos[row * k + slot] = v > 0.f ? atomicAdd(&feat_cnt[c], 1u) : 0xffffffffu;
-        }
-    }
+    sae_topk_row_lds(hidden, idx_out, val_out, d_sae, k, row, feat_cnt, wpos, hist, cand_key, cand_idx);      // (sae.hpp)
 }
 
 // ------------------------------------------------------------------------------------------------
