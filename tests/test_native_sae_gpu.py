@@ -1436,6 +1436,55 @@ def test_folded_launches_equal_the_single_launches_bitwise(d_in, d_sae, k, n, sp
         NV.set_tuning("reset")
 
 
+@pytest.mark.parametrize("case", ["range", "pair_ties", "massive_ties", "weight_range"])
+def test_folded_step_recomputes_undecided_tokens_inline_and_equals_the_listed_form(case):
+    """The folded training step has no fallback launches: a token the filter cannot decide (outside the fp16 range, candidate-list
+    overflow from massive ties, a poisoned weight bound) is recomputed exactly inside the select kernel by its own workgroup, in the
+    arithmetic of the two fallback kernels.  On the adversarial inputs of test_filtered_encoder_exact_fallback_* the folded step
+    (sae_fold = 1) and the step that lists such tokens for sae_fb_hidden_kernel + sae_topk_kernel (sae_fold = 0) count the same
+    undecided tokens and agree bit for bit -- reconstruction, scalars, gradients, parameters after the optimizer step."""
+    from vit_prisma_amd import _native as NV
+    d_in, d_sae, k, n = 64, 4096, 8, 40
+    engines, states = [], []
+    for _ in range(2):
+        _, _, _, T = fresh(d_in, d_sae)
+        with torch.no_grad():
+            if case == "pair_ties":
+                T["W_enc"][:, 1::2] = T["W_enc"][:, 0::2]
+                T["b_enc"][1::2] = T["b_enc"][0::2]
+            if case in ("massive_ties", "weight_range"):
+                T["W_enc"][:, :2048] = T["W_enc"][:, :1].clone()
+                T["b_enc"][:2048] = 5.0
+            if case == "weight_range":
+                T["W_enc"][3, 77] = 1.0e6
+        states.append(T)
+        engines.append(NativeSAE(T["W_enc"], T["W_dec"], T["b_enc"], T["b_dec"], k, False, n))     # (no input LayerNorm: raw magnitudes reach the GEMM)
+    x = torch.from_numpy(synth_sae_batch(n, d_in, seed=2)).cuda()
+    if case == "range":
+        x[3, 5] = 3.0e5
+        x[7] *= 1e-7
+    try:
+        for t in range(2):
+            counts = []
+            for fold, e in enumerate(engines):
+                NV.set_tuning("sae_fold", fold)
+                e.step(x, want_out=True, renorm_decoder=True, fused_sqnorm=True)
+                counts.append(e.fallback_rows())
+            torch.cuda.synchronize()
+            a, b = engines
+            assert counts[0] == counts[1] and (counts[0] == n if case in ("massive_ties", "weight_range") else counts[0] >= (1 if case == "range" else 0)), counts
+            assert torch.equal(a.sae_out, b.sae_out) and torch.equal(a.scalars[:4], b.scalars[:4])
+            assert torch.equal(a.topk_val[:n].sort(dim=1).values, b.topk_val[:n].sort(dim=1).values)
+            assert torch.equal(a.flat_g, b.flat_g)
+            for fold, e in enumerate(engines):
+                NV.set_tuning("sae_fold", fold)
+                e.apply(1e-3, 1.0)
+            torch.cuda.synchronize()
+            assert torch.equal(a.W_encT, b.W_encT) and torch.equal(a.params["W_dec"], b.params["W_dec"]) and torch.equal(a.params["b_enc"], b.params["b_enc"])
+    finally:
+        NV.set_tuning("reset")
+
+
 def test_sample_pass_on_128_row_tiles_equals_256_row_tiles_bitwise():
     """The sample GEMM of the filtered encoder (every 16th feature: 4096 x 1536 outputs at the bench shape) runs on 128 x 256 tiles where
     256 x 256 ones would occupy 96 of 256 CUs.  An output element's K order does not depend on the tile it sits in, so the thresholds,

@@ -603,14 +603,20 @@ __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // select: candidates -> exact top-k.  One workgroup per token.
 // ---------------------------------------------------------------------------------------------------
-template <int V4>
+// INLINE_FB (the folded training step): a token the filter cannot decide is recomputed exactly by ITS OWN workgroup, right here -- the
+// row of exact pre-activations in sae_fb_hidden_kernel's arithmetic (a wave per feature, the same fma chain, wave_sum), then
+// sae_topk_row_lds on the LDS of the candidate pass -- instead of being listed for the two fallback launches, which cost 9 us + two
+// dispatch gaps per step when their list is empty, i.e. on every step of ordinary data.  A workgroup that takes the exact path runs
+// ~0.3 ms (24 576 x 768 fp32 MACs on four waves); a batch in which EVERY token does (adversarial data) takes about as long as the
+// 32 x 24 workgroups of the listed form did.
+template <int V4, bool INLINE_FB = false>
 __global__ __launch_bounds__(256) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
     uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn, int slots,
     const float* __restrict__ xn = nullptr, const float* __restrict__ batch_mean = nullptr, float* __restrict__ norm_out = nullptr,
-    int d_true = 0) {
+    int d_true = 0, float* __restrict__ hidden = nullptr) {
     __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
     __shared__ int32_t cidx[PV_SAE_CAND_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
@@ -762,8 +768,44 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
         if (lane == 0) norm_out[row] = sqrtf(cn);
     }
     if (bad) {                                                 // (uniform over the workgroup)
-        if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
-        return;
+        if constexpr (!INLINE_FB) {
+            if (tid == 0) fb_list[atomicAdd(fb_count, 1u)] = (int32_t)row;
+            return;
+        } else {
+            if (tid == 0) atomicAdd(fb_count, 1u);             // (the count stays: NativeSAE.fallback_rows)
+            const int d_sae = ntn * 256;
+            float4 xq[V4];
+#pragma unroll
+            for (int i = 0; i < V4; ++i)
+                xq[i] = 4 * lane + 256 * i < d ? *reinterpret_cast<const float4*>(sae_in + row * d + 4 * lane + 256 * i)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j0 = wave * 4; j0 < d_sae; j0 += 16) {
+                float acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* w = W_encT + (int64_t)(j0 + u) * d;
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < V4; ++i) {
+                        if (4 * lane + 256 * i < d) {
+                            const float4 wv = *reinterpret_cast<const float4*>(w + 4 * lane + 256 * i);
+                            a = fmaf(xq[i].x, wv.x, a); a = fmaf(xq[i].y, wv.y, a); a = fmaf(xq[i].z, wv.z, a); a = fmaf(xq[i].w, wv.w, a);
+                        }
+                    }
+                    acc[u] = a;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = wave_sum(acc[u]);
+                if (lane < 4) {
+                    const float av = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+                    hidden[row * d_sae + j0 + lane] = av + b_enc[j0 + lane];
+                }
+            }
+            __threadfence_block();
+            __syncthreads();                                   // the row is in memory for the whole workgroup
+            sae_topk_row_lds(hidden, idx_out, val_out, d_sae, k, row, feat_cnt, wpos, tcnt, ckey, cidx);
+            return;
+        }
     }
 #ifndef PV_SEL_NO_RESCORE
     // exact fp32 re-scoring: a wave per candidate, four candidates (4 x V4 16-byte loads per lane) in flight
@@ -1140,16 +1182,21 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     p.slots = pv_sae_tile_slots(d);
     rc = launch_enc_gemm(1, p, stream);
     if (rc) return rc;
+#define SEL_ARGS                                                                                                            \
+    dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),                                                          \
+        (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),                            \
+        (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,                 \
+        topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots,                                             \
+        pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean), (float*)(wsb + ws.norm),                  \
+        pre ? pre->d_true : 0, (float*)(wsb + ws.hidden)
 #define CALL(D)                                                                                                             \
-    hipLaunchKernelGGL((sae_select_kernel<D>), dim3(N), dim3(256), 0, stream, (const float*)(wsb + ws.sae_in),              \
-                       (const float*)st->W_encT, (const float*)st->b_enc, (const uint32_t*)(wsb + ws.cand_cnt),             \
-                       (const int2*)(wsb + ws.cand), (const float*)(wsb + ws.sq), (const float*)(wsb + ws.band), topk_idx,  \
-                       topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots,                              \
-                       pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean), (float*)(wsb + ws.norm),   \
-                       pre ? pre->d_true : 0)
+    if (pre) hipLaunchKernelGGL((sae_select_kernel<D, true>), SEL_ARGS);                                                    \
+    else hipLaunchKernelGGL((sae_select_kernel<D>), SEL_ARGS)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else if (d.d_in <= 1024) { CALL(4); } else { CALL(5); }
 #undef CALL
+#undef SEL_ARGS
     PV_LAUNCH_CHECK("sae_select_kernel");
+    if (pre) return PV_OK;                                      // (the folded step: undecided tokens were recomputed inside the select kernel)
     // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)
     hipLaunchKernelGGL(sae_fb_hidden_kernel, dim3(PV_SAE_FB_SLOTS, (d.d_sae + 1023) / 1024), dim3(256), 0, stream,
                        (const float*)(wsb + ws.sae_in), (const float*)st->W_encT, (const float*)st->b_enc, (const int32_t*)fb_list,
