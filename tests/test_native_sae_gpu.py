@@ -1438,11 +1438,13 @@ def test_folded_launches_equal_the_single_launches_bitwise(d_in, d_sae, k, n, sp
 
 @pytest.mark.parametrize("case", ["range", "pair_ties", "massive_ties", "weight_range"])
 def test_folded_step_recomputes_undecided_tokens_inline_and_equals_the_listed_form(case):
-    """The folded training step has no fallback launches: a token the filter cannot decide (outside the fp16 range, candidate-list
-    overflow from massive ties, a poisoned weight bound) is recomputed exactly inside the select kernel by its own workgroup, in the
-    arithmetic of the two fallback kernels.  On the adversarial inputs of test_filtered_encoder_exact_fallback_* the folded step
-    (sae_fold = 1) and the step that lists such tokens for sae_fb_hidden_kernel + sae_topk_kernel (sae_fold = 0) count the same
-    undecided tokens and agree bit for bit -- reconstruction, scalars, gradients, parameters after the optimizer step."""
+    """The inline exact path of the select kernel (tuning key sae_inline_fb; off by default: one undecided token costs the step 0.3 ms of
+    latency, MEASURED.md): a token the filter cannot decide (outside the fp16 range, candidate-list overflow from massive ties, a
+    poisoned weight bound) is recomputed exactly inside the select kernel by its own workgroup, in the arithmetic of the two fallback
+    kernels.  On the adversarial inputs of test_filtered_encoder_exact_fallback_* the folded step with the inline path and the step of
+    single launches that lists such tokens for sae_fb_hidden_kernel + sae_topk_kernel count the same undecided tokens and agree bit
+    for bit -- reconstruction, scalars, gradients, parameters after the optimizer step.  (The folded step's DEFAULT form, which lists
+    them too, is covered by the same comparison in test_folded_launches_* on ordinary data and by case "listed" here.)"""
     from vit_prisma_amd import _native as NV
     d_in, d_sae, k, n = 64, 4096, 8, 40
     engines, states = [], []
@@ -1468,6 +1470,7 @@ def test_folded_step_recomputes_undecided_tokens_inline_and_equals_the_listed_fo
             counts = []
             for fold, e in enumerate(engines):
                 NV.set_tuning("sae_fold", fold)
+                NV.set_tuning("sae_inline_fb", fold)
                 e.step(x, want_out=True, renorm_decoder=True, fused_sqnorm=True)
                 counts.append(e.fallback_rows())
             torch.cuda.synchronize()

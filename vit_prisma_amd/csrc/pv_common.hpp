@@ -172,6 +172,10 @@ struct PvTuning {
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
     int sae_fold = 1;        // 0: pv_sae_step launches its small kernels one by one (the A/B of the fused pre-pass, SaePre, the scan as a role of
                              // the decode launch, ScanRole, the merged list sorts and the Adam pair's tail roles)
+    int sae_inline_fb = 0;   // 1: the folded SAE step recomputes a token the filter cannot decide inside the select kernel (no fallback launches:
+                             // - 14 us per step) -- off: ONE such token costs the step 0.3 ms of latency (its workgroup walks all features
+                             // alone), and harvested activations have a few per step (MEASURED.md); the two fallback launches spread a token
+                             // over 24 workgroups
     int enc_tm256 = 0;       // 1: the SAE sample pass keeps 256-row tiles where 128-row ones would fill more of the chip (A/B of sae_enc_gemm_kernel's MB_)
     int enc_rounds = 0;      // 1: the SAE filter GEMM compacts its hits in a round per 32-row block whatever the shape (A/B of the one-round epilogue)
     int gemm_dbg = 0;        // K-loop / epilogue ablations; honoured only by -DPV_TUNING builds

@@ -1189,14 +1189,15 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
         topk_val, fb_list, fb_count, feat_cnt, wpos, d.d_in, d.k, ntn, p.slots,                                             \
         pre ? pre->x : (const float*)nullptr, (const float*)(wsb + ws.batch_mean), (float*)(wsb + ws.norm),                  \
         pre ? pre->d_true : 0, (float*)(wsb + ws.hidden)
+    const bool inline_fb = pre && g_pv_tuning.sae_inline_fb;
 #define CALL(D)                                                                                                             \
-    if (pre) hipLaunchKernelGGL((sae_select_kernel<D, true>), SEL_ARGS);                                                    \
+    if (inline_fb) hipLaunchKernelGGL((sae_select_kernel<D, true>), SEL_ARGS);                                              \
     else hipLaunchKernelGGL((sae_select_kernel<D>), SEL_ARGS)
     if (d.d_in <= 256) { CALL(1); } else if (d.d_in <= 768) { CALL(3); } else if (d.d_in <= 1024) { CALL(4); } else { CALL(5); }
 #undef CALL
 #undef SEL_ARGS
     PV_LAUNCH_CHECK("sae_select_kernel");
-    if (pre) return PV_OK;                                      // (the folded step: undecided tokens were recomputed inside the select kernel)
+    if (inline_fb) return PV_OK;                                // (undecided tokens were recomputed inside the select kernel)
     // undecided tokens: exact rows + the streaming / radix top-k (both launches are empty-handed when the list is empty)
     hipLaunchKernelGGL(sae_fb_hidden_kernel, dim3(PV_SAE_FB_SLOTS, (d.d_sae + 1023) / 1024), dim3(256), 0, stream,
                        (const float*)(wsb + ws.sae_in), (const float*)st->W_encT, (const float*)st->b_enc, (const int32_t*)fb_list,
