@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vit_prisma_amd.sae.bench_leg import D_SAE, sae_bench_leg
 
+if os.environ.get("PV_TUNE"):                                     # A/B runs: "key=value[,key=value]"
+    from vit_prisma_amd import _native
+    for kv in os.environ["PV_TUNE"].split(","):
+        _native.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 r = sae_bench_leg(dev, dist=None, steps=int(os.environ.get("STEPS", "7")), warmup=2, activation="relu", relu_target_l0=0.035 * D_SAE)

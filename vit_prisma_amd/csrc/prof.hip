@@ -140,6 +140,7 @@ int* tuning_field(const char* key) {
     if (!strcmp(key, "enc_rounds")) return &g_pv_tuning.enc_rounds;
     if (!strcmp(key, "enc_tm256")) return &g_pv_tuning.enc_tm256;
     if (!strcmp(key, "sae_inline_fb")) return &g_pv_tuning.sae_inline_fb;
+    if (!strcmp(key, "dense_group")) return &g_pv_tuning.dense_group;
     if (!strcmp(key, "gemm_dbg")) return &g_pv_tuning.gemm_dbg;
     if (!strcmp(key, "gemm_loop")) return &g_pv_tuning.gemm_loop;
     if (!strcmp(key, "gemm_persist")) return &g_pv_tuning.gemm_persist;
@@ -171,7 +172,7 @@ extern "C" int pv_debug_get_tuning(const char* key, int32_t* value) {
         const PvTuning d;
         const PvTuning& t = g_pv_tuning;
         *value = (t.gemm_tile != d.gemm_tile || t.gemm_v1 != d.gemm_v1 || t.gemm_v1patch != d.gemm_v1patch || t.attn_wg != d.attn_wg || t.attn_direct != d.attn_direct ||
-                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.sae_fold != d.sae_fold || t.enc_rounds != d.enc_rounds || t.enc_tm256 != d.enc_tm256 || t.sae_inline_fb != d.sae_inline_fb || t.gemm_dbg != d.gemm_dbg ||
+                  t.prof_markers != d.prof_markers || t.sae_exact != d.sae_exact || t.sae_fold != d.sae_fold || t.enc_rounds != d.enc_rounds || t.enc_tm256 != d.enc_tm256 || t.sae_inline_fb != d.sae_inline_fb || t.dense_group != d.dense_group || t.gemm_dbg != d.gemm_dbg ||
                   t.gemm_loop != d.gemm_loop || t.gemm_persist != d.gemm_persist || t.gemm_stagger != d.gemm_stagger || t.gemm_cus != d.gemm_cus || t.dense_fp32 != d.dense_fp32) ? 1 : 0;
         return PV_OK;
     }

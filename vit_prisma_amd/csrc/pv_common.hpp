@@ -172,6 +172,8 @@ struct PvTuning {
     int sae_exact = 0;       // 1: SAE encoder on the exact-fp32 MFMA GEMM + streaming top-k (the small-shape / fallback path)
     int sae_fold = 1;        // 0: pv_sae_step launches its small kernels one by one (the A/B of the fused pre-pass, SaePre, the scan as a role of
                              // the decode launch, ScanRole, the merged list sorts and the Adam pair's tail roles)
+    int dense_group = -1;    // tile order of the dense SAE GEMMs (sae_dense.hip): -1 auto (wide outputs: 4 row tiles per group), 0 = N fastest
+                             // everywhere (the order up to round 6's PMC pass), n = n row tiles per group
     int sae_inline_fb = 0;   // 1: the folded SAE step recomputes a token the filter cannot decide inside the select kernel (no fallback launches:
                              // - 14 us per step) -- off: ONE such token costs the step 0.3 ms of latency (its workgroup walks all features
                              // alone), and harvested activations have a few per step (MEASURED.md); the two fallback launches spread a token

@@ -47,6 +47,7 @@ struct DenseGemm {
     const float* B; int64_t ldb;              // B_KN ? [K][ldb] (N contiguous) : [N][ldb] (K contiguous)
     int M, N, K;
     int k_chunk;                              // K range of one blockIdx.y (multiple of 32; K when not split)
+    int group;                                // set by the launcher: row tiles per group of the tile order (see the kernel), 0 = N fastest
     float* out; int64_t ldo;                  // STORE: out + blockIdx.y * out_zstride
     int64_t out_zstride;
     const float* bias;                        // ENC: b_enc [N]
@@ -157,7 +158,22 @@ __global__ __launch_bounds__(256, 2) void dense_gemm_kernel(const DenseGemm p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int ntn = (p.N + DG_BN - 1) / DG_BN;
-    const int tile_m = swz / ntn, tile_n = swz - tile_m * ntn;
+    // Tile order inside an XCD's run.  N fastest (group 0) lets the 64 tiles an XCD runs at a time share ONE row slab and stream 64
+    // different column slabs: at a wide output (the encoder and dH GEMMs: 192 column tiles of 393 KB operand rows each) every XCD
+    // drags the whole B matrix through its 4 MB L2 once per row tile -- 2.8 GB of HBM fetches for a 75 MB matrix, PMC-measured, and
+    // the kernel was bound by them.  Grouped (group G > 0): G row tiles x all column tiles per group, the row tile fastest inside --
+    // the G tiles that share a column slab run side by side, the slab is fetched once per group.
+    int tile_m, tile_n;
+    if (p.group > 0) {
+        const int ntm = (p.M + DG_BM - 1) / DG_BM;
+        const int per = p.group * ntn, g = swz / per, idx = swz - g * per;
+        const int gc = min(p.group, ntm - g * p.group);
+        tile_n = idx / gc;
+        tile_m = g * p.group + (idx - tile_n * gc);
+    } else {
+        tile_m = swz / ntn;
+        tile_n = swz - tile_m * ntn;
+    }
     const int m0 = tile_m * DG_BM, n0 = tile_n * DG_BN;
     const int k_begin = blockIdx.y * p.k_chunk, k_end = min(p.K, k_begin + p.k_chunk);
     const int nk = (k_end - k_begin + DG_KSLAB - 1) / DG_KSLAB;
@@ -568,7 +584,10 @@ int launch_dense_gemm_form(const DenseGemm& p, int splits, hipStream_t stream) {
         attr_done = true;
     }
     const int ntm = (p.M + DG_BM - 1) / DG_BM, ntn = (p.N + DG_BN - 1) / DG_BN;
-    hipLaunchKernelGGL((dense_gemm_kernel<A_KM, B_KN, EPI, SPLIT>), dim3(ntm * ntn, splits), dim3(256), DG_LDS, stream, p);
+    DenseGemm q = p;
+    // wide outputs: grouped tile order (the kernel's comment); tuning key dense_group: -1 auto (4 row tiles per group), 0 off, n
+    q.group = g_pv_tuning.dense_group >= 0 ? g_pv_tuning.dense_group : (ntn > 16 ? 4 : 0);
+    hipLaunchKernelGGL((dense_gemm_kernel<A_KM, B_KN, EPI, SPLIT>), dim3(ntm * ntn, splits), dim3(256), DG_LDS, stream, q);
     PV_LAUNCH_CHECK("dense_gemm_kernel");
     return PV_OK;
 }
