@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ pre_sum = nullptr, const float* __restrict__ addend = nullptr, float dh_add = 0.f,
     const uint32_t* __restrict__ tok_cnt = nullptr, const uint32_t* __restrict__ gate = nullptr, const ScanRole scan = ScanRole{}) {
     // scan.cnt != NULL: the launch carries one more workgroup than the tokens need, and that one runs the CSR scan (scan_body_256)
-    if (MODE == 0 && scan.cnt && blockIdx.x == gridDim.x - 1) {
+    if (MODE != 1 && scan.cnt && blockIdx.x == gridDim.x - 1) {
         scan_body_256(scan);
         return;
     }
@@ -1956,9 +1956,9 @@ static int sae_encode_topk(pv_sae_plan* plan, const pv_sae_state* st, const floa
     uint32_t* wpos = want_csr ? (wpos_over ? wpos_over : (uint32_t*)(wsb + ws.wpos)) : nullptr;
     const bool fast = pv_sae_fast_ok(d) && st->W_encT && st->W_enc16T && st->enc_colsq;
     if (want_csr && !fast) PV_HIP_CHECK(hipMemsetAsync(feat_cnt, 0, (size_t)d.d_sae * 4, stream));      // (fast path: its first kernel zeroes them)
-    // the training step's pre-pass in fused launches (SaePre)
+    // the pre-pass in fused launches (SaePre)
     SaePre pre = {x, 0, false};
-    const bool fused = fast && want_csr && !skip_prep && !cnt_over && g_pv_tuning.sae_fold;
+    const bool fused = fast && !skip_prep && !cnt_over && g_pv_tuning.sae_fold;      // (training steps, the feature-parallel encode, inference)
     if (!skip_prep) {
         int rcp = sae_prep(d, x, (const float*)st->b_dec, batch_mean, N, fast, wsb, ws, stream, sae_in_width(d, st), fused ? &pre : nullptr,
                            st, feat_cnt);
@@ -2963,6 +2963,47 @@ extern "C" int pv_sae_tp_finish(pv_sae_plan* plan, pv_sae_state* st, const float
     // the pairs that survived the global top-k: counts and within-list positions afresh
     PV_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)d.d_sae * 4, stream));
     hipLaunchKernelGGL(sae_recount_kernel, dim3((n_pairs + 255) / 256), block, 0, stream, topk_idx, topk_val, cnt, wposp, n_pairs);
+    if (g_pv_tuning.sae_fold) {
+        // the folded form (as sae_sparse_tail): the CSR scan as one more workgroup of the decode launch, the loss and dY's
+        // partial column sums as roles of the post + fill launch, one launch for both list sorts -- 11 launches instead of 16
+        const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
+        ScanRole scan = {};
+        scan.cnt = (const uint32_t*)cnt; scan.offs = (uint32_t*)(wsb + ws.offs); scan.n_long = (uint32_t*)(wsb + ws.n_long);
+        scan.d_sae = d.d_sae; scan.scalars = out->scalars; scan.inv_tokens = 1.0f / (float)N;
+        const dim3 grid((N + 3) / 4 + 1);
+#define CALL(D)                                                                                                        \
+    hipLaunchKernelGGL((sae_decode_kernel<D, 2>), grid, block, 0, stream, x, (const float*)st->W_dec, (const float*)st->b_dec, \
+                       topk_idx, topk_val, (const float*)(wsb + ws.mu), (const float*)(wsb + ws.sd),                    \
+                       (const float*)(wsb + ws.norm), out->sae_out, dY, dh, (float*)(wsb + ws.loss_part), N, d.d_in, k, \
+                       grad_scale, 1, inv_norm, pre_sum, (const float*)nullptr, 0.f, (const uint32_t*)nullptr,          \
+                       (const uint32_t*)nullptr, scan)
+        V4_DISPATCH(d.d_in, CALL);
+#undef CALL
+        PV_LAUNCH_CHECK("sae_decode_kernel (finish)");
+        SaeTail tb;
+        tb.dh = dh; tb.chunk_start = (uint32_t*)(wsb + ws.cursor); tb.wpos = wposp;
+        tb.seg_range = (uint32_t*)(wsb + ws.seg_range); tb.seg_rows = (float*)(wsb + ws.seg_rows); tb.seg_b = (float*)(wsb + ws.seg_b);
+        tb.pairs = (int32_t*)(wsb + ws.pairs); tb.max_segs = (int)sae_max_segs((size_t)n_pairs);
+        int rc = sae_csr_build(plan, st, N, k, topk_idx, dY, out->scalars, out->fire_count, update_stats, false, tb, wsb, ws,
+                               (const float*)(wsb + ws.loss_part), 1.0f / ((float)n_global * (float)d.d_in), true, nullptr, stream, nullptr,
+                               true);
+        if (rc) return rc;
+        rc = sae_csr_grads(plan, st, N, k, topk_idx, topk_val, dh, dY, sae_in, false, tb, wsb, ws, nullptr, stream, nullptr, nullptr);
+        if (rc) return rc;
+        const int nblk = (N + CS_ROWS - 1) / CS_ROWS, ngb = (d.d_sae + GBD_ROWS - 1) / GBD_ROWS;
+        float* colpart = (float*)(wsb + ws.colpart);
+        hipLaunchKernelGGL(sae_gbdec_partial_kernel, dim3(ngb), dim3(256), 0, stream, (const float*)st->W_encT, (const float*)st->gb_enc,
+                           colpart + (size_t)nblk * d.d_in, d.d_sae, d.d_in);
+        // PV_SAE_TP_ENC_TERM_ONLY: every rank holds the same dY; only one of them contributes its column sum to the all-reduce
+        if (flags & PV_SAE_TP_ENC_TERM_ONLY)
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream,
+                               (const float*)(colpart + (size_t)nblk * d.d_in), st->gb_dec, ngb, d.d_in, 1.0f);
+        else
+            hipLaunchKernelGGL(colsum_final_kernel, dim3((d.d_in + 63) / 64), dim3(1024), 0, stream, (const float*)colpart, st->gb_dec,
+                               nblk + ngb, d.d_in, 1.0f);
+        PV_LAUNCH_CHECK("sae bias-grad kernels");
+        return PV_OK;
+    }
     {
         const float grad_scale = 2.0f / ((float)n_global * (float)d.d_in);
         const dim3 grid((N + 3) / 4);
