@@ -515,7 +515,9 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
             p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)p.slots ? 0xffffffffu : c;
-            if (p.mode && c > (uint32_t)p.slots) atomicOr(p.mode, 1u);
+            const bool over = p.mode && c > (uint32_t)p.slots;
+            const unsigned long long who = __ballot(over);         // one atomic per wave, not one per overflowed row: on a dense batch
+            if (who != 0ull && lane == __ffsll((long long)who) - 1) atomicOr(p.mode, 1u);      // every row of the first 256 tiles overflows
         }
     }
 }
@@ -1049,7 +1051,10 @@ __global__ __launch_bounds__(256) void relu_select_kernel(
     bad = bad || sh_bad != 0u || m > (uint32_t)cap;
     if (bad) {                                                 // (uniform) this token cannot be held: the whole step goes dense
         if (tid == 0) {
-            atomicOr(mode, 1u); tok_cnt[row] = 0u; l1part[row] = 0.f;
+            // (a workgroup that FOUND the word raised leaves it alone: at the published L0 every one of the 4096 does, and their
+            // atomics on the one word were 40 of the 62 us this kernel took to do nothing)
+            if (!already_dense) atomicOr(mode, 1u);
+            tok_cnt[row] = 0u; l1part[row] = 0.f;
             if constexpr (GATED) l0part[row] = 0.f;
         }
         for (int s = tid; s < cap; s += 256) {
