@@ -101,6 +101,67 @@ __device__ __forceinline__ void sae_prep_body(int bid, const float* __restrict__
     const int n = bid * 4 + (threadIdx.x >> 6);
     if (n >= n_tok) return;
     const float* xr = x + (int64_t)n * d;
+    // Rows of up to 64 * PREP_NE elements live in registers: ONE round trip to memory for the row (all of a lane's loads in flight),
+    // the three passes below run out of registers.  The loops further down re-read the row from memory with one dependent load per
+    // trip -- 3 x 12 round trips at d = 768, 14 of this kernel's 17 us by its waves' PMC lifetimes; they remain for wider rows.  Same
+    // operations in the same order either way.
+    constexpr int PREP_NE = 20;
+    if (d <= 64 * PREP_NE) {
+        float xv[PREP_NE], bm[PREP_NE], bd[PREP_NE];
+#pragma unroll
+        for (int u = 0; u < PREP_NE; ++u) {
+            const int i = lane + 64 * u;
+            xv[u] = i < d ? xr[i] : 0.f;
+            bm[u] = (batch_mean && i < d_true) ? batch_mean[i] : 0.f;
+            bd[u] = i < d_true ? b_dec[i] : 0.f;
+        }
+        float s = 0.f, cn = 0.f;
+#pragma unroll
+        for (int u = 0; u < PREP_NE; ++u) {
+            if (lane + 64 * u < d_true) {
+                s += xv[u];
+                if (batch_mean) {
+                    const float c = xv[u] - bm[u];
+                    cn += c * c;
+                }
+            }
+        }
+        const float mu = use_ln == 1 ? wave_sum(s) / (float)d_true : 0.f;
+        cn = wave_sum(cn);
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < PREP_NE; ++u) {
+            if (lane + 64 * u < d_true) {
+                const float c = xv[u] - mu;
+                sq += c * c;
+            }
+        }
+        sq = wave_sum(sq);
+        const float coeff = use_ln == 2 ? sqrtf((float)d_true) / sqrtf(sq) : 1.f;
+        const float sd = use_ln == 1 ? sqrtf(sq / (float)(d_true - 1)) : (use_ln == 2 ? 1.f / coeff : 1.f);
+        float s2 = 0.f, amax = 0.f;
+#pragma unroll
+        for (int u = 0; u < PREP_NE; ++u) {
+            const int i = lane + 64 * u;
+            if (i < d) {
+                const float xh = use_ln == 1 ? (xv[u] - mu) / (sd + eps) : (use_ln == 2 ? xv[u] * coeff : xv[u]);
+                const float si = i < d_true ? xh - bd[u] : 0.f;
+                sae_in[(int64_t)n * d + i] = si;
+                if (x16) x16[(int64_t)n * d + i] = (_Float16)si;
+                s2 += si * si;
+                amax = fmaxf(amax, fabsf(si));
+            }
+        }
+        s2 = wave_sum(s2);
+        amax = wave_max(amax);
+        if (lane == 0) {
+            mu_out[n] = mu;
+            std_out[n] = sd;
+            if (batch_mean) norm_out[n] = sqrtf(cn);
+            if (xnorm_out) xnorm_out[n] = (amax <= 6.0e4f) ? sqrtf(s2) : INFINITY;
+        }
+        return;
+    }
     // batch_mean == NULL: the loss normaliser is left to a later kernel (the select kernel of the fused pre-pass, SaePre)
     float s = 0.f, cn = 0.f;
     if (batch_mean) {
@@ -153,8 +214,9 @@ __global__ __launch_bounds__(256) void sae_prep_kernel(const float* __restrict__
                                                        int d_true) {
     sae_prep_body(blockIdx.x, x, b_dec, batch_mean, sae_in, x16, xnorm_out, mu_out, std_out, norm_out, n_tok, d, use_ln, eps, d_true);
 }
-// The first launch of the fused pre-pass (SaePre): workgroups [0, nb_prep) = prep without the loss normaliser, [nb_prep, nb_prep + nblk)
-// = the 16-row partial column sums of x (the batch mean's first stage; nblk = 0 when the caller supplied the mean), the last one = the
+// The first launch of the fused pre-pass (SaePre): workgroup 0 = the weight bound (below), [1, 1 + nblk) = the 16-row partial column
+// sums of x (the batch mean's first stage; nblk = 0 when the caller supplied the mean), the other nb_prep = prep without the loss
+// normaliser.  The
 // weight bound max_j ||W_enc[:, j]||^2 of the filter's error band + the zeroing of the per-feature pair counters and the fallback
 // count (sae_wmax_kernel of sae_enc.hip on 256 threads; a maximum does not care about the order)
 __global__ __launch_bounds__(256) void sae_prep_roles_kernel(const float* __restrict__ x, const float* __restrict__ b_dec,
@@ -164,22 +226,31 @@ __global__ __launch_bounds__(256) void sae_prep_roles_kernel(const float* __rest
                                                              int d_true, int nb_prep, float* __restrict__ colpart, int nblk,
                                                              const float* __restrict__ colsq, int d_sae, float* __restrict__ wmax_out,
                                                              uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt) {
+    // (the one workgroup of the weight bound is the launch's longest job: it goes FIRST, the column sums next, the tokens last)
     const int b = blockIdx.x;
-    if (b < nb_prep) {
-        sae_prep_body(b, x, b_dec, nullptr, sae_in, x16, xnorm_out, mu_out, std_out, nullptr, n_tok, d, use_ln, eps, d_true);
-    } else if (b < nb_prep + nblk) {
-        colsum_partial_body(b - nb_prep, x, colpart, n_tok, d);
+    if (b > nblk) {
+        sae_prep_body(b - 1 - nblk, x, b_dec, nullptr, sae_in, x16, xnorm_out, mu_out, std_out, nullptr, n_tok, d, use_ln, eps, d_true);
+    } else if (b > 0) {
+        colsum_partial_body(b - 1, x, colpart, n_tok, d);
     } else {
         __shared__ float red[4];
+        // (one workgroup for d_sae values and the launch's long pole: 16-byte accesses, all of a thread's loads in flight at once;
+        // d_sae % 4 == 0 is a plan requirement)
+        const int n4 = d_sae >> 2;
         if (feat_cnt)
-            for (int j = threadIdx.x; j < d_sae; j += 256) feat_cnt[j] = 0u;
+            for (int j = threadIdx.x; j < n4; j += 256) reinterpret_cast<uint4*>(feat_cnt)[j] = make_uint4(0u, 0u, 0u, 0u);
         float m = 0.f;
-        for (int j0 = threadIdx.x; j0 < d_sae; j0 += 8 * 256) {     // 8 independent loads in flight per thread
-            float c[8];
+        constexpr int WM_FL = 12;                                  // (the bench shape: two round trips to memory; 24 in flight cost the launch its occupancy)
+        for (int j0 = threadIdx.x; j0 < n4; j0 += WM_FL * 256) {
+            float4 c[WM_FL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = j0 + u * 256 < d_sae ? colsq[j0 + u * 256] : 0.f;
+            for (int u = 0; u < WM_FL; ++u) c[u] = j0 + u * 256 < n4 ? reinterpret_cast<const float4*>(colsq)[j0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) m = (c[u] == c[u]) ? fmaxf(m, c[u]) : INFINITY;      // a NaN column norm poisons the bound (-> exact fallback)
+            for (int u = 0; u < WM_FL; ++u) {
+                const float e[4] = {c[u].x, c[u].y, c[u].z, c[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = (e[i] == e[i]) ? fmaxf(m, e[i]) : INFINITY;      // a NaN column norm poisons the bound (-> exact fallback)
+            }
         }
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -1181,12 +1252,21 @@ __global__ __launch_bounds__(1024) void colsum_final_sq_kernel(const float* __re
     const int b = blockIdx.x, nb = gridDim.x;
     const float g = colsum_final_body(b, partial, out, nblk, d, 1.0f);
     const float t = sq_block_terms(b, nb, g, rowsq, d_sae, red16);
+    __shared__ uint32_t last;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&sqpart[b], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (mine == (uint32_t)nb - 1u) {
-            float total = 0.f;
-            for (int i = 0; i < nb; ++i) total += __hip_atomic_load(&sqpart[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = mine == (uint32_t)nb - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+        // lane i fetches partial i (one memory round trip for all of them: read one after the other by one thread they were most of
+        // this launch's time), lane 0 adds them in block order (nb <= 64: d_in <= 4096)
+        const int lane = threadIdx.x;
+        const float mine = lane < nb ? __hip_atomic_load(&sqpart[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        float total = 0.f;
+        for (int i = 0; i < nb; ++i) total += __shfl(mine, i, 64);
+        if (lane == 0) {
             scalars[3] = total;
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1219,15 +1299,33 @@ __device__ __forceinline__ void gbdec_partial_body(int bid, const float* __restr
     float4 acc[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = j0 + wv; j < j1; j += 4) {
-        const float g = gb_enc[j];
-        if (g == 0.f) continue;                          // (wave-uniform)
+    // (four of the wave's rows in flight: one row per trip was a chain of 24 dependent row fetches, the launch's whole 13 us; the rows
+    // are still added in row order, a row no token kept is still neither read nor added)
+    for (int jb = j0 + wv; jb < j1; jb += 16) {
+        float g[4];
+        float4 w[4][5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int c = 4 * lane + 256 * i;
-            if (c < d) {
-                const float4 w = *reinterpret_cast<const float4*>(W_encT + (int64_t)j * d + c);
-                acc[i].x -= g * w.x; acc[i].y -= g * w.y; acc[i].z -= g * w.z; acc[i].w -= g * w.w;
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + 4 * u;
+            g[u] = j < j1 ? gb_enc[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + 4 * u;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int c = 4 * lane + 256 * i;
+                w[u][i] = (g[u] != 0.f && c < d) ? *reinterpret_cast<const float4*>(W_encT + (int64_t)j * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g[u] == 0.f) continue;                   // (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (4 * lane + 256 * i < d) {
+                    acc[i].x -= g[u] * w[u][i].x; acc[i].y -= g[u] * w[u][i].y; acc[i].z -= g[u] * w[u][i].z; acc[i].w -= g[u] * w[u][i].w;
+                }
             }
         }
     }
@@ -2819,8 +2917,8 @@ extern "C" int pv_sae_step(pv_sae_plan* plan, pv_sae_state* st, const float* x, 
     const bool fused_sq = (flags & PV_SAE_FUSED_SQNORM) != 0;
     PV_REQUIRE(plan && st && x && out && workspace, "null argument");
     PV_REQUIRE(out->topk_idx && out->topk_val && out->scalars, "pv_sae_out buffers");
-    PV_REQUIRE(!fused_sq || st->tc.b_dec_out == nullptr,
-               "PV_SAE_FUSED_SQNORM: autoencoder states (a transcoder's clip norm has more terms: pv_sae_grad_sqnorm_step)");
+    PV_REQUIRE(!fused_sq || (st->tc.b_dec_out == nullptr && plan->d.d_in <= 4096),
+               "PV_SAE_FUSED_SQNORM: autoencoder states of d_in <= 4096 (a transcoder's clip norm has more terms: pv_sae_grad_sqnorm_step)");
     PV_REQUIRE(st->W_dec && st->b_enc && st->b_dec && st->gW_enc && st->gW_dec && st->gb_enc && st->gb_dec, "state");
     PV_REQUIRE(st->W_encT, "pv_sae_step needs the transposed encoder copy (pv_sae_state.W_encT, see pv_sae_sync_shadows)");
     PV_REQUIRE(!update_stats || (st->act_freq_scores && st->n_fwd_since_fired), "stats buffers");

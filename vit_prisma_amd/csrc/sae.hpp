@@ -36,27 +36,28 @@ struct SaeWs {
 };
 SaeWs sae_carve(const pv_sae_desc& d);
 
-// out[c] = scale * sum_blk partial[blk][c] for the 64 columns of workgroup `bid`, on 256 threads in the summation order of the 1024-thread
-// colsum_final_kernel (sae.hip: 16 partial streams per column, then their sum in stream order) -- each thread plays four of its threads
+// out[c] = scale * sum_blk partial[blk][c] for the 16 columns of workgroup `bid`, on 256 threads in the summation order of the 1024-thread
+// colsum_final_kernel (sae.hip: 16 partial streams per column, then their sum in stream order): thread (part, column) walks stream
+// `part` of its column -- 16 independent loads -- as a thread of that kernel does; a workgroup just spans 16 columns instead of 64
+// (a first form kept 64 columns per workgroup and let every thread play four parts one after the other: 24 us, PMC-measured wave
+// lifetimes, for a 786 KB sum).  (d + 15) / 16 workgroups.
 #ifdef __HIPCC__
 __device__ __forceinline__ void colsum_final_body_256(int bid, const float* __restrict__ partial, float* __restrict__ out, int nblk, int d,
                                                       float scale) {
-    __shared__ float cf_red[16][64];
-    const int lane = threadIdx.x & 63, p4 = threadIdx.x >> 6;
-    const int c = bid * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int part = p4 + 4 * q;
-        float s = 0.f;
-        if (c < d)
-            for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
-        cf_red[part][lane] = s;
+    __shared__ float cf_red[16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = bid * 16 + cl;
+    float s = 0.f;
+    if (c < d) {
+#pragma unroll 8
+        for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
     }
+    cf_red[part][cl] = s;
     __syncthreads();
-    if (p4 == 0 && c < d) {
+    if (part == 0 && c < d) {
         float t = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += cf_red[q][lane];        // fixed order
+        for (int q = 0; q < 16; ++q) t += cf_red[q][cl];          // fixed order
         out[c] = t * scale;
     }
 }

@@ -346,7 +346,7 @@ class NativeSAE:
         bm = None
         if batch_mean is not None:
             bm = self._bm(batch_mean)
-        fuse = bool(fused_sqnorm) and not self.transcoder
+        fuse = bool(fused_sqnorm) and not self.transcoder and self.d_in <= 4096
         N.check(self.lib.pv_sae_step(self._plan, C.byref(st), x.data_ptr(), n, bm.data_ptr() if bm is not None else None,
                                      int(n_global if n_global is not None else n),
                                      int(bool(update_stats)) | (2 if renorm_decoder else 0) | (4 if inv_valid else 0) |
