@@ -68,8 +68,10 @@ __device__ __forceinline__ float colsum_final_body(int bid, const float* __restr
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = bid * 64 + lane;
     float s = 0.f;
-    if (c < d)
-        for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];
+    if (c < d) {
+#pragma unroll 8
+        for (int b = part; b < nblk; b += 16) s += partial[(int64_t)b * d + c];      // (unrolled: the loads of 8 trips in flight, the sum in order)
+    }
     red[part][lane] = s;
     __syncthreads();
     if (part == 0 && c < d) {
@@ -376,11 +378,13 @@ __device__ __forceinline__ void scan_body_256(const ScanRole& r) {
     uint32_t s = 0;
     {
         int i = lo;
-        if (quads)
+        if (quads) {
+#pragma unroll 8
             for (; i + 4 <= hi; i += 4) {
                 const uint4 c = *reinterpret_cast<const uint4*>(r.cnt + i);
                 s += c.x + c.y + c.z + c.w;
             }
+        }
         for (; i < hi; ++i) s += r.cnt[i];
     }
     uint32_t inc = s;
@@ -400,6 +404,7 @@ __device__ __forceinline__ void scan_body_256(const ScanRole& r) {
     {
         int i = lo;
         if (quads)
+#pragma unroll 8
             for (; i + 4 <= hi; i += 4) {
                 const uint4 c = *reinterpret_cast<const uint4*>(r.cnt + i);
                 uint4 o;
@@ -423,6 +428,9 @@ __device__ __forceinline__ void scan_body_256(const ScanRole& r) {
 // MODE 0: the whole thing.  The feature-parallel step cuts it at the reconstruction: MODE 1 = this rank's PARTIAL
 // reconstruction sum_s val_s W_dec[idx_s] only (written to sae_out, no b_dec, no LN-out); MODE 2 = everything behind it, the
 // reconstruction summed over the ranks coming in through pre_sum.
+#ifndef PV_DEC_ROWS
+#define PV_DEC_ROWS 4
+#endif
 template <int V4, int MODE = 0>
 __global__ __launch_bounds__(256) void sae_decode_kernel(
     const float* __restrict__ x, const float* __restrict__ W_dec, const float* __restrict__ b_dec,
@@ -468,14 +476,18 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
 #pragma unroll
         for (int i = 0; i < V4; ++i) acc[i] = ld4(addend + (int64_t)n * d + col[i], ok[i]);
     }
-    for (int s = 0; MODE != 2 && s < k_walk; s += 4) {
-        float a[4];
-        float4 w[4][V4];
+    // DEC_R rows of W_dec in flight per trip (k_walk is a multiple of 4; a trip that reaches past it gathers nothing for those slots: a = 0).
+    // 4: 106 VGPRs = four waves per SIMD = all 4096 tokens of the bench batch resident at once.  8 halves the dependent trips and
+    // costs a wave per SIMD: 66 -> 90 us (tools/probes/dec_rows_ab.sh, -DPV_DEC_ROWS=8; same bits)
+    constexpr int DEC_R = PV_DEC_ROWS;
+    for (int s = 0; MODE != 2 && s < k_walk; s += DEC_R) {
+        float a[DEC_R];
+        float4 w[DEC_R][V4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEC_R; ++u) {
             const int su = min(s + u, k - 1);
             const int ju = ir[su];
-            a[u] = s + u < k ? vr[su] : 0.f;
+            a[u] = s + u < k_walk ? vr[su] : 0.f;
             const bool live = a[u] != 0.f;                        // (wave-uniform) a hole -- a candidate that lost the global top-k of the
                                                                   // feature-parallel step, a clamped negative -- gathers nothing
             if (inv_norm) a[u] *= inv_norm[ju];
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
             for (int i = 0; i < V4; ++i) w[u][i] = ld4(wr + col[i], ok[i] && live);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)                       // (slot order, as torch's dense matmul would not care; fixed here)
+        for (int u = 0; u < DEC_R; ++u)                   // (slot order, as torch's dense matmul would not care; fixed here)
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 acc[i].x += a[u] * w[u][i].x; acc[i].y += a[u] * w[u][i].y;
@@ -520,13 +532,13 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
     lsum = wave_sum(lsum);
     if (lane == 0) loss_partial[n] = lsum;
     if (!want_grad) return;
-    for (int s = 0; s < k_walk; s += 4) {
-        float dot[4];
+    for (int s = 0; s < k_walk; s += DEC_R) {
+        float dot[DEC_R];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEC_R; ++u) {
             const int su = min(s + u, k - 1);
             const int ju = ir[su];
-            const bool live = vr[su] > 0.f;                       // (wave-uniform) dh of a hole is gated to 0 below: no gather
+            const bool live = s + u < k_walk && vr[su] > 0.f;     // (wave-uniform) dh of a hole is gated to 0 below: no gather
             const float* wr = W_dec + (int64_t)ju * d;
             float t = 0.f;
 #pragma unroll
@@ -536,10 +548,12 @@ __global__ __launch_bounds__(256) void sae_decode_kernel(
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+            for (int u = 0; u < DEC_R; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
         // TopK backward: gradient reaches only selected entries; ReLU gate on the kept value
-        if (lane < 4 && s + lane < k) {
-            const float dsel = lane == 0 ? dot[0] : (lane == 1 ? dot[1] : (lane == 2 ? dot[2] : dot[3]));
+        if (lane < DEC_R && s + lane < k && s + lane < ((k_walk + 3) & ~3)) {
+            float dsel = dot[0];
+#pragma unroll
+            for (int u = 1; u < DEC_R; ++u) dsel = lane == u ? dot[u] : dsel;
             dh[(int64_t)n * k + s + lane] = vr[s + lane] > 0.f ? dsel + dh_add : 0.f;
         }
     }
