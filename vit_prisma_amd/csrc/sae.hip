@@ -1221,7 +1221,8 @@ __global__ __launch_bounds__(1024) void sqnorm_rowsq_kernel(const float* __restr
                                                             int n0, const float* __restrict__ extra1, int n1) {
     __shared__ float red[16];
     float s = 0.f;
-    for (int j = threadIdx.x; j < d_sae; j += 1024) s += rowsq[j];
+#pragma unroll 8
+    for (int j = threadIdx.x; j < d_sae; j += 1024) s += rowsq[j];             // (8 loads in flight; the sum in order)
     for (int i = threadIdx.x; i < d_in; i += 1024) s += gb_dec[i] * gb_dec[i];
     for (int i = threadIdx.x; i < n0; i += 1024) s += extra0[i] * extra0[i];          // transcoder: gb_dec_out, gW_skip
     for (int i = threadIdx.x; i < n1; i += 1024) s += extra1[i] * extra1[i];
