@@ -2480,7 +2480,8 @@ __global__ __launch_bounds__(256) void gated_feat_kernel(const uint32_t* __restr
     if (j >= F) return;
     const uint32_t beg = offs[j], end = offs[j + 1];
     float sg = 0.f, sm = 0.f, smf = 0.f, sp = 0.f, fired = 0.f;
-    for (uint32_t q = beg + lane; q < end; q += 64) {
+#pragma unroll 4
+    for (uint32_t q = beg + lane; q < end; q += 64) {      // (unrolled: the gathers of four trips in flight; the sums in order)
         const int p = pairs[q];
         const float f = valf[p], m = dM[p];
         sg += dG[p];

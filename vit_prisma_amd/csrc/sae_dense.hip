@@ -1618,6 +1618,30 @@ __global__ __launch_bounds__(256) void gated_l1_rows_kernel(float* __restrict__ 
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= F) return;
     if (pgsum[j] == 0.f) return;                               // (no token opened this gate: a zero term; most rows of a sparse step)
+    // (rows of up to 64 * L1_NE elements: the row of W_dec and of gW_dec in registers, all loads in flight -- two loops of one dependent
+    // load per trip were 24 round trips to memory per row; same lane mapping, same order)
+    constexpr int L1_NE = 20;
+    if (d <= 64 * L1_NE) {
+        float wv[L1_NE], gv[L1_NE];
+#pragma unroll
+        for (int u = 0; u < L1_NE; ++u) {
+            const int c = lane + 64 * u;
+            wv[u] = c < d ? W_dec[(int64_t)j * d + c] : 0.f;
+            gv[u] = c < d ? gW_dec[(int64_t)j * d + c] : 0.f;
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < L1_NE; ++u)
+            if (lane + 64 * u < d) sq += wv[u] * wv[u];
+        sq = wave_sum(sq);
+        const float s = coef * pgsum[j] / sqrtf(sq);
+#pragma unroll
+        for (int u = 0; u < L1_NE; ++u) {
+            const int c = lane + 64 * u;
+            if (c < d) gW_dec[(int64_t)j * d + c] = gv[u] + s * wv[u];
+        }
+        return;
+    }
     float sq = 0.f;
     for (int c = lane; c < d; c += 64) { const float w = W_dec[(int64_t)j * d + c]; sq += w * w; }
     sq = wave_sum(sq);
