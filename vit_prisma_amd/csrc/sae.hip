@@ -2512,6 +2512,7 @@ __global__ __launch_bounds__(256) void gated_sparse_scalars_kernel(const float* 
     __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float a = 0.f, b = 0.f, c = 0.f, e = 0.f;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n_tok; i += 256) { a += mse_part[i]; b += aux_part[i]; c += l1part[i]; e += l0part[i]; }
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); e = wave_sum(e);
     if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; red[3][wv] = e; }
@@ -2786,6 +2787,7 @@ __global__ __launch_bounds__(256) void gated_topk_scalars_kernel(const float* __
     __shared__ float red[3][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float a = 0.f, b = 0.f, e = 0.f;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n_tok; i += 256) { a += mse_part[i]; b += aux_part[i]; e += l0part[i]; }
     a = wave_sum(a); b = wave_sum(b); e = wave_sum(e);
     if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = e; }

@@ -1154,7 +1154,8 @@ __global__ __launch_bounds__(256) void relu_sparse_scalars_kernel(const float* _
     __shared__ float red[4];
     if (*mode != 0u) return;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) s += l1part[i];
+#pragma unroll 8
+    for (int i = threadIdx.x; i < n; i += 256) s += l1part[i];        // (loads of 8 trips in flight, the sum in order)
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
