@@ -607,6 +607,106 @@ __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // select: candidates -> exact top-k.  One workgroup per token.
 // ---------------------------------------------------------------------------------------------------
+#ifndef PV_SEL_WAVES
+#define PV_SEL_WAVES 8        // waves per SIMD the select kernel is compiled for (see the kernel)
+#endif
+// The k-th largest (with multiplicity) of nc <= 64 KPL ordered keys in LDS, by ONE wave: KPL keys per lane in registers, a radix select
+// from the highest bit in which the keys differ -- a ballot + popcount per key and bit -- that stops as soon as the survivors are exactly
+// the ones still wanted (~10 bits on ordinary data).  Every lane returns the key.
+template <int KPL>
+__device__ __forceinline__ uint32_t sel_radix_kth(const uint32_t* ckey, uint32_t nc, uint32_t k, int lane) {
+    uint32_t key[KPL];
+    uint32_t alive = 0u;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const uint32_t c = (uint32_t)lane + 64u * i;
+        key[i] = c < nc ? ckey[c] : 0u;
+        alive |= c < nc ? (1u << i) : 0u;
+    }
+    auto alive_minmax = [&](uint32_t& mn, uint32_t& mx) {
+        mn = 0xffffffffu; mx = 0u;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i)
+            if (alive & (1u << i)) { mn = min(mn, key[i]); mx = max(mx, key[i]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+    };
+    uint32_t kmin, kmax;
+    alive_minmax(kmin, kmax);
+    uint32_t krem = k, n_alive = nc;
+    if (kmin != kmax) {
+        for (int b = 31 - __clz((int)(kmin ^ kmax)); b >= 0; --b) {       // (everything below is wave-uniform)
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i)
+                cnt += (uint32_t)__popcll(__ballot(((alive >> i) & 1u) != 0u && ((key[i] >> b) & 1u) != 0u));
+            const bool take1 = cnt >= krem;                               // the k-th largest has this bit set
+#pragma unroll
+            for (int i = 0; i < KPL; ++i)
+                if ((((key[i] >> b) & 1u) != 0u) != take1) alive &= ~(1u << i);
+            if (take1) n_alive = cnt;
+            else { krem -= cnt; n_alive -= cnt; }
+            if (n_alive == krem || krem == 1u) break;
+        }
+        alive_minmax(kmin, kmax);
+    }
+    // survivors == wanted: the smallest of them; one wanted (or all survivors equal): the largest
+    return n_alive == krem ? kmin : kmax;
+}
+
+// the same for any nc <= 1024 (PV_SAE_CAND_CAP): the keys stay in LDS, a 16-bit mask per lane says which of its (up to 16) keys are alive
+__device__ __forceinline__ uint32_t sel_radix_kth_lds(const uint32_t* ckey, uint32_t nc, uint32_t k, int lane) {
+    const int nk = (int)((nc + 63u) >> 6);                     // keys per lane (wave-uniform)
+    uint32_t alive = 0u;
+    for (int i = 0; i < nk; ++i) alive |= ((uint32_t)lane + 64u * i) < nc ? (1u << i) : 0u;
+    auto alive_minmax = [&](uint32_t& mn, uint32_t& mx) {
+        mn = 0xffffffffu; mx = 0u;
+        for (int i = 0; i < nk; ++i)
+            if (alive & (1u << i)) { const uint32_t key = ckey[lane + 64 * i]; mn = min(mn, key); mx = max(mx, key); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+    };
+    uint32_t kmin, kmax;
+    alive_minmax(kmin, kmax);
+    uint32_t krem = k, n_alive = nc;
+    if (kmin != kmax) {
+        for (int b = 31 - __clz((int)(kmin ^ kmax)); b >= 0; --b) {       // (everything below is wave-uniform)
+            uint32_t cnt = 0, ones = 0u;
+            for (int i = 0; i < nk; ++i) {
+                const bool one = ((alive >> i) & 1u) != 0u && ((ckey[lane + 64 * i] >> b) & 1u) != 0u;
+                cnt += (uint32_t)__popcll(__ballot(one));
+                ones |= one ? (1u << i) : 0u;
+            }
+            const bool take1 = cnt >= krem;                               // the k-th largest has this bit set
+            alive = take1 ? ones : (alive & ~ones);
+            if (take1) n_alive = cnt;
+            else { krem -= cnt; n_alive -= cnt; }
+            if (n_alive == krem || krem == 1u) break;
+        }
+        alive_minmax(kmin, kmax);
+    }
+    return n_alive == krem ? kmin : kmax;
+}
+
+#ifdef PV_SEL_TRACE       // (debug build, tools/build_variant.sh: per-workgroup time stamps of the select kernel into the hidden scratch -- 100 MHz wall clock)
+#define SEL_STAMP(slot)                                                                                                   \
+    do {                                                                                                                  \
+        if (hidden && threadIdx.x == 0) {                                                                                 \
+            uint64_t* tr = reinterpret_cast<uint64_t*>(hidden);                                                           \
+            tr[(int64_t)blockIdx.x * 4 + (slot)] = wall_clock64();                                                        \
+            if ((slot) == 0) tr[(int64_t)blockIdx.x * 4 + 3] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+                                                              (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);        \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define SEL_STAMP(slot) do { } while (0)
+#endif
 // INLINE_FB (the folded training step): a token the filter cannot decide is recomputed exactly by ITS OWN workgroup, right here -- the
 // row of exact pre-activations in sae_fb_hidden_kernel's arithmetic (a wave per feature, the same fma chain, wave_sum), then
 // sae_topk_row_lds on the LDS of the candidate pass -- instead of being listed for the two fallback launches, which cost 9 us + two
@@ -614,21 +714,27 @@ __global__ __launch_bounds__(1024) void sae_wmax_kernel(const float* __restrict_
 // ~0.3 ms (24 576 x 768 fp32 MACs on four waves); a batch in which EVERY token does (adversarial data) takes about as long as the
 // 32 x 24 workgroups of the listed form did.
 template <int V4, bool INLINE_FB = false>
-__global__ __launch_bounds__(256) void sae_select_kernel(
+__global__ __launch_bounds__(256, PV_SEL_WAVES) void sae_select_kernel(
     const float* __restrict__ sae_in, const float* __restrict__ W_encT, const float* __restrict__ b_enc,
     const uint32_t* __restrict__ tile_cnt, const int2* __restrict__ cand, const float* __restrict__ sq,
     const float* __restrict__ band, int32_t* __restrict__ idx_out, float* __restrict__ val_out, int32_t* __restrict__ fb_list,
     uint32_t* __restrict__ fb_count, uint32_t* __restrict__ feat_cnt, uint32_t* __restrict__ wpos, int d, int k, int ntn, int slots,
     const float* __restrict__ xn = nullptr, const float* __restrict__ batch_mean = nullptr, float* __restrict__ norm_out = nullptr,
     int d_true = 0, float* __restrict__ hidden = nullptr) {
-    __shared__ uint32_t ckey[PV_SAE_CAND_CAP];
-    __shared__ int32_t cidx[PV_SAE_CAND_CAP];
+#ifdef PV_SEL_CAP_TEST        // (timing experiment, tools/build_variant.sh: a smaller candidate list = less LDS per workgroup = more workgroups per CU?)
+    constexpr int SEL_CAP = PV_SEL_CAP_TEST;
+#else
+    constexpr int SEL_CAP = PV_SAE_CAND_CAP;
+#endif
+    __shared__ uint32_t ckey[SEL_CAP];
+    __shared__ int32_t cidx[SEL_CAP];
     __shared__ int32_t ridx[PV_SAE_RESCORE_MAX];
     __shared__ float rval[PV_SAE_RESCORE_MAX];
     __shared__ uint32_t tcnt[256];
     __shared__ uint32_t sh_t, sh_nr, sh_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
+    SEL_STAMP(0);
     // (the fused pre-pass, SaePre) the loss normaliser ||x_n - mean_batch(x)||_2 that prep left out because the mean was not there yet:
     // sae_prep_kernel's loop in its order, on the wave that has nothing to do while the candidate lists are gathered.  The loads leave
     // here; they are used behind the candidate pass (the first barrier of the kernel would otherwise wait for this wave's HBM trip)
@@ -659,7 +765,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
             off += t < tid ? c : 0u;
             n += c;
         }
-        bad = n > (uint32_t)PV_SAE_CAND_CAP || n < (uint32_t)k;
+        bad = n > (uint32_t)SEL_CAP || n < (uint32_t)k;
     }
     if (!bad && tid < ntn && myc > 0u) {
         const int2* src = cand + (row * ntn + tid) * slots;
@@ -688,60 +794,14 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
 #ifdef PV_SEL_RANK2                                            // (timing ablation, tools/build_variant.sh: the pass twice)
     for (int rep = 0; rep < 2; ++rep)
 #endif
-    if (!bad && nc <= 256u) {
-        if (wave == 0) {
-            uint32_t key[4];
-            uint32_t alive = 0u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t c = (uint32_t)lane + 64u * i;
-                key[i] = c < nc ? ckey[c] : 0u;
-                alive |= c < nc ? (1u << i) : 0u;
-            }
-            auto alive_minmax = [&](uint32_t& mn, uint32_t& mx) {
-                mn = 0xffffffffu; mx = 0u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (alive & (1u << i)) { mn = min(mn, key[i]); mx = max(mx, key[i]); }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-                    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-                }
-            };
-            uint32_t kmin, kmax;
-            alive_minmax(kmin, kmax);
-            uint32_t krem = (uint32_t)k, n_alive = nc;
-            if (kmin != kmax) {
-                for (int b = 31 - __clz((int)(kmin ^ kmax)); b >= 0; --b) {       // (everything below is wave-uniform)
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        cnt += (uint32_t)__popcll(__ballot(((alive >> i) & 1u) != 0u && ((key[i] >> b) & 1u) != 0u));
-                    const bool take1 = cnt >= krem;                               // the k-th largest has this bit set
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if ((((key[i] >> b) & 1u) != 0u) != take1) alive &= ~(1u << i);
-                    if (take1) n_alive = cnt;
-                    else { krem -= cnt; n_alive -= cnt; }
-                    if (n_alive == krem || krem == 1u) break;
-                }
-                alive_minmax(kmin, kmax);
-            }
-            // survivors == wanted: the smallest of them; one wanted (or all survivors equal): the largest
-            if (lane == 0) sh_t = n_alive == krem ? kmin : kmax;
-        }
-    } else if (!bad) {
-        for (uint32_t c = tid; c < nc; c += 256) {
-            const uint32_t kc = ckey[c];
-            const int32_t ic = cidx[c];
-            uint32_t rank = 0;
-            for (uint32_t o = 0; o < nc; ++o) {
-                const uint32_t ko = ckey[o];
-                rank += (ko > kc) || (ko == kc && cidx[o] < ic);
-            }
-            if (rank == (uint32_t)(k - 1)) sh_t = kc;
-        }
+    if (!bad && wave == 0) {
+        // (up to 256 candidates: four keys per lane in registers; more -- 1 % of the bench batch's tokens, which an all-pairs ranking
+        // out of LDS kept in this kernel for 55 us while the others were done in 10, the kernel's tail -- the same select with the keys
+        // re-read from LDS in every bit round: sixteen reads per lane and bit at the list's capacity)
+        uint32_t kth;
+        if (nc <= 256u) kth = sel_radix_kth<4>(ckey, nc, (uint32_t)k, lane);
+        else kth = sel_radix_kth_lds(ckey, nc, (uint32_t)k, lane);
+        if (lane == 0) sh_t = kth;
     }
     __syncthreads();
     const float t = ord2f(sh_t);
@@ -761,6 +821,7 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
     __syncthreads();
     const uint32_t nr = sh_nr;
     bad = bad || nr > (uint32_t)PV_SAE_RESCORE_MAX;
+    SEL_STAMP(2);                                              // (candidate pass + threshold select done)
     if (norm_wave) {
         float cn = 0.f;
 #pragma unroll
@@ -869,6 +930,10 @@ __global__ __launch_bounds__(256) void sae_select_kernel(
             if (feat_cnt) wpos[row * k + rank] = v > 0.f ? atomicAdd(&feat_cnt[ic], 1u) : 0xffffffffu;
         }
     }
+#ifdef PV_SEL_TRACE
+    __syncthreads();
+    SEL_STAMP(1);
+#endif
 }
 
 // exact fp32 hidden_pre rows of the tokens the filter could not decide -> hidden scratch.  Reads W_enc as W_encT (the fp32
@@ -1156,6 +1221,22 @@ int launch_enc_gemm(int mode, const EncParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+// debug: workgroups of the filtered encoder's small kernels the runtime says fit a CU (tools/probes/select_timeline.py counts six select
+// workgroups alive per CU where the compiler's register model says eight)
+extern "C" int pv_debug_select_occupancy(int32_t* out4) {
+    int n = 0;
+    PV_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&sae_select_kernel<3, false>), 256, 0));
+    out4[0] = n;
+    PV_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&sae_thr_kernel<32>), 256, 0));
+    out4[1] = n;
+    PV_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&relu_select_kernel<3, false>), 256, 0));
+    out4[2] = n;
+    hipFuncAttributes fa;
+    PV_HIP_CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&sae_select_kernel<3, false>)));
+    out4[3] = fa.numRegs;
+    return PV_OK;
+}
 
 int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t* topk_idx, float* topk_val,
                     uint32_t* feat_cnt, uint32_t* wpos, unsigned char* wsb, const SaeWs& ws, hipStream_t stream, const SaePre* pre) {
