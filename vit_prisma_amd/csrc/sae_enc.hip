@@ -50,6 +50,7 @@ struct EncParams {
     uint32_t* cnt;            //         [M][ntn] hits of (token, N-tile); 0xffffffff = more than `slots`
     int2* cand;               //         [M][ntn][slots] (feature, bits of a)
     int32_t slots;            //         pv_sae_tile_slots(plan)
+    uint64_t* trace;          // debug build (-DPV_ENC_TRACE): per-workgroup wall-clock stamps {start, K loop done, end, hw id}, else unused
     uint32_t* mode;           // ReLU filter (pv_sae_relu_step) or NULL: the step's mode word -- a row with more hits than slots raises it
                               // (the step then runs dense), and a tile that finds it raised skips its hit lists
 };
@@ -110,6 +111,19 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
             if (skip) return;
         }
     }
+#ifdef PV_ENC_TRACE
+#define ENC_STAMP(slot)                                                                                                    \
+    do {                                                                                                                   \
+        if (MODE == 1 && p.trace && tid == 0) {                                                                            \
+            p.trace[(int64_t)blockIdx.x * 4 + (slot)] = wall_clock64();                                                    \
+            if ((slot) == 0) p.trace[(int64_t)blockIdx.x * 4 + 3] = ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+                                                                    (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);    \
+        }                                                                                                                  \
+    } while (0)
+#else
+#define ENC_STAMP(slot) do { } while (0)
+#endif
+    ENC_STAMP(0);
     const unsigned Kb = (unsigned)p.K * 2u;
     const int nk = (int)((Kb + 63) / 64);
     const bool ktail = (Kb % 64) != 0;
@@ -364,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): drain the off-the-end prefetches (and the threshold DMA)
     __syncthreads();
+    ENC_STAMP(2);
 
     const int rows_left = p.M - (m0 + wm * 32 * MB);       // local row r of this wave's block is real iff r < rows_left
     if constexpr (MODE == 0) {
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(512, 2) void sae_enc_gemm_kernel(const EncParams p)
                 __syncthreads();
             }
         }
+        ENC_STAMP(1);
         if (tid < 256 && m0 + tid < p.M) {
             const uint32_t c = rowcnt[tid];
             p.cnt[(int64_t)(m0 + tid) * ntn + tile_n] = c > (uint32_t)p.slots ? 0xffffffffu : c;
@@ -1266,6 +1282,9 @@ int sae_encode_fast(const pv_sae_desc& d, const pv_sae_state* st, int N, int32_t
     // filter: all features
     p.N = d.d_sae; p.ldb_bytes = (uint32_t)d.d_in * 2u; p.b_span = (uint32_t)d.d_sae * p.ldb_bytes; p.bias_stride = 1;
     p.out = nullptr; p.thr = (const float*)(wsb + ws.thr); p.cnt = (uint32_t*)(wsb + ws.cand_cnt); p.cand = (int2*)(wsb + ws.cand);
+#ifdef PV_ENC_TRACE
+    p.trace = reinterpret_cast<uint64_t*>(wsb + ws.hidden) + 4 * 8192;      // (behind the select kernel's stamps)
+#endif
     const int ntn = d.d_sae / 256;
     p.slots = pv_sae_tile_slots(d);
     rc = launch_enc_gemm(1, p, stream);
